@@ -1,0 +1,62 @@
+"""ctypes binding of libdtlr_hip.so (include/dtlr_hip.h).  There is no fallback: if the shared
+object is missing or a symbol is absent, importing/using the product path raises."""
+from __future__ import annotations
+
+import ctypes
+import os
+from ctypes import c_char_p, c_int, c_int64, c_void_p, c_float, POINTER
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(HERE, "libdtlr_hip.so")
+
+DTLR_F32, DTLR_F64, DTLR_BF16 = 0, 1, 2
+
+_lib = None
+
+
+class DTLRError(RuntimeError):
+    pass
+
+
+# name -> (restype, argtypes): every symbol include/dtlr_hip.h declares
+_SIGNATURES = {
+    "dtlr_strerror": (c_char_p, [c_int]),
+    "dtlr_last_hip_error": (c_int, []),
+    "dtlr_abi_version": (c_int, []),
+    "dtlr_msda_forward": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
+                                  c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p, c_void_p]),
+}
+
+
+def lib() -> ctypes.CDLL:
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise DTLRError(f"{LIB_PATH} not built: run `python -m dtlr_amd.build` (needs hipcc); "
+                            "the DTLR HIP path has no CPU/PyTorch fallback")
+        L = ctypes.CDLL(LIB_PATH)
+        for name, (res, args) in _SIGNATURES.items():
+            fn = getattr(L, name)          # AttributeError if the .so is stale -> loud
+            fn.restype, fn.argtypes = res, args
+        _lib = L
+    return _lib
+
+
+def declared_symbols():
+    return list(_SIGNATURES)
+
+
+def check(code: int, what: str) -> None:
+    if code != 0:
+        L = lib()
+        msg = L.dtlr_strerror(code).decode()
+        raise DTLRError(f"{what}: {msg} (code {code}, hip error {L.dtlr_last_hip_error()})")
+
+
+def ptr(t) -> int:
+    return t.data_ptr()
+
+
+def current_stream() -> int:
+    import torch
+    return torch.cuda.current_stream().cuda_stream

@@ -1,0 +1,57 @@
+"""Build libdtlr_hip.so (gfx950 only) in-tree with hipcc.  `python -m dtlr_amd.build [--force]`.
+
+No torch headers are involved: the library is a pure C-ABI shared object taking raw device
+pointers and a hipStream_t (include/dtlr_hip.h), so it is independent of the torch/ROCm pairing.
+"""
+from __future__ import annotations
+
+import glob
+import hashlib
+import os
+import subprocess
+import sys
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+CSRC = os.path.join(HERE, "csrc")
+LIB = os.path.join(HERE, "libdtlr_hip.so")
+STAMP = os.path.join(HERE, ".libdtlr_hip.stamp")
+HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-Wall", "-Wno-unused-function"]
+
+
+def _sources():
+    return sorted(glob.glob(os.path.join(CSRC, "*.hip")))
+
+
+def _fingerprint() -> str:
+    h = hashlib.sha256()
+    for p in _sources() + sorted(glob.glob(os.path.join(CSRC, "*.h"))) + [os.path.join(HERE, "..", "include", "dtlr_hip.h")]:
+        with open(p, "rb") as f:
+            h.update(p.encode() + b"\0" + f.read())
+    h.update(" ".join(FLAGS).encode())
+    return h.hexdigest()
+
+
+def build(force: bool = False, verbose: bool = True) -> str:
+    fp = _fingerprint()
+    if not force and os.path.exists(LIB) and os.path.exists(STAMP) and open(STAMP).read().strip() == fp:
+        return LIB
+    objs = []
+    for src in _sources():
+        obj = os.path.join(CSRC, os.path.basename(src)[:-4] + ".o")
+        cmd = [HIPCC, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-function", "-c", src, "-o", obj]
+        if verbose:
+            print("[dtlr build]", " ".join(cmd), flush=True)
+        subprocess.check_call(cmd)
+        objs.append(obj)
+    cmd = [HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB] + objs
+    if verbose:
+        print("[dtlr build]", " ".join(cmd), flush=True)
+    subprocess.check_call(cmd)
+    with open(STAMP, "w") as f:
+        f.write(fp)
+    return LIB
+
+
+if __name__ == "__main__":
+    print(build(force="--force" in sys.argv))

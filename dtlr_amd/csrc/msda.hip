@@ -1,0 +1,242 @@
+// Multi-scale deformable attention forward for gfx950.
+//
+// What it computes (reference: models/dino/ops/src/cuda/ms_deform_im2col_cuda.cuh:33-84,237-299):
+//   out[b,q,m,:] = sum_l sum_p A[b,q,m,l,p] * bilinear(value_l[b,:,m,:], (x*W_l-0.5, y*H_l-0.5))
+// with zero padding outside the map.  The reference runs one thread per output SCALAR (block 1024);
+// here a thread owns VEC contiguous channels of one (b,q,m) so every corner fetch is one 16-byte
+// load and the D/VEC lanes of a head form one coalesced segment: with M=8, D=32 (fp32, VEC=4) a
+// 64-lane wavefront is exactly one query -- its 8 heads x 8 lanes -- so the 384 floats of
+// loc/attn of that query are one contiguous 1.5 KB region read through same-address broadcast
+// loads, and the 256-float output row is one coalesced 1 KB store.
+//
+// HBM roofline: compulsory bytes per call = value + loc + attn + out.  The
+// 4-corner gather re-reads value ~18x (Lq*M*L*P*4*D elements); that traffic is served by L2 (the
+// per-image value map is 5.6 MB fp32 / 2.8 MB bf16, blocks of one image are launched adjacently),
+// so HBM traffic stays near compulsory -- see DESIGN.md for the measured FETCH_SIZE.
+#include "dtlr_common.h"
+
+namespace dtlr {
+
+thread_local int g_last_hip_error = 0;
+
+template <typename T> struct Elem;
+template <> struct Elem<float>  { using acc = float;  static __device__ __forceinline__ float ld(const float* p) { return *p; } };
+template <> struct Elem<double> { using acc = double; static __device__ __forceinline__ double ld(const double* p) { return *p; } };
+
+// ---- vector fetch of VEC contiguous channels into accumulator-typed registers ------------------
+template <typename T, int VEC> struct Vec;
+template <> struct Vec<float, 4> {
+    static __device__ __forceinline__ void load(const float* p, float (&v)[4]) {
+        const float4 t = *reinterpret_cast<const float4*>(p); v[0] = t.x; v[1] = t.y; v[2] = t.z; v[3] = t.w; }
+    static __device__ __forceinline__ void store(float* p, const float (&v)[4]) {
+        *reinterpret_cast<float4*>(p) = make_float4(v[0], v[1], v[2], v[3]); }
+};
+template <> struct Vec<float, 2> {
+    static __device__ __forceinline__ void load(const float* p, float (&v)[2]) {
+        const float2 t = *reinterpret_cast<const float2*>(p); v[0] = t.x; v[1] = t.y; }
+    static __device__ __forceinline__ void store(float* p, const float (&v)[2]) {
+        *reinterpret_cast<float2*>(p) = make_float2(v[0], v[1]); }
+};
+template <> struct Vec<float, 1> {
+    static __device__ __forceinline__ void load(const float* p, float (&v)[1]) { v[0] = *p; }
+    static __device__ __forceinline__ void store(float* p, const float (&v)[1]) { *p = v[0]; }
+};
+template <> struct Vec<double, 1> {
+    static __device__ __forceinline__ void load(const double* p, double (&v)[1]) { v[0] = *p; }
+    static __device__ __forceinline__ void store(double* p, const double (&v)[1]) { *p = v[0]; }
+};
+template <> struct Vec<double, 2> {
+    static __device__ __forceinline__ void load(const double* p, double (&v)[2]) {
+        const double2 t = *reinterpret_cast<const double2*>(p); v[0] = t.x; v[1] = t.y; }
+    static __device__ __forceinline__ void store(double* p, const double (&v)[2]) {
+        *reinterpret_cast<double2*>(p) = make_double2(v[0], v[1]); }
+};
+// bf16 storage (uint16_t), f32 arithmetic: 8 channels = one 16-byte load
+template <> struct Vec<uint16_t, 8> {
+    static __device__ __forceinline__ void load(const uint16_t* p, float (&v)[8]) {
+        const uint4 t = *reinterpret_cast<const uint4*>(p);
+        const uint32_t w[4] = {t.x, t.y, t.z, t.w};
+#pragma unroll
+        for (int i = 0; i < 4; ++i) { v[2 * i] = __uint_as_float(w[i] << 16); v[2 * i + 1] = __uint_as_float(w[i] & 0xffff0000u); }
+    }
+    static __device__ __forceinline__ void store(uint16_t* p, const float (&v)[8]) {
+        *reinterpret_cast<uint4*>(p) = make_uint4(pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3]),
+                                                  pack_bf16x2(v[4], v[5]), pack_bf16x2(v[6], v[7])); }
+};
+template <> struct Vec<uint16_t, 1> {
+    static __device__ __forceinline__ void load(const uint16_t* p, float (&v)[1]) { v[0] = bf16_to_f32(*p); }
+    static __device__ __forceinline__ void store(uint16_t* p, const float (&v)[1]) { *p = f32_to_bf16(v[0]); }
+};
+
+// One sampling point: adds A * bilinear(...) for VEC channels.  `base` points at
+// value[b, level_start, m, c0]; row stride = W*M*D elements, column stride = M*D elements.
+template <typename T, typename A, int VEC>
+__device__ __forceinline__ void sample_point(const T* __restrict__ base, int H, int W, int MD,
+                                             A loc_w, A loc_h, A weight, A (&col)[VEC]) {
+    const A h_im = loc_h * (A)H - (A)0.5;
+    const A w_im = loc_w * (A)W - (A)0.5;
+    if (!(h_im > (A)-1 && w_im > (A)-1 && h_im < (A)H && w_im < (A)W)) return;
+    const A hf = floor(h_im), wf = floor(w_im);
+    const int h_low = (int)hf, w_low = (int)wf;
+    const int h_high = h_low + 1, w_high = w_low + 1;
+    const A lh = h_im - hf, lw = w_im - wf, hh = (A)1 - lh, hw = (A)1 - lw;
+    const long row_stride = (long)W * MD;
+    const T* p_lo = base + (long)h_low * row_stride + (long)w_low * MD;
+    const bool top = h_low >= 0, bot = h_high <= H - 1, left = w_low >= 0, right = w_high <= W - 1;
+    A v1[VEC], v2[VEC], v3[VEC], v4[VEC];
+#pragma unroll
+    for (int i = 0; i < VEC; ++i) { v1[i] = 0; v2[i] = 0; v3[i] = 0; v4[i] = 0; }
+    if (top && left) Vec<T, VEC>::load(p_lo, v1);
+    if (top && right) Vec<T, VEC>::load(p_lo + MD, v2);
+    if (bot && left) Vec<T, VEC>::load(p_lo + row_stride, v3);
+    if (bot && right) Vec<T, VEC>::load(p_lo + row_stride + MD, v4);
+    const A w1 = hh * hw, w2 = hh * lw, w3 = lh * hw, w4 = lh * lw;
+#pragma unroll
+    for (int i = 0; i < VEC; ++i) col[i] += (w1 * v1[i] + w2 * v2[i] + w3 * v3[i] + w4 * v4[i]) * weight;
+}
+
+// T: storage type of value/out; LT: type of loc/attn; VEC channels per thread.
+template <typename T, typename LT, typename A, int VEC>
+__global__ __launch_bounds__(256) void msda_fwd_kernel(
+    const T* __restrict__ value, const int64_t* __restrict__ shapes, const int64_t* __restrict__ lsi,
+    const LT* __restrict__ loc, const LT* __restrict__ attn,
+    int S, int M, int D, int L, int Lq, int P, T* __restrict__ out, long total)
+{
+    const long tid = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (tid >= total) return;
+    const int cpv = D / VEC;                       // lanes per (b,q,m)
+    const int c0 = (int)(tid % cpv) * VEC;
+    const long si = tid / cpv;                     // ((b*Lq)+q)*M + m
+    const int m = (int)(si % M);
+    const long bq = si / M;
+    const int b = (int)(bq / Lq);
+    const int MD = M * D;
+    const LT* lp = loc + si * (long)(L * P) * 2;
+    const LT* ap = attn + si * (long)(L * P);
+    const T* vb = value + (long)b * S * MD + m * D + c0;
+    A col[VEC];
+#pragma unroll
+    for (int i = 0; i < VEC; ++i) col[i] = 0;
+    for (int l = 0; l < L; ++l) {
+        const int H = (int)shapes[2 * l], W = (int)shapes[2 * l + 1];
+        const T* base = vb + (long)lsi[l] * MD;
+        for (int p = 0; p < P; ++p) {
+            sample_point<T, A, VEC>(base, H, W, MD, (A)lp[0], (A)lp[1], (A)ap[0], col);
+            lp += 2; ap += 1;
+        }
+    }
+    Vec<T, VEC>::store(out + si * D + c0, col);
+}
+
+// Hot shape: L=4 levels x P=4 points, loc/attn fp32.  Fully unrolled; the 32 loc floats and the 16
+// attn floats of this (b,q,m) come in as 8 + 4 16-byte loads (all lanes of a head read the same
+// addresses: one request each) issued before any gather so their latency overlaps.
+template <typename T, int VEC>
+__global__ __launch_bounds__(256) void msda_fwd_l4p4_kernel(
+    const T* __restrict__ value, const int64_t* __restrict__ shapes, const int64_t* __restrict__ lsi,
+    const float* __restrict__ loc, const float* __restrict__ attn,
+    int S, int M, int D, int Lq, T* __restrict__ out, long total)
+{
+    const long tid = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (tid >= total) return;
+    const int cpv = D / VEC;
+    const int c0 = (int)(tid % cpv) * VEC;
+    const long si = tid / cpv;
+    const int m = (int)(si % M);
+    const int b = (int)((si / M) / Lq);
+    const int MD = M * D;
+    const float4* lp = reinterpret_cast<const float4*>(loc + si * 32);
+    const float4* ap = reinterpret_cast<const float4*>(attn + si * 16);
+    float4 lv[8], av[4];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) lv[i] = lp[i];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) av[i] = ap[i];
+    int Hs[4], Ws[4]; long st[4];
+#pragma unroll
+    for (int l = 0; l < 4; ++l) { Hs[l] = (int)shapes[2 * l]; Ws[l] = (int)shapes[2 * l + 1]; st[l] = (long)lsi[l]; }
+    const T* vb = value + (long)b * S * MD + m * D + c0;
+    float col[VEC];
+#pragma unroll
+    for (int i = 0; i < VEC; ++i) col[i] = 0.f;
+#pragma unroll
+    for (int l = 0; l < 4; ++l) {
+        const T* base = vb + st[l] * MD;
+        const float a[4] = {av[l].x, av[l].y, av[l].z, av[l].w};
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            const float4 t = lv[2 * l + h];
+            sample_point<T, float, VEC>(base, Hs[l], Ws[l], MD, t.x, t.y, a[2 * h], col);
+            sample_point<T, float, VEC>(base, Hs[l], Ws[l], MD, t.z, t.w, a[2 * h + 1], col);
+        }
+    }
+    Vec<T, VEC>::store(out + si * D + c0, col);
+}
+
+template <typename T, typename LT, typename A, int VEC>
+static int launch_generic(const void* value, const int64_t* shapes, const int64_t* lsi, const void* loc, const void* attn,
+                          int N, int S, int M, int D, int L, int Lq, int P, void* out, hipStream_t st) {
+    const long total = (long)N * Lq * M * (D / VEC);
+    const int block = 256;
+    const long grid = (total + block - 1) / block;
+    if (grid > 0x7fffffffL) return DTLR_ESHAPE;
+    hipLaunchKernelGGL((msda_fwd_kernel<T, LT, A, VEC>), dim3((unsigned)grid), dim3(block), 0, st,
+                       (const T*)value, shapes, lsi, (const LT*)loc, (const LT*)attn, S, M, D, L, Lq, P, (T*)out, total);
+    return check_launch();
+}
+
+template <typename T, int VEC>
+static int launch_l4p4(const void* value, const int64_t* shapes, const int64_t* lsi, const void* loc, const void* attn,
+                       int N, int S, int M, int D, int Lq, void* out, hipStream_t st) {
+    const long total = (long)N * Lq * M * (D / VEC);
+    const int block = 256;
+    const long grid = (total + block - 1) / block;
+    if (grid > 0x7fffffffL) return DTLR_ESHAPE;
+    hipLaunchKernelGGL((msda_fwd_l4p4_kernel<T, VEC>), dim3((unsigned)grid), dim3(block), 0, st,
+                       (const T*)value, shapes, lsi, (const float*)loc, (const float*)attn, S, M, D, Lq, (T*)out, total);
+    return check_launch();
+}
+
+}  // namespace dtlr
+
+using namespace dtlr;
+
+extern "C" int dtlr_msda_forward(const void* value, const int64_t* shapes, const int64_t* lsi,
+                                 const void* loc, const void* attn,
+                                 int N, int S, int M, int D, int L, int Lq, int P,
+                                 int dtype, void* out, void* stream)
+{
+    if (!value || !shapes || !lsi || !loc || !attn || !out) return DTLR_EINVAL;
+    if (N <= 0 || S <= 0 || M <= 0 || D <= 0 || L <= 0 || Lq <= 0 || P <= 0) return DTLR_EINVAL;
+    hipStream_t st = (hipStream_t)stream;
+    const bool hot = (L == 4 && P == 4);
+    switch (dtype) {
+    case DTLR_F32:
+        if (hot && D % 4 == 0) return launch_l4p4<float, 4>(value, shapes, lsi, loc, attn, N, S, M, D, Lq, out, st);
+        if (D % 4 == 0) return launch_generic<float, float, float, 4>(value, shapes, lsi, loc, attn, N, S, M, D, L, Lq, P, out, st);
+        if (D % 2 == 0) return launch_generic<float, float, float, 2>(value, shapes, lsi, loc, attn, N, S, M, D, L, Lq, P, out, st);
+        return launch_generic<float, float, float, 1>(value, shapes, lsi, loc, attn, N, S, M, D, L, Lq, P, out, st);
+    case DTLR_F64:
+        if (D % 2 == 0) return launch_generic<double, double, double, 2>(value, shapes, lsi, loc, attn, N, S, M, D, L, Lq, P, out, st);
+        return launch_generic<double, double, double, 1>(value, shapes, lsi, loc, attn, N, S, M, D, L, Lq, P, out, st);
+    case DTLR_BF16:
+        if (hot && D % 8 == 0) return launch_l4p4<uint16_t, 8>(value, shapes, lsi, loc, attn, N, S, M, D, Lq, out, st);
+        if (D % 8 == 0) return launch_generic<uint16_t, float, float, 8>(value, shapes, lsi, loc, attn, N, S, M, D, L, Lq, P, out, st);
+        return launch_generic<uint16_t, float, float, 1>(value, shapes, lsi, loc, attn, N, S, M, D, L, Lq, P, out, st);
+    default:
+        return DTLR_EDTYPE;
+    }
+}
+
+extern "C" const char* dtlr_strerror(int code) {
+    switch (code) {
+    case DTLR_OK: return "ok";
+    case DTLR_EINVAL: return "invalid argument (null pointer or non-positive size)";
+    case DTLR_EDTYPE: return "unsupported dtype code";
+    case DTLR_ESHAPE: return "shape not supported by the gfx950 kernels";
+    case DTLR_ELAUNCH: return "HIP launch/runtime error (see dtlr_last_hip_error)";
+    default: return "unknown error";
+    }
+}
+extern "C" int dtlr_last_hip_error(void) { return g_last_hip_error; }
+extern "C" int dtlr_abi_version(void) { return 1; }

@@ -1,0 +1,373 @@
+"""The MI355X forward of DTLR: ResNet-50 -> input_proj -> 6x deformable encoder -> two-stage query
+selection -> 6x decoder -> heads.  Mirrors the reference call stack stage by stage (SURVEY.md
+section 3.1; every method cites the reference lines it replaces) but is laid out for the GPU:
+
+  * activations are NHWC / token-major ([B, H*W, C]) end to end, so a backbone map IS the token
+    matrix the transformer consumes -- no flatten/transpose copies (deformable_transformer.py:278-285);
+  * FrozenBatchNorm is folded into the conv weights/bias once at pack time (backbone.py:62-72);
+  * sampling_offsets and attention_weights are one fused 256->384 projection (ms_deform_attn.py:97-98);
+  * the six decoder cross-attention value projections of `memory` are batch-first and need no
+    seq-first transposes (deformable_transformer.py:394-403 transposes everything);
+  * position embeddings, reference points and proposals depend only on the padding masks and are
+    computed once per forward (the reference recomputes reference points per encoder call);
+  * aux heads for decoder layers 0..4 are skipped unless asked for (dino.py:339-354 computes all 6).
+
+All compute goes through dtlr_amd.ops (HIP kernels / ROCm libraries on the GPU).  `dtype` is the
+storage/compute type of activations and GEMM operands (float32 = parity path, bfloat16 = bench
+path); selection scores, softmax, normalisation statistics and box arithmetic are always fp32.
+"""
+from __future__ import annotations
+
+import math
+from typing import Dict, List, Optional, Sequence
+
+import torch
+
+from . import ops
+from .config import DTLRConfig
+
+
+def _fold_bn(sd, conv_key: str, bn_prefix: str):
+    """conv -> FrozenBatchNorm2d (models/dino/backbone.py:62-72) as one conv with bias."""
+    w = sd[conv_key].float()
+    scale = sd[bn_prefix + ".weight"].float() * torch.rsqrt(sd[bn_prefix + ".running_var"].float() + 1e-5)
+    bias = sd[bn_prefix + ".bias"].float() - sd[bn_prefix + ".running_mean"].float() * scale
+    return w * scale.view(-1, 1, 1, 1), bias
+
+
+class DTLREngine:
+    def __init__(self, cfg: DTLRConfig, state_dict: Dict[str, torch.Tensor], device="cuda:0",
+                 dtype: torch.dtype = torch.float32):
+        cfg.validate()
+        self.cfg, self.device, self.dtype = cfg, torch.device(device), dtype
+        if self.device.type != "cuda":
+            raise RuntimeError("DTLREngine runs on the GPU only (no CPU path)")
+        ops.require_cuda(torch.empty(0, device=self.device))
+        self.w: Dict[str, torch.Tensor] = {}
+        self._pack(state_dict)
+        self._shape_cache: Dict[tuple, dict] = {}
+
+    # ------------------------------------------------------------------------------ packing
+    def _put(self, name, t, dtype=None):
+        self.w[name] = t.to(device=self.device, dtype=dtype or self.dtype).contiguous()
+
+    def _put_conv(self, name, w, b):
+        self.w[name + ".w"] = w.to(device=self.device, dtype=self.dtype).contiguous(memory_format=torch.channels_last)
+        self.w[name + ".b"] = b.to(device=self.device, dtype=self.dtype).contiguous()
+
+    def _put_linear(self, name, w, b):
+        self._put(name + ".w", w)
+        self._put(name + ".b", b)
+
+    def _pack(self, sd):
+        cfg, f32 = self.cfg, torch.float32
+        b = "backbone.0.body."
+        self._put_conv("conv1", *_fold_bn(sd, b + "conv1.weight", b + "bn1"))
+        for li, nblocks in enumerate(cfg.backbone_blocks, start=1):
+            for bi in range(nblocks):
+                p = f"{b}layer{li}.{bi}."
+                q = f"l{li}.{bi}."
+                for c in (1, 2, 3):
+                    self._put_conv(f"{q}c{c}", *_fold_bn(sd, f"{p}conv{c}.weight", f"{p}bn{c}"))
+                if bi == 0:
+                    self._put_conv(q + "ds", *_fold_bn(sd, p + "downsample.0.weight", p + "downsample.1"))
+        for l in range(cfg.num_feature_levels):
+            w, bias = sd[f"input_proj.{l}.0.weight"].float(), sd[f"input_proj.{l}.0.bias"].float()
+            if l < cfg.num_feature_levels - 1:
+                self._put_linear(f"ip{l}", w.flatten(1), bias)            # 1x1 conv == linear on NHWC tokens
+            else:
+                self._put_conv(f"ip{l}", w, bias)
+            self._put(f"ip{l}.gn.w", sd[f"input_proj.{l}.1.weight"], f32)
+            self._put(f"ip{l}.gn.b", sd[f"input_proj.{l}.1.bias"], f32)
+        t = "transformer."
+        self._put("level_embed", sd[t + "level_embed"], f32)
+
+        def msda_pack(dst, src):
+            self._put_linear(dst + ".ow", torch.cat([sd[src + ".sampling_offsets.weight"], sd[src + ".attention_weights.weight"]], 0),
+                             torch.cat([sd[src + ".sampling_offsets.bias"], sd[src + ".attention_weights.bias"]], 0))
+            self._put_linear(dst + ".value", sd[src + ".value_proj.weight"], sd[src + ".value_proj.bias"])
+            self._put_linear(dst + ".out", sd[src + ".output_proj.weight"], sd[src + ".output_proj.bias"])
+
+        def norm_pack(dst, src):
+            self._put(dst + ".w", sd[src + ".weight"], f32)
+            self._put(dst + ".b", sd[src + ".bias"], f32)
+
+        for n in range(cfg.enc_layers):
+            p, q = f"{t}encoder.layers.{n}.", f"enc{n}."
+            msda_pack(q + "attn", p + "self_attn")
+            norm_pack(q + "norm1", p + "norm1")
+            norm_pack(q + "norm2", p + "norm2")
+            self._put_linear(q + "ff1", sd[p + "linear1.weight"], sd[p + "linear1.bias"])
+            self._put_linear(q + "ff2", sd[p + "linear2.weight"], sd[p + "linear2.bias"])
+        C = cfg.hidden_dim
+        for n in range(cfg.dec_layers):
+            p, q = f"{t}decoder.layers.{n}.", f"dec{n}."
+            msda_pack(q + "attn", p + "cross_attn")
+            for k in ("norm1", "norm2", "norm3"):
+                norm_pack(q + k, p + k)
+            W, Bi = sd[p + "self_attn.in_proj_weight"], sd[p + "self_attn.in_proj_bias"]
+            self._put_linear(q + "sa.qk", W[:2 * C], Bi[:2 * C])          # q,k share the input tgt+pos
+            self._put_linear(q + "sa.v", W[2 * C:], Bi[2 * C:])
+            self._put_linear(q + "sa.out", sd[p + "self_attn.out_proj.weight"], sd[p + "self_attn.out_proj.bias"])
+            self._put_linear(q + "ff1", sd[p + "linear1.weight"], sd[p + "linear1.bias"])
+            self._put_linear(q + "ff2", sd[p + "linear2.weight"], sd[p + "linear2.bias"])
+        norm_pack("dec.norm", t + "decoder.norm")
+        for i in range(2):
+            self._put_linear(f"dec.rph{i}", sd[f"{t}decoder.ref_point_head.layers.{i}.weight"], sd[f"{t}decoder.ref_point_head.layers.{i}.bias"])
+        self._put("tgt_embed", sd[t + "tgt_embed.weight"])
+        self._put_linear("enc_output", sd[t + "enc_output.weight"], sd[t + "enc_output.bias"])
+        norm_pack("enc_output_norm", t + "enc_output_norm")
+        # heads: selection scores and boxes stay fp32 (discrete selections amplify rounding)
+        for i in range(3):
+            self._put(f"enc_bbox{i}.w", sd[f"{t}enc_out_bbox_embed.layers.{i}.weight"], f32)
+            self._put(f"enc_bbox{i}.b", sd[f"{t}enc_out_bbox_embed.layers.{i}.bias"], f32)
+            self._put(f"bbox{i}.w", sd[f"bbox_embed.0.layers.{i}.weight"], f32)
+            self._put(f"bbox{i}.b", sd[f"bbox_embed.0.layers.{i}.bias"], f32)
+        self._put("enc_class.w", sd[t + "enc_out_class_embed.weight"], f32)
+        self._put("enc_class.b", sd[t + "enc_out_class_embed.bias"], f32)
+        self._put("class.w", sd["class_embed.0.weight"], f32)
+        self._put("class.b", sd["class_embed.0.bias"], f32)
+        self.num_classes = int(sd["class_embed.0.weight"].shape[0])
+
+    # ------------------------------------------------------------------------------ stages
+    def _conv(self, name, x, stride, padding, relu=False, residual=None):
+        return ops.conv2d_nhwc(x, self.w[name + ".w"], self.w[name + ".b"], stride, padding, relu, residual)
+
+    def _lin(self, name, x, relu=False, residual=None):
+        return ops.linear(x, self.w[name + ".w"], self.w[name + ".b"], relu, residual)
+
+    def _ln(self, name, x):
+        return ops.layernorm(x, self.w[name + ".w"], self.w[name + ".b"])
+
+    def backbone(self, x_nhwc) -> List[torch.Tensor]:
+        """torchvision resnet50 (v1.5) body with FrozenBN folded; returns layer2/3/4 maps, NHWC
+        (models/dino/backbone.py:97-106,118-120)."""
+        x = self._conv("conv1", x_nhwc, 2, 3, relu=True)
+        x = ops.maxpool_nhwc(x)
+        outs = []
+        for li, nblocks in enumerate(self.cfg.backbone_blocks, start=1):
+            for bi in range(nblocks):
+                q = f"l{li}.{bi}."
+                stride = 2 if (bi == 0 and li > 1) else 1
+                idt = self._conv(q + "ds", x, stride, 0) if bi == 0 else x
+                o = self._conv(q + "c1", x, 1, 0, relu=True)
+                o = self._conv(q + "c2", o, stride, 1, relu=True)
+                x = self._conv(q + "c3", o, 1, 0, relu=True, residual=idt)
+            if li >= 2:
+                outs.append(x)
+        return outs
+
+    @staticmethod
+    def _nearest_mask(mask, h, w):
+        """F.interpolate(mask[None].float(), size=(h,w)).bool() (backbone.py:103, dino.py:304-307):
+        nearest, source index = min(floor(dst * float(in)/out), in-1) in fp32 like ATen."""
+        B, H, W = mask.shape
+        dev = mask.device
+        iy = (torch.arange(h, device=dev, dtype=torch.float32) * (float(H) / h)).floor().long().clamp_(max=H - 1)
+        ix = (torch.arange(w, device=dev, dtype=torch.float32) * (float(W) / w)).floor().long().clamp_(max=W - 1)
+        return mask[:, iy][:, :, ix]
+
+    def _pos_embed(self, mask):
+        """PositionEmbeddingSineHW (position_encoding.py:79-108) -> [B, h*w, 256] tokens, fp32."""
+        cfg = self.cfg
+        npf = cfg.hidden_dim // 2
+        not_mask = ~mask
+        y_embed = not_mask.cumsum(1, dtype=torch.float32)
+        x_embed = not_mask.cumsum(2, dtype=torch.float32)
+        eps, scale = 1e-6, 2 * math.pi
+        y_embed = y_embed / (y_embed[:, -1:, :] + eps) * scale
+        x_embed = x_embed / (x_embed[:, :, -1:] + eps) * scale
+        i = torch.arange(npf, dtype=torch.float32, device=mask.device)
+        dim_tx = cfg.pe_temperatureW ** (2 * torch.div(i, 2, rounding_mode="floor") / npf)
+        dim_ty = cfg.pe_temperatureH ** (2 * torch.div(i, 2, rounding_mode="floor") / npf)
+        px = x_embed[..., None] / dim_tx
+        py = y_embed[..., None] / dim_ty
+        px = torch.stack((px[..., 0::2].sin(), px[..., 1::2].cos()), dim=4).flatten(3)
+        py = torch.stack((py[..., 0::2].sin(), py[..., 1::2].cos()), dim=4).flatten(3)
+        return torch.cat((py, px), dim=3).flatten(1, 2)              # already NHWC -> tokens
+
+    def _geometry(self, mask, level_hw):
+        """Everything that depends only on the padding masks (computed once per forward):
+        per-level masks, pos+level embeds, valid ratios, encoder reference points, proposals."""
+        cfg, dev = self.cfg, mask.device
+        B = mask.shape[0]
+        masks = [self._nearest_mask(mask, h, w) for (h, w) in level_hw]
+        pos = torch.cat([self._pos_embed(m) + self.w["level_embed"][l].view(1, 1, -1) for l, m in enumerate(masks)], 1)
+        mask_flat = torch.cat([m.flatten(1) for m in masks], 1)
+        # valid ratios (deformable_transformer.py:239-246) -> (w, h)
+        vr = torch.stack([torch.stack([(~m[:, 0, :]).sum(1).float() / m.shape[2], (~m[:, :, 0]).sum(1).float() / m.shape[1]], -1)
+                          for m in masks], 1)                         # [B, L, 2]
+        # encoder reference points (deformable_transformer.py:479-492)
+        refs, props = [], []
+        for l, ((h, w), m) in enumerate(zip(level_hw, masks)):
+            ys = torch.linspace(0.5, h - 0.5, h, dtype=torch.float32, device=dev)
+            xs = torch.linspace(0.5, w - 0.5, w, dtype=torch.float32, device=dev)
+            ry, rx = torch.meshgrid(ys, xs, indexing="ij")
+            ry = ry.reshape(-1)[None] / (vr[:, None, l, 1] * h)
+            rx = rx.reshape(-1)[None] / (vr[:, None, l, 0] * w)
+            refs.append(torch.stack((rx, ry), -1))
+            # proposals (models/dino/utils.py:31-49)
+            valid_h = (~m[:, :, 0]).sum(1)
+            valid_w = (~m[:, 0, :]).sum(1)
+            gy, gx = torch.meshgrid(torch.linspace(0, h - 1, h, dtype=torch.float32, device=dev),
+                                    torch.linspace(0, w - 1, w, dtype=torch.float32, device=dev), indexing="ij")
+            grid = torch.stack([gx, gy], -1)[None].expand(B, -1, -1, -1)
+            sc = torch.stack([valid_w, valid_h], 1).view(B, 1, 1, 2)
+            grid = (grid + 0.5) / sc
+            wh = torch.ones_like(grid) * 0.05 * (2.0 ** l)
+            props.append(torch.cat((grid, wh), -1).view(B, -1, 4))
+        ref = torch.cat(refs, 1)[:, :, None] * vr[:, None]             # [B, S, L, 2]
+        prop = torch.cat(props, 1)
+        valid = ((prop > 0.01) & (prop < 0.99)).all(-1, keepdim=True)
+        prop = torch.log(prop / (1 - prop))
+        prop = prop.masked_fill(mask_flat.unsqueeze(-1), float("inf")).masked_fill(~valid, float("inf"))
+        keep = (~mask_flat.unsqueeze(-1)) & valid                     # rows of memory that survive (utils.py:60-62)
+        shapes = torch.as_tensor(level_hw, dtype=torch.long, device=dev)
+        lsi = torch.cat((shapes.new_zeros((1,)), shapes.prod(1).cumsum(0)[:-1]))
+        return dict(masks=masks, pos=pos, mask_flat=mask_flat, valid_ratios=vr, enc_ref=ref.contiguous(),
+                    proposals=prop, keep=keep, shapes=shapes, lsi=lsi)
+
+    def _msda_module(self, name, query, ref, value_src, g, n_points):
+        """MSDeformAttn.forward (ops/modules/ms_deform_attn.py:78-126) without the output
+        projection (fused by the caller with residual + LayerNorm)."""
+        cfg = self.cfg
+        B, Lq, C = query.shape
+        S = value_src.shape[1]
+        M, L, P = cfg.nheads, cfg.num_feature_levels, n_points
+        value = self._lin(name + ".value", value_src)
+        value = value.masked_fill(g["mask_flat"][..., None], 0.0)
+        ow = self._lin(name + ".ow", query).float()
+        off = ow[..., : M * L * P * 2].reshape(B, Lq, M, L, P, 2)
+        aw = torch.softmax(ow[..., M * L * P * 2:].reshape(B, Lq, M, L * P), -1).reshape(B, Lq, M, L, P)
+        if ref.shape[-1] == 2:
+            normalizer = torch.stack([g["shapes"][:, 1], g["shapes"][:, 0]], -1).float()
+            loc = ref[:, :, None, :, None, :] + off / normalizer[None, None, None, :, None, :]
+        else:
+            loc = ref[:, :, None, :, None, :2] + off / P * ref[:, :, None, :, None, 2:] * 0.5
+        return ops.msda(value.view(B, S, M, C // M), g["shapes"], g["lsi"], loc.contiguous(), aw.contiguous())
+
+    def encoder(self, src, g):
+        """TransformerEncoder.forward + DeformableTransformerEncoderLayer.forward
+        (deformable_transformer.py:494-580, 804-823)."""
+        pos = g["pos"].to(src.dtype)
+        for n in range(self.cfg.enc_layers):
+            q = f"enc{n}."
+            a = self._msda_module(q + "attn", src + pos, g["enc_ref"], src, g, self.cfg.enc_n_points)
+            src = self._ln(q + "norm1", self._lin(q + "attn.out", a, residual=src))
+            h = self._lin(q + "ff1", src, relu=True)
+            src = self._ln(q + "norm2", self._lin(q + "ff2", h, residual=src))
+        return src
+
+    def two_stage(self, memory, g, forced_topk=None):
+        """deformable_transformer.py:320-363 with gen_encoder_output_proposals (utils.py:15-64).
+        The box MLP runs only on the selected rows (selection uses class scores only)."""
+        cfg = self.cfg
+        om = memory * g["keep"].to(memory.dtype)
+        om = self._ln("enc_output_norm", self._lin("enc_output", om)).float()
+        scores = ops.linear(om, self.w["enc_class.w"], self.w["enc_class.b"]).max(-1)[0]
+        idx = ops.topk_rows(scores, cfg.num_queries) if forced_topk is None else forced_topk
+        sel = torch.gather(om, 1, idx.unsqueeze(-1).expand(-1, -1, cfg.hidden_dim))
+        h = ops.linear(sel, self.w["enc_bbox0.w"], self.w["enc_bbox0.b"], relu=True)
+        h = ops.linear(h, self.w["enc_bbox1.w"], self.w["enc_bbox1.b"], relu=True)
+        prop_sel = torch.gather(g["proposals"], 1, idx.unsqueeze(-1).expand(-1, -1, 4))
+        ref_unsig = ops.linear(h, self.w["enc_bbox2.w"], self.w["enc_bbox2.b"]) + prop_sel
+        return dict(topk_idx=idx, topk_scores=scores, ref_unsig=ref_unsig, hs_enc=sel, init_box=prop_sel.sigmoid())
+
+    @staticmethod
+    def _inverse_sigmoid(x, eps=1e-3):
+        """util/misc.py:575-579."""
+        x = x.clamp(min=0, max=1)
+        return torch.log(x.clamp(min=eps) / (1 - x).clamp(min=eps))
+
+    @staticmethod
+    def _sine_embed(boxes):
+        """gen_sineembed_for_position (models/dino/utils.py:141-167): [B,nq,4] -> [B,nq,512] (y|x|w|h)."""
+        dim_t = torch.arange(128, dtype=torch.float32, device=boxes.device)
+        dim_t = 10000 ** (2 * torch.div(dim_t, 2, rounding_mode="floor") / 128)
+        e = (boxes[..., None] * (2 * math.pi)) / dim_t                 # [B,nq,4,128]
+        e = torch.stack((e[..., 0::2].sin(), e[..., 1::2].cos()), dim=4).flatten(3)
+        return torch.cat((e[:, :, 1], e[:, :, 0], e[:, :, 2], e[:, :, 3]), dim=2)
+
+    def _bbox_head(self, x):
+        h = ops.linear(x.float(), self.w["bbox0.w"], self.w["bbox0.b"], relu=True)
+        h = ops.linear(h, self.w["bbox1.w"], self.w["bbox1.b"], relu=True)
+        return ops.linear(h, self.w["bbox2.w"], self.w["bbox2.b"])
+
+    def decoder(self, memory, ts, g, want_aux=False):
+        """TransformerDecoder.forward + DeformableTransformerDecoderLayer
+        (deformable_transformer.py:652-766, 882-997), batch-first."""
+        cfg = self.cfg
+        B = memory.shape[0]
+        vr4 = torch.cat([g["valid_ratios"], g["valid_ratios"]], -1)      # [B, L, 4]
+        ref = ts["ref_unsig"].sigmoid()
+        refs = [ref]
+        tgt = self.w["tgt_embed"][None].expand(B, -1, -1).contiguous()
+        hs = []
+        for n in range(cfg.dec_layers):
+            q = f"dec{n}."
+            ref_in = (ref[:, :, None] * vr4[:, None]).contiguous()       # [B, nq, L, 4]
+            sine = self._sine_embed(ref_in[:, :, 0, :]).to(self.dtype)
+            qpos = self._lin("dec.rph1", self._lin("dec.rph0", sine, relu=True))
+            # self attention (q = k = tgt + query_pos, v = tgt)
+            qk = self._lin(q + "sa.qk", tgt + qpos)
+            v = self._lin(q + "sa.v", tgt)
+            C = cfg.hidden_dim
+            a = ops.mha(qk[..., :C], qk[..., C:], v, cfg.nheads)
+            tgt = self._ln(q + "norm2", self._lin(q + "sa.out", a, residual=tgt))
+            # deformable cross attention
+            a = self._msda_module(q + "attn", tgt + qpos, ref_in, memory, g, cfg.dec_n_points)
+            tgt = self._ln(q + "norm1", self._lin(q + "attn.out", a, residual=tgt))
+            # ffn
+            h = self._lin(q + "ff1", tgt, relu=True)
+            tgt = self._ln(q + "norm3", self._lin(q + "ff2", h, residual=tgt))
+            # iterative box refinement (734-756)
+            ref = (self._bbox_head(tgt) + self._inverse_sigmoid(ref)).sigmoid()
+            refs.append(ref)
+            if want_aux or n == cfg.dec_layers - 1:
+                hs.append(self._ln("dec.norm", tgt))
+            else:
+                hs.append(None)
+        return hs, refs
+
+    # ------------------------------------------------------------------------------ forward
+    @torch.no_grad()
+    def forward(self, x: torch.Tensor, mask: torch.Tensor, forced_topk: Optional[torch.Tensor] = None,
+                want_aux: bool = False, return_debug: bool = False) -> Dict[str, torch.Tensor]:
+        """x [B,3,H,W] fp32 (zero-padded), mask [B,H,W] bool (True = padding)  ->  DINO.forward's
+        dict (models/dino/dino.py:270-415): pred_logits [B,nq,C] raw, pred_boxes [B,nq,4] cxcywh."""
+        ops.require_cuda(x, "images")
+        cfg = self.cfg
+        B = x.shape[0]
+        x_nhwc = x.to(self.dtype).permute(0, 2, 3, 1).contiguous()
+        feats = self.backbone(x_nhwc)
+        level_hw = [(f.shape[1], f.shape[2]) for f in feats]
+        last = self._conv(f"ip{len(feats)}", feats[-1], 2, 1)
+        level_hw.append((last.shape[1], last.shape[2]))
+        g = self._geometry(mask, level_hw)
+        srcs = []
+        for l, f in enumerate(feats):
+            t = self._lin(f"ip{l}", f.flatten(1, 2))
+            srcs.append(ops.groupnorm_tokens(t, 32, self.w[f"ip{l}.gn.w"], self.w[f"ip{l}.gn.b"]))
+        l = len(feats)
+        srcs.append(ops.groupnorm_tokens(last.flatten(1, 2), 32, self.w[f"ip{l}.gn.w"], self.w[f"ip{l}.gn.b"]))
+        src = torch.cat(srcs, 1)
+        memory = self.encoder(src, g)
+        ts = self.two_stage(memory, g, forced_topk)
+        hs, refs = self.decoder(memory, ts, g, want_aux)
+        n = cfg.dec_layers - 1
+        out = {
+            "pred_logits": ops.linear(hs[n].float(), self.w["class.w"], self.w["class.b"]),
+            "pred_boxes": (self._bbox_head(hs[n]) + self._inverse_sigmoid(refs[n])).sigmoid(),
+        }
+        if want_aux:
+            out["aux_outputs"] = [{"pred_logits": ops.linear(hs[i].float(), self.w["class.w"], self.w["class.b"]),
+                                   "pred_boxes": (self._bbox_head(hs[i]) + self._inverse_sigmoid(refs[i])).sigmoid()}
+                                  for i in range(n)]
+        interm_class = ops.linear(ts["hs_enc"], self.w["enc_class.w"], self.w["enc_class.b"])
+        out["interm_outputs"] = {"pred_logits": interm_class, "pred_boxes": ts["ref_unsig"].sigmoid()}
+        out["interm_outputs_for_matching_pre"] = {"pred_logits": interm_class, "pred_boxes": ts["init_box"]}
+        out["dn_meta"] = None
+        if return_debug:
+            out["_debug"] = dict(memory=memory, topk_idx=ts["topk_idx"], topk_scores=ts["topk_scores"], src=src,
+                                 feats=feats, geometry=g)
+        return out

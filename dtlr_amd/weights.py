@@ -1,0 +1,194 @@
+"""Deterministic, name-seeded synthetic weights + checkpoint ingestion.
+
+No checkpoint ships with the reference tree (README.md:63-71 are Drive links), so parity and
+benchmarks run on weights produced here: every tensor of the reference state-dict schema
+(keys as produced by models/dino/dino.py:49-245 + backbone.py:36-128) is
+drawn from a numpy PCG64 stream seeded by crc32(canonical tensor name) ^ seed.  The same call
+yields identical weights in the authoring container (where they are loaded into the imported
+reference to make the golden fixtures) and on the GPU box.
+
+A real checkpoint (`torch.load(path)["model"]`, evaluation.py:55-56) goes through
+`load_checkpoint_state_dict` and is used unchanged.
+"""
+from __future__ import annotations
+
+import math
+import re
+import zlib
+from collections import OrderedDict
+from typing import Dict
+
+import numpy as np
+import torch
+
+from .config import DTLRConfig
+
+GENERATOR_VERSION = 1
+
+
+def _rng(name: str, seed: int) -> np.random.Generator:
+    return np.random.Generator(np.random.PCG64((zlib.crc32(name.encode()) ^ (seed * 0x9E3779B1)) & 0xFFFFFFFF))
+
+
+def _normal(name, seed, shape, std):
+    return torch.from_numpy((_rng(name, seed).standard_normal(shape) * std).astype(np.float32))
+
+
+def _uniform(name, seed, shape, lo, hi):
+    return torch.from_numpy(_rng(name, seed).uniform(lo, hi, shape).astype(np.float32))
+
+
+def _linear(sd, name, out_f, in_f, seed, gain=1.0, bias_std=0.02, bias_const=None):
+    sd[name + ".weight"] = _normal(name + ".weight", seed, (out_f, in_f), gain / math.sqrt(in_f))
+    if bias_const is not None:
+        sd[name + ".bias"] = torch.full((out_f,), float(bias_const))
+    else:
+        sd[name + ".bias"] = _normal(name + ".bias", seed, (out_f,), bias_std)
+
+
+def _norm(sd, name, n, seed):
+    sd[name + ".weight"] = _uniform(name + ".weight", seed, (n,), 0.8, 1.2)
+    sd[name + ".bias"] = _normal(name + ".bias", seed, (n,), 0.05)
+
+
+def _frozen_bn(sd, name, n, seed, scale=1.0):
+    # FrozenBatchNorm2d buffers (models/dino/backbone.py:45-49)
+    sd[name + ".weight"] = _uniform(name + ".weight", seed, (n,), 0.8 * scale, 1.2 * scale)
+    sd[name + ".bias"] = _normal(name + ".bias", seed, (n,), 0.05)
+    sd[name + ".running_mean"] = _normal(name + ".running_mean", seed, (n,), 0.05)
+    sd[name + ".running_var"] = _uniform(name + ".running_var", seed, (n,), 0.6, 1.4)
+
+
+def _conv(sd, name, cout, cin, k, seed, gain=math.sqrt(2.0)):
+    sd[name] = _normal(name, seed, (cout, cin, k, k), gain / math.sqrt(cin * k * k))
+
+
+def _msda(sd, p, cfg: DTLRConfig, n_points: int, seed: int):
+    d, M, L, P = cfg.hidden_dim, cfg.nheads, cfg.num_feature_levels, n_points
+    # offsets: small data-dependent part + the ring-shaped bias pattern the reference initialises
+    # (ops/modules/ms_deform_attn.py:62-70): head h points along angle 2*pi*h/M, point p at radius p+1
+    sd[p + ".sampling_offsets.weight"] = _normal(p + ".sampling_offsets.weight", seed, (M * L * P * 2, d), 0.5 / math.sqrt(d))
+    ang = np.arange(M, dtype=np.float64) * (2.0 * math.pi / M)
+    dirs = np.stack([np.cos(ang), np.sin(ang)], -1)
+    dirs = dirs / np.abs(dirs).max(-1, keepdims=True)
+    grid = np.tile(dirs[:, None, None, :], (1, L, P, 1)) * np.arange(1, P + 1, dtype=np.float64)[None, None, :, None]
+    sd[p + ".sampling_offsets.bias"] = torch.from_numpy(grid.reshape(-1).astype(np.float32))
+    _linear(sd, p + ".attention_weights", M * L * P, d, seed, gain=1.0)
+    _linear(sd, p + ".value_proj", d, d, seed)
+    _linear(sd, p + ".output_proj", d, d, seed)
+
+
+def synthetic_state_dict(cfg: DTLRConfig, seed: int = 0) -> "OrderedDict[str, torch.Tensor]":
+    """fp32 CPU tensors keyed exactly like the reference's `model.state_dict()`."""
+    cfg.validate()
+    sd: "OrderedDict[str, torch.Tensor]" = OrderedDict()
+    d, C, ff = cfg.hidden_dim, cfg.num_classes, cfg.dim_feedforward
+
+    # ---- backbone.0.body.* : ResNet-50 v1.5 with FrozenBN -----------------------------------
+    b = "backbone.0.body."
+    _conv(sd, b + "conv1.weight", 64, 3, 7, seed)
+    _frozen_bn(sd, b + "bn1", 64, seed)
+    inplanes = 64
+    for li, (planes, nblocks) in enumerate(zip((64, 128, 256, 512), cfg.backbone_blocks), start=1):
+        for bi in range(nblocks):
+            p = f"{b}layer{li}.{bi}."
+            _conv(sd, p + "conv1.weight", planes, inplanes, 1, seed)
+            _frozen_bn(sd, p + "bn1", planes, seed)
+            _conv(sd, p + "conv2.weight", planes, planes, 3, seed)
+            _frozen_bn(sd, p + "bn2", planes, seed)
+            _conv(sd, p + "conv3.weight", planes * 4, planes, 1, seed)
+            _frozen_bn(sd, p + "bn3", planes * 4, seed, scale=0.4)   # damp the residual branch
+            if bi == 0:
+                _conv(sd, p + "downsample.0.weight", planes * 4, inplanes, 1, seed, gain=1.0)
+                _frozen_bn(sd, p + "downsample.1", planes * 4, seed)
+            inplanes = planes * 4
+
+    # ---- input_proj (models/dino/dino.py:115-136) ---------------------------------------------
+    for l, cin in enumerate(cfg.backbone_channels):
+        _conv(sd, f"input_proj.{l}.0.weight", d, cin, 1, seed, gain=1.0)
+        sd[f"input_proj.{l}.0.bias"] = _normal(f"input_proj.{l}.0.bias", seed, (d,), 0.02)
+        _norm(sd, f"input_proj.{l}.1", d, seed)
+    l = len(cfg.backbone_channels)
+    _conv(sd, f"input_proj.{l}.0.weight", d, cfg.backbone_channels[-1], 3, seed, gain=1.0)
+    sd[f"input_proj.{l}.0.bias"] = _normal(f"input_proj.{l}.0.bias", seed, (d,), 0.02)
+    _norm(sd, f"input_proj.{l}.1", d, seed)
+
+    # ---- transformer ------------------------------------------------------------------------------
+    t = "transformer."
+    sd[t + "level_embed"] = _normal(t + "level_embed", seed, (cfg.num_feature_levels, d), 1.0)
+    for n in range(cfg.enc_layers):
+        p = f"{t}encoder.layers.{n}."
+        _msda(sd, p + "self_attn", cfg, cfg.enc_n_points, seed)
+        _norm(sd, p + "norm1", d, seed)
+        _linear(sd, p + "linear1", ff, d, seed, gain=math.sqrt(2.0))
+        _linear(sd, p + "linear2", d, ff, seed)
+        _norm(sd, p + "norm2", d, seed)
+    for n in range(cfg.dec_layers):
+        p = f"{t}decoder.layers.{n}."
+        _msda(sd, p + "cross_attn", cfg, cfg.dec_n_points, seed)
+        _norm(sd, p + "norm1", d, seed)
+        sd[p + "self_attn.in_proj_weight"] = _normal(p + "self_attn.in_proj_weight", seed, (3 * d, d), 1.0 / math.sqrt(d))
+        sd[p + "self_attn.in_proj_bias"] = _normal(p + "self_attn.in_proj_bias", seed, (3 * d,), 0.02)
+        _linear(sd, p + "self_attn.out_proj", d, d, seed)
+        _norm(sd, p + "norm2", d, seed)
+        _linear(sd, p + "linear1", ff, d, seed, gain=math.sqrt(2.0))
+        _linear(sd, p + "linear2", d, ff, seed)
+        _norm(sd, p + "norm3", d, seed)
+    _norm(sd, t + "decoder.norm", d, seed)
+    _linear(sd, t + "decoder.ref_point_head.layers.0", d, 2 * d, seed, gain=math.sqrt(2.0))
+    _linear(sd, t + "decoder.ref_point_head.layers.1", d, d, seed)
+    sd[t + "tgt_embed.weight"] = _normal(t + "tgt_embed.weight", seed, (cfg.num_queries, d), 1.0)
+    _linear(sd, t + "enc_output", d, d, seed)
+    _norm(sd, t + "enc_output_norm", d, seed)
+    # Tokens whose proposal is invalid/padded have their memory row zeroed (models/dino/utils.py:
+    # 58-62), so they all share ONE two-stage score.  With zero biases here that score is the bare
+    # class bias (-6), i.e. below every real token, as a trained model arranges; otherwise the
+    # top-k would contain a block of exactly tied scores whose order is implementation-defined
+    # even inside the reference (CPU vs CUDA torch.topk).
+    sd[t + "enc_output.bias"] = torch.zeros(d)
+    sd[t + "enc_output_norm.bias"] = torch.zeros(d)
+    # two-stage heads own their tensors (two_stage_*_embed_share=False, Latin_CTC.py:67-68)
+    _linear(sd, t + "enc_out_bbox_embed.layers.0", d, d, seed, gain=math.sqrt(2.0))
+    _linear(sd, t + "enc_out_bbox_embed.layers.1", d, d, seed, gain=math.sqrt(2.0))
+    _linear(sd, t + "enc_out_bbox_embed.layers.2", 4, d, seed, gain=0.3)
+    # The reference initialises class biases to -log(99) = -4.6 (models/dino/dino.py:164-166); a
+    # TRAINED head is far more bimodal (most queries blank).  -6.0 with a wider weight spread gives
+    # synthetic outputs where both branches of the blank decoder (sum p < 1-eps / >= 1-eps) and
+    # the score>TH filter of the NMS decoder are exercised.
+    cls_bias = -6.0
+    _linear(sd, t + "enc_out_class_embed", C, d, seed, gain=1.0, bias_const=cls_bias)
+
+    # ---- shared decoder heads: ONE MLP / ONE Linear aliased 2 x dec_layers times -----------------
+    shared: Dict[str, torch.Tensor] = OrderedDict()
+    _linear(shared, "bbox_embed.layers.0", d, d, seed, gain=math.sqrt(2.0))
+    _linear(shared, "bbox_embed.layers.1", d, d, seed, gain=math.sqrt(2.0))
+    _linear(shared, "bbox_embed.layers.2", 4, d, seed, gain=0.3)
+    _linear(shared, "class_embed", C, d, seed, gain=2.0, bias_const=cls_bias)
+    for n in range(cfg.dec_layers):
+        for k, v in shared.items():
+            head, rest = k.split(".", 1) if k.startswith("bbox_embed") else ("class_embed", k[len("class_embed."):])
+            key = f"{head}.{n}.{rest}"
+            sd[key] = v
+            sd[t + "decoder." + key] = v
+    sd["label_enc.weight"] = _normal("label_enc.weight", seed, (cfg.dn_labelbook_size + 1, d), 1.0)
+    return sd
+
+
+# --------------------------------------------------------------------------------------------------
+_ALIAS = re.compile(r"^(transformer\.decoder\.)?(class_embed|bbox_embed)\.(\d+)\.")
+
+
+def load_checkpoint_state_dict(path: str) -> "OrderedDict[str, torch.Tensor]":
+    """`checkpoint["model"]` as evaluation.py:55-56 reads it; `module.` prefixes stripped
+    (util/misc.py:581-586)."""
+    ckpt = torch.load(path, map_location="cpu", weights_only=False)
+    sd = ckpt["model"] if isinstance(ckpt, dict) and "model" in ckpt else ckpt
+    out = OrderedDict()
+    for k, v in sd.items():
+        out[k[7:] if k.startswith("module.") else k] = v
+    return out
+
+
+def num_classes_of(sd: Dict[str, torch.Tensor]) -> int:
+    """Class count comes from the checkpoint, not a constant (SURVEY.md section 8 preamble)."""
+    return int(sd["class_embed.0.weight"].shape[0])

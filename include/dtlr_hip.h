@@ -1,0 +1,59 @@
+/* dtlr_hip.h -- C ABI of libdtlr_hip.so, the MI355X (gfx950) implementation of the DTLR
+ * inference hot path.  Plain pointers and sizes only; no torch types.  Every entry point:
+ *   - takes DEVICE pointers to contiguous buffers owned by the caller,
+ *   - enqueues its kernels on `stream` (a hipStream_t passed as void*; NULL = default stream)
+ *     and returns without synchronising,
+ *   - returns DTLR_OK (0) or a negative DTLR_E* code and never throws; dtlr_strerror() maps codes
+ *     to text.  Kernel-launch failures are returned (the reference only printf's them,
+ *     models/dino/ops/src/cuda/ms_deform_im2col_cuda.cuh:948-952).
+ *
+ * Each declaration cites the reference interface it replaces (paths under /root/reference).
+ */
+#ifndef DTLR_HIP_H
+#define DTLR_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define DTLR_OK 0
+#define DTLR_EINVAL (-1)   /* null pointer / non-positive size */
+#define DTLR_EDTYPE (-2)   /* unsupported dtype code */
+#define DTLR_ESHAPE (-3)   /* shape outside what the kernels support */
+#define DTLR_ELAUNCH (-4)  /* hipLaunch / runtime error, see dtlr_last_hip_error() */
+
+/* dtype codes (the arithmetic/storage type of the floating-point operands) */
+#define DTLR_F32 0
+#define DTLR_F64 1
+#define DTLR_BF16 2
+
+const char *dtlr_strerror(int code);
+int dtlr_last_hip_error(void);          /* last hipError_t seen by this library (thread-local) */
+int dtlr_abi_version(void);
+
+/* ---------------------------------------------------------------------------------------------
+ * Multi-scale deformable attention forward.
+ * Replaces: MultiScaleDeformableAttention.ms_deform_attn_forward
+ *           (models/dino/ops/src/vision.cpp:13-16 -> ms_deform_attn.h:20-39 ->
+ *            cuda/ms_deform_attn_cuda.cu:20-80 -> cuda/ms_deform_im2col_cuda.cuh:237-299),
+ *           called by MSDeformAttnFunction.forward (ops/functions/ms_deform_attn_func.py:23-29).
+ *   value  [N,S,M,D]          dtype
+ *   shapes [L,2] int64 (H,W)  level_start_index [L] int64      (device, as the reference passes)
+ *   loc    [N,Lq,M,L,P,2]     (x,y) in units of the level's width/height;  dtype (f32 for BF16)
+ *   attn   [N,Lq,M,L,P]       dtype (f32 for BF16)
+ *   out    [N,Lq,M*D]         dtype; every element is written
+ * out[b,q,m,:] = sum_l sum_p attn * bilinear(value_l[b,:,m,:], (x*W-0.5, y*H-0.5)), zero padding.
+ * No im2col_step: the whole batch is one launch (the reference's chunk loop, cu:50-75, is a CUDA
+ * grid-size workaround; its divisibility check is kept in the Python binding).
+ */
+int dtlr_msda_forward(const void *value, const int64_t *shapes, const int64_t *level_start_index,
+                      const void *loc, const void *attn,
+                      int N, int S, int M, int D, int L, int Lq, int P,
+                      int dtype, void *out, void *stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* DTLR_HIP_H */

@@ -1,0 +1,599 @@
+"""CPU ORACLE for the DTLR inference hot path.  TEST INFRASTRUCTURE ONLY.
+
+This file restates, in plain single-threaded-semantics PyTorch-CPU fp32 (no custom ops, no GPU),
+the algorithm of the reference's inference path: DINO.forward over text-line images -> per-query
+character logits/boxes -> PostProcess / the two decoders -> CER.  Every function cites the
+reference file:line it follows.  Only `tests/`, `__graft_entry__.smoke()` and `bench.py`'s
+`cpu_baseline` leg may import it, and only as the checker / reported baseline; nothing under
+`dtlr_amd/` imports it (tests/test_no_oracle_in_product.py enforces this).
+
+Pinning: the oracle is pinned against the REAL reference model imported in
+the authoring container (`tests/golden/make_golden.py`, which loads /root/reference with the four
+stubs of section 8c) on the same name-seeded weights; the resulting input/output vectors are
+committed under tests/golden/ and re-checked by `tests/test_oracle_golden.py` everywhere.
+Third-party arithmetic that is NOT under /root/reference -- torchvision's resnet50 topology and
+`torchvision.ops.nms` -- is restated from the public definitions (ResNet-50 v1.5; greedy NMS with
+IoU > threshold suppression): that part is "parity unpinned" against torchvision itself.
+
+State-dict keys are the reference's.
+"""
+from __future__ import annotations
+
+import math
+import re
+from typing import Dict, List, Optional, Sequence, Tuple
+
+import torch
+import torch.nn.functional as F
+
+Tensor = torch.Tensor
+
+
+# ======================================================================================
+# util/misc.py
+# ======================================================================================
+def nested_tensor_from_tensor_list(tensor_list: Sequence[Tensor]) -> Tuple[Tensor, Tensor]:
+    """util/misc.py:375-397: zero-pad to the batch max H,W; mask True on padding."""
+    if isinstance(tensor_list, Tensor) and tensor_list.ndim == 4:
+        tensor_list = list(tensor_list)
+    assert tensor_list[0].ndim == 3
+    c = tensor_list[0].shape[0]
+    h = max(int(t.shape[1]) for t in tensor_list)
+    w = max(int(t.shape[2]) for t in tensor_list)
+    b = len(tensor_list)
+    tensor = torch.zeros((b, c, h, w), dtype=tensor_list[0].dtype)
+    mask = torch.ones((b, h, w), dtype=torch.bool)
+    for i, img in enumerate(tensor_list):
+        tensor[i, :, : img.shape[1], : img.shape[2]] = img
+        mask[i, : img.shape[1], : img.shape[2]] = False
+    return tensor, mask
+
+
+def inverse_sigmoid(x: Tensor, eps: float = 1e-3) -> Tensor:
+    """util/misc.py:575-579."""
+    x = x.clamp(min=0, max=1)
+    x1 = x.clamp(min=eps)
+    x2 = (1 - x).clamp(min=eps)
+    return torch.log(x1 / x2)
+
+
+def box_cxcywh_to_xyxy(x: Tensor) -> Tensor:
+    """util/box_ops.py:9-13."""
+    xc, yc, w, h = x.unbind(-1)
+    return torch.stack([xc - 0.5 * w, yc - 0.5 * h, xc + 0.5 * w, yc + 0.5 * h], dim=-1)
+
+
+def box_xyxy_to_cxcywh(x: Tensor) -> Tensor:
+    """util/box_ops.py:16-20."""
+    x0, y0, x1, y1 = x.unbind(-1)
+    return torch.stack([(x0 + x1) / 2, (y0 + y1) / 2, x1 - x0, y1 - y0], dim=-1)
+
+
+# ======================================================================================
+# models/dino/backbone.py  (+ torchvision resnet50, restated from the public definition)
+# ======================================================================================
+def frozen_bn(x: Tensor, sd: Dict[str, Tensor], p: str) -> Tensor:
+    """models/dino/backbone.py:62-72 (eps 1e-5 added before rsqrt)."""
+    w = sd[p + ".weight"].reshape(1, -1, 1, 1)
+    b = sd[p + ".bias"].reshape(1, -1, 1, 1)
+    rv = sd[p + ".running_var"].reshape(1, -1, 1, 1)
+    rm = sd[p + ".running_mean"].reshape(1, -1, 1, 1)
+    scale = w * (rv + 1e-5).rsqrt()
+    return x * scale + (b - rm * scale)
+
+
+def resnet50_body(x: Tensor, sd: Dict[str, Tensor], blocks=(3, 4, 6, 3)) -> List[Tensor]:
+    """torchvision resnet50 as called from backbone.py:118-120 (v1.5: the stride sits on the 3x3
+    conv of each stage's first bottleneck; norm_layer=FrozenBatchNorm2d), returning layer2/3/4
+    (IntermediateLayerGetter with return_interm_indices [1,2,3], backbone.py:84-94)."""
+    b = "backbone.0.body."
+    x = F.conv2d(x, sd[b + "conv1.weight"], None, stride=2, padding=3)
+    x = F.relu(frozen_bn(x, sd, b + "bn1"))
+    x = F.max_pool2d(x, kernel_size=3, stride=2, padding=1)
+    outs = []
+    for li, nblocks in enumerate(blocks, start=1):
+        for bi in range(nblocks):
+            p = f"{b}layer{li}.{bi}."
+            stride = 2 if (bi == 0 and li > 1) else 1
+            idt = x
+            o = F.relu(frozen_bn(F.conv2d(x, sd[p + "conv1.weight"]), sd, p + "bn1"))
+            o = F.relu(frozen_bn(F.conv2d(o, sd[p + "conv2.weight"], None, stride=stride, padding=1), sd, p + "bn2"))
+            o = frozen_bn(F.conv2d(o, sd[p + "conv3.weight"]), sd, p + "bn3")
+            if bi == 0:
+                idt = frozen_bn(F.conv2d(x, sd[p + "downsample.0.weight"], None, stride=stride), sd, p + "downsample.1")
+            x = F.relu(o + idt)
+        if li >= 2:
+            outs.append(x)
+    return outs
+
+
+def interpolate_mask(mask: Tensor, size) -> Tensor:
+    """backbone.py:103 / dino.py:304-307: nearest F.interpolate of the float mask, back to bool."""
+    return F.interpolate(mask[None].float(), size=tuple(int(s) for s in size)).to(torch.bool)[0]
+
+
+# ======================================================================================
+# models/dino/position_encoding.py
+# ======================================================================================
+def position_embedding_sine_hw(mask: Tensor, num_pos_feats: int = 128, tH: float = 20, tW: float = 20) -> Tensor:
+    """position_encoding.py:79-108 (normalize=True, scale 2*pi, eps 1e-6)."""
+    not_mask = ~mask
+    y_embed = not_mask.cumsum(1, dtype=torch.float32)
+    x_embed = not_mask.cumsum(2, dtype=torch.float32)
+    eps, scale = 1e-6, 2 * math.pi
+    y_embed = y_embed / (y_embed[:, -1:, :] + eps) * scale
+    x_embed = x_embed / (x_embed[:, :, -1:] + eps) * scale
+    dim_t = torch.arange(num_pos_feats, dtype=torch.float32)
+    dim_tx = tW ** (2 * (dim_t // 2) / num_pos_feats)
+    dim_ty = tH ** (2 * (dim_t // 2) / num_pos_feats)
+    pos_x = x_embed[:, :, :, None] / dim_tx
+    pos_y = y_embed[:, :, :, None] / dim_ty
+    pos_x = torch.stack((pos_x[:, :, :, 0::2].sin(), pos_x[:, :, :, 1::2].cos()), dim=4).flatten(3)
+    pos_y = torch.stack((pos_y[:, :, :, 0::2].sin(), pos_y[:, :, :, 1::2].cos()), dim=4).flatten(3)
+    return torch.cat((pos_y, pos_x), dim=3).permute(0, 3, 1, 2)
+
+
+# ======================================================================================
+# models/dino/ops : the MSDeformAttn operator and module
+# ======================================================================================
+def ms_deform_attn_core(value: Tensor, spatial_shapes, sampling_locations: Tensor, attention_weights: Tensor) -> Tensor:
+    """Line-by-line restatement of the CUDA forward kernel's arithmetic
+    (ops/src/cuda/ms_deform_im2col_cuda.cuh:33-84 bilinear, :237-299 loop) with torch gathers:
+        h_im = loc_y*H - 0.5 ; w_im = loc_x*W - 0.5 ; sampled iff -1 < h_im < H and -1 < w_im < W
+        four corners, each contributing only when inside the map (zero padding)
+        out[b,q,m,:] = sum_l sum_p A[b,q,m,l,p] * bilinear(...)
+    which the reference states is equivalent to ms_deform_attn_core_pytorch
+    (ops/functions/ms_deform_attn_func.py:41-61; ops/test.py:31-60).
+    value [N,S,M,D], locations [N,Lq,M,L,P,2] (x,y), weights [N,Lq,M,L,P] -> [N,Lq,M*D]."""
+    N, S, M, D = value.shape
+    _, Lq, _, L, P, _ = sampling_locations.shape
+    shapes = [(int(h), int(w)) for h, w in (spatial_shapes.tolist() if isinstance(spatial_shapes, Tensor) else spatial_shapes)]
+    out = torch.zeros((N, Lq, M, D), dtype=value.dtype)
+    start = 0
+    bidx = torch.arange(N).view(N, 1, 1, 1)
+    midx = torch.arange(M).view(1, 1, M, 1)
+    for l, (H, W) in enumerate(shapes):
+        v = value[:, start:start + H * W]                       # [N, HW, M, D]
+        loc = sampling_locations[:, :, :, l]                    # [N, Lq, M, P, 2]
+        aw = attention_weights[:, :, :, l]                      # [N, Lq, M, P]
+        w_im = loc[..., 0] * W - 0.5
+        h_im = loc[..., 1] * H - 0.5
+        inside = (h_im > -1) & (w_im > -1) & (h_im < H) & (w_im < W)
+        h_low = torch.floor(h_im)
+        w_low = torch.floor(w_im)
+        lh, lw = h_im - h_low, w_im - w_low
+        hh, hw = 1 - lh, 1 - lw
+        h_low, w_low = h_low.long(), w_low.long()
+        h_high, w_high = h_low + 1, w_low + 1
+
+        def corner(hi, wi, ok):
+            ok = ok & inside
+            idx = (hi.clamp(0, H - 1) * W + wi.clamp(0, W - 1))           # [N,Lq,M,P]
+            g = v[bidx, idx, midx]                                       # [N,Lq,M,P,D]
+            return g * ok.unsqueeze(-1).to(v.dtype)
+
+        v1 = corner(h_low, w_low, (h_low >= 0) & (w_low >= 0))
+        v2 = corner(h_low, w_high, (h_low >= 0) & (w_high <= W - 1))
+        v3 = corner(h_high, w_low, (h_high <= H - 1) & (w_low >= 0))
+        v4 = corner(h_high, w_high, (h_high <= H - 1) & (w_high <= W - 1))
+        w1, w2, w3, w4 = hh * hw, hh * lw, lh * hw, lh * lw
+        val = w1.unsqueeze(-1) * v1 + w2.unsqueeze(-1) * v2 + w3.unsqueeze(-1) * v3 + w4.unsqueeze(-1) * v4
+        out += (val * aw.unsqueeze(-1)).sum(3)
+        start += H * W
+    return out.reshape(N, Lq, M * D)
+
+
+def msda_sampling_locations(reference_points: Tensor, sampling_offsets: Tensor, spatial_shapes: Tensor, n_points: int) -> Tensor:
+    """ops/modules/ms_deform_attn.py:102-111."""
+    if reference_points.shape[-1] == 2:
+        normalizer = torch.stack([spatial_shapes[..., 1], spatial_shapes[..., 0]], -1).to(sampling_offsets.dtype)
+        return reference_points[:, :, None, :, None, :] + sampling_offsets / normalizer[None, None, None, :, None, :]
+    if reference_points.shape[-1] == 4:
+        return reference_points[:, :, None, :, None, :2] + sampling_offsets / n_points * reference_points[:, :, None, :, None, 2:] * 0.5
+    raise ValueError("Last dim of reference_points must be 2 or 4")
+
+
+def ms_deform_attn_module(sd, p, query, reference_points, input_flatten, spatial_shapes, padding_mask,
+                          n_heads=8, n_levels=4, n_points=4) -> Tensor:
+    """ops/modules/ms_deform_attn.py:78-126 (MSDeformAttn.forward)."""
+    N, Lq, C = query.shape
+    _, S, _ = input_flatten.shape
+    value = F.linear(input_flatten, sd[p + ".value_proj.weight"], sd[p + ".value_proj.bias"])
+    if padding_mask is not None:
+        value = value.masked_fill(padding_mask[..., None], 0.0)
+    value = value.view(N, S, n_heads, C // n_heads)
+    off = F.linear(query, sd[p + ".sampling_offsets.weight"], sd[p + ".sampling_offsets.bias"]).view(N, Lq, n_heads, n_levels, n_points, 2)
+    aw = F.linear(query, sd[p + ".attention_weights.weight"], sd[p + ".attention_weights.bias"]).view(N, Lq, n_heads, n_levels * n_points)
+    aw = F.softmax(aw, -1).view(N, Lq, n_heads, n_levels, n_points)
+    loc = msda_sampling_locations(reference_points, off, spatial_shapes, n_points)
+    out = ms_deform_attn_core(value, spatial_shapes, loc, aw)
+    return F.linear(out, sd[p + ".output_proj.weight"], sd[p + ".output_proj.bias"])
+
+
+# ======================================================================================
+# models/dino/utils.py
+# ======================================================================================
+def gen_encoder_output_proposals(memory: Tensor, padding_mask: Tensor, spatial_shapes) -> Tuple[Tensor, Tensor]:
+    """models/dino/utils.py:15-64 (learnedwh=None)."""
+    N, S, C = memory.shape
+    proposals = []
+    cur = 0
+    for lvl, (H, W) in enumerate(spatial_shapes.tolist()):
+        m = padding_mask[:, cur:cur + H * W].view(N, H, W, 1)
+        valid_H = torch.sum(~m[:, :, 0, 0], 1)
+        valid_W = torch.sum(~m[:, 0, :, 0], 1)
+        gy, gx = torch.meshgrid(torch.linspace(0, H - 1, H, dtype=torch.float32),
+                                torch.linspace(0, W - 1, W, dtype=torch.float32), indexing="ij")
+        grid = torch.cat([gx.unsqueeze(-1), gy.unsqueeze(-1)], -1)
+        scale = torch.cat([valid_W.unsqueeze(-1), valid_H.unsqueeze(-1)], 1).view(N, 1, 1, 2)
+        grid = (grid.unsqueeze(0).expand(N, -1, -1, -1) + 0.5) / scale
+        wh = torch.ones_like(grid) * 0.05 * (2.0 ** lvl)
+        proposals.append(torch.cat((grid, wh), -1).view(N, -1, 4))
+        cur += H * W
+    prop = torch.cat(proposals, 1)
+    valid = ((prop > 0.01) & (prop < 0.99)).all(-1, keepdim=True)
+    prop = torch.log(prop / (1 - prop))
+    prop = prop.masked_fill(padding_mask.unsqueeze(-1), float("inf"))
+    prop = prop.masked_fill(~valid, float("inf"))
+    mem = memory.masked_fill(padding_mask.unsqueeze(-1), 0.0)
+    mem = mem.masked_fill(~valid, 0.0)
+    return mem, prop
+
+
+def mlp(sd, p, x: Tensor, num_layers: int) -> Tensor:
+    """models/dino/utils.py:110-122."""
+    for i in range(num_layers):
+        x = F.linear(x, sd[f"{p}.layers.{i}.weight"], sd[f"{p}.layers.{i}.bias"])
+        if i < num_layers - 1:
+            x = F.relu(x)
+    return x
+
+
+def gen_sineembed_for_position(pos_tensor: Tensor) -> Tensor:
+    """models/dino/utils.py:141-167 (4-d boxes -> [y|x|w|h] x 128)."""
+    scale = 2 * math.pi
+    dim_t = torch.arange(128, dtype=torch.float32)
+    dim_t = 10000 ** (2 * (dim_t // 2) / 128)
+
+    def emb(c):
+        e = (c * scale)[:, :, None] / dim_t
+        return torch.stack((e[:, :, 0::2].sin(), e[:, :, 1::2].cos()), dim=3).flatten(2)
+
+    px, py = emb(pos_tensor[:, :, 0]), emb(pos_tensor[:, :, 1])
+    if pos_tensor.size(-1) == 2:
+        return torch.cat((py, px), dim=2)
+    pw, ph = emb(pos_tensor[:, :, 2]), emb(pos_tensor[:, :, 3])
+    return torch.cat((py, px, pw, ph), dim=2)
+
+
+# ======================================================================================
+# models/dino/deformable_transformer.py
+# ======================================================================================
+def get_valid_ratio(mask: Tensor) -> Tensor:
+    """deformable_transformer.py:239-246 -> (w, h)."""
+    _, H, W = mask.shape
+    valid_H = torch.sum(~mask[:, :, 0], 1)
+    valid_W = torch.sum(~mask[:, 0, :], 1)
+    return torch.stack([valid_W.float() / W, valid_H.float() / H], -1)
+
+
+def encoder_reference_points(spatial_shapes, valid_ratios: Tensor) -> Tensor:
+    """deformable_transformer.py:479-492."""
+    lst = []
+    for lvl, (H, W) in enumerate(spatial_shapes.tolist()):
+        ry, rx = torch.meshgrid(torch.linspace(0.5, H - 0.5, H, dtype=torch.float32),
+                                torch.linspace(0.5, W - 0.5, W, dtype=torch.float32), indexing="ij")
+        ry = ry.reshape(-1)[None] / (valid_ratios[:, None, lvl, 1] * H)
+        rx = rx.reshape(-1)[None] / (valid_ratios[:, None, lvl, 0] * W)
+        lst.append(torch.stack((rx, ry), -1))
+    ref = torch.cat(lst, 1)
+    return ref[:, :, None] * valid_ratios[:, None]
+
+
+def layer_norm(sd, p, x):
+    return F.layer_norm(x, (x.shape[-1],), sd[p + ".weight"], sd[p + ".bias"], 1e-5)
+
+
+def encoder_layer(sd, p, src, pos, ref, spatial_shapes, padding_mask, cfg) -> Tensor:
+    """deformable_transformer.py:804-823 (post-norm, dropout 0)."""
+    src2 = ms_deform_attn_module(sd, p + ".self_attn", src + pos, ref, src, spatial_shapes, padding_mask,
+                                 cfg.nheads, cfg.num_feature_levels, cfg.enc_n_points)
+    src = layer_norm(sd, p + ".norm1", src + src2)
+    ff = F.linear(F.relu(F.linear(src, sd[p + ".linear1.weight"], sd[p + ".linear1.bias"])),
+                  sd[p + ".linear2.weight"], sd[p + ".linear2.bias"])
+    return layer_norm(sd, p + ".norm2", src + ff)
+
+
+def multihead_self_attention(sd, p, q_in: Tensor, v_in: Tensor, n_heads: int) -> Tensor:
+    """nn.MultiheadAttention(256, 8) as used at deformable_transformer.py:847,904-907:
+    q = k = tgt + query_pos, v = tgt; batch-first restatement ([B, nq, C]); scale 1/sqrt(head_dim);
+    no masks in eval."""
+    B, Lq, C = q_in.shape
+    W, bias = sd[p + ".in_proj_weight"], sd[p + ".in_proj_bias"]
+    q = F.linear(q_in, W[:C], bias[:C])
+    k = F.linear(q_in, W[C:2 * C], bias[C:2 * C])
+    v = F.linear(v_in, W[2 * C:], bias[2 * C:])
+    hd = C // n_heads
+    q = q.view(B, Lq, n_heads, hd).transpose(1, 2)
+    k = k.view(B, Lq, n_heads, hd).transpose(1, 2)
+    v = v.view(B, Lq, n_heads, hd).transpose(1, 2)
+    att = torch.softmax((q * (1.0 / math.sqrt(hd))) @ k.transpose(-1, -2), dim=-1)
+    o = (att @ v).transpose(1, 2).reshape(B, Lq, C)
+    return F.linear(o, sd[p + ".out_proj.weight"], sd[p + ".out_proj.bias"])
+
+
+def decoder_layer(sd, p, tgt, query_pos, ref_input, memory, spatial_shapes, padding_mask, cfg) -> Tensor:
+    """deformable_transformer.py:981-997 with module_seq ['sa','ca','ffn'] (sa 882-923, ca 925-959,
+    ffn 876-880); batch-first restatement of the seq-first reference."""
+    t2 = multihead_self_attention(sd, p + ".self_attn", tgt + query_pos, tgt, cfg.nheads)
+    tgt = layer_norm(sd, p + ".norm2", tgt + t2)
+    t2 = ms_deform_attn_module(sd, p + ".cross_attn", tgt + query_pos, ref_input, memory, spatial_shapes, padding_mask,
+                               cfg.nheads, cfg.num_feature_levels, cfg.dec_n_points)
+    tgt = layer_norm(sd, p + ".norm1", tgt + t2)
+    ff = F.linear(F.relu(F.linear(tgt, sd[p + ".linear1.weight"], sd[p + ".linear1.bias"])),
+                  sd[p + ".linear2.weight"], sd[p + ".linear2.bias"])
+    return layer_norm(sd, p + ".norm3", tgt + ff)
+
+
+def transformer_forward(sd, cfg, srcs, masks, poss, forced_topk: Optional[Tensor] = None) -> Dict[str, Tensor]:
+    """DeformableTransformer.forward (deformable_transformer.py:257-429), inference branch
+    (refpoint_embed=None, tgt=None, attn_mask=None).  `forced_topk` [B,nq] overrides the two-stage
+    selection indices: used by parity tests to separate rounding-induced rank swaps of near-tied
+    scores (a discrete effect present between ANY two fp32 implementations) from arithmetic error."""
+    t = "transformer."
+    src_f, mask_f, pos_f, shapes = [], [], [], []
+    for lvl, (src, mask, pos) in enumerate(zip(srcs, masks, poss)):
+        bs, c, h, w = src.shape
+        shapes.append((h, w))
+        src_f.append(src.flatten(2).transpose(1, 2))
+        mask_f.append(mask.flatten(1))
+        pos_f.append(pos.flatten(2).transpose(1, 2) + sd[t + "level_embed"][lvl].view(1, 1, -1))
+    src_flatten = torch.cat(src_f, 1)
+    mask_flatten = torch.cat(mask_f, 1)
+    lvl_pos = torch.cat(pos_f, 1)
+    spatial_shapes = torch.as_tensor(shapes, dtype=torch.long)
+    valid_ratios = torch.stack([get_valid_ratio(m) for m in masks], 1)
+
+    # ---- encoder (494-580) ----
+    ref = encoder_reference_points(spatial_shapes, valid_ratios)
+    memory = src_flatten
+    for n in range(cfg.enc_layers):
+        memory = encoder_layer(sd, f"{t}encoder.layers.{n}", memory, lvl_pos, ref, spatial_shapes, mask_flatten, cfg)
+
+    # ---- two-stage query selection (320-363) ----
+    output_memory, output_proposals = gen_encoder_output_proposals(memory, mask_flatten, spatial_shapes)
+    output_memory = layer_norm(sd, t + "enc_output_norm",
+                               F.linear(output_memory, sd[t + "enc_output.weight"], sd[t + "enc_output.bias"]))
+    enc_class = F.linear(output_memory, sd[t + "enc_out_class_embed.weight"], sd[t + "enc_out_class_embed.bias"])
+    enc_coord = mlp(sd, t + "enc_out_bbox_embed", output_memory, 3) + output_proposals
+    topk_scores = enc_class.max(-1)[0]
+    topk_idx = torch.topk(topk_scores, cfg.num_queries, dim=1)[1] if forced_topk is None else forced_topk
+    refpoint_undetach = torch.gather(enc_coord, 1, topk_idx.unsqueeze(-1).repeat(1, 1, 4))
+    init_box_proposal = torch.gather(output_proposals, 1, topk_idx.unsqueeze(-1).repeat(1, 1, 4)).sigmoid()
+    tgt_undetach = torch.gather(output_memory, 1, topk_idx.unsqueeze(-1).repeat(1, 1, cfg.hidden_dim))
+    bs = memory.shape[0]
+    tgt = sd[t + "tgt_embed.weight"][None].repeat(bs, 1, 1)          # embed_init_tgt=True (354-355)
+
+    # ---- decoder (652-766), batch-first ----
+    reference_points = refpoint_undetach.sigmoid()
+    ref_points = [reference_points]
+    intermediate = []
+    vr4 = torch.cat([valid_ratios, valid_ratios], -1)                 # [B, L, 4]
+    output = tgt
+    for n in range(cfg.dec_layers):
+        ref_input = reference_points[:, :, None] * vr4[:, None]       # [B, nq, L, 4]
+        query_sine = gen_sineembed_for_position(ref_input[:, :, 0, :])
+        query_pos = mlp(sd, t + "decoder.ref_point_head", query_sine, 2)
+        output = decoder_layer(sd, f"{t}decoder.layers.{n}", output, query_pos, ref_input, memory,
+                               spatial_shapes, mask_flatten, cfg)
+        delta = mlp(sd, f"bbox_embed.{n}", output, 3)
+        new_ref = (delta + inverse_sigmoid(reference_points)).sigmoid()
+        reference_points = new_ref
+        ref_points.append(new_ref)
+        intermediate.append(layer_norm(sd, t + "decoder.norm", output))
+    return dict(hs=intermediate, references=ref_points, hs_enc=tgt_undetach, ref_enc=refpoint_undetach.sigmoid(),
+                init_box_proposal=init_box_proposal, topk_idx=topk_idx, topk_scores=topk_scores,
+                memory=memory, spatial_shapes=spatial_shapes, valid_ratios=valid_ratios)
+
+
+# ======================================================================================
+# models/dino/dino.py
+# ======================================================================================
+def input_proj_level(sd, l: int, x: Tensor, stride: int = 1, padding: int = 0) -> Tensor:
+    """dino.py:115-136: Conv + GroupNorm(32, 256)."""
+    x = F.conv2d(x, sd[f"input_proj.{l}.0.weight"], sd[f"input_proj.{l}.0.bias"], stride=stride, padding=padding)
+    return F.group_norm(x, 32, sd[f"input_proj.{l}.1.weight"], sd[f"input_proj.{l}.1.bias"], 1e-5)
+
+
+@torch.no_grad()
+def dino_forward(sd: Dict[str, Tensor], cfg, samples, mask: Optional[Tensor] = None,
+                 forced_topk: Optional[Tensor] = None, return_debug: bool = False) -> Dict[str, Tensor]:
+    """DINO.forward (models/dino/dino.py:270-415), eval, targets=None.
+    `samples`: [B,3,H,W] tensor (+ optional explicit mask) or list of [3,h,w] tensors."""
+    if mask is None:
+        x, mask = nested_tensor_from_tensor_list(samples)
+    else:
+        x = samples
+    feats = resnet50_body(x, sd, cfg.backbone_blocks)
+    srcs, masks, poss = [], [], []
+    for l, f in enumerate(feats):
+        m = interpolate_mask(mask, f.shape[-2:])
+        srcs.append(input_proj_level(sd, l, f))
+        masks.append(m)
+        poss.append(position_embedding_sine_hw(m, cfg.hidden_dim // 2, cfg.pe_temperatureH, cfg.pe_temperatureW))
+    l = len(feats)
+    src = input_proj_level(sd, l, feats[-1], stride=2, padding=1)      # dino.py:299-301
+    m = interpolate_mask(mask, src.shape[-2:])                        # from the FULL-RES mask (304-307)
+    srcs.append(src)
+    masks.append(m)
+    poss.append(position_embedding_sine_hw(m, cfg.hidden_dim // 2, cfg.pe_temperatureH, cfg.pe_temperatureW))
+
+    tr = transformer_forward(sd, cfg, srcs, masks, poss, forced_topk)
+    hs, reference = tr["hs"], tr["references"]
+    coords, classes = [], []
+    for n in range(cfg.dec_layers):                                    # dino.py:339-354
+        coords.append((mlp(sd, f"bbox_embed.{n}", hs[n], 3) + inverse_sigmoid(reference[n])).sigmoid())
+        classes.append(F.linear(hs[n], sd[f"class_embed.{n}.weight"], sd[f"class_embed.{n}.bias"]))
+    out = {"pred_logits": classes[-1], "pred_boxes": coords[-1],
+           "aux_outputs": [{"pred_logits": a, "pred_boxes": b} for a, b in zip(classes[:-1], coords[:-1])]}
+    t = "transformer."
+    interm_class = F.linear(tr["hs_enc"], sd[t + "enc_out_class_embed.weight"], sd[t + "enc_out_class_embed.bias"])
+    out["interm_outputs"] = {"pred_logits": interm_class, "pred_boxes": tr["ref_enc"]}
+    out["interm_outputs_for_matching_pre"] = {"pred_logits": interm_class, "pred_boxes": tr["init_box_proposal"]}
+    out["dn_meta"] = None
+    if return_debug:
+        out["_debug"] = dict(tr, srcs=srcs, masks=masks, poss=poss, feats=feats)
+    return out
+
+
+# ======================================================================================
+# PostProcess + decoders + metrics
+# ======================================================================================
+def nms(boxes: Tensor, scores: Tensor, iou_threshold: float) -> Tensor:
+    """torchvision.ops.nms (public definition; not under /root/reference -> parity unpinned):
+    greedy, descending score, suppress boxes with IoU > threshold; returns kept indices sorted by
+    descending score.  Called from models/dino/dino.py:1029-1033."""
+    order = torch.argsort(scores, descending=True, stable=True)
+    x1, y1, x2, y2 = boxes.unbind(-1)
+    area = (x2 - x1) * (y2 - y1)
+    keep = []
+    suppressed = torch.zeros(len(boxes), dtype=torch.bool)
+    for i in order.tolist():
+        if suppressed[i]:
+            continue
+        keep.append(i)
+        xx1 = torch.maximum(x1[i], x1)
+        yy1 = torch.maximum(y1[i], y1)
+        xx2 = torch.minimum(x2[i], x2)
+        yy2 = torch.minimum(y2[i], y2)
+        inter = (xx2 - xx1).clamp(min=0) * (yy2 - yy1).clamp(min=0)
+        iou = inter / (area[i] + area - inter)
+        suppressed |= iou > iou_threshold
+    return torch.as_tensor(keep, dtype=torch.long)
+
+
+@torch.no_grad()
+def post_process(outputs, target_sizes: Tensor, num_select: int, nms_iou_threshold: float = -1,
+                 not_to_xyxy: bool = False, test: bool = False) -> List[Dict[str, Tensor]]:
+    """PostProcess.forward (models/dino/dino.py:985-1046)."""
+    out_logits, out_bbox = outputs["pred_logits"], outputs["pred_boxes"]
+    assert len(out_logits) == len(target_sizes)
+    assert target_sizes.shape[1] == 2
+    prob = out_logits.sigmoid()
+    topk_values, topk_indexes = torch.topk(prob.view(out_logits.shape[0], -1), num_select, dim=1)
+    scores = topk_values
+    topk_boxes = topk_indexes // out_logits.shape[2]
+    labels = topk_indexes % out_logits.shape[2]
+    boxes = out_bbox if not_to_xyxy else box_cxcywh_to_xyxy(out_bbox)
+    if test:
+        assert not not_to_xyxy
+        boxes[:, :, 2:] = boxes[:, :, 2:] - boxes[:, :, :2]
+    boxes = torch.gather(boxes, 1, topk_boxes.unsqueeze(-1).repeat(1, 1, 4))
+    img_h, img_w = target_sizes.unbind(1)
+    scale_fct = torch.stack([img_w, img_h, img_w, img_h], dim=1)
+    boxes = boxes * scale_fct[:, None, :]
+    if nms_iou_threshold > 0:
+        idx = [nms(b, s, nms_iou_threshold) for b, s in zip(boxes, scores)]
+        return [{"scores": s[i], "labels": l[i], "boxes": b[i]} for s, l, b, i in zip(scores, labels, boxes, idx)]
+    return [{"scores": s, "labels": l, "boxes": b} for s, l, b in zip(scores, labels, boxes)]
+
+
+@torch.no_grad()
+def decode_nms(outputs, TH: float, NM: float) -> List[List[int]]:
+    """evaluation.convert_output_to_pred, NMS branch (evaluation.py:94-115), applied per sample
+    (the reference runs batch 1): num_select=900 (all queries' top entries), size (1,1),
+    keep score > TH, order by box cx."""
+    res = []
+    B, nq, _ = outputs["pred_logits"].shape
+    for b in range(B):
+        one = {"pred_logits": outputs["pred_logits"][b:b + 1], "pred_boxes": outputs["pred_boxes"][b:b + 1]}
+        o = post_process(one, torch.tensor([[1.0, 1.0]]), num_select=900 if nq >= 900 else nq, nms_iou_threshold=NM)[0]
+        boxes = box_xyxy_to_cxcywh(o["boxes"])
+        sel = o["scores"] > TH
+        order = torch.sort(boxes[sel][:, 0], descending=False)[1]
+        res.append([int(i) for i in o["labels"].long()[sel][order]])
+    return res
+
+
+@torch.no_grad()
+def blank_probabilities(outputs, eps: float) -> Tensor:
+    """Shared front of evaluation.py:116-151 and SetCriterion.loss_CTC (dino.py:466-502):
+    sort queries by cx, sigmoid, build the blank channel.  eps = 0.03/C (evaluation.py:141) or
+    0.003 (dino.py:491)."""
+    logits, boxes = outputs["pred_logits"], outputs["pred_boxes"]
+    _, idx = torch.sort(boxes[:, :, 0])
+    p = torch.gather(logits, 1, idx.unsqueeze(-1).expand(-1, -1, logits.shape[-1])).sigmoid()
+    new = torch.zeros((p.shape[0], p.shape[1], p.shape[2] + 1))
+    new[:, :, 1:] = p
+    mask = p.sum(-1) < 1 - eps
+    new[:, :, 0][mask] = 1 - p[mask].sum(-1)
+    mask = ~mask
+    new[:, :, 0][mask] = eps
+    new[:, :, 1:][mask] = (1 - eps) * p[mask] / p[mask].sum(-1).unsqueeze(-1)
+    return new
+
+
+@torch.no_grad()
+def decode_blank(outputs, eps: Optional[float] = None) -> List[List[int]]:
+    """Blank/argmax decoder: evaluation.py:116-158 (which reads batch index 0 only; applied here to
+    every sample independently) == engine.convert_output_to_pred (engine.py:511-530): argmax over
+    [blank | classes], drop blanks, NO repeat collapse."""
+    C = outputs["pred_logits"].shape[-1]
+    new = blank_probabilities(outputs, 0.03 / C if eps is None else eps)
+    pred = new.max(-1)[1]
+    return [[int(i) - 1 for i in row[row != 0]] for row in pred]
+
+
+def levenshtein(s1, s2) -> int:
+    """evaluation.py:309-326 / engine.py:607-624 (== editdistance.eval, the un-vendored C++ package
+    used at evaluation.py:519,524)."""
+    if len(s1) < len(s2):
+        return levenshtein(s2, s1)
+    if len(s2) == 0:
+        return len(s1)
+    prev = list(range(len(s2) + 1))
+    for i, c1 in enumerate(s1):
+        cur = [i + 1]
+        for j, c2 in enumerate(s2):
+            cur.append(min(prev[j + 1] + 1, cur[j] + 1, prev[j] + (c1 != c2)))
+        prev = cur
+    return prev[-1]
+
+
+def character_error_rate_engine(pred, gt) -> float:
+    """engine.py:594-633 (returns 1 when either side is empty)."""
+    cer = levenshtein(pred, gt) / max(len(gt), 1)
+    if len(gt) == 0 or len(pred) == 0:
+        cer = 1
+    return cer
+
+
+def process_pred_string(s: str) -> str:
+    """evaluation.py:430-450."""
+    s = s.replace("B B C", "BBC")
+    s = s.replace("I T V", "ITV")
+    s = s.replace("  ", " ")
+    s = s.replace(" -", "-")
+    s = s.replace("- ", "-")
+    s = s.replace(" .", ".")
+    s = s.replace(" ,", ",")
+    s = re.sub(r"(\d), (\d)", r"\1,\2", s)
+    s = s.replace(""" '""", "'")
+    s = s.replace("""' """, "'")
+    s = re.sub(r"(?<=\S)€(?=\S)", " € ", s)
+    s = re.sub(r"(?<!\.)\.\.(?!\.)", ".", s)
+    s = s.replace(",,", ",")
+    return s
+
+
+def cumulative_cer(gt_strings: Sequence[str], pred_strings: Sequence[str], normalise: bool = True) -> Tuple[float, List[float]]:
+    """evaluation.py:517-529,547,653-656: running sum(dist)/sum(len) appended per sample; the
+    reported number is the MEAN of that running series (a quirk of the reference)."""
+    dists, lens, series = [], [], []
+    for g, p in zip(gt_strings, pred_strings):
+        if normalise:
+            g, p = process_pred_string(g), process_pred_string(p)
+        dists.append(levenshtein(g, p))
+        lens.append(len(g))
+        series.append(sum(dists) / sum(lens))
+    return (sum(series) / len(series) if series else 0.0), series

@@ -1,0 +1,117 @@
+"""Pin the oracle against the committed golden vectors produced by the REAL reference
+(tests/golden/make_golden.py).  CPU only."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from dtlr_amd.config import DTLRConfig
+from dtlr_amd.synth import noise_lines, stroke_lines
+from dtlr_amd.weights import GENERATOR_VERSION, synthetic_state_dict
+from oracle import dtlr_oracle as O
+from tests.util import c_oracle_msda, msda_inputs
+
+
+def _t(a):
+    return torch.from_numpy(np.asarray(a))
+
+
+def test_g1_msda_reference_unit_test_shape(golden_dir, oracle_clib):
+    """ops/test.py shape (N,M,D=1,2,2; Lq,L,P=2,2,2; shapes (6,4),(3,2)), tolerances of ops/test.py:40,56."""
+    g = np.load(os.path.join(golden_dir, "g1_msda.npz"))
+    v, s, loc, aw = _t(g["a_value"]), _t(g["a_shapes"]), _t(g["a_loc"]), _t(g["a_aw"])
+    lsi = torch.cat((s.new_zeros((1,)), s.prod(1).cumsum(0)[:-1]))
+    o32 = O.ms_deform_attn_core(v, s, loc, aw)
+    assert torch.allclose(o32, _t(g["a_out_f32"]), rtol=1e-2, atol=1e-3)
+    assert (o32 - _t(g["a_out_f32"])).abs().max() < 1e-7
+    o64 = O.ms_deform_attn_core(v.double(), s, loc.double(), aw.double())
+    assert torch.allclose(o64, _t(g["a_out_f64"]))
+    c32 = c_oracle_msda(oracle_clib, v, s, lsi, loc, aw)
+    assert (c32 - _t(g["a_out_f32"])).abs().max() < 1e-7
+    c64 = c_oracle_msda(oracle_clib, v.double(), s, lsi, loc.double(), aw.double())
+    assert torch.allclose(c64, _t(g["a_out_f64"]))
+
+
+def test_g1_msda_out_of_range_locations(golden_dir, oracle_clib):
+    g = np.load(os.path.join(golden_dir, "g1_msda.npz"))
+    shapes = [tuple(x) for x in g["b_shapes"].tolist()]
+    v, s, lsi, loc, aw = msda_inputs(2, 8, 32, 77, 4, shapes, seed=int(g["b_seed"]), lo=-0.5, hi=1.5)
+    ref = _t(g["b_out_f32"])
+    assert (O.ms_deform_attn_core(v, s, loc, aw) - ref).abs().max() < 2e-6
+    assert (c_oracle_msda(oracle_clib, v, s, lsi, loc, aw) - ref).abs().max() < 2e-6
+
+
+def test_g1_msda_encoder_shape(golden_dir, oracle_clib):
+    g = np.load(os.path.join(golden_dir, "g1_msda.npz"))
+    shapes = [tuple(x) for x in g["c_shapes"].tolist()]
+    v, s, lsi, loc, aw = msda_inputs(1, 8, 32, 5440, 4, shapes, seed=int(g["c_seed"]), lo=-0.25, hi=1.25)
+    o = c_oracle_msda(oracle_clib, v, s, lsi, loc, aw)
+    assert (o[0, ::97] - _t(g["c_out_rows"])).abs().max() < 2e-6
+    assert abs(o.double().sum().item() - float(g["c_out_sum"])) < 1e-2
+    assert abs(o.double().abs().sum().item() - float(g["c_out_abs_sum"])) / float(g["c_out_abs_sum"]) < 1e-6
+    o2 = O.ms_deform_attn_core(v, s, loc, aw)
+    assert (o2 - o).abs().max() < 2e-6
+
+
+def test_g2_tiny_model_full_outputs(golden_dir):
+    g = np.load(os.path.join(golden_dir, "g2_tiny_model.npz"))
+    assert int(g["generator_version"]) == GENERATOR_VERSION
+    cfg = DTLRConfig.tiny()
+    sd = synthetic_state_dict(cfg, seed=int(g["weight_seed"]))
+    imgs = stroke_lines(1, 32, 256, seed=5) + noise_lines(1, 32, 192, seed=6)
+    out = O.dino_forward(sd, cfg, imgs, forced_topk=_t(g["topk_idx"]).long(), return_debug=True)
+    d = out["_debug"]
+    assert (d["memory"] - _t(g["memory"])).abs().max() < 1e-4
+    assert (d["topk_scores"] - _t(g["topk_scores"])).abs().max() < 1e-4
+    # free-running selection agrees here (no near ties at this size)
+    free = torch.topk(d["topk_scores"], cfg.num_queries, dim=1)[1]
+    assert torch.equal(free, _t(g["topk_idx"]).long())
+    assert (out["pred_logits"] - _t(g["pred_logits"])).abs().max() < 1e-3        # the north_star tolerance
+    assert (out["pred_logits"] - _t(g["pred_logits"])).abs().max() < 1e-4
+    assert (out["pred_boxes"] - _t(g["pred_boxes"])).abs().max() < 1e-5
+    assert (out["interm_outputs"]["pred_logits"] - _t(g["interm_logits"])).abs().max() < 1e-4
+    assert (out["interm_outputs"]["pred_boxes"] - _t(g["interm_boxes"])).abs().max() < 1e-5
+    assert (out["interm_outputs_for_matching_pre"]["pred_boxes"] - _t(g["init_box_proposal"])).abs().max() < 1e-5
+    aux_l = torch.stack([a["pred_logits"] for a in out["aux_outputs"]])
+    aux_b = torch.stack([a["pred_boxes"] for a in out["aux_outputs"]])
+    assert (aux_l - _t(g["aux_logits"])).abs().max() < 1e-4
+    assert (aux_b - _t(g["aux_boxes"])).abs().max() < 1e-5
+
+
+def test_g2_decoders_on_reference_outputs(golden_dir):
+    """PostProcess / blank construction / NMS applied to the REFERENCE's logits must reproduce the
+    reference's own results exactly (same inputs -> discrete outputs identical)."""
+    g = np.load(os.path.join(golden_dir, "g2_tiny_model.npz"))
+    cfg = DTLRConfig.tiny()
+    ref = {"pred_logits": _t(g["pred_logits"]), "pred_boxes": _t(g["pred_boxes"])}
+    pp = O.post_process(ref, torch.ones(2, 2), cfg.num_select)
+    assert torch.equal(torch.stack([p["labels"] for p in pp]), _t(g["pp_labels"]))
+    assert (torch.stack([p["scores"] for p in pp]) - _t(g["pp_scores"])).abs().max() < 1e-7
+    assert (torch.stack([p["boxes"] for p in pp]) - _t(g["pp_boxes"])).abs().max() < 1e-6
+    probs = O.blank_probabilities(ref, 0.003)
+    assert (probs - _t(g["ctc_probs_eps003"])).abs().max() < 1e-6
+    assert torch.equal(probs.argmax(-1).int(), _t(g["ctc_argmax_eps003"]))
+    for b in range(2):
+        one = {"pred_logits": ref["pred_logits"][b:b + 1], "pred_boxes": ref["pred_boxes"][b:b + 1]}
+        r = O.post_process(one, torch.tensor([[1.0, 1.0]]), cfg.num_queries, 0.5)[0]
+        assert torch.equal(r["labels"].int(), _t(g[f"nms_labels_{b}"]))
+        assert (r["scores"] - _t(g[f"nms_scores_{b}"])).abs().max() < 1e-7
+
+
+@pytest.mark.parametrize("tag", ["latin", "chinese"])
+def test_g3_full_model(golden_dir, tag):
+    g = np.load(os.path.join(golden_dir, f"g3_{tag}.npz"))
+    cfg = DTLRConfig.latin() if tag == "latin" else DTLRConfig.chinese()
+    sd = synthetic_state_dict(cfg, seed=int(g["weight_seed"]))
+    h, widths = int(g["height"]), [int(w) for w in g["widths"]]
+    imgs = stroke_lines(1, h, widths[0], seed=21) + noise_lines(1, h, widths[1], seed=22)
+    topk = _t(g["topk_idx"].astype(np.int64))
+    out = O.dino_forward(sd, cfg, imgs, forced_topk=topk, return_debug=True)
+    d = out["_debug"]
+    assert (d["topk_scores"] - _t(g["topk_scores"])).abs().max() < 1e-4
+    assert (d["memory"][:, ::67] - _t(g["memory_rows"])).abs().max() < 2e-4
+    idx = _t(g["top8_idx"].astype(np.int64))
+    assert (torch.gather(out["pred_logits"], 2, idx) - _t(g["top8_val"])).abs().max() < 1e-3
+    assert (out["pred_logits"].double().sum(-1) - _t(g["logits_rowsum"])).abs().max() < 1e-3 * cfg.num_classes
+    assert (out["pred_boxes"] - _t(g["pred_boxes"])).abs().max() < 1e-5

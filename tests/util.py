@@ -1,0 +1,54 @@
+"""Shared helpers for the tests (test infrastructure; may import the oracle)."""
+import ctypes
+
+import numpy as np
+import torch
+
+
+def msda_inputs(N, M, D, Lq, P, shapes, seed, lo=0.0, hi=1.0, value_scale=1.0, dtype=np.float32):
+    """Same generator as tests/golden/make_golden.py::msda_inputs (numpy PCG64)."""
+    r = np.random.Generator(np.random.PCG64(seed))
+    S = sum(h * w for h, w in shapes)
+    L = len(shapes)
+    value = (r.random((N, S, M, D), dtype=np.float32) * 2 - 1) * value_scale
+    loc = r.uniform(lo, hi, (N, Lq, M, L, P, 2)).astype(np.float32)
+    aw = r.random((N, Lq, M, L, P), dtype=np.float32) + 1e-5
+    aw = (aw / aw.sum((-1, -2), keepdims=True)).astype(np.float32)
+    shp = torch.as_tensor(shapes, dtype=torch.long)
+    lsi = torch.cat((shp.new_zeros((1,)), shp.prod(1).cumsum(0)[:-1]))
+    return (torch.from_numpy(value.astype(dtype)), shp, lsi, torch.from_numpy(loc.astype(dtype)), torch.from_numpy(aw.astype(dtype)))
+
+
+def c_oracle_msda(clib, value, shapes, lsi, loc, attn):
+    """Run oracle/msda_ref.c on CPU tensors."""
+    N, S, M, D = value.shape
+    _, Lq, _, L, P, _ = loc.shape
+    out = torch.empty((N, Lq, M * D), dtype=value.dtype)
+    fn = clib.msda_ref_forward_f64 if value.dtype == torch.float64 else clib.msda_ref_forward_f32
+    fn.restype = ctypes.c_int
+    vp = ctypes.c_void_p
+    rc = fn(vp(value.contiguous().data_ptr()), vp(shapes.contiguous().data_ptr()), vp(lsi.contiguous().data_ptr()),
+            vp(loc.contiguous().data_ptr()), vp(attn.contiguous().data_ptr()),
+            N, S, M, D, L, Lq, P, vp(out.data_ptr()))
+    assert rc == 0
+    return out
+
+
+def selection_is_valid(idx, scores, k, tol):
+    """Tie-aware check of a top-k selection `idx` [B,k] against fp32 `scores` [B,S]: every selected
+    score >= (k-th largest - tol), every unselected <= (k-th largest + tol), order descending within tol."""
+    for b in range(scores.shape[0]):
+        s = scores[b]
+        kth = torch.topk(s, k)[0][-1]
+        sel = s[idx[b].long()]
+        if not bool((sel >= kth - tol).all()):
+            return False
+        m = torch.ones_like(s, dtype=torch.bool)
+        m[idx[b].long()] = False
+        if m.any() and not bool((s[m] <= kth + tol).all()):
+            return False
+        if not bool((sel[:-1] >= sel[1:] - tol).all()):
+            return False
+        if len(set(idx[b].tolist())) != k:
+            return False
+    return True
