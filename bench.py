@@ -1,0 +1,189 @@
+#!/usr/bin/env python3
+"""bench.py -- DTLR inference hot path on MI355X: text-lines/sec on synthetic 128x2048 crops.
+
+    python bench.py --gpus 1 --steps 20 --warmup 3
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
+           --master-port P bench.py --gpus N --steps K --warmup W
+
+A "step" = one pass of the hot path over one batch of 32 synthetic lines per GPU, inputs already
+resident in HBM: DINO forward (backbone -> encoder -> two-stage -> decoder -> heads) + the blank
+decoder producing per-line label records (+ ONE RCCL all-gather of those records when N > 1).
+Workload = BASELINE.json configs[1]: Latin model (C=166), bf16, bs=32, 128x2048, random-init
+name-seeded weights (no checkpoint ships with the reference).  Rank 0 prints ONE JSON line.
+
+roofline     : the deformable-sampling kernel (encoder call: Lq = S = 5440 per line), timed live
+               with HIP events on the launch stream during the timed steps; achieved = algorithmic
+               bytes per launch / mean launch duration (DESIGN.md section "MSDA bytes").
+cpu_baseline : the CPU oracle (oracle/dtlr_oracle.py, a port pinned to the reference through
+               tests/golden) timed on the host cores of this box on a bounded sample (rank 0, N=1).
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+import torch  # noqa: E402
+
+T_START = time.perf_counter()
+
+
+def log(msg: str) -> None:
+    print(f"[bench +{time.perf_counter() - T_START:7.1f}s] {msg}", file=sys.stderr, flush=True)
+
+
+HBM_PEAK_GBS = 8000.0      # MI355X_MICROARCH.md: 8.0 TB/s spec (6.29 TB/s measured copy)
+
+
+def msda_algorithmic_bytes_per_line(S: int, Lq: int, value_elem: int, M=8, D=32, L=4, P=4) -> int:
+    """Compulsory bytes of one MSDA call for one line: read value once,
+    read loc + attn (fp32), write out."""
+    return S * M * D * value_elem + Lq * M * L * P * 2 * 4 + Lq * M * L * P * 4 + Lq * M * D * value_elem
+
+
+def cpu_baseline(n_lines: int, height: int, width: int, repeats: int, threads: int = 0):
+    """Bounded sample (target 10-30 s of CPU work): the oracle forward + blank decode on n_lines
+    synthetic lines, fp32, on `threads` host threads (0 = torch's default = the box's physical cores)."""
+    from dtlr_amd import synth, weights
+    from dtlr_amd.config import DTLRConfig
+    from oracle import dtlr_oracle as O      # the reported CPU baseline (a port); never the product path
+    if threads > 0:
+        torch.set_num_threads(threads)
+    cfg = DTLRConfig.latin()
+    sd = weights.synthetic_state_dict(cfg, seed=0)
+    imgs = synth.noise_lines(n_lines, height, width, seed=123)
+
+    def run():
+        t0 = time.perf_counter()
+        out = O.dino_forward(sd, cfg, imgs)
+        O.decode_blank(out)
+        return time.perf_counter() - t0
+    warm = run()
+    log(f"cpu_baseline warm-up: {warm:.2f}s on {torch.get_num_threads()} threads")
+    ts = []
+    budget = 30.0 - warm
+    for _ in range(repeats):
+        if ts and budget < ts[-1]:
+            break
+        ts.append(run())
+        budget -= ts[-1]
+    ts = sorted(ts) or [warm]
+    med = ts[len(ts) // 2]
+    return {"value": round(n_lines / med, 4), "unit": "lines/s", "cores": torch.get_num_threads(), "kind": "port",
+            "sample": f"{n_lines} synthetic {height}x{width} fp32 lines, oracle forward+decode, 1 warm-up + {len(ts)} timed, median"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--batch", type=int, default=32, help="lines per GPU")
+    ap.add_argument("--height", type=int, default=128)
+    ap.add_argument("--width", type=int, default=2048)
+    ap.add_argument("--dtype", default="bf16", choices=["bf16", "f32"])
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-lines", type=int, default=4)
+    ap.add_argument("--cpu-threads", type=int, default=0, help="0 = torch default (physical cores)")
+    args = ap.parse_args()
+    import faulthandler
+    faulthandler.dump_traceback_later(420, exit=False, file=sys.stderr)      # diagnose hangs on the box
+
+    from dtlr_amd import dist as ddist
+    from dtlr_amd import ops, synth, weights
+    from dtlr_amd.config import DTLRConfig
+    from dtlr_amd.engine import DTLREngine
+    from dtlr_amd.evaluation import decode_blank_records
+
+    rank, local, world = ddist.init_from_env()
+    if world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run")
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X (no CPU path)")
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+    dtype = torch.bfloat16 if args.dtype == "bf16" else torch.float32
+
+    cfg = DTLRConfig.latin()
+    sd = weights.synthetic_state_dict(cfg, seed=0)
+    eng = DTLREngine(cfg, sd, dev, dtype)
+    log(f"engine packed ({args.dtype}), rank {rank}/{world}")
+    B = args.batch
+    imgs = synth.noise_lines(B, args.height, args.width, seed=1000 + rank)     # this rank's shard
+    x = torch.stack(imgs).to(dev)
+    mask = torch.zeros((B, args.height, args.width), dtype=torch.bool, device=dev)
+    n_total = B * world
+
+    def step():
+        out = eng.forward(x, mask, has_padding=False)
+        labels, lengths = decode_blank_records(out)
+        return ddist.all_gather_records(labels, lengths, n_total)
+
+    for i in range(args.warmup):
+        step()
+        torch.cuda.synchronize()
+        log(f"warm-up step {i} done")
+    ops.MSDA_EVENTS = []
+    ddist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        rec = step()
+    torch.cuda.synchronize()
+    ddist.barrier()
+    elapsed = ddist.max_over_ranks(time.perf_counter() - t0, dev)
+    events, ops.MSDA_EVENTS = ops.MSDA_EVENTS, None
+    log(f"timed {args.steps} steps in {elapsed:.3f}s")
+
+    if rank != 0:
+        return
+    S = 5440 * (args.height // 128) * (args.width // 2048) if (args.height, args.width) == (128, 2048) else None
+    enc = [(a.elapsed_time(b), n, lq, s) for (a, b, n, lq, s) in events if lq == s]
+    dec = [(a.elapsed_time(b), n, lq, s) for (a, b, n, lq, s) in events if lq != s]
+    velem = 2 if dtype == torch.bfloat16 else 4
+    roof = None
+    if enc:
+        ms = sum(e[0] for e in enc) / len(enc)
+        n, lq, s = enc[0][1], enc[0][2], enc[0][3]
+        alg = msda_algorithmic_bytes_per_line(s, lq, velem) * n
+        achieved = alg / (ms * 1e-3) / 1e9
+        traffic = None
+        tj = os.path.join(ROOT, "profiles", "msda_traffic.json")
+        if os.path.exists(tj):
+            try:
+                traffic = json.load(open(tj)).get(f"{args.dtype}_enc_bytes_per_launch")
+            except Exception:
+                traffic = None
+        roof = {"bound": "hbm", "kernel": "msda_fwd_l4p4 (encoder call, Lq=S)", "achieved": round(achieved, 1),
+                "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
+                "algorithmic_bytes_per_launch": alg, "mean_launch_ms": round(ms, 4), "launches_timed": len(enc)}
+        if dec:
+            msd = sum(e[0] for e in dec) / len(dec)
+            n, lq, s = dec[0][1], dec[0][2], dec[0][3]
+            algd = msda_algorithmic_bytes_per_line(s, lq, velem) * n
+            roof["decoder_call"] = {"achieved": round(algd / (msd * 1e-3) / 1e9, 1), "mean_launch_ms": round(msd, 4)}
+    line = {
+        "metric": "text-lines/sec (128x2048, bs=32)", "value": round(n_total * args.steps / elapsed, 2), "unit": "lines/s",
+        "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": round(elapsed / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak",
+        "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
+        "config": {"workload": f"Latin DTLR (ResNet-50 + 6/6 deformable DETR, C=166) forward+decode, "
+                               f"{B} synthetic {args.height}x{args.width} lines per GPU, random-init name-seeded weights",
+                   "global_batch": n_total, "parallelism": f"dp{world}",
+                   "library_backed_ops": sorted(ops.LIBRARY_BACKED)},
+        "roofline": roof,
+    }
+    if world == 1 and not args.no_cpu_baseline:
+        line["cpu_baseline"] = cpu_baseline(args.cpu_lines, args.height, args.width, repeats=2, threads=args.cpu_threads)
+        line["speedup_vs_cpu"] = round(line["value"] / line["cpu_baseline"]["value"], 1)
+    print(json.dumps(line), flush=True)
+
+
+if __name__ == "__main__":
+    main()

@@ -25,6 +25,11 @@ _SIGNATURES = {
     "dtlr_abi_version": (c_int, []),
     "dtlr_msda_forward": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
                                   c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p, c_void_p]),
+    "dtlr_msda_fused_forward": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int,
+                                        c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p, c_void_p]),
+    "dtlr_layernorm": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, ctypes.c_long, c_int, c_float, c_int, c_void_p]),
+    "dtlr_mha_forward": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p]),
+    "dtlr_mha_workspace_bytes": (ctypes.c_long, [c_int, c_int, c_int, c_int]),
 }
 
 
@@ -34,6 +39,11 @@ def lib() -> ctypes.CDLL:
         if not os.path.exists(LIB_PATH):
             raise DTLRError(f"{LIB_PATH} not built: run `python -m dtlr_amd.build` (needs hipcc); "
                             "the DTLR HIP path has no CPU/PyTorch fallback")
+        # torch must own the process's HIP runtime: libdtlr_hip.so NEEDs libamdhip64.so.7 and, loaded
+        # first, would pull a second runtime from /opt/rocm beside torch's bundled one (kernels then
+        # launch on a runtime that has no device initialised: hipErrorNoDevice).  Importing torch
+        # first makes the loader resolve our dependency to the copy torch already mapped.
+        import torch  # noqa: F401
         L = ctypes.CDLL(LIB_PATH)
         for name, (res, args) in _SIGNATURES.items():
             fn = getattr(L, name)          # AttributeError if the .so is stale -> loud

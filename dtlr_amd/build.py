@@ -27,7 +27,7 @@ def _fingerprint() -> str:
     h = hashlib.sha256()
     for p in _sources() + sorted(glob.glob(os.path.join(CSRC, "*.h"))) + [os.path.join(HERE, "..", "include", "dtlr_hip.h")]:
         with open(p, "rb") as f:
-            h.update(p.encode() + b"\0" + f.read())
+            h.update(os.path.basename(p).encode() + b"\0" + f.read())   # path-independent: the tree moves on the GPU box
     h.update(" ".join(FLAGS).encode())
     return h.hexdigest()
 

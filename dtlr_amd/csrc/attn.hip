@@ -1,0 +1,171 @@
+// Decoder self-attention over the 900 queries (nn.MultiheadAttention(256, 8), q = k = tgt + query_pos,
+// v = tgt, no masks in eval: models/dino/deformable_transformer.py:847,904-907) as one fused
+// flash-style kernel on the bf16 matrix cores: scores, softmax and P.V never touch HBM
+// (the unfused form writes/reads a [B,8,900,900] fp32 score tensor, 829 MB per layer at B=32).
+//
+// One wavefront owns 32 queries of one (batch, head) and walks the keys in blocks of 32; no LDS, no
+// barriers: every MFMA operand fragment is a plain 16-/8-byte global load (K/V of one (b,h) are
+// 115 KB and L2-resident), and the orientation is chosen so that the accumulator layout of the first
+// MFMA IS the operand layout of the second:
+//     S^T[key, query] = K[key, :] . Q[query, :]^T        mfma_16x16x32 (A = K rows, B = Q rows)
+//        C layout: lane (g = l>>4, n = l&15) holds keys 4g..4g+3 of query n  -> softmax statistics of
+//        query n live in the four lanes {n, n+16, n+32, n+48}: two xor-shuffles per reduction
+//     O^T[d, query]  += V^T[d, key] . P^T[key, query]     mfma_16x16x32 (A = V^T rows, B = P^T)
+//        B operand of lane (g,n) = its own 8 probabilities (two key tiles x 4 regs): zero data movement;
+//        the MFMA k-index <-> key permutation this implies is applied identically to the V^T fragment.
+// V^T ([B, H, 32, Lpad], Lpad = 32-multiple, zero padded) is produced by the V projection.
+#include "dtlr_common.h"
+
+namespace dtlr {
+
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
+typedef __attribute__((ext_vector_type(4))) float f32x4;
+
+__device__ __forceinline__ uint32_t pack2(float a, float b) { return pack_bf16x2(a, b); }
+
+// qk [B, L, 2*C]: q in columns [0, C), k in [C, 2C);  vt [B, H, 32, Lpad];  out [B, L, C];  C = H*32.
+__global__ __launch_bounds__(256) void mha_fwd_bf16_kernel(const uint16_t* __restrict__ qk, const uint16_t* __restrict__ vt,
+                                                           uint16_t* __restrict__ out, int L, int Lpad, int H,
+                                                           float scale_log2e)
+{
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int g = lane >> 4, n = lane & 15;
+    const int h = blockIdx.y, b = blockIdx.z;
+    const int C = H * 32;
+    const int q0 = blockIdx.x * 128 + wave * 32;
+    if (q0 >= L) return;                                   // whole wave: no block-level sync is used
+    const uint16_t* qkb = qk + (long)b * L * (2 * C);
+    bf16x8 qf[2];
+#pragma unroll
+    for (int qt = 0; qt < 2; ++qt) {
+        const int q = min(q0 + qt * 16 + n, L - 1);
+        qf[qt] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const uint4*>(qkb + (long)q * (2 * C) + h * 32 + 8 * g));
+    }
+    const uint16_t* vtb = vt + ((long)(b * H + h) * 32) * Lpad;
+    f32x4 o[2][2];
+#pragma unroll
+    for (int qt = 0; qt < 2; ++qt)
+#pragma unroll
+        for (int dt = 0; dt < 2; ++dt) o[qt][dt] = f32x4{0.f, 0.f, 0.f, 0.f};
+    float m[2] = {-INFINITY, -INFINITY}, lsum[2] = {0.f, 0.f};
+
+    for (int kb = 0; kb < Lpad; kb += 32) {
+        bf16x8 kf[2];
+#pragma unroll
+        for (int kt = 0; kt < 2; ++kt) {
+            const int key = min(kb + kt * 16 + n, L - 1);
+            kf[kt] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const uint4*>(qkb + (long)key * (2 * C) + C + h * 32 + 8 * g));
+        }
+        bf16x8 vf[2];
+#pragma unroll
+        for (int dt = 0; dt < 2; ++dt) {
+            const uint16_t* vr = vtb + (long)(dt * 16 + n) * Lpad + kb + 4 * g;
+            const uint2 lo = *reinterpret_cast<const uint2*>(vr), hi = *reinterpret_cast<const uint2*>(vr + 16);
+            vf[dt] = __builtin_bit_cast(bf16x8, make_uint4(lo.x, lo.y, hi.x, hi.y));
+        }
+#pragma unroll
+        for (int qt = 0; qt < 2; ++qt) {
+            f32x4 s[2];
+#pragma unroll
+            for (int kt = 0; kt < 2; ++kt)
+                s[kt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf[kt], qf[qt], f32x4{0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
+            float mx = -INFINITY;
+#pragma unroll
+            for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int key = kb + kt * 16 + 4 * g + r;
+                    const float v = key < L ? s[kt][r] * scale_log2e : -INFINITY;
+                    s[kt][r] = v;
+                    mx = fmaxf(mx, v);
+                }
+            mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
+            mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+            const float m_new = fmaxf(m[qt], mx);              // finite: every 32-key block has >= 1 valid key
+            const float alpha = __builtin_amdgcn_exp2f(m[qt] - m_new);
+            m[qt] = m_new;
+            float ps = 0.f;
+#pragma unroll
+            for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) { s[kt][r] = __builtin_amdgcn_exp2f(s[kt][r] - m_new); ps += s[kt][r]; }
+            lsum[qt] = lsum[qt] * alpha + ps;
+            const bf16x8 pf = __builtin_bit_cast(bf16x8, make_uint4(pack2(s[0][0], s[0][1]), pack2(s[0][2], s[0][3]),
+                                                                    pack2(s[1][0], s[1][1]), pack2(s[1][2], s[1][3])));
+#pragma unroll
+            for (int dt = 0; dt < 2; ++dt) {
+                o[qt][dt] *= alpha;
+                o[qt][dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vf[dt], pf, o[qt][dt], 0, 0, 0);
+            }
+        }
+    }
+#pragma unroll
+    for (int qt = 0; qt < 2; ++qt) {
+        float l = lsum[qt];
+        l += __shfl_xor(l, 16, 64);
+        l += __shfl_xor(l, 32, 64);
+        const float inv = 1.0f / l;
+        const int q = q0 + qt * 16 + n;
+        if (q < L) {
+#pragma unroll
+            for (int dt = 0; dt < 2; ++dt) {
+                const f32x4 v = o[qt][dt] * inv;
+                *reinterpret_cast<uint2*>(out + ((long)b * L + q) * C + h * 32 + dt * 16 + 4 * g) =
+                    make_uint2(pack2(v[0], v[1]), pack2(v[2], v[3]));
+            }
+        }
+    }
+}
+
+// v [B, L, C] -> vt [B, H, 32, Lpad] (zero padded): the transposed image the attention kernel reads.
+__global__ __launch_bounds__(256) void v_transpose_kernel(const uint16_t* __restrict__ v, uint16_t* __restrict__ vt,
+                                                          int L, int Lpad, int H)
+{
+    // one block per (32-key tile, b): tile [32 keys][C] -> LDS -> [C][32 keys]
+    extern __shared__ __attribute__((aligned(16))) uint16_t tile[];
+    const int C = H * 32;
+    const int k0 = blockIdx.x * 32, b = blockIdx.y;
+    for (int i = threadIdx.x; i < 32 * C / 2; i += blockDim.x) {      // bf16 pairs, coalesced rows
+        const int key = i / (C / 2), c2 = i % (C / 2);
+        uint32_t w = 0;
+        if (k0 + key < L) w = *reinterpret_cast<const uint32_t*>(v + ((long)b * L + k0 + key) * C + 2 * c2);
+        tile[(2 * c2) * 33 + key] = (uint16_t)(w & 0xffffu);          // [c][key] padded to 33
+        tile[(2 * c2 + 1) * 33 + key] = (uint16_t)(w >> 16);
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < C * 32; i += blockDim.x) {
+        const int c = i / 32, key = i % 32;
+        const int hh = c / 32, d = c % 32;
+        vt[((long)(b * H + hh) * 32 + d) * Lpad + k0 + key] = tile[c * 33 + key];
+    }
+}
+
+}  // namespace dtlr
+
+using namespace dtlr;
+
+extern "C" int dtlr_mha_forward(const void* qk, const void* v, void* vt_workspace, void* out,
+                                int B, int L, int H, int head_dim, int dtype, void* stream)
+{
+    if (!qk || !v || !vt_workspace || !out) return DTLR_EINVAL;
+    if (B <= 0 || L <= 0 || H <= 0) return DTLR_EINVAL;
+    if (head_dim != 32) return DTLR_ESHAPE;
+    if (dtype != DTLR_BF16) return DTLR_EDTYPE;
+    hipStream_t st = (hipStream_t)stream;
+    const int Lpad = (L + 31) / 32 * 32;
+    const int C = H * 32;
+    hipLaunchKernelGGL(v_transpose_kernel, dim3(Lpad / 32, B), dim3(256), (size_t)C * 33 * sizeof(uint16_t), st,
+                       (const uint16_t*)v, (uint16_t*)vt_workspace, L, Lpad, H);
+    int rc = check_launch();
+    if (rc) return rc;
+    const float scale_log2e = 1.4426950408889634f / sqrtf((float)head_dim);
+    hipLaunchKernelGGL(mha_fwd_bf16_kernel, dim3((L + 127) / 128, H, B), dim3(256), 0, st,
+                       (const uint16_t*)qk, (const uint16_t*)vt_workspace, (uint16_t*)out, L, Lpad, H, scale_log2e);
+    return check_launch();
+}
+
+extern "C" long dtlr_mha_workspace_bytes(int B, int L, int H, int head_dim)
+{
+    const long Lpad = (L + 31) / 32 * 32;
+    return (long)B * H * head_dim * Lpad * 2;
+}

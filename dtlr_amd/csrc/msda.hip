@@ -173,6 +173,102 @@ __global__ __launch_bounds__(256) void msda_fwd_l4p4_kernel(
     Vec<T, VEC>::store(out + si * D + c0, col);
 }
 
+
+// ---------------------------------------------------------------------------------------------
+// Fused front end of MSDeformAttn.forward (ops/modules/ms_deform_attn.py:97-124) for L=4, P=4:
+// reads the raw projection row ow[b,q,:] = [offsets (M,L,P,2) | logits (M,L*P)] and the reference
+// points, and does softmax(16) + sampling-location arithmetic in registers, so `sampling_locations`
+// and `attention_weights` (1.5 KB per query, written then re-read by the reference) never exist in
+// HBM.  REFD = 2: loc = ref + off / (W_l, H_l) (encoder);  REFD = 4: loc = ref_xy + off / P * ref_wh
+// * 0.5 (decoder) -- same operation order as the reference so fp32 results agree to rounding.
+// ---------------------------------------------------------------------------------------------
+template <typename OT> __device__ __forceinline__ void load_row16(const OT* p, float (&v)[16]);
+template <> __device__ __forceinline__ void load_row16<float>(const float* p, float (&v)[16]) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) { const float4 t = reinterpret_cast<const float4*>(p)[i];
+        v[4 * i] = t.x; v[4 * i + 1] = t.y; v[4 * i + 2] = t.z; v[4 * i + 3] = t.w; }
+}
+template <> __device__ __forceinline__ void load_row16<uint16_t>(const uint16_t* p, float (&v)[16]) {
+#pragma unroll
+    for (int i = 0; i < 2; ++i) { const uint4 t = reinterpret_cast<const uint4*>(p)[i];
+        const uint32_t w[4] = {t.x, t.y, t.z, t.w};
+#pragma unroll
+        for (int j = 0; j < 4; ++j) { v[8 * i + 2 * j] = __uint_as_float(w[j] << 16); v[8 * i + 2 * j + 1] = __uint_as_float(w[j] & 0xffff0000u); } }
+}
+
+template <typename T, typename OT, int VEC, int REFD>
+__global__ __launch_bounds__(256) void msda_fused_l4p4_kernel(
+    const T* __restrict__ value, const int64_t* __restrict__ shapes, const int64_t* __restrict__ lsi,
+    const OT* __restrict__ ow, const float* __restrict__ ref,
+    int S, int M, int D, int Lq, T* __restrict__ out, long total)
+{
+    const long tid = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (tid >= total) return;
+    const int cpv = D / VEC;
+    const int c0 = (int)(tid % cpv) * VEC;
+    const long si = tid / cpv;               // (b*Lq + q)*M + m
+    const int m = (int)(si % M);
+    const long bq = si / M;
+    const int b = (int)(bq / Lq);
+    const int MD = M * D;
+    const OT* row = ow + bq * (long)(M * 48);
+    float off[32], lg[16];
+    load_row16<OT>(row + m * 32, *reinterpret_cast<float (*)[16]>(&off[0]));
+    load_row16<OT>(row + m * 32 + 16, *reinterpret_cast<float (*)[16]>(&off[16]));
+    load_row16<OT>(row + M * 32 + m * 16, lg);
+    float rf[4 * REFD];
+    const float4* rp = reinterpret_cast<const float4*>(ref + bq * (4 * REFD));
+#pragma unroll
+    for (int i = 0; i < REFD; ++i) { const float4 t = rp[i]; rf[4 * i] = t.x; rf[4 * i + 1] = t.y; rf[4 * i + 2] = t.z; rf[4 * i + 3] = t.w; }
+    // softmax over the 16 (level, point) logits of this head (ms_deform_attn.py:99-100)
+    float mx = lg[0];
+#pragma unroll
+    for (int i = 1; i < 16; ++i) mx = fmaxf(mx, lg[i]);
+    float sum = 0.f;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) { lg[i] = expf(lg[i] - mx); sum += lg[i]; }
+    const float inv = 1.0f / sum;
+    const T* vb = value + (long)b * S * MD + m * D + c0;
+    float col[VEC];
+#pragma unroll
+    for (int i = 0; i < VEC; ++i) col[i] = 0.f;
+#pragma unroll
+    for (int l = 0; l < 4; ++l) {
+        const int H = (int)shapes[2 * l], W = (int)shapes[2 * l + 1];
+        const T* base = vb + (long)lsi[l] * MD;
+#pragma unroll
+        for (int p = 0; p < 4; ++p) {
+            const float ox = off[(l * 4 + p) * 2], oy = off[(l * 4 + p) * 2 + 1];
+            float lx, ly;
+            if (REFD == 2) {
+                lx = rf[2 * l] + ox / (float)W;
+                ly = rf[2 * l + 1] + oy / (float)H;
+            } else {
+                lx = rf[4 * l] + ox / 4.0f * rf[4 * l + 2] * 0.5f;
+                ly = rf[4 * l + 1] + oy / 4.0f * rf[4 * l + 3] * 0.5f;
+            }
+            sample_point<T, float, VEC>(base, H, W, MD, lx, ly, lg[l * 4 + p] * inv, col);
+        }
+    }
+    Vec<T, VEC>::store(out + si * D + c0, col);
+}
+
+template <typename T, typename OT, int VEC>
+static int launch_fused(const void* value, const int64_t* shapes, const int64_t* lsi, const void* ow, const float* ref,
+                        int ref_dim, int N, int S, int M, int D, int Lq, void* out, hipStream_t st) {
+    const long total = (long)N * Lq * M * (D / VEC);
+    const int block = 256;
+    const long grid = (total + block - 1) / block;
+    if (grid > 0x7fffffffL) return DTLR_ESHAPE;
+    if (ref_dim == 2)
+        hipLaunchKernelGGL((msda_fused_l4p4_kernel<T, OT, VEC, 2>), dim3((unsigned)grid), dim3(block), 0, st,
+                           (const T*)value, shapes, lsi, (const OT*)ow, ref, S, M, D, Lq, (T*)out, total);
+    else
+        hipLaunchKernelGGL((msda_fused_l4p4_kernel<T, OT, VEC, 4>), dim3((unsigned)grid), dim3(block), 0, st,
+                           (const T*)value, shapes, lsi, (const OT*)ow, ref, S, M, D, Lq, (T*)out, total);
+    return check_launch();
+}
+
 template <typename T, typename LT, typename A, int VEC>
 static int launch_generic(const void* value, const int64_t* shapes, const int64_t* lsi, const void* loc, const void* attn,
                           int N, int S, int M, int D, int L, int Lq, int P, void* out, hipStream_t st) {
@@ -226,6 +322,27 @@ extern "C" int dtlr_msda_forward(const void* value, const int64_t* shapes, const
     default:
         return DTLR_EDTYPE;
     }
+}
+
+extern "C" int dtlr_msda_fused_forward(const void* value, const int64_t* shapes, const int64_t* lsi,
+                                       const void* ow, const float* ref, int ref_dim,
+                                       int N, int S, int M, int D, int L, int Lq, int P,
+                                       int dtype, int ow_dtype, void* out, void* stream)
+{
+    if (!value || !shapes || !lsi || !ow || !ref || !out) return DTLR_EINVAL;
+    if (N <= 0 || S <= 0 || M <= 0 || D <= 0 || Lq <= 0) return DTLR_EINVAL;
+    if (L != 4 || P != 4 || (ref_dim != 2 && ref_dim != 4)) return DTLR_ESHAPE;
+    hipStream_t st = (hipStream_t)stream;
+    if (dtype == DTLR_F32 && D % 4 == 0) {
+        if (ow_dtype == DTLR_F32) return launch_fused<float, float, 4>(value, shapes, lsi, ow, ref, ref_dim, N, S, M, D, Lq, out, st);
+        return DTLR_EDTYPE;
+    }
+    if (dtype == DTLR_BF16 && D % 8 == 0) {
+        if (ow_dtype == DTLR_F32) return launch_fused<uint16_t, float, 8>(value, shapes, lsi, ow, ref, ref_dim, N, S, M, D, Lq, out, st);
+        if (ow_dtype == DTLR_BF16) return launch_fused<uint16_t, uint16_t, 8>(value, shapes, lsi, ow, ref, ref_dim, N, S, M, D, Lq, out, st);
+        return DTLR_EDTYPE;
+    }
+    return (dtype == DTLR_F32 || dtype == DTLR_BF16) ? DTLR_ESHAPE : DTLR_EDTYPE;
 }
 
 extern "C" const char* dtlr_strerror(int code) {

@@ -26,8 +26,11 @@ from .ms_deform_attn import MSDeformAttn
 
 # ------------------------------------------------------------------------------- util/misc.py
 class NestedTensor(object):
-    def __init__(self, tensors, mask: Optional[torch.Tensor]):
+    def __init__(self, tensors, mask: Optional[torch.Tensor], has_padding: bool = True):
         self.tensors, self.mask = tensors, mask
+        # host-side knowledge that mask is all-False lets the engine skip the value masked_fill
+        # (ms_deform_attn.py:95-96) without a device sync; True = unknown / padded
+        self.has_padding = has_padding
 
     def to(self, device):
         return NestedTensor(self.tensors.to(device), None if self.mask is None else self.mask.to(device))
@@ -48,7 +51,7 @@ def nested_tensor_from_tensor_list(tensor_list) -> NestedTensor:
         if tensor_list.ndim != 4:
             raise ValueError("not supported")
         b, c, h, w = tensor_list.shape
-        return NestedTensor(tensor_list, torch.zeros((b, h, w), dtype=torch.bool, device=tensor_list.device))
+        return NestedTensor(tensor_list, torch.zeros((b, h, w), dtype=torch.bool, device=tensor_list.device), has_padding=False)
     if tensor_list[0].ndim != 3:
         raise ValueError("not supported")
     c = tensor_list[0].shape[0]
@@ -60,7 +63,8 @@ def nested_tensor_from_tensor_list(tensor_list) -> NestedTensor:
     for i, img in enumerate(tensor_list):
         tensor[i, :, : img.shape[1], : img.shape[2]].copy_(img)
         mask[i, : img.shape[1], : img.shape[2]] = False
-    return NestedTensor(tensor, mask)
+    padded = any(tuple(t.shape[1:]) != (h, w) for t in tensor_list)
+    return NestedTensor(tensor, mask, has_padding=padded)
 
 
 # ------------------------------------------------------------------- parameter containers
@@ -240,7 +244,8 @@ class DINO(nn.Module):
         eng = self.engine()
         x, mask = samples.decompose()
         ops.require_cuda(x, "samples")
-        out = eng.forward(x.float(), mask, forced_topk=forced_topk, want_aux=self.return_aux, return_debug=return_debug)
+        out = eng.forward(x.float(), mask, forced_topk=forced_topk, want_aux=self.return_aux, return_debug=return_debug,
+                          has_padding=getattr(samples, "has_padding", True))
         if not self.return_aux:
             out["aux_outputs"] = []
         return out

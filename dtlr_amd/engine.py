@@ -136,8 +136,8 @@ class DTLREngine:
     def _lin(self, name, x, relu=False, residual=None):
         return ops.linear(x, self.w[name + ".w"], self.w[name + ".b"], relu, residual)
 
-    def _ln(self, name, x):
-        return ops.layernorm(x, self.w[name + ".w"], self.w[name + ".b"])
+    def _ln(self, name, x, residual=None):
+        return ops.layernorm(x, self.w[name + ".w"], self.w[name + ".b"], 1e-5, residual)
 
     def backbone(self, x_nhwc) -> List[torch.Tensor]:
         """torchvision resnet50 (v1.5) body with FrozenBN folded; returns layer2/3/4 maps, NHWC
@@ -186,7 +186,7 @@ class DTLREngine:
         py = torch.stack((py[..., 0::2].sin(), py[..., 1::2].cos()), dim=4).flatten(3)
         return torch.cat((py, px), dim=3).flatten(1, 2)              # already NHWC -> tokens
 
-    def _geometry(self, mask, level_hw):
+    def _geometry(self, mask, level_hw, has_padding=True):
         """Everything that depends only on the padding masks (computed once per forward):
         per-level masks, pos+level embeds, valid ratios, encoder reference points, proposals."""
         cfg, dev = self.cfg, mask.device
@@ -225,7 +225,7 @@ class DTLREngine:
         shapes = torch.as_tensor(level_hw, dtype=torch.long, device=dev)
         lsi = torch.cat((shapes.new_zeros((1,)), shapes.prod(1).cumsum(0)[:-1]))
         return dict(masks=masks, pos=pos, mask_flat=mask_flat, valid_ratios=vr, enc_ref=ref.contiguous(),
-                    proposals=prop, keep=keep, shapes=shapes, lsi=lsi)
+                    proposals=prop, keep=keep, shapes=shapes, lsi=lsi, has_padding=has_padding)
 
     def _msda_module(self, name, query, ref, value_src, g, n_points):
         """MSDeformAttn.forward (ops/modules/ms_deform_attn.py:78-126) without the output
@@ -235,8 +235,12 @@ class DTLREngine:
         S = value_src.shape[1]
         M, L, P = cfg.nheads, cfg.num_feature_levels, n_points
         value = self._lin(name + ".value", value_src)
-        value = value.masked_fill(g["mask_flat"][..., None], 0.0)
-        ow = self._lin(name + ".ow", query).float()
+        if g["has_padding"]:
+            value = value.masked_fill(g["mask_flat"][..., None], 0.0)
+        ow = self._lin(name + ".ow", query)
+        if L == 4 and P == 4:
+            return ops.msda_fused(value.view(B, S, M, C // M), g["shapes"], g["lsi"], ow, ref)
+        ow = ow.float()
         off = ow[..., : M * L * P * 2].reshape(B, Lq, M, L, P, 2)
         aw = torch.softmax(ow[..., M * L * P * 2:].reshape(B, Lq, M, L * P), -1).reshape(B, Lq, M, L, P)
         if ref.shape[-1] == 2:
@@ -253,9 +257,9 @@ class DTLREngine:
         for n in range(self.cfg.enc_layers):
             q = f"enc{n}."
             a = self._msda_module(q + "attn", src + pos, g["enc_ref"], src, g, self.cfg.enc_n_points)
-            src = self._ln(q + "norm1", self._lin(q + "attn.out", a, residual=src))
+            src = self._ln(q + "norm1", self._lin(q + "attn.out", a), residual=src)
             h = self._lin(q + "ff1", src, relu=True)
-            src = self._ln(q + "norm2", self._lin(q + "ff2", h, residual=src))
+            src = self._ln(q + "norm2", self._lin(q + "ff2", h), residual=src)
         return src
 
     def two_stage(self, memory, g, forced_topk=None):
@@ -311,15 +315,14 @@ class DTLREngine:
             # self attention (q = k = tgt + query_pos, v = tgt)
             qk = self._lin(q + "sa.qk", tgt + qpos)
             v = self._lin(q + "sa.v", tgt)
-            C = cfg.hidden_dim
-            a = ops.mha(qk[..., :C], qk[..., C:], v, cfg.nheads)
-            tgt = self._ln(q + "norm2", self._lin(q + "sa.out", a, residual=tgt))
+            a = ops.mha(qk, v, cfg.nheads)
+            tgt = self._ln(q + "norm2", self._lin(q + "sa.out", a), residual=tgt)
             # deformable cross attention
             a = self._msda_module(q + "attn", tgt + qpos, ref_in, memory, g, cfg.dec_n_points)
-            tgt = self._ln(q + "norm1", self._lin(q + "attn.out", a, residual=tgt))
+            tgt = self._ln(q + "norm1", self._lin(q + "attn.out", a), residual=tgt)
             # ffn
             h = self._lin(q + "ff1", tgt, relu=True)
-            tgt = self._ln(q + "norm3", self._lin(q + "ff2", h, residual=tgt))
+            tgt = self._ln(q + "norm3", self._lin(q + "ff2", h), residual=tgt)
             # iterative box refinement (734-756)
             ref = (self._bbox_head(tgt) + self._inverse_sigmoid(ref)).sigmoid()
             refs.append(ref)
@@ -332,7 +335,7 @@ class DTLREngine:
     # ------------------------------------------------------------------------------ forward
     @torch.no_grad()
     def forward(self, x: torch.Tensor, mask: torch.Tensor, forced_topk: Optional[torch.Tensor] = None,
-                want_aux: bool = False, return_debug: bool = False) -> Dict[str, torch.Tensor]:
+                want_aux: bool = False, return_debug: bool = False, has_padding: bool = True) -> Dict[str, torch.Tensor]:
         """x [B,3,H,W] fp32 (zero-padded), mask [B,H,W] bool (True = padding)  ->  DINO.forward's
         dict (models/dino/dino.py:270-415): pred_logits [B,nq,C] raw, pred_boxes [B,nq,4] cxcywh."""
         ops.require_cuda(x, "images")
@@ -343,7 +346,7 @@ class DTLREngine:
         level_hw = [(f.shape[1], f.shape[2]) for f in feats]
         last = self._conv(f"ip{len(feats)}", feats[-1], 2, 1)
         level_hw.append((last.shape[1], last.shape[2]))
-        g = self._geometry(mask, level_hw)
+        g = self._geometry(mask, level_hw, has_padding)
         srcs = []
         for l, f in enumerate(feats):
             t = self._lin(f"ip{l}", f.flatten(1, 2))

@@ -18,7 +18,9 @@ from . import MultiScaleDeformableAttention as _msda
 from . import _lib
 
 # operators still served by ROCm libraries via torch (shrinks as kernels land)
-LIBRARY_BACKED = {"linear", "conv2d_nhwc", "maxpool_nhwc", "groupnorm_tokens", "layernorm", "mha", "topk", "sort"}
+LIBRARY_BACKED = {"linear", "conv2d_nhwc", "maxpool_nhwc", "groupnorm_tokens", "mha", "topk", "sort"}
+
+_DT = {torch.float32: _lib.DTLR_F32, torch.bfloat16: _lib.DTLR_BF16, torch.float64: _lib.DTLR_F64}
 
 
 def require_cuda(t: torch.Tensor, what: str = "input") -> None:
@@ -38,8 +40,20 @@ def linear(x, w, b=None, relu: bool = False, residual=None):
     return y
 
 
-def layernorm(x, w, b, eps: float = 1e-5):
-    return F.layer_norm(x.float(), (x.shape[-1],), w.float(), b.float(), eps).to(x.dtype)
+def layernorm(x, w, b, eps: float = 1e-5, residual=None):
+    """LayerNorm(x [+ residual]) over the last dim (HIP kernel: one wavefront per row, fp32 stats).
+    x/residual [..., C] fp32 or bf16, contiguous; w, b [C] fp32."""
+    C = x.shape[-1]
+    if not x.is_contiguous():
+        x = x.contiguous()
+    if residual is not None and not residual.is_contiguous():
+        residual = residual.contiguous()
+    y = torch.empty_like(x)
+    rows = x.numel() // C
+    code = _lib.lib().dtlr_layernorm(x.data_ptr(), 0 if residual is None else residual.data_ptr(), w.data_ptr(), b.data_ptr(),
+                                     y.data_ptr(), rows, C, eps, _DT[x.dtype], _lib.current_stream())
+    _lib.check(code, "dtlr_layernorm")
+    return y
 
 
 def conv2d_nhwc(x, w_oihw_cl, bias, stride: int, padding: int, relu: bool = False, residual=None):
@@ -70,20 +84,70 @@ def groupnorm_tokens(x, groups: int, w, b, eps: float = 1e-5):
     return y.to(x.dtype)
 
 
+# bench.py sets this to a list to time every MSDA launch with HIP events recorded on the launch
+# stream: entries are (start_event, end_event, N, Lq, S).
+MSDA_EVENTS = None
+
+
 def msda(value, spatial_shapes, level_start_index, loc, attn):
     """value [N,S,M,D]; loc [N,Lq,M,L,P,2] f32; attn [N,Lq,M,L,P] f32 -> [N,Lq,M*D] (HIP kernel)."""
-    return _msda.ms_deform_attn_forward(value, spatial_shapes, level_start_index, loc, attn, 64)
+    if MSDA_EVENTS is None:
+        return _msda.ms_deform_attn_forward(value, spatial_shapes, level_start_index, loc, attn, 64)
+    st = torch.cuda.current_stream()
+    a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    a.record(st)
+    out = _msda.ms_deform_attn_forward(value, spatial_shapes, level_start_index, loc, attn, 64)
+    b.record(st)
+    MSDA_EVENTS.append((a, b, value.shape[0], loc.shape[1], value.shape[1]))
+    return out
 
 
-def mha(q, k, v, n_heads: int):
-    """q,k,v [B, L, C] already projected; softmax(q k^T / sqrt(d)) v per head -> [B, L, C]."""
-    B, L, C = q.shape
+def msda_fused(value, spatial_shapes, level_start_index, ow, ref):
+    """MSDeformAttn front end fused into the sampling kernel (L=4, P=4): value [N,S,M,D] (fp32/bf16),
+    ow [N,Lq,M*48] raw [offsets|logits] projection (fp32, or bf16 with bf16 value),
+    ref [N,Lq,L,2|4] fp32 -> [N,Lq,M*D]."""
+    N, S, M, D = value.shape
+    Lq = ow.shape[1]
+    L = spatial_shapes.shape[0]
+    assert ow.shape[2] == M * L * 4 * 3 and ref.dtype == torch.float32 and ref.shape[:3] == (N, Lq, L)
+    assert value.is_contiguous() and ow.is_contiguous() and ref.is_contiguous()
+    out = torch.empty((N, Lq, M * D), dtype=value.dtype, device=value.device)
+    ev = MSDA_EVENTS
+    if ev is not None:
+        st = torch.cuda.current_stream()
+        a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        a.record(st)
+    code = _lib.lib().dtlr_msda_fused_forward(value.data_ptr(), spatial_shapes.data_ptr(), level_start_index.data_ptr(),
+                                              ow.data_ptr(), ref.data_ptr(), ref.shape[-1], N, S, M, D, L, Lq, 4,
+                                              _DT[value.dtype], _DT[ow.dtype], out.data_ptr(), _lib.current_stream())
+    _lib.check(code, "dtlr_msda_fused_forward")
+    if ev is not None:
+        b.record(st)
+        ev.append((a, b, N, Lq, S))
+    return out
+
+
+def mha(qk, v, n_heads: int):
+    """Self-attention core.  qk [B, L, 2C] (projected q | k), v [B, L, C] -> [B, L, C].
+    bf16: fused flash-style HIP kernel on the matrix cores (scores never leave the chip).
+    fp32 (parity path): rocBLAS batched GEMMs + softmax through torch."""
+    B, L, C2 = qk.shape
+    C = C2 // 2
     hd = C // n_heads
-    qh = q.view(B, L, n_heads, hd).transpose(1, 2)
-    kh = k.view(B, L, n_heads, hd).transpose(1, 2)
+    if qk.dtype == torch.bfloat16 and hd == 32:
+        qk, v = qk.contiguous(), v.contiguous()
+        L_ = _lib.lib()
+        ws = torch.empty(L_.dtlr_mha_workspace_bytes(B, L, n_heads, hd), dtype=torch.uint8, device=qk.device)
+        out = torch.empty((B, L, C), dtype=qk.dtype, device=qk.device)
+        code = L_.dtlr_mha_forward(qk.data_ptr(), v.data_ptr(), ws.data_ptr(), out.data_ptr(), B, L, n_heads, hd,
+                                   _lib.DTLR_BF16, _lib.current_stream())
+        _lib.check(code, "dtlr_mha_forward")
+        return out
+    qh = qk[..., :C].reshape(B, L, n_heads, hd).transpose(1, 2)
+    kh = qk[..., C:].reshape(B, L, n_heads, hd).transpose(1, 2)
     vh = v.view(B, L, n_heads, hd).transpose(1, 2)
     att = torch.softmax((qh.float() * (1.0 / math.sqrt(hd))) @ kh.float().transpose(-1, -2), dim=-1)
-    o = (att @ vh.float()).to(q.dtype)
+    o = (att @ vh.float()).to(qk.dtype)
     return o.transpose(1, 2).reshape(B, L, C)
 
 

@@ -53,6 +53,46 @@ int dtlr_msda_forward(const void *value, const int64_t *shapes, const int64_t *l
                       int N, int S, int M, int D, int L, int Lq, int P,
                       int dtype, void *out, void *stream);
 
+/* ---------------------------------------------------------------------------------------------
+ * MSDeformAttn.forward front end fused into the sampling kernel (L = 4 levels, P = 4 points).
+ * Replaces: ops/modules/ms_deform_attn.py:97-124 -- `sampling_offsets`/`attention_weights` views,
+ *           F.softmax over the 16 (level,point) logits per head, the sampling-location arithmetic
+ *           (102-105 for 2-d reference points, 106-108 for 4-d boxes) and MSDeformAttnFunction.apply.
+ *   ow   [N,Lq, M*L*P*2 + M*L*P]  the fused projection row: offsets (M,L,P,2) then logits (M,L*P);
+ *                                 ow_dtype F32 or BF16
+ *   ref  [N,Lq,L,ref_dim] fp32    ref_dim 2: (x,y) per level;  4: (cx,cy,w,h) per level
+ *   value/out as dtlr_msda_forward (dtype F32 or BF16).
+ */
+int dtlr_msda_fused_forward(const void *value, const int64_t *shapes, const int64_t *level_start_index,
+                            const void *ow, const float *ref, int ref_dim,
+                            int N, int S, int M, int D, int L, int Lq, int P,
+                            int dtype, int ow_dtype, void *out, void *stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * y = LayerNorm(x [+ residual]) * gamma + beta over rows of C channels (C multiple of 256).
+ * Replaces: the `src = norm(src + dropout(src2))` post-norm pattern of
+ *           DeformableTransformerEncoderLayer / DecoderLayer (deformable_transformer.py:804-823,
+ *           876-959; nn.LayerNorm eps 1e-5, dropout 0) and TransformerDecoder.norm (:758).
+ *   x, residual (may be NULL), y: [rows, C] dtype (F32 or BF16); gamma, beta: [C] fp32.
+ */
+int dtlr_layernorm(const void *x, const void *residual, const float *gamma, const float *beta,
+                   void *y, long rows, int C, float eps, int dtype, void *stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * Multi-head self-attention over the decoder queries, fused (scores/softmax/PV stay on chip).
+ * Replaces: nn.MultiheadAttention(256, 8, dropout=0)(q, k, v)[0] minus its in/out projections, as
+ *           called from DeformableTransformerDecoderLayer.forward_sa
+ *           (models/dino/deformable_transformer.py:847,904-907): softmax(q k^T / sqrt(head_dim)) v
+ *           per head, no masks (eval).
+ *   qk  [B, L, 2*H*head_dim]  projected q (first half of the row) and k (second half);  dtype
+ *   v   [B, L, H*head_dim]    projected v;  dtype
+ *   vt_workspace              >= dtlr_mha_workspace_bytes(B, L, H, head_dim) bytes of scratch
+ *   out [B, L, H*head_dim]    dtype.   head_dim must be 32; dtype BF16 (fp32 accumulate/softmax).
+ */
+int dtlr_mha_forward(const void *qk, const void *v, void *vt_workspace, void *out,
+                     int B, int L, int H, int head_dim, int dtype, void *stream);
+long dtlr_mha_workspace_bytes(int B, int L, int H, int head_dim);
+
 #ifdef __cplusplus
 }
 #endif

@@ -1,0 +1,107 @@
+"""Numerics of the individual gfx950 kernels against plain fp32 CPU references of the same op."""
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+from tests.util import msda_inputs
+
+pytestmark = pytest.mark.gpu
+
+
+def _rand(shape, seed, scale=1.0):
+    return torch.from_numpy((np.random.Generator(np.random.PCG64(seed)).standard_normal(shape) * scale).astype(np.float32))
+
+
+@pytest.mark.parametrize("C", [256, 512, 2048])
+@pytest.mark.parametrize("with_res", [False, True])
+def test_layernorm_f32(C, with_res):
+    from dtlr_amd import ops
+    x, r = _rand((3, 37, C), 1, 2.0) + 0.5, _rand((3, 37, C), 2)
+    w, b = _rand((C,), 3) * 0.2 + 1.0, _rand((C,), 4) * 0.1
+    want = F.layer_norm(x + r if with_res else x, (C,), w, b, 1e-5)
+    got = ops.layernorm(x.cuda(), w.cuda(), b.cuda(), 1e-5, r.cuda() if with_res else None).cpu()
+    assert (got - want).abs().max() < 5e-6
+
+
+def test_layernorm_bf16_and_ragged_rows():
+    from dtlr_amd import ops
+    C = 256
+    for rows in (1, 3, 4, 5, 1023):
+        x, r = _rand((rows, C), rows, 2.0).bfloat16(), _rand((rows, C), rows + 1).bfloat16()
+        w, b = _rand((C,), 3) * 0.2 + 1.0, _rand((C,), 4) * 0.1
+        want = F.layer_norm(x.float() + r.float(), (C,), w, b, 1e-5)
+        got = ops.layernorm(x.cuda(), w.cuda(), b.cuda(), 1e-5, r.cuda()).cpu()
+        assert got.dtype == torch.bfloat16 and got.shape == x.shape
+        assert (got.float() - want).abs().max() < 0.03       # one bf16 ulp at |y| <= 4
+
+
+@pytest.mark.parametrize("ref_dim", [2, 4])
+def test_msda_fused_front_end_vs_oracle(ref_dim):
+    """dtlr_msda_fused_forward == MSDeformAttn.forward lines 97-124 (softmax, locations, sampling)."""
+    from dtlr_amd import ops
+    from oracle import dtlr_oracle as O
+    shapes = [(16, 256), (8, 128), (4, 64), (2, 32)]
+    N, M, D, Lq, L, P = 2, 8, 32, 211, 4, 4
+    v, s, lsi, _, _ = msda_inputs(N, M, D, Lq, P, shapes, seed=3)
+    ow = _rand((N, Lq, M * L * P * 3), 5)
+    ow[..., : M * L * P * 2] *= 3.0                                        # offsets of a few pixels
+    g = np.random.Generator(np.random.PCG64(9))
+    if ref_dim == 2:
+        ref = torch.from_numpy(g.uniform(-0.05, 1.05, (N, Lq, L, 2)).astype(np.float32))
+    else:
+        ref = torch.from_numpy(np.concatenate([g.uniform(0, 1, (N, Lq, L, 2)), g.uniform(0.01, 0.4, (N, Lq, L, 2))], -1).astype(np.float32))
+    off = ow[..., : M * L * P * 2].view(N, Lq, M, L, P, 2)
+    aw = torch.softmax(ow[..., M * L * P * 2:].view(N, Lq, M, L * P), -1).view(N, Lq, M, L, P)
+    loc = O.msda_sampling_locations(ref, off, s, P)
+    want = O.ms_deform_attn_core(v, s, loc, aw)
+    got = ops.msda_fused(v.cuda(), s.cuda(), lsi.cuda(), ow.cuda(), ref.cuda()).cpu()
+    assert (got - want).abs().max() < 5e-6
+    # bf16 value (+ fp32 or bf16 projection row)
+    gotb = ops.msda_fused(v.bfloat16().cuda(), s.cuda(), lsi.cuda(), ow.cuda(), ref.cuda()).cpu()
+    wantb = O.ms_deform_attn_core(v.bfloat16().float(), s, loc, aw)
+    assert (gotb.float() - wantb).abs().max() <= wantb.abs().max() * 2 ** -8 + 1e-6
+    gotbb = ops.msda_fused(v.bfloat16().cuda(), s.cuda(), lsi.cuda(), ow.bfloat16().cuda(), ref.cuda()).cpu()
+    owb = ow.bfloat16().float()
+    offb = owb[..., : M * L * P * 2].view(N, Lq, M, L, P, 2)
+    awb = torch.softmax(owb[..., M * L * P * 2:].view(N, Lq, M, L * P), -1).view(N, Lq, M, L, P)
+    wantbb = O.ms_deform_attn_core(v.bfloat16().float(), s, O.msda_sampling_locations(ref, offb, s, P), awb)
+    assert (gotbb.float() - wantbb).abs().max() <= wantbb.abs().max() * 2 ** -8 + 1e-5
+
+
+@pytest.mark.parametrize("B,L", [(2, 900), (1, 37), (3, 128), (1, 1)])
+def test_mha_bf16_vs_fp32_reference(B, L):
+    """Fused attention kernel vs plain fp32 softmax(QK^T/sqrt(d))V on the same bf16-rounded inputs.
+    Tolerance: P and O are rounded to bf16 (2^-8 relative) -> |err| <= 2^-6 * max|v|."""
+    import math
+    from dtlr_amd import ops
+    H, hd = 8, 32
+    C = H * hd
+    qk = (_rand((B, L, 2 * C), 11) * 1.5).bfloat16()
+    v = _rand((B, L, C), 12).bfloat16()
+    q = qk[..., :C].float().view(B, L, H, hd).transpose(1, 2)
+    k = qk[..., C:].float().view(B, L, H, hd).transpose(1, 2)
+    vv = v.float().view(B, L, H, hd).transpose(1, 2)
+    want = (torch.softmax(q @ k.transpose(-1, -2) / math.sqrt(hd), -1) @ vv).transpose(1, 2).reshape(B, L, C)
+    got = ops.mha(qk.cuda(), v.cuda(), H).float().cpu()
+    assert got.shape == want.shape
+    assert (got - want).abs().max() <= 2 ** -6 * v.float().abs().max() + 1e-3, (got - want).abs().max()
+
+
+def test_mha_softmax_extremes():
+    """Large score spread (online-softmax rescale path) and a dominant key."""
+    import math
+    from dtlr_amd import ops
+    B, L, H, hd = 1, 200, 8, 32
+    C = H * hd
+    qk = (_rand((B, L, 2 * C), 21) * 4.0)
+    qk[:, 150, C:] *= 6.0                       # one key with huge scores late in the sequence
+    qk = qk.bfloat16()
+    v = _rand((B, L, C), 22).bfloat16()
+    q = qk[..., :C].float().view(B, L, H, hd).transpose(1, 2)
+    k = qk[..., C:].float().view(B, L, H, hd).transpose(1, 2)
+    vv = v.float().view(B, L, H, hd).transpose(1, 2)
+    want = (torch.softmax(q @ k.transpose(-1, -2) / math.sqrt(hd), -1) @ vv).transpose(1, 2).reshape(B, L, C)
+    got = ops.mha(qk.cuda(), v.cuda(), H).float().cpu()
+    assert torch.isfinite(got).all()
+    assert (got - want).abs().max() <= 2 ** -6 * v.float().abs().max() + 1e-3

@@ -1,0 +1,107 @@
+#!/usr/bin/env python3
+"""Standalone launches of the hand-written kernels at the bench shapes (B=32, 128x2048), for
+rocprofv3 (--kernel-trace --stats, or --pmc FETCH_SIZE / WRITE_SIZE in their own passes) and for
+HIP-event timing.  Prints one JSON line per kernel with the mean launch time and achieved GB/s.
+
+    python tools/profile_kernels.py [--iters 20] [--only msda_enc_bf16,...]
+A 1 GiB torch device-to-device copy is launched first as the byte-count calibration for the
+FETCH_SIZE / WRITE_SIZE counters (MI355X_MICROARCH.md section HBM).
+"""
+import argparse
+import json
+import os
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import numpy as np  # noqa: E402
+import torch  # noqa: E402
+
+from dtlr_amd import ops  # noqa: E402
+
+
+def timeit(fn, iters):
+    for _ in range(3):
+        fn()
+    torch.cuda.synchronize()
+    a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    a.record()
+    for _ in range(iters):
+        fn()
+    b.record()
+    torch.cuda.synchronize()
+    return a.elapsed_time(b) / iters
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--iters", type=int, default=20)
+    ap.add_argument("--only", default="")
+    ap.add_argument("--batch", type=int, default=32)
+    args = ap.parse_args()
+    only = set(filter(None, args.only.split(",")))
+    dev = torch.device("cuda:0")
+    B, M, D, L, P = args.batch, 8, 32, 4, 4
+    shapes_l = [(16, 256), (8, 128), (4, 64), (2, 32)]
+    S = sum(h * w for h, w in shapes_l)
+    shapes = torch.as_tensor(shapes_l, dtype=torch.long, device=dev)
+    lsi = torch.cat((shapes.new_zeros((1,)), shapes.prod(1).cumsum(0)[:-1]))
+    g = torch.Generator(device="cpu").manual_seed(0)
+    res = []
+
+    def want(name):
+        return not only or name in only
+
+    if want("calib_copy"):
+        src = torch.empty(1 << 30, dtype=torch.uint8, device=dev).random_()
+        dst = torch.empty_like(src)
+        ms = timeit(lambda: dst.copy_(src), 5)
+        res.append({"kernel": "calib_copy_1GiB", "ms": ms, "bytes_read": 1 << 30, "bytes_written": 1 << 30, "GBps": 2 * (1 << 30) / ms / 1e6})
+        del src, dst
+
+    for dt_name, dt in (("f32", torch.float32), ("bf16", torch.bfloat16)):
+        velem = 4 if dt == torch.float32 else 2
+        value = (torch.rand((B, S, M, D), generator=g) * 2 - 1).to(dev).to(dt)
+        for tag, Lq in (("enc", S), ("dec", 900)):
+            # realistic encoder-like locations: reference grid + a few pixels of offset
+            ow = torch.randn((B, Lq, M * L * P * 3), generator=g).to(dev)
+            ow[..., : M * L * P * 2] *= 2.0
+            ref2 = torch.rand((B, Lq, L, 2), generator=g).to(dev)
+            ref4 = torch.cat([ref2, torch.full_like(ref2, 0.05)], -1).contiguous()
+            off = ow[..., : M * L * P * 2].view(B, Lq, M, L, P, 2)
+            norm = torch.stack([shapes[:, 1], shapes[:, 0]], -1).float()
+            loc = (ref2[:, :, None, :, None, :] + off / norm[None, None, None, :, None, :]).contiguous()
+            aw = torch.softmax(ow[..., M * L * P * 2:].view(B, Lq, M, L * P), -1).view(B, Lq, M, L, P).contiguous()
+            alg = B * (S * M * D * velem + Lq * M * L * P * 3 * 4 + Lq * M * D * velem)
+            name = f"msda_{tag}_{dt_name}"
+            if want(name):
+                ms = timeit(lambda: ops.msda(value, shapes, lsi, loc, aw), args.iters)
+                res.append({"kernel": name, "ms": ms, "algorithmic_bytes": alg, "GBps": alg / ms / 1e6})
+            name = f"msda_fused_{tag}_{dt_name}"
+            if want(name):
+                r = ref2 if tag == "enc" else ref4
+                ms = timeit(lambda: ops.msda_fused(value, shapes, lsi, ow, r), args.iters)
+                res.append({"kernel": name, "ms": ms, "algorithmic_bytes": alg, "GBps": alg / ms / 1e6})
+            del ow, loc, aw, off
+        T = B * S
+        x = torch.randn((T, 256), generator=g).to(dev).to(dt)
+        r = torch.randn((T, 256), generator=g).to(dev).to(dt)
+        w, b = torch.ones(256, device=dev), torch.zeros(256, device=dev)
+        name = f"layernorm_res_{dt_name}"
+        if want(name):
+            ms = timeit(lambda: ops.layernorm(x, w, b, 1e-5, r), args.iters)
+            alg = 3 * T * 256 * velem
+            res.append({"kernel": name, "ms": ms, "algorithmic_bytes": alg, "GBps": alg / ms / 1e6})
+        del x, r, value
+    if want("mha_bf16"):
+        qk = torch.randn((B, 900, 512), generator=g).to(dev).bfloat16()
+        v = torch.randn((B, 900, 256), generator=g).to(dev).bfloat16()
+        ms = timeit(lambda: ops.mha(qk, v, 8), args.iters)
+        flops = B * 8 * 2 * 2 * 900 * 900 * 32
+        res.append({"kernel": "mha_bf16", "ms": ms, "flops": flops, "TFLOPs": flops / ms / 1e9})
+    for r in res:
+        print(json.dumps(r))
+
+
+if __name__ == "__main__":
+    main()
