@@ -49,34 +49,45 @@ def msda_algorithmic_bytes_per_line(S: int, Lq: int, value_elem: int, M=8, D=32,
 
 def cpu_baseline(n_lines: int, height: int, width: int, repeats: int, threads: int = 0):
     """Bounded sample (target 10-30 s of CPU work): the oracle forward + blank decode on n_lines
-    synthetic lines, fp32, on `threads` host threads (0 = torch's default = the box's physical cores)."""
+    synthetic lines, fp32.  threads = 0: the oracle's torch-CPU ops stop scaling (and regress) far below
+    the box's core count, so a few thread counts are tried and the FASTEST is reported, with the
+    thread count actually used in `cores`."""
     from dtlr_amd import synth, weights
     from dtlr_amd.config import DTLRConfig
     from oracle import dtlr_oracle as O      # the reported CPU baseline (a port); never the product path
-    if threads > 0:
-        torch.set_num_threads(threads)
     cfg = DTLRConfig.latin()
     sd = weights.synthetic_state_dict(cfg, seed=0)
     imgs = synth.noise_lines(n_lines, height, width, seed=123)
+    ncpu = os.cpu_count() or 8
 
     def run():
         t0 = time.perf_counter()
         out = O.dino_forward(sd, cfg, imgs)
         O.decode_blank(out)
         return time.perf_counter() - t0
-    warm = run()
-    log(f"cpu_baseline warm-up: {warm:.2f}s on {torch.get_num_threads()} threads")
-    ts = []
-    budget = 30.0 - warm
-    for _ in range(repeats):
-        if ts and budget < ts[-1]:
+
+    cands = [threads] if threads > 0 else sorted({min(16, ncpu), min(32, ncpu), min(64, ncpu)})
+    best = None
+    spent = 0.0
+    for th in cands:
+        if spent > 25.0 and best is not None:
             break
-        ts.append(run())
-        budget -= ts[-1]
-    ts = sorted(ts) or [warm]
-    med = ts[len(ts) // 2]
-    return {"value": round(n_lines / med, 4), "unit": "lines/s", "cores": torch.get_num_threads(), "kind": "port",
-            "sample": f"{n_lines} synthetic {height}x{width} fp32 lines, oracle forward+decode, 1 warm-up + {len(ts)} timed, median"}
+        torch.set_num_threads(th)
+        warm = run()
+        ts = []
+        for _ in range(repeats):
+            ts.append(run())
+            if sum(ts) + warm > 12.0:
+                break
+        spent += warm + sum(ts)
+        med = sorted(ts)[len(ts) // 2]
+        log(f"cpu_baseline: {th} threads: warm-up {warm:.2f}s, timed {['%.2f' % t for t in ts]}")
+        if best is None or med < best[0]:
+            best = (med, th, len(ts))
+    med, th, nt = best
+    return {"value": round(n_lines / med, 4), "unit": "lines/s", "cores": th, "kind": "port",
+            "sample": f"{n_lines} synthetic {height}x{width} fp32 lines, oracle forward+decode, 1 warm-up + {nt} timed (median), "
+                      f"best of thread counts {cands} on a {ncpu}-cpu host"}
 
 
 def main():
@@ -89,8 +100,8 @@ def main():
     ap.add_argument("--width", type=int, default=2048)
     ap.add_argument("--dtype", default="bf16", choices=["bf16", "f32"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-lines", type=int, default=4)
-    ap.add_argument("--cpu-threads", type=int, default=0, help="0 = torch default (physical cores)")
+    ap.add_argument("--cpu-lines", type=int, default=2)
+    ap.add_argument("--cpu-threads", type=int, default=0, help="0 = try 16/32/64 threads, report the fastest")
     args = ap.parse_args()
     import faulthandler
     faulthandler.dump_traceback_later(420, exit=False, file=sys.stderr)      # diagnose hangs on the box

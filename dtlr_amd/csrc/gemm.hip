@@ -22,7 +22,7 @@
 //     run on one XCD's L2.
 // Fused prologue: A + A2 (query = src + pos, deformable_transformer.py:797-812).
 // Fused epilogue: + bias, ReLU, zero masked rows (value.masked_fill, ms_deform_attn.py:95-96),
-//                 + residual, output fp32 or bf16.
+//                 + residual, ReLU-after-residual (ResNet bottleneck tail), output fp32 or bf16.
 #include "dtlr_common.h"
 
 namespace dtlr {
@@ -33,7 +33,7 @@ typedef __attribute__((ext_vector_type(4))) float f32x4_t;
 constexpr int BM = 128, BN = 128, SLAB = 128, LDS_ROW = 144;      // bytes
 constexpr int TILE_BYTES = BM * LDS_ROW;                           // one operand tile in LDS
 
-enum : int { EPI_BIAS = 1, EPI_RELU = 2, EPI_RESIDUAL = 4, EPI_ROWMASK = 8 };
+enum : int { EPI_BIAS = 1, EPI_RELU = 2, EPI_RESIDUAL = 4, EPI_ROWMASK = 8, EPI_RELU_POST = 16 };
 
 template <typename T> struct GT;
 template <> struct GT<uint16_t> {   // bf16
@@ -113,23 +113,25 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(
     const char* Ab = reinterpret_cast<const char*>(A);
     const char* A2b = reinterpret_cast<const char*>(A2);
     const char* Wb = reinterpret_cast<const char*>(W);
-    uint4 ra[4], rw[4];
+    // Staging registers are named scalars on purpose: as arrays written under `if (kt + 1 < nk)` hipcc
+    // (ROCm 7.2) leaves them in scratch memory (global_load -> scratch_store ... scratch_load -> ds_write).
+    uint4 ra0, ra1, ra2, ra3, rw0, rw1, rw2, rw3;
+#define GLOAD1(I, OFF)                                                                             \
+    rw##I = *reinterpret_cast<const uint4*>(Wb + w_off[I] + (OFF));                                \
+    ra##I = *reinterpret_cast<const uint4*>(Ab + a_off[I] + (OFF));                                \
+    if (HAS_A2) ra##I = GT<T>::add(ra##I, *reinterpret_cast<const uint4*>(A2b + a_off[I] + (OFF)));
 #define GLOAD(KT)                                                                                  \
     {                                                                                              \
         const long off_ = (long)(KT) * SLAB;                                                       \
-        _Pragma("unroll") for (int i = 0; i < 4; ++i) {                                            \
-            rw[i] = *reinterpret_cast<const uint4*>(Wb + w_off[i] + off_);                         \
-            ra[i] = *reinterpret_cast<const uint4*>(Ab + a_off[i] + off_);                         \
-            if (HAS_A2) ra[i] = GT<T>::add(ra[i], *reinterpret_cast<const uint4*>(A2b + a_off[i] + off_)); \
-        }                                                                                          \
+        GLOAD1(0, off_) GLOAD1(1, off_) GLOAD1(2, off_) GLOAD1(3, off_)                            \
     }
+#define LSTORE1(I)                                                                                 \
+    *reinterpret_cast<uint4*>(wt_ + I * 32 * LDS_ROW) = rw##I;                                     \
+    *reinterpret_cast<uint4*>(wt_ + TILE_BYTES + I * 32 * LDS_ROW) = ra##I;
 #define LSTORE(STAGE)                                                                              \
     {                                                                                              \
         unsigned char* wt_ = smem + (STAGE) * 2 * TILE_BYTES + lds0;                               \
-        _Pragma("unroll") for (int i = 0; i < 4; ++i) {                                            \
-            *reinterpret_cast<uint4*>(wt_ + i * 32 * LDS_ROW) = rw[i];                             \
-            *reinterpret_cast<uint4*>(wt_ + TILE_BYTES + i * 32 * LDS_ROW) = ra[i];                \
-        }                                                                                          \
+        LSTORE1(0) LSTORE1(1) LSTORE1(2) LSTORE1(3)                                                \
     }
 
     f32x4_t acc[4][4];
@@ -165,6 +167,8 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(
 
 #undef GLOAD
 #undef LSTORE
+#undef GLOAD1
+#undef LSTORE1
     // epilogue: lane (g,n) holds channels ch = n0 + wn*64 + ci*16 + 4g + r of token m0 + wm*64 + ti*16 + n
     const bool vec_ok = (N & 3) == 0;
 #pragma unroll
@@ -193,6 +197,10 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(
             OutT* cp = C + (long)tok * N + ch;
             if (full) {
                 if (flags & EPI_RESIDUAL) { float rr[4]; Out<OutT>::ld4(residual + (long)tok * N + ch, rr); v[0] += rr[0]; v[1] += rr[1]; v[2] += rr[2]; v[3] += rr[3]; }
+                if (flags & EPI_RELU_POST) {
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) v[r] = fmaxf(v[r], 0.f);
+                }
                 Out<OutT>::st4(cp, v);
             } else {
 #pragma unroll
@@ -200,6 +208,7 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(
                     if (ch + r < N) {
                         float x = v[r];
                         if (flags & EPI_RESIDUAL) x += Out<OutT>::ld(residual + (long)tok * N + ch + r);
+                        if (flags & EPI_RELU_POST) x = fmaxf(x, 0.f);
                         Out<OutT>::st(cp + r, x);
                     }
             }
@@ -239,7 +248,8 @@ extern "C" int dtlr_gemm_nt(const void* A, const void* A2, const void* W, const 
 {
     if (!A || !W || !C) return DTLR_EINVAL;
     if (M <= 0 || N <= 0 || K <= 0) return DTLR_EINVAL;
-    int flags = (bias ? EPI_BIAS : 0) | (relu ? EPI_RELU : 0) | (residual ? EPI_RESIDUAL : 0) | (row_mask ? EPI_ROWMASK : 0);
+    int flags = (bias ? EPI_BIAS : 0) | (relu == 1 ? EPI_RELU : 0) | (relu == 2 ? EPI_RELU_POST : 0) |
+                (residual ? EPI_RESIDUAL : 0) | (row_mask ? EPI_ROWMASK : 0);
     hipStream_t st = (hipStream_t)stream;
     if (in_dtype == DTLR_BF16) {
         if (K % 64) return DTLR_ESHAPE;

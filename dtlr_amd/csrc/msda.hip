@@ -30,26 +30,35 @@ template <> struct Vec<float, 4> {
         const float4 t = *reinterpret_cast<const float4*>(p); v[0] = t.x; v[1] = t.y; v[2] = t.z; v[3] = t.w; }
     static __device__ __forceinline__ void store(float* p, const float (&v)[4]) {
         *reinterpret_cast<float4*>(p) = make_float4(v[0], v[1], v[2], v[3]); }
+    static __device__ __forceinline__ void load_sel(const float* p, bool ok, float (&v)[4]) {
+        const float4 t = *reinterpret_cast<const float4*>(p);
+        v[0] = ok ? t.x : 0.f; v[1] = ok ? t.y : 0.f; v[2] = ok ? t.z : 0.f; v[3] = ok ? t.w : 0.f; }
 };
 template <> struct Vec<float, 2> {
     static __device__ __forceinline__ void load(const float* p, float (&v)[2]) {
         const float2 t = *reinterpret_cast<const float2*>(p); v[0] = t.x; v[1] = t.y; }
     static __device__ __forceinline__ void store(float* p, const float (&v)[2]) {
         *reinterpret_cast<float2*>(p) = make_float2(v[0], v[1]); }
+    static __device__ __forceinline__ void load_sel(const float* p, bool ok, float (&v)[2]) {
+        const float2 t = *reinterpret_cast<const float2*>(p); v[0] = ok ? t.x : 0.f; v[1] = ok ? t.y : 0.f; }
 };
 template <> struct Vec<float, 1> {
     static __device__ __forceinline__ void load(const float* p, float (&v)[1]) { v[0] = *p; }
     static __device__ __forceinline__ void store(float* p, const float (&v)[1]) { *p = v[0]; }
+    static __device__ __forceinline__ void load_sel(const float* p, bool ok, float (&v)[1]) { const float t = *p; v[0] = ok ? t : 0.f; }
 };
 template <> struct Vec<double, 1> {
     static __device__ __forceinline__ void load(const double* p, double (&v)[1]) { v[0] = *p; }
     static __device__ __forceinline__ void store(double* p, const double (&v)[1]) { *p = v[0]; }
+    static __device__ __forceinline__ void load_sel(const double* p, bool ok, double (&v)[1]) { const double t = *p; v[0] = ok ? t : 0.0; }
 };
 template <> struct Vec<double, 2> {
     static __device__ __forceinline__ void load(const double* p, double (&v)[2]) {
         const double2 t = *reinterpret_cast<const double2*>(p); v[0] = t.x; v[1] = t.y; }
     static __device__ __forceinline__ void store(double* p, const double (&v)[2]) {
         *reinterpret_cast<double2*>(p) = make_double2(v[0], v[1]); }
+    static __device__ __forceinline__ void load_sel(const double* p, bool ok, double (&v)[2]) {
+        const double2 t = *reinterpret_cast<const double2*>(p); v[0] = ok ? t.x : 0.0; v[1] = ok ? t.y : 0.0; }
 };
 // bf16 storage (uint16_t), f32 arithmetic: 8 channels = one 16-byte load
 template <> struct Vec<uint16_t, 8> {
@@ -62,37 +71,150 @@ template <> struct Vec<uint16_t, 8> {
     static __device__ __forceinline__ void store(uint16_t* p, const float (&v)[8]) {
         *reinterpret_cast<uint4*>(p) = make_uint4(pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3]),
                                                   pack_bf16x2(v[4], v[5]), pack_bf16x2(v[6], v[7])); }
+    static __device__ __forceinline__ void load_sel(const uint16_t* p, bool ok, float (&v)[8]) {
+        const uint4 t = *reinterpret_cast<const uint4*>(p);
+        const uint32_t w[4] = {ok ? t.x : 0u, ok ? t.y : 0u, ok ? t.z : 0u, ok ? t.w : 0u};   // select on packed words
+#pragma unroll
+        for (int i = 0; i < 4; ++i) { v[2 * i] = __uint_as_float(w[i] << 16); v[2 * i + 1] = __uint_as_float(w[i] & 0xffff0000u); }
+    }
+};
+template <> struct Vec<uint16_t, 4> {
+    static __device__ __forceinline__ void load(const uint16_t* p, float (&v)[4]) {
+        const uint2 t = *reinterpret_cast<const uint2*>(p);
+        v[0] = __uint_as_float(t.x << 16); v[1] = __uint_as_float(t.x & 0xffff0000u);
+        v[2] = __uint_as_float(t.y << 16); v[3] = __uint_as_float(t.y & 0xffff0000u); }
+    static __device__ __forceinline__ void store(uint16_t* p, const float (&v)[4]) {
+        *reinterpret_cast<uint2*>(p) = make_uint2(pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3])); }
+    static __device__ __forceinline__ void load_sel(const uint16_t* p, bool ok, float (&v)[4]) {
+        const uint2 t = *reinterpret_cast<const uint2*>(p);
+        const uint32_t a = ok ? t.x : 0u, b = ok ? t.y : 0u;
+        v[0] = __uint_as_float(a << 16); v[1] = __uint_as_float(a & 0xffff0000u);
+        v[2] = __uint_as_float(b << 16); v[3] = __uint_as_float(b & 0xffff0000u); }
 };
 template <> struct Vec<uint16_t, 1> {
     static __device__ __forceinline__ void load(const uint16_t* p, float (&v)[1]) { v[0] = bf16_to_f32(*p); }
     static __device__ __forceinline__ void store(uint16_t* p, const float (&v)[1]) { *p = f32_to_bf16(v[0]); }
+    static __device__ __forceinline__ void load_sel(const uint16_t* p, bool ok, float (&v)[1]) { const uint16_t t = *p; v[0] = ok ? bf16_to_f32(t) : 0.f; }
 };
 
 // One sampling point: adds A * bilinear(...) for VEC channels.  `base` points at
 // value[b, level_start, m, c0]; row stride = W*M*D elements, column stride = M*D elements.
+// BRANCH-FREE on purpose: the four corner fetches are always issued (addresses clamped into the map)
+// and an invalid corner's data is replaced by zero with v_cndmask.  With `if (valid) load` hipcc puts
+// each load in its own exec-masked block followed by s_waitcnt vmcnt(0) -- 64 serialized L2 round
+// trips per thread (first version of this kernel: 0.56 ms per encoder call); unconditional loads let
+// the 4 corners x several points be in flight together.  Same arithmetic as the reference
+// (cuh:33-84): v_i = 0 for corners outside the map, val = w1 v1 + w2 v2 + w3 v3 + w4 v4, col += val * A.
 template <typename T, typename A, int VEC>
 __device__ __forceinline__ void sample_point(const T* __restrict__ base, int H, int W, int MD,
                                              A loc_w, A loc_h, A weight, A (&col)[VEC]) {
     const A h_im = loc_h * (A)H - (A)0.5;
     const A w_im = loc_w * (A)W - (A)0.5;
-    if (!(h_im > (A)-1 && w_im > (A)-1 && h_im < (A)H && w_im < (A)W)) return;
+    const bool inside = h_im > (A)-1 && w_im > (A)-1 && h_im < (A)H && w_im < (A)W;
     const A hf = floor(h_im), wf = floor(w_im);
-    const int h_low = (int)hf, w_low = (int)wf;
-    const int h_high = h_low + 1, w_high = w_low + 1;
     const A lh = h_im - hf, lw = w_im - wf, hh = (A)1 - lh, hw = (A)1 - lw;
+    // clamp in floating point first so the int conversion is defined for far-away / non-finite locations
+    const int h_low = (int)fmin(fmax(hf, (A)-1), (A)H), w_low = (int)fmin(fmax(wf, (A)-1), (A)W);
+    const int h_high = h_low + 1, w_high = w_low + 1;
+    const bool top = inside && h_low >= 0, bot = inside && h_high <= H - 1;
+    const bool left = w_low >= 0, right = w_high <= W - 1;
+    // clamp BOTH ways: for a far-outside sample h_low can be H (then h_high = H+1): data unused, address must stay in the map
+    const int h0 = min(max(h_low, 0), H - 1), h1 = max(min(h_high, H - 1), 0), w0 = min(max(w_low, 0), W - 1), w1 = max(min(w_high, W - 1), 0);
     const long row_stride = (long)W * MD;
-    const T* p_lo = base + (long)h_low * row_stride + (long)w_low * MD;
-    const bool top = h_low >= 0, bot = h_high <= H - 1, left = w_low >= 0, right = w_high <= W - 1;
+    const T* r0 = base + (long)h0 * row_stride;
+    const T* r1 = base + (long)h1 * row_stride;
     A v1[VEC], v2[VEC], v3[VEC], v4[VEC];
+    Vec<T, VEC>::load_sel(r0 + (long)w0 * MD, top && left, v1);
+    Vec<T, VEC>::load_sel(r0 + (long)w1 * MD, top && right, v2);
+    Vec<T, VEC>::load_sel(r1 + (long)w0 * MD, bot && left, v3);
+    Vec<T, VEC>::load_sel(r1 + (long)w1 * MD, bot && right, v4);
+    const A w1_ = hh * hw, w2_ = hh * lw, w3_ = lh * hw, w4_ = lh * lw;
 #pragma unroll
-    for (int i = 0; i < VEC; ++i) { v1[i] = 0; v2[i] = 0; v3[i] = 0; v4[i] = 0; }
-    if (top && left) Vec<T, VEC>::load(p_lo, v1);
-    if (top && right) Vec<T, VEC>::load(p_lo + MD, v2);
-    if (bot && left) Vec<T, VEC>::load(p_lo + row_stride, v3);
-    if (bot && right) Vec<T, VEC>::load(p_lo + row_stride + MD, v4);
-    const A w1 = hh * hw, w2 = hh * lw, w3 = lh * hw, w4 = lh * lw;
+    for (int i = 0; i < VEC; ++i) col[i] += (w1_ * v1[i] + w2_ * v2[i] + w3_ * v3[i] + w4_ * v4[i]) * weight;
+}
+
+// Hot path (P = 4): one LEVEL at a time -- geometry of its 4 points first, then all 16 corner fetches
+// issued back to back (64 data VGPRs in flight per lane), then the arithmetic.  A scheduling barrier
+// after each level stops hipcc from hoisting the next level's loads too (unbounded hoisting costs 256
+// VGPRs or kilobytes of scratch); 16 independent 16-byte loads per lane x 3-4 waves per SIMD is what
+// covers the L2 latency of the gather.
+template <typename T, int VEC> struct Raw;
+template <> struct Raw<float, 4> {
+    using raw_t = float4;
+    static constexpr int GROUP = 4;        // points whose corner fetches are in flight together
+    static __device__ __forceinline__ raw_t ld(const float* p) { return *reinterpret_cast<const float4*>(p); }
+    static __device__ __forceinline__ void unpack(raw_t t, bool ok, float (&v)[4]) {
+        v[0] = ok ? t.x : 0.f; v[1] = ok ? t.y : 0.f; v[2] = ok ? t.z : 0.f; v[3] = ok ? t.w : 0.f; }
+};
+template <> struct Raw<uint16_t, 4> {      // bf16: 4 channels = one 8-byte load; same register shape as fp32
+    using raw_t = uint2;
+    static constexpr int GROUP = 4;
+    static __device__ __forceinline__ raw_t ld(const uint16_t* p) { return *reinterpret_cast<const uint2*>(p); }
+    static __device__ __forceinline__ void unpack(raw_t t, bool ok, float (&v)[4]) {
+        const uint32_t a = ok ? t.x : 0u, b = ok ? t.y : 0u;          // select on the packed words
+        v[0] = __uint_as_float(a << 16); v[1] = __uint_as_float(a & 0xffff0000u);
+        v[2] = __uint_as_float(b << 16); v[3] = __uint_as_float(b & 0xffff0000u); }
+};
+
+template <typename T, int VEC>
+__device__ __forceinline__ void sample_level4(const T* __restrict__ base, int H, int W, int MD,
+                                              const float (&lx)[4], const float (&ly)[4], const float (&aw)[4],
+                                              float (&col)[VEC]) {
+    using R = Raw<T, VEC>;
+    constexpr int G = R::GROUP;
+    const int row_stride = W * MD;            // intra-level element offsets fit 32 bits (one image's map)
 #pragma unroll
-    for (int i = 0; i < VEC; ++i) col[i] += (w1 * v1[i] + w2 * v2[i] + w3 * v3[i] + w4 * v4[i]) * weight;
+    for (int p0 = 0; p0 < 4; p0 += G) {
+        typename R::raw_t d[G][4];
+        float wgt[G][4];
+        bool ok[G][4];
+#pragma unroll
+        for (int q = 0; q < G; ++q) {
+            const int p = p0 + q;
+            const float h_im = ly[p] * (float)H - 0.5f;
+            const float w_im = lx[p] * (float)W - 0.5f;
+            const bool inside = h_im > -1.f && w_im > -1.f && h_im < (float)H && w_im < (float)W;
+            const float hf = floorf(h_im), wf = floorf(w_im);
+            const float lh = h_im - hf, lw = w_im - wf, hh = 1.f - lh, hw = 1.f - lw;
+            const int h_low = (int)fminf(fmaxf(hf, -1.f), (float)H), w_low = (int)fminf(fmaxf(wf, -1.f), (float)W);
+            const int h_high = h_low + 1, w_high = w_low + 1;
+            const bool top = inside && h_low >= 0, bot = inside && h_high <= H - 1;
+            const bool left = w_low >= 0, right = w_high <= W - 1;
+            // clamp BOTH ways: for a far-outside sample h_low can be H (then h_high = H+1): data unused, address must stay in the map
+    const int h0 = min(max(h_low, 0), H - 1), h1 = max(min(h_high, H - 1), 0), w0 = min(max(w_low, 0), W - 1), w1 = max(min(w_high, W - 1), 0);
+            const int r0 = h0 * row_stride, r1 = h1 * row_stride, c0 = w0 * MD, c1 = w1 * MD;
+            d[q][0] = R::ld(base + (r0 + c0));
+            d[q][1] = R::ld(base + (r0 + c1));
+            d[q][2] = R::ld(base + (r1 + c0));
+            d[q][3] = R::ld(base + (r1 + c1));
+            ok[q][0] = top && left; ok[q][1] = top && right; ok[q][2] = bot && left; ok[q][3] = bot && right;
+            wgt[q][0] = hh * hw; wgt[q][1] = hh * lw; wgt[q][2] = lh * hw; wgt[q][3] = lh * lw;
+        }
+#pragma unroll
+        for (int q = 0; q < G; ++q) {
+            float v1[VEC], v2[VEC], v3[VEC], v4[VEC];
+            R::unpack(d[q][0], ok[q][0], v1);
+            R::unpack(d[q][1], ok[q][1], v2);
+            R::unpack(d[q][2], ok[q][2], v3);
+            R::unpack(d[q][3], ok[q][3], v4);
+#pragma unroll
+            for (int i = 0; i < VEC; ++i)
+                col[i] += (wgt[q][0] * v1[i] + wgt[q][1] * v2[i] + wgt[q][2] * v3[i] + wgt[q][3] * v4[i]) * aw[p0 + q];
+        }
+        __builtin_amdgcn_sched_barrier(0);
+    }
+}
+
+// XCD-aware work placement: the dispatcher puts workgroup b on XCD b % 8 and each XCD has a private
+// 4 MiB L2.  The gather re-reads an image's value map (2.8 MB bf16 / 5.6 MB fp32) ~18x, so all
+// workgroups of image i are sent to XCD i % 8: that L2 then holds one image's map instead of slices
+// of every image in flight.  Used when a workgroup never straddles two images and N % 8 == 0;
+// otherwise the identity map.  (Speed only -- results do not depend on placement.)
+__device__ __forceinline__ long xcd_block_map(long bid, int bpi /*blocks per image*/, int N) {
+    if (bpi <= 0 || (N & 7)) return bid;
+    const long xcd = bid & 7, idx = bid >> 3;
+    const long img = (idx / bpi) * 8 + xcd, blk = idx % bpi;
+    return img * bpi + blk;
 }
 
 // T: storage type of value/out; LT: type of loc/attn; VEC channels per thread.
@@ -132,12 +254,12 @@ __global__ __launch_bounds__(256) void msda_fwd_kernel(
 // attn floats of this (b,q,m) come in as 8 + 4 16-byte loads (all lanes of a head read the same
 // addresses: one request each) issued before any gather so their latency overlaps.
 template <typename T, int VEC>
-__global__ __launch_bounds__(256) void msda_fwd_l4p4_kernel(
+__global__ __launch_bounds__(256, sizeof(T) == 2 ? 2 : 3) void msda_fwd_l4p4_kernel(
     const T* __restrict__ value, const int64_t* __restrict__ shapes, const int64_t* __restrict__ lsi,
     const float* __restrict__ loc, const float* __restrict__ attn,
-    int S, int M, int D, int Lq, T* __restrict__ out, long total)
+    int S, int M, int D, int Lq, T* __restrict__ out, long total, int bpi, int nimg)
 {
-    const long tid = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    const long tid = xcd_block_map(blockIdx.x, bpi, nimg) * blockDim.x + threadIdx.x;
     if (tid >= total) return;
     const int cpv = D / VEC;
     const int c0 = (int)(tid % cpv) * VEC;
@@ -163,12 +285,9 @@ __global__ __launch_bounds__(256) void msda_fwd_l4p4_kernel(
     for (int l = 0; l < 4; ++l) {
         const T* base = vb + st[l] * MD;
         const float a[4] = {av[l].x, av[l].y, av[l].z, av[l].w};
-#pragma unroll
-        for (int h = 0; h < 2; ++h) {
-            const float4 t = lv[2 * l + h];
-            sample_point<T, float, VEC>(base, Hs[l], Ws[l], MD, t.x, t.y, a[2 * h], col);
-            sample_point<T, float, VEC>(base, Hs[l], Ws[l], MD, t.z, t.w, a[2 * h + 1], col);
-        }
+        const float lx[4] = {lv[2 * l].x, lv[2 * l].z, lv[2 * l + 1].x, lv[2 * l + 1].z};
+        const float ly[4] = {lv[2 * l].y, lv[2 * l].w, lv[2 * l + 1].y, lv[2 * l + 1].w};
+        sample_level4<T, VEC>(base, Hs[l], Ws[l], MD, lx, ly, a, col);
     }
     Vec<T, VEC>::store(out + si * D + c0, col);
 }
@@ -197,12 +316,12 @@ template <> __device__ __forceinline__ void load_row16<uint16_t>(const uint16_t*
 }
 
 template <typename T, typename OT, int VEC, int REFD>
-__global__ __launch_bounds__(256) void msda_fused_l4p4_kernel(
+__global__ __launch_bounds__(256, sizeof(T) == 2 ? 2 : 3) void msda_fused_l4p4_kernel(
     const T* __restrict__ value, const int64_t* __restrict__ shapes, const int64_t* __restrict__ lsi,
     const OT* __restrict__ ow, const float* __restrict__ ref,
-    int S, int M, int D, int Lq, T* __restrict__ out, long total)
+    int S, int M, int D, int Lq, T* __restrict__ out, long total, int bpi, int nimg)
 {
-    const long tid = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    const long tid = xcd_block_map(blockIdx.x, bpi, nimg) * blockDim.x + threadIdx.x;
     if (tid >= total) return;
     const int cpv = D / VEC;
     const int c0 = (int)(tid % cpv) * VEC;
@@ -236,19 +355,20 @@ __global__ __launch_bounds__(256) void msda_fused_l4p4_kernel(
     for (int l = 0; l < 4; ++l) {
         const int H = (int)shapes[2 * l], W = (int)shapes[2 * l + 1];
         const T* base = vb + (long)lsi[l] * MD;
+        float lx[4], ly[4], aw4[4];
 #pragma unroll
         for (int p = 0; p < 4; ++p) {
             const float ox = off[(l * 4 + p) * 2], oy = off[(l * 4 + p) * 2 + 1];
-            float lx, ly;
             if (REFD == 2) {
-                lx = rf[2 * l] + ox / (float)W;
-                ly = rf[2 * l + 1] + oy / (float)H;
+                lx[p] = rf[2 * l] + ox / (float)W;
+                ly[p] = rf[2 * l + 1] + oy / (float)H;
             } else {
-                lx = rf[4 * l] + ox / 4.0f * rf[4 * l + 2] * 0.5f;
-                ly = rf[4 * l + 1] + oy / 4.0f * rf[4 * l + 3] * 0.5f;
+                lx[p] = rf[4 * l] + ox / 4.0f * rf[4 * l + 2] * 0.5f;
+                ly[p] = rf[4 * l + 1] + oy / 4.0f * rf[4 * l + 3] * 0.5f;
             }
-            sample_point<T, float, VEC>(base, H, W, MD, lx, ly, lg[l * 4 + p] * inv, col);
+            aw4[p] = lg[l * 4 + p] * inv;
         }
+        sample_level4<T, VEC>(base, H, W, MD, lx, ly, aw4, col);
     }
     Vec<T, VEC>::store(out + si * D + c0, col);
 }
@@ -260,12 +380,14 @@ static int launch_fused(const void* value, const int64_t* shapes, const int64_t*
     const int block = 256;
     const long grid = (total + block - 1) / block;
     if (grid > 0x7fffffffL) return DTLR_ESHAPE;
+    const long per_img = (long)Lq * M * (D / VEC);
+    const int bpi = (per_img % block == 0 && N % 8 == 0) ? (int)(per_img / block) : 0;
     if (ref_dim == 2)
         hipLaunchKernelGGL((msda_fused_l4p4_kernel<T, OT, VEC, 2>), dim3((unsigned)grid), dim3(block), 0, st,
-                           (const T*)value, shapes, lsi, (const OT*)ow, ref, S, M, D, Lq, (T*)out, total);
+                           (const T*)value, shapes, lsi, (const OT*)ow, ref, S, M, D, Lq, (T*)out, total, bpi, N);
     else
         hipLaunchKernelGGL((msda_fused_l4p4_kernel<T, OT, VEC, 4>), dim3((unsigned)grid), dim3(block), 0, st,
-                           (const T*)value, shapes, lsi, (const OT*)ow, ref, S, M, D, Lq, (T*)out, total);
+                           (const T*)value, shapes, lsi, (const OT*)ow, ref, S, M, D, Lq, (T*)out, total, bpi, N);
     return check_launch();
 }
 
@@ -288,8 +410,10 @@ static int launch_l4p4(const void* value, const int64_t* shapes, const int64_t* 
     const int block = 256;
     const long grid = (total + block - 1) / block;
     if (grid > 0x7fffffffL) return DTLR_ESHAPE;
+    const long per_img = (long)Lq * M * (D / VEC);
+    const int bpi = (per_img % block == 0 && N % 8 == 0) ? (int)(per_img / block) : 0;
     hipLaunchKernelGGL((msda_fwd_l4p4_kernel<T, VEC>), dim3((unsigned)grid), dim3(block), 0, st,
-                       (const T*)value, shapes, lsi, (const float*)loc, (const float*)attn, S, M, D, Lq, (T*)out, total);
+                       (const T*)value, shapes, lsi, (const float*)loc, (const float*)attn, S, M, D, Lq, (T*)out, total, bpi, N);
     return check_launch();
 }
 
@@ -316,7 +440,7 @@ extern "C" int dtlr_msda_forward(const void* value, const int64_t* shapes, const
         if (D % 2 == 0) return launch_generic<double, double, double, 2>(value, shapes, lsi, loc, attn, N, S, M, D, L, Lq, P, out, st);
         return launch_generic<double, double, double, 1>(value, shapes, lsi, loc, attn, N, S, M, D, L, Lq, P, out, st);
     case DTLR_BF16:
-        if (hot && D % 8 == 0) return launch_l4p4<uint16_t, 8>(value, shapes, lsi, loc, attn, N, S, M, D, Lq, out, st);
+        if (hot && D % 4 == 0) return launch_l4p4<uint16_t, 4>(value, shapes, lsi, loc, attn, N, S, M, D, Lq, out, st);
         if (D % 8 == 0) return launch_generic<uint16_t, float, float, 8>(value, shapes, lsi, loc, attn, N, S, M, D, L, Lq, P, out, st);
         return launch_generic<uint16_t, float, float, 1>(value, shapes, lsi, loc, attn, N, S, M, D, L, Lq, P, out, st);
     default:
@@ -337,9 +461,9 @@ extern "C" int dtlr_msda_fused_forward(const void* value, const int64_t* shapes,
         if (ow_dtype == DTLR_F32) return launch_fused<float, float, 4>(value, shapes, lsi, ow, ref, ref_dim, N, S, M, D, Lq, out, st);
         return DTLR_EDTYPE;
     }
-    if (dtype == DTLR_BF16 && D % 8 == 0) {
-        if (ow_dtype == DTLR_F32) return launch_fused<uint16_t, float, 8>(value, shapes, lsi, ow, ref, ref_dim, N, S, M, D, Lq, out, st);
-        if (ow_dtype == DTLR_BF16) return launch_fused<uint16_t, uint16_t, 8>(value, shapes, lsi, ow, ref, ref_dim, N, S, M, D, Lq, out, st);
+    if (dtype == DTLR_BF16 && D % 4 == 0) {
+        if (ow_dtype == DTLR_F32) return launch_fused<uint16_t, float, 4>(value, shapes, lsi, ow, ref, ref_dim, N, S, M, D, Lq, out, st);
+        if (ow_dtype == DTLR_BF16) return launch_fused<uint16_t, uint16_t, 4>(value, shapes, lsi, ow, ref, ref_dim, N, S, M, D, Lq, out, st);
         return DTLR_EDTYPE;
     }
     return (dtype == DTLR_F32 || dtype == DTLR_BF16) ? DTLR_ESHAPE : DTLR_EDTYPE;

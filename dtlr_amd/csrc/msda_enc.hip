@@ -1,0 +1,255 @@
+// LDS-staged multi-scale deformable attention for the ENCODER (queries = the pixels of the 4 levels).
+//
+// Why: the gather form (msda.hip) moves Lq*M*L*P*4 corner rows = 356 MB/line (fp32) through the
+// vector L1 at <= 64 B/clk/CU; measured it is L1/TA-bound at ~0.6 ms per call (B=32), 10x above the
+// HBM time of the compulsory bytes.  Text lines are wide and short (level 0 is 16 x 256 at
+// 128x2048), sampling offsets are a few pixels, so the value rows a block of neighbouring queries
+// touches form a narrow column window of each level: stage it in LDS once (coalesced 16-byte
+// loads, each byte of `value` fetched ~1.5x instead of ~18x) and serve the 64 corner reads per
+// (query, head) from LDS at 256 B/clk/CU.
+//
+// Decomposition: grid = (x-tiles, heads, images).  A workgroup owns the queries of ALL levels whose
+// pixel centre falls in one slab [t, t+1) * TW0 / W_0 of the normalised x axis (exact integer
+// partition, any level widths), for ONE head, and holds for that head the full-height windows
+//     level l: columns [floor(t*TW0*W_l/W_0) - R, ceil((t+1)*TW0*W_l/W_0) + R)  x  32 channels.
+// A sample whose needed columns are not all inside the window takes the global-memory path (same
+// arithmetic) -- correctness never depends on the offsets being small; only speed does.
+// Front end fused as in msda_fused_l4p4: softmax(16) + location arithmetic from the raw projection row.
+// Arithmetic order = the reference's (cuh:33-84,237-299): fp32 results agree to rounding.
+#include "dtlr_common.h"
+
+namespace dtlr {
+
+struct EncLevels { int H[4], W[4], start[4], wmax[4], loff[4]; };   // loff: LDS offset of level l, in pixels
+
+template <typename T> struct ET;
+template <> struct ET<float> {
+    static constexpr int VEC = 4, CP = 8;              // channels per 16-byte chunk; chunks per 32-channel pixel row
+    static __device__ __forceinline__ void unpack(uint4 t, float (&v)[4]) {
+        v[0] = __uint_as_float(t.x); v[1] = __uint_as_float(t.y); v[2] = __uint_as_float(t.z); v[3] = __uint_as_float(t.w); }
+    static __device__ __forceinline__ uint4 pack(const float (&v)[4]) {
+        return make_uint4(__float_as_uint(v[0]), __float_as_uint(v[1]), __float_as_uint(v[2]), __float_as_uint(v[3])); }
+};
+template <> struct ET<uint16_t> {
+    static constexpr int VEC = 8, CP = 4;
+    static __device__ __forceinline__ void unpack(uint4 t, float (&v)[8]) {
+        const uint32_t w[4] = {t.x, t.y, t.z, t.w};
+#pragma unroll
+        for (int i = 0; i < 4; ++i) { v[2 * i] = __uint_as_float(w[i] << 16); v[2 * i + 1] = __uint_as_float(w[i] & 0xffff0000u); } }
+    static __device__ __forceinline__ uint4 pack(const float (&v)[8]) {
+        return make_uint4(pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3]), pack_bf16x2(v[4], v[5]), pack_bf16x2(v[6], v[7])); }
+};
+
+template <typename OT> __device__ __forceinline__ void ld16f(const OT* p, float (&v)[16]);
+template <> __device__ __forceinline__ void ld16f<float>(const float* p, float (&v)[16]) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) { const float4 t = reinterpret_cast<const float4*>(p)[i];
+        v[4 * i] = t.x; v[4 * i + 1] = t.y; v[4 * i + 2] = t.z; v[4 * i + 3] = t.w; }
+}
+template <> __device__ __forceinline__ void ld16f<uint16_t>(const uint16_t* p, float (&v)[16]) {
+#pragma unroll
+    for (int i = 0; i < 2; ++i) { const uint4 t = reinterpret_cast<const uint4*>(p)[i];
+        const uint32_t w[4] = {t.x, t.y, t.z, t.w};
+#pragma unroll
+        for (int j = 0; j < 4; ++j) { v[8 * i + 2 * j] = __uint_as_float(w[j] << 16); v[8 * i + 2 * j + 1] = __uint_as_float(w[j] & 0xffff0000u); } }
+}
+
+// number of columns j of a W_l-wide level whose centre (j+0.5)/W_l lies left of tile boundary t*TW0/W_0:
+// exact integers: (2j+1)*W_0 < 2*t*TW0*W_l
+__device__ __forceinline__ int cols_left_of(int t, int TW0, int W0, int Wl) {
+    const long num = 2L * t * TW0 * Wl - W0;                  // j < num / (2*W0)
+    if (num <= 0) return 0;
+    const long c = (num + 2L * W0 - 1) / (2L * W0);            // ceil
+    return (int)(c < Wl ? c : Wl);
+}
+
+template <typename T, typename OT>
+__global__ __launch_bounds__(256) void msda_enc_lds_kernel(
+    const T* __restrict__ value, const OT* __restrict__ ow, const float* __restrict__ ref, T* __restrict__ out,
+    EncLevels lv, int S, int M, int TW0, int R)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    constexpr int VEC = ET<T>::VEC, CP = ET<T>::CP;
+    constexpr int PIX_BYTES = 32 * (int)sizeof(T);
+    const int tid = threadIdx.x;
+    const int t = blockIdx.x, m = blockIdx.y, b = blockIdx.z;
+    const int MD = M * 32;
+    const int W0 = lv.W[0];
+
+    // ---- per-level geometry of this tile (uniform across the workgroup) ---------------------------
+    int qc0[4], qn[4], wc0[4], wc1[4], qbase[5];
+    qbase[0] = 0;
+#pragma unroll
+    for (int l = 0; l < 4; ++l) {
+        qc0[l] = cols_left_of(t, TW0, W0, lv.W[l]);
+        const int qc1 = cols_left_of(t + 1, TW0, W0, lv.W[l]);
+        qn[l] = qc1 - qc0[l];
+        const int lo = (int)(((long)t * TW0 * lv.W[l]) / W0) - R;
+        const int hi = (int)((((long)(t + 1) * TW0 * lv.W[l]) + W0 - 1) / W0) + R;
+        wc0[l] = max(lo, 0);
+        wc1[l] = min(min(hi, lv.W[l]), wc0[l] + lv.wmax[l]);
+        qbase[l + 1] = qbase[l] + lv.H[l] * qn[l];
+    }
+    const int nq = qbase[4];
+
+    // ---- stage the four windows of head m: coalesced 16-byte chunks, CP chunks per pixel ------------
+    const T* vimg = value + (long)b * S * MD + m * 32;
+#pragma unroll
+    for (int l = 0; l < 4; ++l) {
+        const int ww = wc1[l] - wc0[l];
+        const int nchunk = lv.H[l] * ww * CP;
+        const T* src = vimg + (long)lv.start[l] * MD;
+        unsigned char* dst = smem + (long)lv.loff[l] * PIX_BYTES;
+        for (int c = tid; c < nchunk; c += 256) {
+            const int part = c % CP, pc = c / CP;
+            const int col = pc % ww, row = pc / ww;
+            const uint4 d = *reinterpret_cast<const uint4*>(src + (long)(row * lv.W[l] + wc0[l] + col) * MD + part * VEC);
+            *reinterpret_cast<uint4*>(dst + (row * lv.wmax[l] + col) * PIX_BYTES + part * 16) = d;
+        }
+    }
+    __syncthreads();
+
+    // ---- queries: CP lanes per query (16 bytes = VEC channels each) ---------------------------------
+    for (int it = tid; it < nq * CP; it += 256) {
+        const int part = it % CP, q = it / CP;
+        int lq = 0;
+        if (q >= qbase[1]) lq = 1;
+        if (q >= qbase[2]) lq = 2;
+        if (q >= qbase[3]) lq = 3;
+        int r, nc, c0q, Wq, stq;
+        switch (lq) {       // scalar selects (arrays indexed by a lane-varying value would go to scratch)
+        case 0: r = q - qbase[0]; nc = qn[0]; c0q = qc0[0]; Wq = lv.W[0]; stq = lv.start[0]; break;
+        case 1: r = q - qbase[1]; nc = qn[1]; c0q = qc0[1]; Wq = lv.W[1]; stq = lv.start[1]; break;
+        case 2: r = q - qbase[2]; nc = qn[2]; c0q = qc0[2]; Wq = lv.W[2]; stq = lv.start[2]; break;
+        default: r = q - qbase[3]; nc = qn[3]; c0q = qc0[3]; Wq = lv.W[3]; stq = lv.start[3]; break;
+        }
+        const int qi = r / nc, qj = c0q + r % nc;
+        const long bq = (long)b * S + stq + qi * Wq + qj;
+
+        const OT* row = ow + bq * (long)(M * 48);
+        float off[32], lg[16];
+        ld16f<OT>(row + m * 32, *reinterpret_cast<float (*)[16]>(&off[0]));
+        ld16f<OT>(row + m * 32 + 16, *reinterpret_cast<float (*)[16]>(&off[16]));
+        ld16f<OT>(row + M * 32 + m * 16, lg);
+        float rf[8];
+        {
+            const float4 a = reinterpret_cast<const float4*>(ref + bq * 8)[0], c = reinterpret_cast<const float4*>(ref + bq * 8)[1];
+            rf[0] = a.x; rf[1] = a.y; rf[2] = a.z; rf[3] = a.w; rf[4] = c.x; rf[5] = c.y; rf[6] = c.z; rf[7] = c.w;
+        }
+        float mx = lg[0];
+#pragma unroll
+        for (int i = 1; i < 16; ++i) mx = fmaxf(mx, lg[i]);
+        float sum = 0.f;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) { lg[i] = expf(lg[i] - mx); sum += lg[i]; }
+        const float inv = 1.0f / sum;
+
+        float col[VEC];
+#pragma unroll
+        for (int i = 0; i < VEC; ++i) col[i] = 0.f;
+#pragma unroll
+        for (int l = 0; l < 4; ++l) {
+            const int H = lv.H[l], W = lv.W[l];
+            const unsigned char* win = smem + (long)lv.loff[l] * PIX_BYTES + part * 16;
+            const T* gsrc = vimg + (long)lv.start[l] * MD + part * VEC;
+            const int wstride = lv.wmax[l];
+#pragma unroll
+            for (int p = 0; p < 4; ++p) {
+                const float lx = rf[2 * l] + off[(l * 4 + p) * 2] / (float)W;
+                const float ly = rf[2 * l + 1] + off[(l * 4 + p) * 2 + 1] / (float)H;
+                const float h_im = ly * (float)H - 0.5f, w_im = lx * (float)W - 0.5f;
+                if (!(h_im > -1.f && w_im > -1.f && h_im < (float)H && w_im < (float)W)) continue;
+                const float hf = floorf(h_im), wf = floorf(w_im);
+                const int h_low = (int)hf, w_low = (int)wf, h_high = h_low + 1, w_high = w_low + 1;
+                const float lh = h_im - hf, lw = w_im - wf, hh = 1.f - lh, hw = 1.f - lw;
+                const bool top = h_low >= 0, bot = h_high <= H - 1, left = w_low >= 0, right = w_high <= W - 1;
+                const int h0 = max(h_low, 0), h1 = min(h_high, H - 1), w0 = max(w_low, 0), w1 = min(w_high, W - 1);
+                uint4 d1, d2, d3, d4;
+                if (w0 >= wc0[l] && w1 < wc1[l]) {          // both columns resident: LDS path (always-issued reads)
+                    const int a0 = w0 - wc0[l], a1 = w1 - wc0[l];
+                    d1 = *reinterpret_cast<const uint4*>(win + (h0 * wstride + a0) * PIX_BYTES);
+                    d2 = *reinterpret_cast<const uint4*>(win + (h0 * wstride + a1) * PIX_BYTES);
+                    d3 = *reinterpret_cast<const uint4*>(win + (h1 * wstride + a0) * PIX_BYTES);
+                    d4 = *reinterpret_cast<const uint4*>(win + (h1 * wstride + a1) * PIX_BYTES);
+                } else {                                    // outside the staged window: global path
+                    d1 = *reinterpret_cast<const uint4*>(gsrc + (long)(h0 * W + w0) * MD);
+                    d2 = *reinterpret_cast<const uint4*>(gsrc + (long)(h0 * W + w1) * MD);
+                    d3 = *reinterpret_cast<const uint4*>(gsrc + (long)(h1 * W + w0) * MD);
+                    d4 = *reinterpret_cast<const uint4*>(gsrc + (long)(h1 * W + w1) * MD);
+                }
+                const uint4 z = make_uint4(0u, 0u, 0u, 0u);
+                float v1[VEC], v2[VEC], v3[VEC], v4[VEC];
+                ET<T>::unpack((top && left) ? d1 : z, v1);
+                ET<T>::unpack((top && right) ? d2 : z, v2);
+                ET<T>::unpack((bot && left) ? d3 : z, v3);
+                ET<T>::unpack((bot && right) ? d4 : z, v4);
+                const float w1_ = hh * hw, w2_ = hh * lw, w3_ = lh * hw, w4_ = lh * lw, a = lg[l * 4 + p] * inv;
+#pragma unroll
+                for (int i = 0; i < VEC; ++i) col[i] += (w1_ * v1[i] + w2_ * v2[i] + w3_ * v3[i] + w4_ * v4[i]) * a;
+            }
+        }
+        *reinterpret_cast<uint4*>(out + bq * MD + m * 32 + part * VEC) = ET<T>::pack(col);
+    }
+}
+
+struct EncPlan { EncLevels lv; int S, TW0, R, ntiles; size_t lds; };
+
+static bool make_plan(const int* hw, int elem, int R, EncPlan& pl) {
+    int start = 0;
+    for (int l = 0; l < 4; ++l) {
+        pl.lv.H[l] = hw[2 * l]; pl.lv.W[l] = hw[2 * l + 1]; pl.lv.start[l] = start;
+        if (pl.lv.H[l] <= 0 || pl.lv.W[l] <= 0) return false;
+        start += hw[2 * l] * hw[2 * l + 1];
+    }
+    pl.S = start; pl.R = R;
+    const int W0 = pl.lv.W[0];
+    // widest level-0 tile whose windows fit: first try 2 workgroups per CU (<= 80 KB), then 1 (<= 160 KB)
+    for (int pass = 0; pass < 2; ++pass) {
+        const size_t cap = pass == 0 ? 80 * 1024 : 160 * 1024;
+        for (int TW0 = 64; TW0 >= (pass == 0 ? 16 : 4); TW0 >>= 1) {
+            long pix = 0;
+            for (int l = 0; l < 4; ++l) {
+                pl.lv.wmax[l] = (int)(((long)TW0 * pl.lv.W[l] + W0 - 1) / W0) + 2 * R + 1;
+                if (pl.lv.wmax[l] > pl.lv.W[l]) pl.lv.wmax[l] = pl.lv.W[l];
+                pl.lv.loff[l] = (int)pix;
+                pix += (long)pl.lv.H[l] * pl.lv.wmax[l];
+            }
+            const size_t lds = (size_t)pix * 32 * elem;
+            if (lds <= cap) {
+                pl.TW0 = TW0; pl.lds = lds; pl.ntiles = (W0 + TW0 - 1) / TW0;
+                return true;
+            }
+        }
+    }
+    return false;
+}
+
+template <typename T, typename OT>
+static int launch_enc(const void* value, const void* ow, const float* ref, void* out, const EncPlan& pl, int N, int M, hipStream_t st) {
+    static bool attr = false;
+    if (!attr) { (void)hipFuncSetAttribute((const void*)msda_enc_lds_kernel<T, OT>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); attr = true; }
+    hipLaunchKernelGGL((msda_enc_lds_kernel<T, OT>), dim3(pl.ntiles, M, N), dim3(256), pl.lds, st,
+                       (const T*)value, (const OT*)ow, ref, (T*)out, pl.lv, pl.S, M, pl.TW0, pl.R);
+    return check_launch();
+}
+
+}  // namespace dtlr
+
+using namespace dtlr;
+
+extern "C" int dtlr_msda_encoder_forward(const void* value, const void* ow, const float* ref, const int* level_hw,
+                                         int N, int M, int D, int L, int P, int halo,
+                                         int dtype, int ow_dtype, void* out, void* stream)
+{
+    if (!value || !ow || !ref || !level_hw || !out) return DTLR_EINVAL;
+    if (N <= 0 || M <= 0 || halo < 0) return DTLR_EINVAL;
+    if (L != 4 || P != 4 || D != 32) return DTLR_ESHAPE;
+    EncPlan pl;
+    const int elem = dtype == DTLR_F32 ? 4 : 2;
+    if (!make_plan(level_hw, elem, halo, pl)) return DTLR_ESHAPE;
+    hipStream_t st = (hipStream_t)stream;
+    if (dtype == DTLR_F32 && ow_dtype == DTLR_F32) return launch_enc<float, float>(value, ow, ref, out, pl, N, M, st);
+    if (dtype == DTLR_BF16 && ow_dtype == DTLR_F32) return launch_enc<uint16_t, float>(value, ow, ref, out, pl, N, M, st);
+    if (dtype == DTLR_BF16 && ow_dtype == DTLR_BF16) return launch_enc<uint16_t, uint16_t>(value, ow, ref, out, pl, N, M, st);
+    return DTLR_EDTYPE;
+}

@@ -46,18 +46,22 @@ class DTLREngine:
         self.w: Dict[str, torch.Tensor] = {}
         self._pack(state_dict)
         self._shape_cache: Dict[tuple, dict] = {}
+        self.use_lds_msda = True       # encoder MSDA with LDS-staged windows (False: gather kernel)
 
     # ------------------------------------------------------------------------------ packing
     def _put(self, name, t, dtype=None):
         self.w[name] = t.to(device=self.device, dtype=dtype or self.dtype).contiguous()
 
     def _put_conv(self, name, w, b):
-        self.w[name + ".w"] = w.to(device=self.device, dtype=self.dtype).contiguous(memory_format=torch.channels_last)
-        self.w[name + ".b"] = b.to(device=self.device, dtype=self.dtype).contiguous()
+        if w.shape[2] == 1 and w.shape[3] == 1:      # 1x1 conv == linear over NHWC pixels: [Cout, Cin]
+            self.w[name + ".w"] = w.flatten(1).to(device=self.device, dtype=self.dtype).contiguous()
+        else:
+            self.w[name + ".w"] = w.to(device=self.device, dtype=self.dtype).contiguous(memory_format=torch.channels_last)
+        self.w[name + ".b"] = b.to(device=self.device, dtype=torch.float32).contiguous()
 
     def _put_linear(self, name, w, b):
         self._put(name + ".w", w)
-        self._put(name + ".b", b)
+        self._put(name + ".b", b, torch.float32)          # biases enter the GEMM epilogue in fp32
 
     def _pack(self, sd):
         cfg, f32 = self.cfg, torch.float32
@@ -131,10 +135,16 @@ class DTLREngine:
 
     # ------------------------------------------------------------------------------ stages
     def _conv(self, name, x, stride, padding, relu=False, residual=None):
-        return ops.conv2d_nhwc(x, self.w[name + ".w"], self.w[name + ".b"], stride, padding, relu, residual)
+        """NHWC convolution with the folded FrozenBN bias, optional residual add, then ReLU."""
+        w = self.w[name + ".w"]
+        if w.dim() == 2:                              # 1x1: the MFMA GEMM with the whole tail fused
+            if stride != 1:
+                x = x[:, ::stride, ::stride, :].contiguous()
+            return ops.linear(x, w, self.w[name + ".b"], relu=(2 if relu else 0), residual=residual)
+        return ops.conv2d_nhwc(x, w, self.w[name + ".b"].to(x.dtype), stride, padding, relu, residual)
 
-    def _lin(self, name, x, relu=False, residual=None):
-        return ops.linear(x, self.w[name + ".w"], self.w[name + ".b"], relu, residual)
+    def _lin(self, name, x, relu=False, residual=None, a2=None, row_mask=None, out_dtype=None):
+        return ops.linear(x, self.w[name + ".w"], self.w[name + ".b"], relu, residual, a2, row_mask, out_dtype)
 
     def _ln(self, name, x, residual=None):
         return ops.layernorm(x, self.w[name + ".w"], self.w[name + ".b"], 1e-5, residual)
@@ -225,20 +235,22 @@ class DTLREngine:
         shapes = torch.as_tensor(level_hw, dtype=torch.long, device=dev)
         lsi = torch.cat((shapes.new_zeros((1,)), shapes.prod(1).cumsum(0)[:-1]))
         return dict(masks=masks, pos=pos, mask_flat=mask_flat, valid_ratios=vr, enc_ref=ref.contiguous(),
-                    proposals=prop, keep=keep, shapes=shapes, lsi=lsi, has_padding=has_padding)
+                    proposals=prop, keep=keep, shapes=shapes, lsi=lsi, has_padding=has_padding,
+                    level_hw=[(int(h), int(w)) for h, w in level_hw])
 
-    def _msda_module(self, name, query, ref, value_src, g, n_points):
+    def _msda_module(self, name, query, query_pos, ref, value_src, g, n_points):
         """MSDeformAttn.forward (ops/modules/ms_deform_attn.py:78-126) without the output
-        projection (fused by the caller with residual + LayerNorm)."""
+        projection (done by the caller, followed by the fused residual + LayerNorm).
+        query + query_pos is formed in the GEMM prologue; the padding fill of `value` is its epilogue."""
         cfg = self.cfg
         B, Lq, C = query.shape
         S = value_src.shape[1]
         M, L, P = cfg.nheads, cfg.num_feature_levels, n_points
-        value = self._lin(name + ".value", value_src)
-        if g["has_padding"]:
-            value = value.masked_fill(g["mask_flat"][..., None], 0.0)
-        ow = self._lin(name + ".ow", query)
+        value = self._lin(name + ".value", value_src, row_mask=g["mask_flat"] if g["has_padding"] else None)
+        ow = self._lin(name + ".ow", query, a2=query_pos, out_dtype=torch.float32)
         if L == 4 and P == 4:
+            if Lq == S and ref.shape[-1] == 2 and C // M == 32 and self.use_lds_msda:      # encoder self-attention
+                return ops.msda_encoder(value.view(B, S, M, C // M), g["level_hw"], ow, ref)
             return ops.msda_fused(value.view(B, S, M, C // M), g["shapes"], g["lsi"], ow, ref)
         ow = ow.float()
         off = ow[..., : M * L * P * 2].reshape(B, Lq, M, L, P, 2)
@@ -253,10 +265,10 @@ class DTLREngine:
     def encoder(self, src, g):
         """TransformerEncoder.forward + DeformableTransformerEncoderLayer.forward
         (deformable_transformer.py:494-580, 804-823)."""
-        pos = g["pos"].to(src.dtype)
+        pos = g["pos"].to(src.dtype).contiguous()
         for n in range(self.cfg.enc_layers):
             q = f"enc{n}."
-            a = self._msda_module(q + "attn", src + pos, g["enc_ref"], src, g, self.cfg.enc_n_points)
+            a = self._msda_module(q + "attn", src, pos, g["enc_ref"], src, g, self.cfg.enc_n_points)
             src = self._ln(q + "norm1", self._lin(q + "attn.out", a), residual=src)
             h = self._lin(q + "ff1", src, relu=True)
             src = self._ln(q + "norm2", self._lin(q + "ff2", h), residual=src)
@@ -313,12 +325,12 @@ class DTLREngine:
             sine = self._sine_embed(ref_in[:, :, 0, :]).to(self.dtype)
             qpos = self._lin("dec.rph1", self._lin("dec.rph0", sine, relu=True))
             # self attention (q = k = tgt + query_pos, v = tgt)
-            qk = self._lin(q + "sa.qk", tgt + qpos)
+            qk = self._lin(q + "sa.qk", tgt, a2=qpos)
             v = self._lin(q + "sa.v", tgt)
             a = ops.mha(qk, v, cfg.nheads)
             tgt = self._ln(q + "norm2", self._lin(q + "sa.out", a), residual=tgt)
             # deformable cross attention
-            a = self._msda_module(q + "attn", tgt + qpos, ref_in, memory, g, cfg.dec_n_points)
+            a = self._msda_module(q + "attn", tgt, qpos, ref_in, memory, g, cfg.dec_n_points)
             tgt = self._ln(q + "norm1", self._lin(q + "attn.out", a), residual=tgt)
             # ffn
             h = self._lin(q + "ff1", tgt, relu=True)

@@ -18,7 +18,7 @@ from . import MultiScaleDeformableAttention as _msda
 from . import _lib
 
 # operators still served by ROCm libraries via torch (shrinks as kernels land)
-LIBRARY_BACKED = {"linear", "conv2d_nhwc", "maxpool_nhwc", "groupnorm_tokens", "mha", "topk", "sort"}
+LIBRARY_BACKED = {"conv2d_nhwc", "maxpool_nhwc", "groupnorm_tokens", "mha", "topk", "sort"}
 
 _DT = {torch.float32: _lib.DTLR_F32, torch.bfloat16: _lib.DTLR_BF16, torch.float64: _lib.DTLR_F64}
 
@@ -30,14 +30,46 @@ def require_cuda(t: torch.Tensor, what: str = "input") -> None:
 
 
 # --------------------------------------------------------------------------------------------
-def linear(x, w, b=None, relu: bool = False, residual=None):
-    """y = x @ w.T + b [+ReLU] [+residual]."""
-    y = F.linear(x, w, b)
-    if relu:
+def linear(x, w, b=None, relu=False, residual=None, a2=None, row_mask=None, out_dtype=None):
+    """y = epilogue((x [+ a2]) @ w.T): + b -> ReLU (relu=True/1) -> zero rows where row_mask -> + residual
+    -> ReLU (relu=2, the ResNet bottleneck tail).
+    x [..., K] and w [N, K] share a dtype (bf16 or fp32); b fp32 [N]; row_mask bool [...];
+    residual [..., N] in the output dtype.  HIP MFMA kernel (dtlr_gemm_nt); no library fallback
+    except shapes the kernel does not take (K not a multiple of the 128-byte slab)."""
+    K = x.shape[-1]
+    N = w.shape[0]
+    out_dtype = out_dtype or x.dtype
+    slab = 64 if x.dtype == torch.bfloat16 else 32
+    if x.dtype in (torch.bfloat16, torch.float32) and w.dtype == x.dtype and K % slab == 0 \
+            and (x.dtype == torch.bfloat16 or out_dtype == torch.float32):
+        x = x if x.is_contiguous() else x.contiguous()
+        if a2 is not None and not a2.is_contiguous():
+            a2 = a2.contiguous()
+        if residual is not None:
+            residual = residual if residual.is_contiguous() else residual.contiguous()
+            assert residual.dtype == out_dtype
+        if b is not None and b.dtype != torch.float32:
+            b = b.float()
+        M = x.numel() // K
+        y = torch.empty(x.shape[:-1] + (N,), dtype=out_dtype, device=x.device)
+        code = _lib.lib().dtlr_gemm_nt(x.data_ptr(), 0 if a2 is None else a2.data_ptr(), w.data_ptr(),
+                                       0 if b is None else b.data_ptr(), 0 if residual is None else residual.data_ptr(),
+                                       0 if row_mask is None else row_mask.data_ptr(), y.data_ptr(),
+                                       M, N, K, int(relu), _DT[x.dtype], _DT[out_dtype], _lib.current_stream())
+        _lib.check(code, "dtlr_gemm_nt")
+        return y
+    if a2 is not None:
+        x = x + a2
+    y = F.linear(x, w, None if b is None else b.to(x.dtype))
+    if int(relu) == 1:
         y = F.relu(y, inplace=True)
+    if row_mask is not None:
+        y = y.masked_fill(row_mask[..., None], 0.0)
     if residual is not None:
         y = y + residual
-    return y
+    if int(relu) == 2:
+        y = F.relu(y, inplace=True)
+    return y.to(out_dtype)
 
 
 def layernorm(x, w, b, eps: float = 1e-5, residual=None):
@@ -124,6 +156,32 @@ def msda_fused(value, spatial_shapes, level_start_index, ow, ref):
     if ev is not None:
         b.record(st)
         ev.append((a, b, N, Lq, S))
+    return out
+
+
+MSDA_HALO = int(__import__("os").environ.get("DTLR_MSDA_HALO", "8"))
+
+
+def msda_encoder(value, level_hw, ow, ref):
+    """Encoder MSDA (Lq == S, queries are the level pixels) with LDS-staged value windows.
+    value [N,S,M,32] fp32/bf16; level_hw: HOST list of (H_l, W_l); ow [N,S,M*48]; ref [N,S,4,2] fp32."""
+    N, S, M, D = value.shape
+    assert len(level_hw) == 4 and sum(h * w for h, w in level_hw) == S and ow.shape[1] == S and D == 32
+    assert value.is_contiguous() and ow.is_contiguous() and ref.is_contiguous() and ref.dtype == torch.float32
+    import ctypes
+    hw = (ctypes.c_int * 8)(*[int(v) for pair in level_hw for v in pair])
+    out = torch.empty((N, S, M * D), dtype=value.dtype, device=value.device)
+    ev = MSDA_EVENTS
+    if ev is not None:
+        st = torch.cuda.current_stream()
+        a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        a.record(st)
+    code = _lib.lib().dtlr_msda_encoder_forward(value.data_ptr(), ow.data_ptr(), ref.data_ptr(), hw, N, M, D, 4, 4, MSDA_HALO,
+                                                _DT[value.dtype], _DT[ow.dtype], out.data_ptr(), _lib.current_stream())
+    _lib.check(code, "dtlr_msda_encoder_forward")
+    if ev is not None:
+        b.record(st)
+        ev.append((a, b, N, S, S))
     return out
 
 

@@ -69,6 +69,21 @@ int dtlr_msda_fused_forward(const void *value, const int64_t *shapes, const int6
                             int dtype, int ow_dtype, void *out, void *stream);
 
 /* ---------------------------------------------------------------------------------------------
+ * Encoder self-attention form of the above (queries ARE the pixels of the L = 4 levels, Lq = S), with
+ * the value windows of each (x-tile, head) staged in LDS and a global-memory path for samples that
+ * leave the window.  Same inputs/outputs/arithmetic as dtlr_msda_fused_forward with ref_dim = 2.
+ * Replaces: MSDeformAttn.forward lines 97-124 as called from DeformableTransformerEncoderLayer
+ *           (models/dino/deformable_transformer.py:810-813).
+ *   level_hw  HOST array [L*2] = (H_0, W_0, ..., H_3, W_3) -- the tiling is planned on the host
+ *   halo      extra window columns on each side, in pixels of every level (offsets beyond it still
+ *             give exact results through the global path)
+ *   D must be 32, L = P = 4.  Returns DTLR_ESHAPE if no window plan fits the 160 KB LDS.
+ */
+int dtlr_msda_encoder_forward(const void *value, const void *ow, const float *ref, const int *level_hw,
+                              int N, int M, int D, int L, int P, int halo,
+                              int dtype, int ow_dtype, void *out, void *stream);
+
+/* ---------------------------------------------------------------------------------------------
  * y = LayerNorm(x [+ residual]) * gamma + beta over rows of C channels (C multiple of 256).
  * Replaces: the `src = norm(src + dropout(src2))` post-norm pattern of
  *           DeformableTransformerEncoderLayer / DecoderLayer (deformable_transformer.py:804-823,
@@ -92,6 +107,24 @@ int dtlr_layernorm(const void *x, const void *residual, const float *gamma, cons
 int dtlr_mha_forward(const void *qk, const void *v, void *vt_workspace, void *out,
                      int B, int L, int H, int head_dim, int dtype, void *stream);
 long dtlr_mha_workspace_bytes(int B, int L, int H, int head_dim);
+
+/* ---------------------------------------------------------------------------------------------
+ * C[M,N] = epilogue( (A [+ A2])[M,K] . W[N,K]^T )   -- every nn.Linear and 1x1 convolution on the path.
+ * Replaces: F.linear / nn.Linear.forward call sites of the hot path: MSDeformAttn's value_proj,
+ *           sampling_offsets|attention_weights, output_proj (ops/modules/ms_deform_attn.py:94-98,125);
+ *           FFN linear1/linear2 (deformable_transformer.py:804-808,876-880); MultiheadAttention in/out
+ *           projections (:847); enc_output, class/bbox heads (:338-342, dino.py:339-354); ref_point_head;
+ *           1x1 Conv2d of input_proj (dino.py:121-123) and of the ResNet bottlenecks on NHWC tokens.
+ *   A, A2 (may be NULL): [M,K] in_dtype; the prologue adds them (query = src + pos).
+ *   W: [N,K] in_dtype (nn.Linear layout).  bias (may be NULL): [N] fp32.
+ *   epilogue order: + bias -> ReLU (if relu == 1) -> zero rows where row_mask[m] != 0 (may be NULL,
+ *   [M] bytes; value.masked_fill of ms_deform_attn.py:95-96) -> + residual (may be NULL, [M,N] out_dtype)
+ *   -> ReLU (if relu == 2: the bottleneck tail relu(conv3 + identity)) -> store.
+ *   in_dtype BF16 (K % 64 == 0; fp32 accumulate; out BF16 or F32) or F32 (K % 32 == 0; exact fp32 MFMA).
+ */
+int dtlr_gemm_nt(const void *A, const void *A2, const void *W, const float *bias,
+                 const void *residual, const unsigned char *row_mask, void *C,
+                 int M, int N, int K, int relu, int in_dtype, int out_dtype, void *stream);
 
 #ifdef __cplusplus
 }

@@ -105,3 +105,104 @@ def test_mha_softmax_extremes():
     got = ops.mha(qk.cuda(), v.cuda(), H).float().cpu()
     assert torch.isfinite(got).all()
     assert (got - want).abs().max() <= 2 ** -6 * v.float().abs().max() + 1e-3
+
+
+def _gemm_ref(x, w, b, relu, res, a2, mask):
+    a = x if a2 is None else x + a2
+    y = a.double() @ w.double().t()
+    if b is not None:
+        y = y + b.double()
+    if relu == 1:
+        y = y.clamp(min=0)
+    if mask is not None:
+        y = y.masked_fill(mask[..., None], 0.0)
+    if res is not None:
+        y = y + res.double()
+    if relu == 2:
+        y = y.clamp(min=0)
+    return y.float()
+
+
+GEMM_SHAPES = [(128, 128, 32), (300, 166, 256), (129, 384, 64), (1, 4, 256), (1000, 2048, 256), (777, 256, 2048),
+               (5440, 256, 256), (64, 7356, 256)]
+
+
+@pytest.mark.parametrize("M,N,K", GEMM_SHAPES)
+def test_gemm_f32_exact_mfma(M, N, K):
+    """fp32-in MFMA GEMM (v_mfma_f32_16x16x4_f32) vs an fp64 reference; all epilogue/prologue combos.
+    Includes M/N tails (N = 166, 4, 7356 are not tile multiples) -- asymmetric random operands."""
+    from dtlr_amd import ops
+    x, a2 = _rand((M, K), 1), _rand((M, K), 2)
+    w, b = _rand((N, K), 3) / np.sqrt(K), _rand((N,), 4)
+    res = _rand((M, N), 5)
+    mask = torch.from_numpy(np.random.Generator(np.random.PCG64(6)).random(M) < 0.3)
+    for relu, use_b, use_res, use_a2, use_mask in ((0, False, False, False, False), (1, True, False, False, False),
+                                                   (0, True, True, True, True), (2, True, True, False, False)):
+        want = _gemm_ref(x, w, b if use_b else None, relu, res if use_res else None, a2 if use_a2 else None, mask if use_mask else None)
+        got = ops.linear(x.cuda(), w.cuda(), b.cuda() if use_b else None, relu, res.cuda() if use_res else None,
+                         a2.cuda() if use_a2 else None, mask.cuda() if use_mask else None).cpu()
+        assert got.shape == want.shape
+        assert (got - want).abs().max() < 2e-5 * max(1.0, want.abs().max().item()), (relu, use_b, use_res, use_a2, use_mask)
+
+
+@pytest.mark.parametrize("M,N,K", [s for s in GEMM_SHAPES if s[2] % 64 == 0])
+@pytest.mark.parametrize("out_f32", [False, True])
+def test_gemm_bf16(M, N, K, out_f32):
+    """bf16 MFMA GEMM, fp32 accumulation: vs fp64 reference on the same bf16-rounded operands.
+    Tolerance: bf16 rounding of the a+a2 prologue (2^-8 relative per element, averaged over K) and of
+    the bf16 output (2^-8 relative)."""
+    from dtlr_amd import ops
+    x, a2 = _rand((M, K), 1).bfloat16(), _rand((M, K), 2).bfloat16()
+    w, b = (_rand((N, K), 3) / np.sqrt(K)).bfloat16(), _rand((N,), 4)
+    od = torch.float32 if out_f32 else torch.bfloat16
+    res = _rand((M, N), 5).to(od)
+    mask = torch.from_numpy(np.random.Generator(np.random.PCG64(6)).random(M) < 0.3)
+    for relu, use_b, use_res, use_a2, use_mask in ((0, False, False, False, False), (1, True, False, False, False),
+                                                   (0, True, True, True, True), (2, True, True, False, False)):
+        xa = (x.float() + a2.float()).bfloat16().float() if use_a2 else x.float()
+        want = _gemm_ref(xa, w.float(), b if use_b else None, relu, res.float() if use_res else None, None, mask if use_mask else None)
+        got = ops.linear(x.cuda(), w.cuda(), b.cuda() if use_b else None, relu, res.cuda() if use_res else None,
+                         a2.cuda() if use_a2 else None, mask.cuda() if use_mask else None, out_dtype=od).cpu()
+        assert got.dtype == od and got.shape == want.shape
+        scale = max(1.0, want.abs().max().item())
+        tol = (2e-5 if out_f32 else 2 ** -8) * scale + 1e-4
+        assert (got.float() - want).abs().max() < tol, (relu, use_b, use_res, use_a2, use_mask, (got.float() - want).abs().max().item())
+
+
+@pytest.mark.parametrize("level_hw,offscale", [([(16, 256), (8, 128), (4, 64), (2, 32)], 2.0),
+                                               ([(16, 256), (8, 128), (4, 64), (2, 32)], 40.0),     # far offsets: global path
+                                               ([(5, 83), (3, 42), (2, 21), (1, 11)], 3.0),          # odd sizes (not exact halves)
+                                               ([(4, 32), (2, 16), (1, 8), (1, 4)], 1.5),
+                                               ([(1, 7), (1, 4), (1, 2), (1, 1)], 1.0)])
+def test_msda_encoder_lds_vs_oracle(level_hw, offscale):
+    """LDS-staged encoder kernel == oracle MSDeformAttn (softmax + locations + sampling) for every query
+    of every level, including samples that leave the staged window (global path) and level shapes that
+    are not exact halves; checked for the default halo and halo 0 (window = tile only)."""
+    from dtlr_amd import ops
+    from oracle import dtlr_oracle as O
+    N, M, D, L, P = 2, 8, 32, 4, 4
+    S = sum(h * w for h, w in level_hw)
+    v, s, lsi, _, _ = msda_inputs(N, M, D, S, P, level_hw, seed=13)
+    ow = _rand((N, S, M * L * P * 3), 15)
+    ow[..., : M * L * P * 2] *= offscale
+    # encoder reference points with a valid-ratio-like scaling (deformable_transformer.py:479-492)
+    vr = torch.tensor([[[1.0, 1.0]] * 4, [[0.75, 1.0]] * 4])
+    ref = O.encoder_reference_points(s, vr).contiguous()
+    off = ow[..., : M * L * P * 2].view(N, S, M, L, P, 2)
+    aw = torch.softmax(ow[..., M * L * P * 2:].view(N, S, M, L * P), -1).view(N, S, M, L, P)
+    want = O.ms_deform_attn_core(v, s, O.msda_sampling_locations(ref, off, s, P), aw)
+    old = ops.MSDA_HALO
+    try:
+        for halo in (8, 0):
+            ops.MSDA_HALO = halo
+            got = ops.msda_encoder(v.cuda(), level_hw, ow.cuda(), ref.cuda()).cpu()
+            assert (got - want).abs().max() < 5e-6, (halo, (got - want).abs().max().item())
+        ops.MSDA_HALO = 8
+        gotb = ops.msda_encoder(v.bfloat16().cuda(), level_hw, ow.cuda(), ref.cuda()).float().cpu()
+        wantb = O.ms_deform_attn_core(v.bfloat16().float(), s, O.msda_sampling_locations(ref, off, s, P), aw)
+        assert (gotb - wantb).abs().max() <= wantb.abs().max() * 2 ** -8 + 1e-6
+        # must agree with the gather kernel bit-for-bit in fp32 (same arithmetic order)
+        g2 = ops.msda_fused(v.cuda(), s.cuda(), lsi.cuda(), ow.cuda(), ref.cuda()).cpu()
+        assert (g2 - got).abs().max() < 1e-6
+    finally:
+        ops.MSDA_HALO = old

@@ -82,6 +82,17 @@ def main():
                 r = ref2 if tag == "enc" else ref4
                 ms = timeit(lambda: ops.msda_fused(value, shapes, lsi, ow, r), args.iters)
                 res.append({"kernel": name, "ms": ms, "algorithmic_bytes": alg, "GBps": alg / ms / 1e6})
+            name = f"msda_lds_{tag}_{dt_name}"
+            if tag == "enc" and want(name):
+                # encoder-like reference grid (pixel centres), offsets of a few pixels
+                ys = [torch.linspace(0.5, h - 0.5, h) / h for h, w in shapes_l]
+                xs = [torch.linspace(0.5, w - 0.5, w) / w for h, w in shapes_l]
+                rp = torch.cat([torch.stack(torch.meshgrid(y, x, indexing="ij")[::-1], -1).reshape(-1, 2) for y, x in zip(ys, xs)], 0)
+                refg = rp[None, :, None, :].expand(B, S, L, 2).contiguous().to(dev)
+                ms = timeit(lambda: ops.msda_encoder(value, shapes_l, ow, refg), args.iters)
+                res.append({"kernel": name, "ms": ms, "algorithmic_bytes": alg, "GBps": alg / ms / 1e6})
+                ms = timeit(lambda: ops.msda_fused(value, shapes, lsi, ow, refg), args.iters)
+                res.append({"kernel": name.replace("lds", "gather_gridref"), "ms": ms, "algorithmic_bytes": alg, "GBps": alg / ms / 1e6})
             del ow, loc, aw, off
         T = B * S
         x = torch.randn((T, 256), generator=g).to(dev).to(dt)
@@ -99,6 +110,26 @@ def main():
         ms = timeit(lambda: ops.mha(qk, v, 8), args.iters)
         flops = B * 8 * 2 * 2 * 900 * 900 * 32
         res.append({"kernel": "mha_bf16", "ms": ms, "flops": flops, "TFLOPs": flops / ms / 1e9})
+    # the MFMA GEMM at the encoder shapes vs the library (hipBLASLt through torch) on the same data
+    import torch.nn.functional as F
+    T = B * S
+    for (N_, K_, relu) in ((256, 256, 0), (384, 256, 0), (2048, 256, 1), (256, 2048, 0)):
+        for dt_name, dt in (("bf16", torch.bfloat16), ("f32", torch.float32)):
+            name = f"gemm_{dt_name}_M{T}_N{N_}_K{K_}"
+            if not want(name) and not want("gemm"):
+                continue
+            if only and "gemm" not in only and name not in only:
+                continue
+            x = torch.randn((T, K_), generator=g).to(dev).to(dt)
+            w = (torch.randn((N_, K_), generator=g) / K_ ** 0.5).to(dev).to(dt)
+            bb = torch.randn((N_,), generator=g).to(dev)
+            flops = 2.0 * T * N_ * K_
+            ms = timeit(lambda: ops.linear(x, w, bb, relu), max(5, args.iters // 2))
+            res.append({"kernel": name, "ms": ms, "TFLOPs": flops / ms / 1e9})
+            bl = bb.to(dt)
+            ms = timeit(lambda: (F.relu(F.linear(x, w, bl), inplace=True) if relu else F.linear(x, w, bl)), max(5, args.iters // 2))
+            res.append({"kernel": name + "_library", "ms": ms, "TFLOPs": flops / ms / 1e9})
+            del x, w
     for r in res:
         print(json.dumps(r))
 
