@@ -18,8 +18,9 @@
 //   * bf16: v_mfma_f32_16x16x32_bf16 (one per 64-byte k-slab);  fp32: v_mfma_f32_16x16x4_f32 (exact
 //     fp32, four per 64-byte slab; the lane's 4 consecutive k of a 16-byte read feed MFMA j = 0..3 --
 //     a k-permutation applied identically to both operands, so the sum is unchanged).
-//   * workgroup ids are remapped XCD-aware (bijective form) so the tiles sharing an activation panel
-//     run on one XCD's L2.
+//   * persistent tile chains: a workgroup walks a contiguous run of output tiles (channel tiles fastest, so
+//     a chain re-reads its activation rows from its own XCD's L2) as one continuously pipelined slab
+//     stream -- the load-latency prologue is paid once per workgroup, not once per 128x128 tile.
 // Fused prologue: A + A2 (query = src + pos, deformable_transformer.py:797-812).
 // Fused epilogue: + bias, ReLU, zero masked rows (value.masked_fill, ms_deform_attn.py:95-96),
 //                 + residual, ReLU-after-residual (ResNet bottleneck tail), output fp32 or bf16.
@@ -81,48 +82,88 @@ template <> struct Out<uint16_t> {
     static __device__ __forceinline__ void st(uint16_t* p, float v) { *p = f32_to_bf16(v); }
 };
 
-template <typename T, typename OutT, bool HAS_A2>
+// Implicit-GEMM convolution (CONV = true): the "A" operand is gathered on the fly from an NHWC image,
+// M = B*Ho*Wo output pixels, K = KH*KW*Cin ordered (kh, kw, ci) so that a 128-byte K slab lies inside
+// one filter tap (Cin*sizeof(T) % 128 == 0) and is one contiguous, 16-byte-aligned run of channels;
+// taps that fall into the zero padding contribute zeros.  Weights are packed [Cout][KH][KW][Cin].
+struct ConvP { int H, W, Cin, Ho, Wo, KH, KW, stride, pad; };
+
+template <typename T, typename OutT, bool HAS_A2, bool CONV>
 __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(
     const T* __restrict__ A, const T* __restrict__ A2, const T* __restrict__ W,
     const float* __restrict__ bias, const OutT* __restrict__ residual, const uint8_t* __restrict__ row_mask,
-    OutT* __restrict__ C, int M, int N, int K, int flags, int nN, int nwg)
+    OutT* __restrict__ C, int M, int N, int K, int flags, int nN, int ntiles, int tiles_per_block, ConvP cp)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];   // [2 stages][W tile | X tile]
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int g = lane >> 4, n = lane & 15;
     const int wm = wave >> 1, wn = wave & 1;
-    // XCD-aware bijective remap (cdna_hip_programming.md section 5, "XCD swizzle must be bijective")
-    const int bid = blockIdx.x, q8 = nwg >> 3, r8 = nwg & 7, xcd = bid & 7;
-    const int wgid = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + (bid >> 3);
-    const int tn = wgid % nN, tm = wgid / nN;
-    const int m0 = tm * BM, n0 = tn * BN;
     constexpr int BK = GT<T>::BK;
     const int nk = K / BK;
 
-    // staging: each operand tile = 128 rows x 128 B = 1024 16-byte chunks; thread t takes chunks t + 256 i
-    // (8 consecutive lanes cover one 128-byte row slab).  Row r of chunk i = (tid>>3) + 32 i, kc = tid & 7.
+    // PERSISTENT tile chain: this block owns tiles [t_begin, t_end) of the (tm, tn) grid, tn fastest, and
+    // walks them as ONE flat stream of K slabs, software-pipelined across tile boundaries: the global
+    // loads of the next tile's first slab are in flight while the current tile's last slab is being
+    // multiplied.  With K = 256 a tile is only 4 slabs, so paying the ~2 us load latency once per
+    // block instead of once per tile is worth more than any in-tile tuning; consecutive tiles of a
+    // chain share their activation rows (tn fastest), re-read from L2.
+    const int t_begin = blockIdx.x * tiles_per_block;
+    const int t_end = min(t_begin + tiles_per_block, ntiles);
+    if (t_begin >= t_end) return;
+    const int total = (t_end - t_begin) * nk;
+
+    // staging: each operand tile = 128 rows x 128 B = 1024 16-byte chunks; thread t takes rows srow + 32 i
+    // (8 consecutive lanes cover one 128-byte row slab), kc = tid & 7.
     const int srow = tid >> 3, kc = tid & 7;
     const int lds0 = srow * LDS_ROW + kc * 16;
-    long a_off[4], w_off[4];                                    // byte offsets of the chunk at k-slab 0
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        const long ar = min(m0 + srow + 32 * i, M - 1), wr = min(n0 + srow + 32 * i, N - 1);   // tails: clamp loads, skip stores
-        a_off[i] = (ar * K) * (long)sizeof(T) + kc * 16;
-        w_off[i] = (wr * K) * (long)sizeof(T) + kc * 16;
-    }
+    long a_off[4], w_off[4];                                    // loader state: byte offsets at k-slab 0
+    int hi0[4], wi0[4];                                         // CONV: top-left input coordinate of the pixel
+    const int slabs_per_tap = CONV ? (cp.Cin * (int)sizeof(T)) / SLAB : 1;
     const char* Ab = reinterpret_cast<const char*>(A);
     const char* A2b = reinterpret_cast<const char*>(A2);
     const char* Wb = reinterpret_cast<const char*>(W);
-    // Staging registers are named scalars on purpose: as arrays written under `if (kt + 1 < nk)` hipcc
+
+#define SET_LOAD_TILE(TILE)                                                                        \
+    {                                                                                              \
+        const int lm0_ = ((TILE) / nN) * BM, ln0_ = ((TILE) % nN) * BN;                            \
+        _Pragma("unroll") for (int i = 0; i < 4; ++i) {                                            \
+            const long ar = min(lm0_ + srow + 32 * i, M - 1), wr = min(ln0_ + srow + 32 * i, N - 1); \
+            w_off[i] = (wr * K) * (long)sizeof(T) + kc * 16;                                       \
+            if (CONV) {                                                                            \
+                const int hw = cp.Ho * cp.Wo;                                                      \
+                const int bimg = (int)(ar / hw), rem = (int)(ar % hw);                             \
+                hi0[i] = (rem / cp.Wo) * cp.stride - cp.pad;                                       \
+                wi0[i] = (rem % cp.Wo) * cp.stride - cp.pad;                                       \
+                a_off[i] = (long)bimg * cp.H * cp.W * cp.Cin * (long)sizeof(T) + kc * 16;          \
+            } else {                                                                               \
+                hi0[i] = wi0[i] = 0;                                                               \
+                a_off[i] = (ar * K) * (long)sizeof(T) + kc * 16;                                   \
+            }                                                                                      \
+        }                                                                                          \
+    }
+
+    // Staging registers are named scalars on purpose: as arrays written under a condition hipcc
     // (ROCm 7.2) leaves them in scratch memory (global_load -> scratch_store ... scratch_load -> ds_write).
     uint4 ra0, ra1, ra2, ra3, rw0, rw1, rw2, rw3;
 #define GLOAD1(I, OFF)                                                                             \
     rw##I = *reinterpret_cast<const uint4*>(Wb + w_off[I] + (OFF));                                \
-    ra##I = *reinterpret_cast<const uint4*>(Ab + a_off[I] + (OFF));                                \
-    if (HAS_A2) ra##I = GT<T>::add(ra##I, *reinterpret_cast<const uint4*>(A2b + a_off[I] + (OFF)));
+    if (CONV) {                                                                                    \
+        const int hi_ = hi0[I] + kh_, wi_ = wi0[I] + kw_;                                          \
+        const bool ok_ = hi_ >= 0 && hi_ < cp.H && wi_ >= 0 && wi_ < cp.W;                         \
+        const long po_ = ((long)(ok_ ? hi_ : 0) * cp.W + (ok_ ? wi_ : 0)) * cp.Cin * (long)sizeof(T) + coff_; \
+        const uint4 t_ = *reinterpret_cast<const uint4*>(Ab + a_off[I] + po_);                     \
+        ra##I = ok_ ? t_ : make_uint4(0u, 0u, 0u, 0u);                                             \
+    } else {                                                                                       \
+        ra##I = *reinterpret_cast<const uint4*>(Ab + a_off[I] + (OFF));                            \
+        if (HAS_A2) ra##I = GT<T>::add(ra##I, *reinterpret_cast<const uint4*>(A2b + a_off[I] + (OFF))); \
+    }
 #define GLOAD(KT)                                                                                  \
     {                                                                                              \
         const long off_ = (long)(KT) * SLAB;                                                       \
+        const int tap_ = (KT) / slabs_per_tap;                                                     \
+        const int kh_ = CONV ? tap_ / cp.KW : 0, kw_ = CONV ? tap_ % cp.KW : 0;                    \
+        const long coff_ = (long)((KT) % slabs_per_tap) * SLAB;                                    \
+        (void)kh_; (void)kw_; (void)coff_;                                                         \
         GLOAD1(0, off_) GLOAD1(1, off_) GLOAD1(2, off_) GLOAD1(3, off_)                            \
     }
 #define LSTORE1(I)                                                                                 \
@@ -140,12 +181,19 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(
 #pragma unroll
         for (int ti = 0; ti < 4; ++ti) acc[ci][ti] = f32x4_t{0.f, 0.f, 0.f, 0.f};
 
+    SET_LOAD_TILE(t_begin)
     GLOAD(0)
     LSTORE(0)
     __syncthreads();
-    for (int kt = 0; kt < nk; ++kt) {
-        const int cur = kt & 1;
-        if (kt + 1 < nk) GLOAD(kt + 1)
+    int kt = 0, tile = t_begin;              // slab being multiplied
+    int lkt = 0, ltile = t_begin;            // slab whose loads were issued last
+    for (int s = 0; s < total; ++s) {
+        const int cur = s & 1;
+        const bool more = s + 1 < total;
+        if (more) {
+            if (++lkt == nk) { lkt = 0; ++ltile; SET_LOAD_TILE(ltile) }
+            GLOAD(lkt)
+        }
         const unsigned char* wt = smem + cur * 2 * TILE_BYTES + (wn * 64 + n) * LDS_ROW + g * 16;
         const unsigned char* xt = smem + cur * 2 * TILE_BYTES + TILE_BYTES + (wm * 64 + n) * LDS_ROW + g * 16;
 #pragma unroll
@@ -161,79 +209,115 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(
 #pragma unroll
                 for (int ti = 0; ti < 4; ++ti) GT<T>::mma(wf[ci], xf[ti], acc[ci][ti]);
         }
-        if (kt + 1 < nk) LSTORE(cur ^ 1)
+        if (more) LSTORE(cur ^ 1)
         __syncthreads();
-    }
+        if (++kt < nk) continue;
 
+        // ---- tile finished: epilogue (the next tile's first slab is already in LDS) ----------------------
+        // lane (g,n) holds channels ch = n0 + wn*64 + ci*16 + 4g + r of token m0 + wm*64 + ti*16 + n
+        const int m0 = (tile / nN) * BM, n0 = (tile % nN) * BN;
+        const bool vec_ok = (N & 3) == 0;
+#pragma unroll
+        for (int ti = 0; ti < 4; ++ti) {
+            const int tok = m0 + wm * 64 + ti * 16 + n;
+            const bool tok_ok = tok < M;
+            const bool masked = tok_ok && (flags & EPI_ROWMASK) && row_mask[tok];
+#pragma unroll
+            for (int ci = 0; ci < 4; ++ci) {
+                const int ch = n0 + wn * 64 + ci * 16 + 4 * g;
+                float v[4] = {acc[ci][ti][0], acc[ci][ti][1], acc[ci][ti][2], acc[ci][ti][3]};
+                acc[ci][ti] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+                if (!tok_ok || ch >= N) continue;
+                const bool full = vec_ok && ch + 3 < N;
+                if (flags & EPI_BIAS) {
+                    if (full) { const float4 bb = *reinterpret_cast<const float4*>(bias + ch); v[0] += bb.x; v[1] += bb.y; v[2] += bb.z; v[3] += bb.w; }
+                    else {
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) if (ch + r < N) v[r] += bias[ch + r];
+                    }
+                }
+                if (flags & EPI_RELU) {
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) v[r] = fmaxf(v[r], 0.f);
+                }
+                if (masked) { v[0] = v[1] = v[2] = v[3] = 0.f; }
+                OutT* cptr = C + (long)tok * N + ch;
+                if (full) {
+                    if (flags & EPI_RESIDUAL) { float rr[4]; Out<OutT>::ld4(residual + (long)tok * N + ch, rr); v[0] += rr[0]; v[1] += rr[1]; v[2] += rr[2]; v[3] += rr[3]; }
+                    if (flags & EPI_RELU_POST) {
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) v[r] = fmaxf(v[r], 0.f);
+                    }
+                    Out<OutT>::st4(cptr, v);
+                } else {
+#pragma unroll
+                    for (int r = 0; r < 4; ++r)
+                        if (ch + r < N) {
+                            float x = v[r];
+                            if (flags & EPI_RESIDUAL) x += Out<OutT>::ld(residual + (long)tok * N + ch + r);
+                            if (flags & EPI_RELU_POST) x = fmaxf(x, 0.f);
+                            Out<OutT>::st(cptr + r, x);
+                        }
+                }
+            }
+        }
+        kt = 0; ++tile;
+    }
 #undef GLOAD
 #undef LSTORE
 #undef GLOAD1
 #undef LSTORE1
-    // epilogue: lane (g,n) holds channels ch = n0 + wn*64 + ci*16 + 4g + r of token m0 + wm*64 + ti*16 + n
-    const bool vec_ok = (N & 3) == 0;
-#pragma unroll
-    for (int ti = 0; ti < 4; ++ti) {
-        const int tok = m0 + wm * 64 + ti * 16 + n;
-        if (tok >= M) continue;
-        const bool masked = (flags & EPI_ROWMASK) && row_mask[tok];
-#pragma unroll
-        for (int ci = 0; ci < 4; ++ci) {
-            const int ch = n0 + wn * 64 + ci * 16 + 4 * g;
-            if (ch >= N) continue;
-            float v[4] = {acc[ci][ti][0], acc[ci][ti][1], acc[ci][ti][2], acc[ci][ti][3]};
-            const bool full = vec_ok && ch + 3 < N;
-            if (flags & EPI_BIAS) {
-                if (full) { const float4 bb = *reinterpret_cast<const float4*>(bias + ch); v[0] += bb.x; v[1] += bb.y; v[2] += bb.z; v[3] += bb.w; }
-                else {
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) if (ch + r < N) v[r] += bias[ch + r];
-                }
-            }
-            if (flags & EPI_RELU) {
-#pragma unroll
-                for (int r = 0; r < 4; ++r) v[r] = fmaxf(v[r], 0.f);
-            }
-            if (masked) { v[0] = v[1] = v[2] = v[3] = 0.f; }
-            OutT* cp = C + (long)tok * N + ch;
-            if (full) {
-                if (flags & EPI_RESIDUAL) { float rr[4]; Out<OutT>::ld4(residual + (long)tok * N + ch, rr); v[0] += rr[0]; v[1] += rr[1]; v[2] += rr[2]; v[3] += rr[3]; }
-                if (flags & EPI_RELU_POST) {
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) v[r] = fmaxf(v[r], 0.f);
-                }
-                Out<OutT>::st4(cp, v);
-            } else {
-#pragma unroll
-                for (int r = 0; r < 4; ++r)
-                    if (ch + r < N) {
-                        float x = v[r];
-                        if (flags & EPI_RESIDUAL) x += Out<OutT>::ld(residual + (long)tok * N + ch + r);
-                        if (flags & EPI_RELU_POST) x = fmaxf(x, 0.f);
-                        Out<OutT>::st(cp + r, x);
-                    }
-            }
-        }
-    }
+#undef SET_LOAD_TILE
+}
+
+// tiles per block: enough chains to fill the chip (2 resident workgroups x 256 CUs) a few times over
+static inline int plan_chain(long ntiles) {
+    const long target_blocks = 2 * 256 * 2;
+    long per = (ntiles + target_blocks - 1) / target_blocks;
+    if (per < 1) per = 1;
+    if (per > 64) per = 64;
+    return (int)per;
+}
+
+template <typename T, typename OutT>
+static int launch_conv(const void* X, const void* W, const float* bias, const void* residual, void* C,
+                       int M, int N, int K, int flags, const ConvP& cp, hipStream_t st)
+{
+    const int nM = (M + BM - 1) / BM, nN = (N + BN - 1) / BN;
+    const long nwg = (long)nM * nN;
+    if (nwg > 0x7fffffffL) return DTLR_ESHAPE;
+    const size_t lds = 4 * TILE_BYTES;
+    static bool attr = false;
+    if (!attr) { (void)hipFuncSetAttribute((const void*)gemm_nt_kernel<T, OutT, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); attr = true; }
+    const int per = plan_chain(nwg);
+    const unsigned grid = (unsigned)((nwg + per - 1) / per);
+    hipLaunchKernelGGL((gemm_nt_kernel<T, OutT, false, true>), dim3(grid), dim3(256), lds, st,
+                       (const T*)X, (const T*)nullptr, (const T*)W, bias, (const OutT*)residual, (const uint8_t*)nullptr, (OutT*)C,
+                       M, N, K, flags, nN, (int)nwg, per, cp);
+    return check_launch();
 }
 
 template <typename T, typename OutT>
 static int launch_gemm(const void* A, const void* A2, const void* W, const float* bias, const void* residual,
                        const uint8_t* row_mask, void* C, int M, int N, int K, int flags, hipStream_t st)
 {
+    const ConvP cp{};
+    const int per = plan_chain((long)((M + BM - 1) / BM) * ((N + BN - 1) / BN));
+    const unsigned grid = (unsigned)(((long)((M + BM - 1) / BM) * ((N + BN - 1) / BN) + per - 1) / per);
     const int nM = (M + BM - 1) / BM, nN = (N + BN - 1) / BN;
     const long nwg = (long)nM * nN;
     if (nwg > 0x7fffffffL) return DTLR_ESHAPE;
     const size_t lds = 4 * TILE_BYTES;
     if (A2) {
         static bool attr_a2 = false;
-        if (!attr_a2) { hipFuncSetAttribute((const void*)gemm_nt_kernel<T, OutT, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); attr_a2 = true; }
-        hipLaunchKernelGGL((gemm_nt_kernel<T, OutT, true>), dim3((unsigned)nwg), dim3(256), lds, st,
-                           (const T*)A, (const T*)A2, (const T*)W, bias, (const OutT*)residual, row_mask, (OutT*)C, M, N, K, flags, nN, (int)nwg);
+        if (!attr_a2) { (void)hipFuncSetAttribute((const void*)gemm_nt_kernel<T, OutT, true, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); attr_a2 = true; }
+        hipLaunchKernelGGL((gemm_nt_kernel<T, OutT, true, false>), dim3(grid), dim3(256), lds, st,
+                           (const T*)A, (const T*)A2, (const T*)W, bias, (const OutT*)residual, row_mask, (OutT*)C, M, N, K, flags, nN, (int)nwg, per, cp);
     } else {
         static bool attr = false;
-        if (!attr) { hipFuncSetAttribute((const void*)gemm_nt_kernel<T, OutT, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); attr = true; }
-        hipLaunchKernelGGL((gemm_nt_kernel<T, OutT, false>), dim3((unsigned)nwg), dim3(256), lds, st,
-                           (const T*)A, (const T*)nullptr, (const T*)W, bias, (const OutT*)residual, row_mask, (OutT*)C, M, N, K, flags, nN, (int)nwg);
+        if (!attr) { (void)hipFuncSetAttribute((const void*)gemm_nt_kernel<T, OutT, false, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); attr = true; }
+        hipLaunchKernelGGL((gemm_nt_kernel<T, OutT, false, false>), dim3(grid), dim3(256), lds, st,
+                           (const T*)A, (const T*)nullptr, (const T*)W, bias, (const OutT*)residual, row_mask, (OutT*)C, M, N, K, flags, nN, (int)nwg, per, cp);
     }
     return check_launch();
 }
@@ -263,4 +347,27 @@ extern "C" int dtlr_gemm_nt(const void* A, const void* A2, const void* W, const 
         return DTLR_EDTYPE;
     }
     return DTLR_EDTYPE;
+}
+
+extern "C" int dtlr_conv2d_nhwc(const void* X, const void* W, const float* bias, const void* residual, void* Y,
+                                int B, int H, int Wd, int Cin, int Cout, int KH, int KW, int stride, int pad,
+                                int relu, int dtype, void* stream)
+{
+    if (!X || !W || !Y) return DTLR_EINVAL;
+    if (B <= 0 || H <= 0 || Wd <= 0 || Cin <= 0 || Cout <= 0 || KH <= 0 || KW <= 0 || stride <= 0 || pad < 0) return DTLR_EINVAL;
+    const int elem = dtype == DTLR_BF16 ? 2 : dtype == DTLR_F32 ? 4 : 0;
+    if (!elem) return DTLR_EDTYPE;
+    if ((Cin * elem) % SLAB) return DTLR_ESHAPE;                 // a K slab must stay inside one tap
+    ConvP cp;
+    cp.H = H; cp.W = Wd; cp.Cin = Cin; cp.KH = KH; cp.KW = KW; cp.stride = stride; cp.pad = pad;
+    cp.Ho = (H + 2 * pad - KH) / stride + 1;
+    cp.Wo = (Wd + 2 * pad - KW) / stride + 1;
+    if (cp.Ho <= 0 || cp.Wo <= 0) return DTLR_ESHAPE;
+    const long M = (long)B * cp.Ho * cp.Wo;
+    if (M > 0x7fffffffL) return DTLR_ESHAPE;
+    const int K = KH * KW * Cin;
+    int flags = (bias ? EPI_BIAS : 0) | (relu == 1 ? EPI_RELU : 0) | (relu == 2 ? EPI_RELU_POST : 0) | (residual ? EPI_RESIDUAL : 0);
+    hipStream_t st = (hipStream_t)stream;
+    if (dtype == DTLR_BF16) return launch_conv<uint16_t, uint16_t>(X, W, bias, residual, Y, (int)M, Cout, K, flags, cp, st);
+    return launch_conv<float, float>(X, W, bias, residual, Y, (int)M, Cout, K, flags, cp, st);
 }

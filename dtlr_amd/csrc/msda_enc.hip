@@ -100,11 +100,22 @@ __global__ __launch_bounds__(256) void msda_enc_lds_kernel(
         const int nchunk = lv.H[l] * ww * CP;
         const T* src = vimg + (long)lv.start[l] * MD;
         unsigned char* dst = smem + (long)lv.loff[l] * PIX_BYTES;
-        for (int c = tid; c < nchunk; c += 256) {
-            const int part = c % CP, pc = c / CP;
-            const int col = pc % ww, row = pc / ww;
-            const uint4 d = *reinterpret_cast<const uint4*>(src + (long)(row * lv.W[l] + wc0[l] + col) * MD + part * VEC);
-            *reinterpret_cast<uint4*>(dst + (row * lv.wmax[l] + col) * PIX_BYTES + part * 16) = d;
+        // 4 independent 16-byte loads in flight per lane before the first LDS store (a plain
+        // load->store loop is one serialized L2/HBM round trip per chunk: ~19 per thread per workgroup)
+        for (int c0 = tid; c0 < nchunk; c0 += 256 * 4) {
+            uint4 d[4];
+            int dst_off[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int c = min(c0 + 256 * u, nchunk - 1);               // clamp: tail lanes re-read a valid chunk
+                const int part = c % CP, pc = c / CP;
+                const int col = pc % ww, row = pc / ww;
+                d[u] = *reinterpret_cast<const uint4*>(src + (long)(row * lv.W[l] + wc0[l] + col) * MD + part * VEC);
+                dst_off[u] = (row * lv.wmax[l] + col) * PIX_BYTES + part * 16;
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u)
+                if (c0 + 256 * u < nchunk) *reinterpret_cast<uint4*>(dst + dst_off[u]) = d[u];
         }
     }
     __syncthreads();

@@ -53,9 +53,12 @@ class DTLREngine:
         self.w[name] = t.to(device=self.device, dtype=dtype or self.dtype).contiguous()
 
     def _put_conv(self, name, w, b):
+        elem = 2 if self.dtype == torch.bfloat16 else 4
         if w.shape[2] == 1 and w.shape[3] == 1:      # 1x1 conv == linear over NHWC pixels: [Cout, Cin]
             self.w[name + ".w"] = w.flatten(1).to(device=self.device, dtype=self.dtype).contiguous()
-        else:
+        elif (w.shape[1] * elem) % 128 == 0:         # implicit-GEMM HIP kernel: [Cout, KH, KW, Cin]
+            self.w[name + ".w"] = w.permute(0, 2, 3, 1).to(device=self.device, dtype=self.dtype).contiguous()
+        else:                                        # 3-channel 7x7 stem: MIOpen, OIHW channels_last
             self.w[name + ".w"] = w.to(device=self.device, dtype=self.dtype).contiguous(memory_format=torch.channels_last)
         self.w[name + ".b"] = b.to(device=self.device, dtype=torch.float32).contiguous()
 
@@ -141,7 +144,7 @@ class DTLREngine:
             if stride != 1:
                 x = x[:, ::stride, ::stride, :].contiguous()
             return ops.linear(x, w, self.w[name + ".b"], relu=(2 if relu else 0), residual=residual)
-        return ops.conv2d_nhwc(x, w, self.w[name + ".b"].to(x.dtype), stride, padding, relu, residual)
+        return ops.conv2d_nhwc(x, w, self.w[name + ".b"], stride, padding, relu, residual)
 
     def _lin(self, name, x, relu=False, residual=None, a2=None, row_mask=None, out_dtype=None):
         return ops.linear(x, self.w[name + ".w"], self.w[name + ".b"], relu, residual, a2, row_mask, out_dtype)
@@ -358,7 +361,16 @@ class DTLREngine:
         level_hw = [(f.shape[1], f.shape[2]) for f in feats]
         last = self._conv(f"ip{len(feats)}", feats[-1], 2, 1)
         level_hw.append((last.shape[1], last.shape[2]))
-        g = self._geometry(mask, level_hw, has_padding)
+        # geometry depends only on the canvas shape and the padding masks: for an unpadded batch it is
+        # the same for every forward of that shape -> cached (legal savings)
+        gkey = (tuple(x.shape), tuple(level_hw)) if not has_padding else None
+        g = self._shape_cache.get(gkey) if gkey is not None else None
+        if g is None:
+            g = self._geometry(mask, level_hw, has_padding)
+            if gkey is not None:
+                if len(self._shape_cache) > 8:
+                    self._shape_cache.clear()
+                self._shape_cache[gkey] = g
         srcs = []
         for l, f in enumerate(feats):
             t = self._lin(f"ip{l}", f.flatten(1, 2))

@@ -18,7 +18,7 @@ from . import MultiScaleDeformableAttention as _msda
 from . import _lib
 
 # operators still served by ROCm libraries via torch (shrinks as kernels land)
-LIBRARY_BACKED = {"conv2d_nhwc", "maxpool_nhwc", "groupnorm_tokens", "mha", "topk", "sort"}
+LIBRARY_BACKED = {"conv2d_nhwc(7x7 stem only)", "maxpool_nhwc", "groupnorm_tokens", "mha", "topk", "sort"}
 
 _DT = {torch.float32: _lib.DTLR_F32, torch.bfloat16: _lib.DTLR_BF16, torch.float64: _lib.DTLR_F64}
 
@@ -88,10 +88,26 @@ def layernorm(x, w, b, eps: float = 1e-5, residual=None):
     return y
 
 
-def conv2d_nhwc(x, w_oihw_cl, bias, stride: int, padding: int, relu: bool = False, residual=None):
-    """x: [B,H,W,Cin] contiguous (NHWC); w: [Cout,Cin,kh,kw] in channels_last memory format with the
-    FrozenBN scale already folded in; bias [Cout].  Returns [B,Ho,Wo,Cout] contiguous."""
-    y = F.conv2d(x.permute(0, 3, 1, 2), w_oihw_cl, bias, stride=stride, padding=padding)
+def conv2d_nhwc(x, w, bias, stride: int, padding: int, relu=False, residual=None):
+    """NHWC convolution + folded-BN bias [+ residual] [+ ReLU].  x [B,H,W,Cin] contiguous.
+    w: [Cout,KH,KW,Cin] contiguous ("OHWI") -> the implicit-GEMM HIP kernel (dtlr_conv2d_nhwc), which
+    needs Cin*elem % 128 == 0; otherwise w is an OIHW channels_last tensor for the MIOpen path (the
+    3-channel 7x7 stem).  relu: False/0, True/2 = ReLU after the residual add (bottleneck tail)."""
+    if w.dim() == 4 and w.is_contiguous() and w.shape[3] == x.shape[3] and (x.shape[3] * x.element_size()) % 128 == 0:
+        B, H, W, Cin = x.shape
+        Cout, KH, KW, _ = w.shape
+        Ho, Wo = (H + 2 * padding - KH) // stride + 1, (W + 2 * padding - KW) // stride + 1
+        x = x if x.is_contiguous() else x.contiguous()
+        y = torch.empty((B, Ho, Wo, Cout), dtype=x.dtype, device=x.device)
+        if residual is not None:
+            residual = residual if residual.is_contiguous() else residual.contiguous()
+        code = _lib.lib().dtlr_conv2d_nhwc(x.data_ptr(), w.data_ptr(), 0 if bias is None else bias.data_ptr(),
+                                           0 if residual is None else residual.data_ptr(), y.data_ptr(),
+                                           B, H, W, Cin, Cout, KH, KW, stride, padding, 2 if relu else 0,
+                                           _DT[x.dtype], _lib.current_stream())
+        _lib.check(code, "dtlr_conv2d_nhwc")
+        return y
+    y = F.conv2d(x.permute(0, 3, 1, 2), w, None if bias is None else bias.to(x.dtype), stride=stride, padding=padding)
     y = y.permute(0, 2, 3, 1)
     if residual is not None:
         y = y + residual

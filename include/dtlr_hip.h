@@ -126,6 +126,20 @@ int dtlr_gemm_nt(const void *A, const void *A2, const void *W, const float *bias
                  const void *residual, const unsigned char *row_mask, void *C,
                  int M, int N, int K, int relu, int in_dtype, int out_dtype, void *stream);
 
+/* ---------------------------------------------------------------------------------------------
+ * NHWC convolution as an implicit GEMM on the matrix cores, with the FrozenBN-folded bias, optional
+ * residual and ReLU fused (same epilogue as dtlr_gemm_nt).
+ * Replaces: the 3x3 convolutions of torchvision's resnet50 bottlenecks + FrozenBatchNorm2d + ReLU as
+ *           run by BackboneBase.forward (models/dino/backbone.py:36-72,97-106), and the stride-2 3x3
+ *           Conv2d of input_proj level 3 (models/dino/dino.py:126-133, used at :299-301).
+ *   X [B,H,W,Cin]  W [Cout,KH,KW,Cin] (filter taps outermost, channels innermost)  bias [Cout] fp32 or NULL
+ *   residual / Y [B,Ho,Wo,Cout],  Ho = (H + 2 pad - KH)/stride + 1.   dtype BF16 or F32 (X, W, Y alike).
+ *   relu: 0 none, 1 after bias, 2 after the residual add.   Needs Cin*sizeof(elem) % 128 == 0.
+ */
+int dtlr_conv2d_nhwc(const void *X, const void *W, const float *bias, const void *residual, void *Y,
+                     int B, int H, int Wd, int Cin, int Cout, int KH, int KW, int stride, int pad,
+                     int relu, int dtype, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -206,3 +206,31 @@ def test_msda_encoder_lds_vs_oracle(level_hw, offscale):
         assert (g2 - got).abs().max() < 1e-6
     finally:
         ops.MSDA_HALO = old
+
+
+@pytest.mark.parametrize("B,H,W,Cin,Cout,k,stride,pad", [(2, 16, 40, 64, 64, 3, 1, 1), (3, 9, 33, 128, 128, 3, 2, 1),
+                                                         (1, 4, 64, 2048, 256, 3, 2, 1), (2, 5, 7, 32, 48, 3, 1, 1),
+                                                         (2, 6, 10, 64, 96, 1, 1, 0)])
+def test_conv2d_nhwc_implicit_gemm(B, H, W, Cin, Cout, k, stride, pad):
+    """Implicit-GEMM NHWC convolution vs torch CPU conv2d (fp64 reference), with bias / residual / ReLU;
+    includes stride 2, odd sizes (tile tails) and zero padding taps."""
+    import torch.nn.functional as F
+    from dtlr_amd import ops
+    x = _rand((B, H, W, Cin), 1)
+    w = _rand((Cout, Cin, k, k), 2) / np.sqrt(Cin * k * k)
+    b = _rand((Cout,), 3)
+    ref = F.conv2d(x.permute(0, 3, 1, 2).double(), w.double(), b.double(), stride=stride, padding=pad).permute(0, 2, 3, 1)
+    res = _rand(tuple(ref.shape), 4)
+    w_ohwi = w.permute(0, 2, 3, 1).contiguous()
+    for relu, use_res in ((False, False), (True, False), (True, True)):
+        want = ref + res.double() if use_res else ref
+        want = want.clamp(min=0) if relu else want
+        got = ops.conv2d_nhwc(x.cuda(), w_ohwi.cuda(), b.cuda(), stride, pad, relu, res.cuda() if use_res else None).cpu()
+        assert got.shape == want.shape
+        assert (got - want.float()).abs().max() < 3e-5 * max(1.0, want.abs().max().item()), (relu, use_res)
+    if (Cin * 2) % 128 == 0:
+        xb, wb = x.bfloat16(), w_ohwi.bfloat16()
+        refb = F.conv2d(xb.float().permute(0, 3, 1, 2).double(), wb.float().permute(0, 3, 1, 2).double(), b.double(),
+                        stride=stride, padding=pad).permute(0, 2, 3, 1).clamp(min=0).float()
+        gotb = ops.conv2d_nhwc(xb.cuda(), wb.cuda(), b.cuda(), stride, pad, True, None).float().cpu()
+        assert (gotb - refb).abs().max() < 2 ** -8 * max(1.0, refb.abs().max().item()) + 1e-4
