@@ -36,6 +36,8 @@ _SIGNATURES = {
                              c_int, c_int, c_int, c_int, c_int, c_int, c_void_p]),
     "dtlr_conv2d_nhwc": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
                                  c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p]),
+    "dtlr_decoder_query_prep": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p]),
+    "dtlr_box_refine": (c_int, [c_void_p, c_void_p, c_void_p, ctypes.c_long, c_void_p]),
 }
 
 

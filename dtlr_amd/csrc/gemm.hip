@@ -34,6 +34,24 @@ typedef __attribute__((ext_vector_type(4))) float f32x4_t;
 constexpr int BM = 128, BN = 128, SLAB = 128, LDS_ROW = 144;      // bytes
 constexpr int TILE_BYTES = BM * LDS_ROW;                           // one operand tile in LDS
 
+// Staging loads are issued through inline asm so that hipcc does not count them: across the loop
+// back-edge its waitcnt pass is conservative and drains vmcnt to 0 at the first LDS store of the older
+// register set, which collapses the two-slab prefetch distance to one.  The kernel places the counted
+// wait itself (cdna_hip_programming.md section 5.7, form iii): one `s_waitcnt vmcnt(N)` + sched_barrier
+// before the LDS stores of a set, N = number of staging loads issued after that set's loads.  vmcnt
+// also counts the epilogue's stores/loads issued in between; that only makes the wait stricter.
+__device__ __forceinline__ uint4 asm_load16(const char* p) {
+    uint4 r;
+    asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(r) : "v"(p) : "memory");
+    return r;
+}
+template <int N> __device__ __forceinline__ void wait_vmcnt() {
+    if constexpr (N == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    else if constexpr (N == 8) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+    else if constexpr (N == 12) asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
+    __builtin_amdgcn_sched_barrier(0);
+}
+
 enum : int { EPI_BIAS = 1, EPI_RELU = 2, EPI_RESIDUAL = 4, EPI_ROWMASK = 8, EPI_RELU_POST = 16 };
 
 template <typename T> struct GT;
@@ -82,11 +100,66 @@ template <> struct Out<uint16_t> {
     static __device__ __forceinline__ void st(uint16_t* p, float v) { *p = f32_to_bf16(v); }
 };
 
+// Epilogue of one 64x64 wave sub-tile: lane (g,n) holds, for ti = 0..3 and ci = 0..3, channels
+// ch0 + ci*16 + r (r = 0..3) of token tok0 + ti*16.  Zeroes the accumulators for the next tile.
+template <typename OutT>
+__device__ __forceinline__ void epilogue_tile(f32x4_t (&acc)[4][4], OutT* __restrict__ C, const float* __restrict__ bias,
+                                              const OutT* __restrict__ residual, const uint8_t* __restrict__ row_mask,
+                                              int M, int N, int flags, int tok0, int ch0)
+{
+    const bool vec_ok = (N & 3) == 0;
+#pragma unroll
+    for (int ti = 0; ti < 4; ++ti) {
+        const int tok = tok0 + ti * 16;
+        const bool tok_ok = tok < M;
+        const bool masked = tok_ok && (flags & EPI_ROWMASK) && row_mask[tok];
+#pragma unroll
+        for (int ci = 0; ci < 4; ++ci) {
+            const int ch = ch0 + ci * 16;
+            float v[4] = {acc[ci][ti][0], acc[ci][ti][1], acc[ci][ti][2], acc[ci][ti][3]};
+            acc[ci][ti] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+            if (!tok_ok || ch >= N) continue;
+            const bool full = vec_ok && ch + 3 < N;
+            if (flags & EPI_BIAS) {
+                if (full) { const float4 bb = *reinterpret_cast<const float4*>(bias + ch); v[0] += bb.x; v[1] += bb.y; v[2] += bb.z; v[3] += bb.w; }
+                else {
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) if (ch + r < N) v[r] += bias[ch + r];
+                }
+            }
+            if (flags & EPI_RELU) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) v[r] = fmaxf(v[r], 0.f);
+            }
+            if (masked) { v[0] = v[1] = v[2] = v[3] = 0.f; }
+            OutT* cptr = C + (long)tok * N + ch;
+            if (full) {
+                if (flags & EPI_RESIDUAL) { float rr[4]; Out<OutT>::ld4(residual + (long)tok * N + ch, rr); v[0] += rr[0]; v[1] += rr[1]; v[2] += rr[2]; v[3] += rr[3]; }
+                if (flags & EPI_RELU_POST) {
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) v[r] = fmaxf(v[r], 0.f);
+                }
+                Out<OutT>::st4(cptr, v);
+            } else {
+#pragma unroll
+                for (int r = 0; r < 4; ++r)
+                    if (ch + r < N) {
+                        float x = v[r];
+                        if (flags & EPI_RESIDUAL) x += Out<OutT>::ld(residual + (long)tok * N + ch + r);
+                        if (flags & EPI_RELU_POST) x = fmaxf(x, 0.f);
+                        Out<OutT>::st(cptr + r, x);
+                    }
+            }
+        }
+    }
+}
+
 // Implicit-GEMM convolution (CONV = true): the "A" operand is gathered on the fly from an NHWC image,
 // M = B*Ho*Wo output pixels, K = KH*KW*Cin ordered (kh, kw, ci) so that a 128-byte K slab lies inside
 // one filter tap (Cin*sizeof(T) % 128 == 0) and is one contiguous, 16-byte-aligned run of channels;
 // taps that fall into the zero padding contribute zeros.  Weights are packed [Cout][KH][KW][Cin].
 struct ConvP { int H, W, Cin, Ho, Wo, KH, KW, stride, pad; };
+__device__ __attribute__((aligned(16))) unsigned int g_zero_line[4] = {0u, 0u, 0u, 0u};   // what a padding tap reads
 
 template <typename T, typename OutT, bool HAS_A2, bool CONV>
 __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(
@@ -122,6 +195,8 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(
     const char* Ab = reinterpret_cast<const char*>(A);
     const char* A2b = reinterpret_cast<const char*>(A2);
     const char* Wb = reinterpret_cast<const char*>(W);
+    const char* zero_line = reinterpret_cast<const char*>(g_zero_line);
+    (void)zero_line;
 
 #define SET_LOAD_TILE(TILE)                                                                        \
     {                                                                                              \
@@ -144,35 +219,51 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(
 
     // Staging registers are named scalars on purpose: as arrays written under a condition hipcc
     // (ROCm 7.2) leaves them in scratch memory (global_load -> scratch_store ... scratch_load -> ds_write).
-    uint4 ra0, ra1, ra2, ra3, rw0, rw1, rw2, rw3;
-#define GLOAD1(I, OFF)                                                                             \
-    rw##I = *reinterpret_cast<const uint4*>(Wb + w_off[I] + (OFF));                                \
+    // TWO sets (P, Q): the loads of slab s+2 are issued before slab s is multiplied and are consumed
+    // (stored to LDS) after slab s+1 has been multiplied -- two compute phases to cover the L2/HBM
+    // latency.  With one set (distance 1) the bf16 kernel stalled ~2500 cycles per slab at the LDS
+    // store (fp32 MFMA work is 4x longer and hid it: 65% of its peak vs 15% for bf16).
+    uint4 raP0, raP1, raP2, raP3, rwP0, rwP1, rwP2, rwP3;
+    uint4 raQ0, raQ1, raQ2, raQ3, rwQ0, rwQ1, rwQ2, rwQ3;
+    // asm (uncounted) loads only where the register budget leaves no spills: a spilled in-flight register
+    // would be copied before its data lands.  The A2 and fp32-conv variants keep compiler-counted loads.
+    constexpr bool ASM_LOADS = !HAS_A2 && !(CONV && sizeof(T) == 4);
+    constexpr int LOADS_PER_SLAB = 8;
+#define LD16(PTR) (ASM_LOADS ? asm_load16(PTR) : *reinterpret_cast<const uint4*>(PTR))
+#define GLOAD1(S, I, OFF)                                                                          \
+    rw##S##I = LD16(Wb + w_off[I] + (OFF));                                                        \
     if (CONV) {                                                                                    \
         const int hi_ = hi0[I] + kh_, wi_ = wi0[I] + kw_;                                          \
         const bool ok_ = hi_ >= 0 && hi_ < cp.H && wi_ >= 0 && wi_ < cp.W;                         \
-        const long po_ = ((long)(ok_ ? hi_ : 0) * cp.W + (ok_ ? wi_ : 0)) * cp.Cin * (long)sizeof(T) + coff_; \
-        const uint4 t_ = *reinterpret_cast<const uint4*>(Ab + a_off[I] + po_);                     \
-        ra##I = ok_ ? t_ : make_uint4(0u, 0u, 0u, 0u);                                             \
+        /* a tap in the zero padding reads the shared zero line instead (no select on in-flight data) */ \
+        const long po_ = ((long)hi_ * cp.W + wi_) * cp.Cin * (long)sizeof(T) + coff_;              \
+        ra##S##I = LD16(ok_ ? Ab + a_off[I] + po_ : zero_line);                                    \
     } else {                                                                                       \
-        ra##I = *reinterpret_cast<const uint4*>(Ab + a_off[I] + (OFF));                            \
-        if (HAS_A2) ra##I = GT<T>::add(ra##I, *reinterpret_cast<const uint4*>(A2b + a_off[I] + (OFF))); \
+        ra##S##I = LD16(Ab + a_off[I] + (OFF));                                                    \
+        if (HAS_A2) ra##S##I = GT<T>::add(ra##S##I, *reinterpret_cast<const uint4*>(A2b + a_off[I] + (OFF))); \
     }
-#define GLOAD(KT)                                                                                  \
+#define GLOAD(S, KT)                                                                               \
     {                                                                                              \
         const long off_ = (long)(KT) * SLAB;                                                       \
         const int tap_ = (KT) / slabs_per_tap;                                                     \
         const int kh_ = CONV ? tap_ / cp.KW : 0, kw_ = CONV ? tap_ % cp.KW : 0;                    \
         const long coff_ = (long)((KT) % slabs_per_tap) * SLAB;                                    \
         (void)kh_; (void)kw_; (void)coff_;                                                         \
-        GLOAD1(0, off_) GLOAD1(1, off_) GLOAD1(2, off_) GLOAD1(3, off_)                            \
+        GLOAD1(S, 0, off_) GLOAD1(S, 1, off_) GLOAD1(S, 2, off_) GLOAD1(S, 3, off_)                \
     }
-#define LSTORE1(I)                                                                                 \
-    *reinterpret_cast<uint4*>(wt_ + I * 32 * LDS_ROW) = rw##I;                                     \
-    *reinterpret_cast<uint4*>(wt_ + TILE_BYTES + I * 32 * LDS_ROW) = ra##I;
-#define LSTORE(STAGE)                                                                              \
+#define LSTORE1(S, I)                                                                              \
+    *reinterpret_cast<uint4*>(wt_ + I * 32 * LDS_ROW) = rw##S##I;                                  \
+    *reinterpret_cast<uint4*>(wt_ + TILE_BYTES + I * 32 * LDS_ROW) = ra##S##I;
+#define LSTORE(S, STAGE)                                                                           \
     {                                                                                              \
         unsigned char* wt_ = smem + (STAGE) * 2 * TILE_BYTES + lds0;                               \
-        LSTORE1(0) LSTORE1(1) LSTORE1(2) LSTORE1(3)                                                \
+        LSTORE1(S, 0) LSTORE1(S, 1) LSTORE1(S, 2) LSTORE1(S, 3)                                    \
+    }
+// advance the loader by one slab (possibly into the next tile of the chain) and issue its loads into set S
+#define ADVANCE_AND_LOAD(S)                                                                        \
+    {                                                                                              \
+        if (++lkt == nk) { lkt = 0; ++ltile; SET_LOAD_TILE(ltile) }                                \
+        GLOAD(S, lkt)                                                                              \
     }
 
     f32x4_t acc[4][4];
@@ -182,92 +273,63 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(
         for (int ti = 0; ti < 4; ++ti) acc[ci][ti] = f32x4_t{0.f, 0.f, 0.f, 0.f};
 
     SET_LOAD_TILE(t_begin)
-    GLOAD(0)
-    LSTORE(0)
+    int lkt = 0, ltile = t_begin;            // slab whose loads were issued last
+    GLOAD(P, 0)
+    if (ASM_LOADS) wait_vmcnt<0>();
+    LSTORE(P, 0)                             // slab 0 -> stage 0
+    if (total > 1) ADVANCE_AND_LOAD(Q)       // slab 1 in flight in set Q
     __syncthreads();
     int kt = 0, tile = t_begin;              // slab being multiplied
-    int lkt = 0, ltile = t_begin;            // slab whose loads were issued last
-    for (int s = 0; s < total; ++s) {
-        const int cur = s & 1;
-        const bool more = s + 1 < total;
-        if (more) {
-            if (++lkt == nk) { lkt = 0; ++ltile; SET_LOAD_TILE(ltile) }
-            GLOAD(lkt)
-        }
-        const unsigned char* wt = smem + cur * 2 * TILE_BYTES + (wn * 64 + n) * LDS_ROW + g * 16;
-        const unsigned char* xt = smem + cur * 2 * TILE_BYTES + TILE_BYTES + (wm * 64 + n) * LDS_ROW + g * 16;
-#pragma unroll
-        for (int kq = 0; kq < 2; ++kq) {
-            uint4 wf[4], xf[4];
-#pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                wf[i] = *reinterpret_cast<const uint4*>(wt + i * 16 * LDS_ROW + kq * 64);
-                xf[i] = *reinterpret_cast<const uint4*>(xt + i * 16 * LDS_ROW + kq * 64);
-            }
-#pragma unroll
-            for (int ci = 0; ci < 4; ++ci)
-#pragma unroll
-                for (int ti = 0; ti < 4; ++ti) GT<T>::mma(wf[ci], xf[ti], acc[ci][ti]);
-        }
-        if (more) LSTORE(cur ^ 1)
-        __syncthreads();
-        if (++kt < nk) continue;
 
-        // ---- tile finished: epilogue (the next tile's first slab is already in LDS) ----------------------
-        // lane (g,n) holds channels ch = n0 + wn*64 + ci*16 + 4g + r of token m0 + wm*64 + ti*16 + n
-        const int m0 = (tile / nN) * BM, n0 = (tile % nN) * BN;
-        const bool vec_ok = (N & 3) == 0;
-#pragma unroll
-        for (int ti = 0; ti < 4; ++ti) {
-            const int tok = m0 + wm * 64 + ti * 16 + n;
-            const bool tok_ok = tok < M;
-            const bool masked = tok_ok && (flags & EPI_ROWMASK) && row_mask[tok];
-#pragma unroll
-            for (int ci = 0; ci < 4; ++ci) {
-                const int ch = n0 + wn * 64 + ci * 16 + 4 * g;
-                float v[4] = {acc[ci][ti][0], acc[ci][ti][1], acc[ci][ti][2], acc[ci][ti][3]};
-                acc[ci][ti] = f32x4_t{0.f, 0.f, 0.f, 0.f};
-                if (!tok_ok || ch >= N) continue;
-                const bool full = vec_ok && ch + 3 < N;
-                if (flags & EPI_BIAS) {
-                    if (full) { const float4 bb = *reinterpret_cast<const float4*>(bias + ch); v[0] += bb.x; v[1] += bb.y; v[2] += bb.z; v[3] += bb.w; }
-                    else {
-#pragma unroll
-                        for (int r = 0; r < 4; ++r) if (ch + r < N) v[r] += bias[ch + r];
-                    }
-                }
-                if (flags & EPI_RELU) {
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) v[r] = fmaxf(v[r], 0.f);
-                }
-                if (masked) { v[0] = v[1] = v[2] = v[3] = 0.f; }
-                OutT* cptr = C + (long)tok * N + ch;
-                if (full) {
-                    if (flags & EPI_RESIDUAL) { float rr[4]; Out<OutT>::ld4(residual + (long)tok * N + ch, rr); v[0] += rr[0]; v[1] += rr[1]; v[2] += rr[2]; v[3] += rr[3]; }
-                    if (flags & EPI_RELU_POST) {
-#pragma unroll
-                        for (int r = 0; r < 4; ++r) v[r] = fmaxf(v[r], 0.f);
-                    }
-                    Out<OutT>::st4(cptr, v);
-                } else {
-#pragma unroll
-                    for (int r = 0; r < 4; ++r)
-                        if (ch + r < N) {
-                            float x = v[r];
-                            if (flags & EPI_RESIDUAL) x += Out<OutT>::ld(residual + (long)tok * N + ch + r);
-                            if (flags & EPI_RELU_POST) x = fmaxf(x, 0.f);
-                            Out<OutT>::st(cptr + r, x);
-                        }
-                }
-            }
-        }
-        kt = 0; ++tile;
+    // one half-iteration: multiply the slab in stage CUR; before it, issue slab s+2 into set LS (the set
+    // that held the slab now in stage CUR); after it, store slab s+1 (set SS, loaded one half-iteration
+    // ago) into the other stage.  The loop is unrolled by two so P/Q roles are compile-time: a runtime
+    // `cur ? P : Q` select makes hipcc merge the two sets through phi copies and wait vmcnt(0) at the join.
+#define HALF(CUR, LS, SS)                                                                          \
+    {                                                                                              \
+        if (s + 2 < total) ADVANCE_AND_LOAD(LS)                                                    \
+        const unsigned char* wt = smem + (CUR) * 2 * TILE_BYTES + (wn * 64 + n) * LDS_ROW + g * 16; \
+        const unsigned char* xt = wt + TILE_BYTES + ((wm - wn) * 64) * LDS_ROW;                    \
+        _Pragma("unroll") for (int kq = 0; kq < 2; ++kq) {                                         \
+            uint4 wf[4], xf[4];                                                                    \
+            _Pragma("unroll") for (int i = 0; i < 4; ++i) {                                        \
+                wf[i] = *reinterpret_cast<const uint4*>(wt + i * 16 * LDS_ROW + kq * 64);          \
+                xf[i] = *reinterpret_cast<const uint4*>(xt + i * 16 * LDS_ROW + kq * 64);          \
+            }                                                                                      \
+            _Pragma("unroll") for (int ci = 0; ci < 4; ++ci)                                       \
+                _Pragma("unroll") for (int ti = 0; ti < 4; ++ti) GT<T>::mma(wf[ci], xf[ti], acc[ci][ti]); \
+        }                                                                                          \
+        if (s + 1 < total) {                                                                       \
+            /* slab s+1's loads are older than the LOADS_PER_SLAB loads of slab s+2 (if any were issued) */ \
+            if (ASM_LOADS) { if (s + 2 < total) wait_vmcnt<LOADS_PER_SLAB>(); else wait_vmcnt<0>(); } \
+            LSTORE(SS, 1 - (CUR))                                                                  \
+        }                                                                                          \
+        __syncthreads();                                                                           \
+        if (++kt == nk) { EPILOGUE() kt = 0; ++tile; }                                             \
+        ++s;                                                                                       \
     }
+
+#define EPILOGUE()                                                                                 \
+    {                                                                                              \
+        const int m0 = (tile / nN) * BM, n0 = (tile % nN) * BN;                                    \
+        epilogue_tile<OutT>(acc, C, bias, residual, row_mask, M, N, flags, m0 + wm * 64 + n, n0 + wn * 64 + 4 * g); \
+    }
+
+    int s = 0;
+    while (s < total) {
+        HALF(0, P, Q)
+        if (s >= total) break;
+        HALF(1, Q, P)
+    }
+#undef HALF
+#undef EPILOGUE
+#undef LD16
 #undef GLOAD
 #undef LSTORE
 #undef GLOAD1
 #undef LSTORE1
 #undef SET_LOAD_TILE
+#undef ADVANCE_AND_LOAD
 }
 
 // tiles per block: enough chains to fill the chip (2 resident workgroups x 256 CUs) a few times over

@@ -1,0 +1,79 @@
+// Small fused elementwise kernels of the decoder loop (each replaces a dozen tiny launches per layer).
+#include "dtlr_common.h"
+
+namespace dtlr {
+
+// TransformerDecoder.forward per-layer query preparation (deformable_transformer.py:684-690) +
+// gen_sineembed_for_position (models/dino/utils.py:141-167):
+//   ref_in[q, l, :] = ref[q, :] * (vr[b,l,0], vr[b,l,1], vr[b,l,0], vr[b,l,1])
+//   sine[q, :]      = [emb(y) | emb(x) | emb(w) | emb(h)] of ref_in[q, 0, :],  emb(c)[i] = sin/cos(c * 2pi / dim_t[i])
+// one thread per (query, frequency pair): 64 pairs x 4 coordinates; dim_t comes from the host so it is
+// bit-identical to the table torch builds (10000 ** (2*(i//2)/128) in fp32).
+template <typename OT>
+__global__ __launch_bounds__(256) void query_prep_kernel(const float* __restrict__ ref, const float* __restrict__ vr,
+                                                         const float* __restrict__ dim_t, float* __restrict__ ref_in,
+                                                         OT* __restrict__ sine, int nq, int L, long total)
+{
+    const long tid = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (tid >= total) return;
+    const int pair = (int)(tid & 63);
+    const long q = tid >> 6;
+    const int b = (int)(q / nq);
+    const float4 r = *reinterpret_cast<const float4*>(ref + q * 4);
+    if (pair < L) {                                   // lanes 0..L-1 also write the per-level reference boxes
+        const float vx = vr[(b * L + pair) * 2], vy = vr[(b * L + pair) * 2 + 1];
+        *reinterpret_cast<float4*>(ref_in + (q * L + pair) * 4) = make_float4(r.x * vx, r.y * vy, r.z * vx, r.w * vy);
+    }
+    const float vx0 = vr[(b * L) * 2], vy0 = vr[(b * L) * 2 + 1];
+    const float scale = 6.283185307179586f;           // 2*pi, as `scale = 2 * math.pi` rounded to fp32 by torch
+    const float c[4] = {r.y * vy0 * scale, r.x * vx0 * scale, r.z * vx0 * scale, r.w * vy0 * scale};   // order y, x, w, h
+    const float d0 = dim_t[2 * pair], d1 = dim_t[2 * pair + 1];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const float s = sinf(c[k] / d0), co = cosf(c[k] / d1);
+        OT* o = sine + q * 512 + k * 128 + 2 * pair;
+        if (sizeof(OT) == 2) *reinterpret_cast<uint32_t*>(o) = pack_bf16x2(s, co);
+        else { reinterpret_cast<float*>(o)[0] = s; reinterpret_cast<float*>(o)[1] = co; }
+    }
+}
+
+// iterative box refinement (deformable_transformer.py:734-756; inverse_sigmoid util/misc.py:575-579):
+//   out = sigmoid(delta + log(clamp(x,1e-3) / clamp(1-x,1e-3))),  x = clamp(ref, 0, 1)
+__global__ __launch_bounds__(256) void box_refine_kernel(const float* __restrict__ delta, const float* __restrict__ ref,
+                                                         float* __restrict__ out, long n)
+{
+    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    float x = fminf(fmaxf(ref[i], 0.f), 1.f);
+    const float x1 = fmaxf(x, 1e-3f), x2 = fmaxf(1.f - x, 1e-3f);
+    const float u = delta[i] + logf(x1 / x2);
+    out[i] = 1.f / (1.f + expf(-u));
+}
+
+}  // namespace dtlr
+
+using namespace dtlr;
+
+extern "C" int dtlr_decoder_query_prep(const float* ref, const float* valid_ratios, const float* dim_t,
+                                       float* ref_in, void* sine, int B, int nq, int L, int sine_dtype, void* stream)
+{
+    if (!ref || !valid_ratios || !dim_t || !ref_in || !sine) return DTLR_EINVAL;
+    if (B <= 0 || nq <= 0 || L <= 0 || L > 64) return DTLR_EINVAL;
+    const long total = (long)B * nq * 64;
+    const long grid = (total + 255) / 256;
+    hipStream_t st = (hipStream_t)stream;
+    if (sine_dtype == DTLR_BF16)
+        hipLaunchKernelGGL((query_prep_kernel<uint16_t>), dim3((unsigned)grid), dim3(256), 0, st, ref, valid_ratios, dim_t, ref_in, (uint16_t*)sine, nq, L, total);
+    else if (sine_dtype == DTLR_F32)
+        hipLaunchKernelGGL((query_prep_kernel<float>), dim3((unsigned)grid), dim3(256), 0, st, ref, valid_ratios, dim_t, ref_in, (float*)sine, nq, L, total);
+    else return DTLR_EDTYPE;
+    return check_launch();
+}
+
+extern "C" int dtlr_box_refine(const float* delta, const float* ref, float* out, long n, void* stream)
+{
+    if (!delta || !ref || !out) return DTLR_EINVAL;
+    if (n <= 0) return DTLR_EINVAL;
+    hipLaunchKernelGGL(box_refine_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, delta, ref, out, n);
+    return check_launch();
+}

@@ -100,3 +100,158 @@ extern "C" int dtlr_layernorm(const void* x, const void* residual, const float* 
     default: return DTLR_EDTYPE;
     }
 }
+
+// ---------------------------------------------------------------------------------------------
+// GroupNorm(32, 256) over the tokens of ONE feature level: x [B, T, 256], statistics per (sample, group)
+// over T positions x 8 channels (models/dino/dino.py:121-134, eps 1e-5, affine).
+//   pass 1 (gn_partial): grid (slabs, B); a wave owns rows of its slab, lane l owns channels 4l..4l+3, so
+//           lanes 2g and 2g+1 hold group g; per-lane fp32 sum / sum of squares -> one (sum, sumsq) per
+//           (block, group) in the workspace.
+//   pass 2 (gn_apply):   each block first reduces the slab partials of its sample in fp64 (32 groups),
+//           then normalises rows (one wave per row, 16-byte loads).
+// ---------------------------------------------------------------------------------------------
+namespace dtlr {
+
+template <typename T>
+__global__ __launch_bounds__(256) void gn_partial_kernel(const T* __restrict__ x, float2* __restrict__ part, int T_tokens, int rows_per_slab)
+{
+    __shared__ float2 red[4][32];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int slab = blockIdx.x, b = blockIdx.y;
+    const int r0 = slab * rows_per_slab, r1 = min(r0 + rows_per_slab, T_tokens);
+    float s = 0.f, q = 0.f;
+    for (int r = r0 + wave; r < r1; r += 4) {
+        float v[4];
+        IO<T>::load4(x + ((long)b * T_tokens + r) * 256 + 4 * lane, v);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) { s += v[i]; q += v[i] * v[i]; }
+    }
+    s += __shfl_xor(s, 1, 64);
+    q += __shfl_xor(q, 1, 64);
+    if ((lane & 1) == 0) red[wave][lane >> 1] = make_float2(s, q);
+    __syncthreads();
+    if (threadIdx.x < 32) {
+        float2 a = red[0][threadIdx.x];
+#pragma unroll
+        for (int w = 1; w < 4; ++w) { a.x += red[w][threadIdx.x].x; a.y += red[w][threadIdx.x].y; }
+        part[((long)b * gridDim.x + slab) * 32 + threadIdx.x] = a;
+    }
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void gn_apply_kernel(const T* __restrict__ x, const float2* __restrict__ part,
+                                                       const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                       T* __restrict__ y, int T_tokens, int nslab, int rows_per_block, float eps)
+{
+    __shared__ float2 stat[32];                     // (mean, rstd) per group
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int b = blockIdx.y;
+    if (threadIdx.x < 32) {
+        double s = 0.0, q = 0.0;
+        for (int k = 0; k < nslab; ++k) { const float2 p = part[((long)b * nslab + k) * 32 + threadIdx.x]; s += (double)p.x; q += (double)p.y; }
+        const double n = (double)T_tokens * 8.0;
+        const double mean = s / n;
+        double var = q / n - mean * mean;
+        if (var < 0.0) var = 0.0;
+        stat[threadIdx.x] = make_float2((float)mean, (float)(1.0 / sqrt(var + (double)eps)));
+    }
+    __syncthreads();
+    const float2 st = stat[lane >> 1];
+    const float4 ga = *reinterpret_cast<const float4*>(gamma + 4 * lane);
+    const float4 be = *reinterpret_cast<const float4*>(beta + 4 * lane);
+    const int r0 = blockIdx.x * rows_per_block, r1 = min(r0 + rows_per_block, T_tokens);
+    for (int r = r0 + wave; r < r1; r += 4) {
+        const long off = ((long)b * T_tokens + r) * 256 + 4 * lane;
+        float v[4];
+        IO<T>::load4(x + off, v);
+        float o[4] = {(v[0] - st.x) * st.y * ga.x + be.x, (v[1] - st.x) * st.y * ga.y + be.y,
+                      (v[2] - st.x) * st.y * ga.z + be.z, (v[3] - st.x) * st.y * ga.w + be.w};
+        IO<T>::store4(y + off, o);
+    }
+}
+
+// 3x3 stride-2 pad-1 max pooling on NHWC (torchvision resnet50.maxpool as run by backbone.py:97-106);
+// a thread owns VEC channels of one output pixel; padding behaves as -inf.
+template <typename T, int VEC>
+__global__ __launch_bounds__(256) void maxpool3x3s2_kernel(const T* __restrict__ x, T* __restrict__ y,
+                                                           int H, int W, int C, int Ho, int Wo, long total)
+{
+    const long tid = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (tid >= total) return;
+    const int cv = C / VEC;
+    const int c0 = (int)(tid % cv) * VEC;
+    long p = tid / cv;
+    const int wo = (int)(p % Wo); p /= Wo;
+    const int ho = (int)(p % Ho);
+    const long b = p / Ho;
+    float m[VEC];
+#pragma unroll
+    for (int i = 0; i < VEC; ++i) m[i] = -INFINITY;
+#pragma unroll
+    for (int kh = 0; kh < 3; ++kh) {
+        const int hi = 2 * ho - 1 + kh;
+        if (hi < 0 || hi >= H) continue;
+#pragma unroll
+        for (int kw = 0; kw < 3; ++kw) {
+            const int wi = 2 * wo - 1 + kw;
+            if (wi < 0 || wi >= W) continue;
+            float v[VEC];
+            const T* src = x + ((b * H + hi) * W + wi) * C + c0;
+            if (VEC == 4) IO<T>::load4(src, *reinterpret_cast<float (*)[4]>(v));
+            else { IO<T>::load4(src, *reinterpret_cast<float (*)[4]>(v)); IO<T>::load4(src + 4, *reinterpret_cast<float (*)[4]>(v + 4)); }
+#pragma unroll
+            for (int i = 0; i < VEC; ++i) m[i] = fmaxf(m[i], v[i]);
+        }
+    }
+    T* dst = y + ((b * Ho + ho) * Wo + wo) * C + c0;
+    IO<T>::store4(dst, *reinterpret_cast<float (*)[4]>(m));
+    if (VEC == 8) IO<T>::store4(dst + 4, *reinterpret_cast<float (*)[4]>(m + 4));
+}
+
+}  // namespace dtlr
+
+extern "C" long dtlr_groupnorm_workspace_bytes(int B, int T_tokens)
+{
+    const int rows_per_slab = 64;
+    const long nslab = (T_tokens + rows_per_slab - 1) / rows_per_slab;
+    return (long)B * nslab * 32 * (long)sizeof(float2);
+}
+
+extern "C" int dtlr_groupnorm_tokens(const void* x, const float* gamma, const float* beta, void* y, void* workspace,
+                                     int B, int T_tokens, int C, int groups, float eps, int dtype, void* stream)
+{
+    if (!x || !gamma || !beta || !y || !workspace) return DTLR_EINVAL;
+    if (B <= 0 || T_tokens <= 0) return DTLR_EINVAL;
+    if (C != 256 || groups != 32) return DTLR_ESHAPE;
+    hipStream_t st = (hipStream_t)stream;
+    const int rows_per_slab = 64;
+    const int nslab = (T_tokens + rows_per_slab - 1) / rows_per_slab;
+    const int rows_per_block = 32;
+    const int nblk = (T_tokens + rows_per_block - 1) / rows_per_block;
+    if (dtype == DTLR_F32) {
+        hipLaunchKernelGGL((gn_partial_kernel<float>), dim3(nslab, B), dim3(256), 0, st, (const float*)x, (float2*)workspace, T_tokens, rows_per_slab);
+        hipLaunchKernelGGL((gn_apply_kernel<float>), dim3(nblk, B), dim3(256), 0, st, (const float*)x, (const float2*)workspace, gamma, beta, (float*)y, T_tokens, nslab, rows_per_block, eps);
+    } else if (dtype == DTLR_BF16) {
+        hipLaunchKernelGGL((gn_partial_kernel<uint16_t>), dim3(nslab, B), dim3(256), 0, st, (const uint16_t*)x, (float2*)workspace, T_tokens, rows_per_slab);
+        hipLaunchKernelGGL((gn_apply_kernel<uint16_t>), dim3(nblk, B), dim3(256), 0, st, (const uint16_t*)x, (const float2*)workspace, gamma, beta, (uint16_t*)y, T_tokens, nslab, rows_per_block, eps);
+    } else return DTLR_EDTYPE;
+    return check_launch();
+}
+
+extern "C" int dtlr_maxpool3x3s2_nhwc(const void* x, void* y, int B, int H, int W, int C, int dtype, void* stream)
+{
+    if (!x || !y) return DTLR_EINVAL;
+    if (B <= 0 || H <= 0 || W <= 0 || C <= 0) return DTLR_EINVAL;
+    const int Ho = (H + 2 - 3) / 2 + 1, Wo = (W + 2 - 3) / 2 + 1;
+    hipStream_t st = (hipStream_t)stream;
+    if (dtype == DTLR_BF16 && C % 8 == 0) {
+        const long total = (long)B * Ho * Wo * (C / 8);
+        hipLaunchKernelGGL((maxpool3x3s2_kernel<uint16_t, 8>), dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st,
+                           (const uint16_t*)x, (uint16_t*)y, H, W, C, Ho, Wo, total);
+    } else if (dtype == DTLR_F32 && C % 4 == 0) {
+        const long total = (long)B * Ho * Wo * (C / 4);
+        hipLaunchKernelGGL((maxpool3x3s2_kernel<float, 4>), dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st,
+                           (const float*)x, (float*)y, H, W, C, Ho, Wo, total);
+    } else return (dtype == DTLR_BF16 || dtype == DTLR_F32) ? DTLR_ESHAPE : DTLR_EDTYPE;
+    return check_launch();
+}

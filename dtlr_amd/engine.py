@@ -324,8 +324,7 @@ class DTLREngine:
         hs = []
         for n in range(cfg.dec_layers):
             q = f"dec{n}."
-            ref_in = (ref[:, :, None] * vr4[:, None]).contiguous()       # [B, nq, L, 4]
-            sine = self._sine_embed(ref_in[:, :, 0, :]).to(self.dtype)
+            ref_in, sine = ops.decoder_query_prep(ref, g["valid_ratios"], self.dtype)      # [B,nq,L,4], [B,nq,512]
             qpos = self._lin("dec.rph1", self._lin("dec.rph0", sine, relu=True))
             # self attention (q = k = tgt + query_pos, v = tgt)
             qk = self._lin(q + "sa.qk", tgt, a2=qpos)
@@ -339,7 +338,7 @@ class DTLREngine:
             h = self._lin(q + "ff1", tgt, relu=True)
             tgt = self._ln(q + "norm3", self._lin(q + "ff2", h), residual=tgt)
             # iterative box refinement (734-756)
-            ref = (self._bbox_head(tgt) + self._inverse_sigmoid(ref)).sigmoid()
+            ref = ops.box_refine(self._bbox_head(tgt), ref)
             refs.append(ref)
             if want_aux or n == cfg.dec_layers - 1:
                 hs.append(self._ln("dec.norm", tgt))
@@ -384,11 +383,11 @@ class DTLREngine:
         n = cfg.dec_layers - 1
         out = {
             "pred_logits": ops.linear(hs[n].float(), self.w["class.w"], self.w["class.b"]),
-            "pred_boxes": (self._bbox_head(hs[n]) + self._inverse_sigmoid(refs[n])).sigmoid(),
+            "pred_boxes": ops.box_refine(self._bbox_head(hs[n]), refs[n]),
         }
         if want_aux:
             out["aux_outputs"] = [{"pred_logits": ops.linear(hs[i].float(), self.w["class.w"], self.w["class.b"]),
-                                   "pred_boxes": (self._bbox_head(hs[i]) + self._inverse_sigmoid(refs[i])).sigmoid()}
+                                   "pred_boxes": ops.box_refine(self._bbox_head(hs[i]), refs[i])}
                                   for i in range(n)]
         interm_class = ops.linear(ts["hs_enc"], self.w["enc_class.w"], self.w["enc_class.b"])
         out["interm_outputs"] = {"pred_logits": interm_class, "pred_boxes": ts["ref_unsig"].sigmoid()}

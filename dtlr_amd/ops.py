@@ -225,6 +225,36 @@ def mha(qk, v, n_heads: int):
     return o.transpose(1, 2).reshape(B, L, C)
 
 
+_DIM_T = {}
+
+
+def decoder_query_prep(ref, valid_ratios, out_dtype):
+    """ref [B,nq,4] fp32, valid_ratios [B,L,2] fp32 -> (ref_in [B,nq,L,4] fp32, sine [B,nq,512] out_dtype)."""
+    B, nq, _ = ref.shape
+    L = valid_ratios.shape[1]
+    key = ref.device
+    if key not in _DIM_T:       # the exact table gen_sineembed_for_position builds (models/dino/utils.py:145-146)
+        t = torch.arange(128, dtype=torch.float32, device=ref.device)
+        _DIM_T[key] = (10000 ** (2 * torch.div(t, 2, rounding_mode="floor") / 128)).contiguous()
+    ref = ref.contiguous()
+    valid_ratios = valid_ratios.contiguous()
+    ref_in = torch.empty((B, nq, L, 4), dtype=torch.float32, device=ref.device)
+    sine = torch.empty((B, nq, 512), dtype=out_dtype, device=ref.device)
+    code = _lib.lib().dtlr_decoder_query_prep(ref.data_ptr(), valid_ratios.data_ptr(), _DIM_T[key].data_ptr(), ref_in.data_ptr(),
+                                              sine.data_ptr(), B, nq, L, _DT[out_dtype], _lib.current_stream())
+    _lib.check(code, "dtlr_decoder_query_prep")
+    return ref_in, sine
+
+
+def box_refine(delta, ref):
+    """sigmoid(delta + inverse_sigmoid(ref)) (fp32)."""
+    delta, ref = delta.contiguous(), ref.contiguous()
+    out = torch.empty_like(ref)
+    code = _lib.lib().dtlr_box_refine(delta.data_ptr(), ref.data_ptr(), out.data_ptr(), ref.numel(), _lib.current_stream())
+    _lib.check(code, "dtlr_box_refine")
+    return out
+
+
 def topk_rows(scores, k: int):
     """Indices of the k largest per row, descending (two-stage selection,
     deformable_transformer.py:345).  Scores are always fp32."""

@@ -140,6 +140,21 @@ int dtlr_conv2d_nhwc(const void *X, const void *W, const float *bias, const void
                      int B, int H, int Wd, int Cin, int Cout, int KH, int KW, int stride, int pad,
                      int relu, int dtype, void *stream);
 
+/* ---------------------------------------------------------------------------------------------
+ * Per-decoder-layer query preparation, fused.
+ * Replaces: TransformerDecoder.forward lines 684-690 (reference_points[:, :, None] * cat(valid_ratios,
+ *           valid_ratios)) + gen_sineembed_for_position (models/dino/utils.py:141-167).
+ *   ref [B*nq,4] fp32 (cx,cy,w,h)   valid_ratios [B,L,2] fp32 (w,h)   dim_t [128] fp32 = 10000**(2*(i//2)/128)
+ *   ref_in [B*nq,L,4] fp32          sine [B*nq,512] sine_dtype: [emb(y)|emb(x)|emb(w)|emb(h)] of level 0
+ */
+int dtlr_decoder_query_prep(const float *ref, const float *valid_ratios, const float *dim_t,
+                            float *ref_in, void *sine, int B, int nq, int L, int sine_dtype, void *stream);
+
+/* out = sigmoid(delta + inverse_sigmoid(ref)), elementwise over n fp32 values.
+ * Replaces: the box refinement of TransformerDecoder.forward (deformable_transformer.py:734-739) and of
+ *           DINO.forward (models/dino/dino.py:343-346) with inverse_sigmoid of util/misc.py:575-579 (eps 1e-3). */
+int dtlr_box_refine(const float *delta, const float *ref, float *out, long n, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

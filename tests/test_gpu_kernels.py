@@ -234,3 +234,25 @@ def test_conv2d_nhwc_implicit_gemm(B, H, W, Cin, Cout, k, stride, pad):
                         stride=stride, padding=pad).permute(0, 2, 3, 1).clamp(min=0).float()
         gotb = ops.conv2d_nhwc(xb.cuda(), wb.cuda(), b.cuda(), stride, pad, True, None).float().cpu()
         assert (gotb - refb).abs().max() < 2 ** -8 * max(1.0, refb.abs().max().item()) + 1e-4
+
+
+def test_decoder_query_prep_and_box_refine_vs_oracle():
+    """Fused decoder glue == oracle gen_sineembed_for_position / reference scaling / inverse_sigmoid refinement."""
+    from dtlr_amd import ops
+    from oracle import dtlr_oracle as O
+    g = np.random.Generator(np.random.PCG64(3))
+    B, nq, L = 3, 37, 4
+    ref = torch.from_numpy(g.uniform(0, 1, (B, nq, 4)).astype(np.float32))
+    ref[0, 0] = torch.tensor([0.0, 1.0, 0.0005, 0.9999])             # inverse_sigmoid clamps
+    vr = torch.from_numpy(g.uniform(0.5, 1.0, (B, L, 2)).astype(np.float32))
+    ref_in, sine = ops.decoder_query_prep(ref.cuda(), vr.cuda(), torch.float32)
+    want_in = ref[:, :, None] * torch.cat([vr, vr], -1)[:, None]
+    assert (ref_in.cpu() - want_in).abs().max() < 1e-7
+    want_sine = O.gen_sineembed_for_position(want_in[:, :, 0, :])
+    assert (sine.cpu() - want_sine).abs().max() < 2e-6
+    _, sine_b = ops.decoder_query_prep(ref.cuda(), vr.cuda(), torch.bfloat16)
+    assert (sine_b.float().cpu() - want_sine).abs().max() < 2 ** -8
+    delta = torch.from_numpy(g.standard_normal((B, nq, 4)).astype(np.float32))
+    got = ops.box_refine(delta.cuda(), ref.cuda()).cpu()
+    want = (delta + O.inverse_sigmoid(ref)).sigmoid()
+    assert (got - want).abs().max() < 1e-6
