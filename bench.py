@@ -171,7 +171,7 @@ def main():
                 traffic = json.load(open(tj)).get(f"{args.dtype}_enc_bytes_per_launch")
             except Exception:
                 traffic = None
-        roof = {"bound": "hbm", "kernel": "msda_fwd_l4p4 (encoder call, Lq=S)", "achieved": round(achieved, 1),
+        roof = {"bound": "hbm", "kernel": "msda_enc_lds_kernel (deformable sampling, encoder call, Lq=S=5440/line)", "achieved": round(achieved, 1),
                 "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
                 "algorithmic_bytes_per_launch": alg, "mean_launch_ms": round(ms, 4), "launches_timed": len(enc)}
         if dec:

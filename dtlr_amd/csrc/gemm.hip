@@ -25,6 +25,7 @@
 // Fused epilogue: + bias, ReLU, zero masked rows (value.masked_fill, ms_deform_attn.py:95-96),
 //                 + residual, ReLU-after-residual (ResNet bottleneck tail), output fp32 or bf16.
 #include "dtlr_common.h"
+#include <cstdlib>
 
 namespace dtlr {
 
@@ -52,7 +53,8 @@ template <int N> __device__ __forceinline__ void wait_vmcnt() {
     __builtin_amdgcn_sched_barrier(0);
 }
 
-enum : int { EPI_BIAS = 1, EPI_RELU = 2, EPI_RESIDUAL = 4, EPI_ROWMASK = 8, EPI_RELU_POST = 16 };
+enum : int { EPI_BIAS = 1, EPI_RELU = 2, EPI_RESIDUAL = 4, EPI_ROWMASK = 8, EPI_RELU_POST = 16,
+              DBG_NO_LOAD = 256, DBG_NO_MMA = 512, DBG_NO_LDS = 1024 };   // ablation switches (env DTLR_GEMM_ABLATE), timing only
 
 template <typename T> struct GT;
 template <> struct GT<uint16_t> {   // bf16
@@ -263,7 +265,7 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(
 #define ADVANCE_AND_LOAD(S)                                                                        \
     {                                                                                              \
         if (++lkt == nk) { lkt = 0; ++ltile; SET_LOAD_TILE(ltile) }                                \
-        GLOAD(S, lkt)                                                                              \
+        if (!(flags & DBG_NO_LOAD)) GLOAD(S, lkt)                                                  \
     }
 
     f32x4_t acc[4][4];
@@ -296,10 +298,14 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(
                 wf[i] = *reinterpret_cast<const uint4*>(wt + i * 16 * LDS_ROW + kq * 64);          \
                 xf[i] = *reinterpret_cast<const uint4*>(xt + i * 16 * LDS_ROW + kq * 64);          \
             }                                                                                      \
-            _Pragma("unroll") for (int ci = 0; ci < 4; ++ci)                                       \
-                _Pragma("unroll") for (int ti = 0; ti < 4; ++ti) GT<T>::mma(wf[ci], xf[ti], acc[ci][ti]); \
+            if (!(flags & DBG_NO_MMA)) {                                                           \
+                _Pragma("unroll") for (int ci = 0; ci < 4; ++ci)                                   \
+                    _Pragma("unroll") for (int ti = 0; ti < 4; ++ti) GT<T>::mma(wf[ci], xf[ti], acc[ci][ti]); \
+            } else {                                                                               \
+                _Pragma("unroll") for (int i = 0; i < 4; ++i) { asm volatile("" :: "v"(wf[i].x), "v"(xf[i].x)); } \
+            }                                                                                      \
         }                                                                                          \
-        if (s + 1 < total) {                                                                       \
+        if (s + 1 < total && !(flags & DBG_NO_LDS)) {                                              \
             /* slab s+1's loads are older than the LOADS_PER_SLAB loads of slab s+2 (if any were issued) */ \
             if (ASM_LOADS) { if (s + 2 < total) wait_vmcnt<LOADS_PER_SLAB>(); else wait_vmcnt<0>(); } \
             LSTORE(SS, 1 - (CUR))                                                                  \
@@ -396,6 +402,7 @@ extern "C" int dtlr_gemm_nt(const void* A, const void* A2, const void* W, const 
     if (M <= 0 || N <= 0 || K <= 0) return DTLR_EINVAL;
     int flags = (bias ? EPI_BIAS : 0) | (relu == 1 ? EPI_RELU : 0) | (relu == 2 ? EPI_RELU_POST : 0) |
                 (residual ? EPI_RESIDUAL : 0) | (row_mask ? EPI_ROWMASK : 0);
+    if (const char* ab = getenv("DTLR_GEMM_ABLATE")) flags |= (atoi(ab) & (DBG_NO_LOAD | DBG_NO_MMA | DBG_NO_LDS));   // timing experiments only
     hipStream_t st = (hipStream_t)stream;
     if (in_dtype == DTLR_BF16) {
         if (K % 64) return DTLR_ESHAPE;

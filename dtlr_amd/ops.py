@@ -18,7 +18,7 @@ from . import MultiScaleDeformableAttention as _msda
 from . import _lib
 
 # operators still served by ROCm libraries via torch (shrinks as kernels land)
-LIBRARY_BACKED = {"conv2d_nhwc(7x7 stem only)", "maxpool_nhwc", "groupnorm_tokens", "mha", "topk", "sort"}
+LIBRARY_BACKED = {"conv2d_nhwc(7x7 stem only)", "mha(fp32 path only)", "topk", "sort"}
 
 _DT = {torch.float32: _lib.DTLR_F32, torch.bfloat16: _lib.DTLR_BF16, torch.float64: _lib.DTLR_F64}
 
@@ -117,19 +117,28 @@ def conv2d_nhwc(x, w, bias, stride: int, padding: int, relu=False, residual=None
 
 
 def maxpool_nhwc(x, k: int = 3, stride: int = 2, padding: int = 1):
-    y = F.max_pool2d(x.permute(0, 3, 1, 2), k, stride, padding)
-    return y.permute(0, 2, 3, 1).contiguous()
+    """3x3/s2/p1 max pooling on NHWC (HIP kernel)."""
+    assert (k, stride, padding) == (3, 2, 1)
+    B, H, W, C = x.shape
+    x = x if x.is_contiguous() else x.contiguous()
+    y = torch.empty((B, (H - 1) // 2 + 1, (W - 1) // 2 + 1, C), dtype=x.dtype, device=x.device)
+    code = _lib.lib().dtlr_maxpool3x3s2_nhwc(x.data_ptr(), y.data_ptr(), B, H, W, C, _DT[x.dtype], _lib.current_stream())
+    _lib.check(code, "dtlr_maxpool3x3s2_nhwc")
+    return y
 
 
 def groupnorm_tokens(x, groups: int, w, b, eps: float = 1e-5):
     """GroupNorm(32, 256) over [B, T, C] tokens of one feature level: statistics per (sample,
-    group) over (C/groups channels x T positions) -- models/dino/dino.py:121-134."""
+    group) over (C/groups channels x T positions) -- models/dino/dino.py:121-134 (HIP kernels)."""
     B, T, C = x.shape
-    xf = x.float().reshape(B, T, groups, C // groups)
-    mean = xf.mean(dim=(1, 3), keepdim=True)
-    var = xf.var(dim=(1, 3), unbiased=False, keepdim=True)
-    y = ((xf - mean) * torch.rsqrt(var + eps)).reshape(B, T, C) * w.float() + b.float()
-    return y.to(x.dtype)
+    x = x if x.is_contiguous() else x.contiguous()
+    L_ = _lib.lib()
+    ws = torch.empty(L_.dtlr_groupnorm_workspace_bytes(B, T), dtype=torch.uint8, device=x.device)
+    y = torch.empty_like(x)
+    code = L_.dtlr_groupnorm_tokens(x.data_ptr(), w.data_ptr(), b.data_ptr(), y.data_ptr(), ws.data_ptr(), B, T, C, groups, eps,
+                                    _DT[x.dtype], _lib.current_stream())
+    _lib.check(code, "dtlr_groupnorm_tokens")
+    return y
 
 
 # bench.py sets this to a list to time every MSDA launch with HIP events recorded on the launch

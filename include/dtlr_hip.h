@@ -155,6 +155,21 @@ int dtlr_decoder_query_prep(const float *ref, const float *valid_ratios, const f
  *           DINO.forward (models/dino/dino.py:343-346) with inverse_sigmoid of util/misc.py:575-579 (eps 1e-3). */
 int dtlr_box_refine(const float *delta, const float *ref, float *out, long n, void *stream);
 
+/* ---------------------------------------------------------------------------------------------
+ * GroupNorm(32, 256) over the tokens of one feature level (statistics per sample and group over
+ * T positions x 8 channels, eps, affine).
+ * Replaces: the nn.GroupNorm(32, hidden_dim) of every input_proj level (models/dino/dino.py:121-134,
+ *           applied at :293,299-301) on the NHWC/token layout.
+ *   x, y [B, T, 256] dtype (F32/BF16); gamma, beta [256] fp32; workspace >= dtlr_groupnorm_workspace_bytes.
+ */
+int dtlr_groupnorm_tokens(const void *x, const float *gamma, const float *beta, void *y, void *workspace,
+                          int B, int T_tokens, int C, int groups, float eps, int dtype, void *stream);
+long dtlr_groupnorm_workspace_bytes(int B, int T_tokens);
+
+/* 3x3 / stride 2 / pad 1 max pooling on NHWC.
+ * Replaces: torchvision resnet50 `maxpool` as run through IntermediateLayerGetter (backbone.py:94,98). */
+int dtlr_maxpool3x3s2_nhwc(const void *x, void *y, int B, int H, int W, int C, int dtype, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

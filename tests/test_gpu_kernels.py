@@ -256,3 +256,30 @@ def test_decoder_query_prep_and_box_refine_vs_oracle():
     got = ops.box_refine(delta.cuda(), ref.cuda()).cpu()
     want = (delta + O.inverse_sigmoid(ref)).sigmoid()
     assert (got - want).abs().max() < 1e-6
+
+
+@pytest.mark.parametrize("B,T", [(2, 4096), (3, 37), (1, 1), (2, 128)])
+def test_groupnorm_tokens(B, T):
+    import torch.nn.functional as F
+    from dtlr_amd import ops
+    x = _rand((B, T, 256), 1, 2.0) + 0.7
+    w, b = _rand((256,), 2) * 0.2 + 1.0, _rand((256,), 3) * 0.1
+    want = F.group_norm(x.double().transpose(1, 2), 32, w.double(), b.double(), 1e-5).transpose(1, 2).float()
+    got = ops.groupnorm_tokens(x.cuda(), 32, w.cuda(), b.cuda()).cpu()
+    assert (got - want).abs().max() < 2e-5
+    xb = x.bfloat16()
+    wantb = F.group_norm(xb.double().transpose(1, 2), 32, w.double(), b.double(), 1e-5).transpose(1, 2).float()
+    gotb = ops.groupnorm_tokens(xb.cuda(), 32, w.cuda(), b.cuda()).float().cpu()
+    assert (gotb - wantb).abs().max() < 2 ** -7 * max(1.0, wantb.abs().max().item())
+
+
+@pytest.mark.parametrize("B,H,W,C", [(2, 64, 96, 64), (1, 7, 9, 64), (2, 1, 1, 8), (1, 5, 4, 16)])
+def test_maxpool_nhwc(B, H, W, C):
+    import torch.nn.functional as F
+    from dtlr_amd import ops
+    x = _rand((B, H, W, C), 5)
+    want = F.max_pool2d(x.permute(0, 3, 1, 2), 3, 2, 1).permute(0, 2, 3, 1)
+    assert torch.equal(ops.maxpool_nhwc(x.cuda()).cpu(), want)
+    xb = x.bfloat16()
+    wantb = F.max_pool2d(xb.float().permute(0, 3, 1, 2), 3, 2, 1).permute(0, 2, 3, 1)
+    assert torch.equal(ops.maxpool_nhwc(xb.cuda()).float().cpu(), wantb)
