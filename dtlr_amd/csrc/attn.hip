@@ -140,6 +140,129 @@ __global__ __launch_bounds__(256) void v_transpose_kernel(const uint16_t* __rest
     }
 }
 
+
+// ---- fp32 variant (parity path): same orientation trick on the exact-fp32 matrix core v_mfma_f32_16x16x4_f32.
+// A lane feeds ONE float per MFMA (A[row = l&15][k = l>>4]); the lane's 8 contiguous d (or 4 contiguous keys)
+// are spread over 8 (or 4) MFMAs -- a permutation of the contraction index applied to both operands alike.
+//   S^T tile (16 keys x 16 queries): 8 MFMAs, lane (g,n) supplies K[key n][8g+j] and Q[query n][8g+j], j = 0..7
+//   O^T tile (16 d x 16 queries) per 16-key tile: 4 MFMAs, lane supplies V^T[d n][4g+r] and its own P[key 4g+r]
+__global__ __launch_bounds__(256) void mha_fwd_f32_kernel(const float* __restrict__ qk, const float* __restrict__ vt,
+                                                          float* __restrict__ out, int L, int Lpad, int H, float scale_log2e)
+{
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int g = lane >> 4, n = lane & 15;
+    const int h = blockIdx.y, b = blockIdx.z;
+    const int C = H * 32;
+    const int q0 = blockIdx.x * 128 + wave * 32;
+    if (q0 >= L) return;
+    const float* qkb = qk + (long)b * L * (2 * C);
+    float qf[2][8];
+#pragma unroll
+    for (int qt = 0; qt < 2; ++qt) {
+        const int q = min(q0 + qt * 16 + n, L - 1);
+        const float4* p = reinterpret_cast<const float4*>(qkb + (long)q * (2 * C) + h * 32 + 8 * g);
+        const float4 a = p[0], c = p[1];
+        qf[qt][0] = a.x; qf[qt][1] = a.y; qf[qt][2] = a.z; qf[qt][3] = a.w; qf[qt][4] = c.x; qf[qt][5] = c.y; qf[qt][6] = c.z; qf[qt][7] = c.w;
+    }
+    const float* vtb = vt + ((long)(b * H + h) * 32) * Lpad;
+    f32x4 o[2][2];
+#pragma unroll
+    for (int qt = 0; qt < 2; ++qt)
+#pragma unroll
+        for (int dt = 0; dt < 2; ++dt) o[qt][dt] = f32x4{0.f, 0.f, 0.f, 0.f};
+    float m[2] = {-INFINITY, -INFINITY}, lsum[2] = {0.f, 0.f};
+
+    for (int kb = 0; kb < Lpad; kb += 32) {
+        float kf[2][8];
+#pragma unroll
+        for (int kt = 0; kt < 2; ++kt) {
+            const int key = min(kb + kt * 16 + n, L - 1);
+            const float4* p = reinterpret_cast<const float4*>(qkb + (long)key * (2 * C) + C + h * 32 + 8 * g);
+            const float4 a = p[0], c = p[1];
+            kf[kt][0] = a.x; kf[kt][1] = a.y; kf[kt][2] = a.z; kf[kt][3] = a.w; kf[kt][4] = c.x; kf[kt][5] = c.y; kf[kt][6] = c.z; kf[kt][7] = c.w;
+        }
+        float vf[2][2][4];                                  // [d tile][key tile][r]
+#pragma unroll
+        for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+            for (int kt = 0; kt < 2; ++kt) {
+                const float4 t = *reinterpret_cast<const float4*>(vtb + (long)(dt * 16 + n) * Lpad + kb + kt * 16 + 4 * g);
+                vf[dt][kt][0] = t.x; vf[dt][kt][1] = t.y; vf[dt][kt][2] = t.z; vf[dt][kt][3] = t.w;
+            }
+#pragma unroll
+        for (int qt = 0; qt < 2; ++qt) {
+            f32x4 s[2];
+#pragma unroll
+            for (int kt = 0; kt < 2; ++kt) {
+                s[kt] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                for (int j = 0; j < 8; ++j) s[kt] = __builtin_amdgcn_mfma_f32_16x16x4f32(kf[kt][j], qf[qt][j], s[kt], 0, 0, 0);
+            }
+            float mx = -INFINITY;
+#pragma unroll
+            for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int key = kb + kt * 16 + 4 * g + r;
+                    const float v = key < L ? s[kt][r] * scale_log2e : -INFINITY;
+                    s[kt][r] = v;
+                    mx = fmaxf(mx, v);
+                }
+            mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
+            mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+            const float m_new = fmaxf(m[qt], mx);
+            const float alpha = exp2f(m[qt] - m_new);
+            m[qt] = m_new;
+            float ps = 0.f;
+#pragma unroll
+            for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) { s[kt][r] = exp2f(s[kt][r] - m_new); ps += s[kt][r]; }
+            lsum[qt] = lsum[qt] * alpha + ps;
+#pragma unroll
+            for (int dt = 0; dt < 2; ++dt) {
+                o[qt][dt] *= alpha;
+#pragma unroll
+                for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r)
+                        o[qt][dt] = __builtin_amdgcn_mfma_f32_16x16x4f32(vf[dt][kt][r], s[kt][r], o[qt][dt], 0, 0, 0);
+            }
+        }
+    }
+#pragma unroll
+    for (int qt = 0; qt < 2; ++qt) {
+        float l = lsum[qt];
+        l += __shfl_xor(l, 16, 64);
+        l += __shfl_xor(l, 32, 64);
+        const float inv = 1.0f / l;
+        const int q = q0 + qt * 16 + n;
+        if (q < L) {
+#pragma unroll
+            for (int dt = 0; dt < 2; ++dt) {
+                const f32x4 v = o[qt][dt] * inv;
+                *reinterpret_cast<float4*>(out + ((long)b * L + q) * C + h * 32 + dt * 16 + 4 * g) = make_float4(v[0], v[1], v[2], v[3]);
+            }
+        }
+    }
+}
+
+__global__ __launch_bounds__(256) void v_transpose_f32_kernel(const float* __restrict__ v, float* __restrict__ vt, int L, int Lpad, int H)
+{
+    extern __shared__ __attribute__((aligned(16))) float tilef[];      // [C][33]
+    const int C = H * 32;
+    const int k0 = blockIdx.x * 32, b = blockIdx.y;
+    for (int i = threadIdx.x; i < 32 * C; i += blockDim.x) {
+        const int key = i / C, c = i % C;
+        tilef[c * 33 + key] = (k0 + key < L) ? v[((long)b * L + k0 + key) * C + c] : 0.f;
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < C * 32; i += blockDim.x) {
+        const int c = i / 32, key = i % 32;
+        vt[((long)(b * H + c / 32) * 32 + c % 32) * Lpad + k0 + key] = tilef[c * 33 + key];
+    }
+}
+
 }  // namespace dtlr
 
 using namespace dtlr;
@@ -150,10 +273,20 @@ extern "C" int dtlr_mha_forward(const void* qk, const void* v, void* vt_workspac
     if (!qk || !v || !vt_workspace || !out) return DTLR_EINVAL;
     if (B <= 0 || L <= 0 || H <= 0) return DTLR_EINVAL;
     if (head_dim != 32) return DTLR_ESHAPE;
-    if (dtype != DTLR_BF16) return DTLR_EDTYPE;
+    if (dtype != DTLR_BF16 && dtype != DTLR_F32) return DTLR_EDTYPE;
     hipStream_t st = (hipStream_t)stream;
     const int Lpad = (L + 31) / 32 * 32;
     const int C = H * 32;
+    if (dtype == DTLR_F32) {
+        hipLaunchKernelGGL(v_transpose_f32_kernel, dim3(Lpad / 32, B), dim3(256), (size_t)C * 33 * sizeof(float), st,
+                           (const float*)v, (float*)vt_workspace, L, Lpad, H);
+        int rc0 = check_launch();
+        if (rc0) return rc0;
+        hipLaunchKernelGGL(mha_fwd_f32_kernel, dim3((L + 127) / 128, H, B), dim3(256), 0, st,
+                           (const float*)qk, (const float*)vt_workspace, (float*)out, L, Lpad, H,
+                           1.4426950408889634f / sqrtf((float)head_dim));
+        return check_launch();
+    }
     hipLaunchKernelGGL(v_transpose_kernel, dim3(Lpad / 32, B), dim3(256), (size_t)C * 33 * sizeof(uint16_t), st,
                        (const uint16_t*)v, (uint16_t*)vt_workspace, L, Lpad, H);
     int rc = check_launch();
@@ -167,5 +300,5 @@ extern "C" int dtlr_mha_forward(const void* qk, const void* v, void* vt_workspac
 extern "C" long dtlr_mha_workspace_bytes(int B, int L, int H, int head_dim)
 {
     const long Lpad = (L + 31) / 32 * 32;
-    return (long)B * H * head_dim * Lpad * 2;
+    return (long)B * H * head_dim * Lpad * 4;        // sized for fp32; bf16 uses half
 }

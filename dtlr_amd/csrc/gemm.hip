@@ -13,8 +13,8 @@
 //     8/16-byte vectors, and a per-token reduction is in-lane + two xor-shuffles.
 //   * K is walked in 128-byte slabs (64 bf16 / 32 fp32) staged global -> registers -> LDS (16-byte
 //     loads, 8 lanes per 128-byte row: full-line coalescing), double-buffered with ONE barrier per
-//     slab; LDS rows are padded to 144 B (9 x 16 B, 9 coprime with 16) so the 16 rows of a fragment
-//     land on 16 distinct 16-byte slots for ds_read_b128.
+//     slab; LDS rows are 128 B with their 16-byte chunks XOR-swizzled by (row & 7) so the 16 lanes of
+//     every ds_read_b128 service group land on 16 distinct 16-byte slots.
 //   * bf16: v_mfma_f32_16x16x32_bf16 (one per 64-byte k-slab);  fp32: v_mfma_f32_16x16x4_f32 (exact
 //     fp32, four per 64-byte slab; the lane's 4 consecutive k of a 16-byte read feed MFMA j = 0..3 --
 //     a k-permutation applied identically to both operands, so the sum is unchanged).
@@ -32,7 +32,7 @@ namespace dtlr {
 typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8_t;
 typedef __attribute__((ext_vector_type(4))) float f32x4_t;
 
-constexpr int BM = 128, BN = 128, SLAB = 128, LDS_ROW = 144;      // bytes
+constexpr int BM = 128, BN = 128, SLAB = 128, LDS_ROW = 128;      // bytes (rows unpadded; XOR-swizzled 16-byte chunks)
 constexpr int TILE_BYTES = BM * LDS_ROW;                           // one operand tile in LDS
 
 // Staging loads are issued through inline asm so that hipcc does not count them: across the loop
@@ -52,6 +52,14 @@ template <int N> __device__ __forceinline__ void wait_vmcnt() {
     else if constexpr (N == 12) asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
     __builtin_amdgcn_sched_barrier(0);
 }
+
+// Ablation switches for timing experiments (tools/profile_kernels.py --only gemm_ablate): only honoured when
+// the library is built with -DDTLR_GEMM_ABLATION, so the production hot loop carries no extra branches.
+#ifdef DTLR_GEMM_ABLATION
+#define ABLATE(BIT) (flags & (BIT))
+#else
+#define ABLATE(BIT) false
+#endif
 
 enum : int { EPI_BIAS = 1, EPI_RELU = 2, EPI_RESIDUAL = 4, EPI_ROWMASK = 8, EPI_RELU_POST = 16,
               DBG_NO_LOAD = 256, DBG_NO_MMA = 512, DBG_NO_LDS = 1024 };   // ablation switches (env DTLR_GEMM_ABLATE), timing only
@@ -190,7 +198,12 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(
     // staging: each operand tile = 128 rows x 128 B = 1024 16-byte chunks; thread t takes rows srow + 32 i
     // (8 consecutive lanes cover one 128-byte row slab), kc = tid & 7.
     const int srow = tid >> 3, kc = tid & 7;
-    const int lds0 = srow * LDS_ROW + kc * 16;
+    // LDS image: row r = 128 bytes, its 16-byte chunk c stored at chunk position c ^ (r & 7).  For
+    // ds_read_b128 (serviced in the non-contiguous 16-lane groups {0-3,12-15,20-27}, ...) the 16 lanes of a
+    // group then hit 16 distinct 16-byte slots of the 256-byte bank row; a padded stride (144 B, the first
+    // version) is NOT conflict-free for those groups -- 7 of 16 lanes collided (measured: the LDS-read +
+    // barrier skeleton alone was a third of the kernel time).
+    const int lds0 = srow * LDS_ROW + ((kc ^ (srow & 7)) * 16);
     long a_off[4], w_off[4];                                    // loader state: byte offsets at k-slab 0
     int hi0[4], wi0[4];                                         // CONV: top-left input coordinate of the pixel
     const int slabs_per_tap = CONV ? (cp.Cin * (int)sizeof(T)) / SLAB : 1;
@@ -265,7 +278,7 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(
 #define ADVANCE_AND_LOAD(S)                                                                        \
     {                                                                                              \
         if (++lkt == nk) { lkt = 0; ++ltile; SET_LOAD_TILE(ltile) }                                \
-        if (!(flags & DBG_NO_LOAD)) GLOAD(S, lkt)                                                  \
+        if (!ABLATE(DBG_NO_LOAD)) GLOAD(S, lkt)                                                    \
     }
 
     f32x4_t acc[4][4];
@@ -290,22 +303,27 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(
 #define HALF(CUR, LS, SS)                                                                          \
     {                                                                                              \
         if (s + 2 < total) ADVANCE_AND_LOAD(LS)                                                    \
-        const unsigned char* wt = smem + (CUR) * 2 * TILE_BYTES + (wn * 64 + n) * LDS_ROW + g * 16; \
+        const unsigned char* wt = smem + (CUR) * 2 * TILE_BYTES + (wn * 64 + n) * LDS_ROW;         \
         const unsigned char* xt = wt + TILE_BYTES + ((wm - wn) * 64) * LDS_ROW;                    \
+        /* all 16 fragment reads of the slab are issued before the first MFMA: the matrix pipe then starts as \
+           soon as the first pair lands and the second k-half's LDS latency hides behind the first half's MFMAs */ \
+        uint4 wf[2][4], xf[2][4];                                                                  \
         _Pragma("unroll") for (int kq = 0; kq < 2; ++kq) {                                         \
-            uint4 wf[4], xf[4];                                                                    \
+            const int sw = (((kq * 4 + g) ^ (n & 7)) * 16);      /* rows i*16 + n: (row & 7) == (n & 7) */ \
             _Pragma("unroll") for (int i = 0; i < 4; ++i) {                                        \
-                wf[i] = *reinterpret_cast<const uint4*>(wt + i * 16 * LDS_ROW + kq * 64);          \
-                xf[i] = *reinterpret_cast<const uint4*>(xt + i * 16 * LDS_ROW + kq * 64);          \
-            }                                                                                      \
-            if (!(flags & DBG_NO_MMA)) {                                                           \
-                _Pragma("unroll") for (int ci = 0; ci < 4; ++ci)                                   \
-                    _Pragma("unroll") for (int ti = 0; ti < 4; ++ti) GT<T>::mma(wf[ci], xf[ti], acc[ci][ti]); \
-            } else {                                                                               \
-                _Pragma("unroll") for (int i = 0; i < 4; ++i) { asm volatile("" :: "v"(wf[i].x), "v"(xf[i].x)); } \
+                wf[kq][i] = *reinterpret_cast<const uint4*>(wt + i * 16 * LDS_ROW + sw);           \
+                xf[kq][i] = *reinterpret_cast<const uint4*>(xt + i * 16 * LDS_ROW + sw);           \
             }                                                                                      \
         }                                                                                          \
-        if (s + 1 < total && !(flags & DBG_NO_LDS)) {                                              \
+        _Pragma("unroll") for (int kq = 0; kq < 2; ++kq) {                                         \
+            if (!ABLATE(DBG_NO_MMA)) {                                                             \
+                _Pragma("unroll") for (int ci = 0; ci < 4; ++ci)                                   \
+                    _Pragma("unroll") for (int ti = 0; ti < 4; ++ti) GT<T>::mma(wf[kq][ci], xf[kq][ti], acc[ci][ti]); \
+            } else {                                                                               \
+                _Pragma("unroll") for (int i = 0; i < 4; ++i) { asm volatile("" :: "v"(wf[kq][i].x), "v"(xf[kq][i].x)); } \
+            }                                                                                      \
+        }                                                                                          \
+        if (s + 1 < total && !ABLATE(DBG_NO_LDS)) {                                                \
             /* slab s+1's loads are older than the LOADS_PER_SLAB loads of slab s+2 (if any were issued) */ \
             if (ASM_LOADS) { if (s + 2 < total) wait_vmcnt<LOADS_PER_SLAB>(); else wait_vmcnt<0>(); } \
             LSTORE(SS, 1 - (CUR))                                                                  \
@@ -402,7 +420,9 @@ extern "C" int dtlr_gemm_nt(const void* A, const void* A2, const void* W, const 
     if (M <= 0 || N <= 0 || K <= 0) return DTLR_EINVAL;
     int flags = (bias ? EPI_BIAS : 0) | (relu == 1 ? EPI_RELU : 0) | (relu == 2 ? EPI_RELU_POST : 0) |
                 (residual ? EPI_RESIDUAL : 0) | (row_mask ? EPI_ROWMASK : 0);
+#ifdef DTLR_GEMM_ABLATION
     if (const char* ab = getenv("DTLR_GEMM_ABLATE")) flags |= (atoi(ab) & (DBG_NO_LOAD | DBG_NO_MMA | DBG_NO_LDS));   // timing experiments only
+#endif
     hipStream_t st = (hipStream_t)stream;
     if (in_dtype == DTLR_BF16) {
         if (K % 64) return DTLR_ESHAPE;

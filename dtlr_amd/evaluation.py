@@ -36,19 +36,11 @@ def blank_probabilities(outputs: Dict[str, torch.Tensor], eps: float) -> torch.T
 
 @torch.no_grad()
 def decode_blank_records(outputs, eps: Optional[float] = None) -> Tuple[torch.Tensor, torch.Tensor]:
-    """Device-side blank/argmax decode -> (labels [B,nq] int32 left-packed, -1 padded; lengths [B] int32).
-    No repeat collapse (engine.py:511-530, duplicate=False)."""
+    """Device-side blank/argmax decode (HIP kernel, one workgroup per line) -> (labels [B,nq] int32
+    left-packed, -1 padded; lengths [B] int32).  No repeat collapse (engine.py:511-530, duplicate=False)."""
+    from . import ops
     C = outputs["pred_logits"].shape[-1]
-    probs = blank_probabilities(outputs, 0.03 / C if eps is None else eps)
-    pred = probs.argmax(-1)                                     # 0 = blank
-    keep = pred != 0
-    B, nq = pred.shape
-    # stable left-pack: position of each kept token = (#kept before it)
-    pos = torch.cumsum(keep, 1) - 1
-    labels = torch.full((B, nq), -1, dtype=torch.int32, device=pred.device)
-    rows = torch.arange(B, device=pred.device)[:, None].expand(B, nq)
-    labels[rows[keep], pos[keep]] = (pred[keep] - 1).to(torch.int32)
-    return labels, keep.sum(1).to(torch.int32)
+    return ops.decode_blank(outputs["pred_logits"], outputs["pred_boxes"], 0.03 / C if eps is None else eps)
 
 
 def records_to_lists(labels: torch.Tensor, lengths: torch.Tensor) -> List[List[int]]:

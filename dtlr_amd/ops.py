@@ -18,7 +18,7 @@ from . import MultiScaleDeformableAttention as _msda
 from . import _lib
 
 # operators still served by ROCm libraries via torch (shrinks as kernels land)
-LIBRARY_BACKED = {"conv2d_nhwc(7x7 stem only)", "mha(fp32 path only)", "topk", "sort"}
+LIBRARY_BACKED = {"conv2d_nhwc(7x7 stem only)", "postprocess topk / nms"}
 
 _DT = {torch.float32: _lib.DTLR_F32, torch.bfloat16: _lib.DTLR_BF16, torch.float64: _lib.DTLR_F64}
 
@@ -211,27 +211,21 @@ def msda_encoder(value, level_hw, ow, ref):
 
 
 def mha(qk, v, n_heads: int):
-    """Self-attention core.  qk [B, L, 2C] (projected q | k), v [B, L, C] -> [B, L, C].
-    bf16: fused flash-style HIP kernel on the matrix cores (scores never leave the chip).
-    fp32 (parity path): rocBLAS batched GEMMs + softmax through torch."""
+    """Self-attention core.  qk [B, L, 2C] (projected q | k), v [B, L, C] -> [B, L, C].  Fused flash-style HIP
+    kernel on the matrix cores, scores never leave the chip: bf16 (mfma 16x16x32) or exact fp32 (mfma 16x16x4)."""
     B, L, C2 = qk.shape
     C = C2 // 2
     hd = C // n_heads
-    if qk.dtype == torch.bfloat16 and hd == 32:
-        qk, v = qk.contiguous(), v.contiguous()
-        L_ = _lib.lib()
-        ws = torch.empty(L_.dtlr_mha_workspace_bytes(B, L, n_heads, hd), dtype=torch.uint8, device=qk.device)
-        out = torch.empty((B, L, C), dtype=qk.dtype, device=qk.device)
-        code = L_.dtlr_mha_forward(qk.data_ptr(), v.data_ptr(), ws.data_ptr(), out.data_ptr(), B, L, n_heads, hd,
-                                   _lib.DTLR_BF16, _lib.current_stream())
-        _lib.check(code, "dtlr_mha_forward")
-        return out
-    qh = qk[..., :C].reshape(B, L, n_heads, hd).transpose(1, 2)
-    kh = qk[..., C:].reshape(B, L, n_heads, hd).transpose(1, 2)
-    vh = v.view(B, L, n_heads, hd).transpose(1, 2)
-    att = torch.softmax((qh.float() * (1.0 / math.sqrt(hd))) @ kh.float().transpose(-1, -2), dim=-1)
-    o = (att @ vh.float()).to(qk.dtype)
-    return o.transpose(1, 2).reshape(B, L, C)
+    if qk.dtype not in (torch.bfloat16, torch.float32) or hd != 32:
+        raise RuntimeError(f"dtlr_amd.ops.mha: unsupported dtype/head_dim {qk.dtype}/{hd}")
+    qk, v = qk.contiguous(), v.contiguous()
+    L_ = _lib.lib()
+    ws = torch.empty(L_.dtlr_mha_workspace_bytes(B, L, n_heads, hd), dtype=torch.uint8, device=qk.device)
+    out = torch.empty((B, L, C), dtype=qk.dtype, device=qk.device)
+    code = L_.dtlr_mha_forward(qk.data_ptr(), v.data_ptr(), ws.data_ptr(), out.data_ptr(), B, L, n_heads, hd,
+                               _DT[qk.dtype], _lib.current_stream())
+    _lib.check(code, "dtlr_mha_forward")
+    return out
 
 
 _DIM_T = {}
@@ -265,6 +259,26 @@ def box_refine(delta, ref):
 
 
 def topk_rows(scores, k: int):
-    """Indices of the k largest per row, descending (two-stage selection,
-    deformable_transformer.py:345).  Scores are always fp32."""
-    return torch.topk(scores, k, dim=1)[1]
+    """Indices [B,k] int64 of the k largest per row, descending, ties -> lower index (two-stage selection,
+    deformable_transformer.py:345).  Scores are always fp32.  HIP kernel: per-row bitonic sort in LDS."""
+    B, S = scores.shape
+    scores = scores.float().contiguous()
+    idx = torch.empty((B, k), dtype=torch.int64, device=scores.device)
+    code = _lib.lib().dtlr_topk_rows(scores.data_ptr(), idx.data_ptr(), B, S, k, _lib.current_stream())
+    _lib.check(code, "dtlr_topk_rows")
+    return idx
+
+
+def decode_blank(logits, boxes, eps: float):
+    """Blank/argmax decoder (HIP kernel): logits [B,nq,C], boxes [B,nq,4] -> (labels [B,nq] int32 left-packed
+    -1 padded, lengths [B] int32)."""
+    require_cuda(logits, "pred_logits")
+    B, nq, C = logits.shape
+    logits = logits.float().contiguous()
+    boxes = boxes.float().contiguous()
+    labels = torch.empty((B, nq), dtype=torch.int32, device=logits.device)
+    lengths = torch.empty((B,), dtype=torch.int32, device=logits.device)
+    code = _lib.lib().dtlr_decode_blank(logits.data_ptr(), boxes.data_ptr(), labels.data_ptr(), lengths.data_ptr(), B, nq, C,
+                                        float(eps), _lib.current_stream())
+    _lib.check(code, "dtlr_decode_blank")
+    return labels, lengths

@@ -102,7 +102,8 @@ int dtlr_layernorm(const void *x, const void *residual, const float *gamma, cons
  *   qk  [B, L, 2*H*head_dim]  projected q (first half of the row) and k (second half);  dtype
  *   v   [B, L, H*head_dim]    projected v;  dtype
  *   vt_workspace              >= dtlr_mha_workspace_bytes(B, L, H, head_dim) bytes of scratch
- *   out [B, L, H*head_dim]    dtype.   head_dim must be 32; dtype BF16 (fp32 accumulate/softmax).
+ *   out [B, L, H*head_dim]    dtype.   head_dim must be 32; dtype BF16 (fp32 accumulate/softmax) or F32
+ *                             (exact-fp32 MFMA).
  */
 int dtlr_mha_forward(const void *qk, const void *v, void *vt_workspace, void *out,
                      int B, int L, int H, int head_dim, int dtype, void *stream);
@@ -169,6 +170,27 @@ long dtlr_groupnorm_workspace_bytes(int B, int T_tokens);
 /* 3x3 / stride 2 / pad 1 max pooling on NHWC.
  * Replaces: torchvision resnet50 `maxpool` as run through IntermediateLayerGetter (backbone.py:94,98). */
 int dtlr_maxpool3x3s2_nhwc(const void *x, void *y, int B, int H, int W, int C, int dtype, void *stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * Indices of the k largest scores of every row, in descending score order; equal scores keep the lower
+ * index first (deterministic; torch.topk leaves ties unspecified).
+ * Replaces: torch.topk(enc_outputs_class_unselected.max(-1)[0], num_queries, dim=1)[1]
+ *           (models/dino/deformable_transformer.py:345).   scores [B,S] fp32 -> idx_out [B,k] int64.
+ */
+int dtlr_topk_rows(const float *scores, long *idx_out, int B, int S, int k, void *stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * Blank/argmax decoder, one workgroup per line.
+ * Replaces: evaluation.convert_output_to_pred, blank branch (evaluation.py:116-158) == the blank
+ *           construction of SetCriterion.loss_CTC (models/dino/dino.py:466-502) followed by
+ *           engine.convert_output_to_pred (engine.py:511-530): sort queries by box cx; p = sigmoid(logits);
+ *           s = sum_c p; blank = 1 - s if s < 1 - eps else eps (then p <- (1-eps) p / s); argmax over
+ *           [blank | p]; drop blanks; no repeat collapse.
+ *   logits [B,nq,C] fp32, boxes [B,nq,4] fp32 (cx first) -> labels [B,nq] int32 left-packed, -1 padded;
+ *   lengths [B] int32.   eps = 0.03/C (evaluation.py:141) or 0.003 (dino.py:491).
+ */
+int dtlr_decode_blank(const float *logits, const float *boxes, int *labels, int *lengths,
+                      int B, int nq, int C, float eps, void *stream);
 
 #ifdef __cplusplus
 }

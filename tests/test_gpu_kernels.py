@@ -283,3 +283,54 @@ def test_maxpool_nhwc(B, H, W, C):
     xb = x.bfloat16()
     wantb = F.max_pool2d(xb.float().permute(0, 3, 1, 2), 3, 2, 1).permute(0, 2, 3, 1)
     assert torch.equal(ops.maxpool_nhwc(xb.cuda()).float().cpu(), wantb)
+
+
+@pytest.mark.parametrize("B,S,k", [(2, 5440, 900), (3, 172, 30), (1, 7, 7), (2, 6800, 900)])
+def test_topk_rows(B, S, k):
+    """Per-row top-k indices: descending scores, ties -> lower index; also with a block of exactly tied
+    scores and +/-inf entries."""
+    from dtlr_amd import ops
+    sc = _rand((B, S), 7)
+    if S > 100:
+        sc[0, 10:60] = sc[0, 5]                 # exact ties
+        sc[0, 3] = float("inf")
+        sc[0, 4] = float("-inf")
+    got = ops.topk_rows(sc.cuda(), k).cpu()
+    order = torch.sort(sc, dim=1, descending=True, stable=True)[1][:, :k]       # stable: ties keep the lower index
+    assert torch.equal(got, order)
+
+
+@pytest.mark.parametrize("C,bias", [(23, -5.0), (23, -1.0), (166, -6.0), (166, -3.0), (7356, -9.5)])
+def test_decode_blank_kernel_vs_oracle(C, bias):
+    """HIP blank decoder == oracle (evaluation.py:116-158 / dino.py:466-502) on both branches of the blank rule,
+    both eps conventions, including rows where every query is blank."""
+    from dtlr_amd import evaluation as E
+    from oracle import dtlr_oracle as O
+    g = np.random.Generator(np.random.PCG64(C + int(-bias * 10)))
+    B, nq = 3, 900 if C < 1000 else 120
+    out = {"pred_logits": torch.from_numpy((g.standard_normal((B, nq, C)) + bias).astype(np.float32)),
+           "pred_boxes": torch.from_numpy(g.uniform(0.02, 0.98, (B, nq, 4)).astype(np.float32))}
+    out["pred_logits"][0, :, :] -= 6.0                                        # line 0: everything blank
+    dev = {k: v.cuda() for k, v in out.items()}
+    for eps in (None, 0.003):
+        labels, lengths = E.decode_blank_records(dev, eps)
+        got = E.records_to_lists(labels, lengths)
+        want = O.decode_blank(out, eps)
+        assert got == want
+        assert (labels.cpu()[torch.arange(nq)[None, :] >= lengths.cpu()[:, None]] == -1).all()
+
+
+@pytest.mark.parametrize("B,L", [(2, 900), (1, 37), (1, 1)])
+def test_mha_f32_vs_fp64_reference(B, L):
+    """Exact-fp32 MFMA attention kernel (parity path) vs an fp64 softmax(QK^T/sqrt(d))V."""
+    import math
+    from dtlr_amd import ops
+    H, hd = 8, 32
+    C = H * hd
+    qk, v = _rand((B, L, 2 * C), 31) * 1.5, _rand((B, L, C), 32)
+    q = qk[..., :C].double().view(B, L, H, hd).transpose(1, 2)
+    k = qk[..., C:].double().view(B, L, H, hd).transpose(1, 2)
+    vv = v.double().view(B, L, H, hd).transpose(1, 2)
+    want = (torch.softmax(q @ k.transpose(-1, -2) / math.sqrt(hd), -1) @ vv).transpose(1, 2).reshape(B, L, C).float()
+    got = ops.mha(qk.cuda(), v.cuda(), H).cpu()
+    assert (got - want).abs().max() < 2e-5
