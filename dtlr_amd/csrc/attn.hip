@@ -270,6 +270,7 @@ using namespace dtlr;
 extern "C" int dtlr_mha_forward(const void* qk, const void* v, void* vt_workspace, void* out,
                                 int B, int L, int H, int head_dim, int dtype, void* stream)
 {
+    clear_stale_error();
     if (!qk || !v || !vt_workspace || !out) return DTLR_EINVAL;
     if (B <= 0 || L <= 0 || H <= 0) return DTLR_EINVAL;
     if (head_dim != 32) return DTLR_ESHAPE;

@@ -114,13 +114,15 @@ using namespace dtlr;
 
 extern "C" int dtlr_topk_rows(const float* scores, long* idx_out, int B, int S, int k, void* stream)
 {
+    clear_stale_error();
     if (!scores || !idx_out) return DTLR_EINVAL;
     if (B <= 0 || S <= 0 || k <= 0 || k > S) return DTLR_EINVAL;
     const int np = next_pow2(S);
     const size_t lds = (size_t)np * 8;
     if (lds > 160 * 1024) return DTLR_ESHAPE;
-    static bool attr = false;
-    if (!attr) { (void)hipFuncSetAttribute((const void*)topk_rows_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); attr = true; }
+    (void)hipGetLastError();                                   // do not inherit a stale error from an earlier API call
+    if (lds > 64 * 1024) (void)hipFuncSetAttribute((const void*)topk_rows_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    (void)hipGetLastError();
     hipLaunchKernelGGL(topk_rows_kernel, dim3(B), dim3(1024), lds, (hipStream_t)stream, scores, idx_out, S, k, np);
     return check_launch();
 }
@@ -128,13 +130,15 @@ extern "C" int dtlr_topk_rows(const float* scores, long* idx_out, int B, int S, 
 extern "C" int dtlr_decode_blank(const float* logits, const float* boxes, int* labels, int* lengths,
                                  int B, int nq, int C, float eps, void* stream)
 {
+    clear_stale_error();
     if (!logits || !boxes || !labels || !lengths) return DTLR_EINVAL;
     if (B <= 0 || nq <= 0 || C <= 0) return DTLR_EINVAL;
     const int np = next_pow2(nq);
     const size_t lds = (size_t)np * 12;
-    if (lds > 160 * 1024) return DTLR_ESHAPE;
-    static bool attr = false;
-    if (!attr) { (void)hipFuncSetAttribute((const void*)decode_blank_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); attr = true; }
+    if (lds > 150 * 1024) return DTLR_ESHAPE;
+    (void)hipGetLastError();
+    if (lds > 60 * 1024) (void)hipFuncSetAttribute((const void*)decode_blank_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    (void)hipGetLastError();
     hipLaunchKernelGGL(decode_blank_kernel, dim3(B), dim3(1024), lds, (hipStream_t)stream, logits, boxes, labels, lengths, nq, C, eps, np);
     return check_launch();
 }

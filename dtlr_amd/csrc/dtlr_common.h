@@ -10,6 +10,10 @@ constexpr int kWave = 64;
 
 extern thread_local int g_last_hip_error;
 
+// Call at the top of every C-ABI entry point: the HIP "last error" is sticky per thread, so an error left by an
+// unrelated earlier call (e.g. a failed attribute query) must not be blamed on this launch.
+inline void clear_stale_error() { (void)hipGetLastError(); }
+
 inline int check_launch() {
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) { g_last_hip_error = (int)e; return DTLR_ELAUNCH; }

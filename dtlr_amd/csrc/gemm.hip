@@ -416,6 +416,7 @@ extern "C" int dtlr_gemm_nt(const void* A, const void* A2, const void* W, const 
                             const void* residual, const unsigned char* row_mask, void* C,
                             int M, int N, int K, int relu, int in_dtype, int out_dtype, void* stream)
 {
+    clear_stale_error();
     if (!A || !W || !C) return DTLR_EINVAL;
     if (M <= 0 || N <= 0 || K <= 0) return DTLR_EINVAL;
     int flags = (bias ? EPI_BIAS : 0) | (relu == 1 ? EPI_RELU : 0) | (relu == 2 ? EPI_RELU_POST : 0) |
@@ -442,6 +443,7 @@ extern "C" int dtlr_conv2d_nhwc(const void* X, const void* W, const float* bias,
                                 int B, int H, int Wd, int Cin, int Cout, int KH, int KW, int stride, int pad,
                                 int relu, int dtype, void* stream)
 {
+    clear_stale_error();
     if (!X || !W || !Y) return DTLR_EINVAL;
     if (B <= 0 || H <= 0 || Wd <= 0 || Cin <= 0 || Cout <= 0 || KH <= 0 || KW <= 0 || stride <= 0 || pad < 0) return DTLR_EINVAL;
     const int elem = dtype == DTLR_BF16 ? 2 : dtype == DTLR_F32 ? 4 : 0;

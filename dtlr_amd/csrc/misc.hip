@@ -57,6 +57,7 @@ using namespace dtlr;
 extern "C" int dtlr_decoder_query_prep(const float* ref, const float* valid_ratios, const float* dim_t,
                                        float* ref_in, void* sine, int B, int nq, int L, int sine_dtype, void* stream)
 {
+    clear_stale_error();
     if (!ref || !valid_ratios || !dim_t || !ref_in || !sine) return DTLR_EINVAL;
     if (B <= 0 || nq <= 0 || L <= 0 || L > 64) return DTLR_EINVAL;
     const long total = (long)B * nq * 64;
@@ -72,6 +73,7 @@ extern "C" int dtlr_decoder_query_prep(const float* ref, const float* valid_rati
 
 extern "C" int dtlr_box_refine(const float* delta, const float* ref, float* out, long n, void* stream)
 {
+    clear_stale_error();
     if (!delta || !ref || !out) return DTLR_EINVAL;
     if (n <= 0) return DTLR_EINVAL;
     hipLaunchKernelGGL(box_refine_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, delta, ref, out, n);

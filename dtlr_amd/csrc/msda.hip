@@ -426,6 +426,7 @@ extern "C" int dtlr_msda_forward(const void* value, const int64_t* shapes, const
                                  int N, int S, int M, int D, int L, int Lq, int P,
                                  int dtype, void* out, void* stream)
 {
+    clear_stale_error();
     if (!value || !shapes || !lsi || !loc || !attn || !out) return DTLR_EINVAL;
     if (N <= 0 || S <= 0 || M <= 0 || D <= 0 || L <= 0 || Lq <= 0 || P <= 0) return DTLR_EINVAL;
     hipStream_t st = (hipStream_t)stream;
@@ -453,6 +454,7 @@ extern "C" int dtlr_msda_fused_forward(const void* value, const int64_t* shapes,
                                        int N, int S, int M, int D, int L, int Lq, int P,
                                        int dtype, int ow_dtype, void* out, void* stream)
 {
+    clear_stale_error();
     if (!value || !shapes || !lsi || !ow || !ref || !out) return DTLR_EINVAL;
     if (N <= 0 || S <= 0 || M <= 0 || D <= 0 || Lq <= 0) return DTLR_EINVAL;
     if (L != 4 || P != 4 || (ref_dim != 2 && ref_dim != 4)) return DTLR_ESHAPE;
@@ -479,5 +481,7 @@ extern "C" const char* dtlr_strerror(int code) {
     default: return "unknown error";
     }
 }
-extern "C" int dtlr_last_hip_error(void) { return g_last_hip_error; }
-extern "C" int dtlr_abi_version(void) { return 1; }
+extern "C" int dtlr_last_hip_error(void) {
+    clear_stale_error(); return g_last_hip_error; }
+extern "C" int dtlr_abi_version(void) {
+    clear_stale_error(); return 1; }

@@ -164,39 +164,74 @@ __global__ __launch_bounds__(256) void msda_enc_lds_kernel(
             const unsigned char* win = smem + (long)lv.loff[l] * PIX_BYTES + part * 16;
             const T* gsrc = vimg + (long)lv.start[l] * MD + part * VEC;
             const int wstride = lv.wmax[l];
+            // geometry of the 4 points of this level first (so that, on the common path where every point is
+            // inside the map and inside the staged window, all 16 LDS reads are issued back to back)
+            int o00[4], o01[4], o10[4], o11[4];               // LDS byte offsets of the 4 corners (clamped)
+            float w1[4], w2[4], w3[4], w4[4];                 // bilinear weights x attention, zero for invalid corners
+            bool fast = true;
+            int gh0[4], gh1[4], gw0[4], gw1[4];
+            bool ins[4];
 #pragma unroll
             for (int p = 0; p < 4; ++p) {
                 const float lx = rf[2 * l] + off[(l * 4 + p) * 2] / (float)W;
                 const float ly = rf[2 * l + 1] + off[(l * 4 + p) * 2 + 1] / (float)H;
                 const float h_im = ly * (float)H - 0.5f, w_im = lx * (float)W - 0.5f;
-                if (!(h_im > -1.f && w_im > -1.f && h_im < (float)H && w_im < (float)W)) continue;
+                const bool inside = h_im > -1.f && w_im > -1.f && h_im < (float)H && w_im < (float)W;
                 const float hf = floorf(h_im), wf = floorf(w_im);
-                const int h_low = (int)hf, w_low = (int)wf, h_high = h_low + 1, w_high = w_low + 1;
+                const int h_low = (int)fminf(fmaxf(hf, -1.f), (float)H), w_low = (int)fminf(fmaxf(wf, -1.f), (float)W);
+                const int h_high = h_low + 1, w_high = w_low + 1;
                 const float lh = h_im - hf, lw = w_im - wf, hh = 1.f - lh, hw = 1.f - lw;
-                const bool top = h_low >= 0, bot = h_high <= H - 1, left = w_low >= 0, right = w_high <= W - 1;
-                const int h0 = max(h_low, 0), h1 = min(h_high, H - 1), w0 = max(w_low, 0), w1 = min(w_high, W - 1);
-                uint4 d1, d2, d3, d4;
-                if (w0 >= wc0[l] && w1 < wc1[l]) {          // both columns resident: LDS path (always-issued reads)
-                    const int a0 = w0 - wc0[l], a1 = w1 - wc0[l];
-                    d1 = *reinterpret_cast<const uint4*>(win + (h0 * wstride + a0) * PIX_BYTES);
-                    d2 = *reinterpret_cast<const uint4*>(win + (h0 * wstride + a1) * PIX_BYTES);
-                    d3 = *reinterpret_cast<const uint4*>(win + (h1 * wstride + a0) * PIX_BYTES);
-                    d4 = *reinterpret_cast<const uint4*>(win + (h1 * wstride + a1) * PIX_BYTES);
-                } else {                                    // outside the staged window: global path
-                    d1 = *reinterpret_cast<const uint4*>(gsrc + (long)(h0 * W + w0) * MD);
-                    d2 = *reinterpret_cast<const uint4*>(gsrc + (long)(h0 * W + w1) * MD);
-                    d3 = *reinterpret_cast<const uint4*>(gsrc + (long)(h1 * W + w0) * MD);
-                    d4 = *reinterpret_cast<const uint4*>(gsrc + (long)(h1 * W + w1) * MD);
-                }
-                const uint4 z = make_uint4(0u, 0u, 0u, 0u);
-                float v1[VEC], v2[VEC], v3[VEC], v4[VEC];
-                ET<T>::unpack((top && left) ? d1 : z, v1);
-                ET<T>::unpack((top && right) ? d2 : z, v2);
-                ET<T>::unpack((bot && left) ? d3 : z, v3);
-                ET<T>::unpack((bot && right) ? d4 : z, v4);
-                const float w1_ = hh * hw, w2_ = hh * lw, w3_ = lh * hw, w4_ = lh * lw, a = lg[l * 4 + p] * inv;
+                const bool top = inside && h_low >= 0, bot = inside && h_high <= H - 1, left = w_low >= 0, right = w_high <= W - 1;
+                const int h0 = min(max(h_low, 0), H - 1), h1 = max(min(h_high, H - 1), 0);
+                const int w0 = min(max(w_low, 0), W - 1), w1c = max(min(w_high, W - 1), 0);
+                gh0[p] = h0; gh1[p] = h1; gw0[p] = w0; gw1[p] = w1c; ins[p] = inside;
+                const bool res = (w0 >= wc0[l]) && (w1c < wc1[l]);
+                fast = fast && (res || !inside);
+                const int a0 = min(max(w0 - wc0[l], 0), wstride - 1), a1 = min(max(w1c - wc0[l], 0), wstride - 1);
+                o00[p] = (h0 * wstride + a0) * PIX_BYTES; o01[p] = (h0 * wstride + a1) * PIX_BYTES;
+                o10[p] = (h1 * wstride + a0) * PIX_BYTES; o11[p] = (h1 * wstride + a1) * PIX_BYTES;
+                // the reference multiplies val = w1 v1 + w2 v2 + w3 v3 + w4 v4 by the attention weight afterwards;
+                // keep that order: the weights below are the pure bilinear ones, zeroed for corners outside the map
+                w1[p] = (top && left) ? hh * hw : 0.f;  w2[p] = (top && right) ? hh * lw : 0.f;
+                w3[p] = (bot && left) ? lh * hw : 0.f;  w4[p] = (bot && right) ? lh * lw : 0.f;
+            }
+            if (fast) {
+                uint4 d[4][4];
 #pragma unroll
-                for (int i = 0; i < VEC; ++i) col[i] += (w1_ * v1[i] + w2_ * v2[i] + w3_ * v3[i] + w4_ * v4[i]) * a;
+                for (int p = 0; p < 4; ++p) {
+                    d[p][0] = *reinterpret_cast<const uint4*>(win + o00[p]);
+                    d[p][1] = *reinterpret_cast<const uint4*>(win + o01[p]);
+                    d[p][2] = *reinterpret_cast<const uint4*>(win + o10[p]);
+                    d[p][3] = *reinterpret_cast<const uint4*>(win + o11[p]);
+                }
+#pragma unroll
+                for (int p = 0; p < 4; ++p) {
+                    float v1[VEC], v2[VEC], v3[VEC], v4[VEC];
+                    ET<T>::unpack(d[p][0], v1); ET<T>::unpack(d[p][1], v2); ET<T>::unpack(d[p][2], v3); ET<T>::unpack(d[p][3], v4);
+                    const float a = lg[l * 4 + p] * inv;
+#pragma unroll
+                    for (int i = 0; i < VEC; ++i) col[i] += (w1[p] * v1[i] + w2[p] * v2[i] + w3[p] * v3[i] + w4[p] * v4[i]) * a;
+                }
+            } else {
+#pragma unroll
+                for (int p = 0; p < 4; ++p) {
+                    if (!ins[p]) continue;
+                    uint4 d1, d2, d3, d4;
+                    if (gw0[p] >= wc0[l] && gw1[p] < wc1[l]) {
+                        d1 = *reinterpret_cast<const uint4*>(win + o00[p]); d2 = *reinterpret_cast<const uint4*>(win + o01[p]);
+                        d3 = *reinterpret_cast<const uint4*>(win + o10[p]); d4 = *reinterpret_cast<const uint4*>(win + o11[p]);
+                    } else {                                    // outside the staged window: global path
+                        d1 = *reinterpret_cast<const uint4*>(gsrc + (long)(gh0[p] * W + gw0[p]) * MD);
+                        d2 = *reinterpret_cast<const uint4*>(gsrc + (long)(gh0[p] * W + gw1[p]) * MD);
+                        d3 = *reinterpret_cast<const uint4*>(gsrc + (long)(gh1[p] * W + gw0[p]) * MD);
+                        d4 = *reinterpret_cast<const uint4*>(gsrc + (long)(gh1[p] * W + gw1[p]) * MD);
+                    }
+                    float v1[VEC], v2[VEC], v3[VEC], v4[VEC];
+                    ET<T>::unpack(d1, v1); ET<T>::unpack(d2, v2); ET<T>::unpack(d3, v3); ET<T>::unpack(d4, v4);
+                    const float a = lg[l * 4 + p] * inv;
+#pragma unroll
+                    for (int i = 0; i < VEC; ++i) col[i] += (w1[p] * v1[i] + w2[p] * v2[i] + w3[p] * v3[i] + w4[p] * v4[i]) * a;
+                }
             }
         }
         *reinterpret_cast<uint4*>(out + bq * MD + m * 32 + part * VEC) = ET<T>::pack(col);
@@ -252,6 +287,7 @@ extern "C" int dtlr_msda_encoder_forward(const void* value, const void* ow, cons
                                          int N, int M, int D, int L, int P, int halo,
                                          int dtype, int ow_dtype, void* out, void* stream)
 {
+    clear_stale_error();
     if (!value || !ow || !ref || !level_hw || !out) return DTLR_EINVAL;
     if (N <= 0 || M <= 0 || halo < 0) return DTLR_EINVAL;
     if (L != 4 || P != 4 || D != 32) return DTLR_ESHAPE;

@@ -90,6 +90,7 @@ using namespace dtlr;
 extern "C" int dtlr_layernorm(const void* x, const void* residual, const float* gamma, const float* beta,
                               void* y, long rows, int C, float eps, int dtype, void* stream)
 {
+    clear_stale_error();
     if (!x || !gamma || !beta || !y) return DTLR_EINVAL;
     if (rows <= 0 || C <= 0) return DTLR_EINVAL;
     if (C % 256 != 0) return DTLR_ESHAPE;
@@ -220,6 +221,7 @@ extern "C" long dtlr_groupnorm_workspace_bytes(int B, int T_tokens)
 extern "C" int dtlr_groupnorm_tokens(const void* x, const float* gamma, const float* beta, void* y, void* workspace,
                                      int B, int T_tokens, int C, int groups, float eps, int dtype, void* stream)
 {
+    clear_stale_error();
     if (!x || !gamma || !beta || !y || !workspace) return DTLR_EINVAL;
     if (B <= 0 || T_tokens <= 0) return DTLR_EINVAL;
     if (C != 256 || groups != 32) return DTLR_ESHAPE;
@@ -240,6 +242,7 @@ extern "C" int dtlr_groupnorm_tokens(const void* x, const float* gamma, const fl
 
 extern "C" int dtlr_maxpool3x3s2_nhwc(const void* x, void* y, int B, int H, int W, int C, int dtype, void* stream)
 {
+    clear_stale_error();
     if (!x || !y) return DTLR_EINVAL;
     if (B <= 0 || H <= 0 || W <= 0 || C <= 0) return DTLR_EINVAL;
     const int Ho = (H + 2 - 3) / 2 + 1, Wo = (W + 2 - 3) / 2 + 1;
