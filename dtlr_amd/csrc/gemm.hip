@@ -356,7 +356,196 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(
 #undef ADVANCE_AND_LOAD
 }
 
+// ---------------------------------------------------------------------------------------------
+// Wave-specialised variant (the default): 512 threads = 4 MFMA waves + 4 loader waves, one workgroup per CU.
+//
+// Measured on the uniform kernel above (tools/profile_kernels.py --only gemm_ablate, K = 2048): the phase costs
+// are ADDITIVE -- LDS reads + barriers 123 us, LDS stores ~45 us, MFMA ~60 us, global loads ~108 us of 364 us --
+// because the two resident workgroups of a CU execute the same phases in lock-step and contend instead of
+// overlapping.  Here the phases run on different waves at the same time:
+//   loader waves (4..7): slab s+1's registers -> LDS stage (s+1)&1, then issue slab s+3's global loads
+//                        (two register sets, inline-asm loads, one counted vmcnt wait: two full slabs of latency cover)
+//   MFMA waves   (0..3): 16 ds_read_b128 + 32 MFMA on stage s&1
+// and meet at ONE barrier per slab.  Same tile chain, same LDS image, same epilogue as above.
+// ---------------------------------------------------------------------------------------------
+template <typename T, typename OutT, bool HAS_A2, bool CONV>
+__global__ __launch_bounds__(512, 2) void gemm_ws_kernel(
+    const T* __restrict__ A, const T* __restrict__ A2, const T* __restrict__ W,
+    const float* __restrict__ bias, const OutT* __restrict__ residual, const uint8_t* __restrict__ row_mask,
+    OutT* __restrict__ C, int M, int N, int K, int flags, int nN, int ntiles, int tiles_per_block, ConvP cp)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];   // [2 stages][W tile | X tile]
+    const int wave = threadIdx.x >> 6;
+    constexpr int BK = GT<T>::BK;
+    const int nk = K / BK;
+    const int t_begin = blockIdx.x * tiles_per_block;
+    const int t_end = min(t_begin + tiles_per_block, ntiles);
+    if (t_begin >= t_end) return;
+    const int total = (t_end - t_begin) * nk;
+
+    if (wave >= 4) {
+        // ================================ loader role ================================
+        const int tid = threadIdx.x - 256;
+        const int srow = tid >> 3, kc = tid & 7;
+        const int lds0 = srow * LDS_ROW + ((kc ^ (srow & 7)) * 16);
+        long a_off[4], w_off[4];
+        int hi0[4], wi0[4];
+        const int slabs_per_tap = CONV ? (cp.Cin * (int)sizeof(T)) / SLAB : 1;
+        const char* Ab = reinterpret_cast<const char*>(A);
+        const char* A2b = reinterpret_cast<const char*>(A2);
+        const char* Wb = reinterpret_cast<const char*>(W);
+        const char* zero_line = reinterpret_cast<const char*>(g_zero_line);
+        (void)zero_line; (void)A2b;
+        // asm (uncounted) loads only in the variants whose ISA audit shows no compiler copy of an in-flight register
+        // (the A2 variant gets v_mov shuffles right after the loads); A2 keeps compiler-counted loads -- conservative
+        // waits, but they only stall loader waves.
+        constexpr bool ASM = !HAS_A2;
+        constexpr int NLOAD = 8;                               // asm loads per slab per lane
+#define WS_SET_TILE(TILE)                                                                          \
+        {                                                                                          \
+            const int lm0_ = ((TILE) / nN) * BM, ln0_ = ((TILE) % nN) * BN;                        \
+            _Pragma("unroll") for (int i = 0; i < 4; ++i) {                                        \
+                const long ar = min(lm0_ + srow + 32 * i, M - 1), wr = min(ln0_ + srow + 32 * i, N - 1); \
+                w_off[i] = (wr * K) * (long)sizeof(T) + kc * 16;                                   \
+                if (CONV) {                                                                        \
+                    const int hw = cp.Ho * cp.Wo;                                                  \
+                    const int bimg = (int)(ar / hw), rem = (int)(ar % hw);                         \
+                    hi0[i] = (rem / cp.Wo) * cp.stride - cp.pad;                                   \
+                    wi0[i] = (rem % cp.Wo) * cp.stride - cp.pad;                                   \
+                    a_off[i] = (long)bimg * cp.H * cp.W * cp.Cin * (long)sizeof(T) + kc * 16;      \
+                } else {                                                                           \
+                    hi0[i] = wi0[i] = 0;                                                           \
+                    a_off[i] = (ar * K) * (long)sizeof(T) + kc * 16;                               \
+                }                                                                                  \
+            }                                                                                      \
+        }
+        uint4 raP0, raP1, raP2, raP3, rwP0, rwP1, rwP2, rwP3, rbP0, rbP1, rbP2, rbP3;
+        uint4 raQ0, raQ1, raQ2, raQ3, rwQ0, rwQ1, rwQ2, rwQ3, rbQ0, rbQ1, rbQ2, rbQ3;
+        (void)rbP0; (void)rbP1; (void)rbP2; (void)rbP3; (void)rbQ0; (void)rbQ1; (void)rbQ2; (void)rbQ3;
+#define WS_LD16(PTR) (ASM ? asm_load16(PTR) : *reinterpret_cast<const uint4*>(PTR))
+#define WS_GLOAD1(S, I, OFF)                                                                       \
+        rw##S##I = WS_LD16(Wb + w_off[I] + (OFF));                                                 \
+        if (CONV) {                                                                                \
+            const int hi_ = hi0[I] + kh_, wi_ = wi0[I] + kw_;                                      \
+            const bool ok_ = hi_ >= 0 && hi_ < cp.H && wi_ >= 0 && wi_ < cp.W;                     \
+            const long po_ = ((long)hi_ * cp.W + wi_) * cp.Cin * (long)sizeof(T) + coff_;          \
+            ra##S##I = WS_LD16(ok_ ? Ab + a_off[I] + po_ : zero_line);                             \
+        } else {                                                                                   \
+            ra##S##I = WS_LD16(Ab + a_off[I] + (OFF));                                             \
+            if (HAS_A2) rb##S##I = WS_LD16(A2b + a_off[I] + (OFF));                                \
+        }
+#define WS_GLOAD(S, KT)                                                                            \
+        {                                                                                          \
+            const long off_ = (long)(KT) * SLAB;                                                   \
+            const int tap_ = (KT) / slabs_per_tap;                                                 \
+            const int kh_ = CONV ? tap_ / cp.KW : 0, kw_ = CONV ? tap_ % cp.KW : 0;                \
+            const long coff_ = (long)((KT) % slabs_per_tap) * SLAB;                                \
+            (void)kh_; (void)kw_; (void)coff_;                                                     \
+            WS_GLOAD1(S, 0, off_) WS_GLOAD1(S, 1, off_) WS_GLOAD1(S, 2, off_) WS_GLOAD1(S, 3, off_) \
+        }
+#define WS_LSTORE1(S, I)                                                                           \
+        *reinterpret_cast<uint4*>(wt_ + I * 32 * LDS_ROW) = rw##S##I;                              \
+        *reinterpret_cast<uint4*>(wt_ + TILE_BYTES + I * 32 * LDS_ROW) = HAS_A2 ? GT<T>::add(ra##S##I, rb##S##I) : ra##S##I;
+#define WS_LSTORE(S, STAGE)                                                                        \
+        {                                                                                          \
+            unsigned char* wt_ = smem + (STAGE) * 2 * TILE_BYTES + lds0;                           \
+            WS_LSTORE1(S, 0) WS_LSTORE1(S, 1) WS_LSTORE1(S, 2) WS_LSTORE1(S, 3)                    \
+        }
+#define WS_ADVANCE_AND_LOAD(S)                                                                     \
+        {                                                                                          \
+            if (++lkt == nk) { lkt = 0; ++ltile; WS_SET_TILE(ltile) }                              \
+            WS_GLOAD(S, lkt)                                                                       \
+        }
+        int lkt = 0, ltile = t_begin;
+        WS_SET_TILE(t_begin)
+        WS_GLOAD(P, 0)
+        if (ASM) wait_vmcnt<0>();
+        WS_LSTORE(P, 0)                                          // slab 0 -> stage 0
+        if (total > 1) WS_ADVANCE_AND_LOAD(Q)                    // slab 1 -> set Q (odd slabs)
+        if (total > 2) WS_ADVANCE_AND_LOAD(P)                    // slab 2 -> set P (even slabs)
+        __syncthreads();                                         // barrier #0: slab 0 visible
+        // iteration i (the MFMA waves multiply slab i): store slab i+1, then refill its set with slab i+3
+        int i = 0;
+        while (i < total) {
+            if (i + 1 < total) {                                 // i even: slab i+1 is odd -> set Q, stage 1
+                if (ASM) { if (i + 2 < total) wait_vmcnt<NLOAD>(); else wait_vmcnt<0>(); }
+                WS_LSTORE(Q, 1)
+                if (i + 3 < total) WS_ADVANCE_AND_LOAD(Q)
+            }
+            __syncthreads();
+            if (++i >= total) break;
+            if (i + 1 < total) {                                 // i odd: slab i+1 is even -> set P, stage 0
+                if (ASM) { if (i + 2 < total) wait_vmcnt<NLOAD>(); else wait_vmcnt<0>(); }
+                WS_LSTORE(P, 0)
+                if (i + 3 < total) WS_ADVANCE_AND_LOAD(P)
+            }
+            __syncthreads();
+            ++i;
+        }
+#undef WS_LD16
+#undef WS_SET_TILE
+#undef WS_GLOAD1
+#undef WS_GLOAD
+#undef WS_LSTORE1
+#undef WS_LSTORE
+#undef WS_ADVANCE_AND_LOAD
+        return;
+    }
+
+    // ================================ MFMA role ================================
+    const int lane = threadIdx.x & 63;
+    const int g = lane >> 4, n = lane & 15;
+    const int wm = wave >> 1, wn = wave & 1;
+    f32x4_t acc[4][4];
+#pragma unroll
+    for (int ci = 0; ci < 4; ++ci)
+#pragma unroll
+        for (int ti = 0; ti < 4; ++ti) acc[ci][ti] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+    int kt = 0, tile = t_begin;
+    __syncthreads();                                             // barrier #0
+    for (int s = 0; s < total; ++s) {
+        const unsigned char* wt = smem + (s & 1) * 2 * TILE_BYTES + (wn * 64 + n) * LDS_ROW;
+        const unsigned char* xt = wt + TILE_BYTES + ((wm - wn) * 64) * LDS_ROW;
+        uint4 wf[2][4], xf[2][4];
+#pragma unroll
+        for (int kq = 0; kq < 2; ++kq) {
+            const int sw = (((kq * 4 + g) ^ (n & 7)) * 16);
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                wf[kq][i] = *reinterpret_cast<const uint4*>(wt + i * 16 * LDS_ROW + sw);
+                xf[kq][i] = *reinterpret_cast<const uint4*>(xt + i * 16 * LDS_ROW + sw);
+            }
+        }
+#pragma unroll
+        for (int kq = 0; kq < 2; ++kq)
+#pragma unroll
+            for (int ci = 0; ci < 4; ++ci)
+#pragma unroll
+                for (int ti = 0; ti < 4; ++ti) GT<T>::mma(wf[kq][ci], xf[kq][ti], acc[ci][ti]);
+        __syncthreads();
+        if (++kt == nk) {
+            const int m0 = (tile / nN) * BM, n0 = (tile % nN) * BN;
+            epilogue_tile<OutT>(acc, C, bias, residual, row_mask, M, N, flags, m0 + wm * 64 + n, n0 + wn * 64 + 4 * g);
+            kt = 0; ++tile;
+        }
+    }
+}
+
 // tiles per block: enough chains to fill the chip (2 resident workgroups x 256 CUs) a few times over
+// wave-specialised kernel: ONE workgroup (8 waves) per CU -> chains sized for 256 x 3 workgroups
+static inline int plan_chain_ws(long ntiles) {
+    const long target_blocks = 2 * 256 * 2;     // two 8-wave workgroups fit a CU (99 VGPRs, 64 KB LDS)
+    long per = (ntiles + target_blocks - 1) / target_blocks;
+    if (per < 1) per = 1;
+    if (per > 128) per = 128;
+    return (int)per;
+}
+static inline bool use_ws() {
+    static int v = -1;
+    if (v < 0) { const char* e = getenv("DTLR_GEMM_WS"); v = (e && e[0] == '0') ? 0 : 1; }   // DTLR_GEMM_WS=0: uniform kernel (A/B timing)
+    return v == 1;
+}
+
 static inline int plan_chain(long ntiles) {
     const long target_blocks = 2 * 256 * 2;
     long per = (ntiles + target_blocks - 1) / target_blocks;
@@ -375,6 +564,16 @@ static int launch_conv(const void* X, const void* W, const float* bias, const vo
     const size_t lds = 4 * TILE_BYTES;
     static bool attr = false;
     if (!attr) { (void)hipFuncSetAttribute((const void*)gemm_nt_kernel<T, OutT, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); attr = true; }
+    if (use_ws()) {
+        static bool attr_ws = false;
+        if (!attr_ws) { (void)hipFuncSetAttribute((const void*)gemm_ws_kernel<T, OutT, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); attr_ws = true; }
+        const int per = plan_chain_ws(nwg);
+        const unsigned grid = (unsigned)((nwg + per - 1) / per);
+        hipLaunchKernelGGL((gemm_ws_kernel<T, OutT, false, true>), dim3(grid), dim3(512), lds, st,
+                           (const T*)X, (const T*)nullptr, (const T*)W, bias, (const OutT*)residual, (const uint8_t*)nullptr, (OutT*)C,
+                           M, N, K, flags, nN, (int)nwg, per, cp);
+        return check_launch();
+    }
     const int per = plan_chain(nwg);
     const unsigned grid = (unsigned)((nwg + per - 1) / per);
     hipLaunchKernelGGL((gemm_nt_kernel<T, OutT, false, true>), dim3(grid), dim3(256), lds, st,
@@ -388,12 +587,28 @@ static int launch_gemm(const void* A, const void* A2, const void* W, const float
                        const uint8_t* row_mask, void* C, int M, int N, int K, int flags, hipStream_t st)
 {
     const ConvP cp{};
-    const int per = plan_chain((long)((M + BM - 1) / BM) * ((N + BN - 1) / BN));
-    const unsigned grid = (unsigned)(((long)((M + BM - 1) / BM) * ((N + BN - 1) / BN) + per - 1) / per);
-    const int nM = (M + BM - 1) / BM, nN = (N + BN - 1) / BN;
-    const long nwg = (long)nM * nN;
+    const int nN = (N + BN - 1) / BN;
+    const long nwg = (long)((M + BM - 1) / BM) * nN;
     if (nwg > 0x7fffffffL) return DTLR_ESHAPE;
     const size_t lds = 4 * TILE_BYTES;
+    if (use_ws()) {
+        const int perw = plan_chain_ws(nwg);
+        const unsigned gridw = (unsigned)((nwg + perw - 1) / perw);
+        if (A2) {
+            static bool a1 = false;
+            if (!a1) { (void)hipFuncSetAttribute((const void*)gemm_ws_kernel<T, OutT, true, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); a1 = true; }
+            hipLaunchKernelGGL((gemm_ws_kernel<T, OutT, true, false>), dim3(gridw), dim3(512), lds, st,
+                               (const T*)A, (const T*)A2, (const T*)W, bias, (const OutT*)residual, row_mask, (OutT*)C, M, N, K, flags, nN, (int)nwg, perw, cp);
+        } else {
+            static bool a0 = false;
+            if (!a0) { (void)hipFuncSetAttribute((const void*)gemm_ws_kernel<T, OutT, false, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); a0 = true; }
+            hipLaunchKernelGGL((gemm_ws_kernel<T, OutT, false, false>), dim3(gridw), dim3(512), lds, st,
+                               (const T*)A, (const T*)nullptr, (const T*)W, bias, (const OutT*)residual, row_mask, (OutT*)C, M, N, K, flags, nN, (int)nwg, perw, cp);
+        }
+        return check_launch();
+    }
+    const int per = plan_chain(nwg);
+    const unsigned grid = (unsigned)((nwg + per - 1) / per);
     if (A2) {
         static bool attr_a2 = false;
         if (!attr_a2) { (void)hipFuncSetAttribute((const void*)gemm_nt_kernel<T, OutT, true, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); attr_a2 = true; }

@@ -187,7 +187,10 @@ __global__ __launch_bounds__(256) void msda_enc_lds_kernel(
                 gh0[p] = h0; gh1[p] = h1; gw0[p] = w0; gw1[p] = w1c; ins[p] = inside;
                 const bool res = (w0 >= wc0[l]) && (w1c < wc1[l]);
                 fast = fast && (res || !inside);
-                const int a0 = min(max(w0 - wc0[l], 0), wstride - 1), a1 = min(max(w1c - wc0[l], 0), wstride - 1);
+                // clamp into the STAGED columns [0, ww): a point outside the map (weights all zero) must still read
+                // initialised LDS -- uninitialised bits can be NaN/Inf and 0 * NaN = NaN
+                const int ww_ = wc1[l] - wc0[l];
+                const int a0 = min(max(w0 - wc0[l], 0), ww_ - 1), a1 = min(max(w1c - wc0[l], 0), ww_ - 1);
                 o00[p] = (h0 * wstride + a0) * PIX_BYTES; o01[p] = (h0 * wstride + a1) * PIX_BYTES;
                 o10[p] = (h1 * wstride + a0) * PIX_BYTES; o11[p] = (h1 * wstride + a1) * PIX_BYTES;
                 // the reference multiplies val = w1 v1 + w2 v2 + w3 v3 + w4 v4 by the attention weight afterwards;
