@@ -171,6 +171,25 @@ __device__ __forceinline__ void epilogue_tile(f32x4_t (&acc)[4][4], OutT* __rest
 struct ConvP { int H, W, Cin, Ho, Wo, KH, KW, stride, pad; };
 __device__ __attribute__((aligned(16))) unsigned int g_zero_line[4] = {0u, 0u, 0u, 0u};   // what a padding tap reads
 
+// Tile chains.  A workgroup owns `tiles_per_block` consecutive TOKEN tiles (tm) of ONE channel tile (tn) and
+// walks them as one continuously pipelined slab stream (load-latency prologue paid once per chain).  Workgroup
+// ids are remapped so that the nN chains covering the same token panels -- tn = 0..nN-1 of one chain group --
+// get consecutive logical ids inside ONE XCD (the dispatcher puts workgroup b on XCD b % 8): they stream the
+// same activation rows at the same time, so the panel is fetched from HBM once and the other nN-1 readers
+// hit that XCD's L2.  (First version: tn fastest inside a chain -> the re-read of a panel came a full K sweep
+// later, after 64 co-resident chains had pushed it out of the 4 MiB L2; operand delivery then ran at
+// beyond-L2 bandwidth, 4-8 TB/s, which capped the 128x128 tile at 300-500 TFLOP/s.)  Speed only: any
+// placement gives the same results.   `ntiles` carries nM (token tiles).
+#define CHAIN_SETUP()                                                                              \
+    const int nM_ = ntiles;                                                                        \
+    const int nwg_ = (int)gridDim.x, q8_ = nwg_ >> 3, r8_ = nwg_ & 7, xcd_ = (int)blockIdx.x & 7; \
+    const int logical_ = (xcd_ < r8_ ? xcd_ * (q8_ + 1) : r8_ * (q8_ + 1) + (xcd_ - r8_) * q8_) + ((int)blockIdx.x >> 3); \
+    const int tn = logical_ % nN;                                                                  \
+    const int t_begin = (logical_ / nN) * tiles_per_block;                                         \
+    const int t_end = min(t_begin + tiles_per_block, nM_);                                         \
+    if (t_begin >= t_end) return;                                                                  \
+    const int total = (t_end - t_begin) * nk;
+
 template <typename T, typename OutT, bool HAS_A2, bool CONV>
 __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(
     const T* __restrict__ A, const T* __restrict__ A2, const T* __restrict__ W,
@@ -190,10 +209,7 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(
     // multiplied.  With K = 256 a tile is only 4 slabs, so paying the ~2 us load latency once per
     // block instead of once per tile is worth more than any in-tile tuning; consecutive tiles of a
     // chain share their activation rows (tn fastest), re-read from L2.
-    const int t_begin = blockIdx.x * tiles_per_block;
-    const int t_end = min(t_begin + tiles_per_block, ntiles);
-    if (t_begin >= t_end) return;
-    const int total = (t_end - t_begin) * nk;
+    CHAIN_SETUP()
 
     // staging: each operand tile = 128 rows x 128 B = 1024 16-byte chunks; thread t takes rows srow + 32 i
     // (8 consecutive lanes cover one 128-byte row slab), kc = tid & 7.
@@ -215,7 +231,7 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(
 
 #define SET_LOAD_TILE(TILE)                                                                        \
     {                                                                                              \
-        const int lm0_ = ((TILE) / nN) * BM, ln0_ = ((TILE) % nN) * BN;                            \
+        const int lm0_ = (TILE) * BM, ln0_ = tn * BN;                                              \
         _Pragma("unroll") for (int i = 0; i < 4; ++i) {                                            \
             const long ar = min(lm0_ + srow + 32 * i, M - 1), wr = min(ln0_ + srow + 32 * i, N - 1); \
             w_off[i] = (wr * K) * (long)sizeof(T) + kc * 16;                                       \
@@ -335,7 +351,7 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(
 
 #define EPILOGUE()                                                                                 \
     {                                                                                              \
-        const int m0 = (tile / nN) * BM, n0 = (tile % nN) * BN;                                    \
+        const int m0 = tile * BM, n0 = tn * BN;                                                    \
         epilogue_tile<OutT>(acc, C, bias, residual, row_mask, M, N, flags, m0 + wm * 64 + n, n0 + wn * 64 + 4 * g); \
     }
 
@@ -378,10 +394,7 @@ __global__ __launch_bounds__(512, 2) void gemm_ws_kernel(
     const int wave = threadIdx.x >> 6;
     constexpr int BK = GT<T>::BK;
     const int nk = K / BK;
-    const int t_begin = blockIdx.x * tiles_per_block;
-    const int t_end = min(t_begin + tiles_per_block, ntiles);
-    if (t_begin >= t_end) return;
-    const int total = (t_end - t_begin) * nk;
+    CHAIN_SETUP()
 
     if (wave >= 4) {
         // ================================ loader role ================================
@@ -403,7 +416,7 @@ __global__ __launch_bounds__(512, 2) void gemm_ws_kernel(
         constexpr int NLOAD = 8;                               // asm loads per slab per lane
 #define WS_SET_TILE(TILE)                                                                          \
         {                                                                                          \
-            const int lm0_ = ((TILE) / nN) * BM, ln0_ = ((TILE) % nN) * BN;                        \
+            const int lm0_ = (TILE) * BM, ln0_ = tn * BN;                                          \
             _Pragma("unroll") for (int i = 0; i < 4; ++i) {                                        \
                 const long ar = min(lm0_ + srow + 32 * i, M - 1), wr = min(ln0_ + srow + 32 * i, N - 1); \
                 w_off[i] = (wr * K) * (long)sizeof(T) + kc * 16;                                   \
@@ -524,7 +537,7 @@ __global__ __launch_bounds__(512, 2) void gemm_ws_kernel(
                 for (int ti = 0; ti < 4; ++ti) GT<T>::mma(wf[kq][ci], xf[kq][ti], acc[ci][ti]);
         __syncthreads();
         if (++kt == nk) {
-            const int m0 = (tile / nN) * BM, n0 = (tile % nN) * BN;
+            const int m0 = tile * BM, n0 = tn * BN;
             epilogue_tile<OutT>(acc, C, bias, residual, row_mask, M, N, flags, m0 + wm * 64 + n, n0 + wn * 64 + 4 * g);
             kt = 0; ++tile;
         }
@@ -568,17 +581,17 @@ static int launch_conv(const void* X, const void* W, const float* bias, const vo
         static bool attr_ws = false;
         if (!attr_ws) { (void)hipFuncSetAttribute((const void*)gemm_ws_kernel<T, OutT, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); attr_ws = true; }
         const int per = plan_chain_ws(nwg);
-        const unsigned grid = (unsigned)((nwg + per - 1) / per);
+        const unsigned grid = (unsigned)(nN * ((nM + per - 1) / per));
         hipLaunchKernelGGL((gemm_ws_kernel<T, OutT, false, true>), dim3(grid), dim3(512), lds, st,
                            (const T*)X, (const T*)nullptr, (const T*)W, bias, (const OutT*)residual, (const uint8_t*)nullptr, (OutT*)C,
-                           M, N, K, flags, nN, (int)nwg, per, cp);
+                           M, N, K, flags, nN, nM, per, cp);
         return check_launch();
     }
     const int per = plan_chain(nwg);
-    const unsigned grid = (unsigned)((nwg + per - 1) / per);
+    const unsigned grid = (unsigned)(nN * ((nM + per - 1) / per));
     hipLaunchKernelGGL((gemm_nt_kernel<T, OutT, false, true>), dim3(grid), dim3(256), lds, st,
                        (const T*)X, (const T*)nullptr, (const T*)W, bias, (const OutT*)residual, (const uint8_t*)nullptr, (OutT*)C,
-                       M, N, K, flags, nN, (int)nwg, per, cp);
+                       M, N, K, flags, nN, nM, per, cp);
     return check_launch();
 }
 
@@ -587,38 +600,38 @@ static int launch_gemm(const void* A, const void* A2, const void* W, const float
                        const uint8_t* row_mask, void* C, int M, int N, int K, int flags, hipStream_t st)
 {
     const ConvP cp{};
-    const int nN = (N + BN - 1) / BN;
-    const long nwg = (long)((M + BM - 1) / BM) * nN;
+    const int nN = (N + BN - 1) / BN, nM = (M + BM - 1) / BM;
+    const long nwg = (long)nM * nN;
     if (nwg > 0x7fffffffL) return DTLR_ESHAPE;
     const size_t lds = 4 * TILE_BYTES;
     if (use_ws()) {
         const int perw = plan_chain_ws(nwg);
-        const unsigned gridw = (unsigned)((nwg + perw - 1) / perw);
+        const unsigned gridw = (unsigned)(nN * ((nM + perw - 1) / perw));
         if (A2) {
             static bool a1 = false;
             if (!a1) { (void)hipFuncSetAttribute((const void*)gemm_ws_kernel<T, OutT, true, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); a1 = true; }
             hipLaunchKernelGGL((gemm_ws_kernel<T, OutT, true, false>), dim3(gridw), dim3(512), lds, st,
-                               (const T*)A, (const T*)A2, (const T*)W, bias, (const OutT*)residual, row_mask, (OutT*)C, M, N, K, flags, nN, (int)nwg, perw, cp);
+                               (const T*)A, (const T*)A2, (const T*)W, bias, (const OutT*)residual, row_mask, (OutT*)C, M, N, K, flags, nN, nM, perw, cp);
         } else {
             static bool a0 = false;
             if (!a0) { (void)hipFuncSetAttribute((const void*)gemm_ws_kernel<T, OutT, false, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); a0 = true; }
             hipLaunchKernelGGL((gemm_ws_kernel<T, OutT, false, false>), dim3(gridw), dim3(512), lds, st,
-                               (const T*)A, (const T*)nullptr, (const T*)W, bias, (const OutT*)residual, row_mask, (OutT*)C, M, N, K, flags, nN, (int)nwg, perw, cp);
+                               (const T*)A, (const T*)nullptr, (const T*)W, bias, (const OutT*)residual, row_mask, (OutT*)C, M, N, K, flags, nN, nM, perw, cp);
         }
         return check_launch();
     }
     const int per = plan_chain(nwg);
-    const unsigned grid = (unsigned)((nwg + per - 1) / per);
+    const unsigned grid = (unsigned)(nN * ((nM + per - 1) / per));
     if (A2) {
         static bool attr_a2 = false;
         if (!attr_a2) { (void)hipFuncSetAttribute((const void*)gemm_nt_kernel<T, OutT, true, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); attr_a2 = true; }
         hipLaunchKernelGGL((gemm_nt_kernel<T, OutT, true, false>), dim3(grid), dim3(256), lds, st,
-                           (const T*)A, (const T*)A2, (const T*)W, bias, (const OutT*)residual, row_mask, (OutT*)C, M, N, K, flags, nN, (int)nwg, per, cp);
+                           (const T*)A, (const T*)A2, (const T*)W, bias, (const OutT*)residual, row_mask, (OutT*)C, M, N, K, flags, nN, nM, per, cp);
     } else {
         static bool attr = false;
         if (!attr) { (void)hipFuncSetAttribute((const void*)gemm_nt_kernel<T, OutT, false, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); attr = true; }
         hipLaunchKernelGGL((gemm_nt_kernel<T, OutT, false, false>), dim3(grid), dim3(256), lds, st,
-                           (const T*)A, (const T*)nullptr, (const T*)W, bias, (const OutT*)residual, row_mask, (OutT*)C, M, N, K, flags, nN, (int)nwg, per, cp);
+                           (const T*)A, (const T*)nullptr, (const T*)W, bias, (const OutT*)residual, row_mask, (OutT*)C, M, N, K, flags, nN, nM, per, cp);
     }
     return check_launch();
 }
