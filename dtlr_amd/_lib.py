@@ -7,7 +7,8 @@ import os
 from ctypes import c_char_p, c_int, c_int64, c_void_p, c_float, POINTER
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(HERE, "libdtlr_hip.so")
+# DTLR_HIP_LIB: profiling tools point this at the instrumented build (dtlr_amd/build.py --instr)
+LIB_PATH = os.environ.get("DTLR_HIP_LIB") or os.path.join(HERE, "libdtlr_hip.so")
 
 DTLR_F32, DTLR_F64, DTLR_BF16 = 0, 1, 2
 

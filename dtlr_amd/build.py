@@ -53,5 +53,20 @@ def build(force: bool = False, verbose: bool = True) -> str:
     return LIB
 
 
+def build_instrumented(verbose: bool = True) -> str:
+    """Profiling-only variant (tools/profile_kernels.py --instr): same sources with -DDTLR_GEMM_ABLATION (phase
+    switches + cycle attribution in the GEMM).  Never loaded by the product; select it with DTLR_HIP_LIB."""
+    out = os.path.join(HERE, "libdtlr_hip_instr.so")
+    cmd = [HIPCC, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-Wall", "-Wno-unused-function",
+           "-DDTLR_GEMM_ABLATION"] + _sources() + ["-o", out]
+    if verbose:
+        print("[dtlr build]", " ".join(cmd), flush=True)
+    subprocess.check_call(cmd)
+    return out
+
+
 if __name__ == "__main__":
-    print(build(force="--force" in sys.argv))
+    if "--instr" in sys.argv:
+        print(build_instrumented())
+    else:
+        print(build(force="--force" in sys.argv))

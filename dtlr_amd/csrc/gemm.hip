@@ -57,12 +57,19 @@ template <int N> __device__ __forceinline__ void wait_vmcnt() {
 // the library is built with -DDTLR_GEMM_ABLATION, so the production hot loop carries no extra branches.
 #ifdef DTLR_GEMM_ABLATION
 #define ABLATE(BIT) (flags & (BIT))
+#define TR(...) __VA_ARGS__
+#define TR_NOW() ((long long)__builtin_readcyclecounter())
+// cycle attribution of the wave-specialised kernel, summed over workgroups (wave 0 = MFMA role, wave 4 = loader role):
+// [0] MFMA total [1] reads+MFMA [2] barrier wait [3] epilogue | [4] loader total [5] vmcnt wait [6] LDS store
+// [7] load issue [8] barrier wait | [9] workgroups
+__device__ unsigned long long g_gemm_trace[16];
 #else
 #define ABLATE(BIT) false
+#define TR(...)
 #endif
 
 enum : int { EPI_BIAS = 1, EPI_RELU = 2, EPI_RESIDUAL = 4, EPI_ROWMASK = 8, EPI_RELU_POST = 16,
-              DBG_NO_LOAD = 256, DBG_NO_MMA = 512, DBG_NO_LDS = 1024 };   // ablation switches (env DTLR_GEMM_ABLATE), timing only
+              DBG_NO_LOAD = 256, DBG_NO_MMA = 512, DBG_NO_LDS = 1024, DBG_NO_EPI = 2048 };   // ablation switches (env DTLR_GEMM_ABLATE), timing only
 
 template <typename T> struct GT;
 template <> struct GT<uint16_t> {   // bf16
@@ -96,12 +103,17 @@ template <> struct GT<float> {
 
 template <typename OutT> struct Out;
 template <> struct Out<float> {
+    using raw4 = float4;
+    static __device__ __forceinline__ void unpack4(const float4& t, float (&v)[4]) { v[0] = t.x; v[1] = t.y; v[2] = t.z; v[3] = t.w; }
     static __device__ __forceinline__ void ld4(const float* p, float (&v)[4]) { const float4 t = *reinterpret_cast<const float4*>(p); v[0] = t.x; v[1] = t.y; v[2] = t.z; v[3] = t.w; }
     static __device__ __forceinline__ void st4(float* p, const float (&v)[4]) { *reinterpret_cast<float4*>(p) = make_float4(v[0], v[1], v[2], v[3]); }
     static __device__ __forceinline__ float ld(const float* p) { return *p; }
     static __device__ __forceinline__ void st(float* p, float v) { *p = v; }
 };
 template <> struct Out<uint16_t> {
+    using raw4 = uint2;
+    static __device__ __forceinline__ void unpack4(const uint2& t, float (&v)[4]) {
+        v[0] = __uint_as_float(t.x << 16); v[1] = __uint_as_float(t.x & 0xffff0000u); v[2] = __uint_as_float(t.y << 16); v[3] = __uint_as_float(t.y & 0xffff0000u); }
     static __device__ __forceinline__ void ld4(const uint16_t* p, float (&v)[4]) {
         const uint2 t = *reinterpret_cast<const uint2*>(p);
         v[0] = __uint_as_float(t.x << 16); v[1] = __uint_as_float(t.x & 0xffff0000u); v[2] = __uint_as_float(t.y << 16); v[3] = __uint_as_float(t.y & 0xffff0000u); }
@@ -112,12 +124,61 @@ template <> struct Out<uint16_t> {
 
 // Epilogue of one 64x64 wave sub-tile: lane (g,n) holds, for ti = 0..3 and ci = 0..3, channels
 // ch0 + ci*16 + r (r = 0..3) of token tok0 + ti*16.  Zeroes the accumulators for the next tile.
+//
+// Interior sub-tiles take the batched path: EVERY load of the epilogue (bias, padding mask, residual) is issued
+// before the first store.  Loads and stores share the one in-order vmcnt counter on gfx9-class ISAs, so a load
+// issued after a store can only be waited for with vmcnt(0), i.e. together with that store's full round trip to
+// L2/HBM.  The first version interleaved them per 4-channel group: 16 serialised round trips per tile, measured
+// (cycle attribution, tools/profile_kernels.py --only gemm_trace) at 2/3 of the K = 256 kernels' time.
 template <typename OutT>
 __device__ __forceinline__ void epilogue_tile(f32x4_t (&acc)[4][4], OutT* __restrict__ C, const float* __restrict__ bias,
                                               const OutT* __restrict__ residual, const uint8_t* __restrict__ row_mask,
                                               int M, int N, int flags, int tok0, int ch0)
 {
     const bool vec_ok = (N & 3) == 0;
+    if (vec_ok && tok0 + 48 < M && ch0 + 51 < N) {
+        float4 bv[4];
+#pragma unroll
+        for (int ci = 0; ci < 4; ++ci)
+            bv[ci] = (flags & EPI_BIAS) ? *reinterpret_cast<const float4*>(bias + ch0 + ci * 16) : make_float4(0.f, 0.f, 0.f, 0.f);
+        bool masked[4];
+#pragma unroll
+        for (int ti = 0; ti < 4; ++ti) masked[ti] = (flags & EPI_ROWMASK) && row_mask[tok0 + ti * 16];
+        constexpr int TB = sizeof(OutT) == 2 ? 2 : 1;              // token groups per batch (register budget: 128 VGPRs)
+#pragma unroll
+        for (int t0 = 0; t0 < 4; t0 += TB) {
+            typename Out<OutT>::raw4 rr[TB][4];
+            if (flags & EPI_RESIDUAL) {
+#pragma unroll
+                for (int tb = 0; tb < TB; ++tb)
+#pragma unroll
+                    for (int ci = 0; ci < 4; ++ci)
+                        rr[tb][ci] = *reinterpret_cast<const typename Out<OutT>::raw4*>(residual + (long)(tok0 + (t0 + tb) * 16) * N + ch0 + ci * 16);
+            }
+#pragma unroll
+            for (int tb = 0; tb < TB; ++tb) {
+                const int ti = t0 + tb;
+#pragma unroll
+                for (int ci = 0; ci < 4; ++ci) {
+                    float v[4] = {acc[ci][ti][0] + bv[ci].x, acc[ci][ti][1] + bv[ci].y, acc[ci][ti][2] + bv[ci].z, acc[ci][ti][3] + bv[ci].w};
+                    acc[ci][ti] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+                    if (flags & EPI_RELU) {
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) v[r] = fmaxf(v[r], 0.f);
+                    }
+                    if (masked[ti]) { v[0] = v[1] = v[2] = v[3] = 0.f; }
+                    if (flags & EPI_RESIDUAL) { float q[4]; Out<OutT>::unpack4(rr[tb][ci], q); v[0] += q[0]; v[1] += q[1]; v[2] += q[2]; v[3] += q[3]; }
+                    if (flags & EPI_RELU_POST) {
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) v[r] = fmaxf(v[r], 0.f);
+                    }
+                    Out<OutT>::st4(C + (long)(tok0 + ti * 16) * N + ch0 + ci * 16, v);
+                }
+            }
+        }
+        return;
+    }
+    // edge sub-tiles (ragged M or N, or N not a multiple of 4): per-group bounds checks, scalar tails
 #pragma unroll
     for (int ti = 0; ti < 4; ++ti) {
         const int tok = tok0 + ti * 16;
@@ -385,7 +446,7 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(
 // and meet at ONE barrier per slab.  Same tile chain, same LDS image, same epilogue as above.
 // ---------------------------------------------------------------------------------------------
 template <typename T, typename OutT, bool HAS_A2, bool CONV>
-__global__ __launch_bounds__(512, 2) void gemm_ws_kernel(
+__global__ __launch_bounds__(512, HAS_A2 ? 2 : 4) void gemm_ws_kernel(
     const T* __restrict__ A, const T* __restrict__ A2, const T* __restrict__ W,
     const float* __restrict__ bias, const OutT* __restrict__ residual, const uint8_t* __restrict__ row_mask,
     OutT* __restrict__ C, int M, int N, int K, int flags, int nN, int ntiles, int tiles_per_block, ConvP cp)
@@ -467,9 +528,10 @@ __global__ __launch_bounds__(512, 2) void gemm_ws_kernel(
 #define WS_ADVANCE_AND_LOAD(S)                                                                     \
         {                                                                                          \
             if (++lkt == nk) { lkt = 0; ++ltile; WS_SET_TILE(ltile) }                              \
-            WS_GLOAD(S, lkt)                                                                       \
+            if (!ABLATE(DBG_NO_LOAD)) WS_GLOAD(S, lkt)                                             \
         }
         int lkt = 0, ltile = t_begin;
+        TR(long long tl0 = TR_NOW(), tvm = 0, tst = 0, tis = 0, tlb = 0, tx = tl0, ty;)
         WS_SET_TILE(t_begin)
         WS_GLOAD(P, 0)
         if (ASM) wait_vmcnt<0>();
@@ -479,22 +541,37 @@ __global__ __launch_bounds__(512, 2) void gemm_ws_kernel(
         __syncthreads();                                         // barrier #0: slab 0 visible
         // iteration i (the MFMA waves multiply slab i): store slab i+1, then refill its set with slab i+3
         int i = 0;
+#define TR_MARK(ACC) TR(ty = TR_NOW(); ACC += ty - tx; tx = ty;)
+        TR(tx = TR_NOW();)
         while (i < total) {
             if (i + 1 < total) {                                 // i even: slab i+1 is odd -> set Q, stage 1
                 if (ASM) { if (i + 2 < total) wait_vmcnt<NLOAD>(); else wait_vmcnt<0>(); }
-                WS_LSTORE(Q, 1)
+                TR_MARK(tvm)
+                if (!ABLATE(DBG_NO_LDS)) WS_LSTORE(Q, 1)
+                TR_MARK(tst)
                 if (i + 3 < total) WS_ADVANCE_AND_LOAD(Q)
+                TR_MARK(tis)
             }
             __syncthreads();
+            TR_MARK(tlb)
             if (++i >= total) break;
             if (i + 1 < total) {                                 // i odd: slab i+1 is even -> set P, stage 0
                 if (ASM) { if (i + 2 < total) wait_vmcnt<NLOAD>(); else wait_vmcnt<0>(); }
-                WS_LSTORE(P, 0)
+                TR_MARK(tvm)
+                if (!ABLATE(DBG_NO_LDS)) WS_LSTORE(P, 0)
+                TR_MARK(tst)
                 if (i + 3 < total) WS_ADVANCE_AND_LOAD(P)
+                TR_MARK(tis)
             }
             __syncthreads();
+            TR_MARK(tlb)
             ++i;
         }
+        TR(if (threadIdx.x == 256) {
+            atomicAdd(&g_gemm_trace[4], (unsigned long long)(TR_NOW() - tl0)); atomicAdd(&g_gemm_trace[5], (unsigned long long)tvm);
+            atomicAdd(&g_gemm_trace[6], (unsigned long long)tst); atomicAdd(&g_gemm_trace[7], (unsigned long long)tis);
+            atomicAdd(&g_gemm_trace[8], (unsigned long long)tlb); })
+#undef TR_MARK
 #undef WS_LD16
 #undef WS_SET_TILE
 #undef WS_GLOAD1
@@ -515,7 +592,9 @@ __global__ __launch_bounds__(512, 2) void gemm_ws_kernel(
 #pragma unroll
         for (int ti = 0; ti < 4; ++ti) acc[ci][ti] = f32x4_t{0.f, 0.f, 0.f, 0.f};
     int kt = 0, tile = t_begin;
+    TR(long long tm0 = TR_NOW(), twk = 0, tmb = 0, tep = 0, tx, ty;)
     __syncthreads();                                             // barrier #0
+    TR(tx = TR_NOW();)
     for (int s = 0; s < total; ++s) {
         const unsigned char* wt = smem + (s & 1) * 2 * TILE_BYTES + (wn * 64 + n) * LDS_ROW;
         const unsigned char* xt = wt + TILE_BYTES + ((wm - wn) * 64) * LDS_ROW;
@@ -534,14 +613,25 @@ __global__ __launch_bounds__(512, 2) void gemm_ws_kernel(
 #pragma unroll
             for (int ci = 0; ci < 4; ++ci)
 #pragma unroll
-                for (int ti = 0; ti < 4; ++ti) GT<T>::mma(wf[kq][ci], xf[kq][ti], acc[ci][ti]);
+                for (int ti = 0; ti < 4; ++ti) {
+                    if (!ABLATE(DBG_NO_MMA)) GT<T>::mma(wf[kq][ci], xf[kq][ti], acc[ci][ti]);
+                    else asm volatile("" :: "v"(wf[kq][ci].x), "v"(xf[kq][ti].x));
+                }
+        TR(ty = TR_NOW(); twk += ty - tx; tx = ty;)
         __syncthreads();
+        TR(ty = TR_NOW(); tmb += ty - tx; tx = ty;)
         if (++kt == nk) {
             const int m0 = tile * BM, n0 = tn * BN;
-            epilogue_tile<OutT>(acc, C, bias, residual, row_mask, M, N, flags, m0 + wm * 64 + n, n0 + wn * 64 + 4 * g);
+            if (!ABLATE(DBG_NO_EPI))
+                epilogue_tile<OutT>(acc, C, bias, residual, row_mask, M, N, flags, m0 + wm * 64 + n, n0 + wn * 64 + 4 * g);
             kt = 0; ++tile;
+            TR(ty = TR_NOW(); tep += ty - tx; tx = ty;)
         }
     }
+    TR(if (threadIdx.x == 0) {
+        atomicAdd(&g_gemm_trace[0], (unsigned long long)(TR_NOW() - tm0)); atomicAdd(&g_gemm_trace[1], (unsigned long long)twk);
+        atomicAdd(&g_gemm_trace[2], (unsigned long long)tmb); atomicAdd(&g_gemm_trace[3], (unsigned long long)tep);
+        atomicAdd(&g_gemm_trace[9], 1ull); })
 }
 
 // tiles per block: enough chains to fill the chip (2 resident workgroups x 256 CUs) a few times over
@@ -650,7 +740,7 @@ extern "C" int dtlr_gemm_nt(const void* A, const void* A2, const void* W, const 
     int flags = (bias ? EPI_BIAS : 0) | (relu == 1 ? EPI_RELU : 0) | (relu == 2 ? EPI_RELU_POST : 0) |
                 (residual ? EPI_RESIDUAL : 0) | (row_mask ? EPI_ROWMASK : 0);
 #ifdef DTLR_GEMM_ABLATION
-    if (const char* ab = getenv("DTLR_GEMM_ABLATE")) flags |= (atoi(ab) & (DBG_NO_LOAD | DBG_NO_MMA | DBG_NO_LDS));   // timing experiments only
+    if (const char* ab = getenv("DTLR_GEMM_ABLATE")) flags |= (atoi(ab) & (DBG_NO_LOAD | DBG_NO_MMA | DBG_NO_LDS | DBG_NO_EPI));   // timing experiments only
 #endif
     hipStream_t st = (hipStream_t)stream;
     if (in_dtype == DTLR_BF16) {
@@ -666,6 +756,18 @@ extern "C" int dtlr_gemm_nt(const void* A, const void* A2, const void* W, const 
     }
     return DTLR_EDTYPE;
 }
+
+#ifdef DTLR_GEMM_ABLATION
+// instrumentation builds only (tools/): read and reset the cycle-attribution counters of gemm_ws_kernel
+extern "C" int dtlr_debug_gemm_trace(unsigned long long* out16)
+{
+    if (hipDeviceSynchronize() != hipSuccess) return DTLR_ELAUNCH;
+    if (hipMemcpyFromSymbol(out16, HIP_SYMBOL(g_gemm_trace), 16 * sizeof(unsigned long long)) != hipSuccess) return DTLR_ELAUNCH;
+    unsigned long long z[16] = {0};
+    if (hipMemcpyToSymbol(HIP_SYMBOL(g_gemm_trace), z, sizeof(z)) != hipSuccess) return DTLR_ELAUNCH;
+    return DTLR_OK;
+}
+#endif
 
 extern "C" int dtlr_conv2d_nhwc(const void* X, const void* W, const float* bias, const void* residual, void* Y,
                                 int B, int H, int Wd, int Cin, int Cout, int KH, int KW, int stride, int pad,

@@ -142,6 +142,36 @@ def main():
                 res.append({"kernel": f"gemm_ablate_bf16_N{N_}_K{K_}_{label}", "ms": ms, "TFLOPs_equiv": flops / ms / 1e9})
             os.environ["DTLR_GEMM_ABLATE"] = "0"
             del x, w
+    if "gemm_trace" in only:
+        # needs DTLR_HIP_LIB=dtlr_amd/libdtlr_hip_instr.so: per-role cycle attribution + phase switches of gemm_ws_kernel
+        import ctypes
+        from dtlr_amd import _lib
+        L = _lib.lib()
+        if not hasattr(L, "dtlr_debug_gemm_trace"):
+            raise SystemExit("gemm_trace needs the instrumented library (python -m dtlr_amd.build --instr; DTLR_HIP_LIB=...)")
+        buf = (ctypes.c_ulonglong * 16)()
+        T = B * S
+        names = ["mfma_total", "mfma_work", "mfma_barrier", "mfma_epilogue", "ld_total", "ld_vmwait", "ld_lds_store", "ld_issue", "ld_barrier", "blocks"]
+        for (N_, K_, relu) in ((256, 256, 0), (2048, 256, 1), (256, 2048, 0)):
+            x = torch.randn((T, K_), generator=g).to(dev).bfloat16()
+            w = (torch.randn((N_, K_), generator=g) / K_ ** 0.5).to(dev).bfloat16()
+            bb = torch.randn((N_,), generator=g).to(dev)
+            flops = 2.0 * T * N_ * K_
+            for code, label in ((0, "full"), (2048, "no_epilogue"), (256, "no_global_loads"), (512, "no_mfma"), (1024, "no_lds_store"),
+                                (2048 + 256, "no_epi_no_loads"), (2048 + 512 + 1024 + 256, "skeleton")):
+                os.environ["DTLR_GEMM_ABLATE"] = str(code)
+                ms = timeit(lambda: ops.linear(x, w, bb, relu), 6)
+                L.dtlr_debug_gemm_trace(buf)
+                ops.linear(x, w, bb, relu)
+                L.dtlr_debug_gemm_trace(buf)
+                v = list(buf)
+                nb = max(v[9], 1)
+                rec = {"kernel": f"gemm_trace_bf16_N{N_}_K{K_}_{label}", "ms": ms, "TFLOPs_equiv": flops / ms / 1e9}
+                rec.update({k: round(v[i] / nb) for i, k in enumerate(names[:9])})
+                rec["blocks"] = v[9]
+                res.append(rec)
+            os.environ["DTLR_GEMM_ABLATE"] = "0"
+            del x, w
     for r in res:
         print(json.dumps(r))
 
