@@ -53,12 +53,13 @@ def build(force: bool = False, verbose: bool = True) -> str:
     return LIB
 
 
-def build_instrumented(verbose: bool = True) -> str:
-    """Profiling-only variant (tools/profile_kernels.py --instr): same sources with -DDTLR_GEMM_ABLATION (phase
-    switches + cycle attribution in the GEMM).  Never loaded by the product; select it with DTLR_HIP_LIB."""
-    out = os.path.join(HERE, "libdtlr_hip_instr.so")
+def build_instrumented(verbose: bool = True, trace: bool = False) -> str:
+    """Profiling-only variants: same sources with -DDTLR_GEMM_ABLATION (phase switches in the GEMM; env
+    DTLR_GEMM_ABLATE) and, with trace, -DDTLR_GEMM_TRACE (per-role cycle attribution; perturbs the kernel).
+    Never loaded by the product; select with DTLR_HIP_LIB."""
+    out = os.path.join(HERE, "libdtlr_hip_trace.so" if trace else "libdtlr_hip_instr.so")
     cmd = [HIPCC, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-Wall", "-Wno-unused-function",
-           "-DDTLR_GEMM_ABLATION"] + _sources() + ["-o", out]
+           "-DDTLR_GEMM_ABLATION"] + (["-DDTLR_GEMM_TRACE"] if trace else []) + _sources() + ["-o", out]
     if verbose:
         print("[dtlr build]", " ".join(cmd), flush=True)
     subprocess.check_call(cmd)
@@ -66,7 +67,7 @@ def build_instrumented(verbose: bool = True) -> str:
 
 
 if __name__ == "__main__":
-    if "--instr" in sys.argv:
-        print(build_instrumented())
+    if "--instr" in sys.argv or "--trace" in sys.argv:
+        print(build_instrumented(trace="--trace" in sys.argv))
     else:
         print(build(force="--force" in sys.argv))

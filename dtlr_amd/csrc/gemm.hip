@@ -57,6 +57,10 @@ template <int N> __device__ __forceinline__ void wait_vmcnt() {
 // the library is built with -DDTLR_GEMM_ABLATION, so the production hot loop carries no extra branches.
 #ifdef DTLR_GEMM_ABLATION
 #define ABLATE(BIT) (flags & (BIT))
+#else
+#define ABLATE(BIT) false
+#endif
+#ifdef DTLR_GEMM_TRACE
 #define TR(...) __VA_ARGS__
 #define TR_NOW() ((long long)__builtin_readcyclecounter())
 // cycle attribution of the wave-specialised kernel, summed over workgroups (wave 0 = MFMA role, wave 4 = loader role):
@@ -64,12 +68,11 @@ template <int N> __device__ __forceinline__ void wait_vmcnt() {
 // [7] load issue [8] barrier wait | [9] workgroups
 __device__ unsigned long long g_gemm_trace[16];
 #else
-#define ABLATE(BIT) false
 #define TR(...)
 #endif
 
 enum : int { EPI_BIAS = 1, EPI_RELU = 2, EPI_RESIDUAL = 4, EPI_ROWMASK = 8, EPI_RELU_POST = 16,
-              DBG_NO_LOAD = 256, DBG_NO_MMA = 512, DBG_NO_LDS = 1024, DBG_NO_EPI = 2048 };   // ablation switches (env DTLR_GEMM_ABLATE), timing only
+              DBG_NO_LOAD = 256, DBG_NO_MMA = 512, DBG_NO_LDS = 1024, DBG_NO_EPI = 2048, DBG_NO_STORE = 4096 };   // ablation switches (env DTLR_GEMM_ABLATE), timing only
 
 template <typename T> struct GT;
 template <> struct GT<uint16_t> {   // bf16
@@ -172,7 +175,8 @@ __device__ __forceinline__ void epilogue_tile(f32x4_t (&acc)[4][4], OutT* __rest
 #pragma unroll
                         for (int r = 0; r < 4; ++r) v[r] = fmaxf(v[r], 0.f);
                     }
-                    Out<OutT>::st4(C + (long)(tok0 + ti * 16) * N + ch0 + ci * 16, v);
+                    if (!ABLATE(DBG_NO_STORE)) Out<OutT>::st4(C + (long)(tok0 + ti * 16) * N + ch0 + ci * 16, v);
+                    else asm volatile("" :: "v"(v[0]), "v"(v[1]), "v"(v[2]), "v"(v[3]));
                 }
             }
         }
@@ -740,7 +744,7 @@ extern "C" int dtlr_gemm_nt(const void* A, const void* A2, const void* W, const 
     int flags = (bias ? EPI_BIAS : 0) | (relu == 1 ? EPI_RELU : 0) | (relu == 2 ? EPI_RELU_POST : 0) |
                 (residual ? EPI_RESIDUAL : 0) | (row_mask ? EPI_ROWMASK : 0);
 #ifdef DTLR_GEMM_ABLATION
-    if (const char* ab = getenv("DTLR_GEMM_ABLATE")) flags |= (atoi(ab) & (DBG_NO_LOAD | DBG_NO_MMA | DBG_NO_LDS | DBG_NO_EPI));   // timing experiments only
+    if (const char* ab = getenv("DTLR_GEMM_ABLATE")) flags |= (atoi(ab) & (DBG_NO_LOAD | DBG_NO_MMA | DBG_NO_LDS | DBG_NO_EPI | DBG_NO_STORE));   // timing experiments only
 #endif
     hipStream_t st = (hipStream_t)stream;
     if (in_dtype == DTLR_BF16) {
@@ -757,7 +761,7 @@ extern "C" int dtlr_gemm_nt(const void* A, const void* A2, const void* W, const 
     return DTLR_EDTYPE;
 }
 
-#ifdef DTLR_GEMM_ABLATION
+#ifdef DTLR_GEMM_TRACE
 // instrumentation builds only (tools/): read and reset the cycle-attribution counters of gemm_ws_kernel
 extern "C" int dtlr_debug_gemm_trace(unsigned long long* out16)
 {

@@ -63,8 +63,162 @@ __device__ __forceinline__ int cols_left_of(int t, int TW0, int W0, int Wl) {
     return (int)(c < Wl ? c : Wl);
 }
 
+// ---- bf16 query phase: one lane per (query, head, LEVEL) ---------------------------------------------
+// The four lanes of a quad are the four levels of one (query, head).  Each lane does the geometry of its own
+// 4 points only (the first version gave a lane 8 channels of ALL 16 points: every lane of the quad repeated
+// the same 16-point geometry + 16-logit softmax, ~45% of the kernel's VALU instructions, and the kernel is
+// VALU-bound: ~2000 instr/lane), accumulates all 32 channels of its level, and the quad is combined with
+// 24 DPP adds.  LDS reads of a pixel row (64 B = 4 x 16-byte pieces) are issued in the rotated piece order
+// (jj + level) & 3 so that the lanes of a quad hit different 16-byte slots (same bank behaviour as the old
+// layout); the rotation cancels in the quad reduce-scatter: lane i ends up owning piece i.
+template <int CTRL> __device__ __forceinline__ float quad_dpp(float v) {
+    return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, 0xf, 0xf, false));
+}
+template <typename OT> __device__ __forceinline__ void ld8f(const OT* p, float (&v)[8]);
+template <> __device__ __forceinline__ void ld8f<float>(const float* p, float (&v)[8]) {
+    const float4 a = reinterpret_cast<const float4*>(p)[0], b = reinterpret_cast<const float4*>(p)[1];
+    v[0] = a.x; v[1] = a.y; v[2] = a.z; v[3] = a.w; v[4] = b.x; v[5] = b.y; v[6] = b.z; v[7] = b.w;
+}
+template <> __device__ __forceinline__ void ld8f<uint16_t>(const uint16_t* p, float (&v)[8]) {
+    ET<uint16_t>::unpack(*reinterpret_cast<const uint4*>(p), v);
+}
+template <typename OT> __device__ __forceinline__ void ld4f(const OT* p, float (&v)[4]);
+template <> __device__ __forceinline__ void ld4f<float>(const float* p, float (&v)[4]) {
+    const float4 a = *reinterpret_cast<const float4*>(p); v[0] = a.x; v[1] = a.y; v[2] = a.z; v[3] = a.w;
+}
+template <> __device__ __forceinline__ void ld4f<uint16_t>(const uint16_t* p, float (&v)[4]) {
+    const uint2 t = *reinterpret_cast<const uint2*>(p);
+    v[0] = __uint_as_float(t.x << 16); v[1] = __uint_as_float(t.x & 0xffff0000u); v[2] = __uint_as_float(t.y << 16); v[3] = __uint_as_float(t.y & 0xffff0000u);
+}
+
+template <typename OT>
+__device__ __forceinline__ void enc_queries_bf16(
+    const unsigned char* smem, const uint16_t* __restrict__ vimg, const OT* __restrict__ ow, const float* __restrict__ ref,
+    uint16_t* __restrict__ out, const EncLevels lv, const int (&qc0)[4], const int (&qn)[4], const int (&wc0)[4],
+    const int (&wc1)[4], const int (&qbase)[5], int nq, int S, int M, int m, int b)
+{
+    const int tid = threadIdx.x, p = tid & 3;
+    const int MD = M * 32;
+    // this lane's level (loop invariant: the loop stride 256 keeps tid & 3)
+    const int Hl = p == 0 ? lv.H[0] : p == 1 ? lv.H[1] : p == 2 ? lv.H[2] : lv.H[3];
+    const int Wl = p == 0 ? lv.W[0] : p == 1 ? lv.W[1] : p == 2 ? lv.W[2] : lv.W[3];
+    const int startl = p == 0 ? lv.start[0] : p == 1 ? lv.start[1] : p == 2 ? lv.start[2] : lv.start[3];
+    const int loffl = p == 0 ? lv.loff[0] : p == 1 ? lv.loff[1] : p == 2 ? lv.loff[2] : lv.loff[3];
+    const int wstride = p == 0 ? lv.wmax[0] : p == 1 ? lv.wmax[1] : p == 2 ? lv.wmax[2] : lv.wmax[3];
+    const int wc0l = p == 0 ? wc0[0] : p == 1 ? wc0[1] : p == 2 ? wc0[2] : wc0[3];
+    const int wc1l = p == 0 ? wc1[0] : p == 1 ? wc1[1] : p == 2 ? wc1[2] : wc1[3];
+    const int wwl = wc1l - wc0l;
+    const float fH = (float)Hl, fW = (float)Wl;
+    const float invH = 1.0f / fH, invW = 1.0f / fW;          // exact for power-of-two maps; else the product differs from the quotient by <= 1 ulp
+    const unsigned char* win = smem + (long)loffl * 64;
+    const uint16_t* gsrc = vimg + (long)startl * MD;
+    int rot[4];
+#pragma unroll
+    for (int jj = 0; jj < 4; ++jj) rot[jj] = ((jj + p) & 3) * 16;
+
+    for (int it = tid; it < nq * 4; it += 256) {
+        const int q = it >> 2;
+        int lq = 0;
+        if (q >= qbase[1]) lq = 1;
+        if (q >= qbase[2]) lq = 2;
+        if (q >= qbase[3]) lq = 3;
+        int r, nc, c0q, Wq, stq;
+        switch (lq) {
+        case 0: r = q - qbase[0]; nc = qn[0]; c0q = qc0[0]; Wq = lv.W[0]; stq = lv.start[0]; break;
+        case 1: r = q - qbase[1]; nc = qn[1]; c0q = qc0[1]; Wq = lv.W[1]; stq = lv.start[1]; break;
+        case 2: r = q - qbase[2]; nc = qn[2]; c0q = qc0[2]; Wq = lv.W[2]; stq = lv.start[2]; break;
+        default: r = q - qbase[3]; nc = qn[3]; c0q = qc0[3]; Wq = lv.W[3]; stq = lv.start[3]; break;
+        }
+        const int qi = r / nc, qj = c0q + r % nc;
+        const long bq = (long)b * S + stq + qi * Wq + qj;
+        const OT* row = ow + bq * (long)(M * 48);
+        float off[8], lg[4];
+        ld8f<OT>(row + m * 32 + p * 8, off);
+        ld4f<OT>(row + M * 32 + m * 16 + p * 4, lg);
+        const float2 rf = *reinterpret_cast<const float2*>(ref + bq * 8 + 2 * p);
+        // softmax over the quad's 16 logits
+        float mx = fmaxf(fmaxf(lg[0], lg[1]), fmaxf(lg[2], lg[3]));
+        mx = fmaxf(mx, quad_dpp<0xB1>(mx));
+        mx = fmaxf(mx, quad_dpp<0x4E>(mx));
+        float sum = 0.f;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) { lg[i] = __expf(lg[i] - mx); sum += lg[i]; }
+        sum += quad_dpp<0xB1>(sum);
+        sum += quad_dpp<0x4E>(sum);
+        const float inv = 1.0f / sum;
+
+        float acc[4][8];
+#pragma unroll
+        for (int jj = 0; jj < 4; ++jj)
+#pragma unroll
+            for (int i = 0; i < 8; ++i) acc[jj][i] = 0.f;
+#define DTLR_ACCUM(D, WGT)                                                                         \
+        _Pragma("unroll") for (int jj = 0; jj < 4; ++jj) {                                         \
+            float v_[8]; ET<uint16_t>::unpack(D[jj], v_);                                          \
+            _Pragma("unroll") for (int i = 0; i < 8; ++i) acc[jj][i] += (WGT) * v_[i];            \
+        }
+        // one point at a time: its geometry, then its 16 reads (4 corners x 4 pieces, 64 registers in flight), then the
+        // accumulate; the scheduling barrier keeps the compiler from hoisting the next points' reads (it spills ~200
+        // registers when it does)
+#pragma unroll
+        for (int pt = 0; pt < 4; ++pt) {
+            const float lx = rf.x + off[2 * pt] * invW;
+            const float ly = rf.y + off[2 * pt + 1] * invH;
+            const float h_im = ly * fH - 0.5f, w_im = lx * fW - 0.5f;
+            const bool inside = h_im > -1.f && w_im > -1.f && h_im < fH && w_im < fW;
+            const float hf = floorf(h_im), wf = floorf(w_im);
+            const int h_low = (int)fminf(fmaxf(hf, -1.f), fH), w_low = (int)fminf(fmaxf(wf, -1.f), fW);
+            const int h_high = h_low + 1, w_high = w_low + 1;
+            const float lh = h_im - hf, lw = w_im - wf, hh = 1.f - lh, hw = 1.f - lw;
+            const bool top = inside && h_low >= 0, bot = inside && h_high <= Hl - 1, left = w_low >= 0, right = w_high <= Wl - 1;
+            const int h0 = min(max(h_low, 0), Hl - 1), h1 = max(min(h_high, Hl - 1), 0);
+            const int w0 = min(max(w_low, 0), Wl - 1), w1c = max(min(w_high, Wl - 1), 0);
+            const bool staged = (w0 >= wc0l) && (w1c < wc1l);
+            const float a = lg[pt] * inv;                       // attention weight folded into the bilinear weights
+            const float k1 = (top && left) ? hh * hw * a : 0.f, k2 = (top && right) ? hh * lw * a : 0.f;
+            const float k3 = (bot && left) ? lh * hw * a : 0.f, k4 = (bot && right) ? lh * lw * a : 0.f;
+            if (staged || !inside) {
+                // a point outside the map has all-zero weights but must still read initialised LDS (0 * NaN = NaN): clamp
+                const int a0 = min(max(w0 - wc0l, 0), wwl - 1), a1 = min(max(w1c - wc0l, 0), wwl - 1);
+                const unsigned char* r0 = win + (h0 * wstride) * 64;
+                const unsigned char* r1 = win + (h1 * wstride) * 64;
+                uint4 d1[4], d2[4], d3[4], d4[4];
+#pragma unroll
+                for (int jj = 0; jj < 4; ++jj) {
+                    d1[jj] = *reinterpret_cast<const uint4*>(r0 + a0 * 64 + rot[jj]);
+                    d2[jj] = *reinterpret_cast<const uint4*>(r0 + a1 * 64 + rot[jj]);
+                    d3[jj] = *reinterpret_cast<const uint4*>(r1 + a0 * 64 + rot[jj]);
+                    d4[jj] = *reinterpret_cast<const uint4*>(r1 + a1 * 64 + rot[jj]);
+                }
+                DTLR_ACCUM(d1, k1) DTLR_ACCUM(d2, k2) DTLR_ACCUM(d3, k3) DTLR_ACCUM(d4, k4)
+            } else {                                            // inside the map, outside the staged window: global path
+#pragma unroll
+                for (int jj = 0; jj < 4; ++jj) {
+                    const int pe = rot[jj] >> 1;                // piece offset in elements
+                    const uint4 e1 = *reinterpret_cast<const uint4*>(gsrc + (long)(h0 * Wl + w0) * MD + pe);
+                    const uint4 e2 = *reinterpret_cast<const uint4*>(gsrc + (long)(h0 * Wl + w1c) * MD + pe);
+                    const uint4 e3 = *reinterpret_cast<const uint4*>(gsrc + (long)(h1 * Wl + w0) * MD + pe);
+                    const uint4 e4 = *reinterpret_cast<const uint4*>(gsrc + (long)(h1 * Wl + w1c) * MD + pe);
+                    float v1[8], v2[8], v3[8], v4[8];
+                    ET<uint16_t>::unpack(e1, v1); ET<uint16_t>::unpack(e2, v2); ET<uint16_t>::unpack(e3, v3); ET<uint16_t>::unpack(e4, v4);
+#pragma unroll
+                    for (int i = 0; i < 8; ++i) acc[jj][i] += k1 * v1[i] + k2 * v2[i] + k3 * v3[i] + k4 * v4[i];
+                }
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        }
+#undef DTLR_ACCUM
+        // quad reduce-scatter: lane i's acc[jj] is piece (jj + i) & 3 of its level; lane i collects piece i
+        float res[8];
+#pragma unroll
+        for (int i = 0; i < 8; ++i)
+            res[i] = (acc[0][i] + quad_dpp<0x39>(acc[3][i])) + (quad_dpp<0x4E>(acc[2][i]) + quad_dpp<0x93>(acc[1][i]));
+        *reinterpret_cast<uint4*>(out + bq * MD + m * 32 + p * 8) = ET<uint16_t>::pack(res);
+    }
+}
+
 template <typename T, typename OT>
-__global__ __launch_bounds__(256) void msda_enc_lds_kernel(
+__global__ __launch_bounds__(256, 2) void msda_enc_lds_kernel(
     const T* __restrict__ value, const OT* __restrict__ ow, const float* __restrict__ ref, T* __restrict__ out,
     EncLevels lv, int S, int M, int TW0, int R)
 {
@@ -120,6 +274,10 @@ __global__ __launch_bounds__(256) void msda_enc_lds_kernel(
     }
     __syncthreads();
 
+    if constexpr (sizeof(T) == 2) {
+        enc_queries_bf16<OT>(smem, vimg, ow, ref, out, lv, qc0, qn, wc0, wc1, qbase, nq, S, M, m, b);
+        return;
+    }
     // ---- queries: CP lanes per query (16 bytes = VEC channels each) ---------------------------------
     for (int it = tid; it < nq * CP; it += 256) {
         const int part = it % CP, q = it / CP;

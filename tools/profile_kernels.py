@@ -128,17 +128,18 @@ def main():
             ms = timeit(lambda: (F.relu(F.linear(x, w, bl), inplace=True) if relu else F.linear(x, w, bl)), max(5, args.iters // 2))
             res.append({"kernel": name + "_library", "ms": ms, "TFLOPs": flops / ms / 1e9})
             del x, w
-    if want("gemm_ablate"):
+    if "gemm_ablate" in only:
         # where does the per-slab time go?  (outputs are garbage under ablation; timing only)
         T = B * S
         for (N_, K_) in ((256, 256), (2048, 256), (256, 2048)):
             x = torch.randn((T, K_), generator=g).to(dev).bfloat16()
             w = (torch.randn((N_, K_), generator=g) / K_ ** 0.5).to(dev).bfloat16()
             flops = 2.0 * T * N_ * K_
-            for code, label in ((0, "full"), (256, "no_global_loads"), (512, "no_mfma"), (1024, "no_lds_store"),
-                                (768, "no_loads_no_mfma"), (1280, "no_loads_no_lds_store"), (1792, "barriers_and_lds_reads_only")):
+            bb = torch.randn((N_,), generator=g).to(dev)
+            for code, label in ((0, "full"), (4096, "no_stores"), (2048, "no_epilogue"), (256, "no_global_loads"), (512, "no_mfma"), (1024, "no_lds_store"),
+                                (2048 + 512, "no_epi_no_mfma"), (2048 + 256 + 1024, "no_epi_no_loads_no_lds_store"), (2048 + 1792, "barriers_and_lds_reads_only")):
                 os.environ["DTLR_GEMM_ABLATE"] = str(code)
-                ms = timeit(lambda: ops.linear(x, w, None, 0), 10)
+                ms = timeit(lambda: ops.linear(x, w, bb, 1), 10)
                 res.append({"kernel": f"gemm_ablate_bf16_N{N_}_K{K_}_{label}", "ms": ms, "TFLOPs_equiv": flops / ms / 1e9})
             os.environ["DTLR_GEMM_ABLATE"] = "0"
             del x, w

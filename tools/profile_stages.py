@@ -1,0 +1,72 @@
+#!/usr/bin/env python3
+"""Stage split of one bench step (HIP events around the engine's stage methods, averaged).
+    python tools/profile_stages.py [--steps 5] [--dtype bf16] [--batch 32]
+Prints one JSON line: ms per stage.  Same workload as bench.py (Latin, 128x2048, synthetic)."""
+import argparse
+import json
+import os
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import torch  # noqa: E402
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--batch", type=int, default=32)
+    ap.add_argument("--dtype", default="bf16")
+    args = ap.parse_args()
+    from dtlr_amd import synth, weights
+    from dtlr_amd.config import DTLRConfig
+    from dtlr_amd.engine import DTLREngine
+    from dtlr_amd.evaluation import decode_blank_records
+    dev = torch.device("cuda:0")
+    dtype = torch.bfloat16 if args.dtype == "bf16" else torch.float32
+    cfg = DTLRConfig.latin()
+    eng = DTLREngine(cfg, weights.synthetic_state_dict(cfg, seed=0), dev, dtype)
+    x = torch.stack(synth.noise_lines(args.batch, 128, 2048, seed=1000)).to(dev)
+    mask = torch.zeros((args.batch, 128, 2048), dtype=torch.bool, device=dev)
+    spans = {}
+
+    def wrap(obj, name, label=None):
+        fn = getattr(obj, name)
+        label = label or name
+
+        def timed(*a, **k):
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            r = fn(*a, **k)
+            e1.record()
+            spans.setdefault(label, []).append((e0, e1))
+            return r
+        setattr(obj, name, timed)
+
+    for n in ("backbone", "encoder", "two_stage", "decoder"):
+        wrap(eng, n)
+
+    def step():
+        e0, e1, e2 = (torch.cuda.Event(enable_timing=True) for _ in range(3))
+        e0.record()
+        out = eng.forward(x, mask, has_padding=False)
+        e1.record()
+        decode_blank_records(out)
+        e2.record()
+        spans.setdefault("forward_total", []).append((e0, e1))
+        spans.setdefault("decode_blank", []).append((e1, e2))
+
+    for _ in range(3):
+        step()
+    torch.cuda.synchronize()
+    spans.clear()
+    for _ in range(args.steps):
+        step()
+    torch.cuda.synchronize()
+    res = {k: round(sum(a.elapsed_time(b) for a, b in v) / args.steps, 3) for k, v in spans.items()}
+    res["input_proj_heads_other"] = round(res["forward_total"] - sum(res[k] for k in ("backbone", "encoder", "two_stage", "decoder")), 3)
+    print(json.dumps({"stage_ms": res, "dtype": args.dtype, "batch": args.batch}))
+
+
+if __name__ == "__main__":
+    main()
