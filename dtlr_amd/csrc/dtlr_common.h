@@ -20,17 +20,17 @@ inline int check_launch() {
     return DTLR_OK;
 }
 
-// ---- bf16 <-> f32 (round-to-nearest-even; NaN kept quiet) -------------------------------------
+// ---- bf16 <-> f32: gfx950 converts in hardware (v_cvt_pk_bf16_f32: round-to-nearest-even, NaN stays a quiet NaN).
+// The first version rounded in software (~10 VALU instructions per pair); in the K = 256 GEMMs that made the
+// epilogue's VALU time equal to the tile's MFMA time.
+typedef float f32x2_hw_t __attribute__((ext_vector_type(2)));
+typedef __bf16 bf16x2_hw_t __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ float bf16_to_f32(uint16_t h) { return __uint_as_float(((uint32_t)h) << 16); }
-__device__ __forceinline__ uint16_t f32_to_bf16(float f) {
-    uint32_t u = __float_as_uint(f);
-    if ((u & 0x7fffffffu) > 0x7f800000u) return (uint16_t)((u >> 16) | 0x40u);
-    u += 0x7fffu + ((u >> 16) & 1u);
-    return (uint16_t)(u >> 16);
-}
 __device__ __forceinline__ uint32_t pack_bf16x2(float lo, float hi) {
-    return (uint32_t)f32_to_bf16(lo) | ((uint32_t)f32_to_bf16(hi) << 16);
+    const f32x2_hw_t f = {lo, hi};
+    return __builtin_bit_cast(uint32_t, __builtin_convertvector(f, bf16x2_hw_t));
 }
+__device__ __forceinline__ uint16_t f32_to_bf16(float f) { return (uint16_t)(pack_bf16x2(f, 0.f) & 0xffffu); }
 
 // ---- wave reductions (all 64 lanes participate) ----------------------------------------------
 __device__ __forceinline__ float wave_sum(float v) {
