@@ -1,0 +1,284 @@
+// Fused position-wise feed-forward block of a deformable-DETR layer, bf16:
+//
+//     Y = LayerNorm( X + relu(X W1^T + b1) W2^T + b2 )            X, Y: [M, 256]   W1: [d_ff, 256]   W2: [256, d_ff]
+// (W2 is handed over packed chunk-major: W2p[c][o][k] = W2[o][32 c + k], shape [d_ff/32][256][32])
+//
+// == forward_ffn + norm2 of the encoder layer (models/dino/deformable_transformer.py:804-823:
+// `src2 = linear2(dropout2(activation(linear1(src)))); src = norm2(src + dropout3(src2))`, dropout = identity at
+// inference) and the ffn + norm3 of the decoder layer (:876-880).
+//
+// Why fuse: as two GEMMs the [M, d_ff] intermediate (713 MB at M = 174080, d_ff = 2048) is written to HBM and
+// read back -- 1.4 GB of the block's 1.6 GB of traffic; measured 0.40 + 0.26 ms + 0.03 ms LayerNorm per encoder
+// layer against an MFMA time of 0.15 ms.  Here the intermediate never leaves the CU: HBM sees X once and Y once.
+//
+// Structure (one workgroup = 128 tokens, 8 waves, one workgroup per CU):
+//   * wave (tg, h): token group tg = 32 tokens (two 16-token MFMA column tiles), half h.
+//   * X^T of the wave's tokens stays in registers for the whole kernel as MFMA B-fragments (64 VGPRs).
+//   * the hidden dimension is streamed in chunks of 32 units.  A chunk's weights (32 rows of W1, 32 columns of W2,
+//     32 KB) are DMA'd global -> LDS (global_load_lds_dwordx4, no VGPR staging) into a 4-stage ring, already in
+//     MFMA-fragment order: every A-fragment is one linear 1 KB block (lane l reads base + 16 l: conflict-free
+//     without swizzle), so the fragment layout is produced by the per-lane SOURCE addresses of the DMA.
+//   * phase A: wave (tg, h) computes H^T[16 hidden of the chunk, 32 tokens] = W1c X^T (16 MFMA), adds b1, ReLU,
+//     rounds to bf16 (the same rounding the unfused path applies when it stores linear1's output) and writes its
+//     8 bytes per lane into the pair's H buffer -- laid out so that a lane's 16 bytes there ARE its B-fragment of
+//     the second GEMM (the hidden units of a chunk are assigned to MFMA rows so that no transpose is needed).
+//   * phase B: Y^T[128 channels (half h), 32 tokens] += W2c H^T (16 MFMA), fp32 accumulators for the whole kernel.
+//   * ONE barrier per chunk: it publishes H(c) to the partner wave, retires chunk c+1's DMA (each wave waits for its
+//     own pieces with a counted vmcnt first) and frees the ring stage the next DMA overwrites.
+//   * epilogue: + b2 + X (the residual is already in registers: W2's rows are assigned to MFMA rows so that a lane's
+//     accumulators are exactly the channels its X fragments hold), LayerNorm over the 256 channels (lane-local
+//     sums, two cross-lane steps, one exchange with the partner wave through LDS), 16-byte stores.
+#include "dtlr_common.h"
+
+namespace dtlr {
+
+typedef __attribute__((ext_vector_type(8))) __bf16 ffn_bf16x8_t;
+typedef __attribute__((ext_vector_type(4))) float ffn_f32x4_t;
+
+constexpr int FFN_NS = 4;                                   // ring stages
+constexpr int FFN_STAGE = 32768;                            // W1 chunk image (16 KB) | W2 chunk image (16 KB)
+constexpr int FFN_H_OFF = FFN_NS * FFN_STAGE;               // H buffers: [tg 4][buf 2][tt 2][1024 B]
+constexpr int FFN_LN_OFF = FFN_H_OFF + 4 * 2 * 2 * 1024;    // LayerNorm exchange: [tg 4][half 2][32 tokens] floats
+constexpr int FFN_B1_OFF = FFN_LN_OFF + 4 * 2 * 32 * 4;     // b1 staged once (a compiler-visible global load inside the chunk
+                                                            // loop would be waited for with vmcnt(0) and drain the DMA queue)
+constexpr int FFN_MAX_DFF = 2048;
+constexpr int FFN_LDS = FFN_B1_OFF + FFN_MAX_DFF * 4;
+
+// LDS-DMA: 64 lanes x 16 bytes, destination = wave-uniform LDS byte address + 16 * lane.  Invisible to hipcc's
+// waitcnt bookkeeping: completion is counted by hand (cdna_hip_programming.md section 5.7).
+__device__ __forceinline__ void glds16(const void* gsrc, unsigned lds_dst) {
+    unsigned keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep) : "v"(gsrc), "s"(lds_dst) : "memory");
+}
+
+__device__ __forceinline__ uint4 ffn_load16(const void* p) {
+    uint4 r;
+    asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(r) : "v"(p) : "memory");
+    return r;
+}
+
+__device__ __forceinline__ ffn_f32x4_t ffn_mma(const uint4& a, const uint4& b, ffn_f32x4_t c) {
+    return __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(ffn_bf16x8_t, a), __builtin_bit_cast(ffn_bf16x8_t, b), c, 0, 0, 0);
+}
+
+__device__ __forceinline__ void unpack8(const uint4& t, float (&v)[8]) {
+    const uint32_t w[4] = {t.x, t.y, t.z, t.w};
+#pragma unroll
+    for (int i = 0; i < 4; ++i) { v[2 * i] = __uint_as_float(w[i] << 16); v[2 * i + 1] = __uint_as_float(w[i] & 0xffff0000u); }
+}
+
+__global__ __launch_bounds__(512, 2) void ffn_fused_bf16_kernel(
+    const uint16_t* __restrict__ X, const uint16_t* __restrict__ W1, const float* __restrict__ b1,
+    const uint16_t* __restrict__ W2, const float* __restrict__ b2, const float* __restrict__ gamma,
+    const float* __restrict__ beta, float eps, uint16_t* __restrict__ Y, int M, int d_ff)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const unsigned lds_base = (unsigned)(size_t)(__attribute__((address_space(3))) unsigned char*)smem;
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const int tg = wave >> 1, half = wave & 1;
+    const int n = lane & 15, g = lane >> 4;
+    const int nchunk = d_ff >> 5;
+    const long tok0 = (long)blockIdx.x * 128 + tg * 32;
+
+    // ---- X^T fragments of this wave's 32 tokens: lane (n, g) holds X[tok][32 ks + 8 g .. +7] ----------------
+    uint4 xf[8][2];
+#pragma unroll
+    for (int tt = 0; tt < 2; ++tt) {
+        const long tok = min(tok0 + tt * 16 + n, (long)M - 1);
+#pragma unroll
+        for (int ks = 0; ks < 8; ++ks) xf[ks][tt] = ffn_load16(X + tok * 256 + ks * 32 + g * 8);
+    }
+    // The X loads are asm (uncounted) and waited for right here: as compiler-counted loads hipcc kept their waits (down
+    // to vmcnt(0)) inside the chunk loop, where every iteration would then drain the DMA queue.
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_sched_barrier(0);
+
+    // ---- DMA sources: wave w moves blocks 4w .. 4w+3 of a chunk image (blocks 0-15: W1, 16-31: W2) ----------
+    // W1 block (j, ks): lane (m = n, g) <- W1[32 c + 8 (m>>2) + 4 j + (m&3)][32 ks + 8 g ..]   (hidden unit of MFMA row m, tile j)
+    // W2 block (h, i) : lane (m = n, g) <- W2[128 h + 32 (i>>1) + 8 (m>>2) + 4 (i&1) + (m&3)][32 c + 8 g ..]  (chunk-major storage)
+    const char* src[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+        const int blk = wave * 4 + u;
+        if (blk < 16) {
+            const int j = blk >> 3, ks = blk & 7;
+            src[u] = reinterpret_cast<const char*>(W1 + (long)(8 * (n >> 2) + 4 * j + (n & 3)) * 256 + ks * 32 + g * 8);
+        } else {
+            const int i = blk & 7, h = (blk >> 3) & 1;
+            src[u] = reinterpret_cast<const char*>(W2 + (long)(128 * h + 32 * (i >> 1) + 8 * (n >> 2) + 4 * (i & 1) + (n & 3)) * 32 + g * 8);
+        }
+    }
+    // bytes per chunk: 32 rows of W1 = one [256 x 32] panel of the chunk-major W2.  (W2 is passed chunk-major -- [d_ff/32][256][32]
+    // -- because in the natural [256][d_ff] layout a chunk is 256 pieces of 64 B at a 4 KB stride: every CU of an XCD then reads
+    // the same few L2 channels at the same time; measured 3300 cycles per chunk against 1000 of MFMA work.)
+    const long cstride = 32L * 256 * 2;
+    const unsigned my_blocks = lds_base + (unsigned)wave * 4096u;
+#define FFN_ISSUE(C)                                                                               \
+    {                                                                                              \
+        const unsigned dst_ = my_blocks + (unsigned)((C) & (FFN_NS - 1)) * FFN_STAGE;              \
+        _Pragma("unroll") for (int u = 0; u < 4; ++u) glds16(src[u] + (long)(C) * cstride, dst_ + u * 1024u); \
+    }
+
+    ffn_f32x4_t yacc[8][2];
+#pragma unroll
+    for (int i = 0; i < 8; ++i)
+#pragma unroll
+        for (int tt = 0; tt < 2; ++tt) yacc[i][tt] = ffn_f32x4_t{0.f, 0.f, 0.f, 0.f};
+
+    {
+        float* b1s = reinterpret_cast<float*>(smem + FFN_B1_OFF);
+        for (int i = (int)threadIdx.x * 4; i < d_ff; i += 512 * 4) *reinterpret_cast<float4*>(b1s + i) = *reinterpret_cast<const float4*>(b1 + i);
+    }
+    // prologue: chunks 0, 1, 2 in flight; chunk 0 landed and visible
+    FFN_ISSUE(0)
+    if (nchunk > 1) FFN_ISSUE(1)
+    if (nchunk > 2) FFN_ISSUE(2)
+    if (nchunk > 2) asm volatile("s_waitcnt vmcnt(8) lgkmcnt(0)" ::: "memory");
+    else if (nchunk > 1) asm volatile("s_waitcnt vmcnt(4) lgkmcnt(0)" ::: "memory");
+    else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+
+    unsigned char* hbuf = smem + FFN_H_OFF + tg * 4096;
+    // phase A of chunk C: H^T[16 hidden (MFMA tile j = half), 32 tokens] = W1c X^T, + b1, ReLU, bf16 -> the pair's H buffer.
+    // Four accumulation chains (even / odd k-steps x two token tiles): two chains leave the matrix pipe idle between
+    // dependent MFMAs whenever the SIMD's other wave is parked at the barrier.
+#define FFN_PHASE_A(C)                                                                             \
+    {                                                                                              \
+        const unsigned char* w1f = smem + ((C) & (FFN_NS - 1)) * FFN_STAGE + half * 8192 + lane * 16; \
+        const float4 bb = *reinterpret_cast<const float4*>(smem + FFN_B1_OFF + ((C) * 32 + g * 8 + half * 4) * 4); \
+        uint4 wa[8];                                                                               \
+        _Pragma("unroll") for (int ks = 0; ks < 8; ++ks) wa[ks] = *reinterpret_cast<const uint4*>(w1f + ks * 1024); \
+        ffn_f32x4_t he[2] = {ffn_f32x4_t{0.f, 0.f, 0.f, 0.f}, ffn_f32x4_t{0.f, 0.f, 0.f, 0.f}};    \
+        ffn_f32x4_t ho[2] = {ffn_f32x4_t{0.f, 0.f, 0.f, 0.f}, ffn_f32x4_t{0.f, 0.f, 0.f, 0.f}};    \
+        _Pragma("unroll") for (int ks = 0; ks < 8; ks += 2) {                                      \
+            he[0] = ffn_mma(wa[ks], xf[ks][0], he[0]);         he[1] = ffn_mma(wa[ks], xf[ks][1], he[1]); \
+            ho[0] = ffn_mma(wa[ks + 1], xf[ks + 1][0], ho[0]); ho[1] = ffn_mma(wa[ks + 1], xf[ks + 1][1], ho[1]); \
+        }                                                                                          \
+        /* lane (n, g) holds hidden units 32 C + 8 g + 4 half + r (r = 0..3) of token n: bytes [8 half, 8 half + 8) of */ \
+        /* the lane's 16-byte B-fragment slot */                                                    \
+        unsigned char* hw = hbuf + ((C) & 1) * 2048 + lane * 16 + half * 8;                        \
+        _Pragma("unroll") for (int tt = 0; tt < 2; ++tt) {                                         \
+            const float h0 = fmaxf(he[tt][0] + ho[tt][0] + bb.x, 0.f), h1 = fmaxf(he[tt][1] + ho[tt][1] + bb.y, 0.f); \
+            const float h2 = fmaxf(he[tt][2] + ho[tt][2] + bb.z, 0.f), h3 = fmaxf(he[tt][3] + ho[tt][3] + bb.w, 0.f); \
+            *reinterpret_cast<uint2*>(hw + tt * 1024) = make_uint2(pack_bf16x2(h0, h1), pack_bf16x2(h2, h3)); \
+        }                                                                                          \
+    }
+
+    // one chunk step: barrier(c) -> DMA of chunk c+3 -> phase B(c) [+ phase A(c+1), same basic block so that hipcc
+    // interleaves the LDS reads of one with the MFMAs of the other]
+#define FFN_STEP(C, WITH_A)                                                                        \
+    {                                                                                              \
+        /* the one barrier of the chunk: publishes H(C) to the partner wave; my pieces of chunk C+1 (read by phase */ \
+        /* A(C+1)) have landed -- chunk C+2's four may stay in flight; my H writes are done */     \
+        if ((C) + 2 < nchunk) asm volatile("s_waitcnt vmcnt(4) lgkmcnt(0)" ::: "memory");         \
+        else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");                           \
+        __builtin_amdgcn_s_barrier();                                                              \
+        if ((C) + 3 < nchunk) FFN_ISSUE((C) + 3)   /* into the stage of chunk C-1: all its readers passed the barrier */ \
+        const uint4 hb0 = *reinterpret_cast<const uint4*>(hbuf + ((C) & 1) * 2048 + lane * 16);    \
+        const uint4 hb1 = *reinterpret_cast<const uint4*>(hbuf + ((C) & 1) * 2048 + 1024 + lane * 16); \
+        const unsigned char* w2f = smem + ((C) & (FFN_NS - 1)) * FFN_STAGE + 16384 + half * 8192 + lane * 16; \
+        uint4 wb[8];                                                                               \
+        _Pragma("unroll") for (int i = 0; i < 8; ++i) wb[i] = *reinterpret_cast<const uint4*>(w2f + i * 1024); \
+        _Pragma("unroll") for (int i = 0; i < 8; ++i) {                                            \
+            yacc[i][0] = ffn_mma(wb[i], hb0, yacc[i][0]);                                          \
+            yacc[i][1] = ffn_mma(wb[i], hb1, yacc[i][1]);                                          \
+        }                                                                                          \
+        if (WITH_A) FFN_PHASE_A((C) + 1)                                                           \
+    }
+
+    FFN_PHASE_A(0)
+    for (int c = 0; c + 1 < nchunk; ++c) FFN_STEP(c, true)
+    FFN_STEP(nchunk - 1, false)
+#undef FFN_STEP
+#undef FFN_PHASE_A
+#undef FFN_ISSUE
+
+    // ---- epilogue: + b2 + residual, LayerNorm over 256 channels, store -----------------------------------------
+    // lane (n, g), ks' = 0..3: channels ch = 128 half + 32 ks' + 8 g + e, e = 0..7: e < 4 from yacc[2 ks'][tt][e],
+    // e >= 4 from yacc[2 ks' + 1][tt][e - 4]; the residual is X fragment ks = 4 half + ks'.
+    float v[2][4][8];
+    float s[2] = {0.f, 0.f};
+#pragma unroll
+    for (int kq = 0; kq < 4; ++kq) {
+        const int ch = 128 * half + 32 * kq + 8 * g;
+        const float4 ba = *reinterpret_cast<const float4*>(b2 + ch), bc = *reinterpret_cast<const float4*>(b2 + ch + 4);
+        const float bias[8] = {ba.x, ba.y, ba.z, ba.w, bc.x, bc.y, bc.z, bc.w};
+#pragma unroll
+        for (int tt = 0; tt < 2; ++tt) {
+            float xr[8];
+            unpack8(half ? xf[4 + kq][tt] : xf[kq][tt], xr);      // (a runtime index into xf would move it to scratch)
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                const float y = e < 4 ? yacc[2 * kq][tt][e] : yacc[2 * kq + 1][tt][e - 4];
+                v[tt][kq][e] = y + bias[e] + xr[e];
+                s[tt] += v[tt][kq][e];
+            }
+        }
+    }
+    float* lnx = reinterpret_cast<float*>(smem + FFN_LN_OFF) + tg * 64;     // [half][32 tokens]
+    float mean[2], rstd[2];
+#pragma unroll
+    for (int tt = 0; tt < 2; ++tt) {
+        s[tt] += __shfl_xor(s[tt], 16, 64);
+        s[tt] += __shfl_xor(s[tt], 32, 64);
+        if (g == 0) lnx[half * 32 + tt * 16 + n] = s[tt];
+    }
+    __syncthreads();
+#pragma unroll
+    for (int tt = 0; tt < 2; ++tt) mean[tt] = (s[tt] + lnx[(half ^ 1) * 32 + tt * 16 + n]) * (1.0f / 256.0f);
+    __syncthreads();
+    float q[2] = {0.f, 0.f};
+#pragma unroll
+    for (int tt = 0; tt < 2; ++tt) {
+#pragma unroll
+        for (int kq = 0; kq < 4; ++kq)
+#pragma unroll
+            for (int e = 0; e < 8; ++e) { const float d = v[tt][kq][e] - mean[tt]; q[tt] += d * d; }
+        q[tt] += __shfl_xor(q[tt], 16, 64);
+        q[tt] += __shfl_xor(q[tt], 32, 64);
+        if (g == 0) lnx[half * 32 + tt * 16 + n] = q[tt];
+    }
+    __syncthreads();
+#pragma unroll
+    for (int tt = 0; tt < 2; ++tt) rstd[tt] = rsqrtf((q[tt] + lnx[(half ^ 1) * 32 + tt * 16 + n]) * (1.0f / 256.0f) + eps);
+#pragma unroll
+    for (int kq = 0; kq < 4; ++kq) {
+        const int ch = 128 * half + 32 * kq + 8 * g;
+        const float4 ga = *reinterpret_cast<const float4*>(gamma + ch), gc = *reinterpret_cast<const float4*>(gamma + ch + 4);
+        const float4 ea = *reinterpret_cast<const float4*>(beta + ch), ec = *reinterpret_cast<const float4*>(beta + ch + 4);
+        const float gm[8] = {ga.x, ga.y, ga.z, ga.w, gc.x, gc.y, gc.z, gc.w};
+        const float bt[8] = {ea.x, ea.y, ea.z, ea.w, ec.x, ec.y, ec.z, ec.w};
+#pragma unroll
+        for (int tt = 0; tt < 2; ++tt) {
+            const long tok = tok0 + tt * 16 + n;
+            float o[8];
+#pragma unroll
+            for (int e = 0; e < 8; ++e) o[e] = (v[tt][kq][e] - mean[tt]) * rstd[tt] * gm[e] + bt[e];
+            if (tok < M)
+                *reinterpret_cast<uint4*>(Y + tok * 256 + ch) =
+                    make_uint4(pack_bf16x2(o[0], o[1]), pack_bf16x2(o[2], o[3]), pack_bf16x2(o[4], o[5]), pack_bf16x2(o[6], o[7]));
+        }
+    }
+}
+
+}  // namespace dtlr
+
+using namespace dtlr;
+
+extern "C" int dtlr_ffn_fused_bf16(const void* X, const void* W1, const float* b1, const void* W2, const float* b2,
+                                   const float* gamma, const float* beta, float eps, void* Y,
+                                   int M, int d_model, int d_ff, void* stream)
+{
+    clear_stale_error();
+    if (!X || !W1 || !b1 || !W2 || !b2 || !gamma || !beta || !Y) return DTLR_EINVAL;
+    if (M <= 0 || d_ff <= 0) return DTLR_EINVAL;
+    if (d_model != 256 || (d_ff & 31) || d_ff > FFN_MAX_DFF) return DTLR_ESHAPE;
+    static bool attr = false;
+    if (!attr) { (void)hipFuncSetAttribute((const void*)ffn_fused_bf16_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, FFN_LDS); (void)hipGetLastError(); attr = true; }
+    const unsigned grid = (unsigned)((M + 127) / 128);
+    hipLaunchKernelGGL(ffn_fused_bf16_kernel, dim3(grid), dim3(512), FFN_LDS, (hipStream_t)stream,
+                       (const uint16_t*)X, (const uint16_t*)W1, b1, (const uint16_t*)W2, b2, gamma, beta, eps, (uint16_t*)Y, M, d_ff);
+    return check_launch();
+}

@@ -47,6 +47,7 @@ class DTLREngine:
         self._pack(state_dict)
         self._shape_cache: Dict[tuple, dict] = {}
         self.use_lds_msda = True       # encoder MSDA with LDS-staged windows (False: gather kernel)
+        self.use_fused_ffn = True      # bf16: linear1+ReLU+linear2+residual+LayerNorm in one kernel (False: two GEMMs + LN)
 
     # ------------------------------------------------------------------------------ packing
     def _put(self, name, t, dtype=None):
@@ -151,6 +152,17 @@ class DTLREngine:
 
     def _ln(self, name, x, residual=None):
         return ops.layernorm(x, self.w[name + ".w"], self.w[name + ".b"], 1e-5, residual)
+
+    def _ffn(self, q, norm, x):
+        """forward_ffn + post-norm (deformable_transformer.py:804-823, 876-880).  bf16 engine: one fused kernel, the
+        d_ff-wide intermediate stays on chip; fp32 engine: two GEMMs + LayerNorm."""
+        w = self.w
+        if self.use_fused_ffn and ops.ffn_fused_supported(x, w[q + "ff1.w"]):
+            if q + "ff2.wp" not in w:                           # chunk-major copy of linear2.weight, packed once
+                w[q + "ff2.wp"] = ops.ffn_pack_w2(w[q + "ff2.w"])
+            return ops.ffn_fused(x, w[q + "ff1.w"], w[q + "ff1.b"], w[q + "ff2.wp"], w[q + "ff2.b"], w[q + norm + ".w"], w[q + norm + ".b"])
+        h = self._lin(q + "ff1", x, relu=True)
+        return self._ln(q + norm, self._lin(q + "ff2", h), residual=x)
 
     def backbone(self, x_nhwc) -> List[torch.Tensor]:
         """torchvision resnet50 (v1.5) body with FrozenBN folded; returns layer2/3/4 maps, NHWC
@@ -275,8 +287,7 @@ class DTLREngine:
             q = f"enc{n}."
             a = self._msda_module(q + "attn", src, pos, g["enc_ref"], src, g, self.cfg.enc_n_points)
             src = self._ln(q + "norm1", self._lin(q + "attn.out", a), residual=src)
-            h = self._lin(q + "ff1", src, relu=True)
-            src = self._ln(q + "norm2", self._lin(q + "ff2", h), residual=src)
+            src = self._ffn(q, "norm2", src)
         return src
 
     def two_stage(self, memory, g, forced_topk=None):
@@ -337,8 +348,7 @@ class DTLREngine:
             a = self._msda_module(q + "attn", tgt, qpos, ref_in, memory, g, cfg.dec_n_points)
             tgt = self._ln(q + "norm1", self._lin(q + "attn.out", a), residual=tgt)
             # ffn
-            h = self._lin(q + "ff1", tgt, relu=True)
-            tgt = self._ln(q + "norm3", self._lin(q + "ff2", h), residual=tgt)
+            tgt = self._ffn(q, "norm3", tgt)
             # iterative box refinement (734-756)
             ref = ops.box_refine(self._bbox_head(tgt), ref)
             refs.append(ref)

@@ -88,6 +88,34 @@ def layernorm(x, w, b, eps: float = 1e-5, residual=None):
     return y
 
 
+def ffn_fused_supported(x, w1) -> bool:
+    """The fused FFN kernel covers the bf16 engine at d_model 256, d_ff <= 2048 (multiple of 32)."""
+    return x.dtype == torch.bfloat16 and x.shape[-1] == 256 and w1.shape[0] % 32 == 0 and w1.shape[0] <= 2048
+
+
+def ffn_pack_w2(w2):
+    """linear2.weight [256, d_ff] -> the chunk-major layout dtlr_ffn_fused_bf16 streams: [d_ff/32, 256, 32]."""
+    o, dff = w2.shape
+    return w2.view(o, dff // 32, 32).permute(1, 0, 2).contiguous()
+
+
+def ffn_fused(x, w1, b1, w2p, b2, ln_w, ln_b, eps: float = 1e-5):
+    """LayerNorm(x + relu(x W1^T + b1) W2^T + b2) in ONE kernel (dtlr_ffn_fused_bf16): the [M, d_ff]
+    intermediate never reaches HBM.  x [..., 256] bf16; W1 [d_ff,256] bf16; w2p = ffn_pack_w2(W2) ([d_ff/32,256,32] bf16);
+    biases / LN params fp32."""
+    require_cuda(x, "x")
+    if w2p.dim() != 3 or w2p.shape[1] != 256 or w2p.shape[2] != 32 or w2p.shape[0] * 32 != w1.shape[0]:
+        raise ValueError("ffn_fused: w2p must be ffn_pack_w2(linear2.weight) of shape [d_ff/32, 256, 32]")
+    x = x if x.is_contiguous() else x.contiguous()
+    y = torch.empty_like(x)
+    M = x.numel() // x.shape[-1]
+    code = _lib.lib().dtlr_ffn_fused_bf16(x.data_ptr(), w1.data_ptr(), b1.data_ptr(), w2p.data_ptr(), b2.data_ptr(),
+                                          ln_w.data_ptr(), ln_b.data_ptr(), eps, y.data_ptr(), M, x.shape[-1], w1.shape[0],
+                                          _lib.current_stream())
+    _lib.check(code, "dtlr_ffn_fused_bf16")
+    return y
+
+
 def conv2d_nhwc(x, w, bias, stride: int, padding: int, relu=False, residual=None):
     """NHWC convolution + folded-BN bias [+ residual] [+ ReLU].  x [B,H,W,Cin] contiguous.
     w: [Cout,KH,KW,Cin] contiguous ("OHWI") -> the implicit-GEMM HIP kernel (dtlr_conv2d_nhwc), which

@@ -94,6 +94,21 @@ int dtlr_layernorm(const void *x, const void *residual, const float *gamma, cons
                    void *y, long rows, int C, float eps, int dtype, void *stream);
 
 /* ---------------------------------------------------------------------------------------------
+ * Fused position-wise feed-forward block + residual + LayerNorm, bf16 (fp32 accumulate / statistics):
+ *     Y = LayerNorm( X + relu(X W1^T + b1) W2^T + b2 )
+ * Replaces: DeformableTransformerEncoderLayer.forward_ffn + norm2
+ *           (models/dino/deformable_transformer.py:804-823: linear1 -> relu -> linear2, src + src2, norm2)
+ *           and the decoder layer's ffn + norm3 (:876-880), dropout = identity at inference.
+ *           The [M, d_ff] intermediate stays on chip (never written to HBM).
+ *   X, Y [M, d_model] bf16 ; W1 [d_ff, d_model] bf16 ; b1 [d_ff], b2/gamma/beta [d_model] fp32
+ *   W2p: linear2.weight [d_model, d_ff] packed chunk-major, W2p[c][o][k] = W2[o][32 c + k] (shape [d_ff/32][d_model][32], bf16)
+ *   d_model must be 256, d_ff a multiple of 32 and <= 2048 (DTLR_ESHAPE otherwise).
+ */
+int dtlr_ffn_fused_bf16(const void *X, const void *W1, const float *b1, const void *W2p, const float *b2,
+                        const float *gamma, const float *beta, float eps, void *Y,
+                        int M, int d_model, int d_ff, void *stream);
+
+/* ---------------------------------------------------------------------------------------------
  * Multi-head self-attention over the decoder queries, fused (scores/softmax/PV stay on chip).
  * Replaces: nn.MultiheadAttention(256, 8, dropout=0)(q, k, v)[0] minus its in/out projections, as
  *           called from DeformableTransformerDecoderLayer.forward_sa

@@ -334,3 +334,29 @@ def test_mha_f32_vs_fp64_reference(B, L):
     want = (torch.softmax(q @ k.transpose(-1, -2) / math.sqrt(hd), -1) @ vv).transpose(1, 2).reshape(B, L, C).float()
     got = ops.mha(qk.cuda(), v.cuda(), H).cpu()
     assert (got - want).abs().max() < 2e-5
+
+
+@pytest.mark.parametrize("M,dff", [(128, 2048), (300, 2048), (1000, 512), (4097, 2048), (37, 64)])
+def test_ffn_fused_bf16_vs_reference(M, dff):
+    """Fused FFN + residual + LayerNorm (dtlr_ffn_fused_bf16) vs an fp64 restatement of
+    norm(x + linear2(relu(linear1(x)))) (deformable_transformer.py:804-823) on the same bf16-rounded
+    inputs, with the intermediate rounded to bf16 as the kernel (and the unfused path) does; and vs the
+    unfused HIP path (two GEMMs + LayerNorm).  Ragged M exercises the token-tile tail."""
+    from dtlr_amd import ops
+    x = _rand((M, 256), 1).bfloat16()
+    w1 = (_rand((dff, 256), 2) / 16).bfloat16()
+    w2 = (_rand((256, dff), 3) / np.sqrt(dff)).bfloat16()
+    b1, b2 = _rand((dff,), 4) * 0.5, _rand((256,), 5) * 0.5
+    gw, gb = 1 + 0.2 * _rand((256,), 6), 0.3 * _rand((256,), 7)
+    h = torch.relu(x.double() @ w1.double().t() + b1.double()).bfloat16().double()
+    pre = x.double() + h @ w2.double().t() + b2.double()
+    want = torch.nn.functional.layer_norm(pre, (256,), gw.double(), gb.double(), 1e-5).float()
+    got = ops.ffn_fused(x.cuda(), w1.cuda(), b1.cuda(), ops.ffn_pack_w2(w2.cuda()), b2.cuda(), gw.cuda(), gb.cuda()).float().cpu()
+    assert got.shape == want.shape
+    # bf16 output rounding (2^-9 relative) + occasional 1-ulp flips of the bf16 intermediate
+    tol = 2 ** -8 * max(1.0, want.abs().max().item()) + 2e-2
+    assert (got - want).abs().max() < tol, (got - want).abs().max().item()
+    assert (got - want).abs().mean() < 4e-3
+    hh = ops.linear(x.cuda(), w1.cuda(), b1.cuda(), relu=True)
+    un = ops.layernorm(ops.linear(hh, w2.cuda(), b2.cuda()), gw.cuda(), gb.cuda(), 1e-5, residual=x.cuda()).float().cpu()
+    assert (got - un).abs().max() < 2 * tol

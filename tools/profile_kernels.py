@@ -143,6 +143,21 @@ def main():
                 res.append({"kernel": f"gemm_ablate_bf16_N{N_}_K{K_}_{label}", "ms": ms, "TFLOPs_equiv": flops / ms / 1e9})
             os.environ["DTLR_GEMM_ABLATE"] = "0"
             del x, w
+    if want("ffn_fused"):
+        T = B * S
+        x = torch.randn((T, 256), generator=g).to(dev).bfloat16()
+        w1 = (torch.randn((2048, 256), generator=g) / 16).to(dev).bfloat16()
+        w2 = (torch.randn((256, 2048), generator=g) / 45).to(dev).bfloat16()
+        b1 = torch.randn((2048,), generator=g).to(dev)
+        b2 = torch.randn((256,), generator=g).to(dev)
+        gw, gb = torch.ones(256, device=dev), torch.zeros(256, device=dev)
+        flops = 2.0 * T * 2048 * 256 * 2
+        w2p = ops.ffn_pack_w2(w2)
+        ms = timeit(lambda: ops.ffn_fused(x, w1, b1, w2p, b2, gw, gb), args.iters)
+        res.append({"kernel": "ffn_fused_bf16_M174080_dff2048", "ms": ms, "TFLOPs": flops / ms / 1e9})
+        ms = timeit(lambda: ops.layernorm(ops.linear(ops.linear(x, w1, b1, relu=True), w2, b2), gw, gb, 1e-5, residual=x), args.iters)
+        res.append({"kernel": "ffn_unfused_bf16_M174080_dff2048", "ms": ms, "TFLOPs": flops / ms / 1e9})
+        del x
     if "gemm_trace" in only:
         # needs DTLR_HIP_LIB=dtlr_amd/libdtlr_hip_instr.so: per-role cycle attribution + phase switches of gemm_ws_kernel
         import ctypes
