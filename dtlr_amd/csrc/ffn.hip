@@ -29,6 +29,7 @@
 //     accumulators are exactly the channels its X fragments hold), LayerNorm over the 256 channels (lane-local
 //     sums, two cross-lane steps, one exchange with the partner wave through LDS), 16-byte stores.
 #include "dtlr_common.h"
+#include <stdlib.h>
 
 namespace dtlr {
 
@@ -58,7 +59,9 @@ __device__ __forceinline__ uint4 ffn_load16(const void* p) {
     return r;
 }
 
+template <int DBG = 0>
 __device__ __forceinline__ ffn_f32x4_t ffn_mma(const uint4& a, const uint4& b, ffn_f32x4_t c) {
+    if constexpr (DBG & 2) { asm volatile("" :: "v"(a.x), "v"(b.x)); return c; }
     return __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(ffn_bf16x8_t, a), __builtin_bit_cast(ffn_bf16x8_t, b), c, 0, 0, 0);
 }
 
@@ -68,6 +71,9 @@ __device__ __forceinline__ void unpack8(const uint4& t, float (&v)[8]) {
     for (int i = 0; i < 4; ++i) { v[2 * i] = __uint_as_float(w[i] << 16); v[2 * i + 1] = __uint_as_float(w[i] & 0xffff0000u); }
 }
 
+// DBG (timing experiments only, env DTLR_FFN_DBG; results are garbage): 1 = no weight DMA after the prologue,
+// 2 = no MFMA, 4 = no per-chunk barrier.  DBG = 0 is the product kernel; the switches are compile-time so it carries no branches.
+template <int DBG>
 __global__ __launch_bounds__(512, 2) void ffn_fused_bf16_kernel(
     const uint16_t* __restrict__ X, const uint16_t* __restrict__ W1, const float* __restrict__ b1,
     const uint16_t* __restrict__ W2, const float* __restrict__ b2, const float* __restrict__ gamma,
@@ -153,8 +159,8 @@ __global__ __launch_bounds__(512, 2) void ffn_fused_bf16_kernel(
         ffn_f32x4_t he[2] = {ffn_f32x4_t{0.f, 0.f, 0.f, 0.f}, ffn_f32x4_t{0.f, 0.f, 0.f, 0.f}};    \
         ffn_f32x4_t ho[2] = {ffn_f32x4_t{0.f, 0.f, 0.f, 0.f}, ffn_f32x4_t{0.f, 0.f, 0.f, 0.f}};    \
         _Pragma("unroll") for (int ks = 0; ks < 8; ks += 2) {                                      \
-            he[0] = ffn_mma(wa[ks], xf[ks][0], he[0]);         he[1] = ffn_mma(wa[ks], xf[ks][1], he[1]); \
-            ho[0] = ffn_mma(wa[ks + 1], xf[ks + 1][0], ho[0]); ho[1] = ffn_mma(wa[ks + 1], xf[ks + 1][1], ho[1]); \
+            he[0] = ffn_mma<DBG>(wa[ks], xf[ks][0], he[0]);         he[1] = ffn_mma<DBG>(wa[ks], xf[ks][1], he[1]); \
+            ho[0] = ffn_mma<DBG>(wa[ks + 1], xf[ks + 1][0], ho[0]); ho[1] = ffn_mma<DBG>(wa[ks + 1], xf[ks + 1][1], ho[1]); \
         }                                                                                          \
         /* lane (n, g) holds hidden units 32 C + 8 g + 4 half + r (r = 0..3) of token n: bytes [8 half, 8 half + 8) of */ \
         /* the lane's 16-byte B-fragment slot */                                                    \
@@ -172,18 +178,18 @@ __global__ __launch_bounds__(512, 2) void ffn_fused_bf16_kernel(
     {                                                                                              \
         /* the one barrier of the chunk: publishes H(C) to the partner wave; my pieces of chunk C+1 (read by phase */ \
         /* A(C+1)) have landed -- chunk C+2's four may stay in flight; my H writes are done */     \
-        if ((C) + 2 < nchunk) asm volatile("s_waitcnt vmcnt(4) lgkmcnt(0)" ::: "memory");         \
+        if (!(DBG & 1) && (C) + 2 < nchunk) asm volatile("s_waitcnt vmcnt(4) lgkmcnt(0)" ::: "memory"); \
         else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");                           \
-        __builtin_amdgcn_s_barrier();                                                              \
-        if ((C) + 3 < nchunk) FFN_ISSUE((C) + 3)   /* into the stage of chunk C-1: all its readers passed the barrier */ \
+        if (!(DBG & 4)) __builtin_amdgcn_s_barrier();                                              \
+        if (!(DBG & 1) && (C) + 3 < nchunk) FFN_ISSUE((C) + 3)   /* into the stage of chunk C-1: all its readers passed the barrier */ \
         const uint4 hb0 = *reinterpret_cast<const uint4*>(hbuf + ((C) & 1) * 2048 + lane * 16);    \
         const uint4 hb1 = *reinterpret_cast<const uint4*>(hbuf + ((C) & 1) * 2048 + 1024 + lane * 16); \
         const unsigned char* w2f = smem + ((C) & (FFN_NS - 1)) * FFN_STAGE + 16384 + half * 8192 + lane * 16; \
         uint4 wb[8];                                                                               \
         _Pragma("unroll") for (int i = 0; i < 8; ++i) wb[i] = *reinterpret_cast<const uint4*>(w2f + i * 1024); \
         _Pragma("unroll") for (int i = 0; i < 8; ++i) {                                            \
-            yacc[i][0] = ffn_mma(wb[i], hb0, yacc[i][0]);                                          \
-            yacc[i][1] = ffn_mma(wb[i], hb1, yacc[i][1]);                                          \
+            yacc[i][0] = ffn_mma<DBG>(wb[i], hb0, yacc[i][0]);                                          \
+            yacc[i][1] = ffn_mma<DBG>(wb[i], hb1, yacc[i][1]);                                          \
         }                                                                                          \
         if (WITH_A) FFN_PHASE_A((C) + 1)                                                           \
     }
@@ -275,10 +281,25 @@ extern "C" int dtlr_ffn_fused_bf16(const void* X, const void* W1, const float* b
     if (!X || !W1 || !b1 || !W2 || !b2 || !gamma || !beta || !Y) return DTLR_EINVAL;
     if (M <= 0 || d_ff <= 0) return DTLR_EINVAL;
     if (d_model != 256 || (d_ff & 31) || d_ff > FFN_MAX_DFF) return DTLR_ESHAPE;
-    static bool attr = false;
-    if (!attr) { (void)hipFuncSetAttribute((const void*)ffn_fused_bf16_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, FFN_LDS); (void)hipGetLastError(); attr = true; }
+    static int dbg = -1;
+    if (dbg < 0) { const char* e = getenv("DTLR_FFN_DBG"); dbg = e ? atoi(e) : 0; }
     const unsigned grid = (unsigned)((M + 127) / 128);
-    hipLaunchKernelGGL(ffn_fused_bf16_kernel, dim3(grid), dim3(512), FFN_LDS, (hipStream_t)stream,
-                       (const uint16_t*)X, (const uint16_t*)W1, b1, (const uint16_t*)W2, b2, gamma, beta, eps, (uint16_t*)Y, M, d_ff);
+#define FFN_LAUNCH(D)                                                                              \
+    {                                                                                              \
+        static bool attr = false;                                                                  \
+        if (!attr) { (void)hipFuncSetAttribute((const void*)ffn_fused_bf16_kernel<D>, hipFuncAttributeMaxDynamicSharedMemorySize, FFN_LDS); (void)hipGetLastError(); attr = true; } \
+        hipLaunchKernelGGL(ffn_fused_bf16_kernel<D>, dim3(grid), dim3(512), FFN_LDS, (hipStream_t)stream, \
+                           (const uint16_t*)X, (const uint16_t*)W1, b1, (const uint16_t*)W2, b2, gamma, beta, eps, (uint16_t*)Y, M, d_ff); \
+    }
+    switch (dbg) {
+    case 1: FFN_LAUNCH(1) break;
+    case 2: FFN_LAUNCH(2) break;
+    case 3: FFN_LAUNCH(3) break;
+    case 4: FFN_LAUNCH(4) break;
+    case 6: FFN_LAUNCH(6) break;
+    case 7: FFN_LAUNCH(7) break;
+    default: FFN_LAUNCH(0) break;
+    }
+#undef FFN_LAUNCH
     return check_launch();
 }

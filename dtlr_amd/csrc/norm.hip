@@ -174,8 +174,8 @@ __global__ __launch_bounds__(256) void gn_apply_kernel(const T* __restrict__ x, 
 // 3x3 stride-2 pad-1 max pooling on NHWC (torchvision resnet50.maxpool as run by backbone.py:97-106);
 // a thread owns VEC channels of one output pixel; padding behaves as -inf.
 template <typename T, int VEC>
-__global__ __launch_bounds__(256) void maxpool3x3s2_kernel(const T* __restrict__ x, T* __restrict__ y,
-                                                           int H, int W, int C, int Ho, int Wo, long total)
+__global__ __launch_bounds__(256) void maxpool3x3s2_kernel(const T* __restrict__ x, T* __restrict__ y, const float* __restrict__ bias,
+                                                           int relu, int H, int W, int C, int Ho, int Wo, long total)
 {
     const long tid = (long)blockIdx.x * blockDim.x + threadIdx.x;
     if (tid >= total) return;
@@ -203,6 +203,17 @@ __global__ __launch_bounds__(256) void maxpool3x3s2_kernel(const T* __restrict__
 #pragma unroll
             for (int i = 0; i < VEC; ++i) m[i] = fmaxf(m[i], v[i]);
         }
+    }
+    // optional per-channel bias + ReLU applied AFTER the max: max_i(x_i + b) == max_i(x_i) + b exactly (rounding is
+    // monotone) and ReLU commutes with max, so conv -> +bias -> ReLU -> maxpool (backbone.py:97-106 with the folded
+    // FrozenBN shift as bias) costs one pass over the full-resolution map instead of three
+    if (bias) {
+#pragma unroll
+        for (int i = 0; i < VEC; ++i) m[i] += bias[c0 + i];
+    }
+    if (relu) {
+#pragma unroll
+        for (int i = 0; i < VEC; ++i) m[i] = fmaxf(m[i], 0.f);
     }
     T* dst = y + ((b * Ho + ho) * Wo + wo) * C + c0;
     IO<T>::store4(dst, *reinterpret_cast<float (*)[4]>(m));
@@ -240,7 +251,7 @@ extern "C" int dtlr_groupnorm_tokens(const void* x, const float* gamma, const fl
     return check_launch();
 }
 
-extern "C" int dtlr_maxpool3x3s2_nhwc(const void* x, void* y, int B, int H, int W, int C, int dtype, void* stream)
+extern "C" int dtlr_maxpool3x3s2_nhwc(const void* x, void* y, const float* bias, int relu, int B, int H, int W, int C, int dtype, void* stream)
 {
     clear_stale_error();
     if (!x || !y) return DTLR_EINVAL;
@@ -250,11 +261,11 @@ extern "C" int dtlr_maxpool3x3s2_nhwc(const void* x, void* y, int B, int H, int 
     if (dtype == DTLR_BF16 && C % 8 == 0) {
         const long total = (long)B * Ho * Wo * (C / 8);
         hipLaunchKernelGGL((maxpool3x3s2_kernel<uint16_t, 8>), dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st,
-                           (const uint16_t*)x, (uint16_t*)y, H, W, C, Ho, Wo, total);
+                           (const uint16_t*)x, (uint16_t*)y, bias, relu, H, W, C, Ho, Wo, total);
     } else if (dtype == DTLR_F32 && C % 4 == 0) {
         const long total = (long)B * Ho * Wo * (C / 4);
         hipLaunchKernelGGL((maxpool3x3s2_kernel<float, 4>), dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st,
-                           (const float*)x, (float*)y, H, W, C, Ho, Wo, total);
+                           (const float*)x, (float*)y, bias, relu, H, W, C, Ho, Wo, total);
     } else return (dtype == DTLR_BF16 || dtype == DTLR_F32) ? DTLR_ESHAPE : DTLR_EDTYPE;
     return check_launch();
 }

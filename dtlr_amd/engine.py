@@ -142,8 +142,8 @@ class DTLREngine:
         """NHWC convolution with the folded FrozenBN bias, optional residual add, then ReLU."""
         w = self.w[name + ".w"]
         if w.dim() == 2:                              # 1x1: the MFMA GEMM with the whole tail fused
-            if stride != 1:
-                x = x[:, ::stride, ::stride, :].contiguous()
+            if stride != 1:                           # strided 1x1 (downsample): the implicit-GEMM kernel gathers the pixels itself
+                return ops.conv2d_nhwc(x, w.view(w.shape[0], 1, 1, w.shape[1]), self.w[name + ".b"], stride, 0, relu, residual)
             return ops.linear(x, w, self.w[name + ".b"], relu=(2 if relu else 0), residual=residual)
         return ops.conv2d_nhwc(x, w, self.w[name + ".b"], stride, padding, relu, residual)
 
@@ -167,8 +167,10 @@ class DTLREngine:
     def backbone(self, x_nhwc) -> List[torch.Tensor]:
         """torchvision resnet50 (v1.5) body with FrozenBN folded; returns layer2/3/4 maps, NHWC
         (models/dino/backbone.py:97-106,118-120)."""
-        x = self._conv("conv1", x_nhwc, 2, 3, relu=True)
-        x = ops.maxpool_nhwc(x)
+        # stem: the 3-channel 7x7 convolution is the one library-backed GEMM-class op (MIOpen); its folded-BN shift,
+        # the ReLU and the max-pool run as ONE pass of our kernel over the full-resolution map
+        x = ops.conv2d_nhwc(x_nhwc, self.w["conv1.w"], None, 2, 3, relu=False)
+        x = ops.maxpool_nhwc(x, bias=self.w["conv1.b"], relu=True)
         outs = []
         for li, nblocks in enumerate(self.cfg.backbone_blocks, start=1):
             for bi in range(nblocks):
@@ -295,7 +297,8 @@ class DTLREngine:
         The box MLP runs only on the selected rows (selection uses class scores only)."""
         cfg = self.cfg
         om = memory * g["keep"].to(memory.dtype)
-        om = self._ln("enc_output_norm", self._lin("enc_output", om)).float()
+        # selection scores are computed in fp32: the projection writes fp32 straight from its accumulators
+        om = self._ln("enc_output_norm", self._lin("enc_output", om, out_dtype=torch.float32))
         scores = ops.linear(om, self.w["enc_class.w"], self.w["enc_class.b"]).max(-1)[0]
         idx = ops.topk_rows(scores, cfg.num_queries) if forced_topk is None else forced_topk
         sel = torch.gather(om, 1, idx.unsqueeze(-1).expand(-1, -1, cfg.hidden_dim))

@@ -144,13 +144,14 @@ def conv2d_nhwc(x, w, bias, stride: int, padding: int, relu=False, residual=None
     return y.contiguous()
 
 
-def maxpool_nhwc(x, k: int = 3, stride: int = 2, padding: int = 1):
-    """3x3/s2/p1 max pooling on NHWC (HIP kernel)."""
+def maxpool_nhwc(x, k: int = 3, stride: int = 2, padding: int = 1, bias=None, relu: bool = False):
+    """3x3/s2/p1 max pooling on NHWC (HIP kernel); with bias/relu: maxpool(relu(x + bias)) in the same pass."""
     assert (k, stride, padding) == (3, 2, 1)
     B, H, W, C = x.shape
     x = x if x.is_contiguous() else x.contiguous()
     y = torch.empty((B, (H - 1) // 2 + 1, (W - 1) // 2 + 1, C), dtype=x.dtype, device=x.device)
-    code = _lib.lib().dtlr_maxpool3x3s2_nhwc(x.data_ptr(), y.data_ptr(), B, H, W, C, _DT[x.dtype], _lib.current_stream())
+    code = _lib.lib().dtlr_maxpool3x3s2_nhwc(x.data_ptr(), y.data_ptr(), 0 if bias is None else bias.data_ptr(), 1 if relu else 0,
+                                             B, H, W, C, _DT[x.dtype], _lib.current_stream())
     _lib.check(code, "dtlr_maxpool3x3s2_nhwc")
     return y
 

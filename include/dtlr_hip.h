@@ -182,9 +182,11 @@ int dtlr_groupnorm_tokens(const void *x, const float *gamma, const float *beta, 
                           int B, int T_tokens, int C, int groups, float eps, int dtype, void *stream);
 long dtlr_groupnorm_workspace_bytes(int B, int T_tokens);
 
-/* 3x3 / stride 2 / pad 1 max pooling on NHWC.
- * Replaces: torchvision resnet50 `maxpool` as run through IntermediateLayerGetter (backbone.py:94,98). */
-int dtlr_maxpool3x3s2_nhwc(const void *x, void *y, int B, int H, int W, int C, int dtype, void *stream);
+/* 3x3 / stride 2 / pad 1 max pooling on NHWC, optionally preceded by a per-channel bias and ReLU:
+ *     y = maxpool(relu(x + bias))      (bias NULL: no bias; relu 0: no ReLU)
+ * Replaces: torchvision resnet50 `maxpool` as run through IntermediateLayerGetter (backbone.py:94,98), and with
+ *           bias/relu also the stem's FrozenBN shift (backbone.py:62-72, folded) + `relu` between conv1 and maxpool. */
+int dtlr_maxpool3x3s2_nhwc(const void *x, void *y, const float *bias, int relu, int B, int H, int W, int C, int dtype, void *stream);
 
 /* ---------------------------------------------------------------------------------------------
  * Indices of the k largest scores of every row, in descending score order; equal scores keep the lower

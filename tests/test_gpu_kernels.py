@@ -283,6 +283,12 @@ def test_maxpool_nhwc(B, H, W, C):
     xb = x.bfloat16()
     wantb = F.max_pool2d(xb.float().permute(0, 3, 1, 2), 3, 2, 1).permute(0, 2, 3, 1)
     assert torch.equal(ops.maxpool_nhwc(xb.cuda()).float().cpu(), wantb)
+    # fused stem tail: maxpool(relu(x + bias)) -- bit-exact in fp32 (max and +bias commute under monotone rounding)
+    b = _rand((C,), 6)
+    wantf = F.max_pool2d(torch.relu(x + b).permute(0, 3, 1, 2), 3, 2, 1).permute(0, 2, 3, 1)
+    assert torch.equal(ops.maxpool_nhwc(x.cuda(), bias=b.cuda(), relu=True).cpu(), wantf)
+    wantfb = F.max_pool2d(torch.relu(xb.float() + b).permute(0, 3, 1, 2), 3, 2, 1).permute(0, 2, 3, 1).bfloat16().float()
+    assert torch.equal(ops.maxpool_nhwc(xb.cuda(), bias=b.cuda(), relu=True).float().cpu(), wantfb)
 
 
 @pytest.mark.parametrize("B,S,k", [(2, 5440, 900), (3, 172, 30), (1, 7, 7), (2, 6800, 900)])
