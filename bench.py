@@ -11,9 +11,13 @@ decoder producing per-line label records (+ ONE RCCL all-gather of those records
 Workload = BASELINE.json configs[1]: Latin model (C=166), bf16, bs=32, 128x2048, random-init
 name-seeded weights (no checkpoint ships with the reference).  Rank 0 prints ONE JSON line.
 
-roofline     : the deformable-sampling kernel (encoder call: Lq = S = 5440 per line), timed live
-               with HIP events on the launch stream during the timed steps; achieved = algorithmic
-               bytes per launch / mean launch duration (DESIGN.md section "MSDA bytes").
+roofline     : the kernel class with the largest share of the timed region, measured live with HIP
+               events recorded on the launch stream around every launch of the timed steps:
+               MFMA-bound classes (GEMM / implicit-GEMM conv, fused FFN): achieved = algorithmic flops per
+               launch (2 M N K; 4 M d d_ff) / mean launch duration vs the dense bf16 MFMA peak;
+               HBM-bound (deformable sampling, encoder call Lq = S = 5440 per line): algorithmic bytes
+               per launch (SURVEY.md 8d / DESIGN.md) / mean launch duration vs the HBM peak, with the
+               PMC-measured traffic.  `roofline_by_kernel` lists every class.
 cpu_baseline : the CPU oracle (oracle/dtlr_oracle.py, a port pinned to the reference through
                tests/golden) timed on the host cores of this box on a bounded sample (rank 0, N=1).
 """
@@ -39,6 +43,8 @@ def log(msg: str) -> None:
 
 
 HBM_PEAK_GBS = 8000.0      # MI355X_MICROARCH.md: 8.0 TB/s spec (6.29 TB/s measured copy)
+MFMA_PEAK_BF16_TFLOPS = 2500.0   # dense bf16 MFMA peak (no sparsity); fp32 MFMA (16x16x4_f32) class: 157
+MFMA_PEAK_F32_TFLOPS = 157.0
 
 
 def msda_algorithmic_bytes_per_line(S: int, Lq: int, value_elem: int, M=8, D=32, L=4, P=4) -> int:
@@ -150,6 +156,17 @@ def main():
     ddist.barrier()
     elapsed = ddist.max_over_ranks(time.perf_counter() - t0, dev)
     events, ops.MSDA_EVENTS = ops.MSDA_EVENTS, None
+    # MFMA-class launches are timed in a REPLAY of the same steps right after the timed region (same inputs, same stream):
+    # ~170 event pairs per step inside it would cost ~2.5 ms of stream time per step and distort `value`.  Only launches of
+    # >= 2 GFLOP are timed (ops.MFMA_EVENTS_MIN_FLOPS), so the event overhead stays below 2% of each measured launch.
+    mfma_events = []
+    if rank == 0:
+        ops.MFMA_EVENTS = mfma_events
+        for _ in range(min(args.steps, 5)):
+            step()
+        torch.cuda.synchronize()
+        ops.MFMA_EVENTS = None
+    replay_steps = min(args.steps, 5)
     log(f"timed {args.steps} steps in {elapsed:.3f}s")
 
     if rank != 0:
@@ -179,6 +196,28 @@ def main():
             n, lq, s = dec[0][1], dec[0][2], dec[0][3]
             algd = msda_algorithmic_bytes_per_line(s, lq, velem) * n
             roof["decoder_call"] = {"achieved": round(algd / (msd * 1e-3) / 1e9, 1), "mean_launch_ms": round(msd, 4)}
+    # ---- per-class rooflines; `roofline` = the class with the largest share of the timed region ----
+    by_kernel = []
+    if roof:
+        r = dict(roof)
+        r["ms_per_step"] = round(sum(e[0] for e in enc) / args.steps, 3)
+        by_kernel.append(r)
+    classes = {}
+    for (a, b, kind, flops) in mfma_events:
+        c = classes.setdefault(kind, [0.0, 0.0, 0])
+        c[0] += a.elapsed_time(b); c[1] += flops; c[2] += 1
+    names = {"gemm_bf16": "gemm_ws_kernel<bf16> (every Linear / 1x1 conv / implicit-GEMM 3x3 conv, fused epilogues)",
+             "gemm_f32": "gemm_ws_kernel<f32> (fp32 heads and selection scores, exact-fp32 MFMA 16x16x4)",
+             "ffn_fused_bf16": "ffn_fused_bf16_kernel (linear1+ReLU+linear2+residual+LayerNorm, intermediate on chip)"}
+    for kind, (ms, flops, cnt) in classes.items():
+        peak = MFMA_PEAK_F32_TFLOPS if kind == "gemm_f32" else MFMA_PEAK_BF16_TFLOPS
+        ach = flops / (ms * 1e-3) / 1e12
+        by_kernel.append({"bound": "mfma", "kernel": names.get(kind, kind), "achieved": round(ach, 1), "peak": peak, "unit": "TFLOP/s",
+                          "frac": round(ach / peak, 4), "traffic": None, "algorithmic_flops_per_launch": round(flops / cnt),
+                          "mean_launch_ms": round(ms / cnt, 4), "launches_timed": cnt, "ms_per_step": round(ms / replay_steps, 3),
+                          "timed_in": "replay of the timed steps, launches >= 2 GFLOP only"})
+    by_kernel.sort(key=lambda r: -r["ms_per_step"])
+    dominant = by_kernel[0] if by_kernel else None
     line = {
         "metric": "text-lines/sec (128x2048, bs=32)", "value": round(n_total * args.steps / elapsed, 2), "unit": "lines/s",
         "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -188,7 +227,8 @@ def main():
                                f"{B} synthetic {args.height}x{args.width} lines per GPU, random-init name-seeded weights",
                    "global_batch": n_total, "parallelism": f"dp{world}",
                    "library_backed_ops": sorted(ops.LIBRARY_BACKED)},
-        "roofline": roof,
+        "roofline": dominant,
+        "roofline_by_kernel": by_kernel,
     }
     if world == 1 and not args.no_cpu_baseline:
         line["cpu_baseline"] = cpu_baseline(args.cpu_lines, args.height, args.width, repeats=2, threads=args.cpu_threads)

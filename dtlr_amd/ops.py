@@ -30,6 +30,35 @@ def require_cuda(t: torch.Tensor, what: str = "input") -> None:
 
 
 # --------------------------------------------------------------------------------------------
+# bench.py sets this to a list to time every MFMA-class launch (GEMM / implicit-GEMM conv / fused FFN) with HIP events on
+# the launch stream: entries are (start_event, end_event, kind, flops).
+MFMA_EVENTS = None
+MFMA_EVENTS_MIN_FLOPS = 2.0e9     # only launches this large are timed: an event pair costs a few microseconds of stream time
+
+
+class _Timed:
+    """with _Timed(kind, flops): <launch>  -- records a HIP event pair around the launch when MFMA_EVENTS is a list."""
+    __slots__ = ("kind", "flops", "a", "st")
+
+    def __init__(self, kind, flops):
+        self.kind, self.flops = kind, flops
+
+    def __enter__(self):
+        self.a = None
+        if MFMA_EVENTS is not None and self.flops >= MFMA_EVENTS_MIN_FLOPS:
+            self.st = torch.cuda.current_stream()
+            self.a = torch.cuda.Event(enable_timing=True)
+            self.a.record(self.st)
+        return self
+
+    def __exit__(self, *exc):
+        if self.a is not None:
+            b = torch.cuda.Event(enable_timing=True)
+            b.record(self.st)
+            MFMA_EVENTS.append((self.a, b, self.kind, self.flops))
+        return False
+
+
 def linear(x, w, b=None, relu=False, residual=None, a2=None, row_mask=None, out_dtype=None):
     """y = epilogue((x [+ a2]) @ w.T): + b -> ReLU (relu=True/1) -> zero rows where row_mask -> + residual
     -> ReLU (relu=2, the ResNet bottleneck tail).
@@ -52,10 +81,11 @@ def linear(x, w, b=None, relu=False, residual=None, a2=None, row_mask=None, out_
             b = b.float()
         M = x.numel() // K
         y = torch.empty(x.shape[:-1] + (N,), dtype=out_dtype, device=x.device)
-        code = _lib.lib().dtlr_gemm_nt(x.data_ptr(), 0 if a2 is None else a2.data_ptr(), w.data_ptr(),
-                                       0 if b is None else b.data_ptr(), 0 if residual is None else residual.data_ptr(),
-                                       0 if row_mask is None else row_mask.data_ptr(), y.data_ptr(),
-                                       M, N, K, int(relu), _DT[x.dtype], _DT[out_dtype], _lib.current_stream())
+        with _Timed("gemm_bf16" if x.dtype == torch.bfloat16 else "gemm_f32", 2.0 * M * N * K):
+            code = _lib.lib().dtlr_gemm_nt(x.data_ptr(), 0 if a2 is None else a2.data_ptr(), w.data_ptr(),
+                                           0 if b is None else b.data_ptr(), 0 if residual is None else residual.data_ptr(),
+                                           0 if row_mask is None else row_mask.data_ptr(), y.data_ptr(),
+                                           M, N, K, int(relu), _DT[x.dtype], _DT[out_dtype], _lib.current_stream())
         _lib.check(code, "dtlr_gemm_nt")
         return y
     if a2 is not None:
@@ -109,9 +139,10 @@ def ffn_fused(x, w1, b1, w2p, b2, ln_w, ln_b, eps: float = 1e-5):
     x = x if x.is_contiguous() else x.contiguous()
     y = torch.empty_like(x)
     M = x.numel() // x.shape[-1]
-    code = _lib.lib().dtlr_ffn_fused_bf16(x.data_ptr(), w1.data_ptr(), b1.data_ptr(), w2p.data_ptr(), b2.data_ptr(),
-                                          ln_w.data_ptr(), ln_b.data_ptr(), eps, y.data_ptr(), M, x.shape[-1], w1.shape[0],
-                                          _lib.current_stream())
+    with _Timed("ffn_fused_bf16", 4.0 * M * x.shape[-1] * w1.shape[0]):
+        code = _lib.lib().dtlr_ffn_fused_bf16(x.data_ptr(), w1.data_ptr(), b1.data_ptr(), w2p.data_ptr(), b2.data_ptr(),
+                                              ln_w.data_ptr(), ln_b.data_ptr(), eps, y.data_ptr(), M, x.shape[-1], w1.shape[0],
+                                              _lib.current_stream())
     _lib.check(code, "dtlr_ffn_fused_bf16")
     return y
 
@@ -129,10 +160,11 @@ def conv2d_nhwc(x, w, bias, stride: int, padding: int, relu=False, residual=None
         y = torch.empty((B, Ho, Wo, Cout), dtype=x.dtype, device=x.device)
         if residual is not None:
             residual = residual if residual.is_contiguous() else residual.contiguous()
-        code = _lib.lib().dtlr_conv2d_nhwc(x.data_ptr(), w.data_ptr(), 0 if bias is None else bias.data_ptr(),
-                                           0 if residual is None else residual.data_ptr(), y.data_ptr(),
-                                           B, H, W, Cin, Cout, KH, KW, stride, padding, 2 if relu else 0,
-                                           _DT[x.dtype], _lib.current_stream())
+        with _Timed("gemm_bf16" if x.dtype == torch.bfloat16 else "gemm_f32", 2.0 * B * Ho * Wo * Cout * KH * KW * Cin):
+            code = _lib.lib().dtlr_conv2d_nhwc(x.data_ptr(), w.data_ptr(), 0 if bias is None else bias.data_ptr(),
+                                               0 if residual is None else residual.data_ptr(), y.data_ptr(),
+                                               B, H, W, Cin, Cout, KH, KW, stride, padding, 2 if relu else 0,
+                                               _DT[x.dtype], _lib.current_stream())
         _lib.check(code, "dtlr_conv2d_nhwc")
         return y
     y = F.conv2d(x.permute(0, 3, 1, 2), w, None if bias is None else bias.to(x.dtype), stride=stride, padding=padding)
