@@ -268,7 +268,13 @@ __device__ __attribute__((aligned(16))) unsigned int g_zero_line[4] = {0u, 0u, 0
 #define CHAIN_SETUP()                                                                              \
     const int nM_ = ntiles;                                                                        \
     const int nwg_ = (int)gridDim.x, q8_ = nwg_ >> 3, r8_ = nwg_ & 7, xcd_ = (int)blockIdx.x & 7; \
-    const int logical_ = (xcd_ < r8_ ? xcd_ * (q8_ + 1) : r8_ * (q8_ + 1) + (xcd_ - r8_) * q8_) + ((int)blockIdx.x >> 3); \
+    const int logical0_ = (xcd_ < r8_ ? xcd_ * (q8_ + 1) : r8_ * (q8_ + 1) + (xcd_ - r8_) * q8_) + ((int)blockIdx.x >> 3); \
+    /* split-K (KSPLIT > 1, small grids only): the grid is KSPLIT copies of the tile grid; copy s multiplies K slabs */ \
+    /* [s nk, (s+1) nk) and writes its fp32 partial tile to slice s of the workspace C points to */ \
+    const int per_split_ = nwg_ / KSPLIT;                                                          \
+    const int split_ = logical0_ / per_split_, logical_ = logical0_ % per_split_;                  \
+    const int koff = split_ * nk;                                                                  \
+    (void)koff;                                                                                    \
     const int tn = logical_ % nN;                                                                  \
     const int t_begin = (logical_ / nN) * tiles_per_block;                                         \
     const int t_end = min(t_begin + tiles_per_block, nM_);                                         \
@@ -287,6 +293,7 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(
     const int wm = wave >> 1, wn = wave & 1;
     constexpr int BK = GT<T>::BK;
     const int nk = K / BK;
+    constexpr int KSPLIT = 1;
 
     // PERSISTENT tile chain: this block owns tiles [t_begin, t_end) of the (tm, tn) grid, tn fastest, and
     // walks them as ONE flat stream of K slabs, software-pipelined across tile boundaries: the global
@@ -473,13 +480,14 @@ template <typename T, typename OutT, bool HAS_A2, bool CONV>
 __global__ __launch_bounds__(512, HAS_A2 ? 2 : 4) void gemm_ws_kernel(
     const T* __restrict__ A, const T* __restrict__ A2, const T* __restrict__ W,
     const float* __restrict__ bias, const OutT* __restrict__ residual, const uint8_t* __restrict__ row_mask,
-    OutT* __restrict__ C, int M, int N, int K, int flags, int nN, int ntiles, int tiles_per_block, ConvP cp)
+    OutT* __restrict__ C, int M, int N, int K, int flags, int nN, int ntiles, int tiles_per_block, ConvP cp, int KSPLIT)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];   // [2 stages][W tile | X tile]
     const int wave = threadIdx.x >> 6;
     constexpr int BK = GT<T>::BK;
-    const int nk = K / BK;
+    const int nk = K / BK / KSPLIT;                                // slabs this workgroup multiplies per tile
     CHAIN_SETUP()
+    C += (long)split_ * M * N;
 
     if (wave >= 4) {
         // ================================ loader role ================================
@@ -534,10 +542,10 @@ __global__ __launch_bounds__(512, HAS_A2 ? 2 : 4) void gemm_ws_kernel(
         }
 #define WS_GLOAD(S, KT)                                                                            \
         {                                                                                          \
-            const long off_ = (long)(KT) * SLAB;                                                   \
-            const int tap_ = (KT) / slabs_per_tap;                                                 \
+            const long off_ = (long)((KT) + koff) * SLAB;                                          \
+            const int tap_ = ((KT) + koff) / slabs_per_tap;                                        \
             const int kh_ = CONV ? tap_ / cp.KW : 0, kw_ = CONV ? tap_ % cp.KW : 0;                \
-            const long coff_ = (long)((KT) % slabs_per_tap) * SLAB;                                \
+            const long coff_ = (long)(((KT) + koff) % slabs_per_tap) * SLAB;                       \
             (void)kh_; (void)kw_; (void)coff_;                                                     \
             WS_GLOAD1(S, 0, off_) WS_GLOAD1(S, 1, off_) WS_GLOAD1(S, 2, off_) WS_GLOAD1(S, 3, off_) \
         }
@@ -681,6 +689,86 @@ static inline int plan_chain(long ntiles) {
     return (int)per;
 }
 
+// ---- split-K for grids that cannot fill the chip (input_proj[3]: 3x3 stride-2 conv 2048 -> 256 on a 2 x 32 map is 32
+// tiles of K = 18432: 0.23 ms on 32 of 256 CUs).  KSPLIT copies of the tile grid each multiply a K range into an fp32
+// partial tile (slice s of a workspace); a second small kernel sums the slices and applies the epilogue.  Deterministic
+// (no atomics): the slices are added in index order.
+static float* g_splitk_ws = nullptr;
+static size_t g_splitk_bytes = 0;
+static float* splitk_workspace(size_t bytes) {
+    if (bytes > g_splitk_bytes) {
+        if (g_splitk_ws) (void)hipFree(g_splitk_ws);
+        g_splitk_ws = nullptr; g_splitk_bytes = 0;
+        if (hipMalloc((void**)&g_splitk_ws, bytes) != hipSuccess) { (void)hipGetLastError(); return nullptr; }
+        g_splitk_bytes = bytes;
+    }
+    return g_splitk_ws;
+}
+static inline int plan_split(long nwg, int nk) {
+    if (nwg >= 96 || nk < 16) return 1;
+    int best = 1;
+    for (int s = 2; s <= 16; ++s)
+        if (nk % s == 0 && nk / s >= 8 && nwg * s <= 288) best = s;
+    return best;
+}
+
+template <typename OutT>
+__global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* __restrict__ ws, int S, const float* __restrict__ bias,
+                                                            const OutT* __restrict__ residual, const uint8_t* __restrict__ row_mask,
+                                                            OutT* __restrict__ C, int M, int N, int flags)
+{
+    const long i4 = ((long)blockIdx.x * 256 + threadIdx.x) * 4;
+    const long MN = (long)M * N;
+    if (i4 >= MN) return;                                       // N % 4 == 0 (checked by the launcher)
+    const int ch = (int)(i4 % N);
+    const long tok = i4 / N;
+    float v[4] = {0.f, 0.f, 0.f, 0.f};
+    for (int s = 0; s < S; ++s) {
+        const float4 t = *reinterpret_cast<const float4*>(ws + (long)s * MN + i4);
+        v[0] += t.x; v[1] += t.y; v[2] += t.z; v[3] += t.w;
+    }
+    if (flags & EPI_BIAS) { const float4 b = *reinterpret_cast<const float4*>(bias + ch); v[0] += b.x; v[1] += b.y; v[2] += b.z; v[3] += b.w; }
+    if (flags & EPI_RELU) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) v[r] = fmaxf(v[r], 0.f);
+    }
+    if ((flags & EPI_ROWMASK) && row_mask[tok]) { v[0] = v[1] = v[2] = v[3] = 0.f; }
+    if (flags & EPI_RESIDUAL) { float q[4]; Out<OutT>::ld4(residual + i4, q); v[0] += q[0]; v[1] += q[1]; v[2] += q[2]; v[3] += q[3]; }
+    if (flags & EPI_RELU_POST) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) v[r] = fmaxf(v[r], 0.f);
+    }
+    Out<OutT>::st4(C + i4, v);
+}
+
+// returns DTLR_OK after launching both kernels, or a negative code; `done` false = not applicable (caller runs the plain path)
+template <typename T, typename OutT, bool CONV>
+static int try_splitk(const void* A, const void* W, const float* bias, const void* residual, const uint8_t* row_mask, void* C,
+                      int M, int N, int K, int flags, const ConvP& cp, hipStream_t st, bool& done)
+{
+    done = false;
+    const int nN = (N + BN - 1) / BN, nM = (M + BM - 1) / BM;
+    const int nk = K / GT<T>::BK;
+    const int S = plan_split((long)nM * nN, nk);
+    if (S <= 1 || (N & 3)) return DTLR_OK;
+    float* ws = splitk_workspace((size_t)S * M * N * sizeof(float));
+    if (!ws) return DTLR_OK;                                     // no workspace: fall back to the plain path
+    const size_t lds = 4 * TILE_BYTES;
+    static bool attr = false;
+    if (!attr) { (void)hipFuncSetAttribute((const void*)gemm_ws_kernel<T, float, false, CONV>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); (void)hipGetLastError(); attr = true; }
+    const unsigned grid = (unsigned)(nN * nM * S);
+    hipLaunchKernelGGL((gemm_ws_kernel<T, float, false, CONV>), dim3(grid), dim3(512), lds, st,
+                       (const T*)A, (const T*)nullptr, (const T*)W, (const float*)nullptr, (const float*)nullptr, (const uint8_t*)nullptr, ws,
+                       M, N, K, 0, nN, nM, 1, cp, S);
+    int rc = check_launch();
+    if (rc != DTLR_OK) return rc;
+    const long n4 = ((long)M * N) / 4;
+    hipLaunchKernelGGL((splitk_reduce_kernel<OutT>), dim3((unsigned)((n4 + 255) / 256)), dim3(256), 0, st,
+                       (const float*)ws, S, bias, (const OutT*)residual, row_mask, (OutT*)C, M, N, flags);
+    done = true;
+    return check_launch();
+}
+
 template <typename T, typename OutT>
 static int launch_conv(const void* X, const void* W, const float* bias, const void* residual, void* C,
                        int M, int N, int K, int flags, const ConvP& cp, hipStream_t st)
@@ -692,13 +780,16 @@ static int launch_conv(const void* X, const void* W, const float* bias, const vo
     static bool attr = false;
     if (!attr) { (void)hipFuncSetAttribute((const void*)gemm_nt_kernel<T, OutT, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); attr = true; }
     if (use_ws()) {
+        bool done = false;
+        const int rc = try_splitk<T, OutT, true>(X, W, bias, residual, nullptr, C, M, N, K, flags, cp, st, done);
+        if (rc != DTLR_OK || done) return rc;
         static bool attr_ws = false;
         if (!attr_ws) { (void)hipFuncSetAttribute((const void*)gemm_ws_kernel<T, OutT, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); attr_ws = true; }
         const int per = plan_chain_ws(nwg);
         const unsigned grid = (unsigned)(nN * ((nM + per - 1) / per));
         hipLaunchKernelGGL((gemm_ws_kernel<T, OutT, false, true>), dim3(grid), dim3(512), lds, st,
                            (const T*)X, (const T*)nullptr, (const T*)W, bias, (const OutT*)residual, (const uint8_t*)nullptr, (OutT*)C,
-                           M, N, K, flags, nN, nM, per, cp);
+                           M, N, K, flags, nN, nM, per, cp, 1);
         return check_launch();
     }
     const int per = plan_chain(nwg);
@@ -719,18 +810,23 @@ static int launch_gemm(const void* A, const void* A2, const void* W, const float
     if (nwg > 0x7fffffffL) return DTLR_ESHAPE;
     const size_t lds = 4 * TILE_BYTES;
     if (use_ws()) {
+        if (!A2) {
+            bool done = false;
+            const int rc = try_splitk<T, OutT, false>(A, W, bias, residual, row_mask, C, M, N, K, flags, cp, st, done);
+            if (rc != DTLR_OK || done) return rc;
+        }
         const int perw = plan_chain_ws(nwg);
         const unsigned gridw = (unsigned)(nN * ((nM + perw - 1) / perw));
         if (A2) {
             static bool a1 = false;
             if (!a1) { (void)hipFuncSetAttribute((const void*)gemm_ws_kernel<T, OutT, true, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); a1 = true; }
             hipLaunchKernelGGL((gemm_ws_kernel<T, OutT, true, false>), dim3(gridw), dim3(512), lds, st,
-                               (const T*)A, (const T*)A2, (const T*)W, bias, (const OutT*)residual, row_mask, (OutT*)C, M, N, K, flags, nN, nM, perw, cp);
+                               (const T*)A, (const T*)A2, (const T*)W, bias, (const OutT*)residual, row_mask, (OutT*)C, M, N, K, flags, nN, nM, perw, cp, 1);
         } else {
             static bool a0 = false;
             if (!a0) { (void)hipFuncSetAttribute((const void*)gemm_ws_kernel<T, OutT, false, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); a0 = true; }
             hipLaunchKernelGGL((gemm_ws_kernel<T, OutT, false, false>), dim3(gridw), dim3(512), lds, st,
-                               (const T*)A, (const T*)nullptr, (const T*)W, bias, (const OutT*)residual, row_mask, (OutT*)C, M, N, K, flags, nN, nM, perw, cp);
+                               (const T*)A, (const T*)nullptr, (const T*)W, bias, (const OutT*)residual, row_mask, (OutT*)C, M, N, K, flags, nN, nM, perw, cp, 1);
         }
         return check_launch();
     }

@@ -131,6 +131,12 @@ class DTLREngine:
             self._put(f"enc_bbox{i}.b", sd[f"{t}enc_out_bbox_embed.layers.{i}.bias"], f32)
             self._put(f"bbox{i}.w", sd[f"bbox_embed.0.layers.{i}.weight"], f32)
             self._put(f"bbox{i}.b", sd[f"bbox_embed.0.layers.{i}.bias"], f32)
+            if i < 2 and self.dtype == torch.bfloat16:
+                # bf16 engine: the two hidden layers of the box MLPs run on the bf16 MFMA path (their input, the decoder
+                # state, is bf16 already); accumulation, the 256->4 output layer and all box arithmetic stay fp32.
+                # (As fp32-MFMA GEMMs these 16 launches of M = 28800 cost 43 us each: 0.7 ms of a 14.4 ms step.)
+                self._put(f"bbox{i}.wh", sd[f"bbox_embed.0.layers.{i}.weight"])
+                self._put(f"enc_bbox{i}.wh", sd[f"{t}enc_out_bbox_embed.layers.{i}.weight"])
         self._put("enc_class.w", sd[t + "enc_out_class_embed.weight"], f32)
         self._put("enc_class.b", sd[t + "enc_out_class_embed.bias"], f32)
         self._put("class.w", sd["class_embed.0.weight"], f32)
@@ -302,8 +308,7 @@ class DTLREngine:
         scores = ops.linear(om, self.w["enc_class.w"], self.w["enc_class.b"]).max(-1)[0]
         idx = ops.topk_rows(scores, cfg.num_queries) if forced_topk is None else forced_topk
         sel = torch.gather(om, 1, idx.unsqueeze(-1).expand(-1, -1, cfg.hidden_dim))
-        h = ops.linear(sel, self.w["enc_bbox0.w"], self.w["enc_bbox0.b"], relu=True)
-        h = ops.linear(h, self.w["enc_bbox1.w"], self.w["enc_bbox1.b"], relu=True)
+        h = self._box_mlp_hidden("enc_bbox", sel)
         prop_sel = torch.gather(g["proposals"], 1, idx.unsqueeze(-1).expand(-1, -1, 4))
         ref_unsig = ops.linear(h, self.w["enc_bbox2.w"], self.w["enc_bbox2.b"]) + prop_sel
         return dict(topk_idx=idx, topk_scores=scores, ref_unsig=ref_unsig, hs_enc=sel, init_box=prop_sel.sigmoid())
@@ -323,10 +328,17 @@ class DTLREngine:
         e = torch.stack((e[..., 0::2].sin(), e[..., 1::2].cos()), dim=4).flatten(3)
         return torch.cat((e[:, :, 1], e[:, :, 0], e[:, :, 2], e[:, :, 3]), dim=2)
 
+    def _box_mlp_hidden(self, name, x):
+        """First two layers (Linear+ReLU, Linear+ReLU) of a 3-layer box MLP (models/dino/dino.py MLP) -> fp32 [.., 256]."""
+        w = self.w
+        if name + "0.wh" in w:                         # bf16 engine: bf16 MFMA, fp32 accumulate, fp32 result
+            h = ops.linear(x.to(self.dtype), w[name + "0.wh"], w[name + "0.b"], relu=True)
+            return ops.linear(h, w[name + "1.wh"], w[name + "1.b"], relu=True, out_dtype=torch.float32)
+        h = ops.linear(x.float(), w[name + "0.w"], w[name + "0.b"], relu=True)
+        return ops.linear(h, w[name + "1.w"], w[name + "1.b"], relu=True)
+
     def _bbox_head(self, x):
-        h = ops.linear(x.float(), self.w["bbox0.w"], self.w["bbox0.b"], relu=True)
-        h = ops.linear(h, self.w["bbox1.w"], self.w["bbox1.b"], relu=True)
-        return ops.linear(h, self.w["bbox2.w"], self.w["bbox2.b"])
+        return ops.linear(self._box_mlp_hidden("bbox", x), self.w["bbox2.w"], self.w["bbox2.b"])
 
     def decoder(self, memory, ts, g, want_aux=False):
         """TransformerDecoder.forward + DeformableTransformerDecoderLayer

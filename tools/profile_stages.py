@@ -17,6 +17,7 @@ def main():
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--batch", type=int, default=32)
     ap.add_argument("--dtype", default="bf16")
+    ap.add_argument("--convs", action="store_true", help="also time every backbone convolution (name, shape, ms, GB/s, TFLOP/s)")
     args = ap.parse_args()
     from dtlr_amd import synth, weights
     from dtlr_amd.config import DTLRConfig
@@ -45,6 +46,23 @@ def main():
 
     for n in ("backbone", "encoder", "two_stage", "decoder"):
         wrap(eng, n)
+    conv_info = {}
+    if args.convs:
+        orig_conv = eng._conv
+
+        def timed_conv(name, x, stride, padding, relu=False, residual=None):
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            y = orig_conv(name, x, stride, padding, relu, residual)
+            e1.record()
+            w = eng.w[name + ".w"]
+            k = w.shape[1] * (w.shape[2] if w.dim() == 4 else 1) * (w.shape[3] if w.dim() == 4 else 1) if w.dim() == 4 else w.shape[1]
+            flops = 2.0 * y.numel() * k
+            byts = (x.numel() / (stride * stride if w.dim() == 2 else 1) + y.numel() * (2 if residual is not None else 1)) * x.element_size()
+            conv_info[name] = (tuple(x.shape), tuple(y.shape), flops, byts)
+            spans.setdefault("conv:" + name, []).append((e0, e1))
+            return y
+        eng._conv = timed_conv
 
     def step():
         e0, e1, e2 = (torch.cuda.Event(enable_timing=True) for _ in range(3))
@@ -63,7 +81,12 @@ def main():
     for _ in range(args.steps):
         step()
     torch.cuda.synchronize()
-    res = {k: round(sum(a.elapsed_time(b) for a, b in v) / args.steps, 3) for k, v in spans.items()}
+    res = {k: round(sum(a.elapsed_time(b) for a, b in v) / args.steps, 3) for k, v in spans.items() if not k.startswith("conv:")}
+    for k, v in spans.items():
+        if k.startswith("conv:"):
+            ms = sum(a.elapsed_time(b) for a, b in v) / args.steps
+            xin, yout, flops, byts = conv_info[k[5:]]
+            print(json.dumps({"conv": k[5:], "in": xin, "out": yout, "ms": round(ms, 4), "TFLOPs": round(flops / ms / 1e9, 1), "GBps_min": round(byts / ms / 1e6, 1)}))
     res["input_proj_heads_other"] = round(res["forward_total"] - sum(res[k] for k in ("backbone", "encoder", "two_stage", "decoder")), 3)
     print(json.dumps({"stage_ms": res, "dtype": args.dtype, "batch": args.batch}))
 
