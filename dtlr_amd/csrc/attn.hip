@@ -117,6 +117,134 @@ __global__ __launch_bounds__(256) void mha_fwd_bf16_kernel(const uint16_t* __res
     }
 }
 
+// ---- LDS-staged variant (the default when K and V^T of one (batch, head) fit the 160 KB LDS: L <= 1184) ----------
+// The kernel above re-reads K and V^T of its (b, h) from global memory in every wave: 29 query blocks x 115 KB = 3.3 MB
+// per (b, h), 855 MB per call at B = 32 -- it was L1/TA-bound at 112 us.  Here ONE workgroup (8 waves) owns a (b, h):
+// it stages K and V^T once, in MFMA-fragment order (a fragment = one linear 1 KB block, lane l at 16 l: conflict-free),
+// and its waves walk the query blocks (wave w takes blocks w, w+16) reading operands with ds_read_b128.
+//   K image : key tile t (16 keys)           at t * 1024       : lane (g, n) <- K[16 t + n][8 g .. 8 g + 7]
+//   V^T image: key block j (32 keys), d tile  at (2 j + dt) * 1024: lane (g, n) <- V^T[16 dt + n][32 j + 4 g .. +3 | 32 j + 16 + 4 g .. +3]
+// Same arithmetic, same operand values and order as mha_fwd_bf16_kernel: results are bit-identical.
+// reductions over the four lanes {n, n+16, n+32, n+48} of a query with the gfx950 row/half swaps (VALU, no LDS round trip):
+// permlane16_swap(x, x) = ([x0,x0,x2,x2], [x1,x1,x3,x3]) by 16-lane rows, permlane32_swap(y, y) = ([lo,lo], [hi,hi])
+__device__ __forceinline__ float g4_max(float x) {
+    const unsigned u = __float_as_uint(x);
+    const auto a = __builtin_amdgcn_permlane16_swap(u, u, false, false);
+    const float y = fmaxf(__uint_as_float(a[0]), __uint_as_float(a[1]));
+    const unsigned v = __float_as_uint(y);
+    const auto c = __builtin_amdgcn_permlane32_swap(v, v, false, false);
+    return fmaxf(__uint_as_float(c[0]), __uint_as_float(c[1]));
+}
+__device__ __forceinline__ float g4_sum(float x) {
+    const unsigned u = __float_as_uint(x);
+    const auto a = __builtin_amdgcn_permlane16_swap(u, u, false, false);
+    const float y = __uint_as_float(a[0]) + __uint_as_float(a[1]);
+    const unsigned v = __float_as_uint(y);
+    const auto c = __builtin_amdgcn_permlane32_swap(v, v, false, false);
+    return __uint_as_float(c[0]) + __uint_as_float(c[1]);
+}
+
+__global__ __launch_bounds__(1024) void mha_fwd_bf16_lds_kernel(const uint16_t* __restrict__ qk, const uint16_t* __restrict__ vt,
+                                                               uint16_t* __restrict__ out, int L, int Lpad, int H,
+                                                               float scale_log2e)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_att[];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int g = lane >> 4, n = lane & 15;
+    const int h = blockIdx.x, b = blockIdx.y;
+    const int C = H * 32;
+    const uint16_t* qkb = qk + (long)b * L * (2 * C);
+    const uint16_t* vtb = vt + ((long)(b * H + h) * 32) * Lpad;
+    const int nkb = Lpad / 32;                               // key blocks
+    unsigned char* kimg = smem_att;                          // nkb * 2 KB
+    unsigned char* vimg = smem_att + (long)nkb * 2048;       // nkb * 2 KB
+    // ---- stage: fragment f of the K image = (tile t = f), of the V^T image = (j, dt); 16 waves-worth per pass ----
+    for (int f = wave; f < 2 * nkb; f += 16) {
+        const int key = min(f * 16 + n, L - 1);
+        const uint4 kd = *reinterpret_cast<const uint4*>(qkb + (long)key * (2 * C) + C + h * 32 + 8 * g);
+        *reinterpret_cast<uint4*>(kimg + f * 1024 + lane * 16) = kd;
+        const int j = f >> 1, dt = f & 1;
+        const uint16_t* vr = vtb + (long)(dt * 16 + n) * Lpad + j * 32 + 4 * g;
+        const uint2 lo = *reinterpret_cast<const uint2*>(vr), hi = *reinterpret_cast<const uint2*>(vr + 16);
+        *reinterpret_cast<uint4*>(vimg + f * 1024 + lane * 16) = make_uint4(lo.x, lo.y, hi.x, hi.y);
+    }
+    __syncthreads();
+    const int nqb = (L + 31) / 32;                           // query blocks of 32
+    for (int qb = wave; qb < nqb; qb += 16) {
+        const int q0 = qb * 32;
+        bf16x8 qf[2];
+#pragma unroll
+        for (int qt = 0; qt < 2; ++qt) {
+            const int q = min(q0 + qt * 16 + n, L - 1);
+            qf[qt] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const uint4*>(qkb + (long)q * (2 * C) + h * 32 + 8 * g));
+        }
+        f32x4 o[2][2];
+#pragma unroll
+        for (int qt = 0; qt < 2; ++qt)
+#pragma unroll
+            for (int dt = 0; dt < 2; ++dt) o[qt][dt] = f32x4{0.f, 0.f, 0.f, 0.f};
+        float m[2] = {-INFINITY, -INFINITY}, lsum[2] = {0.f, 0.f};
+        for (int j = 0; j < nkb; ++j) {
+            const int kb = j * 32;
+            bf16x8 kf[2], vf[2];
+#pragma unroll
+            for (int t = 0; t < 2; ++t) {
+                kf[t] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const uint4*>(kimg + (2 * j + t) * 1024 + lane * 16));
+                vf[t] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const uint4*>(vimg + (2 * j + t) * 1024 + lane * 16));
+            }
+#pragma unroll
+            for (int qt = 0; qt < 2; ++qt) {
+                f32x4 sc[2];
+#pragma unroll
+                for (int kt = 0; kt < 2; ++kt)
+                    sc[kt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf[kt], qf[qt], f32x4{0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
+                float mx = -INFINITY;
+#pragma unroll
+                for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const int key = kb + kt * 16 + 4 * g + r;
+                        const float v = key < L ? sc[kt][r] * scale_log2e : -INFINITY;
+                        sc[kt][r] = v;
+                        mx = fmaxf(mx, v);
+                    }
+                mx = g4_max(mx);
+                const float m_new = fmaxf(m[qt], mx);
+                const float alpha = __builtin_amdgcn_exp2f(m[qt] - m_new);
+                m[qt] = m_new;
+                float ps = 0.f;
+#pragma unroll
+                for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) { sc[kt][r] = __builtin_amdgcn_exp2f(sc[kt][r] - m_new); ps += sc[kt][r]; }
+                lsum[qt] = lsum[qt] * alpha + ps;
+                const bf16x8 pf = __builtin_bit_cast(bf16x8, make_uint4(pack2(sc[0][0], sc[0][1]), pack2(sc[0][2], sc[0][3]),
+                                                                        pack2(sc[1][0], sc[1][1]), pack2(sc[1][2], sc[1][3])));
+#pragma unroll
+                for (int dt = 0; dt < 2; ++dt) {
+                    o[qt][dt] *= alpha;
+                    o[qt][dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vf[dt], pf, o[qt][dt], 0, 0, 0);
+                }
+            }
+        }
+#pragma unroll
+        for (int qt = 0; qt < 2; ++qt) {
+            float l = lsum[qt];
+            l = g4_sum(l);
+            const float inv = 1.0f / l;
+            const int q = q0 + qt * 16 + n;
+            if (q < L) {
+#pragma unroll
+                for (int dt = 0; dt < 2; ++dt) {
+                    const f32x4 v = o[qt][dt] * inv;
+                    *reinterpret_cast<uint2*>(out + ((long)b * L + q) * C + h * 32 + dt * 16 + 4 * g) =
+                        make_uint2(pack2(v[0], v[1]), pack2(v[2], v[3]));
+                }
+            }
+        }
+    }
+}
+
 // v [B, L, C] -> vt [B, H, 32, Lpad] (zero padded): the transposed image the attention kernel reads.
 __global__ __launch_bounds__(256) void v_transpose_kernel(const uint16_t* __restrict__ v, uint16_t* __restrict__ vt,
                                                           int L, int Lpad, int H)
@@ -293,6 +421,14 @@ extern "C" int dtlr_mha_forward(const void* qk, const void* v, void* vt_workspac
     int rc = check_launch();
     if (rc) return rc;
     const float scale_log2e = 1.4426950408889634f / sqrtf((float)head_dim);
+    const size_t lds = (size_t)(Lpad / 32) * 4096;               // K image + V^T image
+    if (lds <= 152 * 1024) {
+        static bool attr = false;
+        if (!attr) { (void)hipFuncSetAttribute((const void*)mha_fwd_bf16_lds_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 152 * 1024); (void)hipGetLastError(); attr = true; }
+        hipLaunchKernelGGL(mha_fwd_bf16_lds_kernel, dim3(H, B), dim3(1024), lds, st,
+                           (const uint16_t*)qk, (const uint16_t*)vt_workspace, (uint16_t*)out, L, Lpad, H, scale_log2e);
+        return check_launch();
+    }
     hipLaunchKernelGGL(mha_fwd_bf16_kernel, dim3((L + 127) / 128, H, B), dim3(256), 0, st,
                        (const uint16_t*)qk, (const uint16_t*)vt_workspace, (uint16_t*)out, L, Lpad, H, scale_log2e);
     return check_launch();
