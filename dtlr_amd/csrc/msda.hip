@@ -319,7 +319,7 @@ template <typename T, typename OT, int VEC, int REFD>
 __global__ __launch_bounds__(256, sizeof(T) == 2 ? 2 : 3) void msda_fused_l4p4_kernel(
     const T* __restrict__ value, const int64_t* __restrict__ shapes, const int64_t* __restrict__ lsi,
     const OT* __restrict__ ow, const float* __restrict__ ref,
-    int S, int M, int D, int Lq, T* __restrict__ out, long total, int bpi, int nimg)
+    int S, int M, int D, int Lq, T* __restrict__ out, long total, int bpi, int nimg, int vstride)
 {
     const long tid = xcd_block_map(blockIdx.x, bpi, nimg) * blockDim.x + threadIdx.x;
     if (tid >= total) return;
@@ -347,14 +347,14 @@ __global__ __launch_bounds__(256, sizeof(T) == 2 ? 2 : 3) void msda_fused_l4p4_k
 #pragma unroll
     for (int i = 0; i < 16; ++i) { lg[i] = expf(lg[i] - mx); sum += lg[i]; }
     const float inv = 1.0f / sum;
-    const T* vb = value + (long)b * S * MD + m * D + c0;
+    const T* vb = value + (long)b * S * vstride + m * D + c0;      // vstride: elements between spatial positions (>= M*D)
     float col[VEC];
 #pragma unroll
     for (int i = 0; i < VEC; ++i) col[i] = 0.f;
 #pragma unroll
     for (int l = 0; l < 4; ++l) {
         const int H = (int)shapes[2 * l], W = (int)shapes[2 * l + 1];
-        const T* base = vb + (long)lsi[l] * MD;
+        const T* base = vb + (long)lsi[l] * vstride;
         float lx[4], ly[4], aw4[4];
 #pragma unroll
         for (int p = 0; p < 4; ++p) {
@@ -368,14 +368,14 @@ __global__ __launch_bounds__(256, sizeof(T) == 2 ? 2 : 3) void msda_fused_l4p4_k
             }
             aw4[p] = lg[l * 4 + p] * inv;
         }
-        sample_level4<T, VEC>(base, H, W, MD, lx, ly, aw4, col);
+        sample_level4<T, VEC>(base, H, W, vstride, lx, ly, aw4, col);
     }
     Vec<T, VEC>::store(out + si * D + c0, col);
 }
 
 template <typename T, typename OT, int VEC>
 static int launch_fused(const void* value, const int64_t* shapes, const int64_t* lsi, const void* ow, const float* ref,
-                        int ref_dim, int N, int S, int M, int D, int Lq, void* out, hipStream_t st) {
+                        int ref_dim, int N, int S, int M, int D, int Lq, void* out, hipStream_t st, int vstride) {
     const long total = (long)N * Lq * M * (D / VEC);
     const int block = 256;
     const long grid = (total + block - 1) / block;
@@ -384,10 +384,10 @@ static int launch_fused(const void* value, const int64_t* shapes, const int64_t*
     const int bpi = (per_img % block == 0 && N % 8 == 0) ? (int)(per_img / block) : 0;
     if (ref_dim == 2)
         hipLaunchKernelGGL((msda_fused_l4p4_kernel<T, OT, VEC, 2>), dim3((unsigned)grid), dim3(block), 0, st,
-                           (const T*)value, shapes, lsi, (const OT*)ow, ref, S, M, D, Lq, (T*)out, total, bpi, N);
+                           (const T*)value, shapes, lsi, (const OT*)ow, ref, S, M, D, Lq, (T*)out, total, bpi, N, vstride);
     else
         hipLaunchKernelGGL((msda_fused_l4p4_kernel<T, OT, VEC, 4>), dim3((unsigned)grid), dim3(block), 0, st,
-                           (const T*)value, shapes, lsi, (const OT*)ow, ref, S, M, D, Lq, (T*)out, total, bpi, N);
+                           (const T*)value, shapes, lsi, (const OT*)ow, ref, S, M, D, Lq, (T*)out, total, bpi, N, vstride);
     return check_launch();
 }
 
@@ -454,18 +454,28 @@ extern "C" int dtlr_msda_fused_forward(const void* value, const int64_t* shapes,
                                        int N, int S, int M, int D, int L, int Lq, int P,
                                        int dtype, int ow_dtype, void* out, void* stream)
 {
+    return dtlr_msda_fused_forward_strided(value, 0, shapes, lsi, ow, ref, ref_dim, N, S, M, D, L, Lq, P, dtype, ow_dtype, out, stream);
+}
+
+extern "C" int dtlr_msda_fused_forward_strided(const void* value, int value_row_stride, const int64_t* shapes, const int64_t* lsi,
+                                               const void* ow, const float* ref, int ref_dim,
+                                               int N, int S, int M, int D, int L, int Lq, int P,
+                                               int dtype, int ow_dtype, void* out, void* stream)
+{
     clear_stale_error();
     if (!value || !shapes || !lsi || !ow || !ref || !out) return DTLR_EINVAL;
     if (N <= 0 || S <= 0 || M <= 0 || D <= 0 || Lq <= 0) return DTLR_EINVAL;
     if (L != 4 || P != 4 || (ref_dim != 2 && ref_dim != 4)) return DTLR_ESHAPE;
+    const int vstride = value_row_stride > 0 ? value_row_stride : M * D;
+    if (vstride < M * D || (vstride & 7)) return DTLR_ESHAPE;
     hipStream_t st = (hipStream_t)stream;
     if (dtype == DTLR_F32 && D % 4 == 0) {
-        if (ow_dtype == DTLR_F32) return launch_fused<float, float, 4>(value, shapes, lsi, ow, ref, ref_dim, N, S, M, D, Lq, out, st);
+        if (ow_dtype == DTLR_F32) return launch_fused<float, float, 4>(value, shapes, lsi, ow, ref, ref_dim, N, S, M, D, Lq, out, st, vstride);
         return DTLR_EDTYPE;
     }
     if (dtype == DTLR_BF16 && D % 4 == 0) {
-        if (ow_dtype == DTLR_F32) return launch_fused<uint16_t, float, 4>(value, shapes, lsi, ow, ref, ref_dim, N, S, M, D, Lq, out, st);
-        if (ow_dtype == DTLR_BF16) return launch_fused<uint16_t, uint16_t, 4>(value, shapes, lsi, ow, ref, ref_dim, N, S, M, D, Lq, out, st);
+        if (ow_dtype == DTLR_F32) return launch_fused<uint16_t, float, 4>(value, shapes, lsi, ow, ref, ref_dim, N, S, M, D, Lq, out, st, vstride);
+        if (ow_dtype == DTLR_BF16) return launch_fused<uint16_t, uint16_t, 4>(value, shapes, lsi, ow, ref, ref_dim, N, S, M, D, Lq, out, st, vstride);
         return DTLR_EDTYPE;
     }
     return (dtype == DTLR_F32 || dtype == DTLR_BF16) ? DTLR_ESHAPE : DTLR_EDTYPE;

@@ -119,6 +119,9 @@ class DTLREngine:
             self._put_linear(q + "sa.out", sd[p + "self_attn.out_proj.weight"], sd[p + "self_attn.out_proj.bias"])
             self._put_linear(q + "ff1", sd[p + "linear1.weight"], sd[p + "linear1.bias"])
             self._put_linear(q + "ff2", sd[p + "linear2.weight"], sd[p + "linear2.bias"])
+        self._put_linear("dec.value_all",
+                         torch.cat([sd[f"{t}decoder.layers.{n}.cross_attn.value_proj.weight"] for n in range(cfg.dec_layers)], 0),
+                         torch.cat([sd[f"{t}decoder.layers.{n}.cross_attn.value_proj.bias"] for n in range(cfg.dec_layers)], 0))
         norm_pack("dec.norm", t + "decoder.norm")
         for i in range(2):
             self._put_linear(f"dec.rph{i}", sd[f"{t}decoder.ref_point_head.layers.{i}.weight"], sd[f"{t}decoder.ref_point_head.layers.{i}.bias"])
@@ -261,7 +264,7 @@ class DTLREngine:
                     proposals=prop, keep=keep, shapes=shapes, lsi=lsi, has_padding=has_padding,
                     level_hw=[(int(h), int(w)) for h, w in level_hw])
 
-    def _msda_module(self, name, query, query_pos, ref, value_src, g, n_points):
+    def _msda_module(self, name, query, query_pos, ref, value_src, g, n_points, value=None):
         """MSDeformAttn.forward (ops/modules/ms_deform_attn.py:78-126) without the output
         projection (done by the caller, followed by the fused residual + LayerNorm).
         query + query_pos is formed in the GEMM prologue; the padding fill of `value` is its epilogue."""
@@ -269,14 +272,15 @@ class DTLREngine:
         B, Lq, C = query.shape
         S = value_src.shape[1]
         M, L, P = cfg.nheads, cfg.num_feature_levels, n_points
-        value = self._lin(name + ".value", value_src, row_mask=g["mask_flat"] if g["has_padding"] else None)
+        if value is None:
+            value = self._lin(name + ".value", value_src, row_mask=g["mask_flat"] if g["has_padding"] else None)
         # the [offsets|logits] row stays in the activation dtype: in the bf16 engine its 2^-8 relative rounding
         # moves a sampling point by < 0.02 px, far below the bf16 noise of the sampled values themselves
         ow = self._lin(name + ".ow", query, a2=query_pos)
         if L == 4 and P == 4:
             if Lq == S and ref.shape[-1] == 2 and C // M == 32 and self.use_lds_msda:      # encoder self-attention
                 return ops.msda_encoder(value.view(B, S, M, C // M), g["level_hw"], ow, ref)
-            return ops.msda_fused(value.view(B, S, M, C // M), g["shapes"], g["lsi"], ow, ref)
+            return ops.msda_fused(value.unflatten(-1, (M, C // M)), g["shapes"], g["lsi"], ow, ref)
         ow = ow.float()
         off = ow[..., : M * L * P * 2].reshape(B, Lq, M, L, P, 2)
         aw = torch.softmax(ow[..., M * L * P * 2:].reshape(B, Lq, M, L * P), -1).reshape(B, Lq, M, L, P)
@@ -350,6 +354,11 @@ class DTLREngine:
         refs = [ref]
         tgt = self.w["tgt_embed"][None].expand(B, -1, -1).contiguous()
         hs = []
+        # value_proj(memory) of all decoder layers in ONE GEMM (same input, N = layers x 256): memory is read once instead
+        # of once per layer; layer n samples its column slice through the strided MSDA entry point
+        C = cfg.hidden_dim
+        vall = ops.linear(memory, self.w["dec.value_all.w"], self.w["dec.value_all.b"],
+                          row_mask=g["mask_flat"] if g["has_padding"] else None)
         for n in range(cfg.dec_layers):
             q = f"dec{n}."
             ref_in, sine = ops.decoder_query_prep(ref, g["valid_ratios"], self.dtype)      # [B,nq,L,4], [B,nq,512]
@@ -360,7 +369,7 @@ class DTLREngine:
             a = ops.mha(qk, v, cfg.nheads)
             tgt = self._ln(q + "norm2", self._lin(q + "sa.out", a), residual=tgt)
             # deformable cross attention
-            a = self._msda_module(q + "attn", tgt, qpos, ref_in, memory, g, cfg.dec_n_points)
+            a = self._msda_module(q + "attn", tgt, qpos, ref_in, memory, g, cfg.dec_n_points, value=vall[..., n * C:(n + 1) * C])
             tgt = self._ln(q + "norm1", self._lin(q + "attn.out", a), residual=tgt)
             # ffn
             tgt = self._ffn(q, "norm3", tgt)

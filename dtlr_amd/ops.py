@@ -228,17 +228,20 @@ def msda_fused(value, spatial_shapes, level_start_index, ow, ref):
     Lq = ow.shape[1]
     L = spatial_shapes.shape[0]
     assert ow.shape[2] == M * L * 4 * 3 and ref.dtype == torch.float32 and ref.shape[:3] == (N, Lq, L)
-    assert value.is_contiguous() and ow.is_contiguous() and ref.is_contiguous()
+    assert ow.is_contiguous() and ref.is_contiguous()
+    # value may be a column slice of a wider [N, S, row_stride] tensor (all decoder layers' value projections in one GEMM)
+    vs = value.stride()
+    assert vs[3] == 1 and vs[2] == D and vs[0] == S * vs[1] and vs[1] >= M * D, "value: [N,S,M,D] view with contiguous heads"
     out = torch.empty((N, Lq, M * D), dtype=value.dtype, device=value.device)
     ev = MSDA_EVENTS
     if ev is not None:
         st = torch.cuda.current_stream()
         a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         a.record(st)
-    code = _lib.lib().dtlr_msda_fused_forward(value.data_ptr(), spatial_shapes.data_ptr(), level_start_index.data_ptr(),
-                                              ow.data_ptr(), ref.data_ptr(), ref.shape[-1], N, S, M, D, L, Lq, 4,
-                                              _DT[value.dtype], _DT[ow.dtype], out.data_ptr(), _lib.current_stream())
-    _lib.check(code, "dtlr_msda_fused_forward")
+    code = _lib.lib().dtlr_msda_fused_forward_strided(value.data_ptr(), vs[1], spatial_shapes.data_ptr(), level_start_index.data_ptr(),
+                                                      ow.data_ptr(), ref.data_ptr(), ref.shape[-1], N, S, M, D, L, Lq, 4,
+                                                      _DT[value.dtype], _DT[ow.dtype], out.data_ptr(), _lib.current_stream())
+    _lib.check(code, "dtlr_msda_fused_forward_strided")
     if ev is not None:
         b.record(st)
         ev.append((a, b, N, Lq, S))

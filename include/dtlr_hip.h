@@ -67,6 +67,13 @@ int dtlr_msda_fused_forward(const void *value, const int64_t *shapes, const int6
                             const void *ow, const float *ref, int ref_dim,
                             int N, int S, int M, int D, int L, int Lq, int P,
                             int dtype, int ow_dtype, void *out, void *stream);
+/* Same, with `value` a column slice of a wider [N, S, value_row_stride] tensor (value_row_stride elements between
+ * consecutive spatial positions, >= M*D, multiple of 8; 0 = contiguous): the value projections of all decoder layers
+ * (`value_proj(memory)` of every layer, ms_deform_attn.py:94, read the same `memory`) are produced by ONE GEMM. */
+int dtlr_msda_fused_forward_strided(const void *value, int value_row_stride, const int64_t *shapes,
+                                    const int64_t *level_start_index, const void *ow, const float *ref, int ref_dim,
+                                    int N, int S, int M, int D, int L, int Lq, int P,
+                                    int dtype, int ow_dtype, void *out, void *stream);
 
 /* ---------------------------------------------------------------------------------------------
  * Encoder self-attention form of the above (queries ARE the pixels of the L = 4 levels, Lq = S), with
