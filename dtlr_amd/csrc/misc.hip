@@ -50,9 +50,53 @@ __global__ __launch_bounds__(256) void box_refine_kernel(const float* __restrict
     out[i] = 1.f / (1.f + expf(-u));
 }
 
+// Output layer of a 3-layer box MLP (256 -> 4, models/dino/dino.py MLP) fused with what consumes it:
+//   mode 0: out = sigmoid(h W^T + b + inverse_sigmoid(ref))      iterative refinement (deformable_transformer.py:734-756)
+//   mode 1: out = h W^T + b + ref                                two-stage initial boxes, unsigmoided (:352-356)
+// One wavefront per row: lane l holds channels 4l..4l+3 of h and of the four weight rows; four wave reductions.
+// (As a GEMM with N = 4 this was a 24 us launch of the fp32 MFMA kernel per decoder layer, plus the refine launch.)
+__global__ __launch_bounds__(256) void box_head_refine_kernel(const float* __restrict__ h, const float* __restrict__ W,
+                                                              const float* __restrict__ bias, const float* __restrict__ ref,
+                                                              float* __restrict__ out, long rows, int mode)
+{
+    const int lane = threadIdx.x & 63;
+    const long row = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= rows) return;
+    const float4 x = *reinterpret_cast<const float4*>(h + row * 256 + 4 * lane);
+    float d[4];
+#pragma unroll
+    for (int o = 0; o < 4; ++o) {
+        const float4 w = *reinterpret_cast<const float4*>(W + o * 256 + 4 * lane);
+        d[o] = wave_sum(x.x * w.x + x.y * w.y + x.z * w.z + x.w * w.w);
+    }
+    if (lane < 4) {
+        const float delta = (lane == 0 ? d[0] : lane == 1 ? d[1] : lane == 2 ? d[2] : d[3]) + bias[lane];
+        const float r = ref[row * 4 + lane];
+        float y;
+        if (mode == 0) {
+            const float xx = fminf(fmaxf(r, 0.f), 1.f);
+            const float x1 = fmaxf(xx, 1e-3f), x2 = fmaxf(1.f - xx, 1e-3f);
+            const float u = delta + logf(x1 / x2);
+            y = 1.f / (1.f + expf(-u));
+        } else y = delta + r;
+        out[row * 4 + lane] = y;
+    }
+}
+
 }  // namespace dtlr
 
 using namespace dtlr;
+
+extern "C" int dtlr_box_head_refine(const float* h, const float* W, const float* bias, const float* ref, float* out,
+                                    long rows, int hidden, int mode, void* stream)
+{
+    clear_stale_error();
+    if (!h || !W || !bias || !ref || !out) return DTLR_EINVAL;
+    if (rows <= 0 || (mode != 0 && mode != 1)) return DTLR_EINVAL;
+    if (hidden != 256) return DTLR_ESHAPE;
+    hipLaunchKernelGGL(box_head_refine_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, (hipStream_t)stream, h, W, bias, ref, out, rows, mode);
+    return check_launch();
+}
 
 extern "C" int dtlr_decoder_query_prep(const float* ref, const float* valid_ratios, const float* dim_t,
                                        float* ref_in, void* sine, int B, int nq, int L, int sine_dtype, void* stream)

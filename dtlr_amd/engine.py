@@ -314,7 +314,7 @@ class DTLREngine:
         sel = torch.gather(om, 1, idx.unsqueeze(-1).expand(-1, -1, cfg.hidden_dim))
         h = self._box_mlp_hidden("enc_bbox", sel)
         prop_sel = torch.gather(g["proposals"], 1, idx.unsqueeze(-1).expand(-1, -1, 4))
-        ref_unsig = ops.linear(h, self.w["enc_bbox2.w"], self.w["enc_bbox2.b"]) + prop_sel
+        ref_unsig = ops.box_head_refine(h, self.w["enc_bbox2.w"], self.w["enc_bbox2.b"], prop_sel, mode=1)
         return dict(topk_idx=idx, topk_scores=scores, ref_unsig=ref_unsig, hs_enc=sel, init_box=prop_sel.sigmoid())
 
     @staticmethod
@@ -341,8 +341,9 @@ class DTLREngine:
         h = ops.linear(x.float(), w[name + "0.w"], w[name + "0.b"], relu=True)
         return ops.linear(h, w[name + "1.w"], w[name + "1.b"], relu=True)
 
-    def _bbox_head(self, x):
-        return ops.linear(self._box_mlp_hidden("bbox", x), self.w["bbox2.w"], self.w["bbox2.b"])
+    def _refine(self, x, ref):
+        """sigmoid(bbox_embed(x) + inverse_sigmoid(ref)) (deformable_transformer.py:734-756; dino.py:339-354)."""
+        return ops.box_head_refine(self._box_mlp_hidden("bbox", x), self.w["bbox2.w"], self.w["bbox2.b"], ref, mode=0)
 
     def decoder(self, memory, ts, g, want_aux=False):
         """TransformerDecoder.forward + DeformableTransformerDecoderLayer
@@ -374,7 +375,7 @@ class DTLREngine:
             # ffn
             tgt = self._ffn(q, "norm3", tgt)
             # iterative box refinement (734-756)
-            ref = ops.box_refine(self._bbox_head(tgt), ref)
+            ref = self._refine(tgt, ref)
             refs.append(ref)
             if want_aux or n == cfg.dec_layers - 1:
                 hs.append(self._ln("dec.norm", tgt))
@@ -419,11 +420,11 @@ class DTLREngine:
         n = cfg.dec_layers - 1
         out = {
             "pred_logits": ops.linear(hs[n].float(), self.w["class.w"], self.w["class.b"]),
-            "pred_boxes": ops.box_refine(self._bbox_head(hs[n]), refs[n]),
+            "pred_boxes": self._refine(hs[n], refs[n]),
         }
         if want_aux:
             out["aux_outputs"] = [{"pred_logits": ops.linear(hs[i].float(), self.w["class.w"], self.w["class.b"]),
-                                   "pred_boxes": ops.box_refine(self._bbox_head(hs[i]), refs[i])}
+                                   "pred_boxes": self._refine(hs[i], refs[i])}
                                   for i in range(n)]
         interm_class = ops.linear(ts["hs_enc"], self.w["enc_class.w"], self.w["enc_class.b"])
         out["interm_outputs"] = {"pred_logits": interm_class, "pred_boxes": ts["ref_unsig"].sigmoid()}

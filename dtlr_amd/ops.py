@@ -313,6 +313,20 @@ def decoder_query_prep(ref, valid_ratios, out_dtype):
     return ref_in, sine
 
 
+def box_head_refine(h, w, b, ref, mode: int = 0):
+    """Last layer of the box MLP (256 -> 4) fused with its consumer (HIP kernel, one wavefront per row):
+    mode 0: sigmoid(h W^T + b + inverse_sigmoid(ref)) ; mode 1: h W^T + b + ref.  h [..,256] fp32, ref [..,4] fp32."""
+    require_cuda(h, "h")
+    assert h.dtype == torch.float32 and ref.dtype == torch.float32 and w.dtype == torch.float32 and h.shape[-1] == 256
+    h = h if h.is_contiguous() else h.contiguous()
+    ref = ref if ref.is_contiguous() else ref.contiguous()
+    out = torch.empty_like(ref)
+    code = _lib.lib().dtlr_box_head_refine(h.data_ptr(), w.data_ptr(), b.data_ptr(), ref.data_ptr(), out.data_ptr(),
+                                           h.numel() // 256, 256, mode, _lib.current_stream())
+    _lib.check(code, "dtlr_box_head_refine")
+    return out
+
+
 def box_refine(delta, ref):
     """sigmoid(delta + inverse_sigmoid(ref)) (fp32)."""
     delta, ref = delta.contiguous(), ref.contiguous()

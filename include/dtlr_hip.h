@@ -178,6 +178,14 @@ int dtlr_decoder_query_prep(const float *ref, const float *valid_ratios, const f
  *           DINO.forward (models/dino/dino.py:343-346) with inverse_sigmoid of util/misc.py:575-579 (eps 1e-3). */
 int dtlr_box_refine(const float *delta, const float *ref, float *out, long n, void *stream);
 
+/* Output layer of the box MLP (256 -> 4) fused with its consumer.
+ * Replaces: bbox_embed[-1] / enc_out_bbox_embed[-1] (the last nn.Linear of MLP(256,256,4,3), models/dino/dino.py) +
+ *           mode 0: `sigmoid(delta + inverse_sigmoid(reference))` (deformable_transformer.py:734-756)
+ *           mode 1: `delta + topk proposals` (unsigmoided two-stage boxes, :352-356)
+ *   h [rows,256] fp32 (second hidden layer, after ReLU); W [4,256], bias [4], ref [rows,4], out [rows,4] fp32. */
+int dtlr_box_head_refine(const float *h, const float *W, const float *bias, const float *ref, float *out,
+                         long rows, int hidden, int mode, void *stream);
+
 /* ---------------------------------------------------------------------------------------------
  * GroupNorm(32, 256) over the tokens of one feature level (statistics per sample and group over
  * T positions x 8 channels, eps, affine).
