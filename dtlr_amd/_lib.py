@@ -46,6 +46,8 @@ _SIGNATURES = {
     "dtlr_groupnorm_tokens": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_float, c_int, c_void_p]),
     "dtlr_groupnorm_workspace_bytes": (ctypes.c_long, [c_int, c_int]),
     "dtlr_box_head_refine": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, ctypes.c_long, c_int, c_int, c_void_p]),
+    "dtlr_stem_pack_weights": (c_int, [c_void_p, c_void_p]),
+    "dtlr_stem_conv7x7": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p]),
     "dtlr_maxpool3x3s2_nhwc": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p]),
     "dtlr_topk_rows": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_void_p]),
     "dtlr_decode_blank": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_float, c_void_p]),

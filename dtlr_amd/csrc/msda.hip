@@ -329,7 +329,7 @@ __global__ __launch_bounds__(256, sizeof(T) == 2 ? 2 : 3) void msda_fused_l4p4_k
     const int m = (int)(si % M);
     const long bq = si / M;
     const int b = (int)(bq / Lq);
-    const int MD = M * D;
+    (void)0;
     const OT* row = ow + bq * (long)(M * 48);
     float off[32], lg[16];
     load_row16<OT>(row + m * 32, *reinterpret_cast<float (*)[16]>(&off[0]));

@@ -1,0 +1,159 @@
+// ResNet stem: 7x7 / stride 2 / pad 3 convolution of the 3-channel input image, on the bf16 matrix cores,
+// reading the NCHW fp32 image directly (torchvision resnet50.conv1 as run by models/dino/backbone.py:97-106; the
+// FrozenBN scale is folded into the weights, its shift + ReLU are applied by the max-pool pass that follows).
+//
+// Why its own kernel: Cin = 3 does not fit the slab loader of the implicit-GEMM kernel (a K slab must be 128
+// contiguous bytes of one tap), and the library path cost 0.32 ms per step (NCHW->NHWC/bf16 conversion passes +
+// MIOpen igemm) for 0.1 GB of input.
+//
+// Formulation: out^T[64 ch, pixels] = Wk[64, K] . patches[K, pixels] with K ordered (ci, kh, kw') and kw' padded 7 -> 8:
+// K = 21 (ci,kh) pairs x 8 = 168 -> 192 = 6 MFMA k-steps of 32 (pairs 21..23 and kw' = 7 carry zero weights).
+//   * For a fixed (ci, kh) the 8 taps of an output pixel are 8 CONSECUTIVE input pixels of one NCHW row:
+//     cols 2 ow - 3 .. 2 ow + 4.  The workgroup stages the rows it needs in LDS as bf16, shifted by 3 so that the
+//     window of pixel ow starts at the EVEN element 2 ow.
+//   * A lane's B-fragment (k-slots 8g..8g+7 = the 8 taps of pair 4 ks + g) is then 16 bytes of one LDS row.  Pixels are
+//     interleaved over the four MFMA column tiles (tile t owns pixels 4 n + t): a lane reads the two ALIGNED 16-byte
+//     pieces n, n+1 of its row once, and tile t's fragment is the dwords t..t+3 of that pair -- a compile-time register
+//     window, no shifts, no unaligned LDS access.  2 ds_read_b128 feed 16 MFMAs.
+//   * All 24 weight fragments (24 KB) live in registers (96 VGPRs) for the whole kernel.
+// Workgroup = 4 output rows x 256 output columns of one image; wave = (row, 64-column strip) units.
+#include "dtlr_common.h"
+
+namespace dtlr {
+
+typedef __attribute__((ext_vector_type(8))) __bf16 stem_bf16x8_t;
+typedef __attribute__((ext_vector_type(4))) float stem_f32x4_t;
+
+constexpr int STEM_ROWS = 4, STEM_COLS = 256;               // conv outputs per workgroup
+constexpr int STEM_IN_ROWS = 2 * STEM_ROWS + 5;             // 13 input rows per channel
+constexpr int STEM_IN_COLS = 2 * STEM_COLS + 8;             // 520 staged input columns
+constexpr int STEM_PITCH = 640;                             // elements per LDS row: 1280 B = 5 x 256 B (rows bank-aligned)
+constexpr int STEM_LDS = 3 * STEM_IN_ROWS * STEM_PITCH * 2; // 49920 B
+
+__device__ __forceinline__ stem_f32x4_t stem_mma(const uint4& a, uint32_t b0, uint32_t b1, uint32_t b2, uint32_t b3, stem_f32x4_t c) {
+    const uint4 b = make_uint4(b0, b1, b2, b3);
+    return __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(stem_bf16x8_t, a), __builtin_bit_cast(stem_bf16x8_t, b), c, 0, 0, 0);
+}
+
+// x [B,3,H,W] fp32 ; wfrag [4][6][64][8] bf16 (fragment-major, see dtlr_stem_pack_weights) ; y [B,Ho,Wo,64] bf16
+__global__ __launch_bounds__(512, 2) void stem_conv7x7_kernel(const float* __restrict__ x, const uint16_t* __restrict__ wfrag,
+                                                              uint16_t* __restrict__ y, int H, int W, int Ho, int Wo)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_stem[];
+    uint16_t* img = reinterpret_cast<uint16_t*>(smem_stem);
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int n = lane & 15, g = lane >> 4;
+    const int ow_b0 = blockIdx.x * STEM_COLS, oh0 = blockIdx.y * STEM_ROWS, b = blockIdx.z;
+    const int ir0 = 2 * oh0 - 3, ic0 = 2 * ow_b0 - 3;
+
+    // ---- weights: 24 fragments, lane's 16 bytes each, held for the whole kernel ------------------------------
+    uint4 wa[4][6];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int ks = 0; ks < 6; ++ks) wa[i][ks] = *reinterpret_cast<const uint4*>(wfrag + ((i * 6 + ks) * 64 + lane) * 8);
+
+    // ---- stage 3 x 13 input rows x 520 columns as bf16 pairs (zero outside the image) -------------------------
+    const float* xb = x + (long)b * 3 * H * W;
+    for (int p = threadIdx.x; p < 3 * STEM_IN_ROWS * (STEM_IN_COLS / 2); p += 512) {
+        const int row = p / (STEM_IN_COLS / 2), cc = (p % (STEM_IN_COLS / 2)) * 2;
+        const int ci = row / STEM_IN_ROWS, ir = ir0 + row % STEM_IN_ROWS, ic = ic0 + cc;
+        float v0 = 0.f, v1 = 0.f;
+        if (ir >= 0 && ir < H) {
+            const float* src = xb + ((long)ci * H + ir) * W;
+            if (ic >= 0 && ic < W) v0 = src[ic];
+            if (ic + 1 >= 0 && ic + 1 < W) v1 = src[ic + 1];
+        }
+        *reinterpret_cast<uint32_t*>(img + row * STEM_PITCH + cc) = pack_bf16x2(v0, v1);
+    }
+    __syncthreads();
+
+    // per-lane LDS row of pair 4 ks + g at output-row offset 0 (pairs >= 21 have zero weights: any finite row will do)
+    int rowoff[6];
+#pragma unroll
+    for (int ks = 0; ks < 6; ++ks) {
+        const int pair = min(4 * ks + g, 20);
+        rowoff[ks] = ((pair / 7) * STEM_IN_ROWS + pair % 7) * STEM_PITCH;
+    }
+    for (int u = wave; u < STEM_ROWS * (STEM_COLS / 64); u += 8) {
+        const int ro = u >> 2, s = u & 3;
+        const int oh = oh0 + ro;
+        if (oh >= Ho) continue;                                 // wave-uniform
+        stem_f32x4_t acc[4][4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int t = 0; t < 4; ++t) acc[i][t] = stem_f32x4_t{0.f, 0.f, 0.f, 0.f};
+        const uint16_t* base = img + 2 * ro * STEM_PITCH + (16 * s + n) * 8;
+#pragma unroll
+        for (int ks = 0; ks < 6; ++ks) {
+            const uint4 p0 = *reinterpret_cast<const uint4*>(base + rowoff[ks]);
+            const uint4 p1 = *reinterpret_cast<const uint4*>(base + rowoff[ks] + 8);
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                acc[i][0] = stem_mma(wa[i][ks], p0.x, p0.y, p0.z, p0.w, acc[i][0]);
+                acc[i][1] = stem_mma(wa[i][ks], p0.y, p0.z, p0.w, p1.x, acc[i][1]);
+                acc[i][2] = stem_mma(wa[i][ks], p0.z, p0.w, p1.x, p1.y, acc[i][2]);
+                acc[i][3] = stem_mma(wa[i][ks], p0.w, p1.x, p1.y, p1.z, acc[i][3]);
+            }
+        }
+        // ---- store: lane (n, g) holds channels 16 i + 4 g + r of pixel 64 s + 4 n + t; channel tiles are paired with
+        // v_permlane16_swap so that a lane writes 8 consecutive channels (16 bytes), 64 contiguous bytes per pixel
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+            const int ow = ow_b0 + 64 * s + 4 * n + t;
+            uint16_t* dst = y + (((long)b * Ho + oh) * Wo + ow) * 64;
+#pragma unroll
+            for (int i = 0; i < 4; i += 2) {
+                const uint32_t lo0 = pack_bf16x2(acc[i][t][0], acc[i][t][1]), hi0 = pack_bf16x2(acc[i][t][2], acc[i][t][3]);
+                const uint32_t lo1 = pack_bf16x2(acc[i + 1][t][0], acc[i + 1][t][1]), hi1 = pack_bf16x2(acc[i + 1][t][2], acc[i + 1][t][3]);
+                const auto s0 = __builtin_amdgcn_permlane16_swap(lo0, lo1, false, false);
+                const auto s1 = __builtin_amdgcn_permlane16_swap(hi0, hi1, false, false);
+                // even g: channels 8 (g/2) .. of tile i ; odd g: the same 8 channels of tile i + 1
+                if (ow < Wo)
+                    *reinterpret_cast<uint4*>(dst + (i + (g & 1)) * 16 + 8 * (g >> 1)) = make_uint4(s0[0], s1[0], s0[1], s1[1]);
+            }
+        }
+    }
+}
+
+}  // namespace dtlr
+
+using namespace dtlr;
+
+// conv1.weight (BN scale folded) [64, 3, 7, 7] fp32 (host or device memory readable by the host is NOT assumed: this packs on
+// the host side from a host pointer) -> wfrag [4][6][64][8] bf16 as uint16 in host memory.
+extern "C" int dtlr_stem_pack_weights(const float* w_oihw_host, unsigned short* wfrag_host)
+{
+    if (!w_oihw_host || !wfrag_host) return DTLR_EINVAL;
+    for (int i = 0; i < 4; ++i)
+        for (int ks = 0; ks < 6; ++ks)
+            for (int lane = 0; lane < 64; ++lane) {
+                const int m = lane & 15, g = lane >> 4, pair = 4 * ks + g;
+                for (int e = 0; e < 8; ++e) {
+                    float v = 0.f;
+                    if (pair < 21 && e < 7) v = w_oihw_host[(((16 * i + m) * 3 + pair / 7) * 7 + pair % 7) * 7 + e];
+                    uint32_t u;
+                    __builtin_memcpy(&u, &v, 4);
+                    if ((u & 0x7fffffffu) > 0x7f800000u) u = (u >> 16) | 0x40u;      // NaN stays NaN
+                    else { u += 0x7fffu + ((u >> 16) & 1u); u >>= 16; }               // round to nearest even
+                    wfrag_host[((i * 6 + ks) * 64 + lane) * 8 + e] = (unsigned short)u;
+                }
+            }
+    return DTLR_OK;
+}
+
+extern "C" int dtlr_stem_conv7x7(const float* x, const void* wfrag, void* y, int B, int H, int W, int out_dtype, void* stream)
+{
+    clear_stale_error();
+    if (!x || !wfrag || !y) return DTLR_EINVAL;
+    if (B <= 0 || H <= 0 || W <= 0) return DTLR_EINVAL;
+    if (out_dtype != DTLR_BF16) return DTLR_EDTYPE;
+    const int Ho = (H + 6 - 7) / 2 + 1, Wo = (W + 6 - 7) / 2 + 1;
+    static bool attr = false;
+    if (!attr) { (void)hipFuncSetAttribute((const void*)stem_conv7x7_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, STEM_LDS); (void)hipGetLastError(); attr = true; }
+    const dim3 grid((Wo + STEM_COLS - 1) / STEM_COLS, (Ho + STEM_ROWS - 1) / STEM_ROWS, B);
+    hipLaunchKernelGGL(stem_conv7x7_kernel, grid, dim3(512), STEM_LDS, (hipStream_t)stream,
+                       x, (const uint16_t*)wfrag, (uint16_t*)y, H, W, Ho, Wo);
+    return check_launch();
+}

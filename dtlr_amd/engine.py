@@ -70,7 +70,10 @@ class DTLREngine:
     def _pack(self, sd):
         cfg, f32 = self.cfg, torch.float32
         b = "backbone.0.body."
-        self._put_conv("conv1", *_fold_bn(sd, b + "conv1.weight", b + "bn1"))
+        w1, b1 = _fold_bn(sd, b + "conv1.weight", b + "bn1")
+        self._put_conv("conv1", w1, b1)
+        if self.dtype == torch.bfloat16:               # bf16 engine: own MFMA stem kernel, weights as a fragment image
+            self.w["conv1.frag"] = ops.stem_pack_weights(w1).to(self.device)
         for li, nblocks in enumerate(cfg.backbone_blocks, start=1):
             for bi in range(nblocks):
                 p = f"{b}layer{li}.{bi}."
@@ -173,12 +176,15 @@ class DTLREngine:
         h = self._lin(q + "ff1", x, relu=True)
         return self._ln(q + norm, self._lin(q + "ff2", h), residual=x)
 
-    def backbone(self, x_nhwc) -> List[torch.Tensor]:
+    def backbone(self, x_nhwc, x_nchw=None) -> List[torch.Tensor]:
         """torchvision resnet50 (v1.5) body with FrozenBN folded; returns layer2/3/4 maps, NHWC
         (models/dino/backbone.py:97-106,118-120)."""
         # stem: the 3-channel 7x7 convolution is the one library-backed GEMM-class op (MIOpen); its folded-BN shift,
         # the ReLU and the max-pool run as ONE pass of our kernel over the full-resolution map
-        x = ops.conv2d_nhwc(x_nhwc, self.w["conv1.w"], None, 2, 3, relu=False)
+        if "conv1.frag" in self.w and x_nchw is not None:
+            x = ops.stem_conv7x7(x_nchw, self.w["conv1.frag"])          # reads the NCHW fp32 image directly
+        else:
+            x = ops.conv2d_nhwc(x_nhwc, self.w["conv1.w"], None, 2, 3, relu=False)
         x = ops.maxpool_nhwc(x, bias=self.w["conv1.b"], relu=True)
         outs = []
         for li, nblocks in enumerate(self.cfg.backbone_blocks, start=1):
@@ -392,8 +398,10 @@ class DTLREngine:
         ops.require_cuda(x, "images")
         cfg = self.cfg
         B = x.shape[0]
-        x_nhwc = x.to(self.dtype).permute(0, 2, 3, 1).contiguous()
-        feats = self.backbone(x_nhwc)
+        if "conv1.frag" in self.w:
+            feats = self.backbone(None, x_nchw=x.float())
+        else:
+            feats = self.backbone(x.to(self.dtype).permute(0, 2, 3, 1).contiguous())
         level_hw = [(f.shape[1], f.shape[2]) for f in feats]
         last = self._conv(f"ip{len(feats)}", feats[-1], 2, 1)
         level_hw.append((last.shape[1], last.shape[2]))

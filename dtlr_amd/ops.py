@@ -18,7 +18,7 @@ from . import MultiScaleDeformableAttention as _msda
 from . import _lib
 
 # operators still served by ROCm libraries via torch (shrinks as kernels land)
-LIBRARY_BACKED = {"conv2d_nhwc(7x7 stem only)", "postprocess topk / nms"}
+LIBRARY_BACKED = {"conv2d_nhwc(7x7 stem, fp32 engine only)", "postprocess topk / nms"}
 
 _DT = {torch.float32: _lib.DTLR_F32, torch.bfloat16: _lib.DTLR_BF16, torch.float64: _lib.DTLR_F64}
 
@@ -174,6 +174,31 @@ def conv2d_nhwc(x, w, bias, stride: int, padding: int, relu=False, residual=None
     if relu:
         y = F.relu(y, inplace=True)
     return y.contiguous()
+
+
+def stem_pack_weights(w_oihw):
+    """conv1.weight with the FrozenBN scale folded, [64,3,7,7] (any float dtype, any device) -> the 24 KB fragment-major
+    bf16 weight image dtlr_stem_conv7x7 keeps in registers (uint16 tensor on the CPU; move it to the device once)."""
+    import numpy as np
+    w = np.ascontiguousarray(w_oihw.detach().float().cpu().numpy())
+    assert w.shape == (64, 3, 7, 7)
+    out = np.zeros(4 * 6 * 64 * 8, dtype=np.uint16)
+    code = _lib.lib().dtlr_stem_pack_weights(w.ctypes.data, out.ctypes.data)
+    _lib.check(code, "dtlr_stem_pack_weights")
+    return torch.from_numpy(out.view(np.int16)).clone()
+
+
+def stem_conv7x7(x_nchw, wfrag):
+    """ResNet stem 7x7/s2/p3 convolution 3 -> 64 on the bf16 MFMA (HIP kernel): x [B,3,H,W] fp32 NCHW -> [B,Ho,Wo,64] bf16
+    NHWC, no bias (the max-pool pass applies the folded-BN shift + ReLU)."""
+    require_cuda(x_nchw, "images")
+    assert x_nchw.dtype == torch.float32 and x_nchw.dim() == 4 and x_nchw.shape[1] == 3
+    x = x_nchw if x_nchw.is_contiguous() else x_nchw.contiguous()
+    B, _, H, W = x.shape
+    y = torch.empty((B, (H - 1) // 2 + 1, (W - 1) // 2 + 1, 64), dtype=torch.bfloat16, device=x.device)
+    code = _lib.lib().dtlr_stem_conv7x7(x.data_ptr(), wfrag.data_ptr(), y.data_ptr(), B, H, W, _DT[torch.bfloat16], _lib.current_stream())
+    _lib.check(code, "dtlr_stem_conv7x7")
+    return y
 
 
 def maxpool_nhwc(x, k: int = 3, stride: int = 2, padding: int = 1, bias=None, relu: bool = False):

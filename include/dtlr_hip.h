@@ -197,6 +197,18 @@ int dtlr_groupnorm_tokens(const void *x, const float *gamma, const float *beta, 
                           int B, int T_tokens, int C, int groups, float eps, int dtype, void *stream);
 long dtlr_groupnorm_workspace_bytes(int B, int T_tokens);
 
+/* ---------------------------------------------------------------------------------------------
+ * ResNet stem convolution: 7x7 / stride 2 / pad 3, 3 -> 64 channels, on the bf16 matrix cores, reading the
+ * NCHW fp32 image directly (bf16-rounded operands, fp32 accumulate) and writing NHWC bf16.
+ * Replaces: torchvision resnet50 `conv1` (+ the FrozenBN scale folded into the weights, backbone.py:62-72) as run by
+ *           IntermediateLayerGetter (backbone.py:94-106); the FrozenBN shift + ReLU + max-pool follow in
+ *           dtlr_maxpool3x3s2_nhwc.
+ *   x [B,3,H,W] fp32 device ; y [B, (H-1)/2+1, (W-1)/2+1, 64] bf16 device
+ *   wfrag: device copy of the 24 KB fragment-major weight image built by dtlr_stem_pack_weights (a HOST-side helper:
+ *          both of its pointers are host memory; w_oihw = conv1.weight * bn_scale, [64,3,7,7] fp32). */
+int dtlr_stem_pack_weights(const float *w_oihw_host, unsigned short *wfrag_host /* [4*6*64*8] */);
+int dtlr_stem_conv7x7(const float *x, const void *wfrag, void *y, int B, int H, int W, int out_dtype, void *stream);
+
 /* 3x3 / stride 2 / pad 1 max pooling on NHWC, optionally preceded by a per-channel bias and ReLU:
  *     y = maxpool(relu(x + bias))      (bias NULL: no bias; relu 0: no ReLU)
  * Replaces: torchvision resnet50 `maxpool` as run through IntermediateLayerGetter (backbone.py:94,98), and with

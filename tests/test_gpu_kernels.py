@@ -386,3 +386,18 @@ def test_ffn_fused_bf16_vs_reference(M, dff):
     hh = ops.linear(x.cuda(), w1.cuda(), b1.cuda(), relu=True)
     un = ops.layernorm(ops.linear(hh, w2.cuda(), b2.cuda()), gw.cuda(), gb.cuda(), 1e-5, residual=x.cuda()).float().cpu()
     assert (got - un).abs().max() < 2 * tol
+
+
+@pytest.mark.parametrize("B,H,W", [(2, 128, 2048), (1, 37, 531), (3, 8, 16), (1, 128, 2560)])
+def test_stem_conv7x7_vs_reference(B, H, W):
+    """Own stem kernel (7x7/s2/p3, 3->64, NCHW fp32 in, NHWC bf16 out) vs torch conv2d in fp64 on the same
+    bf16-rounded image and weights; odd sizes exercise the zero padding and the column/row tails."""
+    import torch.nn.functional as F
+    from dtlr_amd import ops
+    x = _rand((B, 3, H, W), 1)
+    w = _rand((64, 3, 7, 7), 2) / 12
+    frag = ops.stem_pack_weights(w)
+    got = ops.stem_conv7x7(x.cuda(), frag.cuda()).float().cpu()
+    want = F.conv2d(x.bfloat16().double(), w.bfloat16().double(), None, stride=2, padding=3).permute(0, 2, 3, 1).float()
+    assert got.shape == want.shape
+    assert (got - want).abs().max() <= 2 ** -8 * max(1.0, want.abs().max().item()) + 1e-5
