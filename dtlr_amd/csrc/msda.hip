@@ -373,6 +373,149 @@ __global__ __launch_bounds__(256, sizeof(T) == 2 ? 2 : 3) void msda_fused_l4p4_k
     Vec<T, VEC>::store(out + si * D + c0, col);
 }
 
+// ---- bf16, D = 32: quad = (query, head); lane p owns channel piece p (8 channels) AND does the geometry of level p ---
+// The kernel above repeats the 16-point geometry + 16-logit softmax in all 8 lanes of a head (2/3 of its VALU work).
+// Here a quad shares it: lane p computes the 4 points of level p (corner offsets + bilinear x attention weights), and
+// every lane gets the other levels' 32 values by quad-broadcast DPP.  Each corner is then ONE 16-byte load per lane and
+// the four lanes of a quad read the 64 contiguous bytes of a pixel row (coalesced -- a first attempt that gave each lane a
+// whole level of its own made every load touch a private cache line and was 30% slower than the original).
+template <int CTRL> __device__ __forceinline__ float quad_bcast_f(float v) {
+    return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, 0xf, 0xf, false));
+}
+template <int CTRL> __device__ __forceinline__ int quad_bcast_i(int v) { return __builtin_amdgcn_update_dpp(0, v, CTRL, 0xf, 0xf, false); }
+__device__ __forceinline__ void unpack8_bf16(const uint4& t, float (&v)[8]) {
+    const uint32_t w[4] = {t.x, t.y, t.z, t.w};
+#pragma unroll
+    for (int i = 0; i < 4; ++i) { v[2 * i] = __uint_as_float(w[i] << 16); v[2 * i + 1] = __uint_as_float(w[i] & 0xffff0000u); }
+}
+template <typename OT> __device__ __forceinline__ void load8f(const OT* p, float (&v)[8]);
+template <> __device__ __forceinline__ void load8f<float>(const float* p, float (&v)[8]) {
+    const float4 a = reinterpret_cast<const float4*>(p)[0], b = reinterpret_cast<const float4*>(p)[1];
+    v[0] = a.x; v[1] = a.y; v[2] = a.z; v[3] = a.w; v[4] = b.x; v[5] = b.y; v[6] = b.z; v[7] = b.w;
+}
+template <> __device__ __forceinline__ void load8f<uint16_t>(const uint16_t* p, float (&v)[8]) { unpack8_bf16(*reinterpret_cast<const uint4*>(p), v); }
+template <typename OT> __device__ __forceinline__ void load4f(const OT* p, float (&v)[4]);
+template <> __device__ __forceinline__ void load4f<float>(const float* p, float (&v)[4]) {
+    const float4 a = *reinterpret_cast<const float4*>(p); v[0] = a.x; v[1] = a.y; v[2] = a.z; v[3] = a.w;
+}
+template <> __device__ __forceinline__ void load4f<uint16_t>(const uint16_t* p, float (&v)[4]) {
+    const uint2 t = *reinterpret_cast<const uint2*>(p);
+    v[0] = __uint_as_float(t.x << 16); v[1] = __uint_as_float(t.x & 0xffff0000u); v[2] = __uint_as_float(t.y << 16); v[3] = __uint_as_float(t.y & 0xffff0000u);
+}
+
+template <int L_, typename OT, int REFD>
+__device__ __forceinline__ void quad_level(const uint16_t* __restrict__ lbase, const int (&og)[4][4], const float (&kg)[4][4], float (&acc)[8])
+{
+    constexpr int CTRL = L_ * 0x55;                          // quad_perm [L,L,L,L]
+#pragma unroll
+    for (int pt = 0; pt < 4; ++pt) {
+        uint4 d[4];
+        float k[4];
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            const int o = quad_bcast_i<CTRL>(og[pt][c]);
+            k[c] = quad_bcast_f<CTRL>(kg[pt][c]);
+            d[c] = *reinterpret_cast<const uint4*>(lbase + o);
+        }
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            float v[8];
+            unpack8_bf16(d[c], v);
+#pragma unroll
+            for (int i = 0; i < 8; ++i) acc[i] += k[c] * v[i];
+        }
+    }
+}
+
+template <typename OT, int REFD>
+__global__ __launch_bounds__(128, 2) void msda_fused_quad_bf16_kernel(
+    const uint16_t* __restrict__ value, const int64_t* __restrict__ shapes, const int64_t* __restrict__ lsi,
+    const OT* __restrict__ ow, const float* __restrict__ ref,
+    int S, int M, int Lq, uint16_t* __restrict__ out, long total, int bpi, int nimg, int vstride)
+{
+    const long tid = xcd_block_map(blockIdx.x, bpi, nimg) * blockDim.x + threadIdx.x;
+    if (tid >= total) return;                       // total is a multiple of 4: quads are never split
+    const int p = (int)(tid & 3);
+    const long si = tid >> 2;                       // (b*Lq + q)*M + m
+    const int m = (int)(si % M);
+    const long bq = si / M;
+    const int b = (int)(bq / Lq);
+    const int Hl = (int)(p == 0 ? shapes[0] : p == 1 ? shapes[2] : p == 2 ? shapes[4] : shapes[6]);
+    const int Wl = (int)(p == 0 ? shapes[1] : p == 1 ? shapes[3] : p == 2 ? shapes[5] : shapes[7]);
+    const float fH = (float)Hl, fW = (float)Wl;
+    const OT* row = ow + bq * (long)(M * 48);
+    float off[8], lg[4];
+    load8f<OT>(row + m * 32 + p * 8, off);
+    load4f<OT>(row + M * 32 + m * 16 + p * 4, lg);
+    float rf[4];
+    if (REFD == 2) { const float2 t = *reinterpret_cast<const float2*>(ref + bq * 8 + 2 * p); rf[0] = t.x; rf[1] = t.y; rf[2] = rf[3] = 0.f; }
+    else { const float4 t = *reinterpret_cast<const float4*>(ref + bq * 16 + 4 * p); rf[0] = t.x; rf[1] = t.y; rf[2] = t.z; rf[3] = t.w; }
+    // softmax over the quad's 16 logits (ms_deform_attn.py:99-100)
+    float mx = fmaxf(fmaxf(lg[0], lg[1]), fmaxf(lg[2], lg[3]));
+    mx = fmaxf(mx, quad_bcast_f<0xB1>(mx));
+    mx = fmaxf(mx, quad_bcast_f<0x4E>(mx));
+    float sum = 0.f;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) { lg[i] = __expf(lg[i] - mx); sum += lg[i]; }
+    sum += quad_bcast_f<0xB1>(sum);
+    sum += quad_bcast_f<0x4E>(sum);
+    const float inv = 1.0f / sum;
+    // geometry of level p: element offsets of the 4 corners relative to the level base, weights = bilinear x attention
+    int og[4][4];
+    float kg[4][4];
+#pragma unroll
+    for (int pt = 0; pt < 4; ++pt) {
+        float lx, ly;
+        if (REFD == 2) { lx = rf[0] + off[2 * pt] / fW; ly = rf[1] + off[2 * pt + 1] / fH; }
+        else { lx = rf[0] + off[2 * pt] / 4.0f * rf[2] * 0.5f; ly = rf[1] + off[2 * pt + 1] / 4.0f * rf[3] * 0.5f; }
+        const float h_im = ly * fH - 0.5f, w_im = lx * fW - 0.5f;
+        const bool inside = h_im > -1.f && w_im > -1.f && h_im < fH && w_im < fW;
+        const float hf = floorf(h_im), wf = floorf(w_im);
+        const int h_low = (int)fminf(fmaxf(hf, -1.f), fH), w_low = (int)fminf(fmaxf(wf, -1.f), fW);
+        const int h_high = h_low + 1, w_high = w_low + 1;
+        const float lh = h_im - hf, lw = w_im - wf, hh = 1.f - lh, hw = 1.f - lw;
+        const bool top = inside && h_low >= 0, bot = inside && h_high <= Hl - 1, left = w_low >= 0, right = w_high <= Wl - 1;
+        const int h0 = min(max(h_low, 0), Hl - 1), h1 = max(min(h_high, Hl - 1), 0);
+        const int w0 = min(max(w_low, 0), Wl - 1), w1c = max(min(w_high, Wl - 1), 0);
+        const float a = lg[pt] * inv;
+        kg[pt][0] = (top && left) ? hh * hw * a : 0.f;  kg[pt][1] = (top && right) ? hh * lw * a : 0.f;
+        kg[pt][2] = (bot && left) ? lh * hw * a : 0.f;  kg[pt][3] = (bot && right) ? lh * lw * a : 0.f;
+        og[pt][0] = (h0 * Wl + w0) * vstride;  og[pt][1] = (h0 * Wl + w1c) * vstride;
+        og[pt][2] = (h1 * Wl + w0) * vstride;  og[pt][3] = (h1 * Wl + w1c) * vstride;
+    }
+    const uint16_t* vb = value + (long)b * S * vstride + m * 32 + p * 8;
+    float acc[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) acc[i] = 0.f;
+    quad_level<0, OT, REFD>(vb + lsi[0] * vstride, og, kg, acc);
+    __builtin_amdgcn_sched_barrier(0);
+    quad_level<1, OT, REFD>(vb + lsi[1] * vstride, og, kg, acc);
+    __builtin_amdgcn_sched_barrier(0);
+    quad_level<2, OT, REFD>(vb + lsi[2] * vstride, og, kg, acc);
+    __builtin_amdgcn_sched_barrier(0);
+    quad_level<3, OT, REFD>(vb + lsi[3] * vstride, og, kg, acc);
+    *reinterpret_cast<uint4*>(out + si * 32 + p * 8) =
+        make_uint4(pack_bf16x2(acc[0], acc[1]), pack_bf16x2(acc[2], acc[3]), pack_bf16x2(acc[4], acc[5]), pack_bf16x2(acc[6], acc[7]));
+}
+
+template <typename OT>
+static int launch_fused_quad(const void* value, const int64_t* shapes, const int64_t* lsi, const void* ow, const float* ref,
+                             int ref_dim, int N, int S, int M, int Lq, void* out, hipStream_t st, int vstride) {
+    const long total = (long)N * Lq * M * 4;
+    const int block = 128;
+    const long grid = (total + block - 1) / block;
+    if (grid > 0x7fffffffL) return DTLR_ESHAPE;
+    const long per_img = (long)Lq * M * 4;
+    const int bpi = (per_img % block == 0 && N % 8 == 0) ? (int)(per_img / block) : 0;
+    if (ref_dim == 2)
+        hipLaunchKernelGGL((msda_fused_quad_bf16_kernel<OT, 2>), dim3((unsigned)grid), dim3(block), 0, st,
+                           (const uint16_t*)value, shapes, lsi, (const OT*)ow, ref, S, M, Lq, (uint16_t*)out, total, bpi, N, vstride);
+    else
+        hipLaunchKernelGGL((msda_fused_quad_bf16_kernel<OT, 4>), dim3((unsigned)grid), dim3(block), 0, st,
+                           (const uint16_t*)value, shapes, lsi, (const OT*)ow, ref, S, M, Lq, (uint16_t*)out, total, bpi, N, vstride);
+    return check_launch();
+}
+
 template <typename T, typename OT, int VEC>
 static int launch_fused(const void* value, const int64_t* shapes, const int64_t* lsi, const void* ow, const float* ref,
                         int ref_dim, int N, int S, int M, int D, int Lq, void* out, hipStream_t st, int vstride) {
@@ -471,6 +614,11 @@ extern "C" int dtlr_msda_fused_forward_strided(const void* value, int value_row_
     hipStream_t st = (hipStream_t)stream;
     if (dtype == DTLR_F32 && D % 4 == 0) {
         if (ow_dtype == DTLR_F32) return launch_fused<float, float, 4>(value, shapes, lsi, ow, ref, ref_dim, N, S, M, D, Lq, out, st, vstride);
+        return DTLR_EDTYPE;
+    }
+    if (dtype == DTLR_BF16 && D == 32 && (long)S * vstride < (1L << 31)) {       // the hot configuration
+        if (ow_dtype == DTLR_F32) return launch_fused_quad<float>(value, shapes, lsi, ow, ref, ref_dim, N, S, M, Lq, out, st, vstride);
+        if (ow_dtype == DTLR_BF16) return launch_fused_quad<uint16_t>(value, shapes, lsi, ow, ref, ref_dim, N, S, M, Lq, out, st, vstride);
         return DTLR_EDTYPE;
     }
     if (dtype == DTLR_BF16 && D % 4 == 0) {
