@@ -269,6 +269,143 @@ __global__ __launch_bounds__(512, 2) void ffn_fused_bf16_kernel(
     }
 }
 
+
+// ---------------------------------------------------------------------------------------------------------------
+// Output projection + residual + LayerNorm of an attention block, bf16:   Y = LayerNorm(R + A W^T + b),  all [M, 256]
+// == `src = norm1(src + dropout1(self_attn(...)))` where the last op of self_attn is `output_proj`
+// (models/dino/deformable_transformer.py:810-815; ops/modules/ms_deform_attn.py:124), and the decoder's
+// `tgt = norm2(tgt + self_attn.out_proj(...))` / `tgt = norm1(tgt + cross_attn.output_proj(...))` (:847-870).
+// As GEMM + LayerNorm the projected rows make an HBM round trip (178 MB per encoder call); here they stay in the
+// accumulators.  Same building blocks as the fused FFN above: A^T of 32 tokens per wave in registers as B-fragments, the
+// whole 256x256 weight (128 KB) DMA'd into LDS in fragment order in four k-groups with counted waits, W's rows assigned
+// to MFMA rows so that a lane's accumulators are 8-channel runs (16-byte residual loads and stores), LayerNorm with one
+// exchange between the two waves of a token group.
+constexpr int PLN_LN_OFF = 128 * 1024;
+constexpr int PLN_LDS = PLN_LN_OFF + 4 * 2 * 32 * 4;
+
+__global__ __launch_bounds__(512, 2) void proj_ln_bf16_kernel(
+    const uint16_t* __restrict__ A, const uint16_t* __restrict__ W, const float* __restrict__ bias,
+    const uint16_t* __restrict__ R, const float* __restrict__ gamma, const float* __restrict__ beta, float eps,
+    uint16_t* __restrict__ Y, int M)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const unsigned lds_base = (unsigned)(size_t)(__attribute__((address_space(3))) unsigned char*)smem;
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const int tg = wave >> 1, half = wave & 1;
+    const int n = lane & 15, g = lane >> 4;
+    const long tok0 = (long)blockIdx.x * 128 + tg * 32;
+
+    uint4 af[8][2], rr[4][2];
+#pragma unroll
+    for (int tt = 0; tt < 2; ++tt) {
+        const long tok = min(tok0 + tt * 16 + n, (long)M - 1);
+#pragma unroll
+        for (int ks = 0; ks < 8; ++ks) af[ks][tt] = ffn_load16(A + tok * 256 + ks * 32 + g * 8);
+#pragma unroll
+        for (int kq = 0; kq < 4; ++kq) rr[kq][tt] = ffn_load16(R + tok * 256 + 128 * half + 32 * kq + 8 * g);
+    }
+    // weight DMA: k-group j = k-steps {2j, 2j+1}; wave w moves blocks 4w..4w+3 of each group: (i = 2w + (u>>1), ks = 2j + (u&1))
+    // block (i, ks) at LDS (i*8 + ks) KB: lane (m = n, g) <- W[sigma(i, m)][32 ks + 8 g ..],
+    // sigma(i, m) = 128 (i>>3) + 32 ((i&7)>>1) + 8 (m>>2) + 4 (i&1) + (m&3)
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int i = 2 * wave + (u >> 1), ks = 2 * j + (u & 1);
+            const int row = 128 * (i >> 3) + 32 * ((i & 7) >> 1) + 8 * (n >> 2) + 4 * (i & 1) + (n & 3);
+            glds16(W + (long)row * 256 + ks * 32 + g * 8, lds_base + (unsigned)(i * 8 + ks) * 1024u);
+        }
+    ffn_f32x4_t yacc[8][2];
+#pragma unroll
+    for (int i = 0; i < 8; ++i)
+#pragma unroll
+        for (int tt = 0; tt < 2; ++tt) yacc[i][tt] = ffn_f32x4_t{0.f, 0.f, 0.f, 0.f};
+#define PLN_GROUP(J, WAIT)                                                                         \
+    {                                                                                              \
+        asm volatile("s_waitcnt vmcnt(" #WAIT ")" ::: "memory");   /* A, R (older) and my pieces of groups <= J landed */ \
+        __builtin_amdgcn_sched_barrier(0);                                                         \
+        __builtin_amdgcn_s_barrier();                                                              \
+        _Pragma("unroll") for (int kk = 0; kk < 2; ++kk) {                                         \
+            const int ks = 2 * (J) + kk;                                                           \
+            uint4 wf[8];                                                                           \
+            _Pragma("unroll") for (int i = 0; i < 8; ++i)                                          \
+                wf[i] = *reinterpret_cast<const uint4*>(smem + ((8 * half + i) * 8 + ks) * 1024 + lane * 16); \
+            _Pragma("unroll") for (int i = 0; i < 8; ++i) {                                        \
+                yacc[i][0] = ffn_mma<0>(wf[i], af[ks][0], yacc[i][0]);                             \
+                yacc[i][1] = ffn_mma<0>(wf[i], af[ks][1], yacc[i][1]);                             \
+            }                                                                                      \
+        }                                                                                          \
+    }
+    PLN_GROUP(0, 12) PLN_GROUP(1, 8) PLN_GROUP(2, 4) PLN_GROUP(3, 0)
+#undef PLN_GROUP
+
+    // ---- epilogue: + bias + residual, LayerNorm over 256 channels, store (as in the fused FFN) -------------------------
+    float v[2][4][8];
+    float s[2] = {0.f, 0.f};
+#pragma unroll
+    for (int kq = 0; kq < 4; ++kq) {
+        const int ch = 128 * half + 32 * kq + 8 * g;
+        const float4 ba = *reinterpret_cast<const float4*>(bias + ch), bc = *reinterpret_cast<const float4*>(bias + ch + 4);
+        const float bs[8] = {ba.x, ba.y, ba.z, ba.w, bc.x, bc.y, bc.z, bc.w};
+#pragma unroll
+        for (int tt = 0; tt < 2; ++tt) {
+            float xr[8];
+            unpack8(rr[kq][tt], xr);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                const float y = e < 4 ? yacc[2 * kq][tt][e] : yacc[2 * kq + 1][tt][e - 4];
+                v[tt][kq][e] = y + bs[e] + xr[e];
+                s[tt] += v[tt][kq][e];
+            }
+        }
+    }
+    float* lnx = reinterpret_cast<float*>(smem + PLN_LN_OFF) + tg * 64;
+    float mean[2], rstd[2];
+#pragma unroll
+    for (int tt = 0; tt < 2; ++tt) {
+        s[tt] += __shfl_xor(s[tt], 16, 64);
+        s[tt] += __shfl_xor(s[tt], 32, 64);
+        if (g == 0) lnx[half * 32 + tt * 16 + n] = s[tt];
+    }
+    __syncthreads();
+#pragma unroll
+    for (int tt = 0; tt < 2; ++tt) mean[tt] = (s[tt] + lnx[(half ^ 1) * 32 + tt * 16 + n]) * (1.0f / 256.0f);
+    __syncthreads();
+    float q[2] = {0.f, 0.f};
+#pragma unroll
+    for (int tt = 0; tt < 2; ++tt) {
+#pragma unroll
+        for (int kq = 0; kq < 4; ++kq)
+#pragma unroll
+            for (int e = 0; e < 8; ++e) { const float d = v[tt][kq][e] - mean[tt]; q[tt] += d * d; }
+        q[tt] += __shfl_xor(q[tt], 16, 64);
+        q[tt] += __shfl_xor(q[tt], 32, 64);
+        if (g == 0) lnx[half * 32 + tt * 16 + n] = q[tt];
+    }
+    __syncthreads();
+#pragma unroll
+    for (int tt = 0; tt < 2; ++tt) rstd[tt] = rsqrtf((q[tt] + lnx[(half ^ 1) * 32 + tt * 16 + n]) * (1.0f / 256.0f) + eps);
+#pragma unroll
+    for (int kq = 0; kq < 4; ++kq) {
+        const int ch = 128 * half + 32 * kq + 8 * g;
+        const float4 ga = *reinterpret_cast<const float4*>(gamma + ch), gc = *reinterpret_cast<const float4*>(gamma + ch + 4);
+        const float4 ea = *reinterpret_cast<const float4*>(beta + ch), ec = *reinterpret_cast<const float4*>(beta + ch + 4);
+        const float gm[8] = {ga.x, ga.y, ga.z, ga.w, gc.x, gc.y, gc.z, gc.w};
+        const float bt[8] = {ea.x, ea.y, ea.z, ea.w, ec.x, ec.y, ec.z, ec.w};
+#pragma unroll
+        for (int tt = 0; tt < 2; ++tt) {
+            const long tok = tok0 + tt * 16 + n;
+            float o[8];
+#pragma unroll
+            for (int e = 0; e < 8; ++e) o[e] = (v[tt][kq][e] - mean[tt]) * rstd[tt] * gm[e] + bt[e];
+            if (tok < M)
+                *reinterpret_cast<uint4*>(Y + tok * 256 + ch) =
+                    make_uint4(pack_bf16x2(o[0], o[1]), pack_bf16x2(o[2], o[3]), pack_bf16x2(o[4], o[5]), pack_bf16x2(o[6], o[7]));
+        }
+    }
+}
+
 }  // namespace dtlr
 
 using namespace dtlr;
@@ -301,5 +438,19 @@ extern "C" int dtlr_ffn_fused_bf16(const void* X, const void* W1, const float* b
     default: FFN_LAUNCH(0) break;
     }
 #undef FFN_LAUNCH
+    return check_launch();
+}
+
+extern "C" int dtlr_proj_ln_bf16(const void* A, const void* W, const float* bias, const void* R,
+                                 const float* gamma, const float* beta, float eps, void* Y, int M, int d_model, void* stream)
+{
+    clear_stale_error();
+    if (!A || !W || !bias || !R || !gamma || !beta || !Y) return DTLR_EINVAL;
+    if (M <= 0) return DTLR_EINVAL;
+    if (d_model != 256) return DTLR_ESHAPE;
+    static bool attr = false;
+    if (!attr) { (void)hipFuncSetAttribute((const void*)proj_ln_bf16_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, PLN_LDS); (void)hipGetLastError(); attr = true; }
+    hipLaunchKernelGGL(proj_ln_bf16_kernel, dim3((unsigned)((M + 127) / 128)), dim3(512), PLN_LDS, (hipStream_t)stream,
+                       (const uint16_t*)A, (const uint16_t*)W, bias, (const uint16_t*)R, gamma, beta, eps, (uint16_t*)Y, M);
     return check_launch();
 }

@@ -165,6 +165,13 @@ class DTLREngine:
     def _ln(self, name, x, residual=None):
         return ops.layernorm(x, self.w[name + ".w"], self.w[name + ".b"], 1e-5, residual)
 
+    def _proj_ln(self, proj, norm, a, residual):
+        """output projection of an attention block + residual + post-norm (deformable_transformer.py:810-815, 847-870)."""
+        w = self.w
+        if self.use_fused_ffn and a.dtype == torch.bfloat16 and a.shape[-1] == 256:
+            return ops.proj_ln(a, w[proj + ".w"], w[proj + ".b"], residual, w[norm + ".w"], w[norm + ".b"])
+        return self._ln(norm, self._lin(proj, a), residual=residual)
+
     def _ffn(self, q, norm, x):
         """forward_ffn + post-norm (deformable_transformer.py:804-823, 876-880).  bf16 engine: one fused kernel, the
         d_ff-wide intermediate stays on chip; fp32 engine: two GEMMs + LayerNorm."""
@@ -304,7 +311,7 @@ class DTLREngine:
         for n in range(self.cfg.enc_layers):
             q = f"enc{n}."
             a = self._msda_module(q + "attn", src, pos, g["enc_ref"], src, g, self.cfg.enc_n_points)
-            src = self._ln(q + "norm1", self._lin(q + "attn.out", a), residual=src)
+            src = self._proj_ln(q + "attn.out", q + "norm1", a, src)
             src = self._ffn(q, "norm2", src)
         return src
 
@@ -374,10 +381,10 @@ class DTLREngine:
             qk = self._lin(q + "sa.qk", tgt, a2=qpos)
             v = self._lin(q + "sa.v", tgt)
             a = ops.mha(qk, v, cfg.nheads)
-            tgt = self._ln(q + "norm2", self._lin(q + "sa.out", a), residual=tgt)
+            tgt = self._proj_ln(q + "sa.out", q + "norm2", a, tgt)
             # deformable cross attention
             a = self._msda_module(q + "attn", tgt, qpos, ref_in, memory, g, cfg.dec_n_points, value=vall[..., n * C:(n + 1) * C])
-            tgt = self._ln(q + "norm1", self._lin(q + "attn.out", a), residual=tgt)
+            tgt = self._proj_ln(q + "attn.out", q + "norm1", a, tgt)
             # ffn
             tgt = self._ffn(q, "norm3", tgt)
             # iterative box refinement (734-756)

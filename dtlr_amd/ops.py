@@ -118,6 +118,22 @@ def layernorm(x, w, b, eps: float = 1e-5, residual=None):
     return y
 
 
+def proj_ln(a, w, b, residual, ln_w, ln_b, eps: float = 1e-5):
+    """LayerNorm(residual + a W^T + b) in ONE kernel (dtlr_proj_ln_bf16): the attention block's output projection with its
+    post-norm; a, residual [..., 256] bf16, W [256,256] bf16, b / LN params fp32."""
+    require_cuda(a, "a")
+    assert a.dtype == torch.bfloat16 and residual.dtype == torch.bfloat16 and w.dtype == torch.bfloat16 and a.shape[-1] == 256
+    a = a if a.is_contiguous() else a.contiguous()
+    residual = residual if residual.is_contiguous() else residual.contiguous()
+    y = torch.empty_like(residual)
+    M = a.numel() // 256
+    with _Timed("proj_ln_bf16", 2.0 * M * 256 * 256):
+        code = _lib.lib().dtlr_proj_ln_bf16(a.data_ptr(), w.data_ptr(), b.data_ptr(), residual.data_ptr(), ln_w.data_ptr(), ln_b.data_ptr(),
+                                            eps, y.data_ptr(), M, 256, _lib.current_stream())
+    _lib.check(code, "dtlr_proj_ln_bf16")
+    return y
+
+
 def ffn_fused_supported(x, w1) -> bool:
     """The fused FFN kernel covers the bf16 engine at d_model 256, d_ff <= 2048 (multiple of 32)."""
     return x.dtype == torch.bfloat16 and x.shape[-1] == 256 and w1.shape[0] % 32 == 0 and w1.shape[0] <= 2048

@@ -401,3 +401,21 @@ def test_stem_conv7x7_vs_reference(B, H, W):
     want = F.conv2d(x.bfloat16().double(), w.bfloat16().double(), None, stride=2, padding=3).permute(0, 2, 3, 1).float()
     assert got.shape == want.shape
     assert (got - want).abs().max() <= 2 ** -8 * max(1.0, want.abs().max().item()) + 1e-5
+
+
+@pytest.mark.parametrize("M", [128, 300, 4097, 37])
+def test_proj_ln_bf16_vs_reference(M):
+    """Fused output projection + residual + LayerNorm (dtlr_proj_ln_bf16) vs fp64 on the same bf16 inputs, and vs the
+    unfused HIP path (GEMM with residual epilogue + LayerNorm kernel)."""
+    from dtlr_amd import ops
+    a, r = _rand((M, 256), 1).bfloat16(), _rand((M, 256), 2).bfloat16()
+    w = (_rand((256, 256), 3) / 16).bfloat16()
+    b = _rand((256,), 4) * 0.5
+    gw, gb = 1 + 0.2 * _rand((256,), 6), 0.3 * _rand((256,), 7)
+    pre = r.double() + a.double() @ w.double().t() + b.double()
+    want = torch.nn.functional.layer_norm(pre, (256,), gw.double(), gb.double(), 1e-5).float()
+    got = ops.proj_ln(a.cuda(), w.cuda(), b.cuda(), r.cuda(), gw.cuda(), gb.cuda()).float().cpu()
+    tol = 2 ** -8 * max(1.0, want.abs().max().item()) + 1e-3
+    assert (got - want).abs().max() < tol, (got - want).abs().max().item()
+    un = ops.layernorm(ops.linear(a.cuda(), w.cuda(), b.cuda()), gw.cuda(), gb.cuda(), 1e-5, residual=r.cuda()).float().cpu()
+    assert (got - un).abs().max() < 3 * tol
