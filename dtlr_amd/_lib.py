@@ -44,6 +44,7 @@ _SIGNATURES = {
                                  c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p]),
     "dtlr_decoder_query_prep": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p]),
     "dtlr_box_refine": (c_int, [c_void_p, c_void_p, c_void_p, ctypes.c_long, c_void_p]),
+    "dtlr_groupnorm_tokens_strided": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, ctypes.c_long, c_void_p, c_int, c_int, c_int, c_int, c_float, c_int, c_void_p]),
     "dtlr_groupnorm_tokens": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_float, c_int, c_void_p]),
     "dtlr_groupnorm_workspace_bytes": (ctypes.c_long, [c_int, c_int]),
     "dtlr_box_head_refine": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, ctypes.c_long, c_int, c_int, c_void_p]),

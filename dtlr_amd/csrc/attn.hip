@@ -124,7 +124,7 @@ __global__ __launch_bounds__(256) void mha_fwd_bf16_kernel(const uint16_t* __res
 // and its waves walk the query blocks (wave w takes blocks w, w+16) reading operands with ds_read_b128.
 //   K image : key tile t (16 keys)           at t * 1024       : lane (g, n) <- K[16 t + n][8 g .. 8 g + 7]
 //   V^T image: key block j (32 keys), d tile  at (2 j + dt) * 1024: lane (g, n) <- V^T[16 dt + n][32 j + 4 g .. +3 | 32 j + 16 + 4 g .. +3]
-// Same arithmetic, same operand values and order as mha_fwd_bf16_kernel: results are bit-identical.
+// Same operand values as mha_fwd_bf16_kernel; the softmax scale is applied by FMA here (results agree to fp32 rounding).
 // reductions over the four lanes {n, n+16, n+32, n+48} of a query with the gfx950 row/half swaps (VALU, no LDS round trip):
 // permlane16_swap(x, x) = ([x0,x0,x2,x2], [x1,x1,x3,x3]) by 16-lane rows, permlane32_swap(y, y) = ([lo,lo], [hi,hi])
 __device__ __forceinline__ float g4_max(float x) {
@@ -184,49 +184,50 @@ __global__ __launch_bounds__(1024) void mha_fwd_bf16_lds_kernel(const uint16_t* 
 #pragma unroll
             for (int dt = 0; dt < 2; ++dt) o[qt][dt] = f32x4{0.f, 0.f, 0.f, 0.f};
         float m[2] = {-INFINITY, -INFINITY}, lsum[2] = {0.f, 0.f};
-        for (int j = 0; j < nkb; ++j) {
-            const int kb = j * 32;
-            bf16x8 kf[2], vf[2];
-#pragma unroll
-            for (int t = 0; t < 2; ++t) {
-                kf[t] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const uint4*>(kimg + (2 * j + t) * 1024 + lane * 16));
-                vf[t] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const uint4*>(vimg + (2 * j + t) * 1024 + lane * 16));
-            }
-#pragma unroll
-            for (int qt = 0; qt < 2; ++qt) {
-                f32x4 sc[2];
-#pragma unroll
-                for (int kt = 0; kt < 2; ++kt)
-                    sc[kt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf[kt], qf[qt], f32x4{0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
-                float mx = -INFINITY;
-#pragma unroll
-                for (int kt = 0; kt < 2; ++kt)
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) {
-                        const int key = kb + kt * 16 + 4 * g + r;
-                        const float v = key < L ? sc[kt][r] * scale_log2e : -INFINITY;
-                        sc[kt][r] = v;
-                        mx = fmaxf(mx, v);
-                    }
-                mx = g4_max(mx);
-                const float m_new = fmaxf(m[qt], mx);
-                const float alpha = __builtin_amdgcn_exp2f(m[qt] - m_new);
-                m[qt] = m_new;
-                float ps = 0.f;
-#pragma unroll
-                for (int kt = 0; kt < 2; ++kt)
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) { sc[kt][r] = __builtin_amdgcn_exp2f(sc[kt][r] - m_new); ps += sc[kt][r]; }
-                lsum[qt] = lsum[qt] * alpha + ps;
-                const bf16x8 pf = __builtin_bit_cast(bf16x8, make_uint4(pack2(sc[0][0], sc[0][1]), pack2(sc[0][2], sc[0][3]),
-                                                                        pack2(sc[1][0], sc[1][1]), pack2(sc[1][2], sc[1][3])));
-#pragma unroll
-                for (int dt = 0; dt < 2; ++dt) {
-                    o[qt][dt] *= alpha;
-                    o[qt][dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vf[dt], pf, o[qt][dt], 0, 0, 0);
-                }
-            }
+        // one 32-key block; MASKED only for the last one (keys >= L are padding).  The softmax scale is folded into one FMA per
+        // score (exp2(s*c - m)) and the running maximum is kept in scaled units: 149 -> ~110 VALU instructions per block, and
+        // this kernel is bound by exactly that work.
+#define MHA_KEY_BLOCK(J, MASKED)                                                                   \
+        {                                                                                          \
+            const int kb = (J) * 32;                                                               \
+            bf16x8 kf[2], vf[2];                                                                   \
+            _Pragma("unroll") for (int t = 0; t < 2; ++t) {                                        \
+                kf[t] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const uint4*>(kimg + (2 * (J) + t) * 1024 + lane * 16)); \
+                vf[t] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const uint4*>(vimg + (2 * (J) + t) * 1024 + lane * 16)); \
+            }                                                                                      \
+            _Pragma("unroll") for (int qt = 0; qt < 2; ++qt) {                                     \
+                f32x4 sc[2];                                                                       \
+                _Pragma("unroll") for (int kt = 0; kt < 2; ++kt)                                   \
+                    sc[kt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf[kt], qf[qt], f32x4{0.f, 0.f, 0.f, 0.f}, 0, 0, 0); \
+                if (MASKED) {                                                                      \
+                    _Pragma("unroll") for (int kt = 0; kt < 2; ++kt)                               \
+                        _Pragma("unroll") for (int r = 0; r < 4; ++r)                              \
+                            if (kb + kt * 16 + 4 * g + r >= L) sc[kt][r] = -INFINITY;              \
+                }                                                                                  \
+                float mx = fmaxf(fmaxf(fmaxf(sc[0][0], sc[0][1]), fmaxf(sc[0][2], sc[0][3])),      \
+                                 fmaxf(fmaxf(sc[1][0], sc[1][1]), fmaxf(sc[1][2], sc[1][3])));     \
+                mx = g4_max(mx) * scale_log2e;                                                     \
+                const float m_new = fmaxf(m[qt], mx);       /* finite: every key block has >= 1 valid key */ \
+                const float alpha = __builtin_amdgcn_exp2f(m[qt] - m_new);                         \
+                m[qt] = m_new;                                                                     \
+                float ps = 0.f;                                                                    \
+                _Pragma("unroll") for (int kt = 0; kt < 2; ++kt)                                   \
+                    _Pragma("unroll") for (int r = 0; r < 4; ++r) {                                \
+                        sc[kt][r] = __builtin_amdgcn_exp2f(__builtin_fmaf(sc[kt][r], scale_log2e, -m_new)); \
+                        ps += sc[kt][r];                                                           \
+                    }                                                                              \
+                lsum[qt] = lsum[qt] * alpha + ps;                                                  \
+                const bf16x8 pf = __builtin_bit_cast(bf16x8, make_uint4(pack2(sc[0][0], sc[0][1]), pack2(sc[0][2], sc[0][3]), \
+                                                                        pack2(sc[1][0], sc[1][1]), pack2(sc[1][2], sc[1][3]))); \
+                _Pragma("unroll") for (int dt = 0; dt < 2; ++dt) {                                 \
+                    o[qt][dt] *= alpha;                                                            \
+                    o[qt][dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vf[dt], pf, o[qt][dt], 0, 0, 0); \
+                }                                                                                  \
+            }                                                                                      \
         }
+        for (int j = 0; j + 1 < nkb; ++j) MHA_KEY_BLOCK(j, false)
+        MHA_KEY_BLOCK(nkb - 1, true)
+#undef MHA_KEY_BLOCK
 #pragma unroll
         for (int qt = 0; qt < 2; ++qt) {
             float l = lsum[qt];

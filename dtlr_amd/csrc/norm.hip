@@ -142,7 +142,8 @@ __global__ __launch_bounds__(256) void gn_partial_kernel(const T* __restrict__ x
 template <typename T>
 __global__ __launch_bounds__(256) void gn_apply_kernel(const T* __restrict__ x, const float2* __restrict__ part,
                                                        const float* __restrict__ gamma, const float* __restrict__ beta,
-                                                       T* __restrict__ y, int T_tokens, int nslab, int rows_per_block, float eps)
+                                                       T* __restrict__ y, int T_tokens, int nslab, int rows_per_block, float eps,
+                                                       long y_bstride)
 {
     __shared__ float2 stat[32];                     // (mean, rstd) per group
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -161,13 +162,21 @@ __global__ __launch_bounds__(256) void gn_apply_kernel(const T* __restrict__ x, 
     const float4 ga = *reinterpret_cast<const float4*>(gamma + 4 * lane);
     const float4 be = *reinterpret_cast<const float4*>(beta + 4 * lane);
     const int r0 = blockIdx.x * rows_per_block, r1 = min(r0 + rows_per_block, T_tokens);
-    for (int r = r0 + wave; r < r1; r += 4) {
-        const long off = ((long)b * T_tokens + r) * 256 + 4 * lane;
-        float v[4];
-        IO<T>::load4(x + off, v);
-        float o[4] = {(v[0] - st.x) * st.y * ga.x + be.x, (v[1] - st.x) * st.y * ga.y + be.y,
-                      (v[2] - st.x) * st.y * ga.z + be.z, (v[3] - st.x) * st.y * ga.w + be.w};
-        IO<T>::store4(y + off, o);
+    // four rows per pass, loads before stores (a load issued after a store waits for that store's round trip: vmcnt is shared)
+    for (int r = r0 + wave; r < r1; r += 16) {
+        float v[4][4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int rr = min(r + 4 * u, r1 - 1);
+            IO<T>::load4(x + ((long)b * T_tokens + rr) * 256 + 4 * lane, v[u]);
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            if (r + 4 * u >= r1) break;
+            float o[4] = {(v[u][0] - st.x) * st.y * ga.x + be.x, (v[u][1] - st.x) * st.y * ga.y + be.y,
+                          (v[u][2] - st.x) * st.y * ga.z + be.z, (v[u][3] - st.x) * st.y * ga.w + be.w};
+            IO<T>::store4(y + (long)b * y_bstride + (long)(r + 4 * u) * 256 + 4 * lane, o);
+        }
     }
 }
 
@@ -232,7 +241,15 @@ extern "C" long dtlr_groupnorm_workspace_bytes(int B, int T_tokens)
 extern "C" int dtlr_groupnorm_tokens(const void* x, const float* gamma, const float* beta, void* y, void* workspace,
                                      int B, int T_tokens, int C, int groups, float eps, int dtype, void* stream)
 {
+    return dtlr_groupnorm_tokens_strided(x, gamma, beta, y, 0, workspace, B, T_tokens, C, groups, eps, dtype, stream);
+}
+
+extern "C" int dtlr_groupnorm_tokens_strided(const void* x, const float* gamma, const float* beta, void* y, long y_batch_stride,
+                                             void* workspace, int B, int T_tokens, int C, int groups, float eps, int dtype, void* stream)
+{
     clear_stale_error();
+    const long ybs = y_batch_stride > 0 ? y_batch_stride : (long)T_tokens * 256;
+    if (ybs < (long)T_tokens * 256) return DTLR_EINVAL;
     if (!x || !gamma || !beta || !y || !workspace) return DTLR_EINVAL;
     if (B <= 0 || T_tokens <= 0) return DTLR_EINVAL;
     if (C != 256 || groups != 32) return DTLR_ESHAPE;
@@ -243,10 +260,10 @@ extern "C" int dtlr_groupnorm_tokens(const void* x, const float* gamma, const fl
     const int nblk = (T_tokens + rows_per_block - 1) / rows_per_block;
     if (dtype == DTLR_F32) {
         hipLaunchKernelGGL((gn_partial_kernel<float>), dim3(nslab, B), dim3(256), 0, st, (const float*)x, (float2*)workspace, T_tokens, rows_per_slab);
-        hipLaunchKernelGGL((gn_apply_kernel<float>), dim3(nblk, B), dim3(256), 0, st, (const float*)x, (const float2*)workspace, gamma, beta, (float*)y, T_tokens, nslab, rows_per_block, eps);
+        hipLaunchKernelGGL((gn_apply_kernel<float>), dim3(nblk, B), dim3(256), 0, st, (const float*)x, (const float2*)workspace, gamma, beta, (float*)y, T_tokens, nslab, rows_per_block, eps, ybs);
     } else if (dtype == DTLR_BF16) {
         hipLaunchKernelGGL((gn_partial_kernel<uint16_t>), dim3(nslab, B), dim3(256), 0, st, (const uint16_t*)x, (float2*)workspace, T_tokens, rows_per_slab);
-        hipLaunchKernelGGL((gn_apply_kernel<uint16_t>), dim3(nblk, B), dim3(256), 0, st, (const uint16_t*)x, (const float2*)workspace, gamma, beta, (uint16_t*)y, T_tokens, nslab, rows_per_block, eps);
+        hipLaunchKernelGGL((gn_apply_kernel<uint16_t>), dim3(nblk, B), dim3(256), 0, st, (const uint16_t*)x, (const float2*)workspace, gamma, beta, (uint16_t*)y, T_tokens, nslab, rows_per_block, eps, ybs);
     } else return DTLR_EDTYPE;
     return check_launch();
 }

@@ -422,13 +422,15 @@ class DTLREngine:
                 if len(self._shape_cache) > 8:
                     self._shape_cache.clear()
                 self._shape_cache[gkey] = g
-        srcs = []
-        for l, f in enumerate(feats):
-            t = self._lin(f"ip{l}", f.flatten(1, 2))
-            srcs.append(ops.groupnorm_tokens(t, 32, self.w[f"ip{l}.gn.w"], self.w[f"ip{l}.gn.b"]))
-        l = len(feats)
-        srcs.append(ops.groupnorm_tokens(last.flatten(1, 2), 32, self.w[f"ip{l}.gn.w"], self.w[f"ip{l}.gn.b"]))
-        src = torch.cat(srcs, 1)
+        # each level is normalised straight into its rows of the concatenated token matrix (no torch.cat pass)
+        S_tot = sum(h * w for h, w in level_hw)
+        src = torch.empty((B, S_tot, cfg.hidden_dim), dtype=self.dtype, device=x.device)
+        off = 0
+        for l, f in enumerate(feats + [last]):
+            t = self._lin(f"ip{l}", f.flatten(1, 2)) if l < len(feats) else f.flatten(1, 2)
+            T_l = t.shape[1]
+            ops.groupnorm_tokens(t, 32, self.w[f"ip{l}.gn.w"], self.w[f"ip{l}.gn.b"], out=src[:, off:off + T_l])
+            off += T_l
         memory = self.encoder(src, g)
         ts = self.two_stage(memory, g, forced_topk)
         hs, refs = self.decoder(memory, ts, g, want_aux)

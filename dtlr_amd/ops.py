@@ -229,16 +229,18 @@ def maxpool_nhwc(x, k: int = 3, stride: int = 2, padding: int = 1, bias=None, re
     return y
 
 
-def groupnorm_tokens(x, groups: int, w, b, eps: float = 1e-5):
+def groupnorm_tokens(x, groups: int, w, b, eps: float = 1e-5, out=None):
     """GroupNorm(32, 256) over [B, T, C] tokens of one feature level: statistics per (sample,
     group) over (C/groups channels x T positions) -- models/dino/dino.py:121-134 (HIP kernels)."""
     B, T, C = x.shape
     x = x if x.is_contiguous() else x.contiguous()
     L_ = _lib.lib()
     ws = torch.empty(L_.dtlr_groupnorm_workspace_bytes(B, T), dtype=torch.uint8, device=x.device)
-    y = torch.empty_like(x)
-    code = L_.dtlr_groupnorm_tokens(x.data_ptr(), w.data_ptr(), b.data_ptr(), y.data_ptr(), ws.data_ptr(), B, T, C, groups, eps,
-                                    _DT[x.dtype], _lib.current_stream())
+    # out: a [B, T, C] slice (dim 1) of a larger contiguous [B, S, C] token matrix -- the level is normalised straight into place
+    y = torch.empty_like(x) if out is None else out
+    assert y.shape == x.shape and y.dtype == x.dtype and y.stride(2) == 1 and y.stride(1) == C
+    code = L_.dtlr_groupnorm_tokens_strided(x.data_ptr(), w.data_ptr(), b.data_ptr(), y.data_ptr(), y.stride(0), ws.data_ptr(),
+                                            B, T, C, groups, eps, _DT[x.dtype], _lib.current_stream())
     _lib.check(code, "dtlr_groupnorm_tokens")
     return y
 

@@ -205,6 +205,11 @@ int dtlr_box_head_refine(const float *h, const float *W, const float *bias, cons
  */
 int dtlr_groupnorm_tokens(const void *x, const float *gamma, const float *beta, void *y, void *workspace,
                           int B, int T_tokens, int C, int groups, float eps, int dtype, void *stream);
+/* Same, writing level l's tokens straight into the concatenated [B, S, 256] token matrix the encoder consumes
+ * (`torch.cat(src_flatten, 1)`, deformable_transformer.py:278-285): y points at the level's first token of image 0 and
+ * y_batch_stride (elements, >= T*256; 0 = T*256) is the distance between images. */
+int dtlr_groupnorm_tokens_strided(const void *x, const float *gamma, const float *beta, void *y, long y_batch_stride,
+                                  void *workspace, int B, int T_tokens, int C, int groups, float eps, int dtype, void *stream);
 long dtlr_groupnorm_workspace_bytes(int B, int T_tokens);
 
 /* ---------------------------------------------------------------------------------------------
