@@ -280,10 +280,14 @@ __global__ __launch_bounds__(512, 2) void ffn_fused_bf16_kernel(
 // whole 256x256 weight (128 KB) DMA'd into LDS in fragment order in four k-groups with counted waits, W's rows assigned
 // to MFMA rows so that a lane's accumulators are 8-channel runs (16-byte residual loads and stores), LayerNorm with one
 // exchange between the two waves of a token group.
-constexpr int PLN_LN_OFF = 128 * 1024;
-constexpr int PLN_LDS = PLN_LN_OFF + 4 * 2 * 32 * 4;
+// Workgroup = 64 tokens, 4 waves (token group tg, channel half h); the weight streams through a 2-stage ring of k-groups
+// (2 x 32 KB) so that TWO workgroups fit a CU and one's load phase overlaps the other's MFMA phase.  (First version: 128
+// tokens, 8 waves, the whole 128 KB weight resident -> one workgroup per CU, its phases strictly serial: 107 us per encoder
+// call against 60 us of HBM time.)
+constexpr int PLN_LN_OFF = 64 * 1024;
+constexpr int PLN_LDS = PLN_LN_OFF + 2 * 2 * 32 * 4;
 
-__global__ __launch_bounds__(512, 2) void proj_ln_bf16_kernel(
+__global__ __launch_bounds__(256, 2) void proj_ln_bf16_kernel(
     const uint16_t* __restrict__ A, const uint16_t* __restrict__ W, const float* __restrict__ bias,
     const uint16_t* __restrict__ R, const float* __restrict__ gamma, const float* __restrict__ beta, float eps,
     uint16_t* __restrict__ Y, int M)
@@ -294,7 +298,7 @@ __global__ __launch_bounds__(512, 2) void proj_ln_bf16_kernel(
     const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     const int tg = wave >> 1, half = wave & 1;
     const int n = lane & 15, g = lane >> 4;
-    const long tok0 = (long)blockIdx.x * 128 + tg * 32;
+    const long tok0 = (long)blockIdx.x * 64 + tg * 32;
 
     uint4 af[8][2], rr[4][2];
 #pragma unroll
@@ -305,40 +309,43 @@ __global__ __launch_bounds__(512, 2) void proj_ln_bf16_kernel(
 #pragma unroll
         for (int kq = 0; kq < 4; ++kq) rr[kq][tt] = ffn_load16(R + tok * 256 + 128 * half + 32 * kq + 8 * g);
     }
-    // weight DMA: k-group j = k-steps {2j, 2j+1}; wave w moves blocks 4w..4w+3 of each group: (i = 2w + (u>>1), ks = 2j + (u&1))
-    // block (i, ks) at LDS (i*8 + ks) KB: lane (m = n, g) <- W[sigma(i, m)][32 ks + 8 g ..],
-    // sigma(i, m) = 128 (i>>3) + 32 ((i&7)>>1) + 8 (m>>2) + 4 (i&1) + (m&3)
-#pragma unroll
-    for (int j = 0; j < 4; ++j)
-#pragma unroll
-        for (int u = 0; u < 4; ++u) {
-            const int i = 2 * wave + (u >> 1), ks = 2 * j + (u & 1);
-            const int row = 128 * (i >> 3) + 32 * ((i & 7) >> 1) + 8 * (n >> 2) + 4 * (i & 1) + (n & 3);
-            glds16(W + (long)row * 256 + ks * 32 + g * 8, lds_base + (unsigned)(i * 8 + ks) * 1024u);
-        }
+    // weight DMA: k-group j = k-steps {2j, 2j+1} = 32 blocks of 1 KB, 8 per wave: block (i = 4 w + (u>>1), kk = u&1) of the
+    // group goes to ring stage j&1 at ((i*2 + kk) KB).  W is pre-packed in image order (dtlr_proj_pack_weights): block
+    // (i, ks) is the contiguous KB number i*8 + ks -- every DMA instruction reads 1 KB of contiguous memory.
+#define PLN_ISSUE(J)                                                                               \
+    {                                                                                              \
+        _Pragma("unroll") for (int u = 0; u < 8; ++u) {                                            \
+            const int i = 4 * wave + (u >> 1), kk = u & 1;                                         \
+            glds16(W + ((long)(i * 8 + 2 * (J) + kk) * 64 + lane) * 8,                             \
+                   lds_base + (unsigned)(((J) & 1) * 32768 + (i * 2 + kk) * 1024));               \
+        }                                                                                          \
+    }
+    PLN_ISSUE(0)
     ffn_f32x4_t yacc[8][2];
 #pragma unroll
     for (int i = 0; i < 8; ++i)
 #pragma unroll
         for (int tt = 0; tt < 2; ++tt) yacc[i][tt] = ffn_f32x4_t{0.f, 0.f, 0.f, 0.f};
-#define PLN_GROUP(J, WAIT)                                                                         \
+#define PLN_GROUP(J)                                                                               \
     {                                                                                              \
-        asm volatile("s_waitcnt vmcnt(" #WAIT ")" ::: "memory");   /* A, R (older) and my pieces of groups <= J landed */ \
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   /* A, R and my pieces of group J landed */ \
         __builtin_amdgcn_sched_barrier(0);                                                         \
-        __builtin_amdgcn_s_barrier();                                                              \
+        __builtin_amdgcn_s_barrier();                      /* ... everyone's; and everyone is done reading the other stage */ \
+        if ((J) + 1 < 4) PLN_ISSUE((J) + 1)                                                        \
         _Pragma("unroll") for (int kk = 0; kk < 2; ++kk) {                                         \
             const int ks = 2 * (J) + kk;                                                           \
             uint4 wf[8];                                                                           \
             _Pragma("unroll") for (int i = 0; i < 8; ++i)                                          \
-                wf[i] = *reinterpret_cast<const uint4*>(smem + ((8 * half + i) * 8 + ks) * 1024 + lane * 16); \
+                wf[i] = *reinterpret_cast<const uint4*>(smem + ((J) & 1) * 32768 + ((8 * half + i) * 2 + kk) * 1024 + lane * 16); \
             _Pragma("unroll") for (int i = 0; i < 8; ++i) {                                        \
                 yacc[i][0] = ffn_mma<0>(wf[i], af[ks][0], yacc[i][0]);                             \
                 yacc[i][1] = ffn_mma<0>(wf[i], af[ks][1], yacc[i][1]);                             \
             }                                                                                      \
         }                                                                                          \
     }
-    PLN_GROUP(0, 12) PLN_GROUP(1, 8) PLN_GROUP(2, 4) PLN_GROUP(3, 0)
+    PLN_GROUP(0) PLN_GROUP(1) PLN_GROUP(2) PLN_GROUP(3)
 #undef PLN_GROUP
+#undef PLN_ISSUE
 
     // ---- epilogue: + bias + residual, LayerNorm over 256 channels, store (as in the fused FFN) -------------------------
     float v[2][4][8];
@@ -441,6 +448,21 @@ extern "C" int dtlr_ffn_fused_bf16(const void* X, const void* W1, const float* b
     return check_launch();
 }
 
+// W [256, 256] row-major bf16 (host) -> the fragment-major image the kernel streams: block (i, ks) = 64 lanes x 8 elements,
+// lane (m = lane & 15, g = lane >> 4) <- W[sigma(i, m)][32 ks + 8 g ..], sigma(i, m) = 128 (i>>3) + 32 ((i&7)>>1) + 8 (m>>2) + 4 (i&1) + (m&3)
+extern "C" int dtlr_proj_pack_weights(const unsigned short* w_host, unsigned short* wp_host)
+{
+    if (!w_host || !wp_host) return DTLR_EINVAL;
+    for (int i = 0; i < 16; ++i)
+        for (int ks = 0; ks < 8; ++ks)
+            for (int lane = 0; lane < 64; ++lane) {
+                const int m = lane & 15, g = lane >> 4;
+                const int row = 128 * (i >> 3) + 32 * ((i & 7) >> 1) + 8 * (m >> 2) + 4 * (i & 1) + (m & 3);
+                for (int e = 0; e < 8; ++e) wp_host[((i * 8 + ks) * 64 + lane) * 8 + e] = w_host[row * 256 + ks * 32 + g * 8 + e];
+            }
+    return DTLR_OK;
+}
+
 extern "C" int dtlr_proj_ln_bf16(const void* A, const void* W, const float* bias, const void* R,
                                  const float* gamma, const float* beta, float eps, void* Y, int M, int d_model, void* stream)
 {
@@ -450,7 +472,7 @@ extern "C" int dtlr_proj_ln_bf16(const void* A, const void* W, const float* bias
     if (d_model != 256) return DTLR_ESHAPE;
     static bool attr = false;
     if (!attr) { (void)hipFuncSetAttribute((const void*)proj_ln_bf16_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, PLN_LDS); (void)hipGetLastError(); attr = true; }
-    hipLaunchKernelGGL(proj_ln_bf16_kernel, dim3((unsigned)((M + 127) / 128)), dim3(512), PLN_LDS, (hipStream_t)stream,
+    hipLaunchKernelGGL(proj_ln_bf16_kernel, dim3((unsigned)((M + 63) / 64)), dim3(256), PLN_LDS, (hipStream_t)stream,
                        (const uint16_t*)A, (const uint16_t*)W, bias, (const uint16_t*)R, gamma, beta, eps, (uint16_t*)Y, M);
     return check_launch();
 }

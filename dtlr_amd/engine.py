@@ -169,7 +169,9 @@ class DTLREngine:
         """output projection of an attention block + residual + post-norm (deformable_transformer.py:810-815, 847-870)."""
         w = self.w
         if self.use_fused_ffn and a.dtype == torch.bfloat16 and a.shape[-1] == 256:
-            return ops.proj_ln(a, w[proj + ".w"], w[proj + ".b"], residual, w[norm + ".w"], w[norm + ".b"])
+            if proj + ".wp" not in w:                          # fragment-major copy of the projection weight, packed once
+                w[proj + ".wp"] = ops.proj_pack_w(w[proj + ".w"])
+            return ops.proj_ln(a, w[proj + ".wp"], w[proj + ".b"], residual, w[norm + ".w"], w[norm + ".b"])
         return self._ln(norm, self._lin(proj, a), residual=residual)
 
     def _ffn(self, q, norm, x):

@@ -118,17 +118,29 @@ def layernorm(x, w, b, eps: float = 1e-5, residual=None):
     return y
 
 
-def proj_ln(a, w, b, residual, ln_w, ln_b, eps: float = 1e-5):
+def proj_pack_w(w):
+    """[256,256] projection weight (bf16, any device) -> the fragment-major image dtlr_proj_ln_bf16 streams (bf16, same device)."""
+    import numpy as np
+    assert tuple(w.shape) == (256, 256)
+    src = np.ascontiguousarray(w.detach().to(torch.bfloat16).cpu().view(torch.int16).numpy()).view(np.uint16)
+    out = np.empty(256 * 256, dtype=np.uint16)
+    code = _lib.lib().dtlr_proj_pack_weights(src.ctypes.data, out.ctypes.data)
+    _lib.check(code, "dtlr_proj_pack_weights")
+    return torch.from_numpy(out.view(np.int16)).view(torch.bfloat16).to(w.device)
+
+
+def proj_ln(a, wp, b, residual, ln_w, ln_b, eps: float = 1e-5):
     """LayerNorm(residual + a W^T + b) in ONE kernel (dtlr_proj_ln_bf16): the attention block's output projection with its
-    post-norm; a, residual [..., 256] bf16, W [256,256] bf16, b / LN params fp32."""
+    post-norm; a, residual [..., 256] bf16, wp = proj_pack_w(W) (bf16, 65536 elements), b / LN params fp32."""
     require_cuda(a, "a")
-    assert a.dtype == torch.bfloat16 and residual.dtype == torch.bfloat16 and w.dtype == torch.bfloat16 and a.shape[-1] == 256
+    assert a.dtype == torch.bfloat16 and residual.dtype == torch.bfloat16 and wp.dtype == torch.bfloat16 and a.shape[-1] == 256
+    assert wp.numel() == 256 * 256 and wp.is_contiguous()
     a = a if a.is_contiguous() else a.contiguous()
     residual = residual if residual.is_contiguous() else residual.contiguous()
     y = torch.empty_like(residual)
     M = a.numel() // 256
     with _Timed("proj_ln_bf16", 2.0 * M * 256 * 256):
-        code = _lib.lib().dtlr_proj_ln_bf16(a.data_ptr(), w.data_ptr(), b.data_ptr(), residual.data_ptr(), ln_w.data_ptr(), ln_b.data_ptr(),
+        code = _lib.lib().dtlr_proj_ln_bf16(a.data_ptr(), wp.data_ptr(), b.data_ptr(), residual.data_ptr(), ln_w.data_ptr(), ln_b.data_ptr(),
                                             eps, y.data_ptr(), M, 256, _lib.current_stream())
     _lib.check(code, "dtlr_proj_ln_bf16")
     return y

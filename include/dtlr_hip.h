@@ -117,11 +117,13 @@ int dtlr_ffn_fused_bf16(const void *X, const void *W1, const float *b1, const vo
 
 /* ---------------------------------------------------------------------------------------------
  * Output projection + residual + LayerNorm of an attention block, bf16 (fp32 accumulate / statistics):
- *     Y = LayerNorm( R + A W^T + b )            A, R, Y [M, 256] bf16 ; W [256, 256] bf16 ; b, gamma, beta [256] fp32
+ *     Y = LayerNorm( R + A W^T + b )            A, R, Y [M, 256] bf16 ; b, gamma, beta [256] fp32
+ *     W: the [256, 256] bf16 weight re-ordered by dtlr_proj_pack_weights (a HOST-side helper, both pointers host memory)
  * Replaces: MSDeformAttn.output_proj (ops/modules/ms_deform_attn.py:124) / nn.MultiheadAttention.out_proj followed by
  *           `src = norm1(src + dropout1(src2))` (models/dino/deformable_transformer.py:810-815) and the decoder's
  *           norm2 / norm1 after self- and cross-attention (:847-870).  d_model must be 256.
  */
+int dtlr_proj_pack_weights(const unsigned short *w_host /* [256*256] bf16, row-major */, unsigned short *wp_host /* [256*256] */);
 int dtlr_proj_ln_bf16(const void *A, const void *W, const float *bias, const void *R,
                       const float *gamma, const float *beta, float eps, void *Y, int M, int d_model, void *stream);
 

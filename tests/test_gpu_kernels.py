@@ -414,7 +414,7 @@ def test_proj_ln_bf16_vs_reference(M):
     gw, gb = 1 + 0.2 * _rand((256,), 6), 0.3 * _rand((256,), 7)
     pre = r.double() + a.double() @ w.double().t() + b.double()
     want = torch.nn.functional.layer_norm(pre, (256,), gw.double(), gb.double(), 1e-5).float()
-    got = ops.proj_ln(a.cuda(), w.cuda(), b.cuda(), r.cuda(), gw.cuda(), gb.cuda()).float().cpu()
+    got = ops.proj_ln(a.cuda(), ops.proj_pack_w(w.cuda()), b.cuda(), r.cuda(), gw.cuda(), gb.cuda()).float().cpu()
     tol = 2 ** -8 * max(1.0, want.abs().max().item()) + 1e-3
     assert (got - want).abs().max() < tol, (got - want).abs().max().item()
     un = ops.layernorm(ops.linear(a.cuda(), w.cuda(), b.cuda()), gw.cuda(), gb.cuda(), 1e-5, residual=r.cuda()).float().cpu()
