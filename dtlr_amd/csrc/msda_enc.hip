@@ -63,6 +63,37 @@ __device__ __forceinline__ int cols_left_of(int t, int TW0, int W0, int Wl) {
     return (int)(c < Wl ? c : Wl);
 }
 
+// The bf16 kernel keeps its LDS windows in FP16: every bf16 value in fp16's range converts exactly (8 significant bits into
+// 11), and the query phase can then feed the halves of a register straight into v_fma_mix_f32 (fp32 weight x fp16 value +
+// fp32 accumulator, one instruction per channel) instead of unpacking bf16 with a shift/mask per channel first -- the
+// unpack was 512 of the ~1100 VALU instructions per lane.  Each staged element is converted once and read ~18 times.
+// (|x| >= 65520 would become inf and |x| < 6e-8 zero; the sampled tensor is value_proj(LayerNorm output): O(1).)
+template <typename T> __device__ __forceinline__ uint4 stage_convert(const uint4& d);
+template <> __device__ __forceinline__ uint4 stage_convert<float>(const uint4& d) { return d; }
+template <> __device__ __forceinline__ uint4 stage_convert<uint16_t>(const uint4& d) {
+    typedef _Float16 h2_t __attribute__((ext_vector_type(2)));
+    typedef float f2_t __attribute__((ext_vector_type(2)));
+    const uint32_t w[4] = {d.x, d.y, d.z, d.w};
+    uint32_t o[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const f2_t f = {__uint_as_float(w[j] << 16), __uint_as_float(w[j] & 0xffff0000u)};
+        o[j] = __builtin_bit_cast(uint32_t, __builtin_convertvector(f, h2_t));
+    }
+    return make_uint4(o[0], o[1], o[2], o[3]);
+}
+// acc += w * fp16 half of `data` (plain asm, not volatile: a pure function of its inputs, the compiler schedules it freely)
+__device__ __forceinline__ float fma_mix_lo(float w, uint32_t data, float acc) {
+    float d;
+    asm("v_fma_mix_f32 %0, %1, %2, %3 op_sel:[0,0,0] op_sel_hi:[0,1,0]" : "=v"(d) : "v"(w), "v"(data), "v"(acc));
+    return d;
+}
+__device__ __forceinline__ float fma_mix_hi(float w, uint32_t data, float acc) {
+    float d;
+    asm("v_fma_mix_f32 %0, %1, %2, %3 op_sel:[0,1,0] op_sel_hi:[0,1,0]" : "=v"(d) : "v"(w), "v"(data), "v"(acc));
+    return d;
+}
+
 // ---- bf16 query phase: one lane per (query, head, LEVEL) ---------------------------------------------
 // The four lanes of a quad are the four levels of one (query, head).  Each lane does the geometry of its own
 // 4 points only (the first version gave a lane 8 channels of ALL 16 points: every lane of the quad repeated
@@ -154,8 +185,11 @@ __device__ __forceinline__ void enc_queries_bf16(
             for (int i = 0; i < 8; ++i) acc[jj][i] = 0.f;
 #define DTLR_ACCUM(D, WGT)                                                                         \
         _Pragma("unroll") for (int jj = 0; jj < 4; ++jj) {                                         \
-            float v_[8]; ET<uint16_t>::unpack(D[jj], v_);                                          \
-            _Pragma("unroll") for (int i = 0; i < 8; ++i) acc[jj][i] += (WGT) * v_[i];            \
+            const uint32_t q_[4] = {D[jj].x, D[jj].y, D[jj].z, D[jj].w};                           \
+            _Pragma("unroll") for (int i = 0; i < 4; ++i) {                                        \
+                acc[jj][2 * i] = fma_mix_lo((WGT), q_[i], acc[jj][2 * i]);                         \
+                acc[jj][2 * i + 1] = fma_mix_hi((WGT), q_[i], acc[jj][2 * i + 1]);                 \
+            }                                                                                      \
         }
         // one point at a time: its geometry, then its 16 reads (4 corners x 4 pieces, 64 registers in flight), then the
         // accumulate; the scheduling barrier keeps the compiler from hoisting the next points' reads (it spills ~200
@@ -269,7 +303,7 @@ __global__ __launch_bounds__(256, 2) void msda_enc_lds_kernel(
             }
 #pragma unroll
             for (int u = 0; u < 4; ++u)
-                if (c0 + 256 * u < nchunk) *reinterpret_cast<uint4*>(dst + dst_off[u]) = d[u];
+                if (c0 + 256 * u < nchunk) *reinterpret_cast<uint4*>(dst + dst_off[u]) = stage_convert<T>(d[u]);
         }
     }
     __syncthreads();
