@@ -124,6 +124,7 @@ __global__ __launch_bounds__(256) void mha_fwd_bf16_kernel(const uint16_t* __res
 // and its waves walk the query blocks (wave w takes blocks w, w+16) reading operands with ds_read_b128.
 //   K image : key tile t (16 keys)           at t * 1024       : lane (g, n) <- K[16 t + n][8 g .. 8 g + 7]
 //   V^T image: key block j (32 keys), d tile  at (2 j + dt) * 1024: lane (g, n) <- V^T[16 dt + n][32 j + 4 g .. +3 | 32 j + 16 + 4 g .. +3]
+//              (gathered from the untransposed v while staging)
 // Same operand values as mha_fwd_bf16_kernel; the softmax scale is applied by FMA here (results agree to fp32 rounding).
 // reductions over the four lanes {n, n+16, n+32, n+48} of a query with the gfx950 row/half swaps (VALU, no LDS round trip):
 // permlane16_swap(x, x) = ([x0,x0,x2,x2], [x1,x1,x3,x3]) by 16-lane rows, permlane32_swap(y, y) = ([lo,lo], [hi,hi])
@@ -144,7 +145,7 @@ __device__ __forceinline__ float g4_sum(float x) {
     return __uint_as_float(c[0]) + __uint_as_float(c[1]);
 }
 
-__global__ __launch_bounds__(1024) void mha_fwd_bf16_lds_kernel(const uint16_t* __restrict__ qk, const uint16_t* __restrict__ vt,
+__global__ __launch_bounds__(1024) void mha_fwd_bf16_lds_kernel(const uint16_t* __restrict__ qk, const uint16_t* __restrict__ v,
                                                                uint16_t* __restrict__ out, int L, int Lpad, int H,
                                                                float scale_log2e)
 {
@@ -154,7 +155,7 @@ __global__ __launch_bounds__(1024) void mha_fwd_bf16_lds_kernel(const uint16_t* 
     const int h = blockIdx.x, b = blockIdx.y;
     const int C = H * 32;
     const uint16_t* qkb = qk + (long)b * L * (2 * C);
-    const uint16_t* vtb = vt + ((long)(b * H + h) * 32) * Lpad;
+    const uint16_t* vb = v + (long)b * L * C;
     const int nkb = Lpad / 32;                               // key blocks
     unsigned char* kimg = smem_att;                          // nkb * 2 KB
     unsigned char* vimg = smem_att + (long)nkb * 2048;       // nkb * 2 KB
@@ -163,10 +164,18 @@ __global__ __launch_bounds__(1024) void mha_fwd_bf16_lds_kernel(const uint16_t* 
         const int key = min(f * 16 + n, L - 1);
         const uint4 kd = *reinterpret_cast<const uint4*>(qkb + (long)key * (2 * C) + C + h * 32 + 8 * g);
         *reinterpret_cast<uint4*>(kimg + f * 1024 + lane * 16) = kd;
+        // V^T fragment (j, dt) gathered straight from v [B, L, C] (the transpose happens here, once per workgroup: no separate
+        // transpose pass): lane (g, n) <- V[32 j + 4 g + r][16 dt + n] (r = 0..3) | V[32 j + 16 + 4 g + r][16 dt + n]; keys >= L -> 0
         const int j = f >> 1, dt = f & 1;
-        const uint16_t* vr = vtb + (long)(dt * 16 + n) * Lpad + j * 32 + 4 * g;
-        const uint2 lo = *reinterpret_cast<const uint2*>(vr), hi = *reinterpret_cast<const uint2*>(vr + 16);
-        *reinterpret_cast<uint4*>(vimg + f * 1024 + lane * 16) = make_uint4(lo.x, lo.y, hi.x, hi.y);
+        const uint16_t* vc = vb + h * 32 + dt * 16 + n;
+        uint32_t e[8];
+#pragma unroll
+        for (int r = 0; r < 8; ++r) {
+            const int key = j * 32 + (r >> 2) * 16 + 4 * g + (r & 3);
+            e[r] = key < L ? (uint32_t)vc[(long)key * C] : 0u;
+        }
+        *reinterpret_cast<uint4*>(vimg + f * 1024 + lane * 16) =
+            make_uint4(e[0] | (e[1] << 16), e[2] | (e[3] << 16), e[4] | (e[5] << 16), e[6] | (e[7] << 16));
     }
     __syncthreads();
     const int nqb = (L + 31) / 32;                           // query blocks of 32
@@ -417,19 +426,19 @@ extern "C" int dtlr_mha_forward(const void* qk, const void* v, void* vt_workspac
                            1.4426950408889634f / sqrtf((float)head_dim));
         return check_launch();
     }
+    const float scale_log2e = 1.4426950408889634f / sqrtf((float)head_dim);
+    const size_t lds = (size_t)(Lpad / 32) * 4096;               // K image + V^T image
+    if (lds <= 152 * 1024) {                                     // transposes V while staging: no separate pass, no workspace
+        static bool attr = false;
+        if (!attr) { (void)hipFuncSetAttribute((const void*)mha_fwd_bf16_lds_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 152 * 1024); (void)hipGetLastError(); attr = true; }
+        hipLaunchKernelGGL(mha_fwd_bf16_lds_kernel, dim3(H, B), dim3(1024), lds, st,
+                           (const uint16_t*)qk, (const uint16_t*)v, (uint16_t*)out, L, Lpad, H, scale_log2e);
+        return check_launch();
+    }
     hipLaunchKernelGGL(v_transpose_kernel, dim3(Lpad / 32, B), dim3(256), (size_t)C * 33 * sizeof(uint16_t), st,
                        (const uint16_t*)v, (uint16_t*)vt_workspace, L, Lpad, H);
     int rc = check_launch();
     if (rc) return rc;
-    const float scale_log2e = 1.4426950408889634f / sqrtf((float)head_dim);
-    const size_t lds = (size_t)(Lpad / 32) * 4096;               // K image + V^T image
-    if (lds <= 152 * 1024) {
-        static bool attr = false;
-        if (!attr) { (void)hipFuncSetAttribute((const void*)mha_fwd_bf16_lds_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 152 * 1024); (void)hipGetLastError(); attr = true; }
-        hipLaunchKernelGGL(mha_fwd_bf16_lds_kernel, dim3(H, B), dim3(1024), lds, st,
-                           (const uint16_t*)qk, (const uint16_t*)vt_workspace, (uint16_t*)out, L, Lpad, H, scale_log2e);
-        return check_launch();
-    }
     hipLaunchKernelGGL(mha_fwd_bf16_kernel, dim3((L + 127) / 128, H, B), dim3(256), 0, st,
                        (const uint16_t*)qk, (const uint16_t*)vt_workspace, (uint16_t*)out, L, Lpad, H, scale_log2e);
     return check_launch();
