@@ -206,17 +206,27 @@ def main():
         r["ms_per_step"] = round(sum(e[0] for e in enc) / args.steps, 3)
         by_kernel.append(r)
     classes = {}
-    for (a, b, kind, flops) in mfma_events:
-        c = classes.setdefault(kind, [0.0, 0.0, 0])
-        c[0] += a.elapsed_time(b); c[1] += flops; c[2] += 1
+    for (a, b, kind, flops, nbytes) in mfma_events:
+        c = classes.setdefault(kind, [0.0, 0.0, 0, 0.0])
+        c[0] += a.elapsed_time(b); c[1] += flops; c[2] += 1; c[3] += nbytes
     names = {"gemm_bf16": "gemm_ws_kernel<bf16> (every Linear / 1x1 conv / implicit-GEMM 3x3 conv, fused epilogues)",
              "gemm_f32": "gemm_ws_kernel<f32> (fp32 heads and selection scores, exact-fp32 MFMA 16x16x4)",
              "ffn_fused_bf16": "ffn_fused_bf16_kernel (linear1+ReLU+linear2+residual+LayerNorm, intermediate on chip)"}
-    for kind, (ms, flops, cnt) in classes.items():
+    names["proj_ln_bf16"] = "proj_ln_bf16_kernel (attention output projection + residual + LayerNorm)"
+    for kind, (ms, flops, cnt, nbytes) in classes.items():
         peak = MFMA_PEAK_F32_TFLOPS if kind == "gemm_f32" else MFMA_PEAK_BF16_TFLOPS
         ach = flops / (ms * 1e-3) / 1e12
-        by_kernel.append({"bound": "mfma", "kernel": names.get(kind, kind), "achieved": round(ach, 1), "peak": peak, "unit": "TFLOP/s",
-                          "frac": round(ach / peak, 4), "traffic": None, "algorithmic_flops_per_launch": round(flops / cnt),
+        gbps = nbytes / (ms * 1e-3) / 1e9                        # compulsory operand + result bytes (each tensor once)
+        # the binding roof of the class: most GEMMs of this path have K = 256 (or 64..128 in the first ResNet stage) and are
+        # HBM-bound; both fractions are reported, `bound`/`achieved`/`peak`/`frac` name the larger one
+        mf, hf = ach / peak, gbps / HBM_PEAK_GBS
+        if hf > mf:
+            head = {"bound": "hbm", "kernel": names.get(kind, kind), "achieved": round(gbps, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(hf, 4)}
+        else:
+            head = {"bound": "mfma", "kernel": names.get(kind, kind), "achieved": round(ach, 1), "peak": peak, "unit": "TFLOP/s", "frac": round(mf, 4)}
+        by_kernel.append({**head, "traffic": None, "mfma_tflops": round(ach, 1), "mfma_frac": round(mf, 4),
+                          "hbm_gbps_algorithmic": round(gbps, 1), "hbm_frac": round(hf, 4),
+                          "algorithmic_flops_per_launch": round(flops / cnt), "algorithmic_bytes_per_launch": round(nbytes / cnt),
                           "mean_launch_ms": round(ms / cnt, 4), "launches_timed": cnt, "ms_per_step": round(ms / replay_steps, 3),
                           "timed_in": "replay of the timed steps, launches >= 2 GFLOP only"})
     by_kernel.sort(key=lambda r: -r["ms_per_step"])

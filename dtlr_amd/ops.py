@@ -38,10 +38,10 @@ MFMA_EVENTS_MIN_FLOPS = 2.0e9     # only launches this large are timed: an event
 
 class _Timed:
     """with _Timed(kind, flops): <launch>  -- records a HIP event pair around the launch when MFMA_EVENTS is a list."""
-    __slots__ = ("kind", "flops", "a", "st")
+    __slots__ = ("kind", "flops", "nbytes", "a", "st")
 
-    def __init__(self, kind, flops):
-        self.kind, self.flops = kind, flops
+    def __init__(self, kind, flops, nbytes=0.0):
+        self.kind, self.flops, self.nbytes = kind, flops, nbytes
 
     def __enter__(self):
         self.a = None
@@ -55,7 +55,7 @@ class _Timed:
         if self.a is not None:
             b = torch.cuda.Event(enable_timing=True)
             b.record(self.st)
-            MFMA_EVENTS.append((self.a, b, self.kind, self.flops))
+            MFMA_EVENTS.append((self.a, b, self.kind, self.flops, self.nbytes))
         return False
 
 
@@ -81,7 +81,9 @@ def linear(x, w, b=None, relu=False, residual=None, a2=None, row_mask=None, out_
             b = b.float()
         M = x.numel() // K
         y = torch.empty(x.shape[:-1] + (N,), dtype=out_dtype, device=x.device)
-        with _Timed("gemm_bf16" if x.dtype == torch.bfloat16 else "gemm_f32", 2.0 * M * N * K):
+        es, eo = x.element_size(), (2 if out_dtype == torch.bfloat16 else 4)
+        nbytes = float(M) * K * es * (2 if a2 is not None else 1) + float(N) * K * es + float(M) * N * eo * (2 if residual is not None else 1)
+        with _Timed("gemm_bf16" if x.dtype == torch.bfloat16 else "gemm_f32", 2.0 * M * N * K, nbytes):
             code = _lib.lib().dtlr_gemm_nt(x.data_ptr(), 0 if a2 is None else a2.data_ptr(), w.data_ptr(),
                                            0 if b is None else b.data_ptr(), 0 if residual is None else residual.data_ptr(),
                                            0 if row_mask is None else row_mask.data_ptr(), y.data_ptr(),
@@ -139,7 +141,7 @@ def proj_ln(a, wp, b, residual, ln_w, ln_b, eps: float = 1e-5):
     residual = residual if residual.is_contiguous() else residual.contiguous()
     y = torch.empty_like(residual)
     M = a.numel() // 256
-    with _Timed("proj_ln_bf16", 2.0 * M * 256 * 256):
+    with _Timed("proj_ln_bf16", 2.0 * M * 256 * 256, 3.0 * M * 256 * 2 + 256 * 256 * 2):
         code = _lib.lib().dtlr_proj_ln_bf16(a.data_ptr(), wp.data_ptr(), b.data_ptr(), residual.data_ptr(), ln_w.data_ptr(), ln_b.data_ptr(),
                                             eps, y.data_ptr(), M, 256, _lib.current_stream())
     _lib.check(code, "dtlr_proj_ln_bf16")
@@ -167,7 +169,7 @@ def ffn_fused(x, w1, b1, w2p, b2, ln_w, ln_b, eps: float = 1e-5):
     x = x if x.is_contiguous() else x.contiguous()
     y = torch.empty_like(x)
     M = x.numel() // x.shape[-1]
-    with _Timed("ffn_fused_bf16", 4.0 * M * x.shape[-1] * w1.shape[0]):
+    with _Timed("ffn_fused_bf16", 4.0 * M * x.shape[-1] * w1.shape[0], 2.0 * M * 256 * 2 + 2.0 * w1.numel() * 2):
         code = _lib.lib().dtlr_ffn_fused_bf16(x.data_ptr(), w1.data_ptr(), b1.data_ptr(), w2p.data_ptr(), b2.data_ptr(),
                                               ln_w.data_ptr(), ln_b.data_ptr(), eps, y.data_ptr(), M, x.shape[-1], w1.shape[0],
                                               _lib.current_stream())
@@ -188,7 +190,9 @@ def conv2d_nhwc(x, w, bias, stride: int, padding: int, relu=False, residual=None
         y = torch.empty((B, Ho, Wo, Cout), dtype=x.dtype, device=x.device)
         if residual is not None:
             residual = residual if residual.is_contiguous() else residual.contiguous()
-        with _Timed("gemm_bf16" if x.dtype == torch.bfloat16 else "gemm_f32", 2.0 * B * Ho * Wo * Cout * KH * KW * Cin):
+        es = x.element_size()
+        nbytes = (float(x.numel()) / (stride * stride if KH == 1 else 1) + float(w.numel()) + float(B) * Ho * Wo * Cout * (2 if residual is not None else 1)) * es
+        with _Timed("gemm_bf16" if x.dtype == torch.bfloat16 else "gemm_f32", 2.0 * B * Ho * Wo * Cout * KH * KW * Cin, nbytes):
             code = _lib.lib().dtlr_conv2d_nhwc(x.data_ptr(), w.data_ptr(), 0 if bias is None else bias.data_ptr(),
                                                0 if residual is None else residual.data_ptr(), y.data_ptr(),
                                                B, H, W, Cin, Cout, KH, KW, stride, padding, 2 if relu else 0,
