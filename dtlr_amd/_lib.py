@@ -48,6 +48,7 @@ _SIGNATURES = {
     "dtlr_groupnorm_tokens_strided": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, ctypes.c_long, c_void_p, c_int, c_int, c_int, c_int, c_float, c_int, c_void_p]),
     "dtlr_groupnorm_tokens": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_float, c_int, c_void_p]),
     "dtlr_groupnorm_workspace_bytes": (ctypes.c_long, [c_int, c_int]),
+    "dtlr_box_mlp_refine_bf16": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_void_p]),
     "dtlr_box_head_refine": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, ctypes.c_long, c_int, c_int, c_void_p]),
     "dtlr_stem_pack_weights": (c_int, [c_void_p, c_void_p]),
     "dtlr_stem_conv7x7": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p]),

@@ -40,7 +40,7 @@ constexpr int FFN_NS = 4;                                   // ring stages
 constexpr int FFN_STAGE = 32768;                            // W1 chunk image (16 KB) | W2 chunk image (16 KB)
 constexpr int FFN_H_OFF = FFN_NS * FFN_STAGE;               // H buffers: [tg 4][buf 2][tt 2][1024 B]
 constexpr int FFN_LN_OFF = FFN_H_OFF + 4 * 2 * 2 * 1024;    // LayerNorm exchange: [tg 4][half 2][32 tokens] floats
-constexpr int FFN_B1_OFF = FFN_LN_OFF + 4 * 2 * 32 * 4;     // b1 staged once (a compiler-visible global load inside the chunk
+constexpr int FFN_B1_OFF = FFN_LN_OFF + 4 * 256 * 4;         // (LayerNorm uses 1 KB of it, the MLP-head epilogue 4 KB)     // b1 staged once (a compiler-visible global load inside the chunk
                                                             // loop would be waited for with vmcnt(0) and drain the DMA queue)
 constexpr int FFN_MAX_DFF = 2048;
 constexpr int FFN_LDS = FFN_B1_OFF + FFN_MAX_DFF * 4;
@@ -73,11 +73,15 @@ __device__ __forceinline__ void unpack8(const uint4& t, float (&v)[8]) {
 
 // DBG (timing experiments only, env DTLR_FFN_DBG; results are garbage): 1 = no weight DMA after the prologue,
 // 2 = no MFMA, 4 = no per-chunk barrier.  DBG = 0 is the product kernel; the switches are compile-time so it carries no branches.
-template <int DBG>
+// HEAD = true: the same two MFMA phases run a 3-layer box MLP (models/dino/dino.py MLP(256, 256, 4, 3)): no residual / LayerNorm;
+// the epilogue applies ReLU to the second layer, multiplies by the 4 x 256 output layer (fp32, `gamma` = its weight, `beta` = its
+// bias) and finishes with mode 0: sigmoid(delta + inverse_sigmoid(ref)) or mode 1: delta + ref -- `eps` carries the mode, Y is
+// the fp32 [M, 4] result and `ref4` the fp32 [M, 4] reference boxes.  (3 launches of M = 28800 per evaluation -> 1.)
+template <int DBG, bool HEAD = false>
 __global__ __launch_bounds__(512, 2) void ffn_fused_bf16_kernel(
     const uint16_t* __restrict__ X, const uint16_t* __restrict__ W1, const float* __restrict__ b1,
     const uint16_t* __restrict__ W2, const float* __restrict__ b2, const float* __restrict__ gamma,
-    const float* __restrict__ beta, float eps, uint16_t* __restrict__ Y, int M, int d_ff)
+    const float* __restrict__ beta, float eps, uint16_t* __restrict__ Y, int M, int d_ff, const float* __restrict__ ref4)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const unsigned lds_base = (unsigned)(size_t)(__attribute__((address_space(3))) unsigned char*)smem;
@@ -201,6 +205,62 @@ __global__ __launch_bounds__(512, 2) void ffn_fused_bf16_kernel(
 #undef FFN_PHASE_A
 #undef FFN_ISSUE
 
+    if constexpr (HEAD) {
+        // y = relu(acc + b2) (fp32); out[o] = sum_ch y[ch] W3[o][ch] + b3[o]: lane-local over its 32 channels, then the four g
+        // lanes of a token, then the two waves of the pair through LDS
+        float d[2][4];
+#pragma unroll
+        for (int tt = 0; tt < 2; ++tt)
+#pragma unroll
+            for (int o = 0; o < 4; ++o) d[tt][o] = 0.f;
+#pragma unroll
+        for (int kq = 0; kq < 4; ++kq) {
+            const int ch = 128 * half + 32 * kq + 8 * g;
+            const float4 ba = *reinterpret_cast<const float4*>(b2 + ch), bc = *reinterpret_cast<const float4*>(b2 + ch + 4);
+            const float bias[8] = {ba.x, ba.y, ba.z, ba.w, bc.x, bc.y, bc.z, bc.w};
+            float w3[4][8];
+#pragma unroll
+            for (int o = 0; o < 4; ++o) {
+                const float4 wa = *reinterpret_cast<const float4*>(gamma + o * 256 + ch), wc = *reinterpret_cast<const float4*>(gamma + o * 256 + ch + 4);
+                w3[o][0] = wa.x; w3[o][1] = wa.y; w3[o][2] = wa.z; w3[o][3] = wa.w; w3[o][4] = wc.x; w3[o][5] = wc.y; w3[o][6] = wc.z; w3[o][7] = wc.w;
+            }
+#pragma unroll
+            for (int tt = 0; tt < 2; ++tt)
+#pragma unroll
+                for (int e = 0; e < 8; ++e) {
+                    const float y = fmaxf((e < 4 ? yacc[2 * kq][tt][e] : yacc[2 * kq + 1][tt][e - 4]) + bias[e], 0.f);
+#pragma unroll
+                    for (int o = 0; o < 4; ++o) d[tt][o] += y * w3[o][e];
+                }
+        }
+        float* lnx = reinterpret_cast<float*>(smem + FFN_LN_OFF) + tg * 256;      // [half][32 tokens][4]
+#pragma unroll
+        for (int tt = 0; tt < 2; ++tt)
+#pragma unroll
+            for (int o = 0; o < 4; ++o) {
+                d[tt][o] += __shfl_xor(d[tt][o], 16, 64);
+                d[tt][o] += __shfl_xor(d[tt][o], 32, 64);
+                if (g == 0) lnx[(half * 32 + tt * 16 + n) * 4 + o] = d[tt][o];
+            }
+        __syncthreads();
+        // wave half h finishes token tile tt = h: lane (n, g) -> output component o = g of token n
+        {
+            const int tt = half, o = g;
+            const long tok = tok0 + tt * 16 + n;
+            if (tok < M) {
+                const float delta = lnx[(tt * 16 + n) * 4 + o] + lnx[(32 + tt * 16 + n) * 4 + o] + beta[o];
+                const float r = ref4[tok * 4 + o];
+                float yv;
+                if (eps == 0.f) {                               // mode 0: iterative refinement
+                    const float xx = fminf(fmaxf(r, 0.f), 1.f);
+                    const float x1 = fmaxf(xx, 1e-3f), x2 = fmaxf(1.f - xx, 1e-3f);
+                    yv = 1.f / (1.f + expf(-(delta + logf(x1 / x2))));
+                } else yv = delta + r;                          // mode 1: + proposals (unsigmoided)
+                reinterpret_cast<float*>(Y)[tok * 4 + o] = yv;
+            }
+        }
+        return;
+    }
     // ---- epilogue: + b2 + residual, LayerNorm over 256 channels, store -----------------------------------------
     // lane (n, g), ks' = 0..3: channels ch = 128 half + 32 ks' + 8 g + e, e = 0..7: e < 4 from yacc[2 ks'][tt][e],
     // e >= 4 from yacc[2 ks' + 1][tt][e - 4]; the residual is X fragment ks = 4 half + ks'.
@@ -433,7 +493,7 @@ extern "C" int dtlr_ffn_fused_bf16(const void* X, const void* W1, const float* b
         static bool attr = false;                                                                  \
         if (!attr) { (void)hipFuncSetAttribute((const void*)ffn_fused_bf16_kernel<D>, hipFuncAttributeMaxDynamicSharedMemorySize, FFN_LDS); (void)hipGetLastError(); attr = true; } \
         hipLaunchKernelGGL(ffn_fused_bf16_kernel<D>, dim3(grid), dim3(512), FFN_LDS, (hipStream_t)stream, \
-                           (const uint16_t*)X, (const uint16_t*)W1, b1, (const uint16_t*)W2, b2, gamma, beta, eps, (uint16_t*)Y, M, d_ff); \
+                           (const uint16_t*)X, (const uint16_t*)W1, b1, (const uint16_t*)W2, b2, gamma, beta, eps, (uint16_t*)Y, M, d_ff, (const float*)nullptr); \
     }
     switch (dbg) {
     case 1: FFN_LAUNCH(1) break;
@@ -445,6 +505,19 @@ extern "C" int dtlr_ffn_fused_bf16(const void* X, const void* W1, const float* b
     default: FFN_LAUNCH(0) break;
     }
 #undef FFN_LAUNCH
+    return check_launch();
+}
+
+extern "C" int dtlr_box_mlp_refine_bf16(const void* X, const void* W1, const float* b1, const void* W2p, const float* b2,
+                                        const float* W3, const float* b3, const float* ref, float* out, int M, int mode, void* stream)
+{
+    clear_stale_error();
+    if (!X || !W1 || !b1 || !W2p || !b2 || !W3 || !b3 || !ref || !out) return DTLR_EINVAL;
+    if (M <= 0 || (mode != 0 && mode != 1)) return DTLR_EINVAL;
+    static bool attr = false;
+    if (!attr) { (void)hipFuncSetAttribute((const void*)ffn_fused_bf16_kernel<0, true>, hipFuncAttributeMaxDynamicSharedMemorySize, FFN_LDS); (void)hipGetLastError(); attr = true; }
+    hipLaunchKernelGGL((ffn_fused_bf16_kernel<0, true>), dim3((unsigned)((M + 127) / 128)), dim3(512), FFN_LDS, (hipStream_t)stream,
+                       (const uint16_t*)X, (const uint16_t*)W1, b1, (const uint16_t*)W2p, b2, W3, b3, (float)mode, (uint16_t*)out, M, 256, ref);
     return check_launch();
 }
 

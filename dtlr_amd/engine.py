@@ -143,6 +143,9 @@ class DTLREngine:
                 # (As fp32-MFMA GEMMs these 16 launches of M = 28800 cost 43 us each: 0.7 ms of a 14.4 ms step.)
                 self._put(f"bbox{i}.wh", sd[f"bbox_embed.0.layers.{i}.weight"])
                 self._put(f"enc_bbox{i}.wh", sd[f"{t}enc_out_bbox_embed.layers.{i}.weight"])
+                if i == 1:                             # second layer also chunk-major for the one-launch MLP kernel
+                    self.w["bbox1.wp"] = ops.ffn_pack_w2(self.w["bbox1.wh"])
+                    self.w["enc_bbox1.wp"] = ops.ffn_pack_w2(self.w["enc_bbox1.wh"])
         self._put("enc_class.w", sd[t + "enc_out_class_embed.weight"], f32)
         self._put("enc_class.b", sd[t + "enc_out_class_embed.bias"], f32)
         self._put("class.w", sd["class_embed.0.weight"], f32)
@@ -327,9 +330,8 @@ class DTLREngine:
         scores = ops.linear(om, self.w["enc_class.w"], self.w["enc_class.b"]).max(-1)[0]
         idx = ops.topk_rows(scores, cfg.num_queries) if forced_topk is None else forced_topk
         sel = torch.gather(om, 1, idx.unsqueeze(-1).expand(-1, -1, cfg.hidden_dim))
-        h = self._box_mlp_hidden("enc_bbox", sel)
         prop_sel = torch.gather(g["proposals"], 1, idx.unsqueeze(-1).expand(-1, -1, 4))
-        ref_unsig = ops.box_head_refine(h, self.w["enc_bbox2.w"], self.w["enc_bbox2.b"], prop_sel, mode=1)
+        ref_unsig = self._box_mlp("enc_bbox", sel, prop_sel, mode=1)
         return dict(topk_idx=idx, topk_scores=scores, ref_unsig=ref_unsig, hs_enc=sel, init_box=prop_sel.sigmoid())
 
     @staticmethod
@@ -356,9 +358,17 @@ class DTLREngine:
         h = ops.linear(x.float(), w[name + "0.w"], w[name + "0.b"], relu=True)
         return ops.linear(h, w[name + "1.w"], w[name + "1.b"], relu=True)
 
+    def _box_mlp(self, name, x, ref, mode):
+        """3-layer box MLP + consumer: mode 0 sigmoid(mlp(x) + inverse_sigmoid(ref)), mode 1 mlp(x) + ref."""
+        w = self.w
+        if name + "1.wp" in w:                         # bf16 engine: one launch
+            return ops.box_mlp_refine(x.to(self.dtype), w[name + "0.wh"], w[name + "0.b"], w[name + "1.wp"], w[name + "1.b"],
+                                      w[name + "2.w"], w[name + "2.b"], ref, mode)
+        return ops.box_head_refine(self._box_mlp_hidden(name, x), w[name + "2.w"], w[name + "2.b"], ref, mode=mode)
+
     def _refine(self, x, ref):
         """sigmoid(bbox_embed(x) + inverse_sigmoid(ref)) (deformable_transformer.py:734-756; dino.py:339-354)."""
-        return ops.box_head_refine(self._box_mlp_hidden("bbox", x), self.w["bbox2.w"], self.w["bbox2.b"], ref, mode=0)
+        return self._box_mlp("bbox", x, ref, mode=0)
 
     def decoder(self, memory, ts, g, want_aux=False):
         """TransformerDecoder.forward + DeformableTransformerDecoderLayer

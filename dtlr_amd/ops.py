@@ -372,6 +372,21 @@ def decoder_query_prep(ref, valid_ratios, out_dtype):
     return ref_in, sine
 
 
+def box_mlp_refine(x, w1, b1, w2p, b2, w3, b3, ref, mode: int = 0):
+    """3-layer box MLP + refinement in ONE launch (dtlr_box_mlp_refine_bf16): x [..,256] bf16, W1 [256,256] bf16,
+    w2p = ffn_pack_w2(W2) bf16, W3 [4,256] / biases fp32, ref [..,4] fp32 -> [..,4] fp32.
+    mode 0: sigmoid(mlp(x) + inverse_sigmoid(ref)); mode 1: mlp(x) + ref."""
+    require_cuda(x, "x")
+    assert x.dtype == torch.bfloat16 and x.shape[-1] == 256 and ref.dtype == torch.float32 and w3.dtype == torch.float32
+    x = x if x.is_contiguous() else x.contiguous()
+    ref = ref if ref.is_contiguous() else ref.contiguous()
+    out = torch.empty_like(ref)
+    code = _lib.lib().dtlr_box_mlp_refine_bf16(x.data_ptr(), w1.data_ptr(), b1.data_ptr(), w2p.data_ptr(), b2.data_ptr(), w3.data_ptr(),
+                                               b3.data_ptr(), ref.data_ptr(), out.data_ptr(), x.numel() // 256, mode, _lib.current_stream())
+    _lib.check(code, "dtlr_box_mlp_refine_bf16")
+    return out
+
+
 def box_head_refine(h, w, b, ref, mode: int = 0):
     """Last layer of the box MLP (256 -> 4) fused with its consumer (HIP kernel, one wavefront per row):
     mode 0: sigmoid(h W^T + b + inverse_sigmoid(ref)) ; mode 1: h W^T + b + ref.  h [..,256] fp32, ref [..,4] fp32."""

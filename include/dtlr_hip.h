@@ -198,6 +198,15 @@ int dtlr_box_refine(const float *delta, const float *ref, float *out, long n, vo
 int dtlr_box_head_refine(const float *h, const float *W, const float *bias, const float *ref, float *out,
                          long rows, int hidden, int mode, void *stream);
 
+/* The whole 3-layer box MLP + its consumer in one launch (bf16 engine): hidden layers on the bf16 MFMA path with fp32
+ * accumulation, output layer and box arithmetic in fp32.
+ * Replaces: `bbox_embed[i](hs)` / `enc_out_bbox_embed(output_memory)` = MLP(256, 256, 4, 3) (models/dino/dino.py) followed by
+ *           mode 0 `sigmoid(. + inverse_sigmoid(reference))` (deformable_transformer.py:734-756) or mode 1 `. + proposals` (:352-356).
+ *   X [M,256] bf16 ; W1 [256,256] bf16 ; W2p = layer-2 weight packed chunk-major as for dtlr_ffn_fused_bf16 ([8][256][32] bf16) ;
+ *   b1, b2 [256] fp32 ; W3 [4,256], b3 [4] fp32 ; ref, out [M,4] fp32. */
+int dtlr_box_mlp_refine_bf16(const void *X, const void *W1, const float *b1, const void *W2p, const float *b2,
+                             const float *W3, const float *b3, const float *ref, float *out, int M, int mode, void *stream);
+
 /* ---------------------------------------------------------------------------------------------
  * GroupNorm(32, 256) over the tokens of one feature level (statistics per sample and group over
  * T positions x 8 channels, eps, affine).

@@ -419,3 +419,26 @@ def test_proj_ln_bf16_vs_reference(M):
     assert (got - want).abs().max() < tol, (got - want).abs().max().item()
     un = ops.layernorm(ops.linear(a.cuda(), w.cuda(), b.cuda()), gw.cuda(), gb.cuda(), 1e-5, residual=r.cuda()).float().cpu()
     assert (got - un).abs().max() < 3 * tol
+
+
+@pytest.mark.parametrize("mode", [0, 1])
+def test_box_mlp_refine_bf16_vs_reference(mode):
+    """One-launch box MLP (256->256->256->4) + refinement vs fp64 on bf16-rounded inputs/weights (hidden layer 1 rounded to
+    bf16 as the kernel does), and vs the three-launch HIP path."""
+    from dtlr_amd import ops
+    from oracle import dtlr_oracle as O
+    M = 2 * 900 + 5
+    x = _rand((M, 256), 1).bfloat16()
+    w1, w2 = (_rand((256, 256), 2) / 16).bfloat16(), (_rand((256, 256), 3) / 16).bfloat16()
+    b1, b2 = _rand((256,), 4) * 0.3, _rand((256,), 5) * 0.3
+    w3, b3 = _rand((4, 256), 6) / 16, _rand((4,), 7) * 0.1
+    g = np.random.Generator(np.random.PCG64(5))
+    ref = torch.from_numpy(g.uniform(-0.1, 1.1, (M, 4)).astype(np.float32))
+    h1 = torch.relu(x.double() @ w1.double().t() + b1.double()).bfloat16().double()
+    h2 = torch.relu(h1 @ w2.double().t() + b2.double())
+    delta = h2 @ w3.double().t() + b3.double()
+    want = (torch.sigmoid(delta + O.inverse_sigmoid(ref).double()) if mode == 0 else delta + ref.double()).float()
+    got = ops.box_mlp_refine(x.cuda(), w1.cuda(), b1.cuda(), ops.ffn_pack_w2(w2.cuda()), b2.cuda(), w3.cuda(), b3.cuda(), ref.cuda(), mode).cpu()
+    tol = 2e-3 if mode == 0 else 2e-2                       # bf16 rounding of the first hidden layer (flips of 1 ulp)
+    assert (got - want).abs().max() < tol, (got - want).abs().max().item()
+    assert (got - want).abs().mean() < tol / 20
