@@ -47,10 +47,11 @@ MFMA_PEAK_BF16_TFLOPS = 2500.0   # dense bf16 MFMA peak (no sparsity); fp32 MFMA
 MFMA_PEAK_F32_TFLOPS = 157.0
 
 
-def msda_algorithmic_bytes_per_line(S: int, Lq: int, value_elem: int, M=8, D=32, L=4, P=4) -> int:
-    """Compulsory bytes of one MSDA call for one line: read value once,
-    read loc + attn (fp32), write out."""
-    return S * M * D * value_elem + Lq * M * L * P * 2 * 4 + Lq * M * L * P * 4 + Lq * M * D * value_elem
+def msda_algorithmic_bytes_per_line(S: int, Lq: int, value_elem: int, M=8, D=32, L=4, P=4, ref_dim=2) -> int:
+    """Compulsory bytes of one MSDA call for one line ("all operands in the element size e"): read
+    value once, read the offsets + attention logits of every (head, level, point) once (3 numbers each: the fused kernel
+    takes them as the raw projection row, in the engine dtype), read the fp32 reference points, write out."""
+    return S * M * D * value_elem + Lq * M * L * P * 3 * value_elem + Lq * L * ref_dim * 4 + Lq * M * D * value_elem
 
 
 def cpu_baseline(n_lines: int, height: int, width: int, repeats: int, threads: int = 0):
@@ -197,7 +198,7 @@ def main():
         if dec:
             msd = sum(e[0] for e in dec) / len(dec)
             n, lq, s = dec[0][1], dec[0][2], dec[0][3]
-            algd = msda_algorithmic_bytes_per_line(s, lq, velem) * n
+            algd = msda_algorithmic_bytes_per_line(s, lq, velem, ref_dim=4) * n
             roof["decoder_call"] = {"achieved": round(algd / (msd * 1e-3) / 1e9, 1), "mean_launch_ms": round(msd, 4)}
     # ---- per-class rooflines; `roofline` = the class with the largest share of the timed region ----
     by_kernel = []

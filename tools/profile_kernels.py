@@ -93,6 +93,16 @@ def main():
                 res.append({"kernel": name, "ms": ms, "algorithmic_bytes": alg, "GBps": alg / ms / 1e6})
                 ms = timeit(lambda: ops.msda_fused(value, shapes, lsi, ow, refg), args.iters)
                 res.append({"kernel": name.replace("lds", "gather_gridref"), "ms": ms, "algorithmic_bytes": alg, "GBps": alg / ms / 1e6})
+            name = f"msda_lds_{tag}_{dt_name}_engine"          # the engine's configuration: projection row in bf16 too
+            if tag == "enc" and dt == torch.bfloat16 and want(name):
+                ys = [torch.linspace(0.5, h - 0.5, h) / h for h, w in shapes_l]
+                xs = [torch.linspace(0.5, w - 0.5, w) / w for h, w in shapes_l]
+                rp = torch.cat([torch.stack(torch.meshgrid(y, x, indexing="ij")[::-1], -1).reshape(-1, 2) for y, x in zip(ys, xs)], 0)
+                refg = rp[None, :, None, :].expand(B, S, L, 2).contiguous().to(dev)
+                owb = ow.bfloat16()
+                ms = timeit(lambda: ops.msda_encoder(value, shapes_l, owb, refg), args.iters)
+                res.append({"kernel": name, "ms": ms, "algorithmic_bytes": alg, "GBps": alg / ms / 1e6})
+                del owb
             del ow, loc, aw, off
         T = B * S
         x = torch.randn((T, 256), generator=g).to(dev).to(dt)
