@@ -174,6 +174,7 @@ def main():
     log(f"timed {args.steps} steps in {elapsed:.3f}s")
 
     if rank != 0:
+        ddist.finalize()                 # waits for rank 0 (replay + printing) at a last barrier, then tears the group down
         return
     S = 5440 * (args.height // 128) * (args.width // 2048) if (args.height, args.width) == (128, 2048) else None
     enc = [(a.elapsed_time(b), n, lq, s) for (a, b, n, lq, s) in events if lq == s]
@@ -248,6 +249,7 @@ def main():
         line["cpu_baseline"] = cpu_baseline(args.cpu_lines, args.height, args.width, repeats=2, threads=args.cpu_threads)
         line["speedup_vs_cpu"] = round(line["value"] / line["cpu_baseline"]["value"], 1)
     print(json.dumps(line), flush=True)
+    ddist.finalize()
 
 
 if __name__ == "__main__":

@@ -83,3 +83,14 @@ def max_over_ranks(value: float, device) -> float:
     t = torch.tensor([value], dtype=torch.float64, device=device)
     dist.all_reduce(t, op=dist.ReduceOp.MAX)
     return float(t.item())
+
+
+def finalize() -> None:
+    """Last barrier + process-group teardown (all ranks call it once, at the very end)."""
+    if dist.is_available() and dist.is_initialized():
+        try:
+            if dist.get_world_size() > 1:
+                dist.barrier()
+            dist.destroy_process_group()
+        except Exception:       # a peer that already left must not turn a finished run into a failure
+            pass
