@@ -61,14 +61,28 @@ template <int N> __device__ __forceinline__ void wait_vmcnt() {
 #define ABLATE(BIT) false
 #endif
 #ifdef DTLR_GEMM_TRACE
+// Timeline instrumentation (profiling builds only): lane 0 of wave 0 (MFMA role) and of wave 4 (loader role) of the first
+// 8 logical workgroups append (cycle counter << 8 | event code) records; read back with dtlr_debug_gemm_trace.
+//   loader: 1 wait begin, 2 data landed (vmcnt), 3 LDS stores done, 4 next loads issued, 5 barrier passed
+//   MFMA  : 10 barrier passed (slab start), 11 slab's MFMAs issued, 12 epilogue done
 #define TR(...) __VA_ARGS__
-#define TR_NOW() ((long long)__builtin_readcyclecounter())
-// cycle attribution of the wave-specialised kernel, summed over workgroups (wave 0 = MFMA role, wave 4 = loader role):
-// [0] MFMA total [1] reads+MFMA [2] barrier wait [3] epilogue | [4] loader total [5] vmcnt wait [6] LDS store
-// [7] load issue [8] barrier wait | [9] workgroups
-__device__ unsigned long long g_gemm_trace[16];
+#define TL_BLOCKS 8
+#define TL_EVENTS 1024
+__device__ unsigned long long g_gemm_tl[TL_BLOCKS * 2 * TL_EVENTS];
+#define TL_INIT(ROLE)                                                                              \
+    unsigned long long* tl_ = nullptr; int tl_n_ = 0;                                              \
+    if ((threadIdx.x & 63) == 0 && logical0_ < TL_BLOCKS) tl_ = g_gemm_tl + ((long)logical0_ * 2 + (ROLE)) * TL_EVENTS;
+#define TL_EV(CODE) { if (tl_ && tl_n_ < TL_EVENTS) tl_[tl_n_++] = ((unsigned long long)__builtin_readcyclecounter() << 8) | (CODE); }
+#define TL_PARAMS , unsigned long long* tl_, int& tl_n_
+#define TL_ARGS , tl_, tl_n_
+#define TL_ARGS_NONE , tl_none_, tl_n_none_
 #else
+#define TL_PARAMS
+#define TL_ARGS
+#define TL_ARGS_NONE
 #define TR(...)
+#define TL_INIT(ROLE)
+#define TL_EV(CODE)
 #endif
 
 enum : int { EPI_BIAS = 1, EPI_RELU = 2, EPI_RESIDUAL = 4, EPI_ROWMASK = 8, EPI_RELU_POST = 16,
@@ -136,7 +150,7 @@ template <> struct Out<uint16_t> {
 template <typename OutT>
 __device__ __forceinline__ void epilogue_tile(f32x4_t (&acc)[4][4], OutT* __restrict__ C, const float* __restrict__ bias,
                                               const OutT* __restrict__ residual, const uint8_t* __restrict__ row_mask,
-                                              int M, int N, int flags, int tok0, int ch0)
+                                              int M, int N, int flags, int tok0, int ch0 TL_PARAMS)
 {
     const bool vec_ok = (N & 3) == 0;
     // wave-uniform test (the whole 64x64 sub-tile is interior): the paired bf16 stores exchange data between lanes
@@ -149,6 +163,7 @@ __device__ __forceinline__ void epilogue_tile(f32x4_t (&acc)[4][4], OutT* __rest
         bool masked[4];
 #pragma unroll
         for (int ti = 0; ti < 4; ++ti) masked[ti] = (flags & EPI_ROWMASK) && row_mask[tok0 + ti * 16];
+        TL_EV(20)                                                  // epilogue entered, bias / mask loads issued
         constexpr int TB = sizeof(OutT) == 2 ? 2 : 1;              // token groups per batch (register budget: 128 VGPRs)
 #pragma unroll
         for (int t0 = 0; t0 < 4; t0 += TB) {
@@ -160,6 +175,7 @@ __device__ __forceinline__ void epilogue_tile(f32x4_t (&acc)[4][4], OutT* __rest
                     for (int ci = 0; ci < 4; ++ci)
                         rr[tb][ci] = *reinterpret_cast<const typename Out<OutT>::raw4*>(residual + (long)(tok0 + (t0 + tb) * 16) * N + ch0 + ci * 16);
             }
+            TL_EV(21)                                              // this batch's residual loads issued
 #pragma unroll
             for (int tb = 0; tb < TB; ++tb) {
                 const int ti = t0 + tb;
@@ -199,6 +215,7 @@ __device__ __forceinline__ void epilogue_tile(f32x4_t (&acc)[4][4], OutT* __rest
                     else Out<OutT>::st4(C + (long)(tok0 + ti * 16) * N + ch0 + ci * 16, v);
                 }
             }
+            TL_EV(22)                                              // this batch's stores issued
         }
         return;
     }
@@ -294,6 +311,7 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(
     constexpr int BK = GT<T>::BK;
     const int nk = K / BK;
     constexpr int KSPLIT = 1;
+    TR(unsigned long long* tl_none_ = nullptr; int tl_n_none_ = 0; (void)tl_none_; (void)tl_n_none_;)
 
     // PERSISTENT tile chain: this block owns tiles [t_begin, t_end) of the (tm, tn) grid, tn fastest, and
     // walks them as ONE flat stream of K slabs, software-pipelined across tile boundaries: the global
@@ -444,7 +462,7 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(
 #define EPILOGUE()                                                                                 \
     {                                                                                              \
         const int m0 = tile * BM, n0 = tn * BN;                                                    \
-        epilogue_tile<OutT>(acc, C, bias, residual, row_mask, M, N, flags, m0 + wm * 64 + n, n0 + wn * 64 + 4 * g); \
+        epilogue_tile<OutT>(acc, C, bias, residual, row_mask, M, N, flags, m0 + wm * 64 + n, n0 + wn * 64 + 4 * g TL_ARGS_NONE); \
     }
 
     int s = 0;
@@ -563,7 +581,7 @@ __global__ __launch_bounds__(512, HAS_A2 ? 2 : 4) void gemm_ws_kernel(
             if (!ABLATE(DBG_NO_LOAD)) WS_GLOAD(S, lkt)                                             \
         }
         int lkt = 0, ltile = t_begin;
-        TR(long long tl0 = TR_NOW(), tvm = 0, tst = 0, tis = 0, tlb = 0, tx = tl0, ty;)
+        TL_INIT(1)
         WS_SET_TILE(t_begin)
         WS_GLOAD(P, 0)
         if (ASM) wait_vmcnt<0>();
@@ -573,37 +591,32 @@ __global__ __launch_bounds__(512, HAS_A2 ? 2 : 4) void gemm_ws_kernel(
         __syncthreads();                                         // barrier #0: slab 0 visible
         // iteration i (the MFMA waves multiply slab i): store slab i+1, then refill its set with slab i+3
         int i = 0;
-#define TR_MARK(ACC) TR(ty = TR_NOW(); ACC += ty - tx; tx = ty;)
-        TR(tx = TR_NOW();)
         while (i < total) {
             if (i + 1 < total) {                                 // i even: slab i+1 is odd -> set Q, stage 1
+                TL_EV(1)
                 if (ASM) { if (i + 2 < total) wait_vmcnt<NLOAD>(); else wait_vmcnt<0>(); }
-                TR_MARK(tvm)
+                TL_EV(2)
                 if (!ABLATE(DBG_NO_LDS)) WS_LSTORE(Q, 1)
-                TR_MARK(tst)
+                TL_EV(3)
                 if (i + 3 < total) WS_ADVANCE_AND_LOAD(Q)
-                TR_MARK(tis)
+                TL_EV(4)
             }
             __syncthreads();
-            TR_MARK(tlb)
+            TL_EV(5)
             if (++i >= total) break;
             if (i + 1 < total) {                                 // i odd: slab i+1 is even -> set P, stage 0
+                TL_EV(1)
                 if (ASM) { if (i + 2 < total) wait_vmcnt<NLOAD>(); else wait_vmcnt<0>(); }
-                TR_MARK(tvm)
+                TL_EV(2)
                 if (!ABLATE(DBG_NO_LDS)) WS_LSTORE(P, 0)
-                TR_MARK(tst)
+                TL_EV(3)
                 if (i + 3 < total) WS_ADVANCE_AND_LOAD(P)
-                TR_MARK(tis)
+                TL_EV(4)
             }
             __syncthreads();
-            TR_MARK(tlb)
+            TL_EV(5)
             ++i;
         }
-        TR(if (threadIdx.x == 256) {
-            atomicAdd(&g_gemm_trace[4], (unsigned long long)(TR_NOW() - tl0)); atomicAdd(&g_gemm_trace[5], (unsigned long long)tvm);
-            atomicAdd(&g_gemm_trace[6], (unsigned long long)tst); atomicAdd(&g_gemm_trace[7], (unsigned long long)tis);
-            atomicAdd(&g_gemm_trace[8], (unsigned long long)tlb); })
-#undef TR_MARK
 #undef WS_LD16
 #undef WS_SET_TILE
 #undef WS_GLOAD1
@@ -624,9 +637,9 @@ __global__ __launch_bounds__(512, HAS_A2 ? 2 : 4) void gemm_ws_kernel(
 #pragma unroll
         for (int ti = 0; ti < 4; ++ti) acc[ci][ti] = f32x4_t{0.f, 0.f, 0.f, 0.f};
     int kt = 0, tile = t_begin;
-    TR(long long tm0 = TR_NOW(), twk = 0, tmb = 0, tep = 0, tx, ty;)
+    TL_INIT(0)
     __syncthreads();                                             // barrier #0
-    TR(tx = TR_NOW();)
+    TL_EV(10)
     for (int s = 0; s < total; ++s) {
         const unsigned char* wt = smem + (s & 1) * 2 * TILE_BYTES + (wn * 64 + n) * LDS_ROW;
         const unsigned char* xt = wt + TILE_BYTES + ((wm - wn) * 64) * LDS_ROW;
@@ -649,21 +662,17 @@ __global__ __launch_bounds__(512, HAS_A2 ? 2 : 4) void gemm_ws_kernel(
                     if (!ABLATE(DBG_NO_MMA)) GT<T>::mma(wf[kq][ci], xf[kq][ti], acc[ci][ti]);
                     else asm volatile("" :: "v"(wf[kq][ci].x), "v"(xf[kq][ti].x));
                 }
-        TR(ty = TR_NOW(); twk += ty - tx; tx = ty;)
+        TL_EV(11)
         __syncthreads();
-        TR(ty = TR_NOW(); tmb += ty - tx; tx = ty;)
+        TL_EV(10)
         if (++kt == nk) {
             const int m0 = tile * BM, n0 = tn * BN;
             if (!ABLATE(DBG_NO_EPI))
-                epilogue_tile<OutT>(acc, C, bias, residual, row_mask, M, N, flags, m0 + wm * 64 + n, n0 + wn * 64 + 4 * g);
+                epilogue_tile<OutT>(acc, C, bias, residual, row_mask, M, N, flags, m0 + wm * 64 + n, n0 + wn * 64 + 4 * g TL_ARGS);
             kt = 0; ++tile;
-            TR(ty = TR_NOW(); tep += ty - tx; tx = ty;)
+            TL_EV(12)
         }
     }
-    TR(if (threadIdx.x == 0) {
-        atomicAdd(&g_gemm_trace[0], (unsigned long long)(TR_NOW() - tm0)); atomicAdd(&g_gemm_trace[1], (unsigned long long)twk);
-        atomicAdd(&g_gemm_trace[2], (unsigned long long)tmb); atomicAdd(&g_gemm_trace[3], (unsigned long long)tep);
-        atomicAdd(&g_gemm_trace[9], 1ull); })
 }
 
 // tiles per block: enough chains to fill the chip (2 resident workgroups x 256 CUs) a few times over
@@ -878,13 +887,15 @@ extern "C" int dtlr_gemm_nt(const void* A, const void* A2, const void* W, const 
 }
 
 #ifdef DTLR_GEMM_TRACE
-// instrumentation builds only (tools/): read and reset the cycle-attribution counters of gemm_ws_kernel
-extern "C" int dtlr_debug_gemm_trace(unsigned long long* out16)
+// instrumentation builds only (tools/): read and reset the timeline of gemm_ws_kernel: out[TL_BLOCKS][2][TL_EVENTS]
+extern "C" int dtlr_debug_gemm_trace(unsigned long long* out, int clear_only)
 {
     if (hipDeviceSynchronize() != hipSuccess) return DTLR_ELAUNCH;
-    if (hipMemcpyFromSymbol(out16, HIP_SYMBOL(g_gemm_trace), 16 * sizeof(unsigned long long)) != hipSuccess) return DTLR_ELAUNCH;
-    unsigned long long z[16] = {0};
-    if (hipMemcpyToSymbol(HIP_SYMBOL(g_gemm_trace), z, sizeof(z)) != hipSuccess) return DTLR_ELAUNCH;
+    const size_t bytes = sizeof(unsigned long long) * TL_BLOCKS * 2 * TL_EVENTS;
+    if (!clear_only && hipMemcpyFromSymbol(out, HIP_SYMBOL(g_gemm_tl), bytes) != hipSuccess) return DTLR_ELAUNCH;
+    void* dptr = nullptr;
+    if (hipGetSymbolAddress(&dptr, HIP_SYMBOL(g_gemm_tl)) != hipSuccess) return DTLR_ELAUNCH;
+    if (hipMemset(dptr, 0, bytes) != hipSuccess) return DTLR_ELAUNCH;
     return DTLR_OK;
 }
 #endif

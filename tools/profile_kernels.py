@@ -169,34 +169,45 @@ def main():
         res.append({"kernel": "ffn_unfused_bf16_M174080_dff2048", "ms": ms, "TFLOPs": flops / ms / 1e9})
         del x
     if "gemm_trace" in only:
-        # needs DTLR_HIP_LIB=dtlr_amd/libdtlr_hip_instr.so: per-role cycle attribution + phase switches of gemm_ws_kernel
+        # needs DTLR_HIP_LIB=dtlr_amd/libdtlr_hip_trace.so (python -m dtlr_amd.build --trace): per-slab timeline of gemm_ws_kernel for
+        # the first workgroups: where a slab iteration spends its cycles (loader: wait for data / LDS store / issue / barrier;
+        # MFMA waves: slab / epilogue)
         import ctypes
         from dtlr_amd import _lib
         L = _lib.lib()
         if not hasattr(L, "dtlr_debug_gemm_trace"):
-            raise SystemExit("gemm_trace needs the instrumented library (python -m dtlr_amd.build --instr; DTLR_HIP_LIB=...)")
-        buf = (ctypes.c_ulonglong * 16)()
+            raise SystemExit("gemm_trace needs the trace library (python -m dtlr_amd.build --trace; DTLR_HIP_LIB=...)")
+        NB, NE = 8, 1024
+        buf = (ctypes.c_ulonglong * (NB * 2 * NE))()
         T = B * S
-        names = ["mfma_total", "mfma_work", "mfma_barrier", "mfma_epilogue", "ld_total", "ld_vmwait", "ld_lds_store", "ld_issue", "ld_barrier", "blocks"]
-        for (N_, K_, relu) in ((256, 256, 0), (2048, 256, 1), (256, 2048, 0)):
+        for (N_, K_, relu, use_res) in ((256, 256, 0, False), (256, 256, -1, False), (256, 256, 0, True)):
             x = torch.randn((T, K_), generator=g).to(dev).bfloat16()
             w = (torch.randn((N_, K_), generator=g) / K_ ** 0.5).to(dev).bfloat16()
             bb = torch.randn((N_,), generator=g).to(dev)
-            flops = 2.0 * T * N_ * K_
-            for code, label in ((0, "full"), (2048, "no_epilogue"), (256, "no_global_loads"), (512, "no_mfma"), (1024, "no_lds_store"),
-                                (2048 + 256, "no_epi_no_loads"), (2048 + 512 + 1024 + 256, "skeleton")):
-                os.environ["DTLR_GEMM_ABLATE"] = str(code)
-                ms = timeit(lambda: ops.linear(x, w, bb, relu), 6)
-                L.dtlr_debug_gemm_trace(buf)
-                ops.linear(x, w, bb, relu)
-                L.dtlr_debug_gemm_trace(buf)
-                v = list(buf)
-                nb = max(v[9], 1)
-                rec = {"kernel": f"gemm_trace_bf16_N{N_}_K{K_}_{label}", "ms": ms, "TFLOPs_equiv": flops / ms / 1e9}
-                rec.update({k: round(v[i] / nb) for i, k in enumerate(names[:9])})
-                rec["blocks"] = v[9]
-                res.append(rec)
-            os.environ["DTLR_GEMM_ABLATE"] = "0"
+            rs = torch.randn((T, N_), generator=g).to(dev).bfloat16() if use_res else None
+            if relu < 0:                                        # -1: no bias at all (isolates the epilogue's bias loads)
+                bb, relu = None, 0
+            for _ in range(3):
+                ops.linear(x, w, bb, relu, rs)
+            L.dtlr_debug_gemm_trace(buf, 1)
+            ops.linear(x, w, bb, relu, rs)
+            L.dtlr_debug_gemm_trace(buf, 0)
+            import numpy as np
+            arr = np.frombuffer(buf, dtype=np.uint64).reshape(NB, 2, NE).copy()
+            for blk in (5,):
+                for role, rname in ((0, "mfma"), (1, "loader")):
+                    ev = arr[blk, role]
+                    ev = ev[ev != 0]
+                    t, c = (ev >> np.uint64(8)).astype(np.int64), (ev & np.uint64(0xff)).astype(np.int64)
+                    if len(t) < 4:
+                        continue
+                    d = np.diff(t)
+                    seg = {}
+                    for k in range(len(d)):
+                        seg.setdefault((int(c[k]), int(c[k + 1])), []).append(int(d[k]))
+                    summ = {f"{a}->{b}": [len(v), int(np.median(v)), int(np.mean(v)), int(np.max(v))] for (a, b), v in sorted(seg.items())}
+                    res.append({"kernel": f"gemm_trace_N{N_}_K{K_}_bias{int(bb is not None)}_res{int(use_res)}_blk{blk}_{rname}", "events": int(len(t)),
+                                "span_cycles": int(t[-1] - t[0]), "segments[count,median,mean,max]": summ})
             del x, w
     for r in res:
         print(json.dumps(r))
