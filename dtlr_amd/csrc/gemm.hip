@@ -147,11 +147,15 @@ template <> struct Out<uint16_t> {
 // issued after a store can only be waited for with vmcnt(0), i.e. together with that store's full round trip to
 // L2/HBM.  The first version interleaved them per 4-channel group: 16 serialised round trips per tile, measured
 // (cycle attribution, tools/profile_kernels.py --only gemm_trace) at 2/3 of the K = 256 kernels' time.
-template <typename OutT>
+// CF >= 0: the epilogue flags are a compile-time constant (the hot combinations get their own kernel instantiation): the
+// timeline trace put the generic epilogue at ~50 VALU instructions + 6 branches per 4-channel group -- 40% of a K = 256 tile,
+// VALU-bound -- most of them for options a given call does not use.  CF < 0: runtime flags (every other combination).
+template <typename OutT, int CF = -1>
 __device__ __forceinline__ void epilogue_tile(f32x4_t (&acc)[4][4], OutT* __restrict__ C, const float* __restrict__ bias,
                                               const OutT* __restrict__ residual, const uint8_t* __restrict__ row_mask,
-                                              int M, int N, int flags, int tok0, int ch0 TL_PARAMS)
+                                              int M, int N, int flags_rt, int tok0, int ch0 TL_PARAMS)
 {
+    const int flags = CF >= 0 ? CF : flags_rt;
     const bool vec_ok = (N & 3) == 0;
     // wave-uniform test (the whole 64x64 sub-tile is interior): the paired bf16 stores exchange data between lanes
     const int lane_ = (int)threadIdx.x & 63;
@@ -494,7 +498,7 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(
 //   MFMA waves   (0..3): 16 ds_read_b128 + 32 MFMA on stage s&1
 // and meet at ONE barrier per slab.  Same tile chain, same LDS image, same epilogue as above.
 // ---------------------------------------------------------------------------------------------
-template <typename T, typename OutT, bool HAS_A2, bool CONV>
+template <typename T, typename OutT, bool HAS_A2, bool CONV, int CF = -1>
 __global__ __launch_bounds__(512, HAS_A2 ? 2 : 4) void gemm_ws_kernel(
     const T* __restrict__ A, const T* __restrict__ A2, const T* __restrict__ W,
     const float* __restrict__ bias, const OutT* __restrict__ residual, const uint8_t* __restrict__ row_mask,
@@ -668,7 +672,7 @@ __global__ __launch_bounds__(512, HAS_A2 ? 2 : 4) void gemm_ws_kernel(
         if (++kt == nk) {
             const int m0 = tile * BM, n0 = tn * BN;
             if (!ABLATE(DBG_NO_EPI))
-                epilogue_tile<OutT>(acc, C, bias, residual, row_mask, M, N, flags, m0 + wm * 64 + n, n0 + wn * 64 + 4 * g TL_ARGS);
+                epilogue_tile<OutT, CF>(acc, C, bias, residual, row_mask, M, N, flags, m0 + wm * 64 + n, n0 + wn * 64 + 4 * g TL_ARGS);
             kt = 0; ++tile;
             TL_EV(12)
         }
@@ -778,6 +782,16 @@ static int try_splitk(const void* A, const void* W, const float* bias, const voi
     return check_launch();
 }
 
+// launch gemm_ws_kernel<T, OutT, A2, CONV, CF> (setting its dynamic-LDS attribute once)
+#define WS_LAUNCH(A2, CONV, CF, GRID, ...)                                                          \
+    {                                                                                              \
+        static bool attr_ = false;                                                                 \
+        if (!attr_) { (void)hipFuncSetAttribute((const void*)gemm_ws_kernel<T, OutT, A2, CONV, CF>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); (void)hipGetLastError(); attr_ = true; } \
+        hipLaunchKernelGGL((gemm_ws_kernel<T, OutT, A2, CONV, CF>), dim3(GRID), dim3(512), lds, st, __VA_ARGS__); \
+    }
+// the flag sets that get a specialised epilogue (bf16 -> bf16 only; everything else runs the generic one)
+template <typename T, typename OutT> constexpr bool kSpecialise = (sizeof(T) == 2 && sizeof(OutT) == 2);
+
 template <typename T, typename OutT>
 static int launch_conv(const void* X, const void* W, const float* bias, const void* residual, void* C,
                        int M, int N, int K, int flags, const ConvP& cp, hipStream_t st)
@@ -792,13 +806,16 @@ static int launch_conv(const void* X, const void* W, const float* bias, const vo
         bool done = false;
         const int rc = try_splitk<T, OutT, true>(X, W, bias, residual, nullptr, C, M, N, K, flags, cp, st, done);
         if (rc != DTLR_OK || done) return rc;
-        static bool attr_ws = false;
-        if (!attr_ws) { (void)hipFuncSetAttribute((const void*)gemm_ws_kernel<T, OutT, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); attr_ws = true; }
         const int per = plan_chain_ws(nwg);
         const unsigned grid = (unsigned)(nN * ((nM + per - 1) / per));
-        hipLaunchKernelGGL((gemm_ws_kernel<T, OutT, false, true>), dim3(grid), dim3(512), lds, st,
-                           (const T*)X, (const T*)nullptr, (const T*)W, bias, (const OutT*)residual, (const uint8_t*)nullptr, (OutT*)C,
-                           M, N, K, flags, nN, nM, per, cp, 1);
+#define CONV_ARGS (const T*)X, (const T*)nullptr, (const T*)W, bias, (const OutT*)residual, (const uint8_t*)nullptr, (OutT*)C, M, N, K, flags, nN, nM, per, cp, 1
+        if constexpr (kSpecialise<T, OutT>) {
+            if (flags == (EPI_BIAS | EPI_RELU_POST)) { WS_LAUNCH(false, true, (EPI_BIAS | EPI_RELU_POST), grid, CONV_ARGS) return check_launch(); }
+            if (flags == (EPI_BIAS | EPI_RELU_POST | EPI_RESIDUAL)) { WS_LAUNCH(false, true, (EPI_BIAS | EPI_RELU_POST | EPI_RESIDUAL), grid, CONV_ARGS) return check_launch(); }
+            if (flags == EPI_BIAS) { WS_LAUNCH(false, true, EPI_BIAS, grid, CONV_ARGS) return check_launch(); }
+        }
+        WS_LAUNCH(false, true, -1, grid, CONV_ARGS)
+#undef CONV_ARGS
         return check_launch();
     }
     const int per = plan_chain(nwg);
@@ -826,17 +843,22 @@ static int launch_gemm(const void* A, const void* A2, const void* W, const float
         }
         const int perw = plan_chain_ws(nwg);
         const unsigned gridw = (unsigned)(nN * ((nM + perw - 1) / perw));
+#define GEMM_ARGS(A2P) (const T*)A, (const T*)(A2P), (const T*)W, bias, (const OutT*)residual, row_mask, (OutT*)C, M, N, K, flags, nN, nM, perw, cp, 1
         if (A2) {
-            static bool a1 = false;
-            if (!a1) { (void)hipFuncSetAttribute((const void*)gemm_ws_kernel<T, OutT, true, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); a1 = true; }
-            hipLaunchKernelGGL((gemm_ws_kernel<T, OutT, true, false>), dim3(gridw), dim3(512), lds, st,
-                               (const T*)A, (const T*)A2, (const T*)W, bias, (const OutT*)residual, row_mask, (OutT*)C, M, N, K, flags, nN, nM, perw, cp, 1);
+            if constexpr (kSpecialise<T, OutT>) {
+                if (flags == EPI_BIAS) { WS_LAUNCH(true, false, EPI_BIAS, gridw, GEMM_ARGS(A2)) return check_launch(); }
+            }
+            WS_LAUNCH(true, false, -1, gridw, GEMM_ARGS(A2))
         } else {
-            static bool a0 = false;
-            if (!a0) { (void)hipFuncSetAttribute((const void*)gemm_ws_kernel<T, OutT, false, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); a0 = true; }
-            hipLaunchKernelGGL((gemm_ws_kernel<T, OutT, false, false>), dim3(gridw), dim3(512), lds, st,
-                               (const T*)A, (const T*)nullptr, (const T*)W, bias, (const OutT*)residual, row_mask, (OutT*)C, M, N, K, flags, nN, nM, perw, cp, 1);
+            if constexpr (kSpecialise<T, OutT>) {
+                if (flags == EPI_BIAS) { WS_LAUNCH(false, false, EPI_BIAS, gridw, GEMM_ARGS(nullptr)) return check_launch(); }
+                if (flags == (EPI_BIAS | EPI_RELU)) { WS_LAUNCH(false, false, (EPI_BIAS | EPI_RELU), gridw, GEMM_ARGS(nullptr)) return check_launch(); }
+                if (flags == (EPI_BIAS | EPI_RELU_POST)) { WS_LAUNCH(false, false, (EPI_BIAS | EPI_RELU_POST), gridw, GEMM_ARGS(nullptr)) return check_launch(); }
+                if (flags == (EPI_BIAS | EPI_RELU_POST | EPI_RESIDUAL)) { WS_LAUNCH(false, false, (EPI_BIAS | EPI_RELU_POST | EPI_RESIDUAL), gridw, GEMM_ARGS(nullptr)) return check_launch(); }
+            }
+            WS_LAUNCH(false, false, -1, gridw, GEMM_ARGS(nullptr))
         }
+#undef GEMM_ARGS
         return check_launch();
     }
     const int per = plan_chain(nwg);
