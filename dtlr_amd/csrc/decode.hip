@@ -15,17 +15,29 @@ __device__ __forceinline__ uint32_t f32_sortable(float f) {
     return (u & 0x80000000u) ? ~u : (u | 0x80000000u);
 }
 
-// in-LDS bitonic sort of n = power of two 64-bit keys, ascending
+// in-LDS bitonic sort of n = power of two 64-bit keys, ascending.  A thread owns compare-exchange PAIRS (pair t of stage j is
+// i = the index with bit j cleared, i | j), four at a time, and reads all eight keys before it writes any: one LDS round trip
+// per stage instead of one per element (the element-wise form serialised 8 dependent read->write trips per stage at n = 8192
+// and made the two selection kernels ~100 us each).
 __device__ __forceinline__ void bitonic_sort_u64(unsigned long long* keys, int n) {
+    const int half = n >> 1;
     for (int k = 2; k <= n; k <<= 1) {
         for (int j = k >> 1; j > 0; j >>= 1) {
             __syncthreads();
-            for (int i = threadIdx.x; i < n; i += blockDim.x) {
-                const int ixj = i ^ j;
-                if (ixj > i) {
-                    const unsigned long long a = keys[i], b = keys[ixj];
-                    const bool up = (i & k) == 0;
-                    if ((a > b) == up) { keys[i] = b; keys[ixj] = a; }
+            for (int t0 = threadIdx.x; t0 < half; t0 += 4 * blockDim.x) {
+                unsigned long long a[4], b[4];
+                int ia[4];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    const int t = t0 + u * blockDim.x;
+                    ia[u] = t < half ? (((t & ~(j - 1)) << 1) | (t & (j - 1))) : -1;
+                    if (ia[u] >= 0) { a[u] = keys[ia[u]]; b[u] = keys[ia[u] | j]; }
+                }
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    if (ia[u] < 0) continue;
+                    const bool up = (ia[u] & k) == 0;
+                    if ((a[u] > b[u]) == up) { keys[ia[u]] = b[u]; keys[ia[u] | j] = a[u]; }
                 }
             }
         }
@@ -33,56 +45,139 @@ __device__ __forceinline__ void bitonic_sort_u64(unsigned long long* keys, int n
     __syncthreads();
 }
 
+// k largest scores of a row, descending (ties: lower index first).  key = (~sortable(score) << 32) | index is unique, so the
+// k-th smallest key K* is found EXACTLY by a radix select (six 8-bit histogram passes over the row in LDS: the four score bytes
+// and the two live index bytes), the k keys <= K* are compacted, and only those are sorted (a 1024-key network, 55 stages,
+// instead of the 8192-key one, 91 stages at 8x the traffic: the full sort was LDS-bandwidth bound at ~80 us).
+// KP2 = next_pow2(k) ; when KP2 >= npow2 the row is simply sorted whole.
 __global__ __launch_bounds__(1024) void topk_rows_kernel(const float* __restrict__ scores, long* __restrict__ idx_out,
-                                                         int S, int k, int npow2)
+                                                         int S, int k, int npow2, int kp2)
 {
-    extern __shared__ __attribute__((aligned(16))) unsigned long long keys[];
+    extern __shared__ __attribute__((aligned(16))) unsigned long long keys[];      // [npow2] row keys, then [kp2] candidates
+    __shared__ int hist[256];
+    __shared__ int s_rem, s_digit, s_cnt;
     const int b = blockIdx.x;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const float* row = scores + (long)b * S;
-    // ascending sort of key = (~sortable(score) << 32) | index  ==  descending score, ascending index
     for (int i = threadIdx.x; i < npow2; i += blockDim.x)
         keys[i] = i < S ? (((unsigned long long)(~f32_sortable(row[i]))) << 32) | (unsigned)i : ~0ull;
-    bitonic_sort_u64(keys, npow2);
-    for (int i = threadIdx.x; i < k; i += blockDim.x) idx_out[(long)b * k + i] = (long)(keys[i] & 0xffffffffull);
+    if (kp2 >= npow2) {
+        bitonic_sort_u64(keys, npow2);
+        for (int i = threadIdx.x; i < k; i += blockDim.x) idx_out[(long)b * k + i] = (long)(keys[i] & 0xffffffffull);
+        return;
+    }
+    unsigned long long* cand = keys + npow2;
+    unsigned long long pref = 0ull, mask = 0ull;
+    int rem = k;
+    for (int pass = 0; pass < 6; ++pass) {
+        const int byte = pass < 4 ? 7 - pass : 5 - pass;                          // 7, 6, 5, 4, then 1, 0 (index bytes 3, 2 are zero)
+        if (threadIdx.x < 256) hist[threadIdx.x] = 0;
+        __syncthreads();
+        for (int i = threadIdx.x; i < npow2; i += blockDim.x) {
+            const unsigned long long key = keys[i];
+            if ((key & mask) == pref) atomicAdd(&hist[(int)(key >> (8 * byte)) & 255], 1);
+        }
+        __syncthreads();
+        if (wave == 0) {                                                          // which digit holds the rem-th smallest key?
+            const int4 h = reinterpret_cast<const int4*>(hist)[lane];
+            const int loc = h.x + h.y + h.z + h.w;
+            int inc = loc;
+#pragma unroll
+            for (int o = 1; o < 64; o <<= 1) { const int t = __shfl_up(inc, o, 64); if (lane >= o) inc += t; }
+            const int exc = inc - loc;
+            if (exc < rem && rem <= inc) {                                        // exactly one lane
+                int r = rem - exc, d = 0;
+                if (r > h.x) { r -= h.x; d = 1; if (r > h.y) { r -= h.y; d = 2; if (r > h.z) { r -= h.z; d = 3; } } }
+                s_rem = r; s_digit = 4 * lane + d;
+            }
+        }
+        __syncthreads();
+        rem = s_rem;
+        pref |= (unsigned long long)s_digit << (8 * byte);
+        mask |= 0xffull << (8 * byte);
+        if (byte == 4) mask |= 0xffff0000ull;                                     // index < 2^16: those bytes match as zero
+    }
+    // pref == K*.  Compact the k keys <= K* (any order: they are sorted next), one LDS atomic per wave
+    if (threadIdx.x == 0) s_cnt = 0;
+    for (int i = k + threadIdx.x; i < kp2; i += blockDim.x) cand[i] = ~0ull;
+    __syncthreads();
+    for (int i0 = 0; i0 < npow2; i0 += blockDim.x) {
+        const int i = i0 + threadIdx.x;
+        const unsigned long long key = i < npow2 ? keys[i] : ~0ull;
+        const bool sel = key <= pref;
+        const unsigned long long m = __ballot(sel);
+        int base = 0;
+        if (lane == 0 && m) base = atomicAdd(&s_cnt, __popcll(m));
+        base = __shfl(base, 0, 64);
+        if (sel) cand[base + __popcll(m & ((1ull << lane) - 1ull))] = key;
+    }
+    bitonic_sort_u64(cand, kp2);
+    for (int i = threadIdx.x; i < k; i += blockDim.x) idx_out[(long)b * k + i] = (long)(cand[i] & 0xffffffffull);
 }
 
-// logits [B,nq,C] fp32, boxes [B,nq,4] fp32 -> labels [B,nq] int32 (left-packed, -1 padded), lengths [B]
-__global__ __launch_bounds__(1024) void decode_blank_kernel(const float* __restrict__ logits, const float* __restrict__ boxes,
-                                                            int* __restrict__ labels, int* __restrict__ lengths,
-                                                            int nq, int C, float eps, int npow2)
+template <int CTRL>
+__device__ __forceinline__ float dpp_f(float v) { return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, 0xf, 0xf, true)); }
+template <int CTRL>
+__device__ __forceinline__ int dpp_i(int v) { return __builtin_amdgcn_update_dpp(0, v, CTRL, 0xf, 0xf, true); }
+
+// Step 1 of the blank decoder, chip-wide: the label of every query (class index, or -1 = blank), 16 lanes per query.
+// logits [B*nq, C] fp32 -> raw [B*nq] int32.  The 16-lane reductions are DPP row operations (xor 1, xor 2, half-mirror, mirror):
+// no LDS traffic, no 64-lane butterflies.
+__global__ __launch_bounds__(256) void query_label_kernel(const float* __restrict__ logits, int* __restrict__ raw, long nrows, int C, float eps)
 {
-    extern __shared__ __attribute__((aligned(16))) unsigned long long keys[];      // [npow2] then int lab[npow2]
+    const int l16 = threadIdx.x & 15;
+    const long q = (long)blockIdx.x * 16 + (threadIdx.x >> 4);
+    const bool live = q < nrows;
+    const float* lr = logits + (live ? q : 0) * C;
+    float sum = 0.f, best = -1.f;
+    int arg = 0x7fffffff;
+    for (int c0 = 0; c0 < C; c0 += 64) {                            // four classes per lane in flight
+        float x[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) { const int c = c0 + 16 * u + l16; x[u] = (live && c < C) ? lr[c] : -INFINITY; }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int c = c0 + 16 * u + l16;
+            const float pq = 1.f / (1.f + expf(-x[u]));             // sigmoid(-inf) = 0 for the padding
+            sum += pq;
+            if (c < C && pq > best) { best = pq; arg = c; }         // ascending c: the first maximum of the lane
+        }
+    }
+#define QL_STEP(CTRL)                                                                          \
+    {                                                                                          \
+        sum += dpp_f<CTRL>(sum);                                                               \
+        const float ob = dpp_f<CTRL>(best);                                                    \
+        const int oa = dpp_i<CTRL>(arg);                                                       \
+        if (ob > best || (ob == best && oa < arg)) { best = ob; arg = oa; }                    \
+    }
+    QL_STEP(0xB1) QL_STEP(0x4E) QL_STEP(0x141) QL_STEP(0x140)       // quad xor 1, quad xor 2, row_half_mirror, row_mirror
+#undef QL_STEP
+    // blank channel (dino.py:489-502): sum < 1-eps -> blank = 1-sum ; else blank = eps, p <- (1-eps) p / sum
+    float blank, top;
+    if (sum < 1.f - eps) { blank = 1.f - sum; top = best; }
+    else { blank = eps; top = (1.f - eps) * best / sum; }
+    if (live && l16 == 0) raw[q] = (blank >= top) ? -1 : arg;       // argmax over [blank | classes]: blank wins ties
+}
+
+// Step 2, one workgroup per line: sort the queries by box cx, read their labels in that order, drop the blanks.
+// boxes [B,nq,4] fp32 ; labels [B,nq] int32 holds the per-query labels of step 1 on entry and the left-packed, -1 padded
+// reading-order labels on exit ; lengths [B]
+__global__ __launch_bounds__(1024) void decode_blank_kernel(const float* __restrict__ boxes,
+                                                            int* __restrict__ labels, int* __restrict__ lengths,
+                                                            int nq, int npow2)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned long long keys[];      // [npow2] then int lab[npow2], int rawl[npow2]
     int* lab = reinterpret_cast<int*>(keys + npow2);
+    int* rawl = lab + npow2;
     __shared__ int wave_tot[16];
     const int b = blockIdx.x;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nwave = blockDim.x >> 6;
-    for (int i = threadIdx.x; i < npow2; i += blockDim.x)
+    for (int i = threadIdx.x; i < npow2; i += blockDim.x) {
         keys[i] = i < nq ? (((unsigned long long)f32_sortable(boxes[((long)b * nq + i) * 4])) << 32) | (unsigned)i : ~0ull;
-    bitonic_sort_u64(keys, npow2);                                             // ascending cx, ties: lower index first
-    // one wave per sorted position
-    for (int p = wave; p < nq; p += nwave) {
-        const int q = (int)(keys[p] & 0xffffffffull);
-        const float* lr = logits + ((long)b * nq + q) * C;
-        float sum = 0.f, best = -1.f;
-        int arg = 0x7fffffff;
-        for (int c = lane; c < C; c += 64) {
-            const float pr = 1.f / (1.f + expf(-lr[c]));
-            sum += pr;
-            if (pr > best) { best = pr; arg = c; }                             // first maximum within the lane's stride
-        }
-        sum = wave_sum(sum);
-#pragma unroll
-        for (int o = 32; o > 0; o >>= 1) {                                     // max with lowest-index tie break
-            const float ob = __shfl_xor(best, o, 64);
-            const int oa = __shfl_xor(arg, o, 64);
-            if (ob > best || (ob == best && oa < arg)) { best = ob; arg = oa; }
-        }
-        // blank channel (dino.py:489-502): sum < 1-eps -> blank = 1-sum ; else blank = eps, p <- (1-eps) p / sum
-        float blank, top;
-        if (sum < 1.f - eps) { blank = 1.f - sum; top = best; }
-        else { blank = eps; top = (1.f - eps) * best / sum; }
-        if (lane == 0) lab[p] = (blank >= top) ? -1 : arg;                     // argmax over [blank | classes]: blank wins ties
+        rawl[i] = i < nq ? labels[(long)b * nq + i] : -1;
     }
+    bitonic_sort_u64(keys, npow2);                                             // ascending cx, ties: lower index first
+    for (int p = threadIdx.x; p < nq; p += blockDim.x) lab[p] = rawl[(int)(keys[p] & 0xffffffffull)];
     __syncthreads();
     // stable compaction of the non-blank labels: block-wide exclusive scan of keep flags
     int running = 0;
@@ -117,13 +212,14 @@ extern "C" int dtlr_topk_rows(const float* scores, long* idx_out, int B, int S, 
     clear_stale_error();
     if (!scores || !idx_out) return DTLR_EINVAL;
     if (B <= 0 || S <= 0 || k <= 0 || k > S) return DTLR_EINVAL;
-    const int np = next_pow2(S);
-    const size_t lds = (size_t)np * 8;
-    if (lds > 160 * 1024) return DTLR_ESHAPE;
+    const int np = next_pow2(S), kp = next_pow2(k);
+    if (np > 65536) return DTLR_ESHAPE;                        // the radix select relies on index < 2^16
+    const size_t lds = (size_t)np * 8 + (kp < np ? (size_t)kp * 8 : 0);
+    if (lds > 156 * 1024) return DTLR_ESHAPE;
     (void)hipGetLastError();                                   // do not inherit a stale error from an earlier API call
     if (lds > 64 * 1024) (void)hipFuncSetAttribute((const void*)topk_rows_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     (void)hipGetLastError();
-    hipLaunchKernelGGL(topk_rows_kernel, dim3(B), dim3(1024), lds, (hipStream_t)stream, scores, idx_out, S, k, np);
+    hipLaunchKernelGGL(topk_rows_kernel, dim3(B), dim3(1024), lds, (hipStream_t)stream, scores, idx_out, S, k, np, kp);
     return check_launch();
 }
 
@@ -134,11 +230,13 @@ extern "C" int dtlr_decode_blank(const float* logits, const float* boxes, int* l
     if (!logits || !boxes || !labels || !lengths) return DTLR_EINVAL;
     if (B <= 0 || nq <= 0 || C <= 0) return DTLR_EINVAL;
     const int np = next_pow2(nq);
-    const size_t lds = (size_t)np * 12;
+    const size_t lds = (size_t)np * 16;
     if (lds > 150 * 1024) return DTLR_ESHAPE;
     (void)hipGetLastError();
     if (lds > 60 * 1024) (void)hipFuncSetAttribute((const void*)decode_blank_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     (void)hipGetLastError();
-    hipLaunchKernelGGL(decode_blank_kernel, dim3(B), dim3(1024), lds, (hipStream_t)stream, logits, boxes, labels, lengths, nq, C, eps, np);
+    const long nrows = (long)B * nq;
+    hipLaunchKernelGGL(query_label_kernel, dim3((unsigned)((nrows + 15) / 16)), dim3(256), 0, (hipStream_t)stream, logits, labels, nrows, C, eps);
+    hipLaunchKernelGGL(decode_blank_kernel, dim3(B), dim3(1024), lds, (hipStream_t)stream, boxes, labels, lengths, nq, np);
     return check_launch();
 }

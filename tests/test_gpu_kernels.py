@@ -321,6 +321,11 @@ def test_topk_rows(B, S, k):
         sc[0, 10:60] = sc[0, 5]                 # exact ties
         sc[0, 3] = float("inf")
         sc[0, 4] = float("-inf")
+        if B > 1:
+            sc[1, :] = 0.25                     # a whole row of ties: the cut falls INSIDE the tie block (radix select on (score, index))
+            sc[1, S // 2:] = -0.5
+            if B > 2:
+                sc[2, ::3] = sc[2, 0]           # ties interleaved with distinct values across the cut
     got = ops.topk_rows(sc.cuda(), k).cpu()
     order = torch.sort(sc, dim=1, descending=True, stable=True)[1][:, :k]       # stable: ties keep the lower index
     assert torch.equal(got, order)
