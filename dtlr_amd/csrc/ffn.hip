@@ -72,7 +72,8 @@ __device__ __forceinline__ void unpack8(const uint4& t, float (&v)[8]) {
 }
 
 // DBG (timing experiments only, env DTLR_FFN_DBG; results are garbage): 1 = no weight DMA after the prologue,
-// 2 = no MFMA, 4 = no per-chunk barrier.  DBG = 0 is the product kernel; the switches are compile-time so it carries no branches.
+// 2 = no MFMA, 4 = no per-chunk barrier, 8 = no pinned interleave, 16 = no H store, 32 = no weight-fragment LDS reads after chunk 0
+// (8 and up only in the instrumented build).  DBG = 0 is the product kernel; the switches are compile-time so it carries no branches.
 // HEAD = true: the same two MFMA phases run a 3-layer box MLP (models/dino/dino.py MLP(256, 256, 4, 3)): no residual / LayerNorm;
 // the epilogue applies ReLU to the second layer, multiplies by the 4 x 256 output layer (fp32, `gamma` = its weight, `beta` = its
 // bias) and finishes with mode 0: sigmoid(delta + inverse_sigmoid(ref)) or mode 1: delta + ref -- `eps` carries the mode, Y is
@@ -151,15 +152,28 @@ __global__ __launch_bounds__(512, 2) void ffn_fused_bf16_kernel(
     __builtin_amdgcn_s_barrier();
 
     unsigned char* hbuf = smem + FFN_H_OFF + tg * 4096;
+    // Software pipeline of one wave (registers: wa = W1 fragments of the NEXT chunk, wb = W2 fragments of the CURRENT one):
+    //     barrier(c) | read H(c) ; read wa <- W1(c+1) under phase B(c)'s 16 MFMAs ; read wb <- W2(c+1) under phase A(c+1)'s 16 MFMAs
+    // Both weight images of chunk c+1 became visible at barrier(c), so neither read has to wait behind a barrier with the
+    // matrix pipe idle (the first version fetched W2(c) AFTER barrier(c): all 8 waves then queued 80 ds_read_b128 on the LDS
+    // port before the first MFMA of the chunk).  The interleave is pinned with sched_group_barrier: 1 LDS read per 2 MFMAs
+    // is the rate at which the LDS port (8 waves x 1 KB per read) and the four matrix pipes stay equally busy.
     // phase A of chunk C: H^T[16 hidden (MFMA tile j = half), 32 tokens] = W1c X^T, + b1, ReLU, bf16 -> the pair's H buffer.
     // Four accumulation chains (even / odd k-steps x two token tiles): two chains leave the matrix pipe idle between
     // dependent MFMAs whenever the SIMD's other wave is parked at the barrier.
-#define FFN_PHASE_A(C)                                                                             \
+#define FFN_LOAD_WA(C)                                                                             \
     {                                                                                              \
         const unsigned char* w1f = smem + ((C) & (FFN_NS - 1)) * FFN_STAGE + half * 8192 + lane * 16; \
-        const float4 bb = *reinterpret_cast<const float4*>(smem + FFN_B1_OFF + ((C) * 32 + g * 8 + half * 4) * 4); \
-        uint4 wa[8];                                                                               \
-        _Pragma("unroll") for (int ks = 0; ks < 8; ++ks) wa[ks] = *reinterpret_cast<const uint4*>(w1f + ks * 1024); \
+        if (!(DBG & 32) || (C) == 0) { _Pragma("unroll") for (int ks = 0; ks < 8; ++ks) wa[ks] = *reinterpret_cast<const uint4*>(w1f + ks * 1024); } \
+    }
+#define FFN_LOAD_WB(C)                                                                             \
+    {                                                                                              \
+        const unsigned char* w2f = smem + ((C) & (FFN_NS - 1)) * FFN_STAGE + 16384 + half * 8192 + lane * 16; \
+        if (!(DBG & 32) || (C) == 0) { _Pragma("unroll") for (int i = 0; i < 8; ++i) wb[i] = *reinterpret_cast<const uint4*>(w2f + i * 1024); } \
+    }
+#define FFN_LOAD_B1(C) const float4 bb = *reinterpret_cast<const float4*>(smem + FFN_B1_OFF + ((C) * 32 + g * 8 + half * 4) * 4);
+#define FFN_MMA_A(C)                                                                               \
+    {                                                                                              \
         ffn_f32x4_t he[2] = {ffn_f32x4_t{0.f, 0.f, 0.f, 0.f}, ffn_f32x4_t{0.f, 0.f, 0.f, 0.f}};    \
         ffn_f32x4_t ho[2] = {ffn_f32x4_t{0.f, 0.f, 0.f, 0.f}, ffn_f32x4_t{0.f, 0.f, 0.f, 0.f}};    \
         _Pragma("unroll") for (int ks = 0; ks < 8; ks += 2) {                                      \
@@ -172,37 +186,68 @@ __global__ __launch_bounds__(512, 2) void ffn_fused_bf16_kernel(
         _Pragma("unroll") for (int tt = 0; tt < 2; ++tt) {                                         \
             const float h0 = fmaxf(he[tt][0] + ho[tt][0] + bb.x, 0.f), h1 = fmaxf(he[tt][1] + ho[tt][1] + bb.y, 0.f); \
             const float h2 = fmaxf(he[tt][2] + ho[tt][2] + bb.z, 0.f), h3 = fmaxf(he[tt][3] + ho[tt][3] + bb.w, 0.f); \
-            *reinterpret_cast<uint2*>(hw + tt * 1024) = make_uint2(pack_bf16x2(h0, h1), pack_bf16x2(h2, h3)); \
+            if (!(DBG & 16)) *reinterpret_cast<uint2*>(hw + tt * 1024) = make_uint2(pack_bf16x2(h0, h1), pack_bf16x2(h2, h3)); \
+            else asm volatile("" :: "v"(h0), "v"(h1), "v"(h2), "v"(h3));                           \
         }                                                                                          \
     }
+#define FFN_SGB(MASK, N) __builtin_amdgcn_sched_group_barrier(MASK, N, 0);
 
-    // one chunk step: barrier(c) -> DMA of chunk c+3 -> phase B(c) [+ phase A(c+1), same basic block so that hipcc
-    // interleaves the LDS reads of one with the MFMAs of the other]
-#define FFN_STEP(C, WITH_A)                                                                        \
+    // one chunk step.  Phase B runs ONE STEP LATE: after barrier(c) the wave multiplies chunk c-1 (H(c-1) and W2(c-1) are already
+    // in registers), so the matrix pipe restarts the moment the barrier opens, while the LDS reads that had to wait for this
+    // barrier -- W1(c+1) for phase A(c+1), H(c) and W2(c) for the next step's phase B -- land underneath those 16 MFMAs.
+    // (Measured with the ablation switches: the MFMAs alone cost 0.19 ms and the barrier / LDS-latency / VALU skeleton 0.13 ms,
+    // and in the first version -- read H(c), wait, phase B(c) -- the two simply added up.)
+#define FFN_STEP(C, WITH_B, WITH_A)                                                                \
     {                                                                                              \
         /* the one barrier of the chunk: publishes H(C) to the partner wave; my pieces of chunk C+1 (read by phase */ \
         /* A(C+1)) have landed -- chunk C+2's four may stay in flight; my H writes are done */     \
         if (!(DBG & 1) && (C) + 2 < nchunk) asm volatile("s_waitcnt vmcnt(4) lgkmcnt(0)" ::: "memory"); \
         else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");                           \
         if (!(DBG & 4)) __builtin_amdgcn_s_barrier();                                              \
-        if (!(DBG & 1) && (C) + 3 < nchunk) FFN_ISSUE((C) + 3)   /* into the stage of chunk C-1: all its readers passed the barrier */ \
-        const uint4 hb0 = *reinterpret_cast<const uint4*>(hbuf + ((C) & 1) * 2048 + lane * 16);    \
-        const uint4 hb1 = *reinterpret_cast<const uint4*>(hbuf + ((C) & 1) * 2048 + 1024 + lane * 16); \
-        const unsigned char* w2f = smem + ((C) & (FFN_NS - 1)) * FFN_STAGE + 16384 + half * 8192 + lane * 16; \
-        uint4 wb[8];                                                                               \
-        _Pragma("unroll") for (int i = 0; i < 8; ++i) wb[i] = *reinterpret_cast<const uint4*>(w2f + i * 1024); \
-        _Pragma("unroll") for (int i = 0; i < 8; ++i) {                                            \
-            yacc[i][0] = ffn_mma<DBG>(wb[i], hb0, yacc[i][0]);                                          \
-            yacc[i][1] = ffn_mma<DBG>(wb[i], hb1, yacc[i][1]);                                          \
+        if (!(DBG & 1) && (C) + 3 < nchunk) FFN_ISSUE((C) + 3)   /* into the stage of chunk C-1: its last readers (W2(C-1), step C-1) are done */ \
+        FFN_LOAD_B1((C) + 1)                                      /* ahead of the pinned region: it would otherwise be scheduled last, in front of the H store */ \
+        __builtin_amdgcn_sched_barrier(0);                                                         \
+        if (WITH_A) FFN_LOAD_WA((C) + 1)                                                           \
+        const uint4 hn0 = *reinterpret_cast<const uint4*>(hbuf + ((C) & 1) * 2048 + lane * 16);    \
+        const uint4 hn1 = *reinterpret_cast<const uint4*>(hbuf + ((C) & 1) * 2048 + 1024 + lane * 16); \
+        if (WITH_B) {                                                                              \
+            _Pragma("unroll") for (int i = 0; i < 8; ++i) {                                        \
+                yacc[i][0] = ffn_mma<DBG>(wb[i], hb0, yacc[i][0]);                                 \
+                yacc[i][1] = ffn_mma<DBG>(wb[i], hb1, yacc[i][1]);                                 \
+            }                                                                                      \
         }                                                                                          \
-        if (WITH_A) FFN_PHASE_A((C) + 1)                                                           \
+        FFN_LOAD_WB(C)                                                                             \
+        if (WITH_A) FFN_MMA_A((C) + 1)                                                             \
+        hb0 = hn0; hb1 = hn1;                                                                      \
+        if (WITH_A && WITH_B && !(DBG & (8 | 32))) {                                               \
+            FFN_SGB(0x100, 1)                                                                      \
+            _Pragma("unroll") for (int r_ = 0; r_ < 9; ++r_) { FFN_SGB(0x008, 2) FFN_SGB(0x100, 1) }   /* phase B(c-1) + 2 of A | W1(c+1) x 7, H(c) x 2 */ \
+            _Pragma("unroll") for (int r_ = 0; r_ < 7; ++r_) { FFN_SGB(0x008, 2) FFN_SGB(0x100, 1) }   /* phase A(c+1) | W2(c) x 7 */ \
+            FFN_SGB(0x100, 1)                                                                      \
+        }                                                                                          \
     }
 
-    FFN_PHASE_A(0)
-    for (int c = 0; c + 1 < nchunk; ++c) FFN_STEP(c, true)
-    FFN_STEP(nchunk - 1, false)
+    uint4 wa[8], wb[8];
+    uint4 hb0 = make_uint4(0u, 0u, 0u, 0u), hb1 = hb0;
+    {
+        FFN_LOAD_B1(0)
+        FFN_LOAD_WA(0)
+        FFN_MMA_A(0)
+    }
+    FFN_STEP(0, false, true)
+    for (int c = 1; c + 1 < nchunk; ++c) FFN_STEP(c, true, true)
+    FFN_STEP(nchunk - 1, true, false)
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {                               // phase B of the last chunk
+        yacc[i][0] = ffn_mma<DBG>(wb[i], hb0, yacc[i][0]);
+        yacc[i][1] = ffn_mma<DBG>(wb[i], hb1, yacc[i][1]);
+    }
+#undef FFN_SGB
+#undef FFN_MMA_A
+#undef FFN_LOAD_B1
+#undef FFN_LOAD_WA
+#undef FFN_LOAD_WB
 #undef FFN_STEP
-#undef FFN_PHASE_A
 #undef FFN_ISSUE
 
     if constexpr (HEAD) {
@@ -484,7 +529,7 @@ extern "C" int dtlr_ffn_fused_bf16(const void* X, const void* W1, const float* b
     clear_stale_error();
     if (!X || !W1 || !b1 || !W2 || !b2 || !gamma || !beta || !Y) return DTLR_EINVAL;
     if (M <= 0 || d_ff <= 0) return DTLR_EINVAL;
-    if (d_model != 256 || (d_ff & 31) || d_ff > FFN_MAX_DFF) return DTLR_ESHAPE;
+    if (d_model != 256 || (d_ff & 31) || d_ff < 64 || d_ff > FFN_MAX_DFF) return DTLR_ESHAPE;     // >= 2 chunks: phase B trails by one
     static int dbg = -1;
     if (dbg < 0) { const char* e = getenv("DTLR_FFN_DBG"); dbg = e ? atoi(e) : 0; }
     const unsigned grid = (unsigned)((M + 127) / 128);
@@ -502,6 +547,17 @@ extern "C" int dtlr_ffn_fused_bf16(const void* X, const void* W1, const float* b
     case 4: FFN_LAUNCH(4) break;
     case 6: FFN_LAUNCH(6) break;
     case 7: FFN_LAUNCH(7) break;
+#ifdef DTLR_GEMM_ABLATION
+    case 8: FFN_LAUNCH(8) break;
+    case 16: FFN_LAUNCH(16) break;
+    case 32: FFN_LAUNCH(32) break;
+    case 33: FFN_LAUNCH(33) break;
+    case 34: FFN_LAUNCH(34) break;
+    case 48: FFN_LAUNCH(48) break;
+    case 49: FFN_LAUNCH(49) break;
+    case 51: FFN_LAUNCH(51) break;
+    case 55: FFN_LAUNCH(55) break;
+#endif
     default: FFN_LAUNCH(0) break;
     }
 #undef FFN_LAUNCH
