@@ -8,6 +8,7 @@ nothing here runs on the CPU and nothing imports the oracle.
 """
 from __future__ import annotations
 
+import ctypes
 import math
 from typing import Optional
 
@@ -434,3 +435,21 @@ def decode_blank(logits, boxes, eps: float):
                                         float(eps), _lib.current_stream())
     _lib.check(code, "dtlr_decode_blank")
     return labels, lengths
+
+
+def preprocess_lines(src_u8, offsets, dims, Hc: int, Wc: int, max_downscale: float, mean, std):
+    """Resize + ToTensor + Normalize + pad of a batch of uint8 RGB images in ONE launch (dtlr_preprocess_lines).
+    src_u8: flat uint8 CUDA tensor (images back to back, HWC); offsets [B] int64 CUDA; dims [B,4] int32 CUDA = (h, w, oh, ow).
+    Returns (canvas [B,3,Hc,Wc] fp32, mask [B,Hc,Wc] bool)."""
+    require_cuda(src_u8, "src_u8")
+    assert src_u8.dtype == torch.uint8 and offsets.dtype == torch.int64 and dims.dtype == torch.int32 and dims.shape[1] == 4
+    B = dims.shape[0]
+    canvas = torch.empty((B, 3, Hc, Wc), dtype=torch.float32, device=src_u8.device)
+    mask = torch.empty((B, Hc, Wc), dtype=torch.bool, device=src_u8.device)
+    m = (ctypes.c_float * 3)(*[float(v) for v in mean])
+    s = (ctypes.c_float * 3)(*[float(v) for v in std])
+    code = _lib.lib().dtlr_preprocess_lines(src_u8.data_ptr(), offsets.data_ptr(), dims.data_ptr(), B, Hc, Wc, float(max_downscale),
+                                            ctypes.cast(m, ctypes.c_void_p), ctypes.cast(s, ctypes.c_void_p),
+                                            canvas.data_ptr(), mask.data_ptr(), _lib.current_stream())
+    _lib.check(code, "dtlr_preprocess_lines")
+    return canvas, mask

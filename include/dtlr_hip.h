@@ -224,6 +224,23 @@ int dtlr_groupnorm_tokens_strided(const void *x, const float *gamma, const float
 long dtlr_groupnorm_workspace_bytes(int B, int T_tokens);
 
 /* ---------------------------------------------------------------------------------------------
+ * Eval-time preprocessing of a batch of RGB uint8 line images, on the device: resize (Pillow's fixed-point bilinear
+ * resample, bit-exact) -> /255 -> (x - mean) / std -> zero-padded canvas + padding mask.
+ * Replaces: datasets/transforms.py `resize` (:78-109, F.resize on a PIL image), `ToTensor` (:247-249), `Normalize`
+ *           (:552-559) as composed for evaluation by datasets/IAM.py:110-112,225-230, and the collate
+ *           `nested_tensor_from_tensor_list` (util/misc.py:375-397).
+ *   src      device: the images back to back, image b = [h_b, w_b, 3] uint8 at byte offset offsets[b]
+ *   offsets  device [B] int64 ; dims device [B][4] int32 = (h, w, oh, ow), (oh, ow) = the resized size the HOST derived
+ *            (transforms.py:81-99 `get_size_with_aspect_ratio`; dtlr_amd/transforms.py mirrors it)
+ *   Hc, Wc   canvas size = max oh, max ow over the batch ; max_downscale = max over images and axes of in/out (sizes the
+ *            filter footprint; > 11 -> DTLR_ESHAPE)
+ *   mean3, std3  HOST pointers to 3 floats each (copied into the launch)
+ *   canvas   device [B,3,Hc,Wc] fp32, fully written ; mask device [B,Hc,Wc] uint8, 1 = padding, fully written */
+int dtlr_preprocess_lines(const unsigned char *src, const long *offsets, const int *dims, int B, int Hc, int Wc,
+                          float max_downscale, const float *mean3, const float *std3,
+                          float *canvas, unsigned char *mask, void *stream);
+
+/* ---------------------------------------------------------------------------------------------
  * ResNet stem convolution: 7x7 / stride 2 / pad 3, 3 -> 64 channels, on the bf16 matrix cores, reading the
  * NCHW fp32 image directly (bf16-rounded operands, fp32 accumulate) and writing NHWC bf16.
  * Replaces: torchvision resnet50 `conv1` (+ the FrozenBN scale folded into the weights, backbone.py:62-72) as run by

@@ -597,3 +597,111 @@ def cumulative_cer(gt_strings: Sequence[str], pred_strings: Sequence[str], norma
         lens.append(len(g))
         series.append(sum(dists) / sum(lens))
     return (sum(series) / len(series) if series else 0.0), series
+
+
+# ======================================================================================
+# datasets/transforms.py -- eval-time preprocessing
+# ======================================================================================
+def get_size_with_aspect_ratio(image_size: Tuple[int, int], size: int, max_size: Optional[int] = None) -> Tuple[int, int]:
+    """datasets/transforms.py:81-99: image_size = (w, h) -> (oh, ow); short side -> `size`, capped so that the long side
+    stays <= max_size."""
+    w, h = image_size
+    if max_size is not None:
+        mn, mx = float(min(w, h)), float(max(w, h))
+        if mx / mn * size > max_size:
+            size = int(round(max_size * mn / mx))
+    if (w <= h and w == size) or (h <= w and h == size):
+        return (h, w)
+    if w < h:
+        return (int(size * h / w), size)
+    return (size, int(size * w / h))
+
+
+_PIL_PRECISION_BITS = 32 - 8 - 2
+
+
+def _pil_bilinear_coeffs(in_size: int, out_size: int):
+    """Pillow `precompute_coeffs` + `normalize_coeffs_8bpc` (src/libImaging/Resample.c) for the BILINEAR (triangle) filter over
+    the full box [0, in_size): per output index (first tap, list of fixed-point weights).  Third-party arithmetic (torchvision
+    `F.resize` on a PIL image == `Image.resize(size[::-1], BILINEAR)`, datasets/transforms.py:108): pinned against the installed
+    Pillow in tests/test_oracle_golden.py and through the fixtures made by tests/golden/make_golden_preproc.py."""
+    scale = in_size / out_size                     # doubles, exactly as the C code
+    filterscale = scale if scale >= 1.0 else 1.0
+    support = 1.0 * filterscale
+    ss = 1.0 / filterscale
+    out = []
+    for xx in range(out_size):
+        center = 0.0 + (xx + 0.5) * scale
+        xmin = int(center - support + 0.5)
+        if xmin < 0:
+            xmin = 0
+        xmax = int(center + support + 0.5)
+        if xmax > in_size:
+            xmax = in_size
+        xmax -= xmin
+        ws = []
+        ww = 0.0
+        for x in range(xmax):
+            a = (x + xmin - center + 0.5) * ss
+            if a < 0.0:
+                a = -a
+            w = 1.0 - a if a < 1.0 else 0.0
+            ws.append(w)
+            ww += w
+        ks = []
+        for w in ws:
+            if ww != 0.0:
+                w = w / ww
+            ks.append(int(-0.5 + w * (1 << _PIL_PRECISION_BITS)) if w < 0 else int(0.5 + w * (1 << _PIL_PRECISION_BITS)))
+        out.append((xmin, ks))
+    return out
+
+
+def pil_resize_bilinear_u8(img, oh: int, ow: int):
+    """uint8 [h, w, C] numpy -> uint8 [oh, ow, C]: Pillow's two-pass resample (horizontal into a uint8 image, then vertical),
+    accumulators seeded with half an LSB, `>> 22`, clamp to [0, 255].  A pass whose size does not change is skipped
+    (Resample.c `need_horizontal` / `need_vertical`); equal sizes return a copy (Image.resize)."""
+    import numpy as np
+    h, w, _ = img.shape
+    cur = img
+    if ow != w:
+        co = _pil_bilinear_coeffs(w, ow)
+        tmp = np.empty((h, ow, img.shape[2]), dtype=np.uint8)
+        for xx, (x0, ks) in enumerate(co):
+            acc = np.full((h, img.shape[2]), 1 << (_PIL_PRECISION_BITS - 1), dtype=np.int64)
+            for i, k in enumerate(ks):
+                acc += cur[:, x0 + i, :].astype(np.int64) * k
+            tmp[:, xx, :] = np.clip(acc >> _PIL_PRECISION_BITS, 0, 255).astype(np.uint8)
+        cur = tmp
+    if oh != h:
+        co = _pil_bilinear_coeffs(h, oh)
+        tmp = np.empty((oh, cur.shape[1], img.shape[2]), dtype=np.uint8)
+        for yy, (y0, ks) in enumerate(co):
+            acc = np.full((cur.shape[1], img.shape[2]), 1 << (_PIL_PRECISION_BITS - 1), dtype=np.int64)
+            for i, k in enumerate(ks):
+                acc += cur[y0 + i, :, :].astype(np.int64) * k
+            tmp[yy, :, :] = np.clip(acc >> _PIL_PRECISION_BITS, 0, 255).astype(np.uint8)
+        cur = tmp
+    return cur.copy() if cur is img else cur
+
+
+IMAGENET_MEAN = (0.485, 0.456, 0.406)
+IMAGENET_STD = (0.229, 0.224, 0.225)
+
+
+def preprocess_line(img, size: int = 800, max_size: int = 1333) -> Tensor:
+    """One RGB uint8 [h, w, 3] line image -> normalised fp32 [3, oh, ow]: RandomResize([800], max_size=1333) -> ToTensor ->
+    Normalize (datasets/IAM.py:110-112, 225-230; datasets/transforms.py:78-109, 247-249, 552-559)."""
+    h, w, _ = img.shape
+    oh, ow = get_size_with_aspect_ratio((w, h), size, max_size)
+    r = pil_resize_bilinear_u8(img, oh, ow)
+    t = torch.from_numpy(r).permute(2, 0, 1).to(torch.float32).div(255)                 # F.to_tensor
+    mean = torch.tensor(IMAGENET_MEAN, dtype=torch.float32).view(3, 1, 1)
+    std = torch.tensor(IMAGENET_STD, dtype=torch.float32).view(3, 1, 1)
+    return t.sub(mean).div(std)                                                         # F.normalize
+
+
+def preprocess_lines(images, size: int = 800, max_size: int = 1333) -> Tuple[Tensor, Tensor]:
+    """List of RGB uint8 images -> (padded batch [B, 3, Hmax, Wmax] fp32, mask [B, Hmax, Wmax] bool): the per-item transform
+    above followed by the collate of util/misc.py:375-397."""
+    return nested_tensor_from_tensor_list([preprocess_line(im, size, max_size) for im in images])

@@ -1,4 +1,6 @@
 """Numerics of the individual gfx950 kernels against plain fp32 CPU references of the same op."""
+import os
+
 import numpy as np
 import pytest
 import torch
@@ -447,3 +449,39 @@ def test_box_mlp_refine_bf16_vs_reference(mode):
     tol = 2e-3 if mode == 0 else 2e-2                       # bf16 rounding of the first hidden layer (flips of 1 ulp)
     assert (got - want).abs().max() < tol, (got - want).abs().max().item()
     assert (got - want).abs().mean() < tol / 20
+
+
+@pytest.mark.parametrize("size,max_size", [(800, 1333), (20, 96), (48, 200), (33, None)])
+def test_preprocess_lines_bit_exact(size, max_size):
+    """dtlr_preprocess_lines (resize + ToTensor + Normalize + pad + mask, one launch) == the oracle's restatement of the
+    reference's eval transform + collate (datasets/transforms.py:78-109,247-249,552-559; util/misc.py:375-397): fp32 canvas
+    and mask BIT-EXACT (the resize is integer arithmetic; the normalisation two correctly rounded fp32 divisions).
+    Ragged batch: down- and up-scaling on either axis, identity sizes, a square, a portrait, a grey-scale image."""
+    from dtlr_amd import transforms as T
+    from oracle import dtlr_oracle as O
+    from tests.util import preproc_image
+    shapes = [(128, 2048), (64, 900), (40, 40), (200, 120), (17, 1999), (31, 97), (9, 14)] if size == 800 else \
+             [(24, 160), (31, 97), (12, 300), (40, 40), (9, 14), (64, 48), (33, 50), (50, 33)]
+    imgs = [preproc_image(h, w, 300 + i) for i, (h, w) in enumerate(shapes)]
+    grey = preproc_image(30, 70, 999)[:, :, 0].copy()
+    want_x, want_m = O.preprocess_lines(imgs + [np.repeat(grey[:, :, None], 3, axis=2)], size, max_size)
+    nt = T.preprocess_lines(imgs + [grey], size, max_size)
+    assert nt.tensors.is_cuda and nt.tensors.dtype == torch.float32 and nt.mask.dtype == torch.bool
+    assert torch.equal(nt.mask.cpu(), want_m)
+    assert torch.equal(nt.tensors.cpu(), want_x)
+
+
+def test_preprocess_lines_golden_and_errors(golden_dir):
+    """Against the committed Pillow vectors (tests/golden/g4_preproc.npz) and the C-ABI's shape limits."""
+    from dtlr_amd import transforms as T
+    from tests.util import preproc_image
+    g = np.load(os.path.join(golden_dir, "g4_preproc.npz"))
+    mean = torch.tensor(T.IMAGENET_MEAN).view(3, 1, 1)
+    std = torch.tensor(T.IMAGENET_STD).view(3, 1, 1)
+    for k, (seed, h, w, size, max_size, oh, ow) in enumerate(g["small_cases"].tolist()):
+        nt = T.preprocess_lines([preproc_image(h, w, seed)], size, None if max_size < 0 else max_size)
+        want = (torch.from_numpy(g[f"s{k}_out"]).permute(2, 0, 1).float() / 255 - mean) / std
+        assert tuple(nt.tensors.shape) == (1, 3, oh, ow) and not nt.mask.any()
+        assert torch.equal(nt.tensors[0].cpu(), want), (seed, h, w, size)
+    with pytest.raises(RuntimeError):                       # 13x down-scaling: outside the kernel's filter footprint
+        T.preprocess_lines([preproc_image(400, 30, 1)], 2, None)

@@ -194,3 +194,32 @@ def test_synthetic_inputs_deterministic():
     assert a[0].shape == (3, 32, 64) and a[1].shape == (3, 32, 48)
     w = synth.mixed_widths(8, [1536, 1792, 2048, 2304, 2560], seed=1)
     assert w == synth.mixed_widths(8, [1536, 1792, 2048, 2304, 2560], seed=1) and set(w) <= {1536, 1792, 2048, 2304, 2560}
+
+
+def test_transforms_size_rule_matches_oracle_and_reference_examples():
+    """dtlr_amd.transforms.get_size_with_aspect_ratio (datasets/transforms.py:81-99): equal to the oracle's restatement over a
+    sweep, and the survey's worked example (a 128x2048 crop becomes 83x1328 under 800/1333)."""
+    from dtlr_amd import transforms as T
+    from oracle import dtlr_oracle as O
+    assert T.get_size_with_aspect_ratio((2048, 128), 800, 1333) == (83, 1328)
+    assert T.get_size_with_aspect_ratio((1000, 800), 800, 1333) == (800, 1000)          # already at size: unchanged
+    for w in (1, 7, 33, 128, 800, 1333, 2048, 5000):
+        for h in (1, 9, 64, 128, 800, 1400):
+            for size, ms in ((800, 1333), (32, 100), (480, None)):
+                assert T.get_size_with_aspect_ratio((w, h), size, ms) == O.get_size_with_aspect_ratio((w, h), size, ms)
+
+
+def test_transforms_input_validation():
+    """Host-side argument checks of preprocess_lines run before any device work."""
+    import numpy as np
+    import pytest
+    from dtlr_amd import transforms as T
+    with pytest.raises(ValueError):
+        T.preprocess_lines([], device="cpu")
+    with pytest.raises(TypeError):
+        T.preprocess_lines([np.zeros((4, 4, 3), dtype=np.float32)], device="cpu")
+    with pytest.raises(ValueError):
+        T.preprocess_lines([np.zeros((4, 4, 2), dtype=np.uint8)], device="cpu")
+    # no CPU fallback: a CPU device reaches the HIP wrapper, which refuses non-CUDA tensors
+    with pytest.raises(Exception):
+        T.preprocess_lines([np.zeros((8, 40, 3), dtype=np.uint8)], device="cpu")

@@ -115,3 +115,54 @@ def test_g3_full_model(golden_dir, tag):
     assert (torch.gather(out["pred_logits"], 2, idx) - _t(g["top8_val"])).abs().max() < 1e-3
     assert (out["pred_logits"].double().sum(-1) - _t(g["logits_rowsum"])).abs().max() < 1e-3 * cfg.num_classes
     assert (out["pred_boxes"] - _t(g["pred_boxes"])).abs().max() < 1e-5
+
+
+# ---- eval-time preprocessing: the oracle's Pillow-resample restatement -------------------
+def test_g4_preproc_resize_matches_pillow_vectors(golden_dir):
+    """oracle.pil_resize_bilinear_u8 == the vectors Pillow produced (tests/golden/make_golden_preproc.py), bit for bit;
+    the size rule == the reference's (the generating script asserted it against datasets/transforms.py:81-99)."""
+    import hashlib
+    from tests.util import preproc_image
+    g = np.load(os.path.join(golden_dir, "g4_preproc.npz"))
+    for k, (seed, h, w, size, max_size, oh, ow) in enumerate(g["small_cases"].tolist()):
+        ms = None if max_size < 0 else max_size
+        assert O.get_size_with_aspect_ratio((w, h), size, ms) == (oh, ow)
+        got = O.pil_resize_bilinear_u8(preproc_image(h, w, seed), oh, ow)
+        assert np.array_equal(got, g[f"s{k}_out"]), (seed, h, w, size, ms)
+    for (seed, h, w, size, max_size, oh, ow), digest in zip(g["big_cases"].tolist(), g["big_sha256"].tolist()):
+        assert O.get_size_with_aspect_ratio((w, h), size, max_size) == (oh, ow)
+        got = O.pil_resize_bilinear_u8(preproc_image(h, w, seed), oh, ow)
+        assert hashlib.sha256(got.tobytes()).hexdigest() == digest, (seed, h, w)
+
+
+def test_preproc_oracle_against_installed_pillow():
+    """Same check against whatever Pillow is installed where the tests run (skipped without it): random sizes, both
+    scaling directions per axis, identity axes."""
+    PILImage = pytest.importorskip("PIL.Image")
+    g = np.random.Generator(np.random.PCG64(5))
+    for _ in range(12):
+        h, w = int(g.integers(3, 90)), int(g.integers(3, 400))
+        oh, ow = int(g.integers(2, 120)), int(g.integers(2, 500))
+        if g.random() < 0.25:
+            oh = h
+        if g.random() < 0.25:
+            ow = w
+        img = g.integers(0, 256, (h, w, 3), dtype=np.uint8)
+        ref = np.asarray(PILImage.fromarray(img, "RGB").resize((ow, oh), PILImage.BILINEAR))
+        assert np.array_equal(O.pil_resize_bilinear_u8(img, oh, ow), ref), (h, w, oh, ow)
+
+
+def test_preproc_pipeline_shapes_and_mask():
+    """preprocess_lines == per-item transform + collate (util/misc.py:375-397): canvas = max sizes, zero padding,
+    mask True exactly on the padding; values = ((u8/255) - mean) / std."""
+    from tests.util import preproc_image
+    imgs = [preproc_image(20, 200, 1), preproc_image(31, 90, 2), preproc_image(12, 12, 3)]
+    x, m = O.preprocess_lines(imgs, size=16, max_size=64)
+    sizes = [O.get_size_with_aspect_ratio((im.shape[1], im.shape[0]), 16, 64) for im in imgs]
+    assert tuple(x.shape) == (3, 3, max(s[0] for s in sizes), max(s[1] for s in sizes)) and m.dtype == torch.bool
+    for b, (oh, ow) in enumerate(sizes):
+        assert not m[b, :oh, :ow].any() and m[b, oh:].all() and m[b, :, ow:].all()
+        assert (x[b, :, oh:] == 0).all() and (x[b, :, :, ow:] == 0).all()
+        r = torch.from_numpy(O.pil_resize_bilinear_u8(imgs[b], oh, ow)).permute(2, 0, 1).float()
+        want = (r / 255 - torch.tensor(O.IMAGENET_MEAN).view(3, 1, 1)) / torch.tensor(O.IMAGENET_STD).view(3, 1, 1)
+        assert torch.equal(x[b, :, :oh, :ow], want)

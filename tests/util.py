@@ -52,3 +52,13 @@ def selection_is_valid(idx, scores, k, tol):
         if len(set(idx[b].tolist())) != k:
             return False
     return True
+
+
+def preproc_image(h, w, seed):
+    """Seeded uint8 RGB test image [h, w, 3] shared by tests/golden/make_golden_preproc.py and the preprocessing tests:
+    uniform noise, or (odd seeds) stroke-like light paper with dark runs."""
+    g = np.random.Generator(np.random.PCG64(seed))
+    base = g.integers(0, 256, (h, w, 3), dtype=np.uint8)
+    if seed % 2:
+        base = np.where(g.random((h, w, 1)) < 0.15, base // 4, 200 + base // 5).astype(np.uint8)
+    return base
