@@ -201,6 +201,111 @@ __global__ __launch_bounds__(1024) void decode_blank_kernel(const float* __restr
     if (threadIdx.x == 0) lengths[b] = running;
 }
 
+// ---- evaluation-time CTC loss value (models/dino/dino.py:457-551, SetCriterion.loss_CTC) ------------------------------------
+// Step 1, chip-wide: sum over classes of sigmoid(logit) for every query (16 lanes per query, DPP reductions).
+__global__ __launch_bounds__(256) void query_sum_kernel(const float* __restrict__ logits, float* __restrict__ sums, long nrows, int C)
+{
+    const int l16 = threadIdx.x & 15;
+    const long q = (long)blockIdx.x * 16 + (threadIdx.x >> 4);
+    const bool live = q < nrows;
+    const float* lr = logits + (live ? q : 0) * C;
+    float sum = 0.f;
+    for (int c0 = 0; c0 < C; c0 += 64) {
+        float x[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) { const int c = c0 + 16 * u + l16; x[u] = (live && c < C) ? lr[c] : -INFINITY; }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) sum += 1.f / (1.f + expf(-x[u]));
+    }
+    sum += dpp_f<0xB1>(sum); sum += dpp_f<0x4E>(sum); sum += dpp_f<0x141>(sum); sum += dpp_f<0x140>(sum);
+    if (live && l16 == 0) sums[q] = sum;
+}
+
+// Step 2, one workgroup per line, one thread per state of the blank-extended label sequence l' (S = 2 L + 1 <= blockDim):
+// the CTC forward recursion over T = 2 nq steps -- step 2 i is query i of the reading order (sorted by box cx) with the
+// blank-channel probabilities of dino.py:474-502, step 2 i + 1 the filler row [1, filler, filler, ...] of :505-519 -- in log
+// space with the exact update of torch's CTCLoss (max-shifted three-term log-sum-exp, -inf handling).  Alphas are double
+// buffered in LDS, one barrier per step; the logit a state needs at query i is prefetched CTC_PF queries ahead (a dependent
+// global load per step would cost an HBM round trip 900 times).
+constexpr int CTC_PF = 8;
+
+__global__ __launch_bounds__(1024) void ctc_interleaved_kernel(const float* __restrict__ logits, const float* __restrict__ boxes,
+                                                               const float* __restrict__ sums, const int* __restrict__ targets,
+                                                               const int* __restrict__ target_lengths, float* __restrict__ nll,
+                                                               int nq, int C, int Lmax, float eps, float filler, int npow2)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned long long keys[];      // [npow2] | float ssum[npow2] | float alpha[2][blockDim + 2]
+    float* ssum = reinterpret_cast<float*>(keys + npow2);
+    float* alpha = ssum + npow2;
+    const int b = blockIdx.x, s = threadIdx.x, AP = blockDim.x + 2;
+    const int L = target_lengths[b], S = 2 * L + 1;
+    for (int i = threadIdx.x; i < npow2; i += blockDim.x)
+        keys[i] = i < nq ? (((unsigned long long)f32_sortable(boxes[((long)b * nq + i) * 4])) << 32) | (unsigned)i : ~0ull;
+    bitonic_sort_u64(keys, npow2);                                             // ascending cx, ties: lower index first
+    for (int i = threadIdx.x; i < nq; i += blockDim.x) ssum[i] = sums[(long)b * nq + (int)(keys[i] & 0xffffffffull)];
+    // this thread's state: label (0 = blank), and whether the skip transition s-2 -> s exists
+    const bool live = s < S;
+    const int lab = (live && (s & 1)) ? targets[(long)b * Lmax + (s >> 1)] : 0;
+    const bool skip = live && (s & 1) && s >= 3 && lab != targets[(long)b * Lmax + (s >> 1) - 1];
+    const float one_m_eps = (float)(1.0 - (double)eps), thr = one_m_eps;
+    const float lfill = lab == 0 ? 0.f : logf(filler);
+    const float* lrow = logits + (long)b * nq * C + (lab > 0 ? lab - 1 : 0);
+    __syncthreads();
+    // alpha buffers carry two -inf guard slots in front (states -2, -1)
+    float* a0 = alpha + 2;
+    float* a1 = alpha + AP + 2;
+    if (threadIdx.x < 2) { alpha[threadIdx.x] = -INFINITY; alpha[AP + threadIdx.x] = -INFINITY; }
+
+    float pf[CTC_PF];                                                           // logits of queries i0 .. i0 + CTC_PF - 1 for this state
+#pragma unroll
+    for (int u = 0; u < CTC_PF; ++u) pf[u] = (lab > 0 && u < nq) ? lrow[(long)(int)(keys[u] & 0xffffffffull) * C] : 0.f;
+
+    auto logp = [&](float x, float sum) -> float {                              // log of the blank-augmented probability
+        float p;
+        if (sum < thr) p = lab == 0 ? 1.f - sum : 1.f / (1.f + expf(-x));
+        else p = lab == 0 ? eps : one_m_eps * (1.f / (1.f + expf(-x))) / sum;
+        return logf(p);
+    };
+    auto step = [&](const float* prev, float* cur, float lp) {
+        if (live) {
+            const float la1 = prev[s], la2 = prev[s - 1], la3 = skip ? prev[s - 2] : -INFINITY;
+            float m = fmaxf(la1, fmaxf(la2, la3));
+            if (m == -INFINITY) m = 0.f;
+            cur[s] = logf(expf(la1 - m) + expf(la2 - m) + expf(la3 - m)) + m + lp;
+        }
+        __syncthreads();
+    };
+    for (int i0 = 0; i0 < nq; i0 += CTC_PF) {
+        float nx[CTC_PF];
+#pragma unroll
+        for (int u = 0; u < CTC_PF; ++u) {
+            const int i = i0 + CTC_PF + u;
+            nx[u] = (lab > 0 && i < nq) ? lrow[(long)(int)(keys[i] & 0xffffffffull) * C] : 0.f;
+        }
+#pragma unroll
+        for (int u = 0; u < CTC_PF; ++u) {
+            const int i = i0 + u;
+            if (i < nq) {                                                       // block-uniform
+                const float lp = logp(pf[u], ssum[i]);
+                if (i == 0) {                                                   // t = 0: only states 0 and 1 are reachable
+                    if (live) a0[s] = s < 2 ? lp : -INFINITY;
+                    __syncthreads();
+                } else step(a1, a0, lp);                                        // t = 2 i   : a1 -> a0
+                step(a0, a1, lfill);                                            // t = 2 i + 1: a0 -> a1
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < CTC_PF; ++u) pf[u] = nx[u];
+    }
+    if (threadIdx.x == 0) {                                                     // after t = T - 1 the alphas are in a1
+        const float l1 = a1[S - 1], l2 = L > 0 ? a1[S - 2] : -INFINITY;
+        float m = fmaxf(l1, l2);
+        if (m == -INFINITY) m = 0.f;
+        const float v = -(logf(expf(l1 - m) + expf(l2 - m)) + m);
+        nll[b] = isinf(v) ? 0.f : v;                                            // zero_infinity=True
+    }
+}
+
 static inline int next_pow2(int n) { int p = 1; while (p < n) p <<= 1; return p; }
 
 }  // namespace dtlr
@@ -238,5 +343,28 @@ extern "C" int dtlr_decode_blank(const float* logits, const float* boxes, int* l
     const long nrows = (long)B * nq;
     hipLaunchKernelGGL(query_label_kernel, dim3((unsigned)((nrows + 15) / 16)), dim3(256), 0, (hipStream_t)stream, logits, labels, nrows, C, eps);
     hipLaunchKernelGGL(decode_blank_kernel, dim3(B), dim3(1024), lds, (hipStream_t)stream, boxes, labels, lengths, nq, np);
+    return check_launch();
+}
+
+extern "C" int dtlr_ctc_loss_interleaved(const float* logits, const float* boxes, const int* targets, const int* target_lengths,
+                                         float* nll, float* workspace, int B, int nq, int C, int Lmax, int max_target_length,
+                                         float eps, float filler, void* stream)
+{
+    clear_stale_error();
+    if (!logits || !boxes || !target_lengths || !nll || !workspace) return DTLR_EINVAL;
+    if (B <= 0 || nq <= 0 || C <= 0 || Lmax < 0 || max_target_length < 0 || max_target_length > Lmax) return DTLR_EINVAL;
+    if (Lmax > 0 && !targets) return DTLR_EINVAL;
+    const int S = 2 * max_target_length + 1;
+    if (S > 1024) return DTLR_ESHAPE;                          // one thread per state
+    const int threads = S <= 64 ? 64 : ((S + 63) / 64) * 64;
+    const int np = next_pow2(nq);
+    const size_t lds = (size_t)np * 12 + (size_t)2 * (threads + 2) * 4;
+    if (lds > 150 * 1024) return DTLR_ESHAPE;
+    const long nrows = (long)B * nq;
+    if (lds > 60 * 1024) (void)hipFuncSetAttribute((const void*)ctc_interleaved_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    (void)hipGetLastError();
+    hipLaunchKernelGGL(query_sum_kernel, dim3((unsigned)((nrows + 15) / 16)), dim3(256), 0, (hipStream_t)stream, logits, workspace, nrows, C);
+    hipLaunchKernelGGL(ctc_interleaved_kernel, dim3(B), dim3(threads), lds, (hipStream_t)stream, logits, boxes, workspace, targets,
+                       target_lengths, nll, nq, C, Lmax, eps, filler, np);
     return check_launch();
 }

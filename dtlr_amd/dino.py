@@ -217,9 +217,12 @@ class DINO(nn.Module):
         self._engine = None
         sd = dict(state_dict)
         # checkpoints written through the --new_class_embedding flow carry a bare Linear under
-        # transformer.decoder.class_embed.{weight,bias} (evaluation.py:81; unused by the forward)
-        for k in ("transformer.decoder.class_embed.weight", "transformer.decoder.class_embed.bias"):
-            sd.pop(k, None)
+        # transformer.decoder.class_embed.{weight,bias} (evaluation.py:81; unused by the forward).  When the caller has
+        # performed that flow on THIS module (the decoder attribute is then a bare nn.Linear, evaluation.py:81) the keys
+        # belong to the module and stay; otherwise they are dropped.
+        if not isinstance(self.transformer.decoder.class_embed, nn.Linear):
+            for k in ("transformer.decoder.class_embed.weight", "transformer.decoder.class_embed.bias"):
+                sd.pop(k, None)
         return super().load_state_dict(sd, strict=strict, **kw)
 
     def engine(self) -> DTLREngine:

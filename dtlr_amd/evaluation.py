@@ -17,8 +17,39 @@ import re
 from typing import Dict, List, Optional, Sequence, Tuple
 
 import torch
+from torch import nn
 
 from .dino import PostProcess, box_xyxy_to_cxcywh
+
+
+def load_model(model, weights, device="cuda", new_class_embedding: bool = False, charset_size: Optional[int] = None,
+               new_label_enc: bool = False, fix_enc_out_class: bool = False):
+    """Checkpoint ingestion of the evaluation harness (evaluation.py:51-88), returning the model in eval mode on `device`.
+
+    weights: path of a `checkpoint.pth` ({"model": state_dict}) or a state dict.  Without `new_class_embedding` the
+    checkpoint is loaded as is (:54-59).  With it (HWDB / READ / cipher scripts) the class heads are first rebuilt to the
+    dataset's charset size (:60-83): one Linear shared by the six decoder layers under `model.class_embed`, a separate
+    bare Linear under `model.transformer.decoder.class_embed`, the two-stage head `enc_out_class_embed` unless
+    `fix_enc_out_class`, and with `new_label_enc` the denoising label embedding (:84-85, unused at inference).
+    charset_size None = take it from the checkpoint's `class_embed.0.weight` (what a matching charset has to equal)."""
+    from . import weights as W
+    sd = W.load_checkpoint_state_dict(weights) if isinstance(weights, (str, bytes)) or hasattr(weights, "__fspath__") else weights
+    if new_class_embedding:
+        features_dim = model.class_embed[0].weight.data.shape[1]
+        n = int(charset_size) if charset_size is not None else W.num_classes_of(sd)
+        new_class_embed = nn.Linear(features_dim, n)
+        if not model.dec_pred_class_embed_share:
+            raise NotImplementedError("load_model: the reference's head-resize flow only exists for dec_pred_class_embed_share "
+                                      "(evaluation.py:75-79 leaves class_embed_layerlist undefined otherwise)")
+        model.class_embed = nn.ModuleList([new_class_embed for _ in range(model.transformer.num_decoder_layers)])
+        model.transformer.decoder.class_embed = nn.Linear(features_dim, n)
+        if not fix_enc_out_class:
+            model.transformer.enc_out_class_embed = nn.Linear(features_dim, n)
+        if new_label_enc:
+            model.label_enc = nn.Embedding(n + 1, features_dim)
+    model.load_state_dict(sd)
+    model.eval()
+    return model.to(device)
 
 
 @torch.no_grad()
@@ -41,6 +72,39 @@ def decode_blank_records(outputs, eps: Optional[float] = None) -> Tuple[torch.Te
     from . import ops
     C = outputs["pred_logits"].shape[-1]
     return ops.decode_blank(outputs["pred_logits"], outputs["pred_boxes"], 0.03 / C if eps is None else eps)
+
+
+def loss_ctc(outputs, target_labels: Sequence[Sequence[int]], eps: float = 0.003, filler: float = 1e-5) -> torch.Tensor:
+    """Forward value of `SetCriterion.loss_CTC` (models/dino/dino.py:457-551) as engine.evaluate_CTC logs it
+    (engine.py:381): HIP kernels (per-query sigmoid sums chip-wide, then one workgroup per line for the reading-order sort
+    and the CTC alpha recursion over the 2 nq interleaved steps); the 'mean' reduction of nn.CTCLoss -- per-line NLL over
+    max(target length, 1), averaged over the batch -- is applied here.  target_labels: per line, the label indices
+    (charset positions, WITHOUT the +1 blank shift).  Returns a 0-d fp32 CUDA tensor."""
+    from . import ops
+    logits = outputs["pred_logits"]
+    B = logits.shape[0]
+    if len(target_labels) != B:
+        raise ValueError(f"loss_ctc: {len(target_labels)} label sequences for a batch of {B}")
+    lens = [len(t) for t in target_labels]
+    Lmax = max(lens) if lens else 0
+    tt = torch.zeros((B, max(Lmax, 1)), dtype=torch.int32)
+    for i, t in enumerate(target_labels):
+        if len(t):
+            tt[i, : len(t)] = torch.as_tensor([int(v) for v in t], dtype=torch.int32) + 1
+    tl = torch.tensor(lens, dtype=torch.int32)
+    nll = ops.ctc_loss_interleaved(logits, outputs["pred_boxes"], tt.to(logits.device), tl.to(logits.device), Lmax, eps, filler)
+    return (nll / tl.to(logits.device).clamp(min=1).float()).mean()
+
+
+def evaluate_ctc_step(outputs, target_labels: Sequence[Sequence[int]]) -> Dict[str, float]:
+    """One batch of engine.evaluate_CTC (engine.py:371-411): the CTC loss value and the summed per-line character error rate
+    of the argmax decode that shares the loss's blank construction (eps = 0.003; engine.py:511-530, 544-568, 594-633).
+    Returns {"loss_CTC", "cer_sum", "n"}: the caller accumulates cer_sum / n over the loader like engine.py:413-420."""
+    loss = loss_ctc(outputs, target_labels)
+    labels, lengths = decode_blank_records(outputs, eps=0.003)
+    preds = records_to_lists(labels, lengths)
+    cer = sum(character_error_rate(p, [int(v) for v in t]) for p, t in zip(preds, target_labels))
+    return {"loss_CTC": float(loss.item()), "cer_sum": float(cer), "n": len(preds)}
 
 
 def records_to_lists(labels: torch.Tensor, lengths: torch.Tensor) -> List[List[int]]:

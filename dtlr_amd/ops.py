@@ -453,3 +453,22 @@ def preprocess_lines(src_u8, offsets, dims, Hc: int, Wc: int, max_downscale: flo
                                             canvas.data_ptr(), mask.data_ptr(), _lib.current_stream())
     _lib.check(code, "dtlr_preprocess_lines")
     return canvas, mask
+
+
+def ctc_loss_interleaved(logits, boxes, targets, target_lengths, max_target_length: int, eps: float = 0.003, filler: float = 1e-5):
+    """Per-line CTC negative log-likelihood of the reference's evaluation loss (dtlr_ctc_loss_interleaved): logits [B,nq,C],
+    boxes [B,nq,4], targets [B,Lmax] int32 (label + 1), target_lengths [B] int32 (CUDA) -> nll [B] fp32 (inf -> 0)."""
+    require_cuda(logits, "pred_logits")
+    B, nq, C = logits.shape
+    logits = logits.float().contiguous()
+    boxes = boxes.float().contiguous()
+    assert targets.dtype == torch.int32 and target_lengths.dtype == torch.int32 and targets.is_cuda and target_lengths.is_cuda
+    targets = targets.contiguous()
+    Lmax = targets.shape[1]
+    nll = torch.empty((B,), dtype=torch.float32, device=logits.device)
+    ws = torch.empty((B * nq,), dtype=torch.float32, device=logits.device)
+    code = _lib.lib().dtlr_ctc_loss_interleaved(logits.data_ptr(), boxes.data_ptr(), targets.data_ptr() if Lmax > 0 else None,
+                                                target_lengths.data_ptr(), nll.data_ptr(), ws.data_ptr(), B, nq, C, Lmax,
+                                                int(max_target_length), float(eps), float(filler), _lib.current_stream())
+    _lib.check(code, "dtlr_ctc_loss_interleaved")
+    return nll

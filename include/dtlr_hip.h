@@ -279,6 +279,19 @@ int dtlr_topk_rows(const float *scores, long *idx_out, int B, int S, int k, void
 int dtlr_decode_blank(const float *logits, const float *boxes, int *labels, int *lengths,
                       int B, int nq, int C, float eps, void *stream);
 
+/* Evaluation-time CTC loss value, per line (negative log-likelihood; inf -> 0 as `zero_infinity=True`).
+ * Replaces: the forward of `SetCriterion.loss_CTC` (models/dino/dino.py:457-551) as engine.evaluate_CTC calls it
+ *           (engine.py:381): queries sorted by box cx, sigmoid, blank channel with eps (0.003 there), a filler step
+ *           [1, filler, ...] after every query (T = 2 nq), nn.CTCLoss(blank=0) against labels + 1.  The caller applies the
+ *           'mean' reduction: mean_b( nll[b] / max(target_lengths[b], 1) ).
+ *   logits [B,nq,C] fp32 ; boxes [B,nq,4] fp32 ; targets [B,Lmax] int32 = label + 1, rows padded arbitrarily ;
+ *   target_lengths [B] int32 ; nll [B] fp32 out ; workspace >= B*nq floats ; all device pointers.
+ *   max_target_length = max(target_lengths) as known to the HOST (sizes the workgroup: one thread per state of the
+ *   blank-extended sequence, 2 L + 1 <= 1024, else DTLR_ESHAPE). */
+int dtlr_ctc_loss_interleaved(const float *logits, const float *boxes, const int *targets, const int *target_lengths,
+                              float *nll, float *workspace, int B, int nq, int C, int Lmax, int max_target_length,
+                              float eps, float filler, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -705,3 +705,26 @@ def preprocess_lines(images, size: int = 800, max_size: int = 1333) -> Tuple[Ten
     """List of RGB uint8 images -> (padded batch [B, 3, Hmax, Wmax] fp32, mask [B, Hmax, Wmax] bool): the per-item transform
     above followed by the collate of util/misc.py:375-397."""
     return nested_tensor_from_tensor_list([preprocess_line(im, size, max_size) for im in images])
+
+
+# ======================================================================================
+# models/dino/dino.py:457-551 -- SetCriterion.loss_CTC forward value (SURVEY.md section 8f.3)
+# ======================================================================================
+def loss_ctc(outputs, target_labels: Sequence[Sequence[int]], eps: float = 0.003, filler: float = 1e-5) -> Tensor:
+    """The evaluation-time CTC loss value of engine.evaluate_CTC (engine.py:381): queries in reading order, sigmoid, blank
+    channel (dino.py:474-502 == blank_probabilities with eps 0.003), a filler step [1, 1e-5, ...] after every query
+    (:505-519, sequence length 2 nq), `nn.CTCLoss(blank=0, zero_infinity=True, reduction="mean")` on the log of that
+    against labels + 1 (:520-544).  Returns the scalar loss (fp32, CPU)."""
+    probs = blank_probabilities(outputs, eps)                                   # [B, nq, C + 1]
+    B, nq, C1 = probs.shape
+    blank_rows = torch.zeros_like(probs) + filler
+    blank_rows[:, :, 0] = 1
+    padded = torch.zeros((B, 2 * nq, C1), dtype=probs.dtype)
+    padded[:, ::2, :] = probs
+    padded[:, 1::2, :] = blank_rows
+    lengths = torch.tensor([len(t) for t in target_labels], dtype=torch.int64)
+    tt = torch.zeros((B, int(lengths.max().item()) if B else 0))
+    for i, t in enumerate(target_labels):
+        tt[i, : len(t)] = torch.as_tensor(list(t), dtype=tt.dtype) + 1
+    return F.ctc_loss(torch.log(padded.permute(1, 0, 2)), tt, torch.full((B,), 2 * nq, dtype=torch.int64), lengths,
+                      blank=0, reduction="mean", zero_infinity=True)

@@ -485,3 +485,58 @@ def test_preprocess_lines_golden_and_errors(golden_dir):
         assert torch.equal(nt.tensors[0].cpu(), want), (seed, h, w, size)
     with pytest.raises(RuntimeError):                       # 13x down-scaling: outside the kernel's filter footprint
         T.preprocess_lines([preproc_image(400, 30, 1)], 2, None)
+
+
+def test_ctc_loss_vs_oracle_and_reference_golden(golden_dir):
+    """dtlr_ctc_loss_interleaved (+ the 'mean' reduction in evaluation.loss_ctc) against (a) the oracle, which runs torch's own
+    CTCLoss on CPU exactly as SetCriterion.loss_CTC does (models/dino/dino.py:457-551), and (b) the values the REAL reference
+    criterion produced (tests/golden/g5_ctc.npz).  fp32 log-space recursion over 2 nq steps: tolerance 1e-4 relative."""
+    from dtlr_amd import evaluation as E
+    from oracle import dtlr_oracle as O
+    from tests.util import ctc_case
+    g = np.load(os.path.join(golden_dir, "g5_ctc.npz"))
+    for k, (seed, B, nq, C, bias, lmax) in enumerate(g["cases"].tolist()):
+        outputs, labels = ctc_case(int(seed), int(B), int(nq), int(C), bias, int(lmax))
+        dev = {kk: v.cuda() for kk, v in outputs.items()}
+        got = E.loss_ctc(dev, labels).item()
+        want = O.loss_ctc(outputs, labels).item()
+        assert abs(got - want) <= 1e-4 * max(1.0, abs(want)), (k, got, want)
+        assert abs(got - float(g[f"loss_{k}"])) <= 1e-4 * max(1.0, abs(float(g[f"loss_{k}"]))), (k, got)
+
+
+def test_ctc_loss_edge_cases():
+    """Impossible alignments give 0 (zero_infinity), empty transcriptions are scored against the all-blank path, repeated
+    characters need the filler blank, per-line values match torch's CTCLoss(reduction='none')."""
+    from dtlr_amd import ops
+    from oracle import dtlr_oracle as O
+    from tests.util import ctc_case
+    outputs, _ = ctc_case(11, 4, 12, 7, -2.0, 5)
+    labels = [[1, 1, 1, 1], [], [0, 6, 3], list(range(7)) * 4]          # the last: 28 labels > 24 steps -> infeasible
+    want_each = []
+    for b in range(4):
+        one = {k: v[b:b + 1] for k, v in outputs.items()}
+        want_each.append(O.loss_ctc(one, [labels[b]]).item() * max(len(labels[b]), 1))
+    Lmax = max(len(l) for l in labels)
+    tt = torch.zeros((4, Lmax), dtype=torch.int32)
+    for i, l in enumerate(labels):
+        tt[i, : len(l)] = torch.tensor(l, dtype=torch.int32) + 1
+    tl = torch.tensor([len(l) for l in labels], dtype=torch.int32)
+    nll = ops.ctc_loss_interleaved(outputs["pred_logits"].cuda(), outputs["pred_boxes"].cuda(), tt.cuda(), tl.cuda(), Lmax).cpu()
+    assert nll[3].item() == 0.0 and want_each[3] == 0.0
+    for b in range(3):
+        assert abs(nll[b].item() - want_each[b]) <= 1e-4 * max(1.0, abs(want_each[b])), (b, nll[b].item(), want_each[b])
+    with pytest.raises(RuntimeError):                                   # 2 L + 1 > 1024 states
+        ops.ctc_loss_interleaved(outputs["pred_logits"].cuda(), outputs["pred_boxes"].cuda(),
+                                 torch.ones((4, 600), dtype=torch.int32).cuda(), torch.full((4,), 600, dtype=torch.int32).cuda(), 600)
+
+
+def test_evaluate_ctc_step_matches_oracle():
+    from dtlr_amd import evaluation as E
+    from oracle import dtlr_oracle as O
+    from tests.util import ctc_case
+    outputs, labels = ctc_case(21, 3, 40, 23, -3.0, 15)
+    r = E.evaluate_ctc_step({k: v.cuda() for k, v in outputs.items()}, labels)
+    preds = O.decode_blank(outputs, 0.003)
+    want_cer = sum(O.character_error_rate_engine(p, l) for p, l in zip(preds, labels))
+    assert r["n"] == 3 and abs(r["cer_sum"] - want_cer) < 1e-12
+    assert abs(r["loss_CTC"] - O.loss_ctc(outputs, labels).item()) <= 1e-4 * max(1.0, r["loss_CTC"])

@@ -170,3 +170,27 @@ def test_bf16_padded_batch_close_to_fp32():
     assert diff.mean() < 0.15 and diff.max() < 3.0, (diff.mean().item(), diff.max().item())
     bd = (o16["pred_boxes"].float() - o32["pred_boxes"]).abs()
     assert bd.mean() < 5e-3, bd.mean().item()
+
+
+def test_head_resize_checkpoint_flow_forward(tmp_path):
+    """a model built from the stock config (23 classes here) ingests a checkpoint whose heads were
+    rebuilt to another charset (11 classes) through evaluation.load_model (evaluation.py:51-88) and then produces the
+    oracle's logits for that state dict: the engine sizes its class heads from the weights, not from the config."""
+    import dataclasses
+    from dtlr_amd import evaluation as E
+    from dtlr_amd.dino import DINO
+    from oracle import dtlr_oracle as O
+    cfg = DTLRConfig.tiny()
+    cfg11 = dataclasses.replace(cfg, num_classes=11)            # label_enc keeps its size: no --new_label_enc
+    sd = weights.synthetic_state_dict(cfg11, 4)
+    ck = {k: v for k, v in sd.items() if not k.startswith("transformer.decoder.class_embed.")}
+    ck["transformer.decoder.class_embed.weight"] = torch.zeros(11, 256)
+    ck["transformer.decoder.class_embed.bias"] = torch.zeros(11)
+    torch.save({"model": ck}, tmp_path / "checkpoint.pth")
+    m = E.load_model(DINO(cfg), str(tmp_path / "checkpoint.pth"), device="cuda:0", new_class_embedding=True, charset_size=11)
+    imgs = synth.stroke_lines(2, 32, 256, seed=9)
+    out = m([i.cuda() for i in imgs], return_debug=True)
+    assert tuple(out["pred_logits"].shape) == (2, cfg.num_queries, 11)
+    ref = O.dino_forward(sd, cfg11, imgs, forced_topk=out["_debug"]["topk_idx"].cpu())
+    assert (out["pred_logits"].cpu() - ref["pred_logits"]).abs().max() < LOGIT_TOL
+    assert (out["pred_boxes"].cpu() - ref["pred_boxes"]).abs().max() < BOX_TOL

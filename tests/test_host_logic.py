@@ -223,3 +223,40 @@ def test_transforms_input_validation():
     # no CPU fallback: a CPU device reaches the HIP wrapper, which refuses non-CUDA tensors
     with pytest.raises(Exception):
         T.preprocess_lines([np.zeros((8, 40, 3), dtype=np.uint8)], device="cpu")
+
+
+def test_checkpoint_ingestion_head_resize_flow(tmp_path):
+    """evaluation.load_model == evaluation.py:51-88: a checkpoint written by a model whose heads were rebuilt to a
+    dataset charset (80 classes here; bare Linear under transformer.decoder.class_embed, label_enc of charset+1 rows) loads
+    into a model built from the stock 166-class config once the same rebuild is applied; the engine then takes the class
+    count from the weights."""
+    import dataclasses
+    from dtlr_amd import evaluation as E
+    from dtlr_amd.dino import DINO
+    cfg = DTLRConfig.latin()
+    cfg80 = dataclasses.replace(cfg, num_classes=80, dn_labelbook_size=80)
+    sd = weights.synthetic_state_dict(cfg80, 3)
+    assert weights.num_classes_of(sd) == 80
+    sd = dict(sd)
+    for k in [k for k in sd if k.startswith("transformer.decoder.class_embed.")]:
+        del sd[k]                                                   # the flow replaces the aliased list by a bare Linear
+    sd["transformer.decoder.class_embed.weight"] = torch.zeros(80, 256)
+    sd["transformer.decoder.class_embed.bias"] = torch.zeros(80)
+    path = tmp_path / "checkpoint.pth"
+    torch.save({"model": sd}, path)
+    m = DINO(cfg)
+    with pytest.raises(RuntimeError):                               # without the rebuild the shapes do not match (evaluation.py:54-56)
+        E.load_model(DINO(cfg), str(path), device="cpu")
+    m = E.load_model(m, str(path), device="cpu", new_class_embedding=True, charset_size=80, new_label_enc=True)
+    assert not m.training
+    assert m.class_embed[0].weight.shape == (80, 256) and m.class_embed[0] is m.class_embed[5]
+    assert m.transformer.enc_out_class_embed.out_features == 80 and m.label_enc.weight.shape == (81, 256)
+    assert torch.equal(m.class_embed[3].weight, sd["class_embed.0.weight"])
+    assert weights.num_classes_of(m.state_dict()) == 80            # what DTLREngine sizes its heads from
+    # fix_enc_out_class keeps the stock two-stage head: such a checkpoint must then carry a 166-row one
+    with pytest.raises(RuntimeError):
+        E.load_model(DINO(cfg), str(path), device="cpu", new_class_embedding=True, fix_enc_out_class=True)
+    # plain flow on a stock checkpoint
+    sd166 = weights.synthetic_state_dict(cfg, 0)
+    m2 = E.load_model(DINO(cfg), sd166, device="cpu")
+    assert torch.equal(m2.class_embed[0].bias, sd166["class_embed.0.bias"])

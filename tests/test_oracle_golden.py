@@ -166,3 +166,15 @@ def test_preproc_pipeline_shapes_and_mask():
         r = torch.from_numpy(O.pil_resize_bilinear_u8(imgs[b], oh, ow)).permute(2, 0, 1).float()
         want = (r / 255 - torch.tensor(O.IMAGENET_MEAN).view(3, 1, 1)) / torch.tensor(O.IMAGENET_STD).view(3, 1, 1)
         assert torch.equal(x[b, :, :oh, :ow], want)
+
+
+# ---- evaluation-time CTC loss value -----------------------------------------------------------
+def test_g5_ctc_loss_matches_reference_criterion(golden_dir):
+    """oracle.loss_ctc == SetCriterion.loss_CTC of the real reference (tests/golden/make_golden_ctc.py): same arithmetic
+    (torch's CTCLoss on CPU), so the tolerance only absorbs summation-order noise."""
+    from tests.util import ctc_case
+    g = np.load(os.path.join(golden_dir, "g5_ctc.npz"))
+    for k, (seed, B, nq, C, bias, lmax) in enumerate(g["cases"].tolist()):
+        outputs, labels = ctc_case(int(seed), int(B), int(nq), int(C), bias, int(lmax))
+        got = O.loss_ctc(outputs, labels).item()
+        assert abs(got - float(g[f"loss_{k}"])) <= 1e-5 * max(1.0, abs(float(g[f"loss_{k}"]))), (k, got, float(g[f"loss_{k}"]))

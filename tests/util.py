@@ -62,3 +62,25 @@ def preproc_image(h, w, seed):
     if seed % 2:
         base = np.where(g.random((h, w, 1)) < 0.15, base // 4, 200 + base // 5).astype(np.uint8)
     return base
+
+
+def ctc_case(seed, B, nq, C, bias, lmax):
+    """Seeded head outputs + label sequences for the CTC-loss tests (shared with tests/golden/make_golden_ctc.py):
+    logits ~ N(bias, 1) with a few confident queries per line, boxes uniform, ragged label sequences incl. an empty one and
+    repeated characters."""
+    g = np.random.Generator(np.random.PCG64(1000 + seed))
+    logits = (g.standard_normal((B, nq, C)) + bias).astype(np.float32)
+    for b in range(B):
+        hot = g.choice(nq, size=max(2, nq // 6), replace=False)
+        logits[b, hot, g.integers(0, C, hot.shape[0])] += 9.0
+    boxes = g.uniform(0.02, 0.98, (B, nq, 4)).astype(np.float32)
+    labels = []
+    for b in range(B):
+        L = int(g.integers(1, min(lmax, nq) + 1))
+        seq = g.integers(0, C, L).tolist()
+        if L > 3:
+            seq[2] = seq[1]                                        # a repeated character: needs the blank between them
+        labels.append(seq)
+    if B > 2:
+        labels[-1] = []                                            # an empty transcription
+    return {"pred_logits": torch.from_numpy(logits), "pred_boxes": torch.from_numpy(boxes)}, labels
