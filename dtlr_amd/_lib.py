@@ -37,6 +37,7 @@ _SIGNATURES = {
                                     c_int, c_int, c_int, c_void_p]),
     "dtlr_proj_pack_weights": (c_int, [c_void_p, c_void_p]),
     "dtlr_proj_ln_bf16": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_float, c_void_p, c_int, c_int, c_void_p]),
+    "dtlr_proj_ln_split_bf16": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_float, c_void_p, c_int, c_int, c_void_p]),
     "dtlr_mha_forward": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p]),
     "dtlr_mha_workspace_bytes": (ctypes.c_long, [c_int, c_int, c_int, c_int]),
     "dtlr_gemm_nt": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,

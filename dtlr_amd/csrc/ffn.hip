@@ -392,6 +392,13 @@ __global__ __launch_bounds__(512, 2) void ffn_fused_bf16_kernel(
 constexpr int PLN_LN_OFF = 64 * 1024;
 constexpr int PLN_LDS = PLN_LN_OFF + 2 * 2 * 32 * 4;
 
+// SPLIT = true (two-stage query selection, deformable_transformer.py:320-345: `output_memory = enc_output_norm(enc_output(memory
+// masked))`): no residual; `R` is instead a per-token keep mask (uint8, 0 = the token's features are zeroed BEFORE the
+// projection, models/dino/utils.py:60-62), and the fp32 LayerNorm result is written as THREE bf16 images per token,
+// Y[tok] = [hi | lo | hi] with hi = bf16(y), lo = bf16(y - hi): multiplied with a class-head weight laid out as
+// [W_hi | W_hi | W_lo] the bf16 matrix cores deliver y W^T to ~2^-16 relative -- the selection scores no longer need the
+// fp32 MFMA path (0.27 ms for the 166 x 256 head over 174080 tokens) nor an fp32 copy of output_memory.
+template <bool SPLIT>
 __global__ __launch_bounds__(256, 2) void proj_ln_bf16_kernel(
     const uint16_t* __restrict__ A, const uint16_t* __restrict__ W, const float* __restrict__ bias,
     const uint16_t* __restrict__ R, const float* __restrict__ gamma, const float* __restrict__ beta, float eps,
@@ -411,8 +418,18 @@ __global__ __launch_bounds__(256, 2) void proj_ln_bf16_kernel(
         const long tok = min(tok0 + tt * 16 + n, (long)M - 1);
 #pragma unroll
         for (int ks = 0; ks < 8; ++ks) af[ks][tt] = ffn_load16(A + tok * 256 + ks * 32 + g * 8);
+        if constexpr (!SPLIT) {
 #pragma unroll
-        for (int kq = 0; kq < 4; ++kq) rr[kq][tt] = ffn_load16(R + tok * 256 + 128 * half + 32 * kq + 8 * g);
+            for (int kq = 0; kq < 4; ++kq) rr[kq][tt] = ffn_load16(R + tok * 256 + 128 * half + 32 * kq + 8 * g);
+        } else {
+#pragma unroll
+            for (int kq = 0; kq < 4; ++kq) rr[kq][tt] = make_uint4(0u, 0u, 0u, 0u);
+            if (R && reinterpret_cast<const unsigned char*>(R)[tok] == 0) {        // masked token: features zeroed before the projection
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#pragma unroll
+                for (int ks = 0; ks < 8; ++ks) af[ks][tt] = make_uint4(0u, 0u, 0u, 0u);
+            }
+        }
     }
     // weight DMA: k-group j = k-steps {2j, 2j+1} = 32 blocks of 1 KB, 8 per wave: block (i = 4 w + (u>>1), kk = u&1) of the
     // group goes to ring stage j&1 at ((i*2 + kk) KB).  W is pre-packed in image order (dtlr_proj_pack_weights): block
@@ -511,9 +528,21 @@ __global__ __launch_bounds__(256, 2) void proj_ln_bf16_kernel(
             float o[8];
 #pragma unroll
             for (int e = 0; e < 8; ++e) o[e] = (v[tt][kq][e] - mean[tt]) * rstd[tt] * gm[e] + bt[e];
-            if (tok < M)
-                *reinterpret_cast<uint4*>(Y + tok * 256 + ch) =
-                    make_uint4(pack_bf16x2(o[0], o[1]), pack_bf16x2(o[2], o[3]), pack_bf16x2(o[4], o[5]), pack_bf16x2(o[6], o[7]));
+            const uint4 hi = make_uint4(pack_bf16x2(o[0], o[1]), pack_bf16x2(o[2], o[3]), pack_bf16x2(o[4], o[5]), pack_bf16x2(o[6], o[7]));
+            if constexpr (!SPLIT) {
+                if (tok < M) *reinterpret_cast<uint4*>(Y + tok * 256 + ch) = hi;
+            } else {
+                float hf[8], l[8];
+                unpack8(hi, hf);
+#pragma unroll
+                for (int e = 0; e < 8; ++e) l[e] = o[e] - hf[e];
+                const uint4 lo = make_uint4(pack_bf16x2(l[0], l[1]), pack_bf16x2(l[2], l[3]), pack_bf16x2(l[4], l[5]), pack_bf16x2(l[6], l[7]));
+                if (tok < M) {
+                    *reinterpret_cast<uint4*>(Y + tok * 768 + ch) = hi;
+                    *reinterpret_cast<uint4*>(Y + tok * 768 + 256 + ch) = lo;
+                    *reinterpret_cast<uint4*>(Y + tok * 768 + 512 + ch) = hi;
+                }
+            }
         }
     }
 }
@@ -600,8 +629,22 @@ extern "C" int dtlr_proj_ln_bf16(const void* A, const void* W, const float* bias
     if (M <= 0) return DTLR_EINVAL;
     if (d_model != 256) return DTLR_ESHAPE;
     static bool attr = false;
-    if (!attr) { (void)hipFuncSetAttribute((const void*)proj_ln_bf16_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, PLN_LDS); (void)hipGetLastError(); attr = true; }
-    hipLaunchKernelGGL(proj_ln_bf16_kernel, dim3((unsigned)((M + 63) / 64)), dim3(256), PLN_LDS, (hipStream_t)stream,
+    if (!attr) { (void)hipFuncSetAttribute((const void*)proj_ln_bf16_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, PLN_LDS); (void)hipGetLastError(); attr = true; }
+    hipLaunchKernelGGL(proj_ln_bf16_kernel<false>, dim3((unsigned)((M + 63) / 64)), dim3(256), PLN_LDS, (hipStream_t)stream,
                        (const uint16_t*)A, (const uint16_t*)W, bias, (const uint16_t*)R, gamma, beta, eps, (uint16_t*)Y, M);
+    return check_launch();
+}
+
+extern "C" int dtlr_proj_ln_split_bf16(const void* A, const void* W, const float* bias, const unsigned char* keep,
+                                       const float* gamma, const float* beta, float eps, void* Y3, int M, int d_model, void* stream)
+{
+    clear_stale_error();
+    if (!A || !W || !bias || !gamma || !beta || !Y3) return DTLR_EINVAL;
+    if (M <= 0) return DTLR_EINVAL;
+    if (d_model != 256) return DTLR_ESHAPE;
+    static bool attr = false;
+    if (!attr) { (void)hipFuncSetAttribute((const void*)proj_ln_bf16_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, PLN_LDS); (void)hipGetLastError(); attr = true; }
+    hipLaunchKernelGGL(proj_ln_bf16_kernel<true>, dim3((unsigned)((M + 63) / 64)), dim3(256), PLN_LDS, (hipStream_t)stream,
+                       (const uint16_t*)A, (const uint16_t*)W, bias, reinterpret_cast<const uint16_t*>(keep), gamma, beta, eps, (uint16_t*)Y3, M);
     return check_launch();
 }

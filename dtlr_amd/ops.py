@@ -149,6 +149,42 @@ def proj_ln(a, wp, b, residual, ln_w, ln_b, eps: float = 1e-5):
     return y
 
 
+def proj_ln_split(a, wp, b, keep, ln_w, ln_b, eps: float = 1e-5):
+    """LayerNorm(Linear(a with rows where keep == 0 zeroed)) written as [hi | lo | hi] bf16 (dtlr_proj_ln_split_bf16): a [..., 256]
+    bf16, wp = proj_pack_w(W), keep [...] uint8/bool or None -> [..., 768] bf16.  hi + lo reproduces the fp32 LayerNorm output to
+    2^-17 relative; see split_head_weight for the matching class-head layout."""
+    require_cuda(a, "a")
+    assert a.dtype == torch.bfloat16 and wp.dtype == torch.bfloat16 and a.shape[-1] == 256 and wp.numel() == 256 * 256
+    a = a if a.is_contiguous() else a.contiguous()
+    M = a.numel() // 256
+    if keep is not None:
+        keep = keep.reshape(-1)
+        keep = (keep if keep.dtype in (torch.uint8, torch.bool) else (keep != 0)).contiguous()
+        assert keep.numel() == M and keep.is_cuda
+    y = torch.empty(a.shape[:-1] + (768,), dtype=torch.bfloat16, device=a.device)
+    with _Timed("proj_ln_bf16", 2.0 * M * 256 * 256, 4.0 * M * 256 * 2 + 256 * 256 * 2):
+        code = _lib.lib().dtlr_proj_ln_split_bf16(a.data_ptr(), wp.data_ptr(), b.data_ptr(), keep.data_ptr() if keep is not None else None,
+                                                  ln_w.data_ptr(), ln_b.data_ptr(), eps, y.data_ptr(), M, 256, _lib.current_stream())
+    _lib.check(code, "dtlr_proj_ln_split_bf16")
+    return y
+
+
+def split_head_weight(w, b, pad_to: int = 64):
+    """fp32 head [C, 256] -> bf16 [Cp, 768] = [W_hi | W_hi | W_lo] (+ zero rows up to a multiple of `pad_to`) and an fp32 bias
+    [Cp] whose padding is -inf, for use on a proj_ln_split activation: sum_k [hi|lo|hi][k] * [W_hi|W_hi|W_lo][k] =
+    hi.W_hi + lo.W_hi + hi.W_lo, the three leading terms of the exact product."""
+    C = w.shape[0]
+    Cp = -(-C // pad_to) * pad_to
+    wf = w.float()
+    hi = wf.bfloat16()
+    lo = (wf - hi.float()).bfloat16()
+    out = torch.zeros((Cp, 768), dtype=torch.bfloat16, device=w.device)
+    out[:C, :256], out[:C, 256:512], out[:C, 512:] = hi, hi, lo
+    bias = torch.full((Cp,), float("-inf"), dtype=torch.float32, device=w.device)
+    bias[:C] = b.float()
+    return out.contiguous(), bias
+
+
 def ffn_fused_supported(x, w1) -> bool:
     """The fused FFN kernel covers the bf16 engine at d_model 256, d_ff <= 2048 (multiple of 32)."""
     return x.dtype == torch.bfloat16 and x.shape[-1] == 256 and w1.shape[0] % 32 == 0 and w1.shape[0] <= 2048

@@ -127,6 +127,16 @@ int dtlr_proj_pack_weights(const unsigned short *w_host /* [256*256] bf16, row-m
 int dtlr_proj_ln_bf16(const void *A, const void *W, const float *bias, const void *R,
                       const float *gamma, const float *beta, float eps, void *Y, int M, int d_model, void *stream);
 
+/* Two-stage query selection front end, bf16 engine: output_memory = LayerNorm(Linear(memory with masked tokens zeroed)),
+ * written as three bf16 images per token, Y3[tok] = [hi | lo | hi] (hi = bf16(y), lo = bf16(y - hi)), so that a class head
+ * stored as [W_hi | W_hi | W_lo] ([C, 768] bf16) yields y W^T to ~2^-16 relative on the bf16 matrix cores.
+ * Replaces: `output_memory = output_memory.masked_fill(...)` + `enc_output_norm(enc_output(output_memory))`
+ *           (models/dino/utils.py:60-62 ; models/dino/deformable_transformer.py:325-340) ahead of the class head / top-k (:341-345).
+ *   A [M,256] bf16 ; W packed by dtlr_proj_pack_weights ; bias, gamma, beta [256] fp32 ;
+ *   keep [M] uint8 (0 = zero the token's features before the projection) or NULL ; Y3 [M,768] bf16. */
+int dtlr_proj_ln_split_bf16(const void *A, const void *W_packed, const float *bias, const unsigned char *keep,
+                            const float *gamma, const float *beta, float eps, void *Y3, int M, int d_model, void *stream);
+
 /* ---------------------------------------------------------------------------------------------
  * Multi-head self-attention over the decoder queries, fused (scores/softmax/PV stay on chip).
  * Replaces: nn.MultiheadAttention(256, 8, dropout=0)(q, k, v)[0] minus its in/out projections, as

@@ -540,3 +540,41 @@ def test_evaluate_ctc_step_matches_oracle():
     want_cer = sum(O.character_error_rate_engine(p, l) for p, l in zip(preds, labels))
     assert r["n"] == 3 and abs(r["cer_sum"] - want_cer) < 1e-12
     assert abs(r["loss_CTC"] - O.loss_ctc(outputs, labels).item()) <= 1e-4 * max(1.0, r["loss_CTC"])
+
+
+@pytest.mark.parametrize("M", [128, 300, 4097])
+def test_proj_ln_split_and_split_head(M):
+    """Two-stage front end of the bf16 engine: dtlr_proj_ln_split_bf16 = LayerNorm(Linear(masked a)) as [hi | lo | hi], and the
+    class head on [W_hi | W_hi | W_lo].  (1) hi + lo == the fp64 LayerNorm of the same bf16 inputs up to fp32-accumulation noise;
+    (2) images 0 and 2 are identical and lo is at most half a bf16 ulp of hi; (3) the split-product scores equal
+    (hi + lo) W^T + b computed in fp64 to ~2^-16 relative -- the precision the fp32 MFMA head was kept for; (4) padded head rows
+    come out as -inf so a max over the padded width is the max over the real classes."""
+    from dtlr_amd import ops
+    a = _rand((M, 256), 1).bfloat16()
+    w = (_rand((256, 256), 3) / 16).bfloat16()
+    b = _rand((256,), 4) * 0.5
+    gw, gb = 1 + 0.2 * _rand((256,), 6), 0.3 * _rand((256,), 7)
+    keep = (torch.arange(M) % 7 != 3)
+    pre = (a.double() * keep[:, None]) @ w.double().t() + b.double()
+    want = torch.nn.functional.layer_norm(pre, (256,), gw.double(), gb.double(), 1e-5)
+    y3 = ops.proj_ln_split(a.cuda(), ops.proj_pack_w(w.cuda()), b.cuda(), keep.cuda(), gw.cuda(), gb.cuda())
+    assert tuple(y3.shape) == (M, 768)
+    hi, lo, hi2 = y3[:, :256].cpu(), y3[:, 256:512].cpu(), y3[:, 512:].cpu()
+    assert torch.equal(hi, hi2)
+    rec = hi.double() + lo.double()
+    assert (lo.double().abs() <= hi.double().abs() * 2.0 ** -8 + 1e-30).all()       # lo is the rounding residue of hi: at most half an ulp
+    assert (rec - want).abs().max() < 2e-3 * max(1.0, want.abs().max().item())
+    assert (rec[~keep] - rec[~keep][0]).abs().max() == 0            # masked rows: LayerNorm of the bias alone, all identical
+    C = 166
+    hw, hb = _rand((C, 256), 8) / 8, _rand((C,), 9) - 4.6
+    w3, b3 = ops.split_head_weight(hw.cuda(), hb.cuda())
+    assert tuple(w3.shape) == (192, 768) and torch.isinf(b3[C:]).all()
+    sc = ops.linear(y3, w3, b3, out_dtype=torch.float32).cpu()
+    ref = rec @ hw.double().t() + hb.double()
+    assert (sc[:, :C].double() - ref).abs().max() < 3e-5 * max(1.0, ref.abs().max().item())
+    assert torch.isinf(sc[:, C:]).all() and (sc[:, C:] < 0).all()
+    assert torch.equal(sc.max(-1)[0], sc[:, :C].max(-1)[0])
+    # without a mask
+    y3n = ops.proj_ln_split(a.cuda(), ops.proj_pack_w(w.cuda()), b.cuda(), None, gw.cuda(), gb.cuda())
+    wantn = torch.nn.functional.layer_norm(a.double() @ w.double().t() + b.double(), (256,), gw.double(), gb.double(), 1e-5)
+    assert ((y3n[:, :256].double() + y3n[:, 256:512].double()).cpu() - wantn).abs().max() < 2e-3 * max(1.0, wantn.abs().max().item())
