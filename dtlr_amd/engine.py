@@ -177,6 +177,19 @@ class DTLREngine:
             return ops.proj_ln(a, w[proj + ".wp"], w[proj + ".b"], residual, w[norm + ".w"], w[norm + ".b"])
         return self._ln(norm, self._lin(proj, a), residual=residual)
 
+    def _class_head(self, hs):
+        """class_embed on decoder states (models/dino/dino.py:349-352), fp32 logits.  bf16 engine: the states are exact bf16
+        values, so [hs | hs] . [W_hi | W_lo]^T on the bf16 matrix cores is the fp32-weight product to ~2^-16 relative -- the
+        fp32 MFMA path (a quarter of the rate, plus an fp32 copy of hs) is only used by the fp32 engine."""
+        w = self.w
+        if self.use_fused_ffn and hs.dtype == torch.bfloat16:
+            if "class.w2" not in w:
+                wf = w["class.w"].float()
+                hi = wf.bfloat16()
+                w["class.w2"] = torch.cat([hi, (wf - hi.float()).bfloat16()], 1).contiguous()
+            return ops.linear(torch.cat([hs, hs], -1), w["class.w2"], w["class.b"], out_dtype=torch.float32)
+        return ops.linear(hs.float(), w["class.w"], w["class.b"])
+
     def _ffn(self, q, norm, x):
         """forward_ffn + post-norm (deformable_transformer.py:804-823, 876-880).  bf16 engine: one fused kernel, the
         d_ff-wide intermediate stays on chip; fp32 engine: two GEMMs + LayerNorm."""
@@ -336,9 +349,10 @@ class DTLREngine:
             om3 = ops.proj_ln_split(memory, w["enc_output.wp"], w["enc_output.b"], g["keep"], w["enc_output_norm.w"], w["enc_output_norm.b"])
             scores = ops.linear(om3, w["enc_class.w3"], w["enc_class.b3"], out_dtype=torch.float32).max(-1)[0]
             idx = ops.topk_rows(scores, cfg.num_queries) if forced_topk is None else forced_topk
-            sel3 = torch.gather(om3, 1, idx.unsqueeze(-1).expand(-1, -1, 512))
-            sel = sel3[..., :256].float() + sel3[..., 256:].float()
+            sel3 = torch.gather(om3, 1, idx.unsqueeze(-1).expand(-1, -1, 768))
+            sel = sel3[..., :256].float() + sel3[..., 256:512].float()
         else:
+            sel3 = None
             om = memory * g["keep"].to(memory.dtype)
             # selection scores are computed in fp32: the projection writes fp32 straight from its accumulators
             om = self._ln("enc_output_norm", self._lin("enc_output", om, out_dtype=torch.float32))
@@ -347,7 +361,10 @@ class DTLREngine:
             sel = torch.gather(om, 1, idx.unsqueeze(-1).expand(-1, -1, cfg.hidden_dim))
         prop_sel = torch.gather(g["proposals"], 1, idx.unsqueeze(-1).expand(-1, -1, 4))
         ref_unsig = self._box_mlp("enc_bbox", sel, prop_sel, mode=1)
-        return dict(topk_idx=idx, topk_scores=scores, ref_unsig=ref_unsig, hs_enc=sel, init_box=prop_sel.sigmoid())
+        ts = dict(topk_idx=idx, topk_scores=scores, ref_unsig=ref_unsig, hs_enc=sel, init_box=prop_sel.sigmoid())
+        if sel3 is not None:
+            ts["hs_enc3"] = sel3
+        return ts
 
     @staticmethod
     def _inverse_sigmoid(x, eps=1e-3):
@@ -463,14 +480,17 @@ class DTLREngine:
         hs, refs = self.decoder(memory, ts, g, want_aux)
         n = cfg.dec_layers - 1
         out = {
-            "pred_logits": ops.linear(hs[n].float(), self.w["class.w"], self.w["class.b"]),
+            "pred_logits": self._class_head(hs[n]),
             "pred_boxes": self._refine(hs[n], refs[n]),
         }
         if want_aux:
-            out["aux_outputs"] = [{"pred_logits": ops.linear(hs[i].float(), self.w["class.w"], self.w["class.b"]),
-                                   "pred_boxes": self._refine(hs[i], refs[i])}
+            out["aux_outputs"] = [{"pred_logits": self._class_head(hs[i]), "pred_boxes": self._refine(hs[i], refs[i])}
                                   for i in range(n)]
-        interm_class = ops.linear(ts["hs_enc"], self.w["enc_class.w"], self.w["enc_class.b"])
+        if "hs_enc3" in ts:                                        # bf16 engine: the two-stage head on its split images
+            C = self.num_classes
+            interm_class = ops.linear(ts["hs_enc3"], self.w["enc_class.w3"][:C], self.w["enc_class.b3"][:C], out_dtype=torch.float32)
+        else:
+            interm_class = ops.linear(ts["hs_enc"], self.w["enc_class.w"], self.w["enc_class.b"])
         out["interm_outputs"] = {"pred_logits": interm_class, "pred_boxes": ts["ref_unsig"].sigmoid()}
         out["interm_outputs_for_matching_pre"] = {"pred_logits": interm_class, "pred_boxes": ts["init_box"]}
         out["dn_meta"] = None
