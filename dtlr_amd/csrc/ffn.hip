@@ -53,6 +53,13 @@ __device__ __forceinline__ void glds16(const void* gsrc, unsigned lds_dst) {
                  : "=&s"(keep) : "v"(gsrc), "s"(lds_dst) : "memory");
 }
 
+// same with a wave-uniform base in SGPRs and a 32-bit per-lane byte offset (one VGPR instead of a 64-bit address per source)
+__device__ __forceinline__ void glds16s(const void* sbase, unsigned voff, unsigned lds_dst) {
+    unsigned keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep) : "v"(voff), "s"(sbase), "s"(lds_dst) : "memory");
+}
+
 __device__ __forceinline__ uint4 ffn_load16(const void* p) {
     uint4 r;
     asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(r) : "v"(p) : "memory");
@@ -376,6 +383,241 @@ __global__ __launch_bounds__(512, 2) void ffn_fused_bf16_kernel(
 
 
 // ---------------------------------------------------------------------------------------------------------------
+// Fused FFN, second structure (large M: the encoder call): ONE wave per SIMD, 64 tokens per wave, 256 per workgroup.
+//   * a wave computes ALL 32 hidden units of a chunk for its 64 tokens (phase A: 2 hidden tiles x 4 token tiles x 8 k-steps
+//     = 64 MFMA on 16 weight fragments) -- with the hidden-unit -> MFMA-row assignment of the first structure the two
+//     accumulator tiles of a token tile ARE the B-fragment of the second GEMM, so H never leaves the wave's registers:
+//     no LDS exchange, no pair barrier;
+//   * phase B: all 256 output channels for the 64 tokens (16 channel tiles x 4 token tiles = 64 MFMA on 16 fragments),
+//     256 fp32 accumulator registers per lane (the wave owns 512 registers: one wave per SIMD);
+//   * every weight fragment read from LDS feeds 4 MFMAs (2 in the first structure) and a weight byte DMA'd from L2 serves
+//     256 tokens (128): both shared resources that the ablation of the first structure showed at ~60% are halved per token;
+//   * phase B trails by one chunk, so the H epilogue (bias, ReLU, bf16 rounding: ~80 VALU) of chunk c overlaps the 64 MFMAs
+//     of phase B(c-1);
+//   * W1 and W2 stream through separate 4-stage rings (W1(c) is consumed in iteration c, W2(c) in iteration c+1), three
+//     iterations of DMA lead, one barrier per chunk (DMA visibility + stage reuse only);
+//   * LayerNorm statistics: a token's 256 channels live in the 4 lanes (n, g = 0..3) of ONE wave: two shuffles, no LDS.
+#ifdef DTLR_GEMM_TRACE
+// cycle-counter timeline of the first 8 workgroups' wave 0 (trace build only): 1 iteration top, 2 DMA landed (vmcnt), 3 barrier
+// passed, 4 phase A issued, 5 iteration end; 8 kernel start, 9 main loop done, 10 kernel end
+__device__ unsigned long long g_ffn_tl[8 * 1024];
+#define F2_TL_INIT unsigned long long* tl_ = (threadIdx.x == 0 && blockIdx.x < 8) ? g_ffn_tl + blockIdx.x * 1024 : nullptr; int tl_n_ = 0;
+#define F2_TL(CODE) { if (tl_ && tl_n_ < 1024) tl_[tl_n_++] = ((unsigned long long)__builtin_readcyclecounter() << 8) | (CODE); }
+#else
+#define F2_TL_INIT
+#define F2_TL(CODE)
+#endif
+constexpr int F2_NS = 4;
+constexpr int F2_RING = 16384;                              // one W1 (or W2) chunk image
+constexpr int F2_W2_OFF = F2_NS * F2_RING;
+constexpr int F2_B1_OFF = 2 * F2_NS * F2_RING;
+constexpr int F2_LDS = F2_B1_OFF + FFN_MAX_DFF * 4;
+
+template <int TT>
+__global__ __launch_bounds__(256, 1) void ffn2_bf16_kernel(
+    const uint16_t* __restrict__ X, const uint16_t* __restrict__ W1, const float* __restrict__ b1,
+    const uint16_t* __restrict__ W2, const float* __restrict__ b2, const float* __restrict__ gamma,
+    const float* __restrict__ beta, float eps, uint16_t* __restrict__ Y, int M, int d_ff)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const unsigned lds_base = (unsigned)(size_t)(__attribute__((address_space(3))) unsigned char*)smem;
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const int n = lane & 15, g = lane >> 4;
+    const int nchunk = d_ff >> 5;
+    const long tok0 = (long)blockIdx.x * (64 * TT) + wave * (16 * TT);
+    F2_TL_INIT
+    F2_TL(8)
+
+    // X^T fragments of the wave's 64 tokens: lane (n, g) holds X[tok0 + 16 tt + n][32 ks + 8 g .. +7]
+    uint4 xf[8][TT];
+#pragma unroll
+    for (int tt = 0; tt < TT; ++tt) {
+        const long tok = min(tok0 + tt * 16 + n, (long)M - 1);
+#pragma unroll
+        for (int ks = 0; ks < 8; ++ks) xf[ks][tt] = ffn_load16(X + tok * 256 + ks * 32 + g * 8);
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_sched_barrier(0);
+
+    // DMA sources: wave w moves blocks 4w .. 4w+3 of each 16-block image.
+    // W1 block (j, ks) = 8 j + ks : lane (m, g) <- W1[32 c + 8 (m>>2) + 4 j + (m&3)][32 ks + 8 g ..]
+    // W2 block i                  : lane (m, g) <- W2p[c][32 (i>>1) + 8 (m>>2) + 4 (i&1) + (m&3)][8 g ..]
+    // = a wave-uniform base (SGPRs) + a per-lane byte offset (one VGPR per image).
+    const unsigned v1 = (unsigned)(((8 * (n >> 2) + (n & 3)) * 256 + 8 * g) * 2);
+    const unsigned v2 = (unsigned)(((8 * (n >> 2) + (n & 3)) * 32 + 8 * g) * 2);
+    const long cstride = 32L * 256 * 2;
+    const char* W1b = reinterpret_cast<const char*>(W1);
+    const char* W2b = reinterpret_cast<const char*>(W2);
+    const unsigned my1 = lds_base + (unsigned)wave * 4096u, my2 = my1 + F2_W2_OFF;
+#define F2_ISSUE1(C) { const unsigned d_ = my1 + (unsigned)((C) & (F2_NS - 1)) * F2_RING;           \
+        _Pragma("unroll") for (int u = 0; u < 4; ++u) {                                            \
+            const int blk_ = wave * 4 + u;                                                         \
+            glds16s(W1b + (long)(C) * cstride + ((blk_ >> 3) * 4 * 256 + (blk_ & 7) * 32) * 2, v1, d_ + u * 1024u); } }
+#define F2_ISSUE2(C) { const unsigned d_ = my2 + (unsigned)((C) & (F2_NS - 1)) * F2_RING;           \
+        _Pragma("unroll") for (int u = 0; u < 4; ++u) {                                            \
+            const int blk_ = wave * 4 + u;                                                         \
+            glds16s(W2b + (long)(C) * cstride + ((32 * (blk_ >> 1) + 4 * (blk_ & 1)) * 32) * 2, v2, d_ + u * 1024u); } }
+    // one 1 KB piece at a time: inside the main loop the pieces are spread between MFMA groups (a burst of 8 right behind the barrier
+    // stalls the issuing wave for ~150 cycles per piece -- with one wave per SIMD that is matrix-pipe idle time)
+#define F2_PIECE1(C, U) { const int blk_ = wave * 4 + (U);                                          \
+        glds16s(W1b + (long)(C) * cstride + ((blk_ >> 3) * 4 * 256 + (blk_ & 7) * 32) * 2, v1,     \
+                my1 + (unsigned)((C) & (F2_NS - 1)) * F2_RING + (U) * 1024u); }
+#define F2_PIECE2(C, U) { const int blk_ = wave * 4 + (U);                                          \
+        glds16s(W2b + (long)(C) * cstride + ((32 * (blk_ >> 1) + 4 * (blk_ & 1)) * 32) * 2, v2,    \
+                my2 + (unsigned)((C) & (F2_NS - 1)) * F2_RING + (U) * 1024u); }
+    {
+        float* b1s = reinterpret_cast<float*>(smem + F2_B1_OFF);
+        for (int i = (int)threadIdx.x * 4; i < d_ff; i += 256 * 4) *reinterpret_cast<float4*>(b1s + i) = *reinterpret_cast<const float4*>(b1 + i);
+    }
+    // issue order = the steady state's (iteration c issues W1(c+3), W2(c+2)): W1(0) | W1(1) W2(0) | W1(2) W2(1)
+    F2_ISSUE1(0)
+    if (nchunk > 1) F2_ISSUE1(1)
+    F2_ISSUE2(0)
+    if (nchunk > 2) F2_ISSUE1(2)
+    if (nchunk > 1) F2_ISSUE2(1)
+
+    ffn_f32x4_t yacc[16][TT];
+#pragma unroll
+    for (int i = 0; i < 16; ++i)
+#pragma unroll
+        for (int tt = 0; tt < TT; ++tt) yacc[i][tt] = ffn_f32x4_t{0.f, 0.f, 0.f, 0.f};
+    uint4 hb[TT];                                                   // H^T B-fragments of the chunk phase B works on
+#pragma unroll
+    for (int tt = 0; tt < TT; ++tt) hb[tt] = make_uint4(0u, 0u, 0u, 0u);
+    // ONE 16-fragment register buffer serves both GEMMs: as phase A consumes W1 fragment q the slot is refilled with W2 fragment q
+    // of the chunk phase B works on, and as phase B consumes that, with W1 fragment q of the next chunk -- every LDS read has a
+    // whole phase (16 TT MFMAs) to land, and nothing is read right behind a barrier.  slot q: W1 block (j = q & 1, ks = q >> 1) /
+    // W2 block i = q.
+    uint4 w[16];
+#define F2_W1F(C, Q) (*reinterpret_cast<const uint4*>(smem + ((C) & (F2_NS - 1)) * F2_RING + (((Q) & 1) * 8 + ((Q) >> 1)) * 1024 + lane * 16))
+#define F2_W2F(C, Q) (*reinterpret_cast<const uint4*>(smem + F2_W2_OFF + ((C) & (F2_NS - 1)) * F2_RING + (Q) * 1024 + lane * 16))
+    // W1(0) has to be in registers before the first iteration (the only exposed fragment reads are these and the last W2's)
+    if (nchunk > 1) asm volatile("s_waitcnt vmcnt(16) lgkmcnt(0)" ::: "memory");
+    else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+#pragma unroll
+    for (int q = 0; q < 16; ++q) w[q] = F2_W1F(0, q);
+
+    // iteration C (after barrier C: W1(C+1) and W2(C) are visible; w = W1(C) is already in registers):
+    //     phase A(C)  : 16 x TT MFMA; slot q <- W2(C-1) fragment q as soon as its MFMAs are issued
+    //     phase B(C-1): 16 x TT MFMA; slot q <- W1(C+1) fragment q; the H epilogue of chunk C (VALU) runs underneath
+#define F2_STEP(C, WITH_B, WITH_NEXT, DMA1, DMA2)                                                  \
+    {                                                                                              \
+        F2_TL(1)                                                                                   \
+        if (DMA2) asm volatile("s_waitcnt vmcnt(8) lgkmcnt(0)" ::: "memory");   /* the previous iteration's 8 pieces may stay in flight */ \
+        else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");                           \
+        F2_TL(2)                                                                                   \
+        __builtin_amdgcn_s_barrier();                                                              \
+        F2_TL(3)                                                                                   \
+        const float4 bl = *reinterpret_cast<const float4*>(smem + F2_B1_OFF + ((C) * 32 + g * 8) * 4);      \
+        const float4 bh = *reinterpret_cast<const float4*>(smem + F2_B1_OFF + ((C) * 32 + g * 8 + 4) * 4);  \
+        __builtin_amdgcn_sched_barrier(0);                                                         \
+        ffn_f32x4_t he[2][TT];                                                                     \
+        /* hand-placed stream: one group = TT MFMAs on fragment slot q + the slot's refill (+ a DMA piece every 4th group, + a */ \
+        /* sixth of the H epilogue in phase B); sched_barrier(0) between groups keeps hipcc from re-clustering them */ \
+        _Pragma("unroll") for (int q = 0; q < 16; ++q) {                                           \
+            _Pragma("unroll") for (int tt = 0; tt < TT; ++tt)                                      \
+                he[q & 1][tt] = ffn_mma<0>(w[q], xf[q >> 1][tt], q < 2 ? ffn_f32x4_t{0.f, 0.f, 0.f, 0.f} : he[q & 1][tt]); \
+            if (WITH_B) w[q] = F2_W2F((C) - 1, q);                                                 \
+            else if (WITH_NEXT) w[q] = F2_W1F((C) + 1, q);                                         \
+            if ((q & 3) == 3 && (DMA1)) F2_PIECE1((C) + 3, q >> 2)                                 \
+            if (!(WITH_B) && (q & 3) == 1 && (DMA2)) F2_PIECE2((C) + 2, q >> 2)                    \
+            __builtin_amdgcn_sched_barrier(0);                                                     \
+        }                                                                                          \
+        /* H epilogue unit (j, tt): lane (n, g) holds hidden units 32 C + 8 g + 4 j + r of token n = k-slots 8 g + 4 j + r of the B-fragment */ \
+        uint32_t hp[TT][4];                                                                        \
+        _Pragma("unroll") for (int q = 0; q < 16; ++q) {                                           \
+            if (WITH_B) {                                                                          \
+                _Pragma("unroll") for (int tt = 0; tt < TT; ++tt) yacc[q][tt] = ffn_mma<0>(w[q], hb[tt], yacc[q][tt]); \
+                if (WITH_NEXT) w[q] = F2_W1F((C) + 1, q);                                          \
+                if ((q & 3) == 3 && (DMA2)) F2_PIECE2((C) + 2, q >> 2)                             \
+            }                                                                                      \
+            if (q < 2 * TT) {                                                                      \
+                const int j_ = q & 1, t_ = q >> 1;                                                 \
+                const float4 bb_ = j_ ? bh : bl;                                                   \
+                hp[t_][2 * j_] = pack_bf16x2(fmaxf(he[j_][t_][0] + bb_.x, 0.f), fmaxf(he[j_][t_][1] + bb_.y, 0.f));     \
+                hp[t_][2 * j_ + 1] = pack_bf16x2(fmaxf(he[j_][t_][2] + bb_.z, 0.f), fmaxf(he[j_][t_][3] + bb_.w, 0.f)); \
+            }                                                                                      \
+            __builtin_amdgcn_sched_barrier(0);                                                     \
+        }                                                                                          \
+        _Pragma("unroll") for (int tt = 0; tt < TT; ++tt) hb[tt] = make_uint4(hp[tt][0], hp[tt][1], hp[tt][2], hp[tt][3]); \
+        F2_TL(5)                                                                                   \
+    }
+
+    // nchunk >= 4 (launch check).  The DMA flags are compile-time so that the steady-state iteration is ONE basic block (a runtime
+    // `c + 3 < nchunk` around each piece split it into nine and un-did the MFMA / LDS / VALU interleave).
+    F2_STEP(0, false, true, true, true)
+    for (int c = 1; c + 3 < nchunk; ++c) F2_STEP(c, true, true, true, true)
+    F2_STEP(nchunk - 3, true, true, false, true)
+    F2_STEP(nchunk - 2, true, true, false, false)
+    F2_STEP(nchunk - 1, true, false, false, false)
+#undef F2_STEP
+#undef F2_ISSUE1
+#undef F2_ISSUE2
+#undef F2_PIECE1
+#undef F2_PIECE2
+    F2_TL(9)
+    // phase B of the last chunk (its W2 image was published by the last barrier)
+#pragma unroll
+    for (int q = 0; q < 16; ++q) w[q] = F2_W2F(nchunk - 1, q);
+#pragma unroll
+    for (int q = 0; q < 16; ++q)
+#pragma unroll
+        for (int tt = 0; tt < TT; ++tt) yacc[q][tt] = ffn_mma<0>(w[q], hb[tt], yacc[q][tt]);
+#undef F2_W1F
+#undef F2_W2F
+
+    // ---- epilogue: + b2 + residual (X fragment ks holds exactly the channels of accumulator tiles 2 ks, 2 ks + 1), LayerNorm, store ----
+#pragma unroll
+    for (int tt = 0; tt < TT; ++tt) {
+        const long tok = tok0 + tt * 16 + n;
+        float v[8][8];
+        float sum = 0.f;
+#pragma unroll
+        for (int kq = 0; kq < 8; ++kq) {
+            const int ch = 32 * kq + 8 * g;
+            const float4 ba = *reinterpret_cast<const float4*>(b2 + ch), bc = *reinterpret_cast<const float4*>(b2 + ch + 4);
+            const float bias[8] = {ba.x, ba.y, ba.z, ba.w, bc.x, bc.y, bc.z, bc.w};
+            float xr[8];
+            unpack8(xf[kq][tt], xr);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                const float y = e < 4 ? yacc[2 * kq][tt][e] : yacc[2 * kq + 1][tt][e - 4];
+                v[kq][e] = y + bias[e] + xr[e];
+                sum += v[kq][e];
+            }
+        }
+        sum += __shfl_xor(sum, 16, 64);
+        sum += __shfl_xor(sum, 32, 64);
+        const float mean = sum * (1.0f / 256.0f);
+        float q = 0.f;
+#pragma unroll
+        for (int kq = 0; kq < 8; ++kq)
+#pragma unroll
+            for (int e = 0; e < 8; ++e) { const float d = v[kq][e] - mean; q += d * d; }
+        q += __shfl_xor(q, 16, 64);
+        q += __shfl_xor(q, 32, 64);
+        const float rstd = rsqrtf(q * (1.0f / 256.0f) + eps);
+#pragma unroll
+        for (int kq = 0; kq < 8; ++kq) {
+            const int ch = 32 * kq + 8 * g;
+            const float4 ga = *reinterpret_cast<const float4*>(gamma + ch), gc = *reinterpret_cast<const float4*>(gamma + ch + 4);
+            const float4 ea = *reinterpret_cast<const float4*>(beta + ch), ec = *reinterpret_cast<const float4*>(beta + ch + 4);
+            const float gm[8] = {ga.x, ga.y, ga.z, ga.w, gc.x, gc.y, gc.z, gc.w};
+            const float bt[8] = {ea.x, ea.y, ea.z, ea.w, ec.x, ec.y, ec.z, ec.w};
+            float o[8];
+#pragma unroll
+            for (int e = 0; e < 8; ++e) o[e] = (v[kq][e] - mean) * rstd * gm[e] + bt[e];
+            if (tok < M)
+                *reinterpret_cast<uint4*>(Y + tok * 256 + ch) =
+                    make_uint4(pack_bf16x2(o[0], o[1]), pack_bf16x2(o[2], o[3]), pack_bf16x2(o[4], o[5]), pack_bf16x2(o[6], o[7]));
+        }
+    }
+    F2_TL(10)
+}
+
+// ---------------------------------------------------------------------------------------------------------------
 // Output projection + residual + LayerNorm of an attention block, bf16:   Y = LayerNorm(R + A W^T + b),  all [M, 256]
 // == `src = norm1(src + dropout1(self_attn(...)))` where the last op of self_attn is `output_proj`
 // (models/dino/deformable_transformer.py:810-815; ops/modules/ms_deform_attn.py:124), and the decoder's
@@ -561,6 +803,50 @@ extern "C" int dtlr_ffn_fused_bf16(const void* X, const void* W1, const float* b
     if (d_model != 256 || (d_ff & 31) || d_ff < 64 || d_ff > FFN_MAX_DFF) return DTLR_ESHAPE;     // >= 2 chunks: phase B trails by one
     static int dbg = -1;
     if (dbg < 0) { const char* e = getenv("DTLR_FFN_DBG"); dbg = e ? atoi(e) : 0; }
+    // Second structure (one wave per SIMD, H in registers; see ffn2_bf16_kernel) whenever it has its >= 4 chunks:
+    //   * whole rounds of 256 workgroups x 192 tokens (TT = 3), then the remainder as 128-token workgroups (TT = 2) when those
+    //     fit one round -- at M = 174080 that is 3 full rounds + 208 workgroups of 2/3 the length instead of a fourth round
+    //     that would be 54% full;
+    //   * M <= 32768 (the decoder call, M = 28800: a single partial round) stays on the first structure, which is as fast there.
+    // env DTLR_FFN_V = 1 forces the first structure, 2 the second with TT = 3 only (measurements / tests).
+    const char* ev = getenv("DTLR_FFN_V");
+    const int ver = ev ? atoi(ev) : 0;
+    if (dbg == 0 && d_ff >= 128 && ver != 1 && (ver == 2 || M > 256 * 128)) {          // one partial round or less: the first structure is as fast
+        static bool attr2 = false;
+        if (!attr2) {
+            (void)hipFuncSetAttribute((const void*)ffn2_bf16_kernel<3>, hipFuncAttributeMaxDynamicSharedMemorySize, F2_LDS);
+            (void)hipFuncSetAttribute((const void*)ffn2_bf16_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize, F2_LDS);
+            (void)hipGetLastError();
+            attr2 = true;
+        }
+        const uint16_t* Xp = (const uint16_t*)X;
+        uint16_t* Yp = (uint16_t*)Y;
+        const int NCU = 256;
+        long done = 0;
+        if (ver == 2) {
+            hipLaunchKernelGGL(ffn2_bf16_kernel<3>, dim3((unsigned)((M + 191) / 192)), dim3(256), F2_LDS, (hipStream_t)stream,
+                               Xp, (const uint16_t*)W1, b1, (const uint16_t*)W2, b2, gamma, beta, eps, Yp, M, d_ff);
+            return check_launch();
+        }
+        const long full = ((long)M / 192 / NCU) * NCU;                    // workgroups in whole rounds
+        if (full > 0) {
+            hipLaunchKernelGGL(ffn2_bf16_kernel<3>, dim3((unsigned)full), dim3(256), F2_LDS, (hipStream_t)stream,
+                               Xp, (const uint16_t*)W1, b1, (const uint16_t*)W2, b2, gamma, beta, eps, Yp, (int)(full * 192), d_ff);
+            done = full * 192;
+        }
+        const long rem = M - done;
+        if (rem > 0) {
+            const uint16_t* Xr = Xp + done * 256;
+            uint16_t* Yr = Yp + done * 256;
+            if (rem <= (long)NCU * 128)
+                hipLaunchKernelGGL(ffn2_bf16_kernel<2>, dim3((unsigned)((rem + 127) / 128)), dim3(256), F2_LDS, (hipStream_t)stream,
+                                   Xr, (const uint16_t*)W1, b1, (const uint16_t*)W2, b2, gamma, beta, eps, Yr, (int)rem, d_ff);
+            else
+                hipLaunchKernelGGL(ffn2_bf16_kernel<3>, dim3((unsigned)((rem + 191) / 192)), dim3(256), F2_LDS, (hipStream_t)stream,
+                                   Xr, (const uint16_t*)W1, b1, (const uint16_t*)W2, b2, gamma, beta, eps, Yr, (int)rem, d_ff);
+        }
+        return check_launch();
+    }
     const unsigned grid = (unsigned)((M + 127) / 128);
 #define FFN_LAUNCH(D)                                                                              \
     {                                                                                              \
@@ -648,3 +934,16 @@ extern "C" int dtlr_proj_ln_split_bf16(const void* A, const void* W, const float
                        (const uint16_t*)A, (const uint16_t*)W, bias, reinterpret_cast<const uint16_t*>(keep), gamma, beta, eps, (uint16_t*)Y3, M);
     return check_launch();
 }
+
+#ifdef DTLR_GEMM_TRACE
+extern "C" int dtlr_debug_ffn_trace(unsigned long long* out, int clear_only)
+{
+    if (hipDeviceSynchronize() != hipSuccess) return DTLR_ELAUNCH;
+    const size_t bytes = sizeof(unsigned long long) * 8 * 1024;
+    if (!clear_only && hipMemcpyFromSymbol(out, HIP_SYMBOL(g_ffn_tl), bytes) != hipSuccess) return DTLR_ELAUNCH;
+    void* dptr = nullptr;
+    if (hipGetSymbolAddress(&dptr, HIP_SYMBOL(g_ffn_tl)) != hipSuccess) return DTLR_ELAUNCH;
+    if (hipMemset(dptr, 0, bytes) != hipSuccess) return DTLR_ELAUNCH;
+    return DTLR_OK;
+}
+#endif

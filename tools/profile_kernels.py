@@ -168,6 +168,43 @@ def main():
         ms = timeit(lambda: ops.layernorm(ops.linear(ops.linear(x, w1, b1, relu=True), w2, b2), gw, gb, 1e-5, residual=x), args.iters)
         res.append({"kernel": "ffn_unfused_bf16_M174080_dff2048", "ms": ms, "TFLOPs": flops / ms / 1e9})
         del x
+    if "ffn_trace" in only:
+        # needs DTLR_HIP_LIB=dtlr_amd/libdtlr_hip_trace.so: per-iteration timeline of ffn2_bf16_kernel (wave 0 of the first 8 workgroups)
+        import ctypes
+        import numpy as np
+        from dtlr_amd import _lib
+        L = _lib.lib()
+        if not hasattr(L, "dtlr_debug_ffn_trace"):
+            raise SystemExit("ffn_trace needs the trace library (python -m dtlr_amd.build --trace; DTLR_HIP_LIB=...)")
+        L.dtlr_debug_ffn_trace.restype = ctypes.c_int
+        L.dtlr_debug_ffn_trace.argtypes = [ctypes.c_void_p, ctypes.c_int]
+        T = B * S
+        x = torch.randn((T, 256), generator=g).to(dev).bfloat16()
+        w1 = (torch.randn((2048, 256), generator=g) / 16).to(dev).bfloat16()
+        w2p = ops.ffn_pack_w2((torch.randn((256, 2048), generator=g) / 45).to(dev).bfloat16())
+        b1, b2 = torch.randn((2048,), generator=g).to(dev), torch.randn((256,), generator=g).to(dev)
+        gw, gb = torch.ones(256, device=dev), torch.zeros(256, device=dev)
+        buf = np.zeros(8 * 1024, dtype=np.uint64)
+        for _ in range(3):
+            ops.ffn_fused(x, w1, b1, w2p, b2, gw, gb)
+        L.dtlr_debug_ffn_trace(buf.ctypes.data, 1)
+        ops.ffn_fused(x, w1, b1, w2p, b2, gw, gb)
+        L.dtlr_debug_ffn_trace(buf.ctypes.data, 0)
+        for blk in range(8):
+            ev = buf[blk * 1024:(blk + 1) * 1024]
+            ev = ev[ev != 0]
+            t, c = (ev >> np.uint64(8)).astype(np.int64), (ev & np.uint64(255)).astype(np.int64)
+            def seg(a_, b_):                      # mean ticks from each event a_ to the next event b_
+                d = [t[i + 1] - t[i] for i in range(len(c) - 1) if c[i] == a_ and c[i + 1] == b_]
+                return round(float(np.mean(d)), 1) if d else None
+            tops = t[c == 1]
+            res.append({"kernel": f"ffn2_trace_blk{blk}", "events": int(len(ev)), "iterations": int((c == 1).sum()),
+                        "ticks_per_iteration": round(float(np.mean(np.diff(tops))), 1) if len(tops) > 1 else None,
+                        "wait_dma_1to2": seg(1, 2), "barrier_2to3": seg(2, 3), "body_3to5": seg(3, 5), "end_5to1": seg(5, 1),
+                        "prologue_8_to_first1": int(tops[0] - t[c == 8][0]) if (c == 8).any() and len(tops) else None,
+                        "tail_9to10": int(t[c == 10][0] - t[c == 9][0]) if (c == 10).any() and (c == 9).any() else None,
+                        "total_8to10": int(t[c == 10][0] - t[c == 8][0]) if (c == 10).any() and (c == 8).any() else None})
+        del x
     if "gemm_trace" in only:
         # needs DTLR_HIP_LIB=dtlr_amd/libdtlr_hip_trace.so (python -m dtlr_amd.build --trace): per-slab timeline of gemm_ws_kernel for
         # the first workgroups: where a slab iteration spends its cycles (loader: wait for data / LDS store / issue / barrier;
