@@ -306,6 +306,68 @@ __global__ __launch_bounds__(1024) void ctc_interleaved_kernel(const float* __re
     }
 }
 
+// ---- greedy non-maximum suppression, one workgroup per image (torchvision.ops.nms semantics as models/dino/dino.py:1029-1033 uses
+// it: descending score, a box is dropped when its IoU with an already kept box is > threshold; equal scores keep the lower
+// index first).  Stable score sort (bitonic, LDS) -> boxes in sorted order -> the upper-triangular suppression bit-matrix
+// (n x n/64 words, LDS, all threads) -> ONE wave walks the rows in order, OR-ing a kept row's word into its lane's "removed"
+// word (lane w owns word w; no barriers) -> kept original indices, in descending score order.  n <= 1024.
+__global__ __launch_bounds__(1024) void nms_kernel(const float* __restrict__ boxes, const float* __restrict__ scores, float thr,
+                                                   long* __restrict__ keep, int* __restrict__ counts, int n, int npow2)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned long long nms_lds[];   // matrix [n][W] (its head doubles as the sort keys) | float4 sb[npow2] | int order[npow2]
+    const int W = (n + 63) >> 6;
+    unsigned long long* mat = nms_lds;
+    float4* sb = reinterpret_cast<float4*>(nms_lds + (size_t)max(n * W, npow2));
+    int* order = reinterpret_cast<int*>(sb + npow2);
+    const int b = blockIdx.x;
+    const float* bx = boxes + (long)b * n * 4;
+    unsigned long long* keys = nms_lds;
+    for (int i = threadIdx.x; i < npow2; i += blockDim.x)
+        keys[i] = i < n ? (((unsigned long long)(~f32_sortable(scores[(long)b * n + i]))) << 32) | (unsigned)i : ~0ull;
+    bitonic_sort_u64(keys, npow2);                                             // descending score, ties: lower index first
+    for (int i = threadIdx.x; i < n; i += blockDim.x) {
+        const int o = (int)(keys[i] & 0xffffffffull);
+        order[i] = o;
+        sb[i] = *reinterpret_cast<const float4*>(bx + (long)o * 4);
+    }
+    __syncthreads();                                                           // keys are dead from here: the matrix overwrites them
+    for (int t = threadIdx.x; t < n * W; t += blockDim.x) {
+        const int i = t / W, w = t - i * W;
+        unsigned long long bits = 0ull;
+        if (64 * w + 63 > i) {                                                 // only columns j > i
+            const float4 a = sb[i];
+            const float area_a = (a.z - a.x) * (a.w - a.y);
+            for (int jj = 0; jj < 64; ++jj) {
+                const int j = 64 * w + jj;
+                if (j > i && j < n) {
+                    const float4 c = sb[j];
+                    const float iw = fmaxf(fminf(a.z, c.z) - fmaxf(a.x, c.x), 0.f), ih = fmaxf(fminf(a.w, c.w) - fmaxf(a.y, c.y), 0.f);
+                    const float inter = iw * ih;
+                    const float area_c = (c.z - c.x) * (c.w - c.y);
+                    if (inter / (area_a + area_c - inter) > thr) bits |= 1ull << jj;
+                }
+            }
+        }
+        mat[t] = bits;
+    }
+    __syncthreads();
+    if (threadIdx.x < 64) {                                                    // the sequential sweep, one wave, no barriers
+        const int lane = threadIdx.x;
+        unsigned long long removed = 0ull;                                     // lane w: bits of boxes 64 w .. 64 w + 63
+        int cnt = 0;
+        for (int i = 0; i < n; ++i) {
+            const unsigned long long r = __shfl(removed, i >> 6, 64);
+            if (!((r >> (i & 63)) & 1ull)) {                                   // wave-uniform
+                if (lane == 0) keep[(long)b * n + cnt] = order[i];
+                ++cnt;
+                if (lane < W) removed |= mat[i * W + lane];
+            }
+        }
+        for (int i = cnt + lane; i < n; i += 64) keep[(long)b * n + i] = -1;
+        if (lane == 0) counts[b] = cnt;
+    }
+}
+
 static inline int next_pow2(int n) { int p = 1; while (p < n) p <<= 1; return p; }
 
 }  // namespace dtlr
@@ -366,5 +428,21 @@ extern "C" int dtlr_ctc_loss_interleaved(const float* logits, const float* boxes
     hipLaunchKernelGGL(query_sum_kernel, dim3((unsigned)((nrows + 15) / 16)), dim3(256), 0, (hipStream_t)stream, logits, workspace, nrows, C);
     hipLaunchKernelGGL(ctc_interleaved_kernel, dim3(B), dim3(threads), lds, (hipStream_t)stream, logits, boxes, workspace, targets,
                        target_lengths, nll, nq, C, Lmax, eps, filler, np);
+    return check_launch();
+}
+
+extern "C" int dtlr_nms(const float* boxes, const float* scores, float iou_threshold, long* keep, int* counts, int B, int n, void* stream)
+{
+    clear_stale_error();
+    if (!boxes || !scores || !keep || !counts) return DTLR_EINVAL;
+    if (B <= 0 || n <= 0) return DTLR_EINVAL;
+    if (n > 1024) return DTLR_ESHAPE;                          // the bit-matrix lives in LDS
+    const int np = next_pow2(n), W = (n + 63) / 64;
+    const size_t words = (size_t)(n * W > np ? n * W : np);
+    const size_t lds = words * 8 + (size_t)np * 16 + (size_t)np * 4;
+    if (lds > 160 * 1024) return DTLR_ESHAPE;
+    (void)hipFuncSetAttribute((const void*)nms_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    (void)hipGetLastError();
+    hipLaunchKernelGGL(nms_kernel, dim3(B), dim3(1024), lds, (hipStream_t)stream, boxes, scores, iou_threshold, keep, counts, n, np);
     return check_launch();
 }

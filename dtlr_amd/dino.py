@@ -266,30 +266,13 @@ def box_xyxy_to_cxcywh(x):
 
 
 def nms(boxes: torch.Tensor, scores: torch.Tensor, iou_threshold: float) -> torch.Tensor:
-    """Greedy NMS (torchvision.ops.nms semantics: suppress IoU > threshold, keep order = descending
-    score).  The O(n^2) IoU matrix is built on the GPU; the inherently sequential sweep over <=900
-    candidates runs on the host over the thresholded bit-matrix."""
-    n = boxes.shape[0]
-    if n == 0:
+    """Greedy NMS (torchvision.ops.nms semantics: suppress IoU > threshold, keep order = descending score, equal scores keep the
+    lower index first) on the device: HIP kernel `dtlr_nms` (stable score sort, suppression bit-matrix and the sequential sweep
+    all inside one workgroup).  No CPU path: CPU tensors raise.  The variable-length result costs one host read of the count."""
+    if boxes.shape[0] == 0:
         return torch.empty(0, dtype=torch.long, device=boxes.device)
-    order = torch.argsort(scores, descending=True, stable=True)
-    b = boxes[order]
-    area = (b[:, 2] - b[:, 0]) * (b[:, 3] - b[:, 1])
-    lt = torch.maximum(b[:, None, :2], b[None, :, :2])
-    rb = torch.minimum(b[:, None, 2:], b[None, :, 2:])
-    wh = (rb - lt).clamp(min=0)
-    inter = wh[..., 0] * wh[..., 1]
-    over = (inter / (area[:, None] + area[None, :] - inter) > iou_threshold).cpu().numpy()
-    keep, dead = [], [False] * n
-    for i in range(n):
-        if dead[i]:
-            continue
-        keep.append(i)
-        row = over[i]
-        for j in range(i + 1, n):
-            if row[j]:
-                dead[j] = True
-    return order[torch.as_tensor(keep, dtype=torch.long, device=boxes.device)]
+    keep, counts = ops.nms_batched(boxes[None], scores[None], iou_threshold)
+    return keep[0, : int(counts[0].item())]
 
 
 class PostProcess(nn.Module):
@@ -320,7 +303,9 @@ class PostProcess(nn.Module):
         scale_fct = torch.stack([img_w, img_h, img_w, img_h], dim=1)
         boxes = boxes * scale_fct[:, None, :]
         if self.nms_iou_threshold > 0:
-            idx = [nms(b, s, iou_threshold=self.nms_iou_threshold) for b, s in zip(boxes, scores)]
+            # one launch for the batch (a workgroup per image), one host read of the counts
+            keep, counts = ops.nms_batched(boxes, scores, self.nms_iou_threshold)
+            idx = [keep[i, :c] for i, c in enumerate(counts.tolist())]
             return [{"scores": s[i], "labels": l[i], "boxes": b[i]} for s, l, b, i in zip(scores, labels, boxes, idx)]
         return [{"scores": s, "labels": l, "boxes": b} for s, l, b in zip(scores, labels, boxes)]
 

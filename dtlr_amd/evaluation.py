@@ -118,21 +118,20 @@ def decode_blank(outputs, eps: Optional[float] = None) -> List[List[int]]:
 
 @torch.no_grad()
 def decode_nms(outputs, postprocessor: Optional[PostProcess] = None, TH: float = 0.3, NM: float = 0.5) -> List[List[int]]:
-    """evaluation.py:94-115 per line: PostProcess with num_select = #queries(900), NMS IoU NM on a
-    (1,1) canvas, keep score > TH, order by box cx."""
+    """evaluation.py:94-115 for every line of the batch: PostProcess with num_select = #queries (900), NMS IoU NM on a (1,1)
+    canvas, keep score > TH, order by box cx.  Top-k and the per-line filtering are batched device ops, the NMS one HIP launch
+    for the whole batch (dtlr_nms); the only host transfers are the NMS counts and the final label lists."""
     pp = postprocessor or PostProcess()
     B, nq, _ = outputs["pred_logits"].shape
     pp.num_select, pp.nms_iou_threshold = min(900, nq) if nq < 900 else 900, NM
-    res = []
     dev = outputs["pred_logits"].device
-    for b in range(B):
-        one = {"pred_logits": outputs["pred_logits"][b:b + 1], "pred_boxes": outputs["pred_boxes"][b:b + 1]}
-        o = pp(one, torch.tensor([[1.0, 1.0]], device=dev))[0]
+    res = []
+    for o in pp(outputs, torch.ones((B, 2), device=dev)):
         boxes = box_xyxy_to_cxcywh(o["boxes"])
         sel = o["scores"] > TH
         order = torch.sort(boxes[sel][:, 0], descending=False)[1]
-        res.append([int(i) for i in o["labels"].long()[sel][order].cpu().tolist()])
-    return res
+        res.append(o["labels"].long()[sel][order])
+    return [[int(i) for i in r.cpu().tolist()] for r in res]
 
 
 def labels_to_string(labels: Sequence[int], charset: Sequence[str]) -> str:

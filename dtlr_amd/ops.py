@@ -19,7 +19,7 @@ from . import MultiScaleDeformableAttention as _msda
 from . import _lib
 
 # operators still served by ROCm libraries via torch (shrinks as kernels land)
-LIBRARY_BACKED = {"conv2d_nhwc(7x7 stem, fp32 engine only)", "postprocess topk / nms"}
+LIBRARY_BACKED = {"conv2d_nhwc(7x7 stem, fp32 engine only)", "postprocess topk (torch.topk)"}
 
 _DT = {torch.float32: _lib.DTLR_F32, torch.bfloat16: _lib.DTLR_BF16, torch.float64: _lib.DTLR_F64}
 
@@ -508,3 +508,18 @@ def ctc_loss_interleaved(logits, boxes, targets, target_lengths, max_target_leng
                                                 int(max_target_length), float(eps), float(filler), _lib.current_stream())
     _lib.check(code, "dtlr_ctc_loss_interleaved")
     return nll
+
+
+def nms_batched(boxes, scores, iou_threshold: float):
+    """Greedy NMS per image on the device (dtlr_nms): boxes [B,n,4] xyxy fp32, scores [B,n] fp32 -> (keep [B,n] int64: kept
+    original indices in descending score order, -1 padded; counts [B] int32).  n <= 1024."""
+    require_cuda(boxes, "boxes")
+    B, n, _ = boxes.shape
+    boxes = boxes.float().contiguous()
+    scores = scores.float().contiguous()
+    keep = torch.empty((B, n), dtype=torch.int64, device=boxes.device)
+    counts = torch.empty((B,), dtype=torch.int32, device=boxes.device)
+    code = _lib.lib().dtlr_nms(boxes.data_ptr(), scores.data_ptr(), float(iou_threshold), keep.data_ptr(), counts.data_ptr(), B, n,
+                               _lib.current_stream())
+    _lib.check(code, "dtlr_nms")
+    return keep, counts

@@ -302,6 +302,14 @@ int dtlr_ctc_loss_interleaved(const float *logits, const float *boxes, const int
                               float *nll, float *workspace, int B, int nq, int C, int Lmax, int max_target_length,
                               float eps, float filler, void *stream);
 
+/* Greedy non-maximum suppression, batched: image b keeps, in descending score order (equal scores: lower index first), every
+ * box whose IoU with an already kept box is <= iou_threshold.
+ * Replaces: `torchvision.ops.nms(b, s, iou_threshold)` as PostProcess calls it per image (models/dino/dino.py:1029-1033), i.e.
+ *           the NMS decoder of evaluation.py:94-115 (IAM / READ / RIMES scripts: --NMS 0.5 --TH 0.3).
+ *   boxes [B,n,4] fp32 (x0,y0,x1,y1) ; scores [B,n] fp32 ; keep [B,n] int64: kept ORIGINAL indices, -1 padded ; counts [B] int32.
+ *   n <= 1024 (DTLR_ESHAPE otherwise: the suppression bit-matrix lives in LDS). */
+int dtlr_nms(const float *boxes, const float *scores, float iou_threshold, long *keep, int *counts, int B, int n, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -585,3 +585,32 @@ def test_proj_ln_split_and_split_head(M):
     y3n = ops.proj_ln_split(a.cuda(), ops.proj_pack_w(w.cuda()), b.cuda(), None, gw.cuda(), gb.cuda())
     wantn = torch.nn.functional.layer_norm(a.double() @ w.double().t() + b.double(), (256,), gw.double(), gb.double(), 1e-5)
     assert ((y3n[:, :256].double() + y3n[:, 256:512].double()).cpu() - wantn).abs().max() < 2e-3 * max(1.0, wantn.abs().max().item())
+
+
+@pytest.mark.parametrize("B,n,thr", [(3, 900, 0.5), (2, 300, 0.2), (1, 1, 0.5), (2, 65, 0.7), (1, 1024, 0.3)])
+def test_nms_batched_vs_oracle(B, n, thr):
+    """dtlr_nms == the oracle's greedy NMS (torchvision.ops.nms semantics, models/dino/dino.py:1029-1033): kept indices in the
+    same order, on text-line-like boxes (neighbours overlap heavily), with blocks of exactly equal scores (stable order) and
+    degenerate zero-area boxes (IoU 0/0 = NaN never suppresses)."""
+    from dtlr_amd import ops
+    from oracle import dtlr_oracle as O
+    g = np.random.Generator(np.random.PCG64(n + int(thr * 100)))
+    cx = np.sort(g.uniform(0.02, 0.98, (B, n)), axis=1)
+    w = g.uniform(0.004, 0.03, (B, n))
+    cy, h = g.uniform(0.4, 0.6, (B, n)), g.uniform(0.3, 0.8, (B, n))
+    boxes = np.stack([cx - w / 2, cy - h / 2, cx + w / 2, cy + h / 2], -1).astype(np.float32)
+    scores = g.uniform(0, 1, (B, n)).astype(np.float32)
+    if n > 60:
+        scores[0, 10:40] = scores[0, 5]                     # ties: the lower index wins
+        boxes[0, 50] = boxes[0, 51]                          # identical boxes
+        boxes[-1, 7, 2:] = boxes[-1, 7, :2]                  # zero area
+    bt, st = torch.from_numpy(boxes), torch.from_numpy(scores)
+    keep, counts = ops.nms_batched(bt.cuda(), st.cuda(), thr)
+    keep, counts = keep.cpu(), counts.cpu()
+    for b in range(B):
+        want = O.nms(bt[b], st[b], thr)
+        assert counts[b].item() == len(want)
+        assert torch.equal(keep[b, : len(want)], want)
+        assert (keep[b, len(want):] == -1).all()
+    with pytest.raises(RuntimeError):
+        ops.nms_batched(torch.zeros((1, 1025, 4)).cuda(), torch.zeros((1, 1025)).cuda(), 0.5)
