@@ -57,6 +57,7 @@ _SIGNATURES = {
     "dtlr_preprocess_lines": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_float, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
     "dtlr_topk_rows": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_void_p]),
     "dtlr_ctc_loss_interleaved": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_float, c_float, c_void_p]),
+    "dtlr_topk_flat": (c_int, [c_void_p, c_void_p, c_void_p, c_int, ctypes.c_long, c_int, c_int, c_void_p]),
     "dtlr_nms": (c_int, [c_void_p, c_void_p, c_float, c_void_p, c_void_p, c_int, c_int, c_void_p]),
     "dtlr_decode_blank": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_float, c_void_p]),
 }

@@ -115,6 +115,74 @@ __global__ __launch_bounds__(1024) void topk_rows_kernel(const float* __restrict
     for (int i = threadIdx.x; i < k; i += blockDim.x) idx_out[(long)b * k + i] = (long)(cand[i] & 0xffffffffull);
 }
 
+// k largest of a LONG row that stays in global memory (PostProcess: top `num_select` of the nq x C flattened class scores,
+// models/dino/dino.py:1000-1006; 149400 per line for the Latin model, 6.6 M for the Chinese one).  Same exact radix select as
+// topk_rows on key = (~sortable(x) << 32) | index, but every pass re-reads the row (L2-resident) instead of an LDS copy: four score
+// bytes, then as many index bytes as n needs.  The k survivors are compacted into LDS, sorted, and written as (value, index) with
+// value = sigmoid(x) when `apply_sigmoid` (the selection runs on the logits: sigmoid is monotone, so the result is a valid top-k of
+// the probabilities, descending, with ties ordered by logit and then by lower index).  k <= 1024.
+__global__ __launch_bounds__(1024) void topk_flat_kernel(const float* __restrict__ x, float* __restrict__ values, long* __restrict__ idx_out,
+                                                         long n, int k, int kp2, int index_bytes, int apply_sigmoid)
+{
+    __shared__ unsigned long long cand[1024];
+    __shared__ int hist[256];
+    __shared__ int s_rem, s_digit, s_cnt;
+    const int b = blockIdx.x;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const float* row = x + (long)b * n;
+    unsigned long long pref = 0ull, mask = 0ull;
+    int rem = k;
+    const int npass = 4 + index_bytes;
+    for (int pass = 0; pass < npass; ++pass) {
+        const int byte = pass < 4 ? 7 - pass : index_bytes - 1 - (pass - 4);
+        if (threadIdx.x < 256) hist[threadIdx.x] = 0;
+        __syncthreads();
+        for (long i = threadIdx.x; i < n; i += blockDim.x) {
+            const unsigned long long key = (((unsigned long long)(~f32_sortable(row[i]))) << 32) | (unsigned long long)i;
+            if ((key & mask) == pref) atomicAdd(&hist[(int)(key >> (8 * byte)) & 255], 1);
+        }
+        __syncthreads();
+        if (wave == 0) {
+            const int4 h = reinterpret_cast<const int4*>(hist)[lane];
+            const int loc = h.x + h.y + h.z + h.w;
+            int inc = loc;
+#pragma unroll
+            for (int o = 1; o < 64; o <<= 1) { const int t = __shfl_up(inc, o, 64); if (lane >= o) inc += t; }
+            const int exc = inc - loc;
+            if (exc < rem && rem <= inc) {
+                int r = rem - exc, d = 0;
+                if (r > h.x) { r -= h.x; d = 1; if (r > h.y) { r -= h.y; d = 2; if (r > h.z) { r -= h.z; d = 3; } } }
+                s_rem = r; s_digit = 4 * lane + d;
+            }
+        }
+        __syncthreads();
+        rem = s_rem;
+        pref |= (unsigned long long)s_digit << (8 * byte);
+        mask |= 0xffull << (8 * byte);
+        if (byte == 4 && index_bytes < 4) mask |= 0xffffffffull & ~((1ull << (8 * index_bytes)) - 1ull);   // unused high index bytes are zero
+    }
+    if (threadIdx.x == 0) s_cnt = 0;
+    for (int i = k + threadIdx.x; i < kp2; i += blockDim.x) cand[i] = ~0ull;
+    __syncthreads();
+    for (long i0 = 0; i0 < n; i0 += blockDim.x) {
+        const long i = i0 + threadIdx.x;
+        const unsigned long long key = i < n ? (((unsigned long long)(~f32_sortable(row[i]))) << 32) | (unsigned long long)i : ~0ull;
+        const bool sel = key <= pref;
+        const unsigned long long m = __ballot(sel);
+        int base = 0;
+        if (lane == 0 && m) base = atomicAdd(&s_cnt, __popcll(m));
+        base = __shfl(base, 0, 64);
+        if (sel) cand[base + __popcll(m & ((1ull << lane) - 1ull))] = key;
+    }
+    bitonic_sort_u64(cand, kp2);
+    for (int i = threadIdx.x; i < k; i += blockDim.x) {
+        const long id = (long)(cand[i] & 0xffffffffull);
+        const float v = row[id];
+        idx_out[(long)b * k + i] = id;
+        values[(long)b * k + i] = apply_sigmoid ? 1.f / (1.f + expf(-v)) : v;
+    }
+}
+
 template <int CTRL>
 __device__ __forceinline__ float dpp_f(float v) { return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, 0xf, 0xf, true)); }
 template <int CTRL>
@@ -444,5 +512,17 @@ extern "C" int dtlr_nms(const float* boxes, const float* scores, float iou_thres
     (void)hipFuncSetAttribute((const void*)nms_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     (void)hipGetLastError();
     hipLaunchKernelGGL(nms_kernel, dim3(B), dim3(1024), lds, (hipStream_t)stream, boxes, scores, iou_threshold, keep, counts, n, np);
+    return check_launch();
+}
+
+extern "C" int dtlr_topk_flat(const float* x, float* values, long* idx_out, int B, long n, int k, int apply_sigmoid, void* stream)
+{
+    clear_stale_error();
+    if (!x || !values || !idx_out) return DTLR_EINVAL;
+    if (B <= 0 || n <= 0 || k <= 0 || (long)k > n) return DTLR_EINVAL;
+    if (k > 1024 || n > 0xffffffffl) return DTLR_ESHAPE;
+    int index_bytes = 1;
+    while (index_bytes < 4 && (n - 1) >> (8 * index_bytes)) ++index_bytes;
+    hipLaunchKernelGGL(topk_flat_kernel, dim3(B), dim3(1024), 0, (hipStream_t)stream, x, values, idx_out, n, k, next_pow2(k), index_bytes, apply_sigmoid);
     return check_launch();
 }

@@ -19,7 +19,7 @@ from . import MultiScaleDeformableAttention as _msda
 from . import _lib
 
 # operators still served by ROCm libraries via torch (shrinks as kernels land)
-LIBRARY_BACKED = {"conv2d_nhwc(7x7 stem, fp32 engine only)", "postprocess topk (torch.topk)"}
+LIBRARY_BACKED = {"conv2d_nhwc(7x7 stem, fp32 engine only)", "postprocess topk when num_select > 1024 (torch.topk)"}
 
 _DT = {torch.float32: _lib.DTLR_F32, torch.bfloat16: _lib.DTLR_BF16, torch.float64: _lib.DTLR_F64}
 
@@ -523,3 +523,17 @@ def nms_batched(boxes, scores, iou_threshold: float):
                                _lib.current_stream())
     _lib.check(code, "dtlr_nms")
     return keep, counts
+
+
+def topk_flat(x, k: int, apply_sigmoid: bool = False):
+    """Per-row top-k of a long [B, n] fp32 matrix (dtlr_topk_flat: exact radix select over the row in global memory + a 1024-key sort):
+    -> (values [B,k] fp32 descending, indices [B,k] int64; equal values: lower index first).  k <= 1024."""
+    require_cuda(x, "x")
+    assert x.dim() == 2
+    x = x.float().contiguous()
+    B, n = x.shape
+    values = torch.empty((B, k), dtype=torch.float32, device=x.device)
+    idx = torch.empty((B, k), dtype=torch.int64, device=x.device)
+    code = _lib.lib().dtlr_topk_flat(x.data_ptr(), values.data_ptr(), idx.data_ptr(), B, n, int(k), int(bool(apply_sigmoid)), _lib.current_stream())
+    _lib.check(code, "dtlr_topk_flat")
+    return values, idx

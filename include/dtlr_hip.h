@@ -310,6 +310,12 @@ int dtlr_ctc_loss_interleaved(const float *logits, const float *boxes, const int
  *   n <= 1024 (DTLR_ESHAPE otherwise: the suppression bit-matrix lives in LDS). */
 int dtlr_nms(const float *boxes, const float *scores, float iou_threshold, long *keep, int *counts, int B, int n, void *stream);
 
+/* k largest of each row of a [B, n] fp32 matrix that is too long for LDS, descending, equal values: lower index first.
+ * Replaces: `torch.topk(prob.view(B, -1), num_select, dim=1)` of PostProcess (models/dino/dino.py:1000-1006), with the sigmoid
+ *           folded in (apply_sigmoid: the selection runs on the logits, values are returned as sigmoid(logit)).
+ *   x [B,n] fp32 ; values [B,k] fp32 ; idx_out [B,k] int64 (flat positions: box = idx / C, label = idx % C) ; k <= 1024. */
+int dtlr_topk_flat(const float *x, float *values, long *idx_out, int B, long n, int k, int apply_sigmoid, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -614,3 +614,45 @@ def test_nms_batched_vs_oracle(B, n, thr):
         assert (keep[b, len(want):] == -1).all()
     with pytest.raises(RuntimeError):
         ops.nms_batched(torch.zeros((1, 1025, 4)).cuda(), torch.zeros((1, 1025)).cuda(), 0.5)
+
+
+@pytest.mark.parametrize("B,nq,C,k", [(3, 900, 166, 900), (2, 60, 23, 50), (1, 300, 7356, 300), (2, 5, 3, 15), (1, 1000, 300, 1024)])
+def test_topk_flat_and_postprocess_vs_oracle(B, nq, C, k):
+    """dtlr_topk_flat == a stable descending sort of the flattened logits (ties: lower index first; blocks of exactly tied values
+    straddle the cut), values = sigmoid; and PostProcess built on it (models/dino/dino.py:985-1046) == the oracle's: labels, boxes,
+    scores for the reference's two uses (num_select = 50 with image sizes; num_select = 900 on a (1,1) canvas)."""
+    from dtlr_amd import ops
+    from dtlr_amd.dino import PostProcess
+    from oracle import dtlr_oracle as O
+    g = np.random.Generator(np.random.PCG64(nq + C))
+    logits = torch.from_numpy((g.standard_normal((B, nq, C)) * 2 - 3).astype(np.float32))
+    flat = logits.view(B, -1)
+    if flat.shape[1] > 200:
+        flat[0, 100:180] = flat[0, 7]                       # an exact tie block
+        flat[-1, ::5] = 0.25                                # many ties, possibly across the cut
+    vals, idx = ops.topk_flat(flat.cuda(), k, apply_sigmoid=True)
+    order = torch.sort(flat, dim=1, descending=True, stable=True)[1][:, :k]
+    assert torch.equal(idx.cpu(), order)
+    assert (vals.cpu() - torch.gather(flat, 1, order).sigmoid()).abs().max() < 1e-6
+    raw, idx2 = ops.topk_flat(flat.cuda(), k)
+    assert torch.equal(idx2.cpu(), order) and torch.equal(raw.cpu(), torch.gather(flat, 1, order))
+    if k <= nq:
+        boxes = torch.from_numpy(g.uniform(0.05, 0.95, (B, nq, 4)).astype(np.float32))
+        out = {"pred_logits": logits, "pred_boxes": boxes}
+        ts = torch.tensor([[100.0, 200.0]] * B)
+        got = PostProcess(num_select=k)({kk: v.cuda() for kk, v in out.items()}, ts.cuda())
+        want = O.post_process(out, ts, k)
+        checked = []
+        for a, w in zip(got, want):
+            # sets of (box, label) agree wherever the scores are not tied; compare through a stable re-sort on the oracle's probabilities
+            assert torch.allclose(a["scores"].cpu(), w["scores"], atol=1e-6)
+            tie_free = (w["scores"][1:] != w["scores"][:-1])
+            same = (a["labels"].cpu() == w["labels"]) & (a["boxes"].cpu() - w["boxes"]).abs().amax(-1).lt(1e-4)
+            keep = torch.ones_like(same)
+            nxt = torch.topk(out["pred_logits"][len(checked)].sigmoid().view(-1), min(k + 1, nq * C))[0]
+            if nxt.numel() > k and nxt[k] == nxt[k - 1]:
+                keep[-1] = False                            # the tie straddles the cut: the last member is unspecified
+            checked.append(0)
+            keep[1:] &= tie_free
+            keep[:-1] &= tie_free
+            assert same[keep].all()
