@@ -32,6 +32,9 @@ _SIGNATURES = {
                                                 c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p, c_void_p]),
     "dtlr_msda_encoder_forward": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int,
                                           c_int, c_int, c_void_p, c_void_p]),
+    "dtlr_msda_encoder_plan_ok": (c_int, [c_void_p, c_int, c_int]),
+    "dtlr_geometry": (c_int, [c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_int,
+                              c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
     "dtlr_layernorm": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, ctypes.c_long, c_int, c_float, c_int, c_void_p]),
     "dtlr_ffn_fused_bf16": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_float, c_void_p,
                                     c_int, c_int, c_int, c_void_p]),
@@ -42,6 +45,8 @@ _SIGNATURES = {
     "dtlr_mha_workspace_bytes": (ctypes.c_long, [c_int, c_int, c_int, c_int]),
     "dtlr_gemm_nt": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
                              c_int, c_int, c_int, c_int, c_int, c_int, c_void_p]),
+    "dtlr_gemm_nt_rowmax": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p]),
+    "dtlr_two_stage_gather": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p]),
     "dtlr_conv2d_nhwc": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
                                  c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p]),
     "dtlr_decoder_query_prep": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p]),
@@ -53,6 +58,7 @@ _SIGNATURES = {
     "dtlr_box_head_refine": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, ctypes.c_long, c_int, c_int, c_void_p]),
     "dtlr_stem_pack_weights": (c_int, [c_void_p, c_void_p]),
     "dtlr_stem_conv7x7": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p]),
+    "dtlr_stem_conv7x7_f32": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_void_p]),
     "dtlr_maxpool3x3s2_nhwc": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p]),
     "dtlr_preprocess_lines": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_float, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
     "dtlr_topk_rows": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_void_p]),

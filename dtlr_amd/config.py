@@ -92,7 +92,8 @@ class DTLRConfig:
     @staticmethod
     def from_reference_file(path: str) -> "DTLRConfig":
         """Parse a reference config (`config/*.py`): plain assignments with `_base_` inheritance
-        (util/slconfig.py:192-195 does this through addict/yapf, which the path does not need)."""
+        (util/slconfig.py:192-195 does this through addict/yapf, which the path does not need).
+        Like the reference's loader this EXECUTES the file (configs are Python): only pass configs you trust."""
         def load(p, seen):
             ns: dict = {}
             with open(p) as f:

@@ -429,8 +429,8 @@ extern "C" int dtlr_mha_forward(const void* qk, const void* v, void* vt_workspac
     const float scale_log2e = 1.4426950408889634f / sqrtf((float)head_dim);
     const size_t lds = (size_t)(Lpad / 32) * 4096;               // K image + V^T image
     if (lds <= 152 * 1024) {                                     // transposes V while staging: no separate pass, no workspace
-        static bool attr = false;
-        if (!attr) { (void)hipFuncSetAttribute((const void*)mha_fwd_bf16_lds_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 152 * 1024); (void)hipGetLastError(); attr = true; }
+        static DevOnce attr;
+        if (attr.first()) { (void)hipFuncSetAttribute((const void*)mha_fwd_bf16_lds_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 152 * 1024); (void)hipGetLastError(); }
         hipLaunchKernelGGL(mha_fwd_bf16_lds_kernel, dim3(H, B), dim3(1024), lds, st,
                            (const uint16_t*)qk, (const uint16_t*)v, (uint16_t*)out, L, Lpad, H, scale_log2e);
         return check_launch();

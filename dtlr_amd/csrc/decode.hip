@@ -120,11 +120,12 @@ __global__ __launch_bounds__(1024) void topk_rows_kernel(const float* __restrict
 // topk_rows on key = (~sortable(x) << 32) | index, but every pass re-reads the row (L2-resident) instead of an LDS copy: four score
 // bytes, then as many index bytes as n needs.  The k survivors are compacted into LDS, sorted, and written as (value, index) with
 // value = sigmoid(x) when `apply_sigmoid` (the selection runs on the logits: sigmoid is monotone, so the result is a valid top-k of
-// the probabilities, descending, with ties ordered by logit and then by lower index).  k <= 1024.
+// the probabilities, descending, with ties ordered by logit and then by lower index).  k <= 8192 (the survivors' sort lives in LDS).
+// Also the large-S path of dtlr_topk_rows (rows too long for an LDS copy), with values == nullptr.
 __global__ __launch_bounds__(1024) void topk_flat_kernel(const float* __restrict__ x, float* __restrict__ values, long* __restrict__ idx_out,
                                                          long n, int k, int kp2, int index_bytes, int apply_sigmoid)
 {
-    __shared__ unsigned long long cand[1024];
+    extern __shared__ __attribute__((aligned(16))) unsigned long long cand[];      // [kp2]
     __shared__ int hist[256];
     __shared__ int s_rem, s_digit, s_cnt;
     const int b = blockIdx.x;
@@ -179,7 +180,7 @@ __global__ __launch_bounds__(1024) void topk_flat_kernel(const float* __restrict
         const long id = (long)(cand[i] & 0xffffffffull);
         const float v = row[id];
         idx_out[(long)b * k + i] = id;
-        values[(long)b * k + i] = apply_sigmoid ? 1.f / (1.f + expf(-v)) : v;
+        if (values) values[(long)b * k + i] = apply_sigmoid ? 1.f / (1.f + expf(-v)) : v;
     }
 }
 
@@ -448,9 +449,18 @@ extern "C" int dtlr_topk_rows(const float* scores, long* idx_out, int B, int S, 
     if (!scores || !idx_out) return DTLR_EINVAL;
     if (B <= 0 || S <= 0 || k <= 0 || k > S) return DTLR_EINVAL;
     const int np = next_pow2(S), kp = next_pow2(k);
-    if (np > 65536) return DTLR_ESHAPE;                        // the radix select relies on index < 2^16
     const size_t lds = (size_t)np * 8 + (kp < np ? (size_t)kp * 8 : 0);
-    if (lds > 156 * 1024) return DTLR_ESHAPE;
+    if (np > 65536 || lds > 156 * 1024) {
+        // Rows too long for an LDS copy (tall canvases: S > 16384 tokens): the same exact radix select with the row left in
+        // global memory (topk_flat_kernel, values not wanted) -- identical key order, so identical indices.
+        if (kp > 8192) return DTLR_ESHAPE;
+        int index_bytes = 1;
+        while (index_bytes < 4 && ((long)S - 1) >> (8 * index_bytes)) ++index_bytes;
+        const size_t fl = (size_t)kp * 8;
+        if (fl > 48 * 1024) { (void)hipFuncSetAttribute((const void*)topk_flat_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)fl); (void)hipGetLastError(); }
+        hipLaunchKernelGGL(topk_flat_kernel, dim3(B), dim3(1024), fl, (hipStream_t)stream, scores, (float*)nullptr, idx_out, (long)S, k, kp, index_bytes, 0);
+        return check_launch();
+    }
     (void)hipGetLastError();                                   // do not inherit a stale error from an earlier API call
     if (lds > 64 * 1024) (void)hipFuncSetAttribute((const void*)topk_rows_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     (void)hipGetLastError();
@@ -520,9 +530,11 @@ extern "C" int dtlr_topk_flat(const float* x, float* values, long* idx_out, int 
     clear_stale_error();
     if (!x || !values || !idx_out) return DTLR_EINVAL;
     if (B <= 0 || n <= 0 || k <= 0 || (long)k > n) return DTLR_EINVAL;
-    if (k > 1024 || n > 0xffffffffl) return DTLR_ESHAPE;
+    if (k > 8192 || n > 0xffffffffl) return DTLR_ESHAPE;
     int index_bytes = 1;
     while (index_bytes < 4 && (n - 1) >> (8 * index_bytes)) ++index_bytes;
-    hipLaunchKernelGGL(topk_flat_kernel, dim3(B), dim3(1024), 0, (hipStream_t)stream, x, values, idx_out, n, k, next_pow2(k), index_bytes, apply_sigmoid);
+    const size_t fl = (size_t)next_pow2(k) * 8;
+    if (fl > 48 * 1024) { (void)hipFuncSetAttribute((const void*)topk_flat_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)fl); (void)hipGetLastError(); }
+    hipLaunchKernelGGL(topk_flat_kernel, dim3(B), dim3(1024), fl, (hipStream_t)stream, x, values, idx_out, n, k, next_pow2(k), index_bytes, apply_sigmoid);
     return check_launch();
 }

@@ -20,6 +20,20 @@ inline int check_launch() {
     return DTLR_OK;
 }
 
+// One-time per-DEVICE setup (hipFuncSetAttribute is a per-device property: a process that drives several GPUs must repeat it
+// on each): `static DevOnce once; if (once.first()) { ... }`.
+struct DevOnce {
+    unsigned long long mask = 0;
+    bool first() {
+        int d = 0;
+        (void)hipGetDevice(&d);
+        const unsigned long long bit = 1ull << (d & 63);
+        if (mask & bit) return false;
+        mask |= bit;
+        return true;
+    }
+};
+
 // ---- bf16 <-> f32: gfx950 converts in hardware (v_cvt_pk_bf16_f32: round-to-nearest-even, NaN stays a quiet NaN).
 // The first version rounded in software (~10 VALU instructions per pair); in the K = 256 GEMMs that made the
 // epilogue's VALU time equal to the tile's MFMA time.

@@ -809,15 +809,14 @@ extern "C" int dtlr_ffn_fused_bf16(const void* X, const void* W1, const float* b
     //     that would be 54% full;
     //   * M <= 32768 (the decoder call, M = 28800: a single partial round) stays on the first structure, which is as fast there.
     // env DTLR_FFN_V = 1 forces the first structure, 2 the second with TT = 3 only (measurements / tests).
-    const char* ev = getenv("DTLR_FFN_V");
-    const int ver = ev ? atoi(ev) : 0;
+    static const int ver = [] { const char* ev = getenv("DTLR_FFN_V"); return ev ? atoi(ev) : 0; }();   // read once per process
     if (dbg == 0 && d_ff >= 128 && ver != 1 && (ver == 2 || M > 256 * 128)) {          // one partial round or less: the first structure is as fast
-        static bool attr2 = false;
-        if (!attr2) {
+        static DevOnce attr2;
+        if (attr2.first()) {
             (void)hipFuncSetAttribute((const void*)ffn2_bf16_kernel<3>, hipFuncAttributeMaxDynamicSharedMemorySize, F2_LDS);
             (void)hipFuncSetAttribute((const void*)ffn2_bf16_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize, F2_LDS);
             (void)hipGetLastError();
-            attr2 = true;
+           
         }
         const uint16_t* Xp = (const uint16_t*)X;
         uint16_t* Yp = (uint16_t*)Y;
@@ -850,8 +849,8 @@ extern "C" int dtlr_ffn_fused_bf16(const void* X, const void* W1, const float* b
     const unsigned grid = (unsigned)((M + 127) / 128);
 #define FFN_LAUNCH(D)                                                                              \
     {                                                                                              \
-        static bool attr = false;                                                                  \
-        if (!attr) { (void)hipFuncSetAttribute((const void*)ffn_fused_bf16_kernel<D>, hipFuncAttributeMaxDynamicSharedMemorySize, FFN_LDS); (void)hipGetLastError(); attr = true; } \
+        static DevOnce attr;                                                                  \
+        if (attr.first()) { (void)hipFuncSetAttribute((const void*)ffn_fused_bf16_kernel<D>, hipFuncAttributeMaxDynamicSharedMemorySize, FFN_LDS); (void)hipGetLastError(); } \
         hipLaunchKernelGGL(ffn_fused_bf16_kernel<D>, dim3(grid), dim3(512), FFN_LDS, (hipStream_t)stream, \
                            (const uint16_t*)X, (const uint16_t*)W1, b1, (const uint16_t*)W2, b2, gamma, beta, eps, (uint16_t*)Y, M, d_ff, (const float*)nullptr); \
     }
@@ -885,8 +884,8 @@ extern "C" int dtlr_box_mlp_refine_bf16(const void* X, const void* W1, const flo
     clear_stale_error();
     if (!X || !W1 || !b1 || !W2p || !b2 || !W3 || !b3 || !ref || !out) return DTLR_EINVAL;
     if (M <= 0 || (mode != 0 && mode != 1)) return DTLR_EINVAL;
-    static bool attr = false;
-    if (!attr) { (void)hipFuncSetAttribute((const void*)ffn_fused_bf16_kernel<0, true>, hipFuncAttributeMaxDynamicSharedMemorySize, FFN_LDS); (void)hipGetLastError(); attr = true; }
+    static DevOnce attr;
+    if (attr.first()) { (void)hipFuncSetAttribute((const void*)ffn_fused_bf16_kernel<0, true>, hipFuncAttributeMaxDynamicSharedMemorySize, FFN_LDS); (void)hipGetLastError(); }
     hipLaunchKernelGGL((ffn_fused_bf16_kernel<0, true>), dim3((unsigned)((M + 127) / 128)), dim3(512), FFN_LDS, (hipStream_t)stream,
                        (const uint16_t*)X, (const uint16_t*)W1, b1, (const uint16_t*)W2p, b2, W3, b3, (float)mode, (uint16_t*)out, M, 256, ref);
     return check_launch();
@@ -914,8 +913,8 @@ extern "C" int dtlr_proj_ln_bf16(const void* A, const void* W, const float* bias
     if (!A || !W || !bias || !R || !gamma || !beta || !Y) return DTLR_EINVAL;
     if (M <= 0) return DTLR_EINVAL;
     if (d_model != 256) return DTLR_ESHAPE;
-    static bool attr = false;
-    if (!attr) { (void)hipFuncSetAttribute((const void*)proj_ln_bf16_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, PLN_LDS); (void)hipGetLastError(); attr = true; }
+    static DevOnce attr;
+    if (attr.first()) { (void)hipFuncSetAttribute((const void*)proj_ln_bf16_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, PLN_LDS); (void)hipGetLastError(); }
     hipLaunchKernelGGL(proj_ln_bf16_kernel<false>, dim3((unsigned)((M + 63) / 64)), dim3(256), PLN_LDS, (hipStream_t)stream,
                        (const uint16_t*)A, (const uint16_t*)W, bias, (const uint16_t*)R, gamma, beta, eps, (uint16_t*)Y, M);
     return check_launch();
@@ -928,8 +927,8 @@ extern "C" int dtlr_proj_ln_split_bf16(const void* A, const void* W, const float
     if (!A || !W || !bias || !gamma || !beta || !Y3) return DTLR_EINVAL;
     if (M <= 0) return DTLR_EINVAL;
     if (d_model != 256) return DTLR_ESHAPE;
-    static bool attr = false;
-    if (!attr) { (void)hipFuncSetAttribute((const void*)proj_ln_bf16_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, PLN_LDS); (void)hipGetLastError(); attr = true; }
+    static DevOnce attr;
+    if (attr.first()) { (void)hipFuncSetAttribute((const void*)proj_ln_bf16_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, PLN_LDS); (void)hipGetLastError(); }
     hipLaunchKernelGGL(proj_ln_bf16_kernel<true>, dim3((unsigned)((M + 63) / 64)), dim3(256), PLN_LDS, (hipStream_t)stream,
                        (const uint16_t*)A, (const uint16_t*)W, bias, reinterpret_cast<const uint16_t*>(keep), gamma, beta, eps, (uint16_t*)Y3, M);
     return check_launch();

@@ -86,6 +86,7 @@ __device__ unsigned long long g_gemm_tl[TL_BLOCKS * 2 * TL_EVENTS];
 #endif
 
 enum : int { EPI_BIAS = 1, EPI_RELU = 2, EPI_RESIDUAL = 4, EPI_ROWMASK = 8, EPI_RELU_POST = 16,
+              EPI_ROWMAX = 32,      // C is NOT written: C[token] (fp32, M entries, pre-filled with -inf) <- max over channels of acc + bias
               DBG_NO_LOAD = 256, DBG_NO_MMA = 512, DBG_NO_LDS = 1024, DBG_NO_EPI = 2048, DBG_NO_STORE = 4096 };   // ablation switches (env DTLR_GEMM_ABLATE), timing only
 
 template <typename T> struct GT;
@@ -156,6 +157,42 @@ __device__ __forceinline__ void epilogue_tile(f32x4_t (&acc)[4][4], OutT* __rest
                                               int M, int N, int flags_rt, int tok0, int ch0 TL_PARAMS)
 {
     const int flags = CF >= 0 ? CF : flags_rt;
+    if constexpr (sizeof(OutT) == 4 && CF < 0) {
+        if (flags & EPI_ROWMAX) {
+            // Row-max epilogue (two-stage selection: torch.topk needs only max_c of the class head, deformable_transformer.py:345):
+            // a lane holds 16 channels of each of its 4 tokens; the token's other 48 channels of this sub-tile sit in the lanes
+            // g' != g (xor 16, 32).  One float atomic max per (token, 64-channel sub-tile) instead of a T x C fp32 matrix in HBM
+            // (6.4 GB per step for the 7356-class head at bs = 32) and a separate reduction pass.  max is order-independent, so the
+            // result is deterministic.  Float max through integer atomics: non-negative floats order like ints, negative ones
+            // in reverse as unsigned ints; the destination is pre-filled with -inf.
+            const int lane_ = (int)threadIdx.x & 63;
+#pragma unroll
+            for (int ti = 0; ti < 4; ++ti) {
+                const int tok = tok0 + ti * 16;
+                float mx = -__builtin_huge_valf();
+#pragma unroll
+                for (int ci = 0; ci < 4; ++ci) {
+                    const int ch = ch0 + ci * 16;
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        if (ch + r < N) {
+                            const float v = acc[ci][ti][r] + ((flags & EPI_BIAS) ? bias[ch + r] : 0.f);
+                            mx = fmaxf(mx, v);
+                        }
+                    }
+                    acc[ci][ti] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+                }
+                mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
+                mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+                if ((lane_ >> 4) == 0 && tok < M && mx > -__builtin_huge_valf()) {
+                    float* dst = reinterpret_cast<float*>(C) + tok;
+                    if (mx >= 0.f) atomicMax(reinterpret_cast<int*>(dst), __float_as_int(mx));
+                    else atomicMin(reinterpret_cast<unsigned int*>(dst), __float_as_uint(mx));
+                }
+            }
+            return;
+        }
+    }
     const bool vec_ok = (N & 3) == 0;
     // wave-uniform test (the whole 64x64 sub-tile is interior): the paired bf16 stores exchange data between lanes
     const int lane_ = (int)threadIdx.x & 63;
@@ -767,8 +804,8 @@ static int try_splitk(const void* A, const void* W, const float* bias, const voi
     float* ws = splitk_workspace((size_t)S * M * N * sizeof(float));
     if (!ws) return DTLR_OK;                                     // no workspace: fall back to the plain path
     const size_t lds = 4 * TILE_BYTES;
-    static bool attr = false;
-    if (!attr) { (void)hipFuncSetAttribute((const void*)gemm_ws_kernel<T, float, false, CONV>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); (void)hipGetLastError(); attr = true; }
+    static DevOnce attr;
+    if (attr.first()) { (void)hipFuncSetAttribute((const void*)gemm_ws_kernel<T, float, false, CONV>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); (void)hipGetLastError(); }
     const unsigned grid = (unsigned)(nN * nM * S);
     hipLaunchKernelGGL((gemm_ws_kernel<T, float, false, CONV>), dim3(grid), dim3(512), lds, st,
                        (const T*)A, (const T*)nullptr, (const T*)W, (const float*)nullptr, (const float*)nullptr, (const uint8_t*)nullptr, ws,
@@ -785,8 +822,8 @@ static int try_splitk(const void* A, const void* W, const float* bias, const voi
 // launch gemm_ws_kernel<T, OutT, A2, CONV, CF> (setting its dynamic-LDS attribute once)
 #define WS_LAUNCH(A2, CONV, CF, GRID, ...)                                                          \
     {                                                                                              \
-        static bool attr_ = false;                                                                 \
-        if (!attr_) { (void)hipFuncSetAttribute((const void*)gemm_ws_kernel<T, OutT, A2, CONV, CF>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); (void)hipGetLastError(); attr_ = true; } \
+        static DevOnce attr_;                                                                 \
+        if (attr_.first()) { (void)hipFuncSetAttribute((const void*)gemm_ws_kernel<T, OutT, A2, CONV, CF>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); (void)hipGetLastError(); } \
         hipLaunchKernelGGL((gemm_ws_kernel<T, OutT, A2, CONV, CF>), dim3(GRID), dim3(512), lds, st, __VA_ARGS__); \
     }
 // the flag sets that get a specialised epilogue (bf16 -> bf16 only; everything else runs the generic one)
@@ -800,8 +837,8 @@ static int launch_conv(const void* X, const void* W, const float* bias, const vo
     const long nwg = (long)nM * nN;
     if (nwg > 0x7fffffffL) return DTLR_ESHAPE;
     const size_t lds = 4 * TILE_BYTES;
-    static bool attr = false;
-    if (!attr) { (void)hipFuncSetAttribute((const void*)gemm_nt_kernel<T, OutT, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); attr = true; }
+    static DevOnce attr;
+    if (attr.first()) { (void)hipFuncSetAttribute((const void*)gemm_nt_kernel<T, OutT, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); }
     if (use_ws()) {
         bool done = false;
         const int rc = try_splitk<T, OutT, true>(X, W, bias, residual, nullptr, C, M, N, K, flags, cp, st, done);
@@ -836,7 +873,7 @@ static int launch_gemm(const void* A, const void* A2, const void* W, const float
     if (nwg > 0x7fffffffL) return DTLR_ESHAPE;
     const size_t lds = 4 * TILE_BYTES;
     if (use_ws()) {
-        if (!A2) {
+        if (!A2 && !(flags & EPI_ROWMAX)) {
             bool done = false;
             const int rc = try_splitk<T, OutT, false>(A, W, bias, residual, row_mask, C, M, N, K, flags, cp, st, done);
             if (rc != DTLR_OK || done) return rc;
@@ -864,13 +901,13 @@ static int launch_gemm(const void* A, const void* A2, const void* W, const float
     const int per = plan_chain(nwg);
     const unsigned grid = (unsigned)(nN * ((nM + per - 1) / per));
     if (A2) {
-        static bool attr_a2 = false;
-        if (!attr_a2) { (void)hipFuncSetAttribute((const void*)gemm_nt_kernel<T, OutT, true, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); attr_a2 = true; }
+        static DevOnce attr_a2;
+        if (attr_a2.first()) { (void)hipFuncSetAttribute((const void*)gemm_nt_kernel<T, OutT, true, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); }
         hipLaunchKernelGGL((gemm_nt_kernel<T, OutT, true, false>), dim3(grid), dim3(256), lds, st,
                            (const T*)A, (const T*)A2, (const T*)W, bias, (const OutT*)residual, row_mask, (OutT*)C, M, N, K, flags, nN, nM, per, cp);
     } else {
-        static bool attr = false;
-        if (!attr) { (void)hipFuncSetAttribute((const void*)gemm_nt_kernel<T, OutT, false, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); attr = true; }
+        static DevOnce attr;
+        if (attr.first()) { (void)hipFuncSetAttribute((const void*)gemm_nt_kernel<T, OutT, false, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); }
         hipLaunchKernelGGL((gemm_nt_kernel<T, OutT, false, false>), dim3(grid), dim3(256), lds, st,
                            (const T*)A, (const T*)nullptr, (const T*)W, bias, (const OutT*)residual, row_mask, (OutT*)C, M, N, K, flags, nN, nM, per, cp);
     }
@@ -904,6 +941,27 @@ extern "C" int dtlr_gemm_nt(const void* A, const void* A2, const void* W, const 
         if (K % 32) return DTLR_ESHAPE;
         if (out_dtype == DTLR_F32) return launch_gemm<float, float>(A, A2, W, bias, residual, row_mask, C, M, N, K, flags, st);
         return DTLR_EDTYPE;
+    }
+    return DTLR_EDTYPE;
+}
+
+// scores[m] = max_n ( A[m,:] . W[n,:] + bias[n] ): the GEMM above with the row-max epilogue; the [M, N] product never reaches HBM.
+extern "C" int dtlr_gemm_nt_rowmax(const void* A, const void* W, const float* bias, float* rowmax,
+                                   int M, int N, int K, int in_dtype, void* stream)
+{
+    clear_stale_error();
+    if (!A || !W || !rowmax) return DTLR_EINVAL;
+    if (M <= 0 || N <= 0 || K <= 0) return DTLR_EINVAL;
+    hipStream_t st = (hipStream_t)stream;
+    if (hipMemsetD32Async((hipDeviceptr_t)rowmax, (int)0xff800000u, (size_t)M, st) != hipSuccess) { g_last_hip_error = (int)hipGetLastError(); return DTLR_ELAUNCH; }
+    const int flags = (bias ? EPI_BIAS : 0) | EPI_ROWMAX;
+    if (in_dtype == DTLR_BF16) {
+        if (K % 64) return DTLR_ESHAPE;
+        return launch_gemm<uint16_t, float>(A, nullptr, W, bias, nullptr, nullptr, rowmax, M, N, K, flags, st);
+    }
+    if (in_dtype == DTLR_F32) {
+        if (K % 32) return DTLR_ESHAPE;
+        return launch_gemm<float, float>(A, nullptr, W, bias, nullptr, nullptr, rowmax, M, N, K, flags, st);
     }
     return DTLR_EDTYPE;
 }

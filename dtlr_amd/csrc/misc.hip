@@ -83,9 +83,73 @@ __global__ __launch_bounds__(256) void box_head_refine_kernel(const float* __res
     }
 }
 
+
+// Two-stage query selection, the gathers after the top-k (deformable_transformer.py:347-356; utils.py proposals): for every
+// selected token copy its output_memory row (bf16 engine: the [hi | lo | hi] image, 768 elements, plus bf16(hi + lo) as the box
+// MLP's input; fp32 engine: the 256 fp32 channels), its proposal logits, and sigmoid(proposal) (`init_box_proposal`, :355).
+// One wavefront per selected row; replaces two torch.gather launches, a slice-add, a cast and a sigmoid.
+template <bool SPLIT>
+__global__ __launch_bounds__(256) void two_stage_gather_kernel(const void* __restrict__ om, const float* __restrict__ proposals,
+                                                               const long* __restrict__ idx, void* __restrict__ sel_raw,
+                                                               uint16_t* __restrict__ sel_x, float* __restrict__ prop_sel,
+                                                               float* __restrict__ init_box, int S, int k, long rows)
+{
+    const int lane = threadIdx.x & 63;
+    const long r = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (r >= rows) return;
+    const long b = r / k;
+    const long src = b * S + idx[r];
+    if (SPLIT) {
+        const uint4* s4 = reinterpret_cast<const uint4*>(reinterpret_cast<const uint16_t*>(om) + src * 768);
+        uint4* d4 = reinterpret_cast<uint4*>(reinterpret_cast<uint16_t*>(sel_raw) + r * 768);
+        const uint4 a = s4[lane];                                  // chunks 0..63: hi (0..31) and lo (32..63)
+        d4[lane] = a;
+        if (lane < 32) d4[64 + lane] = s4[64 + lane];              // chunks 64..95: hi again
+        // lane < 32 holds hi[8 lane ..], lane + 32 holds lo[8 lane ..]
+        const uint32_t av[4] = {a.x, a.y, a.z, a.w};
+        uint32_t o[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const uint32_t lo = (uint32_t)__shfl(av[e], (lane & 31) + 32, 64);
+            const float x0 = __uint_as_float(av[e] << 16) + __uint_as_float(lo << 16);
+            const float x1 = __uint_as_float(av[e] & 0xffff0000u) + __uint_as_float(lo & 0xffff0000u);
+            o[e] = pack_bf16x2(x0, x1);
+        }
+        if (lane < 32) reinterpret_cast<uint4*>(sel_x + r * 256)[lane] = make_uint4(o[0], o[1], o[2], o[3]);
+    } else {
+        const float4* s4 = reinterpret_cast<const float4*>(reinterpret_cast<const float*>(om) + src * 256);
+        reinterpret_cast<float4*>(reinterpret_cast<float*>(sel_raw) + r * 256)[lane] = s4[lane];
+    }
+    if (lane == 0) {
+        const float4 p = *reinterpret_cast<const float4*>(proposals + src * 4);
+        *reinterpret_cast<float4*>(prop_sel + r * 4) = p;
+        *reinterpret_cast<float4*>(init_box + r * 4) = make_float4(1.f / (1.f + expf(-p.x)), 1.f / (1.f + expf(-p.y)),
+                                                                  1.f / (1.f + expf(-p.z)), 1.f / (1.f + expf(-p.w)));
+    }
+}
+
 }  // namespace dtlr
 
 using namespace dtlr;
+
+extern "C" int dtlr_two_stage_gather(const void* om, const float* proposals, const long* idx, void* sel_raw, void* sel_x,
+                                     float* prop_sel, float* init_box, int B, int S, int k, int dtype, void* stream)
+{
+    clear_stale_error();
+    if (!om || !proposals || !idx || !sel_raw || !prop_sel || !init_box) return DTLR_EINVAL;
+    if (B <= 0 || S <= 0 || k <= 0) return DTLR_EINVAL;
+    const long rows = (long)B * k;
+    const unsigned grid = (unsigned)((rows + 3) / 4);
+    if (dtype == DTLR_BF16) {
+        if (!sel_x) return DTLR_EINVAL;
+        hipLaunchKernelGGL(two_stage_gather_kernel<true>, dim3(grid), dim3(256), 0, (hipStream_t)stream, om, proposals, idx, sel_raw,
+                           (uint16_t*)sel_x, prop_sel, init_box, S, k, rows);
+    } else if (dtype == DTLR_F32) {
+        hipLaunchKernelGGL(two_stage_gather_kernel<false>, dim3(grid), dim3(256), 0, (hipStream_t)stream, om, proposals, idx, sel_raw,
+                           (uint16_t*)nullptr, prop_sel, init_box, S, k, rows);
+    } else return DTLR_EDTYPE;
+    return check_launch();
+}
 
 extern "C" int dtlr_box_head_refine(const float* h, const float* W, const float* bias, const float* ref, float* out,
                                     long rows, int hidden, int mode, void* stream)

@@ -467,8 +467,8 @@ static bool make_plan(const int* hw, int elem, int R, EncPlan& pl) {
 
 template <typename T, typename OT>
 static int launch_enc(const void* value, const void* ow, const float* ref, void* out, const EncPlan& pl, int N, int M, hipStream_t st) {
-    static bool attr = false;
-    if (!attr) { (void)hipFuncSetAttribute((const void*)msda_enc_lds_kernel<T, OT>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); attr = true; }
+    static DevOnce attr;
+    if (attr.first()) { (void)hipFuncSetAttribute((const void*)msda_enc_lds_kernel<T, OT>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); }
     hipLaunchKernelGGL((msda_enc_lds_kernel<T, OT>), dim3(pl.ntiles, M, N), dim3(256), pl.lds, st,
                        (const T*)value, (const OT*)ow, ref, (T*)out, pl.lv, pl.S, M, pl.TW0, pl.R);
     return check_launch();
@@ -477,6 +477,17 @@ static int launch_enc(const void* value, const void* ow, const float* ref, void*
 }  // namespace dtlr
 
 using namespace dtlr;
+
+// 1 when the LDS window plan of dtlr_msda_encoder_forward fits these level shapes (full-height column windows + halo of all four
+// levels within 160 KB), 0 when it does not (tall canvases: the caller then uses the gather kernel, dtlr_msda_fused_forward,
+// which has no size limit), negative on bad arguments.
+extern "C" int dtlr_msda_encoder_plan_ok(const int* level_hw, int dtype, int halo)
+{
+    if (!level_hw || halo < 0) return DTLR_EINVAL;
+    if (dtype != DTLR_F32 && dtype != DTLR_BF16) return DTLR_EDTYPE;
+    EncPlan pl;
+    return make_plan(level_hw, dtype == DTLR_F32 ? 4 : 2, halo, pl) ? 1 : 0;
+}
 
 extern "C" int dtlr_msda_encoder_forward(const void* value, const void* ow, const float* ref, const int* level_hw,
                                          int N, int M, int D, int L, int P, int halo,

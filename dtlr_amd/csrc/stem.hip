@@ -117,9 +117,87 @@ __global__ __launch_bounds__(512, 2) void stem_conv7x7_kernel(const float* __res
     }
 }
 
+
+// ---- exact-fp32 stem (the parity engine).  Direct convolution on the vector ALUs: 2 * 147 * 64 flop per output pixel is
+// 39 GFLOP for 32 lines of 128 x 2048 -- a millisecond at the fp32 vector rate; the fp32 MFMA (16x16x4) would need the taps
+// as 4-wide k-steps of one (ci, kh) row, i.e. the same LDS staging for a kernel only the fp32 parity path runs.
+// Workgroup = 8 x 32 output pixels of one image, one thread per pixel with all 64 channel accumulators in registers.
+// LDS: the input patch [3][21][72] fp32 (the 7x7/s2 footprint of the tile, zero outside the image) and the weights k-major
+// [147][64] fp32: the inner loop reads one patch value per lane and sixteen float4 weight broadcasts (same address in every
+// lane: conflict-free), 64 FMAs per 17 LDS reads.  A lane stores its 64 channels as 16 x 16 B (the NHWC pixel is 256 B).
+constexpr int SF_ROWS = 8, SF_COLS = 32;
+constexpr int SF_IN_ROWS = 2 * SF_ROWS + 5;                 // 21
+constexpr int SF_IN_COLS = 2 * SF_COLS + 5;                 // 69
+constexpr int SF_PITCH = 72;
+constexpr int SF_LDS = (3 * SF_IN_ROWS * SF_PITCH + 147 * 64) * 4;     // 55776 B
+
+__global__ __launch_bounds__(256) void stem_conv7x7_f32_kernel(const float* __restrict__ x, const float* __restrict__ wk,
+                                                               float* __restrict__ y, int H, int W, int Ho, int Wo)
+{
+    extern __shared__ __attribute__((aligned(16))) float sf_lds[];
+    float* patch = sf_lds;                                   // [3][21][72]
+    float* wl = sf_lds + 3 * SF_IN_ROWS * SF_PITCH;          // [147][64]
+    const int b = blockIdx.z;
+    const int oh0 = blockIdx.y * SF_ROWS, ow0 = blockIdx.x * SF_COLS;
+    const int ih0 = 2 * oh0 - 3, iw0 = 2 * ow0 - 3;
+    const float* xb = x + (long)b * 3 * H * W;
+    for (int i = threadIdx.x; i < 3 * SF_IN_ROWS * SF_IN_COLS; i += 256) {
+        const int c = i % SF_IN_COLS, r = (i / SF_IN_COLS) % SF_IN_ROWS, ci = i / (SF_IN_COLS * SF_IN_ROWS);
+        const int ih = ih0 + r, iw = iw0 + c;
+        float v = 0.f;
+        if (ih >= 0 && ih < H && iw >= 0 && iw < W) v = xb[((long)ci * H + ih) * W + iw];
+        patch[(ci * SF_IN_ROWS + r) * SF_PITCH + c] = v;
+    }
+    for (int i = threadIdx.x; i < 147 * 16; i += 256)
+        reinterpret_cast<float4*>(wl)[i] = reinterpret_cast<const float4*>(wk)[i];
+    __syncthreads();
+    const int pr = threadIdx.x / SF_COLS, pc = threadIdx.x % SF_COLS;
+    float acc[64];
+#pragma unroll
+    for (int c = 0; c < 64; ++c) acc[c] = 0.f;
+    for (int ci = 0; ci < 3; ++ci)
+        for (int kh = 0; kh < 7; ++kh) {
+            const float* prow = patch + (ci * SF_IN_ROWS + 2 * pr + kh) * SF_PITCH + 2 * pc;
+            const float* wrow = wl + ((ci * 7 + kh) * 7) * 64;
+#pragma unroll
+            for (int kw = 0; kw < 7; ++kw) {
+                const float xv = prow[kw];
+#pragma unroll
+                for (int c4 = 0; c4 < 16; ++c4) {
+                    const float4 w4 = *reinterpret_cast<const float4*>(wrow + kw * 64 + c4 * 4);
+                    acc[4 * c4 + 0] = fmaf(xv, w4.x, acc[4 * c4 + 0]);
+                    acc[4 * c4 + 1] = fmaf(xv, w4.y, acc[4 * c4 + 1]);
+                    acc[4 * c4 + 2] = fmaf(xv, w4.z, acc[4 * c4 + 2]);
+                    acc[4 * c4 + 3] = fmaf(xv, w4.w, acc[4 * c4 + 3]);
+                }
+            }
+        }
+    const int oh = oh0 + pr, ow = ow0 + pc;
+    if (oh < Ho && ow < Wo) {
+        float4* o = reinterpret_cast<float4*>(y + (((long)b * Ho + oh) * Wo + ow) * 64);
+#pragma unroll
+        for (int c4 = 0; c4 < 16; ++c4) o[c4] = make_float4(acc[4 * c4], acc[4 * c4 + 1], acc[4 * c4 + 2], acc[4 * c4 + 3]);
+    }
+}
+
 }  // namespace dtlr
 
 using namespace dtlr;
+
+// x [B,3,H,W] fp32 NCHW ; wk [147][64] fp32 (k = (ci*7 + kh)*7 + kw) ; y [B,Ho,Wo,64] fp32 NHWC
+extern "C" int dtlr_stem_conv7x7_f32(const float* x, const float* wk, float* y, int B, int H, int W, void* stream)
+{
+    clear_stale_error();
+    if (!x || !wk || !y) return DTLR_EINVAL;
+    if (B <= 0 || H <= 0 || W <= 0) return DTLR_EINVAL;
+    const int Ho = (H + 6 - 7) / 2 + 1, Wo = (W + 6 - 7) / 2 + 1;
+    static DevOnce attr;
+    if (attr.first()) { (void)hipFuncSetAttribute((const void*)stem_conv7x7_f32_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, SF_LDS); (void)hipGetLastError(); }
+    const dim3 grid((Wo + SF_COLS - 1) / SF_COLS, (Ho + SF_ROWS - 1) / SF_ROWS, B);
+    if (grid.y > 65535u || grid.z > 65535u) return DTLR_ESHAPE;
+    hipLaunchKernelGGL(stem_conv7x7_f32_kernel, grid, dim3(256), SF_LDS, (hipStream_t)stream, x, wk, y, H, W, Ho, Wo);
+    return check_launch();
+}
 
 // conv1.weight (BN scale folded) [64, 3, 7, 7] fp32 (host or device memory readable by the host is NOT assumed: this packs on
 // the host side from a host pointer) -> wfrag [4][6][64][8] bf16 as uint16 in host memory.
@@ -150,8 +228,8 @@ extern "C" int dtlr_stem_conv7x7(const float* x, const void* wfrag, void* y, int
     if (B <= 0 || H <= 0 || W <= 0) return DTLR_EINVAL;
     if (out_dtype != DTLR_BF16) return DTLR_EDTYPE;
     const int Ho = (H + 6 - 7) / 2 + 1, Wo = (W + 6 - 7) / 2 + 1;
-    static bool attr = false;
-    if (!attr) { (void)hipFuncSetAttribute((const void*)stem_conv7x7_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, STEM_LDS); (void)hipGetLastError(); attr = true; }
+    static DevOnce attr;
+    if (attr.first()) { (void)hipFuncSetAttribute((const void*)stem_conv7x7_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, STEM_LDS); (void)hipGetLastError(); }
     const dim3 grid((Wo + STEM_COLS - 1) / STEM_COLS, (Ho + STEM_ROWS - 1) / STEM_ROWS, B);
     hipLaunchKernelGGL(stem_conv7x7_kernel, grid, dim3(512), STEM_LDS, (hipStream_t)stream,
                        x, (const uint16_t*)wfrag, (uint16_t*)y, H, W, Ho, Wo);

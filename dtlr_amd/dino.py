@@ -290,11 +290,8 @@ class PostProcess(nn.Module):
         assert len(out_logits) == len(target_sizes)
         assert target_sizes.shape[1] == 2
         ops.require_cuda(out_logits, "pred_logits")                 # device-only, like the rest of the path
-        if num_select <= 1024:
-            # sigmoid + flat top-k in one HIP kernel (exact radix select on the logits: sigmoid is monotone)
-            topk_values, topk_indexes = ops.topk_flat(out_logits.reshape(out_logits.shape[0], -1), num_select, apply_sigmoid=True)
-        else:                                                      # beyond the kernel's 1024-key sort: torch (ops.LIBRARY_BACKED)
-            topk_values, topk_indexes = torch.topk(out_logits.sigmoid().view(out_logits.shape[0], -1), num_select, dim=1)
+        # sigmoid + flat top-k in one HIP kernel (exact radix select on the logits: sigmoid is monotone); num_select <= 8192
+        topk_values, topk_indexes = ops.topk_flat(out_logits.reshape(out_logits.shape[0], -1), num_select, apply_sigmoid=True)
         scores = topk_values
         topk_boxes = topk_indexes // out_logits.shape[2]
         labels = topk_indexes % out_logits.shape[2]

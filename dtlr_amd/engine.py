@@ -46,6 +46,7 @@ class DTLREngine:
         self.w: Dict[str, torch.Tensor] = {}
         self._pack(state_dict)
         self._shape_cache: Dict[tuple, dict] = {}
+        self._level_cache: Dict[tuple, tuple] = {}
         self.use_lds_msda = True       # encoder MSDA with LDS-staged windows (False: gather kernel)
         self.use_fused_ffn = True      # bf16: linear1+ReLU+linear2+residual+LayerNorm in one kernel (False: two GEMMs + LN)
 
@@ -59,8 +60,8 @@ class DTLREngine:
             self.w[name + ".w"] = w.flatten(1).to(device=self.device, dtype=self.dtype).contiguous()
         elif (w.shape[1] * elem) % 128 == 0:         # implicit-GEMM HIP kernel: [Cout, KH, KW, Cin]
             self.w[name + ".w"] = w.permute(0, 2, 3, 1).to(device=self.device, dtype=self.dtype).contiguous()
-        else:                                        # 3-channel 7x7 stem: MIOpen, OIHW channels_last
-            self.w[name + ".w"] = w.to(device=self.device, dtype=self.dtype).contiguous(memory_format=torch.channels_last)
+        else:
+            raise ValueError(f"_put_conv({name}): Cin = {w.shape[1]} does not fit the implicit-GEMM kernel (the stem has its own)")
         self.w[name + ".b"] = b.to(device=self.device, dtype=torch.float32).contiguous()
 
     def _put_linear(self, name, w, b):
@@ -71,9 +72,11 @@ class DTLREngine:
         cfg, f32 = self.cfg, torch.float32
         b = "backbone.0.body."
         w1, b1 = _fold_bn(sd, b + "conv1.weight", b + "bn1")
-        self._put_conv("conv1", w1, b1)
-        if self.dtype == torch.bfloat16:               # bf16 engine: own MFMA stem kernel, weights as a fragment image
+        self.w["conv1.b"] = b1.to(device=self.device, dtype=torch.float32).contiguous()
+        if self.dtype == torch.bfloat16:               # bf16 engine: MFMA stem kernel, weights as a fragment image in registers
             self.w["conv1.frag"] = ops.stem_pack_weights(w1).to(self.device)
+        else:                                          # fp32 engine: exact-fp32 direct-convolution stem kernel, k-major weights
+            self.w["conv1.wk"] = ops.stem_pack_weights_f32(w1).to(self.device)
         for li, nblocks in enumerate(cfg.backbone_blocks, start=1):
             for bi in range(nblocks):
                 p = f"{b}layer{li}.{bi}."
@@ -201,15 +204,15 @@ class DTLREngine:
         h = self._lin(q + "ff1", x, relu=True)
         return self._ln(q + norm, self._lin(q + "ff2", h), residual=x)
 
-    def backbone(self, x_nhwc, x_nchw=None) -> List[torch.Tensor]:
+    def backbone(self, x_nchw) -> List[torch.Tensor]:
         """torchvision resnet50 (v1.5) body with FrozenBN folded; returns layer2/3/4 maps, NHWC
         (models/dino/backbone.py:97-106,118-120)."""
-        # stem: the 3-channel 7x7 convolution is the one library-backed GEMM-class op (MIOpen); its folded-BN shift,
-        # the ReLU and the max-pool run as ONE pass of our kernel over the full-resolution map
-        if "conv1.frag" in self.w and x_nchw is not None:
-            x = ops.stem_conv7x7(x_nchw, self.w["conv1.frag"])          # reads the NCHW fp32 image directly
+        # stem: own kernels for both engines, reading the NCHW fp32 image directly (bf16: MFMA; fp32: exact direct convolution);
+        # the folded-BN shift, the ReLU and the max-pool run as ONE pass over the full-resolution map
+        if "conv1.frag" in self.w:
+            x = ops.stem_conv7x7(x_nchw, self.w["conv1.frag"])
         else:
-            x = ops.conv2d_nhwc(x_nhwc, self.w["conv1.w"], None, 2, 3, relu=False)
+            x = ops.stem_conv7x7_f32(x_nchw, self.w["conv1.wk"])
         x = ops.maxpool_nhwc(x, bias=self.w["conv1.b"], relu=True)
         outs = []
         for li, nblocks in enumerate(self.cfg.backbone_blocks, start=1):
@@ -224,76 +227,21 @@ class DTLREngine:
                 outs.append(x)
         return outs
 
-    @staticmethod
-    def _nearest_mask(mask, h, w):
-        """F.interpolate(mask[None].float(), size=(h,w)).bool() (backbone.py:103, dino.py:304-307):
-        nearest, source index = min(floor(dst * float(in)/out), in-1) in fp32 like ATen."""
-        B, H, W = mask.shape
-        dev = mask.device
-        iy = (torch.arange(h, device=dev, dtype=torch.float32) * (float(H) / h)).floor().long().clamp_(max=H - 1)
-        ix = (torch.arange(w, device=dev, dtype=torch.float32) * (float(W) / w)).floor().long().clamp_(max=W - 1)
-        return mask[:, iy][:, :, ix]
-
-    def _pos_embed(self, mask):
-        """PositionEmbeddingSineHW (position_encoding.py:79-108) -> [B, h*w, 256] tokens, fp32."""
-        cfg = self.cfg
-        npf = cfg.hidden_dim // 2
-        not_mask = ~mask
-        y_embed = not_mask.cumsum(1, dtype=torch.float32)
-        x_embed = not_mask.cumsum(2, dtype=torch.float32)
-        eps, scale = 1e-6, 2 * math.pi
-        y_embed = y_embed / (y_embed[:, -1:, :] + eps) * scale
-        x_embed = x_embed / (x_embed[:, :, -1:] + eps) * scale
-        i = torch.arange(npf, dtype=torch.float32, device=mask.device)
-        dim_tx = cfg.pe_temperatureW ** (2 * torch.div(i, 2, rounding_mode="floor") / npf)
-        dim_ty = cfg.pe_temperatureH ** (2 * torch.div(i, 2, rounding_mode="floor") / npf)
-        px = x_embed[..., None] / dim_tx
-        py = y_embed[..., None] / dim_ty
-        px = torch.stack((px[..., 0::2].sin(), px[..., 1::2].cos()), dim=4).flatten(3)
-        py = torch.stack((py[..., 0::2].sin(), py[..., 1::2].cos()), dim=4).flatten(3)
-        return torch.cat((py, px), dim=3).flatten(1, 2)              # already NHWC -> tokens
-
     def _geometry(self, mask, level_hw, has_padding=True):
-        """Everything that depends only on the padding masks (computed once per forward):
-        per-level masks, pos+level embeds, valid ratios, encoder reference points, proposals."""
+        """Everything that depends only on the padding masks, ONE HIP launch per forward (ops.geometry): per-level masks
+        (backbone.py:103, dino.py:304-307), pos + level embeds (position_encoding.py:79-108, deformable_transformer.py:281-285),
+        valid ratios (:239-246), encoder reference points (:479-492), proposals and their validity (models/dino/utils.py:31-62)."""
         cfg, dev = self.cfg, mask.device
-        B = mask.shape[0]
-        masks = [self._nearest_mask(mask, h, w) for (h, w) in level_hw]
-        pos = torch.cat([self._pos_embed(m) + self.w["level_embed"][l].view(1, 1, -1) for l, m in enumerate(masks)], 1)
-        mask_flat = torch.cat([m.flatten(1) for m in masks], 1)
-        # valid ratios (deformable_transformer.py:239-246) -> (w, h)
-        vr = torch.stack([torch.stack([(~m[:, 0, :]).sum(1).float() / m.shape[2], (~m[:, :, 0]).sum(1).float() / m.shape[1]], -1)
-                          for m in masks], 1)                         # [B, L, 2]
-        # encoder reference points (deformable_transformer.py:479-492)
-        refs, props = [], []
-        for l, ((h, w), m) in enumerate(zip(level_hw, masks)):
-            ys = torch.linspace(0.5, h - 0.5, h, dtype=torch.float32, device=dev)
-            xs = torch.linspace(0.5, w - 0.5, w, dtype=torch.float32, device=dev)
-            ry, rx = torch.meshgrid(ys, xs, indexing="ij")
-            ry = ry.reshape(-1)[None] / (vr[:, None, l, 1] * h)
-            rx = rx.reshape(-1)[None] / (vr[:, None, l, 0] * w)
-            refs.append(torch.stack((rx, ry), -1))
-            # proposals (models/dino/utils.py:31-49)
-            valid_h = (~m[:, :, 0]).sum(1)
-            valid_w = (~m[:, 0, :]).sum(1)
-            gy, gx = torch.meshgrid(torch.linspace(0, h - 1, h, dtype=torch.float32, device=dev),
-                                    torch.linspace(0, w - 1, w, dtype=torch.float32, device=dev), indexing="ij")
-            grid = torch.stack([gx, gy], -1)[None].expand(B, -1, -1, -1)
-            sc = torch.stack([valid_w, valid_h], 1).view(B, 1, 1, 2)
-            grid = (grid + 0.5) / sc
-            wh = torch.ones_like(grid) * 0.05 * (2.0 ** l)
-            props.append(torch.cat((grid, wh), -1).view(B, -1, 4))
-        ref = torch.cat(refs, 1)[:, :, None] * vr[:, None]             # [B, S, L, 2]
-        prop = torch.cat(props, 1)
-        valid = ((prop > 0.01) & (prop < 0.99)).all(-1, keepdim=True)
-        prop = torch.log(prop / (1 - prop))
-        prop = prop.masked_fill(mask_flat.unsqueeze(-1), float("inf")).masked_fill(~valid, float("inf"))
-        keep = (~mask_flat.unsqueeze(-1)) & valid                     # rows of memory that survive (utils.py:60-62)
-        shapes = torch.as_tensor(level_hw, dtype=torch.long, device=dev)
-        lsi = torch.cat((shapes.new_zeros((1,)), shapes.prod(1).cumsum(0)[:-1]))
-        return dict(masks=masks, pos=pos, mask_flat=mask_flat, valid_ratios=vr, enc_ref=ref.contiguous(),
-                    proposals=prop, keep=keep, shapes=shapes, lsi=lsi, has_padding=has_padding,
-                    level_hw=[(int(h), int(w)) for h, w in level_hw])
+        level_hw = [(int(h), int(w)) for h, w in level_hw]
+        g = ops.geometry(mask, level_hw, self.w["level_embed"], cfg.pe_temperatureH, cfg.pe_temperatureW, self.dtype)
+        key = (dev, tuple(level_hw))
+        if key not in self._level_cache:                              # int64 shapes / level starts for the B1 operator: once per shape
+            shapes = torch.as_tensor(level_hw, dtype=torch.long, device=dev)
+            lsi = torch.cat((shapes.new_zeros((1,)), shapes.prod(1).cumsum(0)[:-1]))
+            self._level_cache[key] = (shapes, lsi, ops.msda_encoder_fits(level_hw, self.dtype))
+        shapes, lsi, fits = self._level_cache[key]
+        g.update(shapes=shapes, lsi=lsi, has_padding=has_padding, level_hw=level_hw, lds_msda_fits=fits)
+        return g
 
     def _msda_module(self, name, query, query_pos, ref, value_src, g, n_points, value=None):
         """MSDeformAttn.forward (ops/modules/ms_deform_attn.py:78-126) without the output
@@ -309,7 +257,7 @@ class DTLREngine:
         # moves a sampling point by < 0.02 px, far below the bf16 noise of the sampled values themselves
         ow = self._lin(name + ".ow", query, a2=query_pos)
         if L == 4 and P == 4:
-            if Lq == S and ref.shape[-1] == 2 and C // M == 32 and self.use_lds_msda:      # encoder self-attention
+            if Lq == S and ref.shape[-1] == 2 and C // M == 32 and self.use_lds_msda and g["lds_msda_fits"]:   # encoder self-attention
                 return ops.msda_encoder(value.view(B, S, M, C // M), g["level_hw"], ow, ref)
             return ops.msda_fused(value.unflatten(-1, (M, C // M)), g["shapes"], g["lsi"], ow, ref)
         ow = ow.float()
@@ -325,7 +273,7 @@ class DTLREngine:
     def encoder(self, src, g):
         """TransformerEncoder.forward + DeformableTransformerEncoderLayer.forward
         (deformable_transformer.py:494-580, 804-823)."""
-        pos = g["pos"].to(src.dtype).contiguous()
+        pos = g["pos"]                                   # already in the engine dtype, level_embed added
         for n in range(self.cfg.enc_layers):
             q = f"enc{n}."
             a = self._msda_module(q + "attn", src, pos, g["enc_ref"], src, g, self.cfg.enc_n_points)
@@ -346,24 +294,22 @@ class DTLREngine:
             if "enc_output.wp" not in w:
                 w["enc_output.wp"] = ops.proj_pack_w(w["enc_output.w"])
                 w["enc_class.w3"], w["enc_class.b3"] = ops.split_head_weight(w["enc_class.w"], w["enc_class.b"])
-            om3 = ops.proj_ln_split(memory, w["enc_output.wp"], w["enc_output.b"], g["keep"], w["enc_output_norm.w"], w["enc_output_norm.b"])
-            scores = ops.linear(om3, w["enc_class.w3"], w["enc_class.b3"], out_dtype=torch.float32).max(-1)[0]
-            idx = ops.topk_rows(scores, cfg.num_queries) if forced_topk is None else forced_topk
-            sel3 = torch.gather(om3, 1, idx.unsqueeze(-1).expand(-1, -1, 768))
-            sel = sel3[..., :256].float() + sel3[..., 256:512].float()
+            om = ops.proj_ln_split(memory, w["enc_output.wp"], w["enc_output.b"], g["keep"], w["enc_output_norm.w"], w["enc_output_norm.b"])
+            # only max_c of the class head feeds the top-k: the GEMM's row-max epilogue (no [T, C] matrix, no reduction pass)
+            scores = ops.linear_rowmax(om, w["enc_class.w3"], w["enc_class.b3"])
         else:
-            sel3 = None
-            om = memory * g["keep"].to(memory.dtype)
+            om = memory * g["keep"].unsqueeze(-1).to(memory.dtype)
             # selection scores are computed in fp32: the projection writes fp32 straight from its accumulators
             om = self._ln("enc_output_norm", self._lin("enc_output", om, out_dtype=torch.float32))
-            scores = ops.linear(om, w["enc_class.w"], w["enc_class.b"]).max(-1)[0]
-            idx = ops.topk_rows(scores, cfg.num_queries) if forced_topk is None else forced_topk
-            sel = torch.gather(om, 1, idx.unsqueeze(-1).expand(-1, -1, cfg.hidden_dim))
-        prop_sel = torch.gather(g["proposals"], 1, idx.unsqueeze(-1).expand(-1, -1, 4))
-        ref_unsig = self._box_mlp("enc_bbox", sel, prop_sel, mode=1)
-        ts = dict(topk_idx=idx, topk_scores=scores, ref_unsig=ref_unsig, hs_enc=sel, init_box=prop_sel.sigmoid())
-        if sel3 is not None:
-            ts["hs_enc3"] = sel3
+            scores = ops.linear_rowmax(om, w["enc_class.w"], w["enc_class.b"])
+        idx = ops.topk_rows(scores, cfg.num_queries) if forced_topk is None else forced_topk
+        sel_raw, sel_x, prop_sel, init_box = ops.two_stage_gather(om, g["proposals"], idx)      # one launch for all the gathers
+        ref_unsig = self._box_mlp("enc_bbox", sel_raw if sel_x is None else sel_x, prop_sel, mode=1)
+        ts = dict(topk_idx=idx, topk_scores=scores, ref_unsig=ref_unsig, init_box=init_box)
+        if sel_x is None:
+            ts["hs_enc"] = sel_raw
+        else:
+            ts["hs_enc3"] = sel_raw
         return ts
 
     @staticmethod
@@ -407,7 +353,6 @@ class DTLREngine:
         (deformable_transformer.py:652-766, 882-997), batch-first."""
         cfg = self.cfg
         B = memory.shape[0]
-        vr4 = torch.cat([g["valid_ratios"], g["valid_ratios"]], -1)      # [B, L, 4]
         ref = ts["ref_unsig"].sigmoid()
         refs = [ref]
         tgt = self.w["tgt_embed"][None].expand(B, -1, -1).contiguous()
@@ -449,10 +394,7 @@ class DTLREngine:
         ops.require_cuda(x, "images")
         cfg = self.cfg
         B = x.shape[0]
-        if "conv1.frag" in self.w:
-            feats = self.backbone(None, x_nchw=x.float())
-        else:
-            feats = self.backbone(x.to(self.dtype).permute(0, 2, 3, 1).contiguous())
+        feats = self.backbone(x.float())
         level_hw = [(f.shape[1], f.shape[2]) for f in feats]
         last = self._conv(f"ip{len(feats)}", feats[-1], 2, 1)
         level_hw.append((last.shape[1], last.shape[2]))
@@ -487,7 +429,7 @@ class DTLREngine:
             out["aux_outputs"] = [{"pred_logits": self._class_head(hs[i]), "pred_boxes": self._refine(hs[i], refs[i])}
                                   for i in range(n)]
         if "hs_enc3" in ts:                                        # bf16 engine: the two-stage head on its split images
-            C = self.num_classes
+            C = int(self.w["enc_class.w"].shape[0])     # the two-stage head's OWN class count (--fix_enc_out_class keeps the old one)
             interm_class = ops.linear(ts["hs_enc3"], self.w["enc_class.w3"][:C], self.w["enc_class.b3"][:C], out_dtype=torch.float32)
         else:
             interm_class = ops.linear(ts["hs_enc"], self.w["enc_class.w"], self.w["enc_class.b"])

@@ -18,8 +18,10 @@ import torch.nn.functional as F
 from . import MultiScaleDeformableAttention as _msda
 from . import _lib
 
-# operators still served by ROCm libraries via torch (shrinks as kernels land)
-LIBRARY_BACKED = {"conv2d_nhwc(7x7 stem, fp32 engine only)", "postprocess topk when num_select > 1024 (torch.topk)"}
+# Operators served by ROCm libraries through torch: NONE.  Every GEMM / convolution / selection of the path runs a kernel of
+# libdtlr_hip.so; a shape a kernel does not take RAISES (DTLRError) instead of silently dropping to hipBLASLt / MIOpen, so a
+# checkpoint with an unusual head size can never bench on a library without anyone noticing.  bench.py prints this set.
+LIBRARY_BACKED: set = set()
 
 _DT = {torch.float32: _lib.DTLR_F32, torch.bfloat16: _lib.DTLR_BF16, torch.float64: _lib.DTLR_F64}
 
@@ -91,18 +93,50 @@ def linear(x, w, b=None, relu=False, residual=None, a2=None, row_mask=None, out_
                                            M, N, K, int(relu), _DT[x.dtype], _DT[out_dtype], _lib.current_stream())
         _lib.check(code, "dtlr_gemm_nt")
         return y
-    if a2 is not None:
-        x = x + a2
-    y = F.linear(x, w, None if b is None else b.to(x.dtype))
-    if int(relu) == 1:
-        y = F.relu(y, inplace=True)
-    if row_mask is not None:
-        y = y.masked_fill(row_mask[..., None], 0.0)
-    if residual is not None:
-        y = y + residual
-    if int(relu) == 2:
-        y = F.relu(y, inplace=True)
-    return y.to(out_dtype)
+    raise _lib.DTLRError(f"ops.linear: no HIP kernel for x {tuple(x.shape)} {x.dtype} @ w {tuple(w.shape)} {w.dtype} -> {out_dtype} "
+                         f"(K must be a multiple of {slab} elements; fp32 operands give fp32 results); there is no library fallback")
+
+
+def linear_rowmax(x, w, b=None):
+    """max over the output channels of (x @ w.T + b), without materialising the product (dtlr_gemm_nt_rowmax: the GEMM's
+    row-max epilogue): x [..., K], w [N, K] (same dtype, bf16 or fp32), b [N] fp32 -> [...] fp32.  The two-stage selection
+    only needs this maximum of the class head (deformable_transformer.py:341-345)."""
+    require_cuda(x, "x")
+    K, N = x.shape[-1], w.shape[0]
+    slab = 64 if x.dtype == torch.bfloat16 else 32
+    if x.dtype not in (torch.bfloat16, torch.float32) or w.dtype != x.dtype or K % slab:
+        raise _lib.DTLRError(f"ops.linear_rowmax: no HIP kernel for x {tuple(x.shape)} {x.dtype} @ w {tuple(w.shape)} {w.dtype}")
+    x = x if x.is_contiguous() else x.contiguous()
+    M = x.numel() // K
+    out = torch.empty(x.shape[:-1], dtype=torch.float32, device=x.device)
+    es = x.element_size()
+    with _Timed("gemm_bf16" if x.dtype == torch.bfloat16 else "gemm_f32", 2.0 * M * N * K, float(M) * K * es + float(N) * K * es + 4.0 * M):
+        code = _lib.lib().dtlr_gemm_nt_rowmax(x.data_ptr(), w.data_ptr(), 0 if b is None else b.data_ptr(), out.data_ptr(),
+                                              M, N, K, _DT[x.dtype], _lib.current_stream())
+    _lib.check(code, "dtlr_gemm_nt_rowmax")
+    return out
+
+
+def two_stage_gather(om, proposals, idx):
+    """The gathers after the two-stage top-k in one launch (dtlr_two_stage_gather).  om [B,S,768] bf16 ([hi|lo|hi]) or [B,S,256]
+    fp32; proposals [B,S,4] fp32; idx [B,k] int64 -> (sel_raw like om with S -> k, sel_x [B,k,256] bf16 = bf16(hi+lo) or None,
+    prop_sel [B,k,4], init_box [B,k,4] = sigmoid(prop_sel))."""
+    require_cuda(om, "om")
+    B, S, Wd = om.shape
+    k = idx.shape[1]
+    split = om.dtype == torch.bfloat16
+    assert (split and Wd == 768) or (om.dtype == torch.float32 and Wd == 256), "om: [B,S,768] bf16 or [B,S,256] fp32"
+    assert om.is_contiguous() and proposals.is_contiguous() and proposals.dtype == torch.float32 and idx.dtype == torch.int64
+    idx = idx if idx.is_contiguous() else idx.contiguous()
+    sel_raw = torch.empty((B, k, Wd), dtype=om.dtype, device=om.device)
+    sel_x = torch.empty((B, k, 256), dtype=torch.bfloat16, device=om.device) if split else None
+    prop_sel = torch.empty((B, k, 4), dtype=torch.float32, device=om.device)
+    init_box = torch.empty((B, k, 4), dtype=torch.float32, device=om.device)
+    code = _lib.lib().dtlr_two_stage_gather(om.data_ptr(), proposals.data_ptr(), idx.data_ptr(), sel_raw.data_ptr(),
+                                            None if sel_x is None else sel_x.data_ptr(), prop_sel.data_ptr(), init_box.data_ptr(),
+                                            B, S, k, _DT[om.dtype], _lib.current_stream())
+    _lib.check(code, "dtlr_two_stage_gather")
+    return sel_raw, sel_x, prop_sel, init_box
 
 
 def layernorm(x, w, b, eps: float = 1e-5, residual=None):
@@ -217,8 +251,8 @@ def ffn_fused(x, w1, b1, w2p, b2, ln_w, ln_b, eps: float = 1e-5):
 def conv2d_nhwc(x, w, bias, stride: int, padding: int, relu=False, residual=None):
     """NHWC convolution + folded-BN bias [+ residual] [+ ReLU].  x [B,H,W,Cin] contiguous.
     w: [Cout,KH,KW,Cin] contiguous ("OHWI") -> the implicit-GEMM HIP kernel (dtlr_conv2d_nhwc), which
-    needs Cin*elem % 128 == 0; otherwise w is an OIHW channels_last tensor for the MIOpen path (the
-    3-channel 7x7 stem).  relu: False/0, True/2 = ReLU after the residual add (bottleneck tail)."""
+    needs Cin*elem % 128 == 0 (anything else raises: the 3-channel 7x7 stem has its own kernels).
+    relu: False/0, True/2 = ReLU after the residual add (bottleneck tail)."""
     if w.dim() == 4 and w.is_contiguous() and w.shape[3] == x.shape[3] and (x.shape[3] * x.element_size()) % 128 == 0:
         B, H, W, Cin = x.shape
         Cout, KH, KW, _ = w.shape
@@ -236,13 +270,9 @@ def conv2d_nhwc(x, w, bias, stride: int, padding: int, relu=False, residual=None
                                                _DT[x.dtype], _lib.current_stream())
         _lib.check(code, "dtlr_conv2d_nhwc")
         return y
-    y = F.conv2d(x.permute(0, 3, 1, 2), w, None if bias is None else bias.to(x.dtype), stride=stride, padding=padding)
-    y = y.permute(0, 2, 3, 1)
-    if residual is not None:
-        y = y + residual
-    if relu:
-        y = F.relu(y, inplace=True)
-    return y.contiguous()
+    raise _lib.DTLRError(f"ops.conv2d_nhwc: no HIP kernel for x {tuple(x.shape)} {x.dtype}, w {tuple(w.shape)} (weights must be "
+                         "[Cout,KH,KW,Cin] contiguous with Cin * element size a multiple of 128 bytes; the 3-channel stem has its "
+                         "own kernels: stem_conv7x7 / stem_conv7x7_f32); there is no library fallback")
 
 
 def stem_pack_weights(w_oihw):
@@ -255,6 +285,27 @@ def stem_pack_weights(w_oihw):
     code = _lib.lib().dtlr_stem_pack_weights(w.ctypes.data, out.ctypes.data)
     _lib.check(code, "dtlr_stem_pack_weights")
     return torch.from_numpy(out.view(np.int16)).clone()
+
+
+def stem_pack_weights_f32(w_oihw):
+    """conv1.weight (FrozenBN scale folded) [64,3,7,7] -> the k-major fp32 image [147, 64] (k = (ci*7 + kh)*7 + kw) the fp32 stem
+    kernel keeps in LDS."""
+    assert tuple(w_oihw.shape) == (64, 3, 7, 7)
+    return w_oihw.detach().float().reshape(64, 147).t().contiguous()
+
+
+def stem_conv7x7_f32(x_nchw, wk):
+    """ResNet stem 7x7/s2/p3 convolution 3 -> 64 in exact fp32 (the parity engine; HIP kernel dtlr_stem_conv7x7_f32, direct
+    convolution on the vector ALUs with the patch and the weights in LDS): x [B,3,H,W] fp32 NCHW -> [B,Ho,Wo,64] fp32 NHWC, no
+    bias (the max-pool pass applies the folded-BN shift + ReLU)."""
+    require_cuda(x_nchw, "images")
+    assert x_nchw.dtype == torch.float32 and x_nchw.dim() == 4 and x_nchw.shape[1] == 3 and tuple(wk.shape) == (147, 64)
+    x = x_nchw if x_nchw.is_contiguous() else x_nchw.contiguous()
+    B, _, H, W = x.shape
+    y = torch.empty((B, (H - 1) // 2 + 1, (W - 1) // 2 + 1, 64), dtype=torch.float32, device=x.device)
+    code = _lib.lib().dtlr_stem_conv7x7_f32(x.data_ptr(), wk.data_ptr(), y.data_ptr(), B, H, W, _lib.current_stream())
+    _lib.check(code, "dtlr_stem_conv7x7_f32")
+    return y
 
 
 def stem_conv7x7(x_nchw, wfrag):
@@ -345,6 +396,50 @@ def msda_fused(value, spatial_shapes, level_start_index, ow, ref):
 
 
 MSDA_HALO = int(__import__("os").environ.get("DTLR_MSDA_HALO", "8"))
+
+
+_POS_TABLES = {}
+
+
+def geometry(mask, level_hw, level_embed, temperature_h: float, temperature_w: float, pos_dtype):
+    """Everything that depends only on the padding mask, in one launch (dtlr_geometry): per-level masks, valid ratios,
+    sine position embedding + level embedding, encoder reference points, proposals and their validity.
+    mask [B,H,W] bool (True = padding); level_hw: host list of 4 (H_l, W_l); level_embed [4,256] fp32.
+    -> dict(mask_flat [B,S] bool, keep [B,S] bool, pos [B,S,256] pos_dtype, valid_ratios [B,4,2], enc_ref [B,S,4,2], proposals [B,S,4])."""
+    require_cuda(mask, "mask")
+    assert mask.dtype == torch.bool and mask.dim() == 3 and len(level_hw) == 4
+    mask = mask if mask.is_contiguous() else mask.contiguous()
+    B, H, W = mask.shape
+    dev = mask.device
+    key = (dev, float(temperature_h), float(temperature_w))
+    if key not in _POS_TABLES:      # the exact tables PositionEmbeddingSineHW builds (position_encoding.py:95-98), once per device
+        i = torch.arange(128, dtype=torch.float32, device=dev)
+        e = 2 * torch.div(i, 2, rounding_mode="floor") / 128
+        _POS_TABLES[key] = ((temperature_h ** e).contiguous(), (temperature_w ** e).contiguous())
+    dim_ty, dim_tx = _POS_TABLES[key]
+    S = sum(int(h) * int(w) for h, w in level_hw)
+    hw = (ctypes.c_int * 8)(*[int(v) for pair in level_hw for v in pair])
+    mask_flat = torch.empty((B, S), dtype=torch.bool, device=dev)
+    keep = torch.empty((B, S), dtype=torch.bool, device=dev)
+    pos = torch.empty((B, S, 256), dtype=pos_dtype, device=dev)
+    vr = torch.empty((B, 4, 2), dtype=torch.float32, device=dev)
+    enc_ref = torch.empty((B, S, 4, 2), dtype=torch.float32, device=dev)
+    prop = torch.empty((B, S, 4), dtype=torch.float32, device=dev)
+    code = _lib.lib().dtlr_geometry(mask.data_ptr(), B, H, W, ctypes.cast(hw, ctypes.c_void_p), level_embed.data_ptr(),
+                                    dim_ty.data_ptr(), dim_tx.data_ptr(), _DT[pos_dtype], mask_flat.data_ptr(), keep.data_ptr(),
+                                    pos.data_ptr(), vr.data_ptr(), enc_ref.data_ptr(), prop.data_ptr(), _lib.current_stream())
+    _lib.check(code, "dtlr_geometry")
+    return dict(mask_flat=mask_flat, keep=keep, pos=pos, valid_ratios=vr, enc_ref=enc_ref, proposals=prop)
+
+
+def msda_encoder_fits(level_hw, dtype) -> bool:
+    """Whether the LDS-window encoder kernel's plan fits these level shapes (it stages full-height column windows: canvases
+    taller than ~270 px in fp32 / ~550 px in bf16 do not fit, and the caller uses msda_fused, the gather kernel, instead)."""
+    hw = (ctypes.c_int * 8)(*[int(v) for pair in level_hw for v in pair])
+    rc = _lib.lib().dtlr_msda_encoder_plan_ok(ctypes.cast(hw, ctypes.c_void_p), _DT[dtype], MSDA_HALO)
+    if rc < 0:
+        _lib.check(rc, "dtlr_msda_encoder_plan_ok")
+    return rc == 1
 
 
 def msda_encoder(value, level_hw, ow, ref):
@@ -527,7 +622,7 @@ def nms_batched(boxes, scores, iou_threshold: float):
 
 def topk_flat(x, k: int, apply_sigmoid: bool = False):
     """Per-row top-k of a long [B, n] fp32 matrix (dtlr_topk_flat: exact radix select over the row in global memory + a 1024-key sort):
-    -> (values [B,k] fp32 descending, indices [B,k] int64; equal values: lower index first).  k <= 1024."""
+    -> (values [B,k] fp32 descending, indices [B,k] int64; equal values: lower index first).  k <= 8192."""
     require_cuda(x, "x")
     assert x.dim() == 2
     x = x.float().contiguous()
@@ -537,3 +632,30 @@ def topk_flat(x, k: int, apply_sigmoid: bool = False):
     code = _lib.lib().dtlr_topk_flat(x.data_ptr(), values.data_ptr(), idx.data_ptr(), B, n, int(k), int(bool(apply_sigmoid)), _lib.current_stream())
     _lib.check(code, "dtlr_topk_flat")
     return values, idx
+
+
+# --------------------------------------------------------------------------------------------
+# Every operator launches on the current stream of the device its FIRST tensor argument lives on (not of whatever device
+# happens to be current): a model moved to cuda:1 while cuda:0 is current would otherwise launch on device 0 with device-1
+# pointers.  The check costs one integer compare per call when the devices already agree.
+def _device_scoped(fn):
+    import functools
+
+    @functools.wraps(fn)
+    def wrapper(*args, **kwargs):
+        for t in args:
+            if isinstance(t, torch.Tensor):
+                if t.is_cuda and t.device.index != torch.cuda.current_device():
+                    with torch.cuda.device(t.device):
+                        return fn(*args, **kwargs)
+                break
+        return fn(*args, **kwargs)
+    return wrapper
+
+
+for _name in ("geometry", "linear", "linear_rowmax", "two_stage_gather", "layernorm", "proj_ln", "proj_ln_split", "ffn_fused", "conv2d_nhwc", "stem_conv7x7", "stem_conv7x7_f32",
+              "maxpool_nhwc", "groupnorm_tokens", "msda", "msda_fused", "msda_encoder", "mha", "decoder_query_prep", "box_mlp_refine",
+              "box_head_refine", "box_refine", "topk_rows", "decode_blank", "preprocess_lines", "ctc_loss_interleaved", "nms_batched",
+              "topk_flat"):
+    globals()[_name] = _device_scoped(globals()[_name])
+del _name

@@ -178,10 +178,26 @@ def synthetic_state_dict(cfg: DTLRConfig, seed: int = 0) -> "OrderedDict[str, to
 _ALIAS = re.compile(r"^(transformer\.decoder\.)?(class_embed|bbox_embed)\.(\d+)\.")
 
 
-def load_checkpoint_state_dict(path: str) -> "OrderedDict[str, torch.Tensor]":
+def load_checkpoint_state_dict(path: str, trust_pickle: bool = False) -> "OrderedDict[str, torch.Tensor]":
     """`checkpoint["model"]` as evaluation.py:55-56 reads it; `module.` prefixes stripped
-    (util/misc.py:581-586)."""
-    ckpt = torch.load(path, map_location="cpu", weights_only=False)
+    (util/misc.py:581-586).
+
+    Checkpoints are third-party files (the DTLR weights are Drive downloads): they are read with
+    `weights_only=True`, which only admits tensors and plain containers.  The reference's own
+    checkpoints also pickle an argparse `args` namespace (finetuning.py:709-721); that one global is
+    allow-listed.  Anything else needs the explicit `trust_pickle=True` opt-in (env
+    DTLR_TRUST_CHECKPOINT=1), which runs the unrestricted unpickler -- only for files you trust."""
+    import argparse
+    import os
+    import pickle
+    try:
+        with torch.serialization.safe_globals([argparse.Namespace]):
+            ckpt = torch.load(path, map_location="cpu", weights_only=True)
+    except pickle.UnpicklingError as e:
+        if not (trust_pickle or os.environ.get("DTLR_TRUST_CHECKPOINT") == "1"):
+            raise RuntimeError(f"{path}: not loadable with weights_only=True ({e}); pass trust_pickle=True / set "
+                               "DTLR_TRUST_CHECKPOINT=1 only if the file comes from a trusted source") from e
+        ckpt = torch.load(path, map_location="cpu", weights_only=False)
     sd = ckpt["model"] if isinstance(ckpt, dict) and "model" in ckpt else ckpt
     out = OrderedDict()
     for k, v in sd.items():

@@ -89,6 +89,9 @@ int dtlr_msda_fused_forward_strided(const void *value, int value_row_stride, con
 int dtlr_msda_encoder_forward(const void *value, const void *ow, const float *ref, const int *level_hw,
                               int N, int M, int D, int L, int P, int halo,
                               int dtype, int ow_dtype, void *out, void *stream);
+/* 1 if the LDS window plan of dtlr_msda_encoder_forward fits these level shapes, 0 if not (canvases taller than ~270 px in
+ * fp32 / ~550 px in bf16: use dtlr_msda_fused_forward, which has no size limit), negative DTLR_E* on bad arguments. */
+int dtlr_msda_encoder_plan_ok(const int *level_hw /* host, 8 ints */, int dtype, int halo);
 
 /* ---------------------------------------------------------------------------------------------
  * y = LayerNorm(x [+ residual]) * gamma + beta over rows of C channels (C multiple of 256).
@@ -170,6 +173,12 @@ long dtlr_mha_workspace_bytes(int B, int L, int H, int head_dim);
 int dtlr_gemm_nt(const void *A, const void *A2, const void *W, const float *bias,
                  const void *residual, const unsigned char *row_mask, void *C,
                  int M, int N, int K, int relu, int in_dtype, int out_dtype, void *stream);
+/* scores[m] = max over n of (A[m,:] . W[n,:] + bias[n]): dtlr_gemm_nt with a row-max epilogue -- the [M,N] product is never
+ * written.  Replaces: enc_outputs_class_unselected.max(-1)[0] (models/dino/deformable_transformer.py:341-345: only the
+ * per-token maximum of the two-stage class head feeds torch.topk).  A [M,K], W [N,K] in_dtype (F32: K % 32 == 0, BF16:
+ * K % 64 == 0), bias [N] fp32 or NULL, rowmax [M] fp32 (every element written; a row whose products are all -inf stays -inf). */
+int dtlr_gemm_nt_rowmax(const void *A, const void *W, const float *bias, float *rowmax,
+                        int M, int N, int K, int in_dtype, void *stream);
 
 /* ---------------------------------------------------------------------------------------------
  * NHWC convolution as an implicit GEMM on the matrix cores, with the FrozenBN-folded bias, optional
@@ -251,6 +260,23 @@ int dtlr_preprocess_lines(const unsigned char *src, const long *offsets, const i
                           float *canvas, unsigned char *mask, void *stream);
 
 /* ---------------------------------------------------------------------------------------------
+ * Mask-derived geometry of one forward, ONE launch (a workgroup per row of a level of an image).
+ * Replaces: the per-level masks F.interpolate(mask[None].float(), size).bool() (models/dino/backbone.py:103, dino.py:304-307);
+ *           get_valid_ratio (models/dino/deformable_transformer.py:239-246); PositionEmbeddingSineHW.forward
+ *           (models/dino/position_encoding.py:79-108) + level_embed (deformable_transformer.py:281-285);
+ *           TransformerEncoder.get_reference_points (deformable_transformer.py:479-492); the proposal / validity part of
+ *           gen_encoder_output_proposals (models/dino/utils.py:31-62).
+ *   mask [B,H,W] uint8 (1 = padding) device ; level_hw HOST 8 ints (H_l, W_l) ; level_embed [4,256] fp32 device ;
+ *   dim_ty / dim_tx [128] fp32 device = temperature{H,W} ** (2 * (i // 2) / 128) (the table position_encoding.py:95-98 builds)
+ *   mask_flat [B,S] uint8, keep [B,S] uint8 (unpadded AND proposal valid), pos [B,S,256] pos_dtype (F32 / BF16, level_embed
+ *   added), valid_ratios [B,4,2] fp32 (w,h), enc_ref [B,S,4,2] fp32 (x,y), proposals [B,S,4] fp32 (logits; +inf where padded
+ *   or invalid).  S = sum H_l W_l; every output element is written. */
+int dtlr_geometry(const unsigned char *mask, int B, int H, int W, const int *level_hw,
+                  const float *level_embed, const float *dim_ty, const float *dim_tx, int pos_dtype,
+                  unsigned char *mask_flat, unsigned char *keep, void *pos, float *valid_ratios,
+                  float *enc_ref, float *proposals, void *stream);
+
+/* ---------------------------------------------------------------------------------------------
  * ResNet stem convolution: 7x7 / stride 2 / pad 3, 3 -> 64 channels, on the bf16 matrix cores, reading the
  * NCHW fp32 image directly (bf16-rounded operands, fp32 accumulate) and writing NHWC bf16.
  * Replaces: torchvision resnet50 `conv1` (+ the FrozenBN scale folded into the weights, backbone.py:62-72) as run by
@@ -261,6 +287,9 @@ int dtlr_preprocess_lines(const unsigned char *src, const long *offsets, const i
  *          both of its pointers are host memory; w_oihw = conv1.weight * bn_scale, [64,3,7,7] fp32). */
 int dtlr_stem_pack_weights(const float *w_oihw_host, unsigned short *wfrag_host /* [4*6*64*8] */);
 int dtlr_stem_conv7x7(const float *x, const void *wfrag, void *y, int B, int H, int W, int out_dtype, void *stream);
+/* The same convolution in exact fp32 (the parity engine; direct convolution on the vector ALUs, patch + weights in LDS).
+ *   wk: device [147][64] fp32, k-major image of conv1.weight * bn_scale (k = (ci*7 + kh)*7 + kw) ; y [B,Ho,Wo,64] fp32 NHWC. */
+int dtlr_stem_conv7x7_f32(const float *x, const float *wk, float *y, int B, int H, int W, void *stream);
 
 /* 3x3 / stride 2 / pad 1 max pooling on NHWC, optionally preceded by a per-channel bias and ReLU:
  *     y = maxpool(relu(x + bias))      (bias NULL: no bias; relu 0: no ReLU)
@@ -275,6 +304,16 @@ int dtlr_maxpool3x3s2_nhwc(const void *x, void *y, const float *bias, int relu, 
  *           (models/dino/deformable_transformer.py:345).   scores [B,S] fp32 -> idx_out [B,k] int64.
  */
 int dtlr_topk_rows(const float *scores, long *idx_out, int B, int S, int k, void *stream);
+
+/* The gathers that follow the two-stage top-k, one launch.
+ * Replaces: torch.gather of output_memory / output_proposals at topk_proposals and the sigmoid of the gathered proposals
+ *           (models/dino/deformable_transformer.py:347-356).
+ *   om        [B,S,768] bf16 = the [hi|lo|hi] image of dtlr_proj_ln_split_bf16 (dtype BF16) or [B,S,256] fp32 (dtype F32)
+ *   proposals [B,S,4] fp32 ; idx [B,k] int64
+ *   sel_raw   [B,k,768] bf16 / [B,k,256] fp32 : the gathered rows ; sel_x [B,k,256] bf16 = bf16(hi + lo) (BF16 only, else NULL)
+ *   prop_sel  [B,k,4] fp32 gathered proposal logits ; init_box [B,k,4] fp32 = sigmoid(prop_sel) */
+int dtlr_two_stage_gather(const void *om, const float *proposals, const long *idx, void *sel_raw, void *sel_x,
+                          float *prop_sel, float *init_box, int B, int S, int k, int dtype, void *stream);
 
 /* ---------------------------------------------------------------------------------------------
  * Blank/argmax decoder, one workgroup per line.
@@ -313,7 +352,7 @@ int dtlr_nms(const float *boxes, const float *scores, float iou_threshold, long 
 /* k largest of each row of a [B, n] fp32 matrix that is too long for LDS, descending, equal values: lower index first.
  * Replaces: `torch.topk(prob.view(B, -1), num_select, dim=1)` of PostProcess (models/dino/dino.py:1000-1006), with the sigmoid
  *           folded in (apply_sigmoid: the selection runs on the logits, values are returned as sigmoid(logit)).
- *   x [B,n] fp32 ; values [B,k] fp32 ; idx_out [B,k] int64 (flat positions: box = idx / C, label = idx % C) ; k <= 1024. */
+ *   x [B,n] fp32 ; values [B,k] fp32 ; idx_out [B,k] int64 (flat positions: box = idx / C, label = idx % C) ; k <= 8192. */
 int dtlr_topk_flat(const float *x, float *values, long *idx_out, int B, long n, int k, int apply_sigmoid, void *stream);
 
 #ifdef __cplusplus

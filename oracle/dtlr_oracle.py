@@ -5,7 +5,7 @@ the algorithm of the reference's inference path: DINO.forward over text-line ima
 character logits/boxes -> PostProcess / the two decoders -> CER.  Every function cites the
 reference file:line it follows.  Only `tests/`, `__graft_entry__.smoke()` and `bench.py`'s
 `cpu_baseline` leg may import it, and only as the checker / reported baseline; nothing under
-`dtlr_amd/` imports it (tests/test_no_oracle_in_product.py enforces this).
+`dtlr_amd/` imports it (tests/test_host_logic.py::test_product_never_imports_oracle_and_has_no_cpu_path enforces this).
 
 Pinning: the oracle is pinned against the REAL reference model imported in
 the authoring container (`tests/golden/make_golden.py`, which loads /root/reference with the four
