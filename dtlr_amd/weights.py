@@ -23,7 +23,17 @@ import torch
 
 from .config import DTLRConfig
 
-GENERATOR_VERSION = 1
+# Version 2 (round 2): heads with TRAINED-LIKE MARGINS.  Version 1 drew every head tensor i.i.d.: all 900 queries decoded to a
+# non-blank class on top-1/top-2 margins of ~0, so any rounding flipped labels and decoded-string comparisons said nothing.
+# Version 2 keeps every backbone / encoder / attention tensor of version 1 and changes only
+#   * the decoder's residual branches (self-attn out_proj, cross-attn output_proj, linear2: x 0.3) so that a query's content
+#     embedding survives the 18 post-norm sublayers next to the image-dependent signal,
+#   * tgt_embed: a weak i.i.d. part + beta_q * sqrt(d) * (the code vector of the query's designated class, or the blank code),
+#   * class_embed: row c = g * code_c - g_b * code_blank + small noise, bias -4.6 (the reference's init, dino.py:164-166),
+# so that ~8% of the queries carry a character (designated-class logit ~ +2..+9, image-dependent spread ~ +-1) and the rest
+# are blank (every class logit << 0), like the output of a trained recogniser.  beta_q varies per query, so margins range from
+# a few tenths of a logit to many logits.
+GENERATOR_VERSION = 2
 
 
 def _rng(name: str, seed: int) -> np.random.Generator:
@@ -78,8 +88,21 @@ def _msda(sd, p, cfg: DTLRConfig, n_points: int, seed: int):
     _linear(sd, p + ".output_proj", d, d, seed)
 
 
+def _codes(cfg: DTLRConfig, seed: int):
+    """Generator v2: unit-norm sign codes, one per class plus the blank code, and the per-query designation
+    (class id or -1 = blank, strength beta)."""
+    d, C, nq = cfg.hidden_dim, cfg.num_classes, cfg.num_queries
+    r = _rng("v2.codes", seed)
+    code = (r.integers(0, 2, (C + 1, d)).astype(np.float32) * 2 - 1) / math.sqrt(d)      # rows 0..C-1: classes, row C: blank
+    r = _rng("v2.designation", seed)
+    is_char = r.random(nq) < 0.08
+    cls = np.where(is_char, r.integers(0, C, nq), -1)
+    beta = np.where(is_char, r.uniform(0.15, 1.0, nq), r.uniform(0.5, 1.0, nq)).astype(np.float32)
+    return code, cls, beta
+
+
 def synthetic_state_dict(cfg: DTLRConfig, seed: int = 0) -> "OrderedDict[str, torch.Tensor]":
-    """fp32 CPU tensors keyed exactly like the reference's `model.state_dict()`."""
+    """fp32 CPU tensors keyed exactly like the reference's `model.state_dict()` (generator version GENERATOR_VERSION)."""
     cfg.validate()
     sd: "OrderedDict[str, torch.Tensor]" = OrderedDict()
     d, C, ff = cfg.hidden_dim, cfg.num_classes, cfg.dim_feedforward
@@ -134,10 +157,19 @@ def synthetic_state_dict(cfg: DTLRConfig, seed: int = 0) -> "OrderedDict[str, to
         _linear(sd, p + "linear1", ff, d, seed, gain=math.sqrt(2.0))
         _linear(sd, p + "linear2", d, ff, seed)
         _norm(sd, p + "norm3", d, seed)
+        for k in ("self_attn.out_proj.weight", "cross_attn.output_proj.weight", "linear2.weight"):
+            sd[p + k] = sd[p + k] * 0.3                      # v2: damped residual branches (see GENERATOR_VERSION)
     _norm(sd, t + "decoder.norm", d, seed)
     _linear(sd, t + "decoder.ref_point_head.layers.0", d, 2 * d, seed, gain=math.sqrt(2.0))
     _linear(sd, t + "decoder.ref_point_head.layers.1", d, d, seed)
-    sd[t + "tgt_embed.weight"] = _normal(t + "tgt_embed.weight", seed, (cfg.num_queries, d), 1.0)
+    code, q_cls, q_beta = _codes(cfg, seed)
+    # a character query points along (its class code + 0.7 blank code): the blank part pushes every OTHER class down, as a trained
+    # head does (sum of the sigmoids stays below 1, the blank channel of the decoders is 1 - sum); a blank query along the blank code
+    kappa = 0.7
+    q_code = np.where((q_cls >= 0)[:, None], (code[np.maximum(q_cls, 0)] + kappa * code[cfg.num_classes]) / math.sqrt(1 + kappa * kappa),
+                      code[cfg.num_classes][None]).astype(np.float32)
+    sd[t + "tgt_embed.weight"] = (_normal(t + "tgt_embed.weight", seed, (cfg.num_queries, d), 0.5)
+                                  + torch.from_numpy(q_beta[:, None] * math.sqrt(d) * q_code))
     _linear(sd, t + "enc_output", d, d, seed)
     _norm(sd, t + "enc_output_norm", d, seed)
     # Tokens whose proposal is invalid/padded have their memory row zeroed (models/dino/utils.py:
@@ -163,7 +195,13 @@ def synthetic_state_dict(cfg: DTLRConfig, seed: int = 0) -> "OrderedDict[str, to
     _linear(shared, "bbox_embed.layers.0", d, d, seed, gain=math.sqrt(2.0))
     _linear(shared, "bbox_embed.layers.1", d, d, seed, gain=math.sqrt(2.0))
     _linear(shared, "bbox_embed.layers.2", 4, d, seed, gain=0.3)
-    _linear(shared, "class_embed", C, d, seed, gain=2.0, bias_const=cls_bias)
+    # v2 class head: row c = g * code_c - g_b * code_blank + noise; bias = the reference's -log(99)
+    g_cls, g_blank = 2.5, 1.0
+    shared["class_embed.weight"] = (torch.from_numpy(g_cls * code[:C] - g_blank * code[C:C + 1])
+                                    + _normal("class_embed.weight", seed, (C, d), 0.25 / math.sqrt(d)))
+    # bias: the reference's init -log(99) = -4.6 (dino.py:164-166), lowered by log(C / 166) for larger charsets so that the summed
+    # sigmoid of the "other" classes stays below 1 as in a trained head (7356 classes: -8.4)
+    shared["class_embed.bias"] = torch.full((C,), -4.6 - max(0.0, math.log(C / 166.0)))
     for n in range(cfg.dec_layers):
         for k, v in shared.items():
             head, rest = k.split(".", 1) if k.startswith("bbox_embed") else ("class_embed", k[len("class_embed."):])

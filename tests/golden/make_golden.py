@@ -155,6 +155,14 @@ def gen_g3():
                    topk_scores=_np(scores), memory_rows=_np(memory[:, ::67]))
         d, _ = _decode_with_reference(ref, post, crit, cfg)
         out.update(d)
+        # the NMS decoder's PostProcess call (evaluation.py:97-100: num_select = 900, IoU 0.5, target size (1,1)), per sample
+        post["bbox"].num_select, post["bbox"].nms_iou_threshold = cfg.num_queries, 0.5
+        for b in range(2):
+            one = {"pred_logits": ref["pred_logits"][b:b + 1], "pred_boxes": ref["pred_boxes"][b:b + 1]}
+            r = post["bbox"](one, torch.tensor([[1.0, 1.0]]))[0]
+            out[f"nms_labels_{b}"], out[f"nms_scores_{b}"] = _np(r["labels"]).astype(np.int32), _np(r["scores"])
+            out[f"nms_boxes_{b}"] = _np(r["boxes"])
+        # per-query decision data for margin-aware gates: the two largest logits of every query are in top8_val[..., :2]
         np.savez_compressed(os.path.join(HERE, f"g3_{tag}.npz"), **out)
         print("g3", tag, "written")
         del model, sd

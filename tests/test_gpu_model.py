@@ -55,11 +55,28 @@ def test_tiny_model_vs_oracle_and_golden(golden_dir):
     assert (out["pred_logits"].cpu() - ref["pred_logits"]).abs().max() < LOGIT_TOL
 
 
+def _reference_order_labels(g):
+    """The reference's blank-decoder decision per QUERY (class index, -1 = blank) from the golden: `ctc_argmax_eps003` holds the
+    argmax over [blank | classes] in reading order (queries sorted by box cx, dino.py:466-502)."""
+    boxes = torch.from_numpy(g["pred_boxes"])
+    seq = torch.from_numpy(g["ctc_argmax_eps003"].astype(np.int64))               # [B, nq], 0 = blank, c + 1 = class c
+    order = torch.argsort(boxes[..., 0], dim=1, stable=True)
+    lab = torch.empty_like(seq)
+    lab.scatter_(1, order, seq - 1)
+    return lab, order
+
+
 @pytest.mark.parametrize("tag", ["latin", "chinese"])
 def test_full_model_vs_golden_and_oracle(golden_dir, tag):
-    """BASELINE configs: Latin 128x2048 and Chinese (C=7356) 128x2560, mixed-width pair (padding)."""
+    """BASELINE configs: Latin 128x2048 and Chinese (C=7356) 128x2560, mixed-width pair (padding).  fp32 engine vs the REAL
+    reference's stored outputs: scores, memory, logits, boxes, and the DECODED goldens (blank decoder decisions in reading order,
+    PostProcess top-k, the NMS decoder's PostProcess call)."""
+    from dtlr_amd import evaluation as E
+    from dtlr_amd.dino import PostProcess
     from oracle import dtlr_oracle as O
+    from tests.util import query_decisions
     g = np.load(os.path.join(golden_dir, f"g3_{tag}.npz"))
+    assert int(g["generator_version"]) == weights.GENERATOR_VERSION
     cfg = DTLRConfig.latin() if tag == "latin" else DTLRConfig.chinese()
     sd = weights.synthetic_state_dict(cfg, 0)
     h, widths = int(g["height"]), [int(w) for w in g["widths"]]
@@ -70,19 +87,116 @@ def test_full_model_vs_golden_and_oracle(golden_dir, tag):
     ref_topk = torch.from_numpy(g["topk_idx"].astype(np.int64))
     out = m(dimgs, forced_topk=ref_topk.cuda(), return_debug=True)
     d = out["_debug"]
-    assert (d["topk_scores"].cpu() - torch.from_numpy(g["topk_scores"])).abs().max() < 5e-4
+    score_err = (d["topk_scores"].cpu() - torch.from_numpy(g["topk_scores"])).abs().max().item()
+    assert score_err < 5e-4, score_err
     assert (d["memory"][:, ::67].cpu() - torch.from_numpy(g["memory_rows"])).abs().max() < 5e-4
     idx = torch.from_numpy(g["top8_idx"].astype(np.int64))
     assert (torch.gather(out["pred_logits"].cpu(), 2, idx) - torch.from_numpy(g["top8_val"])).abs().max() < LOGIT_TOL
     assert (out["pred_boxes"].cpu() - torch.from_numpy(g["pred_boxes"])).abs().max() < BOX_TOL
-    # (1) free-running selection is a valid top-k of the reference's scores (tie-aware)
+    # ---- decoded goldens.  Blank decoder (eps 0.003): per-query decision identical to the reference's wherever the decision
+    # margin exceeds the logit tolerance, and the reading order identical except among queries whose cx differ by < 2 * BOX_TOL
+    host = _cpu(out)
+    ref_lab, ref_order = _reference_order_labels(g)
+    lab, margin = query_decisions(host["pred_logits"], host["pred_boxes"], 0.003)
+    safe = margin > 2 * LOGIT_TOL
+    assert safe.float().mean() > 0.98, safe.float().mean()
+    assert torch.equal(lab[safe], ref_lab[safe])
+    cx_ref = torch.from_numpy(g["pred_boxes"])[..., 0]
+    order = torch.argsort(host["pred_boxes"][..., 0], dim=1, stable=True)
+    moved = order != ref_order
+    for b in range(order.shape[0]):                        # a query may only change rank inside a run of near-equal cx
+        pos = torch.nonzero(moved[b]).flatten()
+        if len(pos):
+            assert (cx_ref[b, order[b, pos]] - cx_ref[b, ref_order[b, pos]]).abs().max() < 2 * BOX_TOL
+    # the product decoder on the engine's outputs == the reference's decoded sequence where all of it is safe
+    dec = E.decode_blank(out, 0.003)
+    for b in range(len(dec)):
+        want = [int(x) for x in ref_lab[b, ref_order[b]] if x >= 0]
+        if bool(safe[b].all()) and not bool(moved[b].any()):
+            assert dec[b] == want
+        assert abs(len(dec[b]) - len(want)) <= int((~safe[b]).sum())
+    # PostProcess (num_select = 300): the sorted score vector is stable under perturbation; labels / boxes must match wherever a
+    # score is separated from its neighbours by more than the score tolerance (sigmoid slope <= 1/4)
+    B = host["pred_logits"].shape[0]
+    pp = PostProcess(num_select=cfg.num_select)(out, torch.ones(B, 2).cuda())
+    sc = torch.stack([p["scores"] for p in pp]).cpu()
+    gs = torch.from_numpy(g["pp_scores"])
+    assert (sc - gs).abs().max() < LOGIT_TOL / 4 + 1e-6
+    sep = torch.ones_like(gs, dtype=torch.bool)
+    close = (gs[:, :-1] - gs[:, 1:]) < 2 * (LOGIT_TOL / 4)
+    sep[:, :-1] &= ~close
+    sep[:, 1:] &= ~close
+    sep[:, -1] = False                                      # the cut itself: the next score is not stored
+    assert sep.float().mean() > 0.2
+    assert torch.equal(torch.stack([p["labels"] for p in pp]).cpu()[sep], torch.from_numpy(g["pp_labels"]).long()[sep])
+    assert (torch.stack([p["boxes"] for p in pp]).cpu()[sep] - torch.from_numpy(g["pp_boxes"])[sep]).abs().max() < 2 * BOX_TOL
+    # the NMS decoder's PostProcess call (num_select = 900, IoU 0.5) per sample: kept (score, label) pairs above TH = 0.3
+    post = PostProcess(num_select=cfg.num_queries, nms_iou_threshold=0.5)
+    for b in range(B):
+        one = {"pred_logits": out["pred_logits"][b:b + 1], "pred_boxes": out["pred_boxes"][b:b + 1]}
+        r = post(one, torch.tensor([[1.0, 1.0]]).cuda())[0]
+        rs, rl = torch.from_numpy(g[f"nms_scores_{b}"]), torch.from_numpy(g[f"nms_labels_{b}"]).long()
+        conf_ref = [(int(l)) for s_, l in zip(rs.tolist(), rl.tolist()) if s_ > 0.3 + 1e-3]
+        conf_got = [(int(l)) for s_, l in zip(r["scores"].cpu().tolist(), r["labels"].cpu().tolist()) if s_ > 0.3 + 1e-3]
+        assert sorted(conf_ref) == sorted(conf_got)
+    # (1) free-running selection is a valid top-k of the reference's scores (tie-aware; tolerance = the measured score error)
     free = m(dimgs, return_debug=True)
     fidx = free["_debug"]["topk_idx"].cpu()
-    assert selection_is_valid(fidx, torch.from_numpy(g["topk_scores"]), cfg.num_queries, tol=1e-3)
-    # ... and with the oracle following that selection, logits agree and decoded strings are identical
+    assert selection_is_valid(fidx, torch.from_numpy(g["topk_scores"]), cfg.num_queries, tol=2 * score_err + 1e-7)
+    # ... and with the oracle following that selection, logits agree
     ref = O.dino_forward(sd, cfg, imgs, forced_topk=fidx)
     assert (free["pred_logits"].cpu() - ref["pred_logits"]).abs().max() < LOGIT_TOL
     assert (free["pred_boxes"].cpu() - ref["pred_boxes"]).abs().max() < BOX_TOL
+
+
+# Stated bounds of the bf16 (bench) engine against the fp32 CPU oracle on the same selection (measured on MI355X, margin-bearing
+# generator v2): max |logit difference| and max |box difference|.
+BF16_LOGIT_BOUND = {"latin": 0.6, "chinese": 0.6}
+BF16_BOX_BOUND = 8e-3
+
+
+@pytest.mark.parametrize("tag", ["latin", "chinese"])
+def test_bf16_engine_vs_oracle_decoded_strings(golden_dir, tag):
+    """The BENCHED engine (bf16 operands) against O.dino_forward -- not against the fp32 HIP engine -- on the BASELINE shapes
+    (Latin 128x2048, Chinese C = 7356 128x2560; mixed-width pair): a stated logit bound, labels identical on every query whose
+    oracle decision margin exceeds the measured bf16 logit error, reading-order strings identical on those (CER == 0), for both
+    decoders' eps."""
+    from dtlr_amd import evaluation as E_
+    from oracle import dtlr_oracle as O
+    from tests.util import compare_decoded
+    g = np.load(os.path.join(golden_dir, f"g3_{tag}.npz"))
+    cfg = DTLRConfig.latin() if tag == "latin" else DTLRConfig.chinese()
+    sd = weights.synthetic_state_dict(cfg, 0)
+    h, widths = int(g["height"]), [int(w) for w in g["widths"]]
+    imgs = synth.stroke_lines(1, h, widths[0], seed=21) + synth.noise_lines(1, h, widths[1], seed=22)
+    ref = O.dino_forward(sd, cfg, imgs, return_debug=True)
+    idx = ref["_debug"]["topk_idx"]
+    m16 = _model(cfg, sd, torch.bfloat16)
+    o16 = m16([i.cuda() for i in imgs], forced_topk=idx.cuda(), return_debug=True)
+    got = _cpu(o16)
+    err = (got["pred_logits"] - ref["pred_logits"]).abs()
+    berr = (got["pred_boxes"] - ref["pred_boxes"]).abs()
+    E, Eb = err.max().item(), berr.max().item()
+    print(f"[bf16 vs oracle, {tag}] logit err max {E:.4f} mean {err.mean().item():.5f}; box err max {Eb:.5f} mean {berr.mean().item():.6f}")
+    assert E < BF16_LOGIT_BOUND[tag] and Eb < BF16_BOX_BOUND, (E, Eb)
+    for eps in (None, 0.003):
+        st = compare_decoded(ref["pred_logits"], ref["pred_boxes"], got["pred_logits"], got["pred_boxes"], eps, E, Eb)
+        print(f"[bf16 vs oracle, {tag}, eps={eps}] {st}")
+        assert st["label_mismatch_on_safe"] == 0 and st["strings_equal"], st      # CER(bf16 vs oracle) == 0 on the safe queries
+        assert st["safe_frac"] > 0.9 and st["safe_chars"] >= 0.25 * st["chars_ref"], st   # the gate covers most queries
+        # unrestricted strings (every query, including the unsafe ones): reported, and bounded -- bf16 rounding may flip a query
+        # whose margin is below the logit error or swap two characters whose cx differ by less than the box error, nothing else
+        a, b = O.decode_blank(ref, eps), E_.decode_blank(o16, eps)
+        dist = sum(O.levenshtein(x, y) for x, y in zip(a, b))
+        n = sum(len(x) for x in a)
+        print(f"[bf16 vs oracle, {tag}, eps={eps}] unrestricted CER {dist}/{n} = {dist / max(n, 1):.4f}")
+        assert dist <= 2 * (st["chars_ref"] - st["safe_chars"]) + 2 * int((1 - st["safe_frac"]) * ref["pred_logits"].shape[0] * ref["pred_logits"].shape[1])
+    # the bf16 engine's own selection is a valid top-k of the oracle's scores within the measured score error
+    free = m16([i.cuda() for i in imgs], return_debug=True)
+    serr = (free["_debug"]["topk_scores"].cpu() - ref["_debug"]["topk_scores"]).abs().max().item()
+    print(f"[bf16 vs oracle, {tag}] two-stage score err {serr:.2e}")
+    assert serr < 5e-3
+    assert selection_is_valid(free["_debug"]["topk_idx"].cpu(), ref["_debug"]["topk_scores"], cfg.num_queries, tol=2 * serr + 1e-7)
 
 
 def test_decoders_and_cer_identical_to_oracle():
@@ -131,45 +245,88 @@ def test_full_size_batch_properties():
     assert (full["pred_boxes"] >= 0).all() and (full["pred_boxes"] <= 1).all()
 
 
-def test_bf16_path_close_to_fp32():
-    """The bench dtype: bf16 operands, fp32 accumulation/statistics/selection.  With the selection
-    pinned, logits stay close to the fp32 path and most decoded labels agree."""
-    from dtlr_amd import evaluation as E
-    cfg = DTLRConfig.latin()
-    sd = weights.synthetic_state_dict(cfg, 0)
-    imgs = [i.cuda() for i in synth.stroke_lines(2, 128, 2048, seed=31)]
-    m32 = _model(cfg, sd)
-    o32 = m32(imgs, return_debug=True)
-    idx = o32["_debug"]["topk_idx"]
-    del m32
-    m16 = _model(cfg, sd, torch.bfloat16)
-    o16 = m16(imgs, forced_topk=idx)
-    assert torch.isfinite(o16["pred_logits"]).all()
-    diff = (o16["pred_logits"].float() - o32["pred_logits"]).abs()
-    assert diff.mean() < 0.15 and diff.max() < 3.0, (diff.mean().item(), diff.max().item())
-    a, b = E.decode_blank(o16), E.decode_blank(o32)
-    agree = np.mean([np.mean([x == y for x, y in zip(p, q)]) if len(p) == len(q) else 0.0 for p, q in zip(a, b)])
-    assert agree >= 0.7, agree
+def _bf16_vs_oracle(tag, cfg, sd, imgs, o16, rows, eps_list=(None,)):
+    """Shared gate: rows `rows` of a bf16 engine output against O.dino_forward on the same lines with the same selection."""
+    from oracle import dtlr_oracle as O
+    from tests.util import compare_decoded
+    idx = o16["_debug"]["topk_idx"][rows].cpu()
+    ref = O.dino_forward(sd, cfg, [imgs[r] for r in rows], forced_topk=idx)
+    got = {"pred_logits": o16["pred_logits"][rows].float().cpu(), "pred_boxes": o16["pred_boxes"][rows].float().cpu()}
+    E = (got["pred_logits"] - ref["pred_logits"]).abs().max().item()
+    Eb = (got["pred_boxes"] - ref["pred_boxes"]).abs().max().item()
+    print(f"[bf16 vs oracle, {tag}] logit err max {E:.4f}, box err max {Eb:.5f}")
+    assert E < BF16_LOGIT_BOUND["chinese" if cfg.num_classes > 1000 else "latin"] and Eb < BF16_BOX_BOUND, (E, Eb)
+    for eps in eps_list:
+        st = compare_decoded(ref["pred_logits"], ref["pred_boxes"], got["pred_logits"], got["pred_boxes"], eps, E, Eb)
+        print(f"[bf16 vs oracle, {tag}, eps={eps}] {st}")
+        assert st["label_mismatch_on_safe"] == 0 and st["strings_equal"] and st["safe_frac"] > 0.9, st
 
 
-def test_bf16_padded_batch_close_to_fp32():
-    """bf16 engine on a MIXED-WIDTH (zero-padded, masked) batch: exercises the padding-row epilogue of the value GEMMs,
-    the batched decoder value projection, the fused FFN and the LDS MSDA kernel on padded maps.  With the selection
-    pinned to the fp32 engine's, logits stay close and the padded line's boxes stay inside its valid width."""
+def test_bf16_bench_batch_vs_oracle_and_line_independence():
+    """BASELINE configs[1] exactly as bench.py runs it: bf16 engine, 32 unpadded 128x2048 lines, its own selection.  (a) lines
+    0 and 17 of the batch against the CPU oracle following the engine's selection: stated logit bound, decoded strings identical
+    on the safe queries; (b) per-line independence in bf16: a line's result does not depend on its batch neighbours (the
+    sub-batch runs other tile shapes / kernel variants, so the comparison uses the bf16 bound, and the decoded labels of the safe
+    queries must be identical)."""
+    from tests.util import compare_decoded
     cfg = DTLRConfig.latin()
     sd = weights.synthetic_state_dict(cfg, 0)
-    imgs = [i.cuda() for i in synth.stroke_lines(3, 128, [2048, 1536, 1792], seed=17)]
-    m32 = _model(cfg, sd)
-    o32 = m32(imgs, return_debug=True)
-    idx = o32["_debug"]["topk_idx"]
-    del m32
+    imgs = synth.noise_lines(32, 128, 2048, seed=4)
     m16 = _model(cfg, sd, torch.bfloat16)
-    o16 = m16(imgs, forced_topk=idx)
+    full = m16(torch.stack(imgs).cuda(), return_debug=True)
+    assert torch.isfinite(full["pred_logits"]).all() and torch.isfinite(full["pred_boxes"]).all()
+    assert (full["pred_boxes"] >= 0).all() and (full["pred_boxes"] <= 1).all()
+    _bf16_vs_oracle("bench batch rows 0,17", cfg, sd, imgs, full, [0, 17], eps_list=(None, 0.003))
+    sub = m16([imgs[7].cuda(), imgs[8].cuda()], forced_topk=full["_debug"]["topk_idx"][7:9])
+    d = (sub["pred_logits"].float() - full["pred_logits"][7:9].float()).abs().max().item()
+    db = (sub["pred_boxes"].float() - full["pred_boxes"][7:9].float()).abs().max().item()
+    print(f"[bf16 line independence] logit diff {d:.4f}, box diff {db:.5f}")
+    assert d < BF16_LOGIT_BOUND["latin"] and db < BF16_BOX_BOUND
+    st = compare_decoded(full["pred_logits"][7:9].float().cpu(), full["pred_boxes"][7:9].float().cpu(),
+                         sub["pred_logits"].float().cpu(), sub["pred_boxes"].float().cpu(), None, max(d, 1e-3), max(db, 1e-5))
+    assert st["label_mismatch_on_safe"] == 0 and st["strings_equal"], st
+
+
+def test_bf16_padded_batch_vs_oracle():
+    """bf16 engine on a MIXED-WIDTH (zero-padded, masked) batch: exercises the padding-row epilogue of the value GEMMs, the
+    batched decoder value projection, the fused FFN and the LDS MSDA kernel on padded maps -- against the CPU oracle."""
+    cfg = DTLRConfig.latin()
+    sd = weights.synthetic_state_dict(cfg, 0)
+    imgs = synth.stroke_lines(3, 128, [2048, 1536, 1792], seed=17)
+    m16 = _model(cfg, sd, torch.bfloat16)
+    o16 = m16([i.cuda() for i in imgs], return_debug=True)
     assert torch.isfinite(o16["pred_logits"]).all() and torch.isfinite(o16["pred_boxes"]).all()
-    diff = (o16["pred_logits"].float() - o32["pred_logits"]).abs()
-    assert diff.mean() < 0.15 and diff.max() < 3.0, (diff.mean().item(), diff.max().item())
-    bd = (o16["pred_boxes"].float() - o32["pred_boxes"]).abs()
-    assert bd.mean() < 5e-3, bd.mean().item()
+    _bf16_vs_oracle("padded 2048/1536/1792", cfg, sd, imgs, o16, [0, 1, 2])
+
+
+def test_bf16_chinese_cfg5_batch_properties():
+    """BASELINE configs[4]: Chinese head (C = 7356), 32 mixed-length lines (widths seeded from {1536..2560}) padded to 128x2560,
+    bf16 engine: finite outputs, boxes inside the canvas, the padded part of a line never selected by the two-stage top-k, line
+    independence on the same canvas, and two lines against the CPU oracle."""
+    from tests.util import compare_decoded
+    cfg = DTLRConfig.chinese()
+    sd = weights.synthetic_state_dict(cfg, 0)
+    widths = synth.mixed_widths(32, [1536, 1792, 2048, 2304, 2560], seed=5)
+    widths[0] = 2560                                               # the canvas width is pinned by line 0
+    imgs = synth.noise_lines(32, 128, widths, seed=44)
+    m16 = _model(cfg, sd, torch.bfloat16)
+    full = m16([i.cuda() for i in imgs], return_debug=True)
+    assert tuple(full["pred_logits"].shape) == (32, cfg.num_queries, 7356)
+    assert torch.isfinite(full["pred_logits"]).all() and torch.isfinite(full["pred_boxes"]).all()
+    assert (full["pred_boxes"] >= 0).all() and (full["pred_boxes"] <= 1).all()
+    g = full["_debug"]["geometry"]
+    picked_pad = torch.gather(g["mask_flat"], 1, full["_debug"]["topk_idx"])
+    assert not picked_pad.any()                                    # padded tokens score the bare bias: never in the top 900
+    rows = [3, 20]
+    _bf16_vs_oracle("cfg5 rows 3,20", cfg, sd, [imgs[0]] + [imgs[r] for r in rows],
+                    {"pred_logits": full["pred_logits"][[0] + rows], "pred_boxes": full["pred_boxes"][[0] + rows],
+                     "_debug": {"topk_idx": full["_debug"]["topk_idx"][[0] + rows]}}, [0, 1, 2])   # line 0 pins the 2560 canvas
+    sub = m16([imgs[0].cuda(), imgs[3].cuda(), imgs[20].cuda()], forced_topk=full["_debug"]["topk_idx"][[0, 3, 20]])
+    d = (sub["pred_logits"].float() - full["pred_logits"][[0, 3, 20]].float()).abs().max().item()
+    assert d < BF16_LOGIT_BOUND["chinese"], d
+    st = compare_decoded(full["pred_logits"][[0, 3, 20]].float().cpu(), full["pred_boxes"][[0, 3, 20]].float().cpu(),
+                         sub["pred_logits"].float().cpu(), sub["pred_boxes"].float().cpu(), None, max(d, 1e-3), BF16_BOX_BOUND)
+    assert st["label_mismatch_on_safe"] == 0, st
 
 
 def test_head_resize_checkpoint_flow_forward(tmp_path):
