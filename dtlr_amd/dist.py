@@ -57,13 +57,14 @@ def all_gather_records(labels: torch.Tensor, lengths: torch.Tensor, n_total: int
     b = labels.shape[0]
     rec[:b, :nq] = labels
     rec[:b, nq] = lengths
-    if labels.is_cuda:                                   # RCCL: one flat all-gather
+    if dist.get_backend() == "nccl":                      # RCCL over xGMI: one flat all-gather of device buffers
         out = torch.empty((world, per, nq + 1), dtype=torch.int32, device=labels.device)
         dist.all_gather_into_tensor(out.view(-1), rec.view(-1))
-    else:                                                # gloo (CPU tests)
-        parts = [torch.empty_like(rec) for _ in range(world)]
-        dist.all_gather(parts, rec)
-        out = torch.stack(parts, 0)
+    else:                                                # gloo (CPU tests; two ranks sharing one GPU in the single-GPU DP test)
+        host = rec.cpu()
+        parts = [torch.empty_like(host) for _ in range(world)]
+        dist.all_gather(parts, host)
+        out = torch.stack(parts, 0).to(labels.device)
     rows = []
     for r in range(world):
         lo, hi = shard_bounds(n_total, r, world)
@@ -80,7 +81,7 @@ def barrier() -> None:
 def max_over_ranks(value: float, device) -> float:
     if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
         return value
-    t = torch.tensor([value], dtype=torch.float64, device=device)
+    t = torch.tensor([value], dtype=torch.float64, device=device if dist.get_backend() == "nccl" else "cpu")
     dist.all_reduce(t, op=dist.ReduceOp.MAX)
     return float(t.item())
 

@@ -5,6 +5,9 @@
                                              blank construction (models/dino/dino.py:466-502)
                                              + engine.convert_output_to_pred (engine.py:511-530)
   CER / cumulative CER / normalisation    <- evaluation.py:296-334,430-450,517-529 ; engine.py:594-633
+  WER, word splitting, gt normalisation   <- evaluation.py:358-428 ; engine.py:487-494,543-593
+  per-character impact, WA, CR            <- evaluation.py:162-290
+  the evaluation loop / CLI               <- evaluation.py:460-659  (dtlr_amd/eval_harness.py; `python -m dtlr_amd.evaluation`)
 
 The reference decodes batch index 0 only (evaluation.py:154-155, batch size 1) with one `.item()`
 device sync per character; here the whole batch is decoded on the device and ONE fixed-width record
@@ -184,3 +187,116 @@ def cumulative_cer(gt_strings: Sequence[str], pred_strings: Sequence[str], norma
         length += len(g)
         series.append(dist / length)
     return (sum(series) / len(series) if series else 0.0), series
+
+
+def word_error_rate(predicted_words, gt_words) -> float:
+    """evaluation.py:358-396: word-level edit distance / max(#gt words, 1).  The reference's loop passes (gt_split, pred_split)
+    (evaluation.py:533-535, 546-549), so the figure it reports is normalised by the number of PREDICTED words; the harness
+    here calls it the same way."""
+    return levenshtein(predicted_words, gt_words) / max(len(gt_words), 1)
+
+
+def split_labels_into_words(labels: Sequence[int], charset: Sequence[str]) -> List[List[int]]:
+    """evaluation.py:400-412: cut a label sequence at the charset's space; no empty words."""
+    space = list(charset).index(" ")
+    words: List[List[int]] = [[]]
+    for lab in labels:
+        if lab == space:
+            if words[-1]:
+                words.append([])
+        else:
+            words[-1].append(lab)
+    return words if words[-1] else words[:-1]
+
+
+_GT_RULES = (("B B C", "BBC"), ("I T V", "ITV"), (" -", "-"), ("- ", "-"), (" -", "-"), ("- ", "-"), (" .", "."), (" ,", ","),
+             (" '", "'"), ("' ", "'"))
+
+
+def process_gt_string(s: str) -> str:
+    """evaluation.py:414-428 (ground-truth normalisation; unlike process_pred_string it does not collapse double blanks or
+    repeated punctuation)."""
+    for a, b in _GT_RULES:
+        s = s.replace(a, b)
+    s = re.sub(r"(\d), (\d)", r"\1,\2", s)
+    return re.sub(r"(?<=\S)€(?=\S)", " € ", s)
+
+
+def character_error_rate_with_impact(pred: Sequence[int], gt: Sequence[int], impact: Dict[int, int]):
+    """evaluation.py:162-210 -> (cer, impact, div).  `impact[c]` grows, for every predicted character c, by the number of
+    ground-truth characters that differ from it (what the reference's bookkeeping inside its DP loop amounts to); written to
+    dict_char.json by the harness.  An empty ground truth raises (the reference fails on it too)."""
+    if len(gt) == 0:
+        raise ValueError("character_error_rate_with_impact: empty ground truth")
+    counts: Dict[int, int] = {}
+    for g_ in gt:
+        counts[int(g_)] = counts.get(int(g_), 0) + 1
+    for p_ in pred:
+        n = len(gt) - counts.get(int(p_), 0)
+        if n:
+            impact[int(p_)] = impact.get(int(p_), 0) + n
+    return levenshtein(pred, gt) / len(gt), impact, len(gt)
+
+
+def compute_wa(gt: Sequence[int], pred: Sequence[int]) -> float:
+    """evaluation.py:212-238 (cipher "word accuracy"): matching positions over max(len(gt), 1)."""
+    return sum(1 for a, b in zip(gt, pred) if a == b) / max(len(gt), 1)
+
+
+def compute_edit_operations(s1: Sequence, s2: Sequence) -> Tuple[int, int, int]:
+    """evaluation.py:239-281 -> (insertions, deletions, substitutions) of the alignment the reference's backtrace picks
+    (substitution before deletion before insertion)."""
+    m, n = len(s1), len(s2)
+    rows = [list(range(n + 1))]
+    for i in range(1, m + 1):
+        prev, cur = rows[-1], [i] + [0] * n
+        for j in range(1, n + 1):
+            cur[j] = prev[j - 1] if s1[i - 1] == s2[j - 1] else 1 + min(prev[j], cur[j - 1], prev[j - 1])
+        rows.append(cur)
+    i, j, ins, dele, sub = m, n, 0, 0, 0
+    while i and j:
+        here = rows[i][j]
+        if s1[i - 1] == s2[j - 1]:
+            i, j = i - 1, j - 1
+        elif here == rows[i - 1][j - 1] + 1:
+            sub, i, j = sub + 1, i - 1, j - 1
+        elif here == rows[i - 1][j] + 1:
+            dele, i = dele + 1, i - 1
+        else:
+            ins, j = ins + 1, j - 1
+    return ins + j, dele + i, sub
+
+
+def compute_cr(gt: Sequence[int], pred: Sequence[int]) -> float:
+    """evaluation.py:283-290 (Chinese correct rate): (len(gt) - deletions - substitutions) / len(gt)."""
+    _, dele, sub = compute_edit_operations(gt, pred)
+    return (len(gt) - dele - sub) / len(gt)
+
+
+_WER_PUNCT = re.compile(r"""([\[\]{}/\()"'&+*=<>?.;:,!\-—_€#%°])""")
+
+
+def format_string_for_wer(s: str) -> List[str]:
+    """engine.py:487-494: every punctuation mark is a word of its own; blanks and line breaks collapse."""
+    s = _WER_PUNCT.sub(r" \1 ", s)
+    return re.sub(r"[ \n]+", " ", s).strip().split(" ")
+
+
+def compute_wer(pred_labels: Sequence[Sequence[int]], target_labels: Sequence[Sequence[int]], charset: Sequence,
+                mode_chr: bool = True) -> Tuple[float, float]:
+    """engine.py:543-593 on decoded label sequences (its duplicate=False path): (sum of per-line WER, sum of per-line CER),
+    WER = word edit distance of the formatted strings / number of ground-truth words, '¬' removed."""
+    wer = cer = 0.0
+    for pred, tgt in zip(pred_labels, target_labels):
+        tgt = [int(t) for t in tgt]
+        cer += character_error_rate(list(pred), tgt)
+        conv = (lambda c: c) if mode_chr else (lambda c: chr(int(c)))
+        gt_words = format_string_for_wer("".join(conv(charset[t]) for t in tgt).replace("¬", ""))
+        pr_words = format_string_for_wer("".join(conv(charset[int(p)]) for p in pred).replace("¬", ""))
+        wer += levenshtein(gt_words, pr_words) / len(gt_words)
+    return wer, cer
+
+
+if __name__ == "__main__":
+    from .eval_harness import main
+    main()

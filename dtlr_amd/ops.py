@@ -41,10 +41,10 @@ MFMA_EVENTS_MIN_FLOPS = 2.0e9     # only launches this large are timed: an event
 
 class _Timed:
     """with _Timed(kind, flops): <launch>  -- records a HIP event pair around the launch when MFMA_EVENTS is a list."""
-    __slots__ = ("kind", "flops", "nbytes", "a", "st")
+    __slots__ = ("kind", "flops", "nbytes", "tag", "a", "st")
 
-    def __init__(self, kind, flops, nbytes=0.0):
-        self.kind, self.flops, self.nbytes = kind, flops, nbytes
+    def __init__(self, kind, flops, nbytes=0.0, tag=None):
+        self.kind, self.flops, self.nbytes, self.tag = kind, flops, nbytes, tag
 
     def __enter__(self):
         self.a = None
@@ -58,7 +58,7 @@ class _Timed:
         if self.a is not None:
             b = torch.cuda.Event(enable_timing=True)
             b.record(self.st)
-            MFMA_EVENTS.append((self.a, b, self.kind, self.flops, self.nbytes))
+            MFMA_EVENTS.append((self.a, b, self.kind, self.flops, self.nbytes, self.tag))
         return False
 
 
@@ -86,7 +86,8 @@ def linear(x, w, b=None, relu=False, residual=None, a2=None, row_mask=None, out_
         y = torch.empty(x.shape[:-1] + (N,), dtype=out_dtype, device=x.device)
         es, eo = x.element_size(), (2 if out_dtype == torch.bfloat16 else 4)
         nbytes = float(M) * K * es * (2 if a2 is not None else 1) + float(N) * K * es + float(M) * N * eo * (2 if residual is not None else 1)
-        with _Timed("gemm_bf16" if x.dtype == torch.bfloat16 else "gemm_f32", 2.0 * M * N * K, nbytes):
+        tag = f"linear M{M} N{N} K{K}" + ("+a2" if a2 is not None else "") + ("+res" if residual is not None else "") + ("" if out_dtype == x.dtype else "->f32")
+        with _Timed("gemm_bf16" if x.dtype == torch.bfloat16 else "gemm_f32", 2.0 * M * N * K, nbytes, tag):
             code = _lib.lib().dtlr_gemm_nt(x.data_ptr(), 0 if a2 is None else a2.data_ptr(), w.data_ptr(),
                                            0 if b is None else b.data_ptr(), 0 if residual is None else residual.data_ptr(),
                                            0 if row_mask is None else row_mask.data_ptr(), y.data_ptr(),
@@ -110,7 +111,8 @@ def linear_rowmax(x, w, b=None):
     M = x.numel() // K
     out = torch.empty(x.shape[:-1], dtype=torch.float32, device=x.device)
     es = x.element_size()
-    with _Timed("gemm_bf16" if x.dtype == torch.bfloat16 else "gemm_f32", 2.0 * M * N * K, float(M) * K * es + float(N) * K * es + 4.0 * M):
+    with _Timed("gemm_bf16" if x.dtype == torch.bfloat16 else "gemm_f32", 2.0 * M * N * K, float(M) * K * es + float(N) * K * es + 4.0 * M,
+                f"rowmax M{M} N{N} K{K}"):
         code = _lib.lib().dtlr_gemm_nt_rowmax(x.data_ptr(), w.data_ptr(), 0 if b is None else b.data_ptr(), out.data_ptr(),
                                               M, N, K, _DT[x.dtype], _lib.current_stream())
     _lib.check(code, "dtlr_gemm_nt_rowmax")
@@ -263,7 +265,8 @@ def conv2d_nhwc(x, w, bias, stride: int, padding: int, relu=False, residual=None
             residual = residual if residual.is_contiguous() else residual.contiguous()
         es = x.element_size()
         nbytes = (float(x.numel()) / (stride * stride if KH == 1 else 1) + float(w.numel()) + float(B) * Ho * Wo * Cout * (2 if residual is not None else 1)) * es
-        with _Timed("gemm_bf16" if x.dtype == torch.bfloat16 else "gemm_f32", 2.0 * B * Ho * Wo * Cout * KH * KW * Cin, nbytes):
+        tag = f"conv{KH}x{KW}s{stride} M{B * Ho * Wo} N{Cout} K{KH * KW * Cin}" + ("+res" if residual is not None else "")
+        with _Timed("gemm_bf16" if x.dtype == torch.bfloat16 else "gemm_f32", 2.0 * B * Ho * Wo * Cout * KH * KW * Cin, nbytes, tag):
             code = _lib.lib().dtlr_conv2d_nhwc(x.data_ptr(), w.data_ptr(), 0 if bias is None else bias.data_ptr(),
                                                0 if residual is None else residual.data_ptr(), y.data_ptr(),
                                                B, H, W, Cin, Cout, KH, KW, stride, padding, 2 if relu else 0,

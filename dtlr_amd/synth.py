@@ -20,10 +20,12 @@ def _rng(seed: int) -> np.random.Generator:
     return np.random.Generator(np.random.PCG64(seed))
 
 
-def noise_lines(n: int, height: int, widths: Sequence[int] | int, seed: int = 0) -> List[torch.Tensor]:
+def noise_lines(n: int, height: int, widths: Sequence[int] | int, seed: int = 0, start: int = 0) -> List[torch.Tensor]:
+    """Lines start .. start+n-1 of the seeded stream: line i depends on (seed, i) only, so a data-parallel rank can materialise
+    its shard of ONE global batch (`start` = its first global index) and any rank can recompute any other shard."""
     if isinstance(widths, int):
         widths = [widths] * n
-    return [torch.from_numpy(_rng(seed * 1000003 + i).standard_normal((3, height, int(w))).astype(np.float32))
+    return [torch.from_numpy(_rng(seed * 1000003 + start + i).standard_normal((3, height, int(w))).astype(np.float32))
             for i, w in zip(range(n), widths)]
 
 

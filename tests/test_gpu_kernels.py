@@ -656,3 +656,161 @@ def test_topk_flat_and_postprocess_vs_oracle(B, nq, C, k):
             keep[1:] &= tie_free
             keep[:-1] &= tie_free
             assert same[keep].all()
+
+
+# ---- round 2 kernels --------------------------------------------------------------------------------------------------------
+def _geometry_masks(B, H, W, kind, seed):
+    g = np.random.Generator(np.random.PCG64(seed))
+    m = torch.zeros((B, H, W), dtype=torch.bool)
+    if kind == "rect":                                   # what collate produces: a valid top-left rectangle per image
+        for b in range(B):
+            h, w = (H, W) if b == 0 else (int(g.integers(H // 2, H + 1)), int(g.integers(W // 3, W + 1)))
+            m[b, h:, :] = True
+            m[b, :, w:] = True
+    elif kind == "random":                               # arbitrary masks: the kernel does real cumulative sums
+        m = torch.from_numpy(g.random((B, H, W)) < 0.3)
+        m[:, 0, 0] = False
+    return m
+
+
+@pytest.mark.parametrize("H,W,kind", [(128, 2048, "none"), (128, 2048, "rect"), (128, 2560, "rect"), (64, 200, "random"), (448, 1344, "rect")])
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_geometry_kernel_vs_oracle(H, W, kind, dtype):
+    """dtlr_geometry == the oracle's restatements of interpolate_mask / PositionEmbeddingSineHW / get_valid_ratio /
+    get_reference_points / gen_encoder_output_proposals, for unpadded, collate-style and arbitrary masks (incl. a tall canvas and a
+    level wider than one 256-token chunk)."""
+    from dtlr_amd import ops
+    from oracle import dtlr_oracle as O
+    B = 3
+    mask = _geometry_masks(B, H, W, kind, seed=H + W)
+    def down(n, k):                                      # ResNet /8,/16,/32 then the stride-2 3x3 conv
+        for _ in range(k):
+            n = (n - 1) // 2 + 1
+        return n
+    level_hw = [(down(H, 3), down(W, 3)), (down(H, 4), down(W, 4)), (down(H, 5), down(W, 5)), (down(H, 6), down(W, 6))]
+    le = _rand((4, 256), 7)
+    g = ops.geometry(mask.cuda(), level_hw, le.cuda(), 20, 20, dtype)
+    masks = [O.interpolate_mask(mask, hw) for hw in level_hw]
+    mask_flat = torch.cat([m.flatten(1) for m in masks], 1)
+    assert torch.equal(g["mask_flat"].cpu(), mask_flat)
+    pos = torch.cat([O.position_embedding_sine_hw(m).flatten(2).transpose(1, 2) + le[l].view(1, 1, -1) for l, m in enumerate(masks)], 1)
+    tol = 2e-5 if dtype == torch.float32 else 0.04
+    assert (g["pos"].float().cpu() - pos).abs().max() < tol
+    vr = torch.stack([O.get_valid_ratio(m) for m in masks], 1)
+    assert (g["valid_ratios"].cpu() - vr).abs().max() < 1e-7
+    shapes = torch.as_tensor(level_hw, dtype=torch.long)
+    ref = O.encoder_reference_points(shapes, vr)
+    assert (g["enc_ref"].cpu() - ref).abs().max() < 1e-6
+    mem = torch.ones((B, mask_flat.shape[1], 4))
+    om, prop = O.gen_encoder_output_proposals(mem, mask_flat, shapes)
+    got = g["proposals"].cpu()
+    assert torch.equal(torch.isinf(got), torch.isinf(prop))
+    fin = ~torch.isinf(prop)
+    assert (got[fin] - prop[fin]).abs().max() < 2e-6
+    assert torch.equal(g["keep"].cpu(), om[..., 0] != 0)
+
+
+@pytest.mark.parametrize("B,H,W", [(2, 128, 2048), (1, 37, 101), (3, 32, 256)])
+def test_stem_conv7x7_f32_vs_reference(B, H, W):
+    """The exact-fp32 stem kernel (parity engine) against F.conv2d on the CPU: 7x7 / stride 2 / pad 3, 3 -> 64, NHWC output."""
+    from dtlr_amd import ops
+    x = _rand((B, 3, H, W), 11)
+    w = _rand((64, 3, 7, 7), 12, 0.1)
+    want = F.conv2d(x, w, None, stride=2, padding=3).permute(0, 2, 3, 1)
+    got = ops.stem_conv7x7_f32(x.cuda(), ops.stem_pack_weights_f32(w).cuda()).cpu()
+    assert got.shape == want.shape
+    assert (got - want).abs().max() < 2e-5
+
+
+@pytest.mark.parametrize("M,N,K,dt", [(5440 * 2, 192, 768, torch.bfloat16), (1000, 7356, 768, torch.bfloat16), (777, 166, 256, torch.float32),
+                                      (130, 23, 256, torch.float32)])
+def test_linear_rowmax_vs_reference(M, N, K, dt):
+    """The GEMM's row-max epilogue == (x @ w.T + b).max(-1) computed from the full product of the same kernel (so the comparison is
+    exact up to nothing: max is order-independent) and close to the fp32 CPU product; -inf padded bias rows never win."""
+    from dtlr_amd import ops
+    x = _rand((M, K), 1).to(dt)
+    w = _rand((N, K), 2, 0.1).to(dt)
+    b = _rand((N,), 3)
+    if N == 192:
+        b[166:] = float("-inf")
+    full = ops.linear(x.cuda(), w.cuda(), b.cuda(), out_dtype=torch.float32)
+    got = ops.linear_rowmax(x.cuda(), w.cuda(), b.cuda())
+    assert torch.equal(got, full.max(-1)[0])
+    want = (x.float() @ w.float().t() + b).max(-1)[0]
+    assert (got.cpu() - want).abs().max() < (1e-4 if dt == torch.float32 else 2e-3)
+
+
+@pytest.mark.parametrize("dt", [torch.bfloat16, torch.float32])
+def test_two_stage_gather(dt):
+    from dtlr_amd import ops
+    B, S, k = 3, 700, 90
+    om = _rand((B, S, 768 if dt == torch.bfloat16 else 256), 5).to(dt)
+    prop = _rand((B, S, 4), 6)
+    prop[0, 5] = float("inf")
+    g = np.random.Generator(np.random.PCG64(2))
+    idx = torch.from_numpy(np.stack([g.permutation(S)[:k] for _ in range(B)])).long()
+    idx[0, 0] = 5
+    raw, sx, ps, ib = ops.two_stage_gather(om.cuda(), prop.cuda(), idx.cuda())
+    want = torch.gather(om, 1, idx[..., None].expand(-1, -1, om.shape[-1]))
+    assert torch.equal(raw.cpu(), want)
+    wp = torch.gather(prop, 1, idx[..., None].expand(-1, -1, 4))
+    assert torch.equal(ps.cpu(), wp)
+    assert (ib.cpu() - wp.sigmoid()).abs().max() < 1e-6
+    if dt == torch.bfloat16:
+        assert torch.equal(sx.cpu(), (want[..., :256].float() + want[..., 256:512].float()).bfloat16())
+    else:
+        assert sx is None
+
+
+@pytest.mark.parametrize("B,S,k", [(2, 20000, 900), (1, 70000, 900), (2, 16385, 30)])
+def test_topk_rows_large_S_global_path(B, S, k):
+    """Rows too long for the LDS copy (tall canvases) take the global-memory radix select: same order, ties -> lower index."""
+    from dtlr_amd import ops
+    x = _rand((B, S), 8)
+    x[:, 100:140] = x[:, 99:100]                       # a block of exact ties
+    x[0, 7] = float("inf")
+    got = ops.topk_rows(x.cuda(), k).cpu()
+    key = torch.argsort(-x, dim=1, stable=True)[:, :k]
+    assert torch.equal(got, key)
+
+
+def test_topk_flat_more_than_1024():
+    from dtlr_amd import ops
+    x = _rand((2, 300 * 166), 4)
+    v, i = ops.topk_flat(x.cuda(), 3000, apply_sigmoid=True)
+    key = torch.argsort(-x, dim=1, stable=True)[:, :3000]
+    assert torch.equal(i.cpu(), key)
+    assert (v.cpu() - torch.gather(x, 1, key).sigmoid()).abs().max() < 1e-6
+
+
+def test_no_library_fallbacks():
+    """Shapes the kernels do not take raise instead of dropping to hipBLASLt / MIOpen; nothing is library-backed."""
+    from dtlr_amd import _lib, ops
+    assert ops.LIBRARY_BACKED == set()
+    with pytest.raises(_lib.DTLRError):
+        ops.linear(_rand((4, 100), 1).cuda(), _rand((8, 100), 2).cuda())
+    with pytest.raises(_lib.DTLRError):
+        ops.conv2d_nhwc(_rand((1, 8, 8, 3), 1).cuda(), _rand((4, 3, 3, 3), 2).cuda(), None, 1, 1)
+
+
+def test_tall_canvas_falls_back_to_gather_msda_and_global_topk():
+    """A 448x1344 line (eval transform: short side 800 / max 1333 for aspect ratio < 5): the LDS-window encoder kernel's plan does
+    not fit (fp32) and S = 9408+... tokens; the engine must fall back to the gather kernel and still match the oracle."""
+    from dtlr_amd import ops
+    from dtlr_amd.config import DTLRConfig
+    from dtlr_amd.dino import DINO
+    from dtlr_amd import synth, weights
+    from oracle import dtlr_oracle as O
+    cfg = DTLRConfig.tiny()
+    sd = weights.synthetic_state_dict(cfg, 1)
+    imgs = synth.noise_lines(1, 448, 1344, seed=3) + synth.noise_lines(1, 300, 1100, seed=4)
+    level_hw = [(56, 168), (28, 84), (14, 42), (7, 21)]
+    assert not ops.msda_encoder_fits(level_hw, torch.float32)
+    m = DINO(cfg)
+    m.load_state_dict(sd)
+    m = m.eval().to("cuda:0")
+    out = m([i.cuda() for i in imgs], return_debug=True)
+    assert out["_debug"]["geometry"]["lds_msda_fits"] is False
+    ref = O.dino_forward(sd, cfg, imgs, forced_topk=out["_debug"]["topk_idx"].cpu())
+    assert (out["pred_logits"].cpu() - ref["pred_logits"]).abs().max() < 1e-3
+    assert (out["pred_boxes"].cpu() - ref["pred_boxes"]).abs().max() < 1e-4

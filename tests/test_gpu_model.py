@@ -351,3 +351,70 @@ def test_head_resize_checkpoint_flow_forward(tmp_path):
     ref = O.dino_forward(sd, cfg11, imgs, forced_topk=out["_debug"]["topk_idx"].cpu())
     assert (out["pred_logits"].cpu() - ref["pred_logits"]).abs().max() < LOGIT_TOL
     assert (out["pred_boxes"].cpu() - ref["pred_boxes"]).abs().max() < BOX_TOL
+
+
+def test_evaluation_cli_on_synthetic_assets(tmp_path):
+    """`python -m dtlr_amd.evaluation` end to end on synthetic assets (checkpoint.pth + a folder of line images + labels): the
+    harness of evaluation.py:460-659 -- preprocess -> forward -> decode -> CER/WER -> the reference's output files.  With
+    `--batching exact` the predictions equal the oracle run the reference's way, ONE image at a time."""
+    import json
+    from PIL import Image
+    from dtlr_amd import eval_harness as H
+    from oracle import dtlr_oracle as O
+    from tests.util import preproc_image
+    cs = H.load_charset(None)
+    cfg = DTLRConfig.tiny(num_classes=len(cs))
+    sd = weights.synthetic_state_dict(cfg, 6)
+    torch.save({"model": sd, "epoch": 3}, tmp_path / "checkpoint.pth")
+    img_dir = tmp_path / "lines"
+    img_dir.mkdir()
+    shapes = [(40, 300), (40, 300), (33, 410), (40, 300), (25, 160)]
+    texts = ["hello world", "The B B C , 1, 2", "x - y", "abc def", "q"]
+    imgs = []
+    for k, (h, w) in enumerate(shapes):
+        im = preproc_image(h, w, 20 + k)
+        imgs.append(im)
+        Image.fromarray(im, "RGB").save(img_dir / f"l{k:02d}.png")
+    (tmp_path / "labels.json").write_text(json.dumps([[f"l{k:02d}", t] for k, t in enumerate(texts)]))
+    res = H.main(["--config", "tiny", "--weights", str(tmp_path / "checkpoint.pth"), "--images", str(img_dir),
+                  "--labels", str(tmp_path / "labels.json"), "--dataset", "IAM", "--out", str(tmp_path / "stats"),
+                  "--dtype", "f32", "--batch", "3", "--size", "32", "--max_size", "256"])
+    # the oracle, one image at a time (evaluation.py:499), same transform parameters
+    want = []
+    for im in imgs:
+        x, m = O.preprocess_lines([im], size=32, max_size=256)
+        want.append(O.decode_blank(O.dino_forward(sd, cfg, x, mask=m))[0])
+    got_str = res["list_preds_str"]
+    assert got_str == ["".join(cs[i] for i in p) for p in want]
+    ref = H.evaluate_predictions(want, texts, cs, "IAM", "default")
+    assert res["CER_list"] == ref["CER_list"] and res["WER_list"] == ref["WER_list"]
+    d = tmp_path / "stats" / "IAM"
+    assert sorted(os.listdir(d)) == ["cer_TH_None_NMS_None.txt", "cer_list.npy", "dict_char.json", "list_gt.txt", "list_preds.txt"]
+    assert (d / "list_gt.txt").read_text().splitlines() == texts
+    # the NMS decoder path of the scripts (--NMS 0.5 --TH 0.3) runs too and writes its own CER file
+    H.main(["--config", "tiny", "--weights", str(tmp_path / "checkpoint.pth"), "--images", str(img_dir), "--labels", str(tmp_path / "labels.json"),
+            "--out", str(tmp_path / "stats"), "--dtype", "bf16", "--NMS", "0.5", "--TH", "0.3", "--size", "32", "--max_size", "256", "--batching", "padded"])
+    assert (d / "cer_TH_0.3_NMS_0.5.txt").exists()
+
+
+def test_data_parallel_two_ranks_on_one_gpu_equals_single_process():
+    """SURVEY.md 8(e) correctness definition on hardware: two ranks of the REAL bench step (each with its own engine, shard of one
+    global seeded batch) exchange their decode records, and rank 0 recomputes both shards itself: gathered == single-process
+    records, bit for bit, in order.  Two ranks share the one GPU of the test box, so the process group is gloo (RCCL refuses
+    duplicate devices); the code path is otherwise the one the 8-GPU run takes."""
+    import json
+    import socket
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1", "--batch", "3",
+           "--backend", "gloo", "--single-device", "--no-cpu-baseline", "--no-parity", "--min-seconds", "0"]
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=600, cwd=root)
+    assert r.returncode == 0, r.stderr[-3000:]
+    line = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
+    assert line["n_gpus"] == 2 and line["config"]["global_batch"] == 6
+    assert line["distributed"] == {"backend": "gloo", "world_size": 2, "dp_verified": True}

@@ -260,3 +260,76 @@ def test_checkpoint_ingestion_head_resize_flow(tmp_path):
     sd166 = weights.synthetic_state_dict(cfg, 0)
     m2 = E.load_model(DINO(cfg), sd166, device="cpu")
     assert torch.equal(m2.class_embed[0].bias, sd166["class_embed.0.bias"])
+
+
+def test_g6_metrics_oracle_and_product_vs_reference_vectors(golden_dir):
+    """WER / word splitting / gt normalisation / per-character impact / WA / CR / engine.compute_wer: the oracle's restatements
+    and the product's implementations both reproduce vectors produced by the REFERENCE's own function bodies
+    (tests/golden/make_golden_metrics.py lifts them out of evaluation.py / engine.py with ast)."""
+    import json
+    from dtlr_amd import evaluation as E
+    g = json.load(open(os.path.join(golden_dir, "g6_metrics.json")))
+    cs = json.load(open(os.path.join(os.path.dirname(E.__file__), "data", "default_charset.json")))
+    assert len(cs) == g["charset_len"] and cs.index(" ") == g["space_index"]
+    for mod, wa, cr, wer_engine, cer_engine in ((O, "compute_wa", "compute_cr", "compute_wer_engine", "character_error_rate_engine"),
+                                                (E, "compute_wa", "compute_cr", "compute_wer", "character_error_rate")):
+        for c in g["cases"]:
+            gt, pred = c["gt"], c["pred"]
+            gw, pw = mod.split_labels_into_words(gt, cs), mod.split_labels_into_words(pred, cs)
+            assert gw == c["gt_words"] and pw == c["pred_words"]
+            assert mod.word_error_rate(gw, pw) == c["wer_as_called"] and mod.word_error_rate(pw, gw) == c["wer_declared"]
+            assert getattr(mod, wa)(gt, pred) == c["wa"]
+            assert list(mod.compute_edit_operations(gt, pred)) == c["edit_ops"]
+            assert getattr(mod, cr)(gt, pred) == c["cr"]
+            assert getattr(mod, cer_engine)(pred, gt) == c["cer_engine"]
+            if "impact" in c:
+                cer, imp, div = mod.character_error_rate_with_impact(pred, gt, {})
+                assert cer == c["impact"]["cer"] and div == c["impact"]["div"]
+                assert {str(a): b for a, b in sorted(imp.items())} == c["impact"]["dict"]
+            w, ce = getattr(mod, wer_engine)([pred], [gt], cs, True)
+            assert abs(w - c["engine_wer"]) < 1e-12 and abs(ce - c["engine_cer"]) < 1e-6      # the reference's CER there is fp32
+        for t in g["strings"]:
+            assert mod.process_gt_string(t["s"]) == t["gt"] and mod.process_pred_string(t["s"]) == t["pred"]
+            assert mod.format_string_for_wer(t["s"]) == t["words"]
+
+
+def test_eval_harness_bookkeeping_and_batch_plan(tmp_path):
+    """dtlr_amd.eval_harness: label/charset loading, the exact (no padding) batch plan, and the per-sample metric bookkeeping of
+    evaluation.py:495-581 against the oracle's restatements (running string-level CER whose MEAN is reported, WER as called)."""
+    import json
+    import pickle
+    from dtlr_amd import eval_harness as H
+    cs = H.load_charset(None)
+    assert len(cs) == 166 and " " in cs
+    rows = [("a-01", "hello world"), ("a-02", "The B B C , 1, 2 - x"), ("b-07", "x")]
+    (tmp_path / "l.json").write_text(json.dumps(dict(rows)))
+    (tmp_path / "l.tsv").write_text("".join(f"{n}\t{t}\n" for n, t in rows))
+    with open(tmp_path / "l.pkl", "wb") as f:
+        pickle.dump({"charset": cs, "ground_truth": {"valid": [{"id": n, "text": t} for n, t in rows], "test": []}}, f)
+    assert H.load_labels(str(tmp_path / "l.json"), "test") == rows == H.load_labels(str(tmp_path / "l.tsv"), "test") == H.load_labels(str(tmp_path / "l.pkl"), "val")
+    # batch plan: exact -> only equal resized sizes share a batch; every index exactly once; at most `batch` per batch
+    sizes = [(128, 2048), (128, 2048), (100, 1800), (128, 2048), (64, 900), (128, 2047)]
+    for exact in (True, False):
+        plan = H.plan_batches(sizes, 2, exact, 800, 1333)
+        assert sorted(i for b in plan for i in b) == list(range(len(sizes))) and all(len(b) <= 2 for b in plan)
+        if exact:
+            from dtlr_amd.transforms import get_size_with_aspect_ratio as gs
+            assert all(len({gs((sizes[i][1], sizes[i][0]), 800, 1333) for i in b}) == 1 for b in plan)
+    # bookkeeping
+    gts = [t for _, t in rows]
+    enc = lambda t: [cs.index(c) for c in t]
+    preds = [enc("helo world"), enc("The BBC, 1,2-y"), []]
+    res = H.evaluate_predictions(preds, gts, cs, "IAM", "default")
+    want_cer, series = O.cumulative_cer(gts, ["helo world", "The BBC, 1,2-y", ""])
+    assert res["CER_list"] == series and abs(res["cer"][0] - want_cer) < 1e-12
+    want_wer = [O.word_error_rate(O.split_labels_into_words(enc(g), cs), O.split_labels_into_words(p, cs)) for g, p in zip(gts, preds)]
+    assert res["WER_list"] == want_wer
+    assert res["list_preds_str"] == ["helo world", "The BBC, 1,2-y", ""] and res["list_gt_str"] == gts
+    imp = {}
+    for p, g in zip(preds[:2], gts[:2]):
+        O.character_error_rate_with_impact(p, enc(g), imp)
+    assert res["dict_char"] == imp
+    res = H.evaluate_predictions(preds, gts, cs, "HWDB", "chinese")
+    assert res["CR_list"][:2] == [O.compute_cr(enc(g), p) for g, p in zip(gts[:2], preds[:2])] and res["CER_list"][2] == 1
+    d = H.write_outputs(res, str(tmp_path / "stats"), "HWDB", None, None)
+    assert sorted(os.listdir(d)) == ["cer_TH_None_NMS_None.txt", "cer_list.npy", "dict_char.json", "list_gt.txt", "list_preds.txt"]

@@ -39,6 +39,8 @@ def test_g1_msda_out_of_range_locations(golden_dir, oracle_clib):
     v, s, lsi, loc, aw = msda_inputs(2, 8, 32, 77, 4, shapes, seed=int(g["b_seed"]), lo=-0.5, hi=1.5)
     ref = _t(g["b_out_f32"])
     assert (O.ms_deform_attn_core(v, s, loc, aw) - ref).abs().max() < 2e-6
+    # the grid_sample formulation (the reference's own CPU core, used by bench.py's cpu_baseline leg) is the same function
+    assert (O.ms_deform_attn_core_grid_sample(v, s, loc, aw) - ref).abs().max() < 2e-6
     assert (c_oracle_msda(oracle_clib, v, s, lsi, loc, aw) - ref).abs().max() < 2e-6
 
 
