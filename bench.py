@@ -143,15 +143,16 @@ def cer_vs_oracle(cfg, sd, x, mask, out, rows):
     got_l, got_b = out["pred_logits"][rows].float().cpu(), out["pred_boxes"][rows].float().cpu()
     E = (got_l - ref["pred_logits"]).abs().max().item()
     Eb = (got_b - ref["pred_boxes"]).abs().max().item()
-    st = compare_decoded(ref["pred_logits"], ref["pred_boxes"], got_l, got_b, None, E, Eb)
+    Ecx = (got_b[..., 0] - ref["pred_boxes"][..., 0]).abs().max().item()
+    st = compare_decoded(ref["pred_logits"], ref["pred_boxes"], got_l, got_b, None, E, Ecx)       # reading order depends on cx only
     a = O.decode_blank(ref)
     b = O.decode_blank({"pred_logits": got_l, "pred_boxes": got_b})
     dist = sum(O.levenshtein(x_, y_) for x_, y_ in zip(a, b))
     n = sum(len(x_) for x_ in a)
-    return {"lines": list(rows), "logit_err_max": round(E, 4), "box_err_max": round(Eb, 5), "cer_all_queries": round(dist / max(n, 1), 5),
+    return {"lines": list(rows), "logit_err_max": round(E, 4), "box_err_max": round(Eb, 5), "cx_err_max": round(Ecx, 5), "cer_all_queries": round(dist / max(n, 1), 5),
             "chars_oracle": n, "edit_distance": dist, "cer_safe_queries": 0.0 if (st["strings_equal"] and st["label_mismatch_on_safe"] == 0) else 1.0,
             "safe_query_frac": round(st["safe_frac"], 4), "safe_chars": st["safe_chars"],
-            "note": "safe = oracle decision margin > 2 x measured logit error and cx separation > 2 x measured box error (tests/util.py)"}
+            "note": "safe = oracle decision margin > 2 x measured logit error and cx separation > 2 x measured cx error (tests/util.py)"}
 
 
 def main():

@@ -32,6 +32,7 @@ _SIGNATURES = {
                                                 c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p, c_void_p]),
     "dtlr_msda_encoder_forward": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int,
                                           c_int, c_int, c_void_p, c_void_p]),
+    "dtlr_msda_encoder_set_variant": (c_int, [c_int]),
     "dtlr_msda_encoder_plan_ok": (c_int, [c_void_p, c_int, c_int]),
     "dtlr_geometry": (c_int, [c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_int,
                               c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
@@ -45,6 +46,7 @@ _SIGNATURES = {
     "dtlr_mha_workspace_bytes": (ctypes.c_long, [c_int, c_int, c_int, c_int]),
     "dtlr_gemm_nt": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
                              c_int, c_int, c_int, c_int, c_int, c_int, c_void_p]),
+    "dtlr_gemm_nt_a2bcast": (c_int, [c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p]),
     "dtlr_gemm_nt_rowmax": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p]),
     "dtlr_two_stage_gather": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p]),
     "dtlr_conv2d_nhwc": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,

@@ -311,7 +311,8 @@ __device__ __forceinline__ void epilogue_tile(f32x4_t (&acc)[4][4], OutT* __rest
 // M = B*Ho*Wo output pixels, K = KH*KW*Cin ordered (kh, kw, ci) so that a 128-byte K slab lies inside
 // one filter tap (Cin*sizeof(T) % 128 == 0) and is one contiguous, 16-byte-aligned run of channels;
 // taps that fall into the zero padding contribute zeros.  Weights are packed [Cout][KH][KW][Cin].
-struct ConvP { int H, W, Cin, Ho, Wo, KH, KW, stride, pad; };
+struct ConvP { int H, W, Cin, Ho, Wo, KH, KW, stride, pad;
+               int a2_rows; };      // plain GEMM with an A2 prologue: A2 has a2_rows rows, row m of A pairs with row m % a2_rows (0 = M rows)
 __device__ __attribute__((aligned(16))) unsigned int g_zero_line[4] = {0u, 0u, 0u, 0u};   // what a padding tap reads
 
 // Tile chains.  A workgroup owns `tiles_per_block` consecutive TOKEN tiles (tm) of ONE channel tile (tn) and
@@ -371,14 +372,14 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(
     // version) is NOT conflict-free for those groups -- 7 of 16 lanes collided (measured: the LDS-read +
     // barrier skeleton alone was a third of the kernel time).
     const int lds0 = srow * LDS_ROW + ((kc ^ (srow & 7)) * 16);
-    long a_off[4], w_off[4];                                    // loader state: byte offsets at k-slab 0
+    long a_off[4], w_off[4], a2_off[4];                         // loader state: byte offsets at k-slab 0
     int hi0[4], wi0[4];                                         // CONV: top-left input coordinate of the pixel
     const int slabs_per_tap = CONV ? (cp.Cin * (int)sizeof(T)) / SLAB : 1;
     const char* Ab = reinterpret_cast<const char*>(A);
     const char* A2b = reinterpret_cast<const char*>(A2);
     const char* Wb = reinterpret_cast<const char*>(W);
     const char* zero_line = reinterpret_cast<const char*>(g_zero_line);
-    (void)zero_line;
+    (void)zero_line; (void)a2_off;
 
 #define SET_LOAD_TILE(TILE)                                                                        \
     {                                                                                              \
@@ -396,6 +397,7 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(
                 hi0[i] = wi0[i] = 0;                                                               \
                 a_off[i] = (ar * K) * (long)sizeof(T) + kc * 16;                                   \
             }                                                                                      \
+            a2_off[i] = HAS_A2 ? (((cp.a2_rows > 0 ? ar % cp.a2_rows : ar) * K) * (long)sizeof(T) + kc * 16) : 0; \
         }                                                                                          \
     }
 
@@ -422,7 +424,7 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(
         ra##S##I = LD16(ok_ ? Ab + a_off[I] + po_ : zero_line);                                    \
     } else {                                                                                       \
         ra##S##I = LD16(Ab + a_off[I] + (OFF));                                                    \
-        if (HAS_A2) ra##S##I = GT<T>::add(ra##S##I, *reinterpret_cast<const uint4*>(A2b + a_off[I] + (OFF))); \
+        if (HAS_A2) ra##S##I = GT<T>::add(ra##S##I, *reinterpret_cast<const uint4*>(A2b + a2_off[I] + (OFF))); \
     }
 #define GLOAD(S, KT)                                                                               \
     {                                                                                              \
@@ -553,14 +555,14 @@ __global__ __launch_bounds__(512, HAS_A2 ? 2 : 4) void gemm_ws_kernel(
         const int tid = threadIdx.x - 256;
         const int srow = tid >> 3, kc = tid & 7;
         const int lds0 = srow * LDS_ROW + ((kc ^ (srow & 7)) * 16);
-        long a_off[4], w_off[4];
+        long a_off[4], w_off[4], a2_off[4];
         int hi0[4], wi0[4];
         const int slabs_per_tap = CONV ? (cp.Cin * (int)sizeof(T)) / SLAB : 1;
         const char* Ab = reinterpret_cast<const char*>(A);
         const char* A2b = reinterpret_cast<const char*>(A2);
         const char* Wb = reinterpret_cast<const char*>(W);
         const char* zero_line = reinterpret_cast<const char*>(g_zero_line);
-        (void)zero_line; (void)A2b;
+        (void)zero_line; (void)A2b; (void)a2_off;
         // asm (uncounted) loads only in the variants whose ISA audit shows no compiler copy of an in-flight register
         // (the A2 variant gets v_mov shuffles right after the loads); A2 keeps compiler-counted loads -- conservative
         // waits, but they only stall loader waves.
@@ -582,6 +584,7 @@ __global__ __launch_bounds__(512, HAS_A2 ? 2 : 4) void gemm_ws_kernel(
                     hi0[i] = wi0[i] = 0;                                                           \
                     a_off[i] = (ar * K) * (long)sizeof(T) + kc * 16;                               \
                 }                                                                                  \
+                a2_off[i] = HAS_A2 ? (((cp.a2_rows > 0 ? ar % cp.a2_rows : ar) * K) * (long)sizeof(T) + kc * 16) : 0; \
             }                                                                                      \
         }
         uint4 raP0, raP1, raP2, raP3, rwP0, rwP1, rwP2, rwP3, rbP0, rbP1, rbP2, rbP3;
@@ -597,7 +600,7 @@ __global__ __launch_bounds__(512, HAS_A2 ? 2 : 4) void gemm_ws_kernel(
             ra##S##I = WS_LD16(ok_ ? Ab + a_off[I] + po_ : zero_line);                             \
         } else {                                                                                   \
             ra##S##I = WS_LD16(Ab + a_off[I] + (OFF));                                             \
-            if (HAS_A2) rb##S##I = WS_LD16(A2b + a_off[I] + (OFF));                                \
+            if (HAS_A2) rb##S##I = WS_LD16(A2b + a2_off[I] + (OFF));                               \
         }
 #define WS_GLOAD(S, KT)                                                                            \
         {                                                                                          \
@@ -865,9 +868,10 @@ static int launch_conv(const void* X, const void* W, const float* bias, const vo
 
 template <typename T, typename OutT>
 static int launch_gemm(const void* A, const void* A2, const void* W, const float* bias, const void* residual,
-                       const uint8_t* row_mask, void* C, int M, int N, int K, int flags, hipStream_t st)
+                       const uint8_t* row_mask, void* C, int M, int N, int K, int flags, hipStream_t st, int a2_rows = 0)
 {
-    const ConvP cp{};
+    ConvP cp{};
+    cp.a2_rows = a2_rows;
     const int nN = (N + BN - 1) / BN, nM = (M + BM - 1) / BM;
     const long nwg = (long)nM * nN;
     if (nwg > 0x7fffffffL) return DTLR_ESHAPE;
@@ -941,6 +945,27 @@ extern "C" int dtlr_gemm_nt(const void* A, const void* A2, const void* W, const 
         if (K % 32) return DTLR_ESHAPE;
         if (out_dtype == DTLR_F32) return launch_gemm<float, float>(A, A2, W, bias, residual, row_mask, C, M, N, K, flags, st);
         return DTLR_EDTYPE;
+    }
+    return DTLR_EDTYPE;
+}
+
+// dtlr_gemm_nt with a row-BROADCAST A2: A2 has a2_rows rows and row m of A is paired with row m % a2_rows (the encoder's
+// position embedding of an unpadded batch is the same [S, 256] matrix for every image: 2.8 MB that stays in L2 instead of a
+// second [B*S, 256] operand streamed from HBM).  bf16 in / bf16 out.
+extern "C" int dtlr_gemm_nt_a2bcast(const void* A, const void* A2, int a2_rows, const void* W, const float* bias, void* C,
+                                    int M, int N, int K, int dtype, void* stream)
+{
+    clear_stale_error();
+    if (!A || !A2 || !W || !C) return DTLR_EINVAL;
+    if (M <= 0 || N <= 0 || K <= 0 || a2_rows <= 0 || M % a2_rows) return DTLR_EINVAL;
+    const int flags = bias ? EPI_BIAS : 0;
+    if (dtype == DTLR_BF16) {
+        if (K % 64) return DTLR_ESHAPE;
+        return launch_gemm<uint16_t, uint16_t>(A, A2, W, bias, nullptr, nullptr, C, M, N, K, flags, (hipStream_t)stream, a2_rows);
+    }
+    if (dtype == DTLR_F32) {
+        if (K % 32) return DTLR_ESHAPE;
+        return launch_gemm<float, float>(A, A2, W, bias, nullptr, nullptr, C, M, N, K, flags, (hipStream_t)stream, a2_rows);
     }
     return DTLR_EDTYPE;
 }

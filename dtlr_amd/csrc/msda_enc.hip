@@ -17,6 +17,7 @@
 // Front end fused as in msda_fused_l4p4: softmax(16) + location arithmetic from the raw projection row.
 // Arithmetic order = the reference's (cuh:33-84,237-299): fp32 results agree to rounding.
 #include "dtlr_common.h"
+#include <cstdlib>
 
 namespace dtlr {
 
@@ -251,8 +252,209 @@ __device__ __forceinline__ void enc_queries_bf16(
     }
 }
 
-template <typename T, typename OT>
-__global__ __launch_bounds__(256, 2) void msda_enc_lds_kernel(
+
+// ---- bf16 query phase, second form: per-level accumulation in PACKED FP16 ------------------------------------------------
+// The first form spends 512 of its ~850 VALU instructions per lane on v_fma_mix_f32, one per (corner, channel).  The windows
+// already hold fp16 pairs, so v_pk_fma_f16 blends TWO channels of a corner per instruction: 256 instructions, 16 accumulator
+// registers instead of 32.  Precision: a lane only accumulates the 16 corner terms of ITS level in fp16 (weights sum to <= 1,
+// values O(1): ~2^-11 relative per term); the four levels are combined in fp32 in the quad reduce-scatter, and the result is
+// rounded to bf16 (2^-9) anyway.  The next query's projection row / reference point are loaded one iteration ahead (the first
+// form started every iteration with a dependent global load at two waves per SIMD), and the lower register count admits
+// NT = 512 threads per workgroup (4 waves per SIMD with two workgroups per CU).
+typedef _Float16 enc_h2_t __attribute__((ext_vector_type(2)));
+typedef float enc_f2_t __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ uint32_t pk_fma_h2(uint32_t w2, uint32_t d, uint32_t acc) {
+    uint32_t r;
+    asm("v_pk_fma_f16 %0, %1, %2, %3" : "=v"(r) : "v"(w2), "v"(d), "v"(acc));
+    return r;
+}
+__device__ __forceinline__ uint32_t h2_splat(float k) {
+    const enc_f2_t f = {k, k};
+    return __builtin_bit_cast(uint32_t, __builtin_convertvector(f, enc_h2_t));
+}
+template <int CTRL> __device__ __forceinline__ uint32_t quad_dpp_u(uint32_t v) {
+    return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, CTRL, 0xf, 0xf, false);
+}
+template <typename OT> struct RowRaw;                    // the lane's slice of the projection row, as loaded (conversion deferred)
+template <> struct RowRaw<uint16_t> {
+    uint4 off; uint2 lg;
+    __device__ __forceinline__ void load(const uint16_t* row, int M, int m, int p) {
+        off = *reinterpret_cast<const uint4*>(row + m * 32 + p * 8);
+        lg = *reinterpret_cast<const uint2*>(row + M * 32 + m * 16 + p * 4);
+    }
+    __device__ __forceinline__ void get(float (&o)[8], float (&l)[4]) const {
+        ET<uint16_t>::unpack(off, o);
+        l[0] = __uint_as_float(lg.x << 16); l[1] = __uint_as_float(lg.x & 0xffff0000u);
+        l[2] = __uint_as_float(lg.y << 16); l[3] = __uint_as_float(lg.y & 0xffff0000u);
+    }
+};
+template <> struct RowRaw<float> {
+    float4 o0, o1, l4;
+    __device__ __forceinline__ void load(const float* row, int M, int m, int p) {
+        o0 = reinterpret_cast<const float4*>(row + m * 32 + p * 8)[0];
+        o1 = reinterpret_cast<const float4*>(row + m * 32 + p * 8)[1];
+        l4 = *reinterpret_cast<const float4*>(row + M * 32 + m * 16 + p * 4);
+    }
+    __device__ __forceinline__ void get(float (&o)[8], float (&l)[4]) const {
+        o[0] = o0.x; o[1] = o0.y; o[2] = o0.z; o[3] = o0.w; o[4] = o1.x; o[5] = o1.y; o[6] = o1.z; o[7] = o1.w;
+        l[0] = l4.x; l[1] = l4.y; l[2] = l4.z; l[3] = l4.w;
+    }
+};
+
+template <typename OT, int NT>
+__device__ __forceinline__ void enc_queries_bf16_h(
+    const unsigned char* smem, const uint16_t* __restrict__ vimg, const OT* __restrict__ ow, const float* __restrict__ ref,
+    uint16_t* __restrict__ out, const EncLevels lv, const int (&qc0)[4], const int (&qn)[4], const int (&wc0)[4],
+    const int (&wc1)[4], const int (&qbase)[5], int nq, int S, int M, int m, int b)
+{
+    const int tid = threadIdx.x, p = tid & 3;
+    const int MD = M * 32;
+    const int Hl = p == 0 ? lv.H[0] : p == 1 ? lv.H[1] : p == 2 ? lv.H[2] : lv.H[3];
+    const int Wl = p == 0 ? lv.W[0] : p == 1 ? lv.W[1] : p == 2 ? lv.W[2] : lv.W[3];
+    const int startl = p == 0 ? lv.start[0] : p == 1 ? lv.start[1] : p == 2 ? lv.start[2] : lv.start[3];
+    const int loffl = p == 0 ? lv.loff[0] : p == 1 ? lv.loff[1] : p == 2 ? lv.loff[2] : lv.loff[3];
+    const int wstride = p == 0 ? lv.wmax[0] : p == 1 ? lv.wmax[1] : p == 2 ? lv.wmax[2] : lv.wmax[3];
+    const int wc0l = p == 0 ? wc0[0] : p == 1 ? wc0[1] : p == 2 ? wc0[2] : wc0[3];
+    const int wc1l = p == 0 ? wc1[0] : p == 1 ? wc1[1] : p == 2 ? wc1[2] : wc1[3];
+    const int wwl = wc1l - wc0l;
+    const float fH = (float)Hl, fW = (float)Wl;
+    const float invH = 1.0f / fH, invW = 1.0f / fW;
+    const unsigned char* win = smem + (long)loffl * 64;
+    const uint16_t* gsrc = vimg + (long)startl * MD;
+    int rot[4];
+#pragma unroll
+    for (int jj = 0; jj < 4; ++jj) rot[jj] = ((jj + p) & 3) * 16;
+
+    // token index of work item `it` (the query's position in the [B, S] token matrix)
+    auto token_of = [&](int it) -> long {
+        const int q = it >> 2;
+        int lq = 0;
+        if (q >= qbase[1]) lq = 1;
+        if (q >= qbase[2]) lq = 2;
+        if (q >= qbase[3]) lq = 3;
+        int r, nc, c0q, Wq, stq;
+        switch (lq) {
+        case 0: r = q - qbase[0]; nc = qn[0]; c0q = qc0[0]; Wq = lv.W[0]; stq = lv.start[0]; break;
+        case 1: r = q - qbase[1]; nc = qn[1]; c0q = qc0[1]; Wq = lv.W[1]; stq = lv.start[1]; break;
+        case 2: r = q - qbase[2]; nc = qn[2]; c0q = qc0[2]; Wq = lv.W[2]; stq = lv.start[2]; break;
+        default: r = q - qbase[3]; nc = qn[3]; c0q = qc0[3]; Wq = lv.W[3]; stq = lv.start[3]; break;
+        }
+        const int qi = r / nc, qj = c0q + r % nc;
+        return (long)b * S + stq + qi * Wq + qj;
+    };
+    const int total = nq * 4;
+    if (tid >= total) return;
+    long bq = token_of(tid);
+    RowRaw<OT> cur, nxt;
+    float2 rf, rf_n;
+    cur.load(ow + bq * (long)(M * 48), M, m, p);
+    rf = *reinterpret_cast<const float2*>(ref + bq * 8 + 2 * p);
+
+    for (int it = tid; it < total; it += NT) {
+        // issue the next item's loads before this item's arithmetic (clamped to a valid item: the last iteration re-reads its own)
+        const int itn = it + NT < total ? it + NT : it;
+        const long bqn = token_of(itn);
+        nxt.load(ow + bqn * (long)(M * 48), M, m, p);
+        rf_n = *reinterpret_cast<const float2*>(ref + bqn * 8 + 2 * p);
+
+        float off[8], lg[4];
+        cur.get(off, lg);
+        float mx = fmaxf(fmaxf(lg[0], lg[1]), fmaxf(lg[2], lg[3]));
+        mx = fmaxf(mx, quad_dpp<0xB1>(mx));
+        mx = fmaxf(mx, quad_dpp<0x4E>(mx));
+        float sum = 0.f;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) { lg[i] = __expf(lg[i] - mx); sum += lg[i]; }
+        sum += quad_dpp<0xB1>(sum);
+        sum += quad_dpp<0x4E>(sum);
+        const float inv = 1.0f / sum;
+
+        uint32_t acc[4][4];
+#pragma unroll
+        for (int jj = 0; jj < 4; ++jj)
+#pragma unroll
+            for (int i = 0; i < 4; ++i) acc[jj][i] = 0u;
+#define DTLR_ACC_H(D, W2)                                                                          \
+        _Pragma("unroll") for (int jj = 0; jj < 4; ++jj) {                                         \
+            acc[jj][0] = pk_fma_h2((W2), D[jj].x, acc[jj][0]);                                     \
+            acc[jj][1] = pk_fma_h2((W2), D[jj].y, acc[jj][1]);                                     \
+            acc[jj][2] = pk_fma_h2((W2), D[jj].z, acc[jj][2]);                                     \
+            acc[jj][3] = pk_fma_h2((W2), D[jj].w, acc[jj][3]);                                     \
+        }
+#pragma unroll
+        for (int pt = 0; pt < 4; ++pt) {
+            const float lx = rf.x + off[2 * pt] * invW;
+            const float ly = rf.y + off[2 * pt + 1] * invH;
+            const float h_im = ly * fH - 0.5f, w_im = lx * fW - 0.5f;
+            const bool inside = h_im > -1.f && w_im > -1.f && h_im < fH && w_im < fW;
+            const float hf = floorf(h_im), wf = floorf(w_im);
+            const int h_low = (int)fminf(fmaxf(hf, -1.f), fH), w_low = (int)fminf(fmaxf(wf, -1.f), fW);
+            const int h_high = h_low + 1, w_high = w_low + 1;
+            const float lh = h_im - hf, lw = w_im - wf, hh = 1.f - lh, hw = 1.f - lw;
+            const bool top = inside && h_low >= 0, bot = inside && h_high <= Hl - 1, left = w_low >= 0, right = w_high <= Wl - 1;
+            const int h0 = min(max(h_low, 0), Hl - 1), h1 = max(min(h_high, Hl - 1), 0);
+            const int w0 = min(max(w_low, 0), Wl - 1), w1c = max(min(w_high, Wl - 1), 0);
+            const bool staged = (w0 >= wc0l) && (w1c < wc1l);
+            const float a = lg[pt] * inv;
+            const uint32_t k1 = h2_splat((top && left) ? hh * hw * a : 0.f), k2 = h2_splat((top && right) ? hh * lw * a : 0.f);
+            const uint32_t k3 = h2_splat((bot && left) ? lh * hw * a : 0.f), k4 = h2_splat((bot && right) ? lh * lw * a : 0.f);
+            // two corners (one map row) at a time: 32 data registers in flight instead of 64, so that the kernel fits 128 VGPRs
+            // (four waves per SIMD); the scheduling barriers keep the compiler from hoisting the second row's reads
+            if (staged || !inside) {
+                const int a0 = min(max(w0 - wc0l, 0), wwl - 1), a1 = min(max(w1c - wc0l, 0), wwl - 1);
+                const unsigned char* r0 = win + (h0 * wstride) * 64;
+                const unsigned char* r1 = win + (h1 * wstride) * 64;
+                {
+                    uint4 d1[4], d2[4];
+#pragma unroll
+                    for (int jj = 0; jj < 4; ++jj) {
+                        d1[jj] = *reinterpret_cast<const uint4*>(r0 + a0 * 64 + rot[jj]);
+                        d2[jj] = *reinterpret_cast<const uint4*>(r0 + a1 * 64 + rot[jj]);
+                    }
+                    DTLR_ACC_H(d1, k1) DTLR_ACC_H(d2, k2)
+                }
+                __builtin_amdgcn_sched_barrier(0);
+                {
+                    uint4 d3[4], d4[4];
+#pragma unroll
+                    for (int jj = 0; jj < 4; ++jj) {
+                        d3[jj] = *reinterpret_cast<const uint4*>(r1 + a0 * 64 + rot[jj]);
+                        d4[jj] = *reinterpret_cast<const uint4*>(r1 + a1 * 64 + rot[jj]);
+                    }
+                    DTLR_ACC_H(d3, k3) DTLR_ACC_H(d4, k4)
+                }
+            } else {                                            // inside the map, outside the staged window: global path
+#pragma unroll
+                for (int jj = 0; jj < 4; ++jj) {
+                    const int pe = rot[jj] >> 1;
+                    const uint4 e1 = stage_convert<uint16_t>(*reinterpret_cast<const uint4*>(gsrc + (long)(h0 * Wl + w0) * MD + pe));
+                    const uint4 e2 = stage_convert<uint16_t>(*reinterpret_cast<const uint4*>(gsrc + (long)(h0 * Wl + w1c) * MD + pe));
+                    const uint4 e3 = stage_convert<uint16_t>(*reinterpret_cast<const uint4*>(gsrc + (long)(h1 * Wl + w0) * MD + pe));
+                    const uint4 e4 = stage_convert<uint16_t>(*reinterpret_cast<const uint4*>(gsrc + (long)(h1 * Wl + w1c) * MD + pe));
+                    acc[jj][0] = pk_fma_h2(k4, e4.x, pk_fma_h2(k3, e3.x, pk_fma_h2(k2, e2.x, pk_fma_h2(k1, e1.x, acc[jj][0]))));
+                    acc[jj][1] = pk_fma_h2(k4, e4.y, pk_fma_h2(k3, e3.y, pk_fma_h2(k2, e2.y, pk_fma_h2(k1, e1.y, acc[jj][1]))));
+                    acc[jj][2] = pk_fma_h2(k4, e4.z, pk_fma_h2(k3, e3.z, pk_fma_h2(k2, e2.z, pk_fma_h2(k1, e1.z, acc[jj][2]))));
+                    acc[jj][3] = pk_fma_h2(k4, e4.w, pk_fma_h2(k3, e3.w, pk_fma_h2(k2, e2.w, pk_fma_h2(k1, e1.w, acc[jj][3]))));
+                }
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        }
+#undef DTLR_ACC_H
+        // quad reduce-scatter in fp32: lane i's acc[jj] is piece (jj + i) & 3 of its level; lane i collects piece i of all four
+        float res[8];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const uint32_t t3 = quad_dpp_u<0x39>(acc[3][i]), t2 = quad_dpp_u<0x4E>(acc[2][i]), t1 = quad_dpp_u<0x93>(acc[1][i]);
+            res[2 * i] = fma_mix_lo(1.f, t1, fma_mix_lo(1.f, t2, fma_mix_lo(1.f, t3, fma_mix_lo(1.f, acc[0][i], 0.f))));
+            res[2 * i + 1] = fma_mix_hi(1.f, t1, fma_mix_hi(1.f, t2, fma_mix_hi(1.f, t3, fma_mix_hi(1.f, acc[0][i], 0.f))));
+        }
+        *reinterpret_cast<uint4*>(out + bq * MD + m * 32 + p * 8) = ET<uint16_t>::pack(res);
+        cur = nxt; rf = rf_n; bq = bqn;
+    }
+}
+
+template <typename T, typename OT, int VAR = 0, int NT = 256>
+__global__ __launch_bounds__(NT, NT / 128) void msda_enc_lds_kernel(
     const T* __restrict__ value, const OT* __restrict__ ow, const float* __restrict__ ref, T* __restrict__ out,
     EncLevels lv, int S, int M, int TW0, int R)
 {
@@ -290,12 +492,12 @@ __global__ __launch_bounds__(256, 2) void msda_enc_lds_kernel(
         unsigned char* dst = smem + (long)lv.loff[l] * PIX_BYTES;
         // 4 independent 16-byte loads in flight per lane before the first LDS store (a plain
         // load->store loop is one serialized L2/HBM round trip per chunk: ~19 per thread per workgroup)
-        for (int c0 = tid; c0 < nchunk; c0 += 256 * 4) {
+        for (int c0 = tid; c0 < nchunk; c0 += NT * 4) {
             uint4 d[4];
             int dst_off[4];
 #pragma unroll
             for (int u = 0; u < 4; ++u) {
-                const int c = min(c0 + 256 * u, nchunk - 1);               // clamp: tail lanes re-read a valid chunk
+                const int c = min(c0 + NT * u, nchunk - 1);                // clamp: tail lanes re-read a valid chunk
                 const int part = c % CP, pc = c / CP;
                 const int col = pc % ww, row = pc / ww;
                 d[u] = *reinterpret_cast<const uint4*>(src + (long)(row * lv.W[l] + wc0[l] + col) * MD + part * VEC);
@@ -303,15 +505,17 @@ __global__ __launch_bounds__(256, 2) void msda_enc_lds_kernel(
             }
 #pragma unroll
             for (int u = 0; u < 4; ++u)
-                if (c0 + 256 * u < nchunk) *reinterpret_cast<uint4*>(dst + dst_off[u]) = stage_convert<T>(d[u]);
+                if (c0 + NT * u < nchunk) *reinterpret_cast<uint4*>(dst + dst_off[u]) = stage_convert<T>(d[u]);
         }
     }
     __syncthreads();
 
     if constexpr (sizeof(T) == 2) {
-        enc_queries_bf16<OT>(smem, vimg, ow, ref, out, lv, qc0, qn, wc0, wc1, qbase, nq, S, M, m, b);
+        if constexpr (VAR == 0) enc_queries_bf16<OT>(smem, vimg, ow, ref, out, lv, qc0, qn, wc0, wc1, qbase, nq, S, M, m, b);
+        else enc_queries_bf16_h<OT, NT>(smem, vimg, ow, ref, out, lv, qc0, qn, wc0, wc1, qbase, nq, S, M, m, b);
         return;
     }
+    static_assert(sizeof(T) == 2 || NT == 256, "the fp32 query phase strides by 256");
     // ---- queries: CP lanes per query (16 bytes = VEC channels each) ---------------------------------
     for (int it = tid; it < nq * CP; it += 256) {
         const int part = it % CP, q = it / CP;
@@ -465,18 +669,33 @@ static bool make_plan(const int* hw, int elem, int R, EncPlan& pl) {
     return false;
 }
 
-template <typename T, typename OT>
+template <typename T, typename OT, int VAR = 0, int NT = 256>
 static int launch_enc(const void* value, const void* ow, const float* ref, void* out, const EncPlan& pl, int N, int M, hipStream_t st) {
     static DevOnce attr;
-    if (attr.first()) { (void)hipFuncSetAttribute((const void*)msda_enc_lds_kernel<T, OT>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); }
-    hipLaunchKernelGGL((msda_enc_lds_kernel<T, OT>), dim3(pl.ntiles, M, N), dim3(256), pl.lds, st,
+    if (attr.first()) { (void)hipFuncSetAttribute((const void*)msda_enc_lds_kernel<T, OT, VAR, NT>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); }
+    hipLaunchKernelGGL((msda_enc_lds_kernel<T, OT, VAR, NT>), dim3(pl.ntiles, M, N), dim3(NT), pl.lds, st,
                        (const T*)value, (const OT*)ow, ref, (T*)out, pl.lv, pl.S, M, pl.TW0, pl.R);
     return check_launch();
+}
+// bf16 query-phase variant: env DTLR_MSDA_ENC_V = 0 first form (fp32 accumulators, v_fma_mix), 1 packed-fp16 form with 256 threads,
+// 2 the same with 512 threads per workgroup (default); read once per process.
+static int g_enc_variant = -1;
+static int enc_variant() {
+    if (g_enc_variant < 0) { const char* e = getenv("DTLR_MSDA_ENC_V"); g_enc_variant = e ? atoi(e) : 2; }
+    return g_enc_variant;
 }
 
 }  // namespace dtlr
 
 using namespace dtlr;
+
+// tuning / measurement knob (tools/msda_sweep.py): select the bf16 query-phase form for subsequent launches; returns the previous value
+extern "C" int dtlr_msda_encoder_set_variant(int v)
+{
+    const int old = enc_variant();
+    if (v >= 0 && v <= 2) g_enc_variant = v;
+    return old;
+}
 
 // 1 when the LDS window plan of dtlr_msda_encoder_forward fits these level shapes (full-height column windows + halo of all four
 // levels within 160 KB), 0 when it does not (tall canvases: the caller then uses the gather kernel, dtlr_msda_fused_forward,
@@ -502,7 +721,15 @@ extern "C" int dtlr_msda_encoder_forward(const void* value, const void* ow, cons
     if (!make_plan(level_hw, elem, halo, pl)) return DTLR_ESHAPE;
     hipStream_t st = (hipStream_t)stream;
     if (dtype == DTLR_F32 && ow_dtype == DTLR_F32) return launch_enc<float, float>(value, ow, ref, out, pl, N, M, st);
-    if (dtype == DTLR_BF16 && ow_dtype == DTLR_F32) return launch_enc<uint16_t, float>(value, ow, ref, out, pl, N, M, st);
-    if (dtype == DTLR_BF16 && ow_dtype == DTLR_BF16) return launch_enc<uint16_t, uint16_t>(value, ow, ref, out, pl, N, M, st);
+    if (dtype == DTLR_BF16 && ow_dtype == DTLR_F32) {
+        if (enc_variant() == 0) return launch_enc<uint16_t, float>(value, ow, ref, out, pl, N, M, st);
+        if (enc_variant() == 1) return launch_enc<uint16_t, float, 1, 256>(value, ow, ref, out, pl, N, M, st);
+        return launch_enc<uint16_t, float, 1, 512>(value, ow, ref, out, pl, N, M, st);
+    }
+    if (dtype == DTLR_BF16 && ow_dtype == DTLR_BF16) {
+        if (enc_variant() == 0) return launch_enc<uint16_t, uint16_t>(value, ow, ref, out, pl, N, M, st);
+        if (enc_variant() == 1) return launch_enc<uint16_t, uint16_t, 1, 256>(value, ow, ref, out, pl, N, M, st);
+        return launch_enc<uint16_t, uint16_t, 1, 512>(value, ow, ref, out, pl, N, M, st);
+    }
     return DTLR_EDTYPE;
 }

@@ -274,6 +274,8 @@ class DTLREngine:
         """TransformerEncoder.forward + DeformableTransformerEncoderLayer.forward
         (deformable_transformer.py:494-580, 804-823)."""
         pos = g["pos"]                                   # already in the engine dtype, level_embed added
+        if not g["has_padding"]:
+            pos = pos[0]                                 # unpadded batch: one [S, 256] matrix for every image (L2-resident A2 operand)
         for n in range(self.cfg.enc_layers):
             q = f"enc{n}."
             a = self._msda_module(q + "attn", src, pos, g["enc_ref"], src, g, self.cfg.enc_n_points)

@@ -72,6 +72,25 @@ def linear(x, w, b=None, relu=False, residual=None, a2=None, row_mask=None, out_
     N = w.shape[0]
     out_dtype = out_dtype or x.dtype
     slab = 64 if x.dtype == torch.bfloat16 else 32
+    if a2 is not None and a2.numel() != x.numel():
+        # row-broadcast A2 ([S, K] against [B, S, K]: the position embedding of an unpadded batch): its own entry point
+        if not (x.dtype in (torch.bfloat16, torch.float32) and w.dtype == x.dtype and a2.dtype == x.dtype and out_dtype == x.dtype and K % slab == 0
+                and not relu and residual is None and row_mask is None and a2.shape[-1] == K and (x.numel() // K) % (a2.numel() // K) == 0):
+            raise _lib.DTLRError("ops.linear: a row-broadcast a2 needs same-dtype operands, K a slab multiple, M a multiple of a2's rows, "
+                                 "and no ReLU / residual / row mask")
+        x = x if x.is_contiguous() else x.contiguous()
+        a2 = a2 if a2.is_contiguous() else a2.contiguous()
+        if b is not None and b.dtype != torch.float32:
+            b = b.float()
+        M, R2 = x.numel() // K, a2.numel() // K
+        y = torch.empty(x.shape[:-1] + (N,), dtype=out_dtype, device=x.device)
+        es = x.element_size()
+        with _Timed("gemm_bf16" if x.dtype == torch.bfloat16 else "gemm_f32", 2.0 * M * N * K,
+                    float(M) * K * es + float(R2) * K * es + float(N) * K * es + float(M) * N * es, f"linear M{M} N{N} K{K}+a2bcast{R2}"):
+            code = _lib.lib().dtlr_gemm_nt_a2bcast(x.data_ptr(), a2.data_ptr(), R2, w.data_ptr(), 0 if b is None else b.data_ptr(), y.data_ptr(),
+                                                   M, N, K, _DT[x.dtype], _lib.current_stream())
+        _lib.check(code, "dtlr_gemm_nt_a2bcast")
+        return y
     if x.dtype in (torch.bfloat16, torch.float32) and w.dtype == x.dtype and K % slab == 0 \
             and (x.dtype == torch.bfloat16 or out_dtype == torch.float32):
         x = x if x.is_contiguous() else x.contiguous()

@@ -92,6 +92,10 @@ int dtlr_msda_encoder_forward(const void *value, const void *ow, const float *re
 /* 1 if the LDS window plan of dtlr_msda_encoder_forward fits these level shapes, 0 if not (canvases taller than ~270 px in
  * fp32 / ~550 px in bf16: use dtlr_msda_fused_forward, which has no size limit), negative DTLR_E* on bad arguments. */
 int dtlr_msda_encoder_plan_ok(const int *level_hw /* host, 8 ints */, int dtype, int halo);
+/* Measurement knob: bf16 query-phase form of dtlr_msda_encoder_forward for subsequent launches (0 = fp32 accumulators /
+ * v_fma_mix_f32, 1 = per-level packed-fp16 accumulation with 256-thread workgroups, 2 = the same with 512 threads: the default;
+ * env DTLR_MSDA_ENC_V sets the initial value).  Returns the previous value; v outside 0..2 only queries. */
+int dtlr_msda_encoder_set_variant(int v);
 
 /* ---------------------------------------------------------------------------------------------
  * y = LayerNorm(x [+ residual]) * gamma + beta over rows of C channels (C multiple of 256).
@@ -177,6 +181,12 @@ int dtlr_gemm_nt(const void *A, const void *A2, const void *W, const float *bias
  * written.  Replaces: enc_outputs_class_unselected.max(-1)[0] (models/dino/deformable_transformer.py:341-345: only the
  * per-token maximum of the two-stage class head feeds torch.topk).  A [M,K], W [N,K] in_dtype (F32: K % 32 == 0, BF16:
  * K % 64 == 0), bias [N] fp32 or NULL, rowmax [M] fp32 (every element written; a row whose products are all -inf stays -inf). */
+/* dtlr_gemm_nt with a row-broadcast A2 prologue: C = (A + A2[m % a2_rows]) . W^T + bias.  A2 [a2_rows, K]; M % a2_rows == 0.
+ * Replaces: `with_pos_embed(src, pos)` feeding sampling_offsets / attention_weights (models/dino/deformable_transformer.py:
+ * 797-812, ops/modules/ms_deform_attn.py:97-98) when the batch is unpadded: the position embedding is then the same [S,256]
+ * matrix for every image and stays L2-resident.  dtype F32 or BF16 (operands and result). */
+int dtlr_gemm_nt_a2bcast(const void *A, const void *A2, int a2_rows, const void *W, const float *bias, void *C,
+                         int M, int N, int K, int dtype, void *stream);
 int dtlr_gemm_nt_rowmax(const void *A, const void *W, const float *bias, float *rowmax,
                         int M, int N, int K, int in_dtype, void *stream);
 

@@ -814,3 +814,17 @@ def test_tall_canvas_falls_back_to_gather_msda_and_global_topk():
     ref = O.dino_forward(sd, cfg, imgs, forced_topk=out["_debug"]["topk_idx"].cpu())
     assert (out["pred_logits"].cpu() - ref["pred_logits"]).abs().max() < 1e-3
     assert (out["pred_boxes"].cpu() - ref["pred_boxes"]).abs().max() < 1e-4
+
+
+@pytest.mark.parametrize("dt", [torch.bfloat16, torch.float32])
+def test_linear_row_broadcast_a2(dt):
+    """(x + a2[m % S]) @ w.T + b with a2 = one [S, K] matrix shared by every image of the batch == the full-size a2 path."""
+    from dtlr_amd import ops
+    B, S, K, N = 3, 333, 256, 384
+    x, a2 = _rand((B, S, K), 1).to(dt), _rand((S, K), 2).to(dt)
+    w, b = _rand((N, K), 3, 0.1).to(dt), _rand((N,), 4)
+    got = ops.linear(x.cuda(), w.cuda(), b.cuda(), a2=a2.cuda())
+    full = ops.linear(x.cuda(), w.cuda(), b.cuda(), a2=a2[None].expand(B, -1, -1).contiguous().cuda())
+    assert torch.equal(got, full)
+    want = ((x.float() + a2.float()[None]).to(dt).float() @ w.float().t() + b)
+    assert (got.float().cpu() - want).abs().max() < (2e-4 if dt == torch.float32 else 0.05)
