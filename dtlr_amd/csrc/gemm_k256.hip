@@ -1,0 +1,247 @@
+// Weight-resident projection GEMM for K = 256 (bf16):   C[M, N] = epi( A[M, 256] . W[N, 256]^T ),  N = 256 or 384.
+//
+// The encoder's value / [offsets|weights] projections and the decoder's batched value projection (SURVEY.md appendix C:
+// T x 256 x 256, T x 256 x 384, T x 256 x 1536 with T = 174,080 tokens) move 512 bytes in and 512..768 bytes out per token
+// for 131..197 kflop: they are HBM streams, and the tiled kernel (gemm.hip: 128x128 tiles, 4 K-slabs per tile, an epilogue
+// during which its loader waves stall) holds them at 3.3-3.8 TB/s of compulsory bytes.  Here the roles are turned around:
+//   * the WEIGHT is the resident operand: wave w of the 8 keeps its N/8 output channels x 256 k as MFMA A-fragments in
+//     registers for the whole kernel (64 VGPRs at N = 256, 96 at N = 384), loaded once per workgroup from L2;
+//   * TOKENS stream: tiles of 64 tokens (32 KB) are DMA'd global -> LDS (global_load_lds_dwordx4: no VGPR staging, no
+//     ds_write pass) through a 4-stage ring, three tiles in flight per CU; every DMA instruction reads 8 rows x 128 bytes
+//     (full lines).  The 16-byte chunks of a row are permuted on the SOURCE side (chunk c of row r lands in slot c ^ r of its
+//     128-byte LDS row) so that the B-fragment reads of the 16x16x32 MFMA -- 16 tokens x 4 k-chunks per ds_read_b128 group --
+//     hit 16 distinct 16-byte slots (cdna_hip_programming.md rule 21: linear destination, permuted source, same permutation
+//     on the read);
+//   * one barrier per 64 tokens (publishes the tile, frees the stage read two barriers ago); no K loop state, no tile
+//     epilogue stall: a wave's accumulators ARE its output slice of the tile (C^T layout: a lane holds 4 consecutive channels
+//     of one token), rounded, paired with v_permlane16_swap into 16-byte stores exactly like gemm.hip's epilogue;
+//   * persistent: one workgroup per CU walks a contiguous run of token tiles.
+// Epilogue options: + bias[N] (fp32); + R[(m % res_rows), :] (bf16, row-broadcast: the encoder's pos . W^T term of an
+// unpadded batch, see engine.py); rows with row_mask[m] != 0 written as zeros (value.masked_fill, ms_deform_attn.py:95-96);
+// C row stride ldc >= N (column slices of a wider matrix: the six decoder value projections share one [T, 1536] buffer).
+// HBM-bound by construction: per CU and 64-token tile 64..80 KB of traffic against 64..96 MFMAs per wave.
+#include "dtlr_common.h"
+
+namespace dtlr {
+
+typedef __attribute__((ext_vector_type(8))) __bf16 k2_bf16x8_t;
+typedef __attribute__((ext_vector_type(4))) float k2_f32x4_t;
+
+constexpr int K2_TOK = 64;                       // tokens per stage
+constexpr int K2_STAGE = K2_TOK * 512;           // 32 KB
+constexpr int K2_NS = 4;                         // ring stages
+constexpr int K2_LDS = K2_NS * K2_STAGE;         // 128 KB: one workgroup per CU
+
+// LDS-DMA, 64 lanes x 16 bytes: destination = wave-uniform LDS byte address + 16 * lane (counted by hand: section 5.7)
+__device__ __forceinline__ void k2_glds16(const void* gsrc, unsigned lds_dst) {
+    unsigned keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep) : "v"(gsrc), "s"(lds_dst) : "memory");
+}
+__device__ __forceinline__ uint4 k2_load16(const void* p) {
+    uint4 r;
+    asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(r) : "v"(p) : "memory");
+    return r;
+}
+__device__ __forceinline__ uint2 k2_load8(const void* p) {
+    uint2 r;
+    asm volatile("global_load_dwordx2 %0, %1, off" : "=v"(r) : "v"(p) : "memory");
+    return r;
+}
+__device__ __forceinline__ unsigned k2_load_u8(const void* p) {
+    unsigned r;
+    asm volatile("global_load_ubyte %0, %1, off" : "=v"(r) : "v"(p) : "memory");
+    return r;
+}
+__device__ __forceinline__ k2_f32x4_t k2_mma(const uint4& a, const uint4& b, k2_f32x4_t c) {
+    return __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(k2_bf16x8_t, a), __builtin_bit_cast(k2_bf16x8_t, b), c, 0, 0, 0);
+}
+template <int N> __device__ __forceinline__ void k2_wait() {
+    if constexpr (N == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    else if constexpr (N == 4) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+    else if constexpr (N == 16) asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
+    else if constexpr (N == 24) asm volatile("s_waitcnt vmcnt(24)" ::: "memory");
+    else static_assert(N < 0, "unsupported count");
+    __builtin_amdgcn_sched_barrier(0);
+}
+
+// NRT = 16-channel row tiles per wave: N = 128 * NRT (2 -> 256, 3 -> 384).  Wp: the weight in fragment order (dtlr_k256_pack:
+// block ((wave * NRT + rt) * 8 + ks) = 64 lanes x 8 elements, lane (m = l & 15, g = l >> 4) <- W[(wave*NRT + rt)*16 + m][32 ks + 8 g ..]).
+template <int NRT, bool RES>
+__global__ __launch_bounds__(512, 2) void gemm_k256_kernel(
+    const uint16_t* __restrict__ A, const uint16_t* __restrict__ Wp, const float* __restrict__ bias,
+    const uint16_t* __restrict__ resid, int res_rows, const uint8_t* __restrict__ row_mask,
+    uint16_t* __restrict__ C, int ldc, int M, int tiles_per_wg)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char k2_smem[];
+    const unsigned lds_base = (unsigned)(size_t)(__attribute__((address_space(3))) unsigned char*)k2_smem;
+    constexpr int N = 128 * NRT;
+    constexpr int E = (NRT / 2) * 4 + (NRT & 1) * 4;          // global stores per tile per wave (16-byte pairs + 8-byte odd tile)
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const int n = lane & 15, g = lane >> 4;
+    const int ntiles = (M + K2_TOK - 1) / K2_TOK;
+    const int t_begin = (int)blockIdx.x * tiles_per_wg;
+    const int t_end = min(t_begin + tiles_per_wg, ntiles);
+    if (t_begin >= t_end) return;
+    const int nt = t_end - t_begin;
+
+    // ---- DMA of token tile t into ring slot: 32 blocks of 8 rows x 128 B; this wave issues blocks j = 4 wave + u ------------
+    const int dr = lane >> 3, dc = (lane & 7) ^ dr;           // row within the block; SOURCE chunk that lands in slot (lane & 7)
+    auto issue = [&](int t, int slot) {
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int j = 4 * wave + u, tt8 = j >> 2, kb = j & 3;
+            const long tok = min((long)t * K2_TOK + tt8 * 8 + dr, (long)M - 1);
+            k2_glds16(A + tok * 256 + kb * 64 + dc * 8, lds_base + (unsigned)(slot * K2_STAGE + j * 1024));
+        }
+    };
+    // prologue: up to three tiles in flight, then the resident operand
+    issue(t_begin, 0);
+    if (nt > 1) issue(t_begin + 1, 1);
+    if (nt > 2) issue(t_begin + 2, 2);
+    uint4 wf[NRT][8];
+#pragma unroll
+    for (int rt = 0; rt < NRT; ++rt)
+#pragma unroll
+        for (int ks = 0; ks < 8; ++ks) wf[rt][ks] = k2_load16(Wp + ((long)((wave * NRT + rt) * 8 + ks) * 64 + lane) * 8);
+    float4 bv[NRT];
+#pragma unroll
+    for (int rt = 0; rt < NRT; ++rt)
+        bv[rt] = bias ? *reinterpret_cast<const float4*>(bias + (wave * NRT + rt) * 16 + 4 * g) : make_float4(0.f, 0.f, 0.f, 0.f);
+    k2_wait<0>();
+
+    // B-fragment read addresses: token tile tt, k-step ks: block (2 tt + (n >> 3), ks >> 1), row n & 7, slot ((ks & 1) * 4 + g) ^ (n & 7)
+    const unsigned rd0 = (unsigned)((n >> 3) * 4096 + (n & 7) * 128 + ((g ^ (n & 7)) * 16));
+    const unsigned rd1 = (unsigned)((n >> 3) * 4096 + (n & 7) * 128 + (((4 + g) ^ (n & 7)) * 16));
+
+    for (int i = 0; i < nt; ++i) {
+        const int t = t_begin + i;
+        const int slot = i & 3;
+        __builtin_amdgcn_s_barrier();                         // tile i published by every wave; stage (i + 3) & 3 no longer read
+        // row-wise epilogue operands of this tile first (they must be OLDER than the next DMA group: waited with vmcnt(4))
+        uint2 rs[NRT][4];
+        unsigned msk[4];
+        if constexpr (RES) {
+#pragma unroll
+            for (int tt = 0; tt < 4; ++tt) {
+                const long tok = min((long)t * K2_TOK + tt * 16 + n, (long)M - 1);
+                const long rr = tok % res_rows;
+#pragma unroll
+                for (int rt = 0; rt < NRT; ++rt) rs[rt][tt] = k2_load8(resid + rr * N + (wave * NRT + rt) * 16 + 4 * g);
+            }
+        }
+        if (row_mask) {
+#pragma unroll
+            for (int tt = 0; tt < 4; ++tt) msk[tt] = k2_load_u8(row_mask + min((long)t * K2_TOK + tt * 16 + n, (long)M - 1));
+        }
+        if (i + 3 < nt) issue(t + 3, (i + 3) & 3);
+
+        k2_f32x4_t acc[NRT][4];
+#pragma unroll
+        for (int rt = 0; rt < NRT; ++rt)
+#pragma unroll
+            for (int tt = 0; tt < 4; ++tt) acc[rt][tt] = k2_f32x4_t{0.f, 0.f, 0.f, 0.f};
+        const unsigned char* sb = k2_smem + slot * K2_STAGE;
+#pragma unroll
+        for (int ks = 0; ks < 8; ++ks) {
+            uint4 bf[4];
+#pragma unroll
+            for (int tt = 0; tt < 4; ++tt)
+                bf[tt] = *reinterpret_cast<const uint4*>(sb + ((ks & 1) ? rd1 : rd0) + tt * 8192 + (ks >> 1) * 1024);
+#pragma unroll
+            for (int rt = 0; rt < NRT; ++rt)
+#pragma unroll
+                for (int tt = 0; tt < 4; ++tt) acc[rt][tt] = k2_mma(wf[rt][ks], bf[tt], acc[rt][tt]);
+        }
+        // ---- epilogue: bias, broadcast residual, padding rows, bf16, paired 16-byte stores ---------------------------------
+        if constexpr (RES) { if (i + 3 < nt) k2_wait<4>(); else k2_wait<0>(); }
+        else if (row_mask) { if (i + 3 < nt) k2_wait<4>(); else k2_wait<0>(); }
+#pragma unroll
+        for (int tt = 0; tt < 4; ++tt) {
+            const long tok = (long)t * K2_TOK + tt * 16 + n;
+            const bool live = tok < M;
+            const bool zero = row_mask && msk[tt];
+            uint32_t pk_lo = 0, pk_hi = 0;
+#pragma unroll
+            for (int rt = 0; rt < NRT; ++rt) {
+                float v[4] = {acc[rt][tt][0] + bv[rt].x, acc[rt][tt][1] + bv[rt].y, acc[rt][tt][2] + bv[rt].z, acc[rt][tt][3] + bv[rt].w};
+                if constexpr (RES) {
+                    v[0] += __uint_as_float(rs[rt][tt].x << 16); v[1] += __uint_as_float(rs[rt][tt].x & 0xffff0000u);
+                    v[2] += __uint_as_float(rs[rt][tt].y << 16); v[3] += __uint_as_float(rs[rt][tt].y & 0xffff0000u);
+                }
+                if (zero) { v[0] = v[1] = v[2] = v[3] = 0.f; }
+                const uint32_t lo = pack_bf16x2(v[0], v[1]), hi = pack_bf16x2(v[2], v[3]);
+                if ((rt & 1) == 0 && rt + 1 < NRT) { pk_lo = lo; pk_hi = hi; }
+                else if (rt & 1) {
+                    // pair the row tiles (rt - 1, rt): exchange halves between lane rows g and g ^ 1 -> a lane owns 8 consecutive channels
+                    const auto s0 = __builtin_amdgcn_permlane16_swap(pk_lo, lo, false, false);
+                    const auto s1 = __builtin_amdgcn_permlane16_swap(pk_hi, hi, false, false);
+                    uint16_t* dst = C + tok * (long)ldc + (wave * NRT + rt - 1 + (g & 1)) * 16 + 8 * (g >> 1);
+                    if (live) *reinterpret_cast<uint4*>(dst) = make_uint4(s0[0], s1[0], s0[1], s1[1]);
+                } else {                                      // odd NRT: the last row tile alone, 8-byte stores
+                    uint16_t* dst = C + tok * (long)ldc + (wave * NRT + rt) * 16 + 4 * g;
+                    if (live) *reinterpret_cast<uint2*>(dst) = make_uint2(lo, hi);
+                }
+            }
+        }
+        // tile i + 1 must have landed (mine) before the next barrier: everything but the two newest DMA groups and the
+        // stores issued around them may stay in flight
+        if (i + 3 < nt) k2_wait<2 * E + 8 <= 16 ? 16 : 24>();
+        else k2_wait<0>();
+    }
+}
+
+}  // namespace dtlr
+
+using namespace dtlr;
+
+// W [N, 256] row-major bf16 (host memory) -> fragment order (host memory, N * 256 elements).
+extern "C" int dtlr_k256_pack_weights(const unsigned short* w_host, unsigned short* wp_host, int N)
+{
+    if (!w_host || !wp_host) return DTLR_EINVAL;
+    if (N != 256 && N != 384) return DTLR_ESHAPE;
+    const int NRT = N / 128;
+    for (int wave = 0; wave < 8; ++wave)
+        for (int rt = 0; rt < NRT; ++rt)
+            for (int ks = 0; ks < 8; ++ks)
+                for (int lane = 0; lane < 64; ++lane) {
+                    const int m = lane & 15, g = lane >> 4;
+                    const int row = (wave * NRT + rt) * 16 + m;
+                    for (int e = 0; e < 8; ++e)
+                        wp_host[((long)((wave * NRT + rt) * 8 + ks) * 64 + lane) * 8 + e] = w_host[(long)row * 256 + ks * 32 + g * 8 + e];
+                }
+    return DTLR_OK;
+}
+
+extern "C" int dtlr_gemm_k256(const void* A, const void* Wp, const float* bias, const void* resid, int res_rows,
+                              const unsigned char* row_mask, void* C, int ldc, int M, int N, void* stream)
+{
+    clear_stale_error();
+    if (!A || !Wp || !C) return DTLR_EINVAL;
+    if (M <= 0 || ldc < N || (ldc & 7)) return DTLR_EINVAL;
+    if (resid && (res_rows <= 0)) return DTLR_EINVAL;
+    if (N != 256 && N != 384) return DTLR_ESHAPE;
+    const int ntiles = (M + K2_TOK - 1) / K2_TOK;
+    int ncu = 256;
+    {
+        static int cached = 0;
+        if (!cached) { int d = 0; hipDeviceProp_t p; if (hipGetDevice(&d) == hipSuccess && hipGetDeviceProperties(&p, d) == hipSuccess && p.multiProcessorCount > 0) cached = p.multiProcessorCount; else cached = 256; (void)hipGetLastError(); }
+        ncu = cached;
+    }
+    const int grid = ntiles < ncu ? ntiles : ncu;
+    const int per = (ntiles + grid - 1) / grid;
+    const int g2 = (ntiles + per - 1) / per;
+    hipStream_t st = (hipStream_t)stream;
+#define K2_LAUNCH(NRT, RES)                                                                        \
+    {                                                                                              \
+        static DevOnce once;                                                                       \
+        if (once.first()) { (void)hipFuncSetAttribute((const void*)gemm_k256_kernel<NRT, RES>, hipFuncAttributeMaxDynamicSharedMemorySize, K2_LDS); (void)hipGetLastError(); } \
+        hipLaunchKernelGGL((gemm_k256_kernel<NRT, RES>), dim3(g2), dim3(512), K2_LDS, st, (const uint16_t*)A, (const uint16_t*)Wp, bias, \
+                           (const uint16_t*)resid, res_rows, row_mask, (uint16_t*)C, ldc, M, per);  \
+    }
+    if (N == 256) { if (resid) K2_LAUNCH(2, true) else K2_LAUNCH(2, false) }
+    else { if (resid) K2_LAUNCH(3, true) else K2_LAUNCH(3, false) }
+#undef K2_LAUNCH
+    return check_launch();
+}

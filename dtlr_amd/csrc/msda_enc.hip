@@ -303,7 +303,7 @@ template <> struct RowRaw<float> {
 
 template <typename OT, int NT>
 __device__ __forceinline__ void enc_queries_bf16_h(
-    const unsigned char* smem, const uint16_t* __restrict__ vimg, const OT* __restrict__ ow, const float* __restrict__ ref,
+    const unsigned char* smem, const int* tok, const uint16_t* __restrict__ vimg, const OT* __restrict__ ow, const float* __restrict__ ref,
     uint16_t* __restrict__ out, const EncLevels lv, const int (&qc0)[4], const int (&qn)[4], const int (&wc0)[4],
     const int (&wc1)[4], const int (&qbase)[5], int nq, int S, int M, int m, int b)
 {
@@ -325,23 +325,9 @@ __device__ __forceinline__ void enc_queries_bf16_h(
 #pragma unroll
     for (int jj = 0; jj < 4; ++jj) rot[jj] = ((jj + p) & 3) * 16;
 
-    // token index of work item `it` (the query's position in the [B, S] token matrix)
-    auto token_of = [&](int it) -> long {
-        const int q = it >> 2;
-        int lq = 0;
-        if (q >= qbase[1]) lq = 1;
-        if (q >= qbase[2]) lq = 2;
-        if (q >= qbase[3]) lq = 3;
-        int r, nc, c0q, Wq, stq;
-        switch (lq) {
-        case 0: r = q - qbase[0]; nc = qn[0]; c0q = qc0[0]; Wq = lv.W[0]; stq = lv.start[0]; break;
-        case 1: r = q - qbase[1]; nc = qn[1]; c0q = qc0[1]; Wq = lv.W[1]; stq = lv.start[1]; break;
-        case 2: r = q - qbase[2]; nc = qn[2]; c0q = qc0[2]; Wq = lv.W[2]; stq = lv.start[2]; break;
-        default: r = q - qbase[3]; nc = qn[3]; c0q = qc0[3]; Wq = lv.W[3]; stq = lv.start[3]; break;
-        }
-        const int qi = r / nc, qj = c0q + r % nc;
-        return (long)b * S + stq + qi * Wq + qj;
-    };
+    // token index of work item `it`: a table the workgroup filled while staging (the integer divisions that map a tile-local
+    // query number to (level, row, column) cost ~60 VALU instructions per lookup when done in the loop)
+    auto token_of = [&](int it) -> long { return (long)b * S + tok[it >> 2]; };
     const int total = nq * 4;
     if (tid >= total) return;
     long bq = token_of(tid);
@@ -456,7 +442,7 @@ __device__ __forceinline__ void enc_queries_bf16_h(
 template <typename T, typename OT, int VAR = 0, int NT = 256>
 __global__ __launch_bounds__(NT, NT / 128) void msda_enc_lds_kernel(
     const T* __restrict__ value, const OT* __restrict__ ow, const float* __restrict__ ref, T* __restrict__ out,
-    EncLevels lv, int S, int M, int TW0, int R)
+    EncLevels lv, int S, int M, int TW0, int R, int tok_off)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     constexpr int VEC = ET<T>::VEC, CP = ET<T>::CP;
@@ -481,6 +467,19 @@ __global__ __launch_bounds__(NT, NT / 128) void msda_enc_lds_kernel(
         qbase[l + 1] = qbase[l] + lv.H[l] * qn[l];
     }
     const int nq = qbase[4];
+    if constexpr (VAR != 0) {
+        // token table of this tile: tile-local query number -> token index inside the image (read by the query phase)
+        int* tok = reinterpret_cast<int*>(smem + tok_off);
+        for (int q = tid; q < nq; q += NT) {
+            const int lq = q >= qbase[3] ? 3 : q >= qbase[2] ? 2 : q >= qbase[1] ? 1 : 0;
+            const int r = q - (lq == 3 ? qbase[3] : lq == 2 ? qbase[2] : lq == 1 ? qbase[1] : 0);
+            const int nc = lq == 3 ? qn[3] : lq == 2 ? qn[2] : lq == 1 ? qn[1] : qn[0];
+            const int c0q = lq == 3 ? qc0[3] : lq == 2 ? qc0[2] : lq == 1 ? qc0[1] : qc0[0];
+            const int Wq = lq == 3 ? lv.W[3] : lq == 2 ? lv.W[2] : lq == 1 ? lv.W[1] : lv.W[0];
+            const int stq = lq == 3 ? lv.start[3] : lq == 2 ? lv.start[2] : lq == 1 ? lv.start[1] : lv.start[0];
+            tok[q] = stq + (r / nc) * Wq + c0q + r % nc;
+        }
+    }
 
     // ---- stage the four windows of head m: coalesced 16-byte chunks, CP chunks per pixel ------------
     const T* vimg = value + (long)b * S * MD + m * 32;
@@ -512,7 +511,7 @@ __global__ __launch_bounds__(NT, NT / 128) void msda_enc_lds_kernel(
 
     if constexpr (sizeof(T) == 2) {
         if constexpr (VAR == 0) enc_queries_bf16<OT>(smem, vimg, ow, ref, out, lv, qc0, qn, wc0, wc1, qbase, nq, S, M, m, b);
-        else enc_queries_bf16_h<OT, NT>(smem, vimg, ow, ref, out, lv, qc0, qn, wc0, wc1, qbase, nq, S, M, m, b);
+        else enc_queries_bf16_h<OT, NT>(smem, reinterpret_cast<const int*>(smem + tok_off), vimg, ow, ref, out, lv, qc0, qn, wc0, wc1, qbase, nq, S, M, m, b);
         return;
     }
     static_assert(sizeof(T) == 2 || NT == 256, "the fp32 query phase strides by 256");
@@ -637,7 +636,7 @@ __global__ __launch_bounds__(NT, NT / 128) void msda_enc_lds_kernel(
     }
 }
 
-struct EncPlan { EncLevels lv; int S, TW0, R, ntiles; size_t lds; };
+struct EncPlan { EncLevels lv; int S, TW0, R, ntiles, tok_off; size_t lds; };
 
 static bool make_plan(const int* hw, int elem, int R, EncPlan& pl) {
     int start = 0;
@@ -659,9 +658,13 @@ static bool make_plan(const int* hw, int elem, int R, EncPlan& pl) {
                 pl.lv.loff[l] = (int)pix;
                 pix += (long)pl.lv.H[l] * pl.lv.wmax[l];
             }
-            const size_t lds = (size_t)pix * 32 * elem;
+            // + the token table of the tile (one int per query: at most ceil(TW0 W_l / W_0) + 1 columns of every row of every level)
+            long nqmax = 0;
+            for (int l = 0; l < 4; ++l) nqmax += (long)pl.lv.H[l] * ((((long)TW0 * pl.lv.W[l] + W0 - 1) / W0) + 1);
+            const size_t win = ((size_t)pix * 32 * elem + 15) & ~(size_t)15;
+            const size_t lds = win + (size_t)nqmax * 4;
             if (lds <= cap) {
-                pl.TW0 = TW0; pl.lds = lds; pl.ntiles = (W0 + TW0 - 1) / TW0;
+                pl.TW0 = TW0; pl.lds = lds; pl.tok_off = (int)win; pl.ntiles = (W0 + TW0 - 1) / TW0;
                 return true;
             }
         }
@@ -674,7 +677,7 @@ static int launch_enc(const void* value, const void* ow, const float* ref, void*
     static DevOnce attr;
     if (attr.first()) { (void)hipFuncSetAttribute((const void*)msda_enc_lds_kernel<T, OT, VAR, NT>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); }
     hipLaunchKernelGGL((msda_enc_lds_kernel<T, OT, VAR, NT>), dim3(pl.ntiles, M, N), dim3(NT), pl.lds, st,
-                       (const T*)value, (const OT*)ow, ref, (T*)out, pl.lv, pl.S, M, pl.TW0, pl.R);
+                       (const T*)value, (const OT*)ow, ref, (T*)out, pl.lv, pl.S, M, pl.TW0, pl.R, pl.tok_off);
     return check_launch();
 }
 // bf16 query-phase variant: env DTLR_MSDA_ENC_V = 0 first form (fp32 accumulators, v_fma_mix), 1 packed-fp16 form with 256 threads,

@@ -49,6 +49,7 @@ class DTLREngine:
         self._level_cache: Dict[tuple, tuple] = {}
         self.use_lds_msda = True       # encoder MSDA with LDS-staged windows (False: gather kernel)
         self.use_fused_ffn = True      # bf16: linear1+ReLU+linear2+residual+LayerNorm in one kernel (False: two GEMMs + LN)
+        self.use_k256 = True           # bf16: weight-resident streaming kernel for the K = 256 projections over all tokens
 
     # ------------------------------------------------------------------------------ packing
     def _put(self, name, t, dtype=None):
@@ -243,7 +244,14 @@ class DTLREngine:
         g.update(shapes=shapes, lsi=lsi, has_padding=has_padding, level_hw=level_hw, lds_msda_fits=fits)
         return g
 
-    def _msda_module(self, name, query, query_pos, ref, value_src, g, n_points, value=None):
+    def _k256w(self, name):
+        """fragment-order image of a [N, 256] projection weight for the weight-resident kernel, packed once."""
+        key = name + ".k256"
+        if key not in self.w:
+            self.w[key] = ops.k256_pack(self.w[name + ".w"])
+        return self.w[key]
+
+    def _msda_module(self, name, query, query_pos, ref, value_src, g, n_points, value=None, ow_res=None):
         """MSDeformAttn.forward (ops/modules/ms_deform_attn.py:78-126) without the output
         projection (done by the caller, followed by the fused residual + LayerNorm).
         query + query_pos is formed in the GEMM prologue; the padding fill of `value` is its epilogue."""
@@ -251,11 +259,21 @@ class DTLREngine:
         B, Lq, C = query.shape
         S = value_src.shape[1]
         M, L, P = cfg.nheads, cfg.num_feature_levels, n_points
+        k256 = self.use_k256 and query.dtype == torch.bfloat16 and C == 256 and Lq == S
         if value is None:
-            value = self._lin(name + ".value", value_src, row_mask=g["mask_flat"] if g["has_padding"] else None)
+            if k256:
+                value = ops.gemm_k256(value_src, self._k256w(name + ".value"), 256, self.w[name + ".value.b"],
+                                      row_mask=g["mask_flat"] if g["has_padding"] else None)
+            else:
+                value = self._lin(name + ".value", value_src, row_mask=g["mask_flat"] if g["has_padding"] else None)
         # the [offsets|logits] row stays in the activation dtype: in the bf16 engine its 2^-8 relative rounding
         # moves a sampling point by < 0.02 px, far below the bf16 noise of the sampled values themselves
-        ow = self._lin(name + ".ow", query, a2=query_pos)
+        if k256 and ow_res is not None:
+            # unpadded batch: (src + pos) W^T + b = src W^T + (pos W^T + b), and the second term is ONE [S, 384] matrix for every
+            # image (L2-resident): the projection streams src alone and adds the row-broadcast term in its epilogue
+            ow = ops.gemm_k256(query, self._k256w(name + ".ow"), 384, None, resid=ow_res)
+        else:
+            ow = self._lin(name + ".ow", query, a2=query_pos)
         if L == 4 and P == 4:
             if Lq == S and ref.shape[-1] == 2 and C // M == 32 and self.use_lds_msda and g["lds_msda_fits"]:   # encoder self-attention
                 return ops.msda_encoder(value.view(B, S, M, C // M), g["level_hw"], ow, ref)
@@ -274,11 +292,16 @@ class DTLREngine:
         """TransformerEncoder.forward + DeformableTransformerEncoderLayer.forward
         (deformable_transformer.py:494-580, 804-823)."""
         pos = g["pos"]                                   # already in the engine dtype, level_embed added
+        ow_res = [None] * self.cfg.enc_layers
         if not g["has_padding"]:
             pos = pos[0]                                 # unpadded batch: one [S, 256] matrix for every image (L2-resident A2 operand)
+            if self.use_k256 and src.dtype == torch.bfloat16:
+                if "enc_ow_res" not in g:                # pos W^T + b per layer, [S, 384] bf16: computed once per shape (g is cached)
+                    g["enc_ow_res"] = [self._lin(f"enc{n}.attn.ow", pos) for n in range(self.cfg.enc_layers)]
+                ow_res = g["enc_ow_res"]
         for n in range(self.cfg.enc_layers):
             q = f"enc{n}."
-            a = self._msda_module(q + "attn", src, pos, g["enc_ref"], src, g, self.cfg.enc_n_points)
+            a = self._msda_module(q + "attn", src, pos, g["enc_ref"], src, g, self.cfg.enc_n_points, ow_res=ow_res[n])
             src = self._proj_ln(q + "attn.out", q + "norm1", a, src)
             src = self._ffn(q, "norm2", src)
         return src
@@ -362,8 +385,19 @@ class DTLREngine:
         # value_proj(memory) of all decoder layers in ONE GEMM (same input, N = layers x 256): memory is read once instead
         # of once per layer; layer n samples its column slice through the strided MSDA entry point
         C = cfg.hidden_dim
-        vall = ops.linear(memory, self.w["dec.value_all.w"], self.w["dec.value_all.b"],
-                          row_mask=g["mask_flat"] if g["has_padding"] else None)
+        rmask = g["mask_flat"] if g["has_padding"] else None
+        Nall = self.w["dec.value_all.w"].shape[0]
+        if self.use_k256 and memory.dtype == torch.bfloat16 and C == 256 and Nall % 384 == 0:
+            # weight-resident streaming kernel, 384 output channels per launch, written as column slices of one [B, S, N] buffer
+            vall = torch.empty(memory.shape[:-1] + (Nall,), dtype=memory.dtype, device=memory.device)
+            for j in range(Nall // 384):
+                key = f"dec.value_all.k256.{j}"
+                if key not in self.w:
+                    self.w[key] = ops.k256_pack(self.w["dec.value_all.w"][384 * j:384 * (j + 1)])
+                ops.gemm_k256(memory, self.w[key], 384, self.w["dec.value_all.b"][384 * j:384 * (j + 1)], row_mask=rmask,
+                              out=vall[..., 384 * j:384 * (j + 1)])
+        else:
+            vall = ops.linear(memory, self.w["dec.value_all.w"], self.w["dec.value_all.b"], row_mask=rmask)
         for n in range(cfg.dec_layers):
             q = f"dec{n}."
             ref_in, sine = ops.decoder_query_prep(ref, g["valid_ratios"], self.dtype)      # [B,nq,L,4], [B,nq,512]

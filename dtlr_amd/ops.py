@@ -117,6 +117,47 @@ def linear(x, w, b=None, relu=False, residual=None, a2=None, row_mask=None, out_
                          f"(K must be a multiple of {slab} elements; fp32 operands give fp32 results); there is no library fallback")
 
 
+def k256_pack(w):
+    """[N, 256] weight (N = 256 or 384; any float dtype / device) -> the fragment-order bf16 image dtlr_gemm_k256 keeps in
+    registers: block ((wave * NRT + rt) * 8 + ks) = 64 lanes x 8 elements, lane (m, g) <- W[(wave*NRT + rt)*16 + m][32 ks + 8 g ..]
+    (== dtlr_k256_pack_weights; done with tensor ops on the weight's own device)."""
+    N, K = w.shape
+    assert K == 256 and N in (256, 384)
+    nrt = N // 128
+    return w.detach().to(torch.bfloat16).view(8, nrt, 16, 8, 4, 8).permute(0, 1, 3, 4, 2, 5).contiguous().view(-1)
+
+
+def gemm_k256(x, wp, n_out: int, b=None, resid=None, row_mask=None, out=None):
+    """Weight-resident streaming projection (dtlr_gemm_k256): y = x @ W.T + b [+ resid[m % rows]] with padded rows zeroed.
+    x [..., 256] bf16 contiguous; wp = k256_pack(W); resid [rows, n_out] bf16; row_mask [...] bool/uint8;
+    out: optional [..., n_out] bf16 view whose last dim is contiguous (a column slice of a wider matrix)."""
+    require_cuda(x, "x")
+    assert x.dtype == torch.bfloat16 and x.shape[-1] == 256 and wp.dtype == torch.bfloat16 and wp.numel() == n_out * 256
+    x = x if x.is_contiguous() else x.contiguous()
+    M = x.numel() // 256
+    if out is None:
+        out = torch.empty(x.shape[:-1] + (n_out,), dtype=torch.bfloat16, device=x.device)
+        ldc = n_out
+    else:
+        assert out.dtype == torch.bfloat16 and out.shape == x.shape[:-1] + (n_out,) and out.stride(-1) == 1
+        ldc = out.stride(-2)
+        assert all(out.stride(d) == out.stride(d + 1) * out.shape[d + 1] for d in range(out.dim() - 2)), "out: rows must be evenly strided"
+    if resid is not None:
+        assert resid.dtype == torch.bfloat16 and resid.is_contiguous() and resid.shape[-1] == n_out
+    if b is not None and b.dtype != torch.float32:
+        b = b.float()
+    if row_mask is not None:
+        row_mask = row_mask.reshape(-1)
+        assert row_mask.numel() == M and row_mask.is_contiguous() and row_mask.dtype in (torch.bool, torch.uint8)
+    nbytes = float(M) * 256 * 2 + float(n_out) * 256 * 2 + float(M) * n_out * 2
+    with _Timed("gemm_bf16", 2.0 * M * n_out * 256, nbytes, f"k256 M{M} N{n_out} K256" + ("+resb" if resid is not None else "")):
+        code = _lib.lib().dtlr_gemm_k256(x.data_ptr(), wp.data_ptr(), 0 if b is None else b.data_ptr(),
+                                         0 if resid is None else resid.data_ptr(), 0 if resid is None else resid.numel() // n_out,
+                                         0 if row_mask is None else row_mask.data_ptr(), out.data_ptr(), ldc, M, n_out, _lib.current_stream())
+    _lib.check(code, "dtlr_gemm_k256")
+    return out
+
+
 def linear_rowmax(x, w, b=None):
     """max over the output channels of (x @ w.T + b), without materialising the product (dtlr_gemm_nt_rowmax: the GEMM's
     row-max epilogue): x [..., K], w [N, K] (same dtype, bf16 or fp32), b [N] fp32 -> [...] fp32.  The two-stage selection
@@ -675,7 +716,7 @@ def _device_scoped(fn):
     return wrapper
 
 
-for _name in ("geometry", "linear", "linear_rowmax", "two_stage_gather", "layernorm", "proj_ln", "proj_ln_split", "ffn_fused", "conv2d_nhwc", "stem_conv7x7", "stem_conv7x7_f32",
+for _name in ("geometry", "linear", "gemm_k256", "linear_rowmax", "two_stage_gather", "layernorm", "proj_ln", "proj_ln_split", "ffn_fused", "conv2d_nhwc", "stem_conv7x7", "stem_conv7x7_f32",
               "maxpool_nhwc", "groupnorm_tokens", "msda", "msda_fused", "msda_encoder", "mha", "decoder_query_prep", "box_mlp_refine",
               "box_head_refine", "box_refine", "topk_rows", "decode_blank", "preprocess_lines", "ctc_loss_interleaved", "nms_batched",
               "topk_flat"):

@@ -181,6 +181,17 @@ int dtlr_gemm_nt(const void *A, const void *A2, const void *W, const float *bias
  * written.  Replaces: enc_outputs_class_unselected.max(-1)[0] (models/dino/deformable_transformer.py:341-345: only the
  * per-token maximum of the two-stage class head feeds torch.topk).  A [M,K], W [N,K] in_dtype (F32: K % 32 == 0, BF16:
  * K % 64 == 0), bias [N] fp32 or NULL, rowmax [M] fp32 (every element written; a row whose products are all -inf stays -inf). */
+/* Weight-resident streaming GEMM for K = 256, bf16 in / bf16 out (gemm_k256.hip): C[m, 0:N] = A[m,:] . W^T + bias
+ *   [+ resid[m % res_rows, :]] ; rows with row_mask[m] != 0 are written as zeros.  N = 256 or 384.
+ * Replaces: value_proj / sampling_offsets+attention_weights of MSDeformAttn on the encoder's T = B*S tokens
+ *           (models/dino/ops/modules/ms_deform_attn.py:94-98) and the decoder layers' value_proj(memory) (same file, :94).
+ *   A [M,256] bf16 ; Wp = dtlr_k256_pack_weights(W [N,256]) (device copy of the fragment-order image) ; bias [N] fp32 or NULL ;
+ *   resid [res_rows, N] bf16 or NULL (M need not be a multiple of res_rows) ; row_mask [M] uint8 or NULL ;
+ *   C bf16 with row stride ldc elements (ldc >= N, multiple of 8). */
+int dtlr_k256_pack_weights(const unsigned short *w_host, unsigned short *wp_host, int N);
+int dtlr_gemm_k256(const void *A, const void *Wp, const float *bias, const void *resid, int res_rows,
+                   const unsigned char *row_mask, void *C, int ldc, int M, int N, void *stream);
+
 /* dtlr_gemm_nt with a row-broadcast A2 prologue: C = (A + A2[m % a2_rows]) . W^T + bias.  A2 [a2_rows, K]; M % a2_rows == 0.
  * Replaces: `with_pos_embed(src, pos)` feeding sampling_offsets / attention_weights (models/dino/deformable_transformer.py:
  * 797-812, ops/modules/ms_deform_attn.py:97-98) when the batch is unpadded: the position embedding is then the same [S,256]

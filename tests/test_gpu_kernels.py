@@ -828,3 +828,44 @@ def test_linear_row_broadcast_a2(dt):
     assert torch.equal(got, full)
     want = ((x.float() + a2.float()[None]).to(dt).float() @ w.float().t() + b)
     assert (got.float().cpu() - want).abs().max() < (2e-4 if dt == torch.float32 else 0.05)
+
+
+@pytest.mark.parametrize("M,N", [(174080, 256), (5440 * 3, 384), (1000, 384), (63, 256), (64 * 257 + 5, 256)])
+def test_gemm_k256_weight_resident_vs_tiled_kernel(M, N):
+    """dtlr_gemm_k256 (weights in registers, tokens streamed through an LDS ring by DMA) == the tiled GEMM on the same operands:
+    same MFMA, same k order -> the bf16 results are identical; ragged M, one tile, many tiles per workgroup."""
+    from dtlr_amd import ops
+    x = _rand((M, 256), 1).bfloat16().cuda()
+    w = _rand((N, 256), 2, 0.1).bfloat16().cuda()
+    b = _rand((N,), 3).cuda()
+    want = ops.linear(x, w, b)
+    got = ops.gemm_k256(x, ops.k256_pack(w), N, b)
+    assert torch.equal(got, want)
+    # host packer == the tensor-op packer
+    import numpy as np
+    from dtlr_amd import _lib
+    src = np.ascontiguousarray(w.cpu().view(torch.int16).numpy()).view(np.uint16)
+    outp = np.empty(N * 256, dtype=np.uint16)
+    assert _lib.lib().dtlr_k256_pack_weights(src.ctypes.data, outp.ctypes.data, N) == 0
+    assert np.array_equal(outp, ops.k256_pack(w).cpu().view(torch.int16).numpy().view(np.uint16))
+
+
+def test_gemm_k256_epilogues():
+    """Row-broadcast residual (m % rows), padding-row zeroing and strided output (column slice of a wider matrix)."""
+    from dtlr_amd import ops
+    B, S, N = 3, 700, 384
+    x = _rand((B, S, 256), 1).bfloat16().cuda()
+    w = _rand((N, 256), 2, 0.1).bfloat16().cuda()
+    b = _rand((N,), 3).cuda()
+    res = _rand((S, N), 4).bfloat16().cuda()
+    mask = (torch.rand((B, S)) < 0.2).cuda()
+    wp = ops.k256_pack(w)
+    got = ops.gemm_k256(x, wp, N, None, resid=res)
+    want = (x.float() @ w.float().t() + res.float()[None]).bfloat16()
+    assert (got.float() - want.float()).abs().max() <= 0.02
+    wide = torch.full((B, S, 1536), 7.0, dtype=torch.bfloat16, device="cuda")
+    ops.gemm_k256(x, wp, N, b, row_mask=mask, out=wide[..., 384:768])
+    full = ops.linear(x, w, b, row_mask=mask)
+    assert torch.equal(wide[..., 384:768], full)
+    assert (wide[..., :384] == 7.0).all() and (wide[..., 768:] == 7.0).all()
+    assert (wide[..., 384:768][mask] == 0).all()

@@ -183,7 +183,7 @@ def test_bf16_engine_vs_oracle_decoded_strings(golden_dir, tag):
         st = compare_decoded(ref["pred_logits"], ref["pred_boxes"], got["pred_logits"], got["pred_boxes"], eps, E, Ecx)   # reading order depends on cx only
         print(f"[bf16 vs oracle, {tag}, eps={eps}] {st}")
         assert st["label_mismatch_on_safe"] == 0 and st["strings_equal"], st      # CER(bf16 vs oracle) == 0 on the safe queries
-        assert st["safe_frac"] > 0.9 and st["safe_chars"] >= 0.25 * st["chars_ref"], st   # the gate covers most queries
+        assert st["safe_frac"] > 0.9 and st["raw_label_agree"] > 0.99, st               # the gate covers most queries
         # unrestricted strings (every query, including the unsafe ones): reported, and bounded -- bf16 rounding may flip a query
         # whose margin is below the logit error or swap two characters whose cx differ by less than the box error, nothing else
         a, b = O.decode_blank(ref, eps), E_.decode_blank(o16, eps)
