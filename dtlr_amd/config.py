@@ -43,20 +43,54 @@ class DTLRConfig:
     dropout: float = 0.0              # :41
     # bottleneck blocks per ResNet stage; (3,4,6,3) is resnet50, fewer only in tiny test configs
     backbone_blocks: tuple = (3, 4, 6, 3)
+    # Swin backbones (models/dino/backbone.py:172-205 -> swin_transformer.py:683-720): the named variants below, or
+    # "swin_custom" with swin_embed_dim / swin_depths / swin_num_heads / swin_window (test-sized networks)
+    swin_embed_dim: int = 0
+    swin_depths: tuple = ()
+    swin_num_heads: tuple = ()
+    swin_window: int = 0
 
     @property
     def head_dim(self) -> int:
         return self.hidden_dim // self.nheads
 
+    SWIN_VARIANTS = {   # swin_transformer.py:686-717
+        "swin_T_224_1k": dict(embed_dim=96, depths=(2, 2, 6, 2), num_heads=(3, 6, 12, 24), window_size=7),
+        "swin_B_224_22k": dict(embed_dim=128, depths=(2, 2, 18, 2), num_heads=(4, 8, 16, 32), window_size=7),
+        "swin_B_384_22k": dict(embed_dim=128, depths=(2, 2, 18, 2), num_heads=(4, 8, 16, 32), window_size=12),
+        "swin_L_224_22k": dict(embed_dim=192, depths=(2, 2, 18, 2), num_heads=(6, 12, 24, 48), window_size=7),
+        "swin_L_384_22k": dict(embed_dim=192, depths=(2, 2, 18, 2), num_heads=(6, 12, 24, 48), window_size=12),
+    }
+
+    @property
+    def is_swin(self) -> bool:
+        return self.backbone.startswith("swin_")
+
+    def swin_params(self) -> dict:
+        """embed_dim / depths / num_heads / window_size of the configured Swin backbone."""
+        if self.backbone == "swin_custom":
+            return dict(embed_dim=self.swin_embed_dim, depths=tuple(self.swin_depths), num_heads=tuple(self.swin_num_heads),
+                        window_size=self.swin_window)
+        return dict(self.SWIN_VARIANTS[self.backbone])
+
     @property
     def backbone_channels(self) -> List[int]:
+        if self.is_swin:                                              # num_features[1:] (backbone.py:204, swin_transformer.py:521)
+            e = self.swin_params()["embed_dim"]
+            return [2 * e, 4 * e, 8 * e]
         return [512, 1024, 2048]   # layer2/3/4 outputs (models/dino/backbone.py:125-126)
 
     def validate(self) -> None:
         """Reject configurations outside the hot path."""
-        if self.backbone != "resnet50":
-            raise NotImplementedError(f"backbone {self.backbone!r}: only resnet50 is on the path "
-                                      "(every shipped reference config uses it, config/*.py:26)")
+        if self.backbone != "resnet50" and not (self.backbone in self.SWIN_VARIANTS or self.backbone == "swin_custom"):
+            raise NotImplementedError(f"backbone {self.backbone!r}: resnet50 (every shipped reference config, config/*.py:26) and the "
+                                      "Swin variants of models/dino/backbone.py:172 are built; resnet101 / convnext are not")
+        if self.is_swin:
+            sp = self.swin_params()
+            if len(sp["depths"]) != 4 or len(sp["num_heads"]) != 4 or sp["window_size"] <= 0 or sp["embed_dim"] <= 0:
+                raise ValueError("swin backbone: 4 stages with depths / heads / window / embed_dim set")
+            if any((sp["embed_dim"] << i) % h or (sp["embed_dim"] << i) // h != 32 for i, h in enumerate(sp["num_heads"])):
+                raise NotImplementedError("swin backbone: head_dim must be 32 (true of every reference variant)")
         if self.two_stage_type != "standard" or not self.embed_init_tgt:
             raise NotImplementedError("only two_stage_type='standard' with embed_init_tgt=True")
         if tuple(self.decoder_module_seq) != ("sa", "ca", "ffn") or self.decoder_sa_type != "sa":

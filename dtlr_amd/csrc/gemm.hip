@@ -86,6 +86,7 @@ __device__ unsigned long long g_gemm_tl[TL_BLOCKS * 2 * TL_EVENTS];
 #endif
 
 enum : int { EPI_BIAS = 1, EPI_RELU = 2, EPI_RESIDUAL = 4, EPI_ROWMASK = 8, EPI_RELU_POST = 16,
+              EPI_GELU = 64,        // exact GELU (erf) after the bias: Swin's Mlp (swin_transformer.py:18-36, nn.GELU)
               EPI_ROWMAX = 32,      // C is NOT written: C[token] (fp32, M entries, pre-filled with -inf) <- max over channels of acc + bias
               DBG_NO_LOAD = 256, DBG_NO_MMA = 512, DBG_NO_LDS = 1024, DBG_NO_EPI = 2048, DBG_NO_STORE = 4096 };   // ablation switches (env DTLR_GEMM_ABLATE), timing only
 
@@ -230,6 +231,10 @@ __device__ __forceinline__ void epilogue_tile(f32x4_t (&acc)[4][4], OutT* __rest
 #pragma unroll
                         for (int r = 0; r < 4; ++r) v[r] = fmaxf(v[r], 0.f);
                     }
+                    if (flags & EPI_GELU) {
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) v[r] = 0.5f * v[r] * (1.0f + erff(v[r] * 0.70710678118654752f));
+                    }
                     if (masked[ti]) { v[0] = v[1] = v[2] = v[3] = 0.f; }
                     if (flags & EPI_RESIDUAL) { float q[4]; Out<OutT>::unpack4(rr[tb][ci], q); v[0] += q[0]; v[1] += q[1]; v[2] += q[2]; v[3] += q[3]; }
                     if (flags & EPI_RELU_POST) {
@@ -283,6 +288,10 @@ __device__ __forceinline__ void epilogue_tile(f32x4_t (&acc)[4][4], OutT* __rest
             if (flags & EPI_RELU) {
 #pragma unroll
                 for (int r = 0; r < 4; ++r) v[r] = fmaxf(v[r], 0.f);
+            }
+            if (flags & EPI_GELU) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) v[r] = 0.5f * v[r] * (1.0f + erff(v[r] * 0.70710678118654752f));
             }
             if (masked) { v[0] = v[1] = v[2] = v[3] = 0.f; }
             OutT* cptr = C + (long)tok * N + ch;
@@ -785,6 +794,10 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* __restr
 #pragma unroll
         for (int r = 0; r < 4; ++r) v[r] = fmaxf(v[r], 0.f);
     }
+    if (flags & EPI_GELU) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) v[r] = 0.5f * v[r] * (1.0f + erff(v[r] * 0.70710678118654752f));
+    }
     if ((flags & EPI_ROWMASK) && row_mask[tok]) { v[0] = v[1] = v[2] = v[3] = 0.f; }
     if (flags & EPI_RESIDUAL) { float q[4]; Out<OutT>::ld4(residual + i4, q); v[0] += q[0]; v[1] += q[1]; v[2] += q[2]; v[3] += q[3]; }
     if (flags & EPI_RELU_POST) {
@@ -929,7 +942,7 @@ extern "C" int dtlr_gemm_nt(const void* A, const void* A2, const void* W, const 
     clear_stale_error();
     if (!A || !W || !C) return DTLR_EINVAL;
     if (M <= 0 || N <= 0 || K <= 0) return DTLR_EINVAL;
-    int flags = (bias ? EPI_BIAS : 0) | (relu == 1 ? EPI_RELU : 0) | (relu == 2 ? EPI_RELU_POST : 0) |
+    int flags = (bias ? EPI_BIAS : 0) | (relu == 1 ? EPI_RELU : 0) | (relu == 2 ? EPI_RELU_POST : 0) | (relu == 3 ? EPI_GELU : 0) |
                 (residual ? EPI_RESIDUAL : 0) | (row_mask ? EPI_ROWMASK : 0);
 #ifdef DTLR_GEMM_ABLATION
     if (const char* ab = getenv("DTLR_GEMM_ABLATE")) flags |= (atoi(ab) & (DBG_NO_LOAD | DBG_NO_MMA | DBG_NO_LDS | DBG_NO_EPI | DBG_NO_STORE));   // timing experiments only

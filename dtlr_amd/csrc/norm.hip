@@ -70,6 +70,54 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const T* __restrict__ x,
     }
 }
 
+// any C with C % 4 == 0 and C <= 3072 (Swin stages: 96 / 192 / 384 / 768 / 1536 ...): lane l owns elements 4l + 256 g, g < ceil(C/256)
+template <typename T>
+__global__ __launch_bounds__(256) void layernorm_any_kernel(const T* __restrict__ x, const T* __restrict__ res,
+                                                            const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                            T* __restrict__ y, long rows, int C, float eps)
+{
+    const int lane = threadIdx.x & 63;
+    const long row = (long)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    if (row >= rows) return;
+    const T* xr = x + row * C;
+    float v[12][4];
+    float s = 0.f;
+#pragma unroll
+    for (int g = 0; g < 12; ++g) {
+        const int e = g * 256 + 4 * lane;
+        v[g][0] = v[g][1] = v[g][2] = v[g][3] = 0.f;
+        if (e < C) {
+            IO<T>::load4(xr + e, v[g]);
+            if (res) {
+                float r[4]; IO<T>::load4(res + row * C + e, r);
+#pragma unroll
+                for (int i = 0; i < 4; ++i) v[g][i] += r[i];
+            }
+            s += (v[g][0] + v[g][1]) + (v[g][2] + v[g][3]);
+        }
+    }
+    const float mean = wave_sum(s) / (float)C;
+    float q = 0.f;
+#pragma unroll
+    for (int g = 0; g < 12; ++g)
+        if (g * 256 + 4 * lane < C) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) { const float d = v[g][i] - mean; q += d * d; }
+        }
+    const float rstd = rsqrtf(wave_sum(q) / (float)C + eps);
+    T* yr = y + row * C;
+#pragma unroll
+    for (int g = 0; g < 12; ++g) {
+        const int e = g * 256 + 4 * lane;
+        if (e < C) {
+            const float4 ga = *reinterpret_cast<const float4*>(gamma + e), be = *reinterpret_cast<const float4*>(beta + e);
+            float o[4] = {(v[g][0] - mean) * rstd * ga.x + be.x, (v[g][1] - mean) * rstd * ga.y + be.y,
+                          (v[g][2] - mean) * rstd * ga.z + be.z, (v[g][3] - mean) * rstd * ga.w + be.w};
+            IO<T>::store4(yr + e, o);
+        }
+    }
+}
+
 template <typename T>
 static int launch_ln(const void* x, const void* res, const float* gamma, const float* beta, void* y,
                      long rows, int C, float eps, hipStream_t st) {
@@ -93,8 +141,18 @@ extern "C" int dtlr_layernorm(const void* x, const void* residual, const float* 
     clear_stale_error();
     if (!x || !gamma || !beta || !y) return DTLR_EINVAL;
     if (rows <= 0 || C <= 0) return DTLR_EINVAL;
-    if (C % 256 != 0) return DTLR_ESHAPE;
     hipStream_t st = (hipStream_t)stream;
+    if (C % 256 != 0) {                                          // generic row kernel (Swin widths)
+        if ((C & 3) || C > 3072) return DTLR_ESHAPE;
+        const long grid = (rows + 3) / 4;
+        if (grid > 0x7fffffffL) return DTLR_ESHAPE;
+        if (dtype == DTLR_F32)
+            hipLaunchKernelGGL(layernorm_any_kernel<float>, dim3((unsigned)grid), dim3(256), 0, st, (const float*)x, (const float*)residual, gamma, beta, (float*)y, rows, C, eps);
+        else if (dtype == DTLR_BF16)
+            hipLaunchKernelGGL(layernorm_any_kernel<uint16_t>, dim3((unsigned)grid), dim3(256), 0, st, (const uint16_t*)x, (const uint16_t*)residual, gamma, beta, (uint16_t*)y, rows, C, eps);
+        else return DTLR_EDTYPE;
+        return check_launch();
+    }
     switch (dtype) {
     case DTLR_F32: return launch_ln<float>(x, residual, gamma, beta, y, rows, C, eps, st);
     case DTLR_BF16: return launch_ln<uint16_t>(x, residual, gamma, beta, y, rows, C, eps, st);

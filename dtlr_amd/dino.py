@@ -118,6 +118,67 @@ class _Backbone(nn.Module):
         self.num_channels = [512, 1024, 2048]
 
 
+class _SwinAttn(nn.Module):
+    def __init__(self, dim, ws, heads):
+        super().__init__()
+        self.relative_position_bias_table = nn.Parameter(torch.zeros((2 * ws - 1) ** 2, heads))
+        self.register_buffer("relative_position_index", torch.zeros((ws * ws, ws * ws), dtype=torch.long))
+        self.qkv = nn.Linear(dim, 3 * dim)
+        self.proj = nn.Linear(dim, dim)
+
+
+class _SwinMlp(nn.Module):
+    def __init__(self, dim):
+        super().__init__()
+        self.fc1 = nn.Linear(dim, 4 * dim)
+        self.fc2 = nn.Linear(4 * dim, dim)
+
+
+class _SwinBlock(nn.Module):
+    def __init__(self, dim, ws, heads):
+        super().__init__()
+        self.norm1 = nn.LayerNorm(dim)
+        self.attn = _SwinAttn(dim, ws, heads)
+        self.norm2 = nn.LayerNorm(dim)
+        self.mlp = _SwinMlp(dim)
+
+
+class _SwinMerge(nn.Module):
+    def __init__(self, dim):
+        super().__init__()
+        self.reduction = nn.Linear(4 * dim, 2 * dim, bias=False)
+        self.norm = nn.LayerNorm(4 * dim)
+
+
+class _SwinStage(nn.Module):
+    def __init__(self, dim, depth, ws, heads, downsample):
+        super().__init__()
+        self.blocks = nn.ModuleList(_SwinBlock(dim, ws, heads) for _ in range(depth))
+        if downsample:
+            self.downsample = _SwinMerge(dim)
+
+
+class _SwinPatchEmbed(nn.Module):
+    def __init__(self, E):
+        super().__init__()
+        self.proj = nn.Conv2d(3, E, kernel_size=4, stride=4)
+        self.norm = nn.LayerNorm(E)
+
+
+class _SwinBackbone(nn.Module):
+    """Parameter container with the state-dict layout of models/dino/swin_transformer.py:435-555 (`backbone.0.*`)."""
+
+    def __init__(self, cfg: DTLRConfig):
+        super().__init__()
+        sp = cfg.swin_params()
+        E, ws = sp["embed_dim"], sp["window_size"]
+        self.patch_embed = _SwinPatchEmbed(E)
+        self.layers = nn.ModuleList(_SwinStage(E << i, sp["depths"][i], ws, sp["num_heads"][i], i < 3) for i in range(4))
+        for i in cfg.return_interm_indices:
+            setattr(self, f"norm{i}", nn.LayerNorm(E << i))
+        self.num_channels = cfg.backbone_channels
+
+
 class MLP(nn.Module):
     """models/dino/utils.py:110-122 (container)."""
 
@@ -193,7 +254,7 @@ class DINO(nn.Module):
         proj = [nn.Sequential(nn.Conv2d(c, d, kernel_size=1), nn.GroupNorm(32, d)) for c in cfg.backbone_channels]
         proj.append(nn.Sequential(nn.Conv2d(cfg.backbone_channels[-1], d, kernel_size=3, stride=2, padding=1), nn.GroupNorm(32, d)))
         self.input_proj = nn.ModuleList(proj)
-        self.backbone = nn.Sequential(_Backbone(cfg.backbone_blocks))
+        self.backbone = nn.Sequential(_SwinBackbone(cfg) if cfg.is_swin else _Backbone(cfg.backbone_blocks))
         self.transformer = _Transformer(cfg)
         self.aux_loss = True
         self.dec_pred_class_embed_share = cfg.dec_pred_class_embed_share

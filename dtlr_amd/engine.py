@@ -19,6 +19,7 @@ path); selection scores, softmax, normalisation statistics and box arithmetic ar
 from __future__ import annotations
 
 import math
+import os
 from typing import Dict, List, Optional, Sequence
 
 import torch
@@ -49,7 +50,7 @@ class DTLREngine:
         self._level_cache: Dict[tuple, tuple] = {}
         self.use_lds_msda = True       # encoder MSDA with LDS-staged windows (False: gather kernel)
         self.use_fused_ffn = True      # bf16: linear1+ReLU+linear2+residual+LayerNorm in one kernel (False: two GEMMs + LN)
-        self.use_k256 = True           # bf16: weight-resident streaming kernel for the K = 256 projections over all tokens
+        self.use_k256 = os.environ.get("DTLR_K256", "1") != "0"   # bf16: weight-resident streaming kernel for the K = 256 projections over all tokens
 
     # ------------------------------------------------------------------------------ packing
     def _put(self, name, t, dtype=None):
@@ -69,8 +70,78 @@ class DTLREngine:
         self._put(name + ".w", w)
         self._put(name + ".b", b, torch.float32)          # biases enter the GEMM epilogue in fp32
 
+    def _pack_swin(self, sd):
+        """backbone.0.* of a Swin backbone (models/dino/swin_transformer.py): GEMM weights in the engine dtype, LayerNorm / bias /
+        relative-position tensors fp32; the dense per-head bias of every block is built here, once."""
+        cfg, f32 = self.cfg, torch.float32
+        sp = cfg.swin_params()
+        E, ws = sp["embed_dim"], sp["window_size"]
+        if self.dtype == torch.bfloat16 and E % 64:
+            raise NotImplementedError(f"swin backbone with embed_dim {E}: the bf16 GEMM needs K a multiple of 64 (swin_B / swin_L); "
+                                      "run this variant with the fp32 engine")
+        b = "backbone.0."
+        self._put("swin.pe.w", sd[b + "patch_embed.proj.weight"].float().reshape(E, 48).t(), f32)      # [48, E], k-major
+        self._put("swin.pe.b", sd[b + "patch_embed.proj.bias"], f32)
+        self._put("swin.pe.ln.w", sd[b + "patch_embed.norm.weight"], f32)
+        self._put("swin.pe.ln.b", sd[b + "patch_embed.norm.bias"], f32)
+        for i in range(4):
+            for j in range(sp["depths"][i]):
+                p, q = f"{b}layers.{i}.blocks.{j}.", f"swin.{i}.{j}."
+                for nm in ("norm1", "norm2"):
+                    self._put(q + nm + ".w", sd[p + nm + ".weight"], f32)
+                    self._put(q + nm + ".b", sd[p + nm + ".bias"], f32)
+                self._put_linear(q + "qkv", sd[p + "attn.qkv.weight"], sd[p + "attn.qkv.bias"])
+                self._put_linear(q + "proj", sd[p + "attn.proj.weight"], sd[p + "attn.proj.bias"])
+                self._put_linear(q + "fc1", sd[p + "mlp.fc1.weight"], sd[p + "mlp.fc1.bias"])
+                self._put_linear(q + "fc2", sd[p + "mlp.fc2.weight"], sd[p + "mlp.fc2.bias"])
+                self.w[q + "rpb"] = ops.swin_dense_bias(sd[p + "attn.relative_position_bias_table"].to(self.device), ws)
+            if i < 3:
+                p, q = f"{b}layers.{i}.downsample.", f"swin.{i}.merge."
+                self._put(q + "ln.w", sd[p + "norm.weight"], f32)
+                self._put(q + "ln.b", sd[p + "norm.bias"], f32)
+                self._put(q + "w", sd[p + "reduction.weight"])
+            if i in cfg.return_interm_indices:
+                self._put(f"swin.norm{i}.w", sd[f"{b}norm{i}.weight"], f32)
+                self._put(f"swin.norm{i}.b", sd[f"{b}norm{i}.bias"], f32)
+
+    def backbone_swin(self, x_nchw) -> List[torch.Tensor]:
+        """SwinTransformer.forward (models/dino/swin_transformer.py:633-673) -> the NHWC maps of return_interm_indices."""
+        cfg, w = self.cfg, self.w
+        sp = cfg.swin_params()
+        ws = sp["window_size"]
+        x = ops.swin_patch_embed(x_nchw, w["swin.pe.w"], w["swin.pe.b"], w["swin.pe.ln.w"], w["swin.pe.ln.b"], self.dtype)
+        outs = []
+        for i in range(4):
+            nh = sp["num_heads"][i]
+            for j in range(sp["depths"][i]):
+                q = f"swin.{i}.{j}."
+                # x = x + proj(window_attention(norm1(x)))  (swin_transformer.py:191-243): shift / partition / padding / reverse are
+                # index arithmetic inside the attention kernel; the residual add is the projection's epilogue
+                y = ops.layernorm(x, w[q + "norm1.w"], w[q + "norm1.b"], 1e-5)
+                qkv = ops.linear(y, w[q + "qkv.w"], w[q + "qkv.b"])
+                a = ops.swin_window_attn(qkv, w[q + "qkv.b"], w[q + "rpb"], nh, ws, 0 if j % 2 == 0 else ws // 2)
+                x = ops.linear(a, w[q + "proj.w"], w[q + "proj.b"], residual=x)
+                # x = x + fc2(gelu(fc1(norm2(x))))  (:244-247)
+                y = ops.layernorm(x, w[q + "norm2.w"], w[q + "norm2.b"], 1e-5)
+                hdn = ops.linear(y, w[q + "fc1.w"], w[q + "fc1.b"], relu=3)
+                x = ops.linear(hdn, w[q + "fc2.w"], w[q + "fc2.b"], residual=x)
+            if i in cfg.return_interm_indices:
+                outs.append(ops.layernorm(x, w[f"swin.norm{i}.w"], w[f"swin.norm{i}.b"], 1e-5))
+            if i < 3:
+                q = f"swin.{i}.merge."
+                x = ops.linear(ops.swin_patch_merge(x, w[q + "ln.w"], w[q + "ln.b"]), w[q + "w"], None)
+        return outs
+
     def _pack(self, sd):
         cfg, f32 = self.cfg, torch.float32
+        if cfg.is_swin:
+            self._pack_swin(sd)
+        else:
+            self._pack_resnet(sd)
+        self._pack_rest(sd)
+
+    def _pack_resnet(self, sd):
+        cfg = self.cfg
         b = "backbone.0.body."
         w1, b1 = _fold_bn(sd, b + "conv1.weight", b + "bn1")
         self.w["conv1.b"] = b1.to(device=self.device, dtype=torch.float32).contiguous()
@@ -86,6 +157,9 @@ class DTLREngine:
                     self._put_conv(f"{q}c{c}", *_fold_bn(sd, f"{p}conv{c}.weight", f"{p}bn{c}"))
                 if bi == 0:
                     self._put_conv(q + "ds", *_fold_bn(sd, p + "downsample.0.weight", p + "downsample.1"))
+
+    def _pack_rest(self, sd):
+        cfg, f32 = self.cfg, torch.float32
         for l in range(cfg.num_feature_levels):
             w, bias = sd[f"input_proj.{l}.0.weight"].float(), sd[f"input_proj.{l}.0.bias"].float()
             if l < cfg.num_feature_levels - 1:
@@ -430,7 +504,7 @@ class DTLREngine:
         ops.require_cuda(x, "images")
         cfg = self.cfg
         B = x.shape[0]
-        feats = self.backbone(x.float())
+        feats = self.backbone_swin(x.float()) if cfg.is_swin else self.backbone(x.float())
         level_hw = [(f.shape[1], f.shape[2]) for f in feats]
         last = self._conv(f"ip{len(feats)}", feats[-1], 2, 1)
         level_hw.append((last.shape[1], last.shape[2]))

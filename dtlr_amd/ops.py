@@ -63,7 +63,7 @@ class _Timed:
 
 
 def linear(x, w, b=None, relu=False, residual=None, a2=None, row_mask=None, out_dtype=None):
-    """y = epilogue((x [+ a2]) @ w.T): + b -> ReLU (relu=True/1) -> zero rows where row_mask -> + residual
+    """y = epilogue((x [+ a2]) @ w.T): + b -> ReLU (relu=True/1) or exact GELU (relu=3) -> zero rows where row_mask -> + residual
     -> ReLU (relu=2, the ResNet bottleneck tail).
     x [..., K] and w [N, K] share a dtype (bf16 or fp32); b fp32 [N]; row_mask bool [...];
     residual [..., N] in the output dtype.  HIP MFMA kernel (dtlr_gemm_nt); no library fallback
@@ -461,6 +461,61 @@ def msda_fused(value, spatial_shapes, level_start_index, ow, ref):
 MSDA_HALO = int(__import__("os").environ.get("DTLR_MSDA_HALO", "8"))
 
 
+def swin_patch_embed(x_nchw, w_kE, b, ln_w, ln_b, out_dtype, eps: float = 1e-5):
+    """PatchEmbed of a Swin backbone (dtlr_swin_patch_embed): x [B,3,H,W] fp32 -> [B, ceil(H/4), ceil(W/4), E] out_dtype
+    (4x4/s4 convolution with zero padding + LayerNorm).  w_kE [48, E] fp32 = proj.weight.reshape(E, 48).t()."""
+    require_cuda(x_nchw, "images")
+    assert x_nchw.dtype == torch.float32 and x_nchw.dim() == 4 and x_nchw.shape[1] == 3 and w_kE.shape[0] == 48
+    x = x_nchw if x_nchw.is_contiguous() else x_nchw.contiguous()
+    B, _, H, W = x.shape
+    E = w_kE.shape[1]
+    out = torch.empty((B, (H + 3) // 4, (W + 3) // 4, E), dtype=out_dtype, device=x.device)
+    code = _lib.lib().dtlr_swin_patch_embed(x.data_ptr(), w_kE.data_ptr(), b.data_ptr(), ln_w.data_ptr(), ln_b.data_ptr(), out.data_ptr(),
+                                            B, H, W, E, eps, _DT[out_dtype], _lib.current_stream())
+    _lib.check(code, "dtlr_swin_patch_embed")
+    return out
+
+
+def swin_window_attn(qkv, qkv_bias, rpb, n_heads: int, window: int, shift: int):
+    """Attention core of a Swin block (dtlr_swin_window_attn): qkv [B,H,W,3C] -> [B,H,W,C]; rpb = swin_dense_bias(table, window)."""
+    require_cuda(qkv, "qkv")
+    B, H, W, C3 = qkv.shape
+    C = C3 // 3
+    assert qkv.is_contiguous() and qkv_bias.dtype == torch.float32 and rpb.dtype == torch.float32 and rpb.is_contiguous()
+    out = torch.empty((B, H, W, C), dtype=qkv.dtype, device=qkv.device)
+    code = _lib.lib().dtlr_swin_window_attn(qkv.data_ptr(), qkv_bias.data_ptr(), rpb.data_ptr(), out.data_ptr(), B, H, W, C, n_heads, window, shift,
+                                            _DT[qkv.dtype], _lib.current_stream())
+    _lib.check(code, "dtlr_swin_window_attn")
+    return out
+
+
+def swin_dense_bias(table, window: int):
+    """relative_position_bias_table [(2w-1)^2, nH] -> the dense, zero-padded bias [nH, ceil16(N), ceil32(N)] fp32 the attention kernel
+    reads (swin_transformer.py:96-106,127-130: table[relative_position_index]); built once per block at pack time."""
+    N = window * window
+    c = torch.stack(torch.meshgrid(torch.arange(window), torch.arange(window), indexing="ij")).flatten(1)
+    rel = (c[:, :, None] - c[:, None, :]).permute(1, 2, 0).contiguous()
+    rel[:, :, 0] += window - 1
+    rel[:, :, 1] += window - 1
+    rel[:, :, 0] *= 2 * window - 1
+    idx = rel.sum(-1).view(-1).to(table.device)
+    dense = table.float()[idx].view(N, N, -1).permute(2, 0, 1)
+    out = torch.zeros((dense.shape[0], -(-N // 16) * 16, -(-N // 32) * 32), dtype=torch.float32, device=table.device)
+    out[:, :N, :N] = dense
+    return out.contiguous()
+
+
+def swin_patch_merge(x, ln_w, ln_b, eps: float = 1e-5):
+    """PatchMerging up to its LayerNorm (dtlr_swin_patch_merge): x [B,H,W,C] -> [B, ceil(H/2), ceil(W/2), 4C]."""
+    require_cuda(x, "x")
+    B, H, W, C = x.shape
+    x = x if x.is_contiguous() else x.contiguous()
+    y = torch.empty((B, (H + 1) // 2, (W + 1) // 2, 4 * C), dtype=x.dtype, device=x.device)
+    code = _lib.lib().dtlr_swin_patch_merge(x.data_ptr(), ln_w.data_ptr(), ln_b.data_ptr(), y.data_ptr(), B, H, W, C, eps, _DT[x.dtype], _lib.current_stream())
+    _lib.check(code, "dtlr_swin_patch_merge")
+    return y
+
+
 _POS_TABLES = {}
 
 
@@ -716,7 +771,7 @@ def _device_scoped(fn):
     return wrapper
 
 
-for _name in ("geometry", "linear", "gemm_k256", "linear_rowmax", "two_stage_gather", "layernorm", "proj_ln", "proj_ln_split", "ffn_fused", "conv2d_nhwc", "stem_conv7x7", "stem_conv7x7_f32",
+for _name in ("swin_patch_embed", "swin_window_attn", "swin_patch_merge", "geometry", "linear", "gemm_k256", "linear_rowmax", "two_stage_gather", "layernorm", "proj_ln", "proj_ln_split", "ffn_fused", "conv2d_nhwc", "stem_conv7x7", "stem_conv7x7_f32",
               "maxpool_nhwc", "groupnorm_tokens", "msda", "msda_fused", "msda_encoder", "mha", "decoder_query_prep", "box_mlp_refine",
               "box_head_refine", "box_refine", "topk_rows", "decode_blank", "preprocess_lines", "ctc_loss_interleaved", "nms_batched",
               "topk_flat"):

@@ -107,7 +107,52 @@ def synthetic_state_dict(cfg: DTLRConfig, seed: int = 0) -> "OrderedDict[str, to
     sd: "OrderedDict[str, torch.Tensor]" = OrderedDict()
     d, C, ff = cfg.hidden_dim, cfg.num_classes, cfg.dim_feedforward
 
+    if cfg.is_swin:
+        _swin(sd, cfg, seed)
     # ---- backbone.0.body.* : ResNet-50 v1.5 with FrozenBN -----------------------------------
+    b = "backbone.0.body."
+    if not cfg.is_swin:
+        _resnet(sd, cfg, seed)
+    _rest(sd, cfg, seed, d, C, ff)
+    return sd
+
+
+def _swin(sd, cfg: DTLRConfig, seed: int):
+    """backbone.0.* of a Swin backbone (models/dino/swin_transformer.py:435-555: patch_embed, layers.{i}.blocks.{j}, downsample,
+    norm{i} for the returned stages; `relative_position_index` is a registered buffer and part of the state dict)."""
+    sp = cfg.swin_params()
+    E, depths, heads, ws = sp["embed_dim"], sp["depths"], sp["num_heads"], sp["window_size"]
+    b = "backbone.0."
+    _conv(sd, b + "patch_embed.proj.weight", E, 3, 4, seed, gain=1.0)
+    sd[b + "patch_embed.proj.bias"] = _normal(b + "patch_embed.proj.bias", seed, (E,), 0.02)
+    _norm(sd, b + "patch_embed.norm", E, seed)
+    coords = np.stack(np.meshgrid(np.arange(ws), np.arange(ws), indexing="ij")).reshape(2, -1)
+    rel = (coords[:, :, None] - coords[:, None, :]).transpose(1, 2, 0).copy()
+    rel[:, :, 0] += ws - 1
+    rel[:, :, 1] += ws - 1
+    rel[:, :, 0] *= 2 * ws - 1
+    rel_index = torch.from_numpy(rel.sum(-1).astype(np.int64))
+    for i in range(4):
+        C = E << i
+        for j in range(depths[i]):
+            p = f"{b}layers.{i}.blocks.{j}."
+            _norm(sd, p + "norm1", C, seed)
+            sd[p + "attn.relative_position_bias_table"] = _normal(p + "attn.relative_position_bias_table", seed, ((2 * ws - 1) ** 2, heads[i]), 0.5)
+            sd[p + "attn.relative_position_index"] = rel_index.clone()
+            _linear(sd, p + "attn.qkv", 3 * C, C, seed, gain=1.4)
+            _linear(sd, p + "attn.proj", C, C, seed, gain=0.5)
+            _norm(sd, p + "norm2", C, seed)
+            _linear(sd, p + "mlp.fc1", 4 * C, C, seed, gain=math.sqrt(2.0))
+            _linear(sd, p + "mlp.fc2", C, 4 * C, seed, gain=0.5)
+        if i < 3:
+            p = f"{b}layers.{i}.downsample."
+            _norm(sd, p + "norm", 4 * C, seed)
+            sd[p + "reduction.weight"] = _normal(p + "reduction.weight", seed, (2 * C, 4 * C), 1.0 / math.sqrt(4 * C))
+        if i in cfg.return_interm_indices:
+            _norm(sd, f"{b}norm{i}", C, seed)
+
+
+def _resnet(sd, cfg: DTLRConfig, seed: int):
     b = "backbone.0.body."
     _conv(sd, b + "conv1.weight", 64, 3, 7, seed)
     _frozen_bn(sd, b + "bn1", 64, seed)
@@ -126,6 +171,9 @@ def synthetic_state_dict(cfg: DTLRConfig, seed: int = 0) -> "OrderedDict[str, to
                 _frozen_bn(sd, p + "downsample.1", planes * 4, seed)
             inplanes = planes * 4
 
+
+
+def _rest(sd, cfg: DTLRConfig, seed: int, d: int, C: int, ff: int):
     # ---- input_proj (models/dino/dino.py:115-136) ---------------------------------------------
     for l, cin in enumerate(cfg.backbone_channels):
         _conv(sd, f"input_proj.{l}.0.weight", d, cin, 1, seed, gain=1.0)
@@ -209,7 +257,6 @@ def synthetic_state_dict(cfg: DTLRConfig, seed: int = 0) -> "OrderedDict[str, to
             sd[key] = v
             sd[t + "decoder." + key] = v
     sd["label_enc.weight"] = _normal("label_enc.weight", seed, (cfg.dn_labelbook_size + 1, d), 1.0)
-    return sd
 
 
 # --------------------------------------------------------------------------------------------------

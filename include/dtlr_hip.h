@@ -281,6 +281,27 @@ int dtlr_preprocess_lines(const unsigned char *src, const long *offsets, const i
                           float *canvas, unsigned char *mask, void *stream);
 
 /* ---------------------------------------------------------------------------------------------
+ * Swin Transformer backbone (selected by `backbone = 'swin_*'`, models/dino/backbone.py:172-205).  Activations are token-major
+ * [B,H,W,C]; head_dim is 32 in every reference variant (swin_transformer.py:686-717).
+ * dtlr_swin_patch_embed  replaces PatchEmbed.forward (models/dino/swin_transformer.py:416-432): zero padding to a multiple of 4,
+ *     4x4/stride-4 convolution, LayerNorm(E).  x [B,3,H,W] fp32 ; w_kE [48,E] fp32 (k = (c*4 + dy)*4 + dx) ; bias/gamma/beta [E] ;
+ *     out [B,ceil(H/4),ceil(W/4),E] (F32 / BF16) ; E in {32, 64, 96, 128, 192}.
+ * dtlr_swin_window_attn  replaces the attention core of SwinTransformerBlock.forward + WindowAttention.forward (:116-147,
+ *     191-236): F.pad to a multiple of the window, torch.roll(-shift), window_partition, q k^T * scale + relative position bias
+ *     (+ the 0/-100 shifted-window mask of BasicLayer.forward :357-376), softmax, p v, window_reverse, roll back, un-pad.
+ *     qkv [B,H,W,3C] = the qkv projection of norm1(x) ; qkv_bias [3C] fp32 (a padded position projects to the bare biases) ;
+ *     rpb [n_heads, ceil16(N), ceil32(N)] fp32 = relative_position_bias_table[relative_position_index], zero padded, N = window^2 ;
+ *     out [B,H,W,C] (the input of `proj`).  dtype F32 (exact-fp32 MFMA) or BF16.  window <= 13, C == 32 * n_heads.
+ * dtlr_swin_patch_merge  replaces PatchMerging.forward up to its LayerNorm (:262-286): y [B,ceil(H/2),ceil(W/2),4C] =
+ *     LayerNorm(cat(x[2i,2j], x[2i+1,2j], x[2i,2j+1], x[2i+1,2j+1])), zeros beyond H/W ; 4C <= 3072. */
+int dtlr_swin_patch_embed(const float *x, const float *w_kE, const float *bias, const float *gamma, const float *beta,
+                          void *out, int B, int H, int W, int E, float eps, int out_dtype, void *stream);
+int dtlr_swin_window_attn(const void *qkv, const float *qkv_bias, const float *rpb, void *out,
+                          int B, int H, int W, int C, int n_heads, int window, int shift, int dtype, void *stream);
+int dtlr_swin_patch_merge(const void *x, const float *gamma, const float *beta, void *y, int B, int H, int W, int C,
+                          float eps, int dtype, void *stream);
+
+/* ---------------------------------------------------------------------------------------------
  * Mask-derived geometry of one forward, ONE launch (a workgroup per row of a level of an image).
  * Replaces: the per-level masks F.interpolate(mask[None].float(), size).bool() (models/dino/backbone.py:103, dino.py:304-307);
  *           get_valid_ratio (models/dino/deformable_transformer.py:239-246); PositionEmbeddingSineHW.forward

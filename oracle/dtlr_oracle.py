@@ -107,6 +107,131 @@ def resnet50_body(x: Tensor, sd: Dict[str, Tensor], blocks=(3, 4, 6, 3)) -> List
     return outs
 
 
+# ======================================================================================
+# models/dino/swin_transformer.py  (backbones selected by `backbone = 'swin_*'`)
+# ======================================================================================
+def swin_window_partition(x: Tensor, ws: int) -> Tensor:
+    """swin_transformer.py:39-50: [B,H,W,C] -> [B*nW, ws, ws, C]."""
+    B, H, W, C = x.shape
+    x = x.view(B, H // ws, ws, W // ws, ws, C)
+    return x.permute(0, 1, 3, 2, 4, 5).contiguous().view(-1, ws, ws, C)
+
+
+def swin_window_reverse(windows: Tensor, ws: int, H: int, W: int) -> Tensor:
+    """swin_transformer.py:53-66."""
+    B = int(windows.shape[0] / (H * W / ws / ws))
+    x = windows.view(B, H // ws, W // ws, ws, ws, -1)
+    return x.permute(0, 1, 3, 2, 4, 5).contiguous().view(B, H, W, -1)
+
+
+def swin_relative_position_index(ws: int) -> Tensor:
+    """swin_transformer.py:96-106 (the registered buffer `relative_position_index`)."""
+    coords = torch.stack(torch.meshgrid([torch.arange(ws), torch.arange(ws)], indexing="ij"))
+    cf = torch.flatten(coords, 1)
+    rel = (cf[:, :, None] - cf[:, None, :]).permute(1, 2, 0).contiguous()
+    rel[:, :, 0] += ws - 1
+    rel[:, :, 1] += ws - 1
+    rel[:, :, 0] *= 2 * ws - 1
+    return rel.sum(-1)
+
+
+def swin_shift_mask(H: int, W: int, ws: int, shift: int) -> Tensor:
+    """BasicLayer.forward, swin_transformer.py:357-376: the 0 / -100 attention mask of the shifted windows, [nW, ws*ws, ws*ws]."""
+    Hp = -(-H // ws) * ws
+    Wp = -(-W // ws) * ws
+    img = torch.zeros((1, Hp, Wp, 1))
+    cnt = 0
+    for h in (slice(0, -ws), slice(-ws, -shift), slice(-shift, None)):
+        for w in (slice(0, -ws), slice(-ws, -shift), slice(-shift, None)):
+            img[:, h, w, :] = cnt
+            cnt += 1
+    mw = swin_window_partition(img, ws).view(-1, ws * ws)
+    am = mw.unsqueeze(1) - mw.unsqueeze(2)
+    return am.masked_fill(am != 0, float(-100.0)).masked_fill(am == 0, float(0.0))
+
+
+def swin_window_attention(sd, p: str, x: Tensor, ws: int, nh: int, mask: Optional[Tensor]) -> Tensor:
+    """WindowAttention.forward, swin_transformer.py:116-147.  x [nW*B, N, C]."""
+    B_, N, C = x.shape
+    qkv = F.linear(x, sd[p + "qkv.weight"], sd[p + "qkv.bias"]).reshape(B_, N, 3, nh, C // nh).permute(2, 0, 3, 1, 4)
+    q, k, v = qkv[0], qkv[1], qkv[2]
+    q = q * ((C // nh) ** -0.5)
+    attn = q @ k.transpose(-2, -1)
+    idx = swin_relative_position_index(ws)
+    bias = sd[p + "relative_position_bias_table"][idx.view(-1)].view(N, N, -1).permute(2, 0, 1).contiguous()
+    attn = attn + bias.unsqueeze(0)
+    if mask is not None:
+        nW = mask.shape[0]
+        attn = attn.view(B_ // nW, nW, nh, N, N) + mask.unsqueeze(1).unsqueeze(0)
+        attn = attn.view(-1, nh, N, N)
+    attn = F.softmax(attn, dim=-1)
+    x = (attn @ v).transpose(1, 2).reshape(B_, N, C)
+    return F.linear(x, sd[p + "proj.weight"], sd[p + "proj.bias"])
+
+
+def swin_block(sd, p: str, x: Tensor, H: int, W: int, ws: int, shift: int, nh: int, mask_matrix: Tensor) -> Tensor:
+    """SwinTransformerBlock.forward, swin_transformer.py:191-247 (drop_path is the identity in eval)."""
+    B, L, C = x.shape
+    shortcut = x
+    x = F.layer_norm(x, (C,), sd[p + "norm1.weight"], sd[p + "norm1.bias"], 1e-5).view(B, H, W, C)
+    pad_r, pad_b = (ws - W % ws) % ws, (ws - H % ws) % ws
+    x = F.pad(x, (0, 0, 0, pad_r, 0, pad_b))
+    Hp, Wp = x.shape[1], x.shape[2]
+    if shift > 0:
+        x = torch.roll(x, shifts=(-shift, -shift), dims=(1, 2))
+    xw = swin_window_partition(x, ws).view(-1, ws * ws, C)
+    aw = swin_window_attention(sd, p + "attn.", xw, ws, nh, mask_matrix if shift > 0 else None)
+    x = swin_window_reverse(aw.view(-1, ws, ws, C), ws, Hp, Wp)
+    if shift > 0:
+        x = torch.roll(x, shifts=(shift, shift), dims=(1, 2))
+    if pad_r > 0 or pad_b > 0:
+        x = x[:, :H, :W, :].contiguous()
+    x = shortcut + x.view(B, H * W, C)
+    y = F.layer_norm(x, (C,), sd[p + "norm2.weight"], sd[p + "norm2.bias"], 1e-5)
+    y = F.linear(F.gelu(F.linear(y, sd[p + "mlp.fc1.weight"], sd[p + "mlp.fc1.bias"])), sd[p + "mlp.fc2.weight"], sd[p + "mlp.fc2.bias"])
+    return x + y
+
+
+def swin_patch_merging(sd, p: str, x: Tensor, H: int, W: int) -> Tensor:
+    """PatchMerging.forward, swin_transformer.py:262-288."""
+    B, L, C = x.shape
+    x = x.view(B, H, W, C)
+    if H % 2 == 1 or W % 2 == 1:
+        x = F.pad(x, (0, 0, 0, W % 2, 0, H % 2))
+    x = torch.cat([x[:, 0::2, 0::2, :], x[:, 1::2, 0::2, :], x[:, 0::2, 1::2, :], x[:, 1::2, 1::2, :]], -1).view(B, -1, 4 * C)
+    x = F.layer_norm(x, (4 * C,), sd[p + "norm.weight"], sd[p + "norm.bias"], 1e-5)
+    return F.linear(x, sd[p + "reduction.weight"])
+
+
+def swin_body(x: Tensor, sd: Dict[str, Tensor], sp: dict, out_indices=(1, 2, 3)) -> List[Tensor]:
+    """SwinTransformer.forward (swin_transformer.py:633-673; patch_size 4, patch_norm, no ape, no dilation) -> the NCHW maps of
+    `out_indices`, each after its norm{i}."""
+    b = "backbone.0."
+    E, depths, heads, ws = sp["embed_dim"], sp["depths"], sp["num_heads"], sp["window_size"]
+    H0, W0 = x.shape[-2:]
+    if W0 % 4:
+        x = F.pad(x, (0, 4 - W0 % 4))
+    if H0 % 4:
+        x = F.pad(x, (0, 0, 0, 4 - H0 % 4))
+    x = F.conv2d(x, sd[b + "patch_embed.proj.weight"], sd[b + "patch_embed.proj.bias"], stride=4)
+    Wh, Ww = x.shape[2], x.shape[3]
+    x = x.flatten(2).transpose(1, 2)
+    x = F.layer_norm(x, (E,), sd[b + "patch_embed.norm.weight"], sd[b + "patch_embed.norm.bias"], 1e-5)
+    outs = []
+    for i in range(4):
+        C = E << i
+        mask = swin_shift_mask(Wh, Ww, ws, ws // 2)
+        for j in range(depths[i]):
+            x = swin_block(sd, f"{b}layers.{i}.blocks.{j}.", x, Wh, Ww, ws, 0 if j % 2 == 0 else ws // 2, heads[i], mask)
+        if i in out_indices:
+            o = F.layer_norm(x, (C,), sd[f"{b}norm{i}.weight"], sd[f"{b}norm{i}.bias"], 1e-5)
+            outs.append(o.view(-1, Wh, Ww, C).permute(0, 3, 1, 2).contiguous())
+        if i < 3:
+            x = swin_patch_merging(sd, f"{b}layers.{i}.downsample.", x, Wh, Ww)
+            Wh, Ww = (Wh + 1) // 2, (Ww + 1) // 2
+    return outs
+
+
 def interpolate_mask(mask: Tensor, size) -> Tensor:
     """backbone.py:103 / dino.py:304-307: nearest F.interpolate of the float mask, back to bool."""
     return F.interpolate(mask[None].float(), size=tuple(int(s) for s in size)).to(torch.bool)[0]
@@ -439,7 +564,10 @@ def dino_forward(sd: Dict[str, Tensor], cfg, samples, mask: Optional[Tensor] = N
         x, mask = nested_tensor_from_tensor_list(samples)
     else:
         x = samples
-    feats = resnet50_body(x, sd, cfg.backbone_blocks)
+    if getattr(cfg, "is_swin", False):
+        feats = swin_body(x, sd, cfg.swin_params(), tuple(cfg.return_interm_indices))     # backbone.py:172-205
+    else:
+        feats = resnet50_body(x, sd, cfg.backbone_blocks)
     srcs, masks, poss = [], [], []
     for l, f in enumerate(feats):
         m = interpolate_mask(mask, f.shape[-2:])

@@ -177,7 +177,7 @@ def build_reference_model(cfg, state_dict):
     from models.dino.dino import build_dino
     args = load_reference_config("Latin_CTC.py")
     for k in ("num_classes", "enc_layers", "dec_layers", "dim_feedforward", "num_queries", "num_select",
-              "dn_labelbook_size", "hidden_dim", "nheads"):
+              "dn_labelbook_size", "hidden_dim", "nheads", "backbone"):
         args[k] = getattr(cfg, k)
     model, criterion, postprocessors = build_dino(args)
     missing, unexpected = model.load_state_dict(state_dict, strict=True)

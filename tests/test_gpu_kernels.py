@@ -862,7 +862,7 @@ def test_gemm_k256_epilogues():
     wp = ops.k256_pack(w)
     got = ops.gemm_k256(x, wp, N, None, resid=res)
     want = (x.float() @ w.float().t() + res.float()[None]).bfloat16()
-    assert (got.float() - want.float()).abs().max() <= 0.02
+    assert (got.float() - want.float()).abs().max() <= 0.07          # one bf16 ulp at |y| < 16
     wide = torch.full((B, S, 1536), 7.0, dtype=torch.bfloat16, device="cuda")
     ops.gemm_k256(x, wp, N, b, row_mask=mask, out=wide[..., 384:768])
     full = ops.linear(x, w, b, row_mask=mask)

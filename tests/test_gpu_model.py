@@ -420,3 +420,63 @@ def test_data_parallel_two_ranks_on_one_gpu_equals_single_process():
     line = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
     assert line["n_gpus"] == 2 and line["config"]["global_batch"] == 6
     assert line["distributed"] == {"backend": "gloo", "world_size": 2, "dp_verified": True}
+
+
+# ---- Swin backbones ---------------------------------------------------------------------------
+def test_swin_backbone_fp32_vs_reference_golden_and_oracle(golden_dir):
+    """engine.backbone_swin (patch embed, window attention with shift / padding / relative bias on the exact-fp32 matrix cores, MLP
+    with the GELU epilogue, patch merging) == the reference's SwinTransformer outputs (G7a: odd sizes) and the oracle on a second
+    shape whose stages are all multiples of the window (no padding path) and one with a single window per axis."""
+    from dtlr_amd.engine import DTLREngine
+    from oracle import dtlr_oracle as O
+    from tests.golden.make_golden_swin import custom_cfg
+    g = np.load(os.path.join(golden_dir, "g7_swin.npz"))
+    cfg = custom_cfg()
+    sd = weights.synthetic_state_dict(cfg, 0)
+    eng = DTLREngine(cfg, sd, "cuda:0", torch.float32)
+    x = torch.stack(synth.noise_lines(2, 37, 90, seed=71))
+    feats = eng.backbone_swin(x.cuda())
+    for i, f in enumerate(feats):
+        want = torch.from_numpy(g[f"a_feat{i}"]).permute(0, 2, 3, 1)
+        assert f.shape == want.shape
+        assert (f.cpu() - want).abs().max() < 2e-4, i
+    for (h, w) in ((64, 128), (16, 16), (33, 260)):
+        x = torch.stack(synth.noise_lines(2, h, w, seed=h))
+        want = O.swin_body(x, sd, cfg.swin_params())
+        got = eng.backbone_swin(x.cuda())
+        for a, b in zip(got, want):
+            assert (a.cpu() - b.permute(0, 2, 3, 1)).abs().max() < 2e-4, (h, w)
+
+
+def test_swin_t_full_model_fp32_vs_reference_golden(golden_dir):
+    """DINO with backbone = 'swin_T_224_1k' (backbone.py:172-205) against the reference's build_dino outputs (G7b), selection pinned."""
+    from tests.golden.make_golden_swin import swin_t_cfg
+    g = np.load(os.path.join(golden_dir, "g7_swin.npz"))
+    cfg = swin_t_cfg()
+    sd = weights.synthetic_state_dict(cfg, 0)
+    m = _model(cfg, sd)
+    imgs = synth.stroke_lines(1, 64, 256, seed=5) + synth.noise_lines(1, 48, 200, seed=6)
+    out = m([i.cuda() for i in imgs], forced_topk=torch.from_numpy(g["b_topk_idx"].astype(np.int64)).cuda(), return_debug=True)
+    assert (out["_debug"]["topk_scores"].cpu() - torch.from_numpy(g["b_topk_scores"])).abs().max() < 5e-4
+    assert (out["_debug"]["memory"][:, ::7].cpu() - torch.from_numpy(g["b_memory"])).abs().max() < 5e-4
+    assert (out["pred_logits"].cpu() - torch.from_numpy(g["b_pred_logits"])).abs().max() < LOGIT_TOL
+    assert (out["pred_boxes"].cpu() - torch.from_numpy(g["b_pred_boxes"])).abs().max() < BOX_TOL
+
+
+def test_swin_backbone_bf16_close_to_oracle():
+    """bf16 engine (bf16 MFMA window attention, bf16 GEMMs) on a Swin whose widths are multiples of 64: features close to the fp32
+    oracle (relative error of a few bf16 ulps per block, 8 blocks)."""
+    import dataclasses
+    from dtlr_amd.engine import DTLREngine
+    from oracle import dtlr_oracle as O
+    cfg = dataclasses.replace(DTLRConfig.tiny(), backbone="swin_custom", swin_embed_dim=64, swin_depths=(2, 2, 2, 2),
+                              swin_num_heads=(2, 4, 8, 16), swin_window=7)
+    sd = weights.synthetic_state_dict(cfg, 2)
+    eng = DTLREngine(cfg, sd, "cuda:0", torch.bfloat16)
+    x = torch.stack(synth.noise_lines(2, 60, 250, seed=3))
+    want = O.swin_body(x, sd, cfg.swin_params())
+    got = eng.backbone_swin(x.cuda())
+    for a, b in zip(got, want):
+        b = b.permute(0, 2, 3, 1)
+        rel = (a.float().cpu() - b).abs().mean() / b.abs().mean()
+        assert rel < 0.03, rel.item()

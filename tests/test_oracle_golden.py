@@ -180,3 +180,26 @@ def test_g5_ctc_loss_matches_reference_criterion(golden_dir):
         outputs, labels = ctc_case(int(seed), int(B), int(nq), int(C), bias, int(lmax))
         got = O.loss_ctc(outputs, labels).item()
         assert abs(got - float(g[f"loss_{k}"])) <= 1e-5 * max(1.0, abs(float(g[f"loss_{k}"]))), (k, got, float(g[f"loss_{k}"]))
+
+
+# ---- Swin backbones ---------------------------------------------------------------------------
+def test_g7_swin_backbone_and_full_model(golden_dir):
+    """oracle.swin_body == the reference's SwinTransformer class (test-sized network, odd sizes: patch padding, window padding,
+    shifted windows, odd patch merging) and oracle.dino_forward with backbone = swin_T_224_1k == the reference's build_dino
+    (tests/golden/make_golden_swin.py)."""
+    from tests.golden.make_golden_swin import custom_cfg, swin_t_cfg
+    g = np.load(os.path.join(golden_dir, "g7_swin.npz"))
+    cfg = custom_cfg()
+    sd = synthetic_state_dict(cfg, seed=0)
+    x = torch.stack(noise_lines(2, 37, 90, seed=71))
+    feats = O.swin_body(x, sd, cfg.swin_params())
+    for i, f in enumerate(feats):
+        assert (f - _t(g[f"a_feat{i}"])).abs().max() < 2e-5
+    cfg = swin_t_cfg()
+    sd = synthetic_state_dict(cfg, seed=0)
+    imgs = stroke_lines(1, 64, 256, seed=5) + noise_lines(1, 48, 200, seed=6)
+    out = O.dino_forward(sd, cfg, imgs, forced_topk=_t(g["b_topk_idx"].astype(np.int64)), return_debug=True)
+    assert (out["_debug"]["topk_scores"] - _t(g["b_topk_scores"])).abs().max() < 1e-4
+    assert (out["_debug"]["memory"][:, ::7] - _t(g["b_memory"])).abs().max() < 2e-4
+    assert (out["pred_logits"] - _t(g["b_pred_logits"])).abs().max() < 1e-3
+    assert (out["pred_boxes"] - _t(g["b_pred_boxes"])).abs().max() < 1e-5
