@@ -142,7 +142,8 @@ extern "C" int dtlr_layernorm(const void* x, const void* residual, const float* 
     if (!x || !gamma || !beta || !y) return DTLR_EINVAL;
     if (rows <= 0 || C <= 0) return DTLR_EINVAL;
     hipStream_t st = (hipStream_t)stream;
-    if (C % 256 != 0) {                                          // generic row kernel (Swin widths)
+    const int ch256 = C / 256;
+    if (C % 256 != 0 || !(ch256 == 1 || ch256 == 2 || ch256 == 4 || ch256 == 8)) {     // generic row kernel (Swin widths: 96 .. 1536, 768, 3072)
         if ((C & 3) || C > 3072) return DTLR_ESHAPE;
         const long grid = (rows + 3) / 4;
         if (grid > 0x7fffffffL) return DTLR_ESHAPE;

@@ -876,6 +876,99 @@ def compute_wer_engine(pred_labels: Sequence[Sequence[int]], target_labels: Sequ
 
 
 # ======================================================================================
+# ngram/prediction_helpers.py -- n-gram re-scoring around a CTC beam decoder
+# ======================================================================================
+def ngram_new_pred_logits(output, multiply_pred_logits_by: float = 1.0) -> Tensor:
+    """prediction_helpers.py:5-46 (get_new_pred_logits)."""
+    logits, boxes = output["pred_logits"], output["pred_boxes"]
+    _, idx = torch.sort(boxes[:, :, 0])
+    p = torch.gather(logits, 1, idx.unsqueeze(-1).expand(-1, -1, logits.shape[-1])).sigmoid() * multiply_pred_logits_by
+    new = torch.zeros((p.shape[0], p.shape[1], p.shape[2] + 1))
+    new[:, :, 1:] = p
+    eps = 0.003
+    mask = p.sum(-1) < 1 - eps
+    new[:, :, 0][mask] = 1 - p[mask].sum(-1)
+    mask = ~mask
+    new[:, :, 0][mask] = eps
+    new[:, :, 1:][mask] = (1 - eps) * p[mask] / p[mask].sum(-1).unsqueeze(-1)
+    return new
+
+
+def ngram_first_non_0(label_list):
+    """prediction_helpers.py:117-121 (UnboundLocalError on an empty list, like the reference)."""
+    for e in label_list:
+        if e > 0:
+            break
+    return e                                          # noqa: F821 - deliberately unbound for an empty list
+
+
+def ngram_input_split_indices(new_pred_logits, ngram_charset, indices_to_ignore, no_uppercase_words=True, no_digits=False, no_dash=True):
+    """prediction_helpers.py:124-173."""
+    model_labels = new_pred_logits[0].argmax(-1)
+    mask = (model_labels[:, None] == torch.tensor(indices_to_ignore)[None, :]).any(-1)
+    split_indices = [-1] + torch.where(mask)[0].tolist() + [len(new_pred_logits[0])]
+    if not (no_uppercase_words or no_digits):
+        return split_indices, split_indices
+    clean = []
+    for i in range(len(split_indices) - 1):
+        try:
+            first = ngram_first_non_0(model_labels[split_indices[i] + 1: split_indices[i + 1] - 1].tolist())
+        except UnboundLocalError:
+            continue
+        if first == 0:
+            continue
+        if no_uppercase_words and ngram_charset[first].isupper():
+            continue
+        if no_digits and ngram_charset[first].isdigit():
+            continue
+        elif no_dash and (ngram_charset.index("-") in model_labels[split_indices[i] + 1: split_indices[i + 1]].tolist()):
+            continue
+        else:
+            clean.append(split_indices[i])
+    clean.append(len(new_pred_logits[0]))
+    return split_indices, clean
+
+
+def ngram_word_per_word_pred(new_pred_logits, ctc_decoder, indices_to_ignore, charset) -> str:
+    """prediction_helpers.py:49-74."""
+    mask = (new_pred_logits[0].argmax(-1)[:, None] == torch.tensor(indices_to_ignore)[None, :]).any(-1)
+    split_indices = [-1] + torch.where(mask)[0].tolist() + [len(new_pred_logits[0])]
+    characs = []
+    model_labels = new_pred_logits[0].argmax(-1)
+    for i in range(len(split_indices) - 1):
+        if split_indices[i] < split_indices[i + 1] - 1:
+            word = new_pred_logits[0][split_indices[i] + 1: split_indices[i + 1]][None, :, :]
+            characs += ctc_decoder(word)[0][0].words
+        if split_indices[i + 1] < len(new_pred_logits[0]):
+            characs += charset[model_labels[split_indices[i + 1]] - 1]
+    return "".join(characs)
+
+
+def ngram_word_per_word_pred_2(new_pred_logits, ctc_decoder, indices_to_ignore, ngram_charset, no_uppercase_words, no_digits, no_dash) -> str:
+    """prediction_helpers.py:176-224."""
+    model_labels = new_pred_logits[0].argmax(-1)
+    split_indices, clean = ngram_input_split_indices(new_pred_logits, ngram_charset, indices_to_ignore, no_uppercase_words, no_digits, no_dash)
+    characs = []
+    max_added = -1
+    for i in range(len(split_indices) - 1):
+        a, b = split_indices[i], split_indices[i + 1]
+        if (a in split_indices[1:]) and (a > max_added):
+            characs += ngram_charset[model_labels[a]]
+            max_added = a
+        if (a < b) and (a in clean):
+            characs += ctc_decoder(new_pred_logits[0][a + 1: b][None, :, :])[0][0].words
+            max_added = max(b - 1, max_added)
+        else:
+            word = model_labels[a + 1: b]
+            characs += [ngram_charset[c] for c in word[word > 0]]
+            max_added = max(b - 1, max_added)
+        if (b in split_indices[:-1]) and (b > max_added):
+            characs += ngram_charset[model_labels[b]]
+            max_added = b
+    return "".join(characs)
+
+
+# ======================================================================================
 # datasets/transforms.py -- eval-time preprocessing (SURVEY.md section 8f.1)
 # ======================================================================================
 def get_size_with_aspect_ratio(image_size: Tuple[int, int], size: int, max_size: Optional[int] = None) -> Tuple[int, int]:

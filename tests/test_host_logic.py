@@ -333,3 +333,39 @@ def test_eval_harness_bookkeeping_and_batch_plan(tmp_path):
     assert res["CR_list"][:2] == [O.compute_cr(enc(g), p) for g, p in zip(gts[:2], preds[:2])] and res["CER_list"][2] == 1
     d = H.write_outputs(res, str(tmp_path / "stats"), "HWDB", None, None)
     assert sorted(os.listdir(d)) == ["cer_TH_None_NMS_None.txt", "cer_list.npy", "dict_char.json", "list_gt.txt", "list_preds.txt"]
+
+
+def test_g8_ngram_glue_oracle_and_product_vs_reference_vectors(golden_dir, tmp_path):
+    """N-gram re-scoring glue (ngram/prediction_helpers.py): emissions, split indices and the two word-per-word assemblies of the
+    oracle AND of dtlr_amd.ngram reproduce the vectors produced by the reference's own function bodies with a fake decoder
+    (tests/golden/make_golden_ngram.py).  The beam decoder itself (torchaudio / KenLM: third party, absent) is exercised separately."""
+    import json
+    from dtlr_amd import ngram as NG
+    from tests.util import fake_ctc_decoder, ngram_case
+    g = json.load(open(os.path.join(golden_dir, "g8_ngram.json")))
+    flags = ((True, False, True), (False, True, True), (True, True, False))
+    for rec in g["cases"]:
+        outputs, charset, ngc, ign = ngram_case(rec["seed"])
+        for new in (O.ngram_new_pred_logits(outputs), NG.get_new_pred_logits(outputs)):
+            assert abs(float(new.double().sum()) - rec["new_sum"]) < 1e-5 and new[0].argmax(-1).tolist() == rec["new_argmax"]
+        assert O.ngram_word_per_word_pred(new, fake_ctc_decoder(ngc), ign, charset) == rec["word_per_word"]
+        assert NG.get_word_per_word_pred(new, fake_ctc_decoder(ngc), ign, charset) == rec["word_per_word"]
+        for k, (up, dg, ds) in enumerate(flags):
+            assert [list(map(int, v)) for v in O.ngram_input_split_indices(new, ngc, ign, up, dg, ds)] == rec[f"split_{k}"]
+            assert [list(v) for v in NG.get_input_split_indices(new[0].argmax(-1).tolist(), ngc, ign, up, dg, ds)] == rec[f"split_{k}"]
+            assert O.ngram_word_per_word_pred_2(new, fake_ctc_decoder(ngc), ign, ngc, up, dg, ds) == rec[f"word_per_word_2_{k}"]
+            assert NG.get_word_per_word_pred_2(new, fake_ctc_decoder(ngc), ign, ngc, up, dg, ds) == rec[f"word_per_word_2_{k}"]
+            assert NG.get_ngram_prediction(outputs, fake_ctc_decoder(ngc), ign, charset, ngc, True, up, dg, ds) == rec[f"word_per_word_2_{k}"]
+    # the self-contained lexicon beam decoder (torchaudio's call interface): picks lexicon words, the n-gram breaks acoustic ties
+    tokens = ["<ctc>", "c", "a", "t", "r", "<space>"]
+    lex = {"cat": ["c", "a", "t"], "car": ["c", "a", "r"], "at": ["a", "t"]}
+    em = torch.full((1, 6, len(tokens)), 0.01)
+    for t, ch in enumerate(["c", "<ctc>", "a", "a", "<ctc>", "t"]):
+        em[0, t, tokens.index(ch)] = 0.9
+    dec = NG.LexiconCTCDecoder(tokens, lex, beam_size=20)
+    assert dec(em)[0][0].words == ["cat"]
+    em[0, 5, tokens.index("t")] = em[0, 5, tokens.index("r")] = 0.45            # acoustic tie between cat / car
+    (tmp_path / "lm.arpa").write_text("\\data\\\nngram 1=4\n\n\\1-grams:\n-0.3\tcar\n-2.0\tcat\n-2.0\tat\n-3.0\t<unk>\n\n\\end\\\n")
+    lm = NG.ArpaLM(str(tmp_path / "lm.arpa"))
+    assert abs(lm.score((), "car") + 0.3) < 1e-9
+    assert NG.LexiconCTCDecoder(tokens, lex, lm=lm, lm_weight=2.0, beam_size=20)(em)[0][0].words == ["car"]

@@ -147,3 +147,47 @@ def compare_decoded(ref_logits, ref_boxes, got_logits, got_boxes, eps, logit_bou
         strings_equal &= (ref_s == got_s)
     return dict(safe_frac=float(safe.float().mean()), label_mismatch_on_safe=mism, strings_equal=strings_equal, safe_chars=n_chars,
                 chars_ref=int((rl >= 0).sum()), chars_got=int((gl >= 0).sum()), raw_label_agree=float((rl == gl).float().mean()))
+
+
+# ---- n-gram re-scoring fixtures (shared by tests/golden/make_golden_ngram.py and the tests) -------------------------------------
+def ngram_case(seed):
+    """Seeded head outputs of ONE line whose argmax sequence looks like text: words of letters / digits / dashes separated by
+    spaces and punctuation, blanks in between.  charset = the model's (label c <-> emission channel c + 1); ngram_charset = the
+    n-gram side's table indexed by emission channel (index 0 = the CTC token)."""
+    g = np.random.Generator(np.random.PCG64(4000 + seed))
+    charset = list("abcdefgHIJ 0123-.,")
+    ngram_charset = ["<ctc>"] + charset
+    ignore = [ngram_charset.index(c) for c in " .,"]
+    nq, C = 40, len(charset)
+    logits = np.full((1, nq, C), -9.0, dtype=np.float32)
+    cx = np.sort(g.uniform(0.02, 0.98, nq)).astype(np.float32)
+    for q in range(nq):
+        r = g.random()
+        if r < 0.25:
+            continue                                               # blank query
+        c = int(g.integers(0, C)) if r < 0.9 else charset.index(" ")
+        logits[0, q, c] = float(g.uniform(2.0, 8.0))
+        if g.random() < 0.2:
+            logits[0, q, int(g.integers(0, C))] = float(g.uniform(-1.0, 1.5))
+    boxes = np.stack([cx, np.full(nq, 0.5, np.float32), np.full(nq, 0.02, np.float32), np.full(nq, 0.8, np.float32)], -1)[None]
+    perm = g.permutation(nq)                                      # queries are not in reading order in the head output
+    return ({"pred_logits": torch.from_numpy(logits[:, perm]), "pred_boxes": torch.from_numpy(boxes[:, perm].copy())},
+            charset, ngram_charset, ignore)
+
+
+def fake_ctc_decoder(ngram_charset):
+    """A deterministic stand-in with torchaudio's ctc_decoder interface: greedy CTC collapse of the emissions, upper-cased, returned
+    as hypothesis.words (a list of strings) -- enough to show WHICH spans were sent to the decoder and where its output lands."""
+    class _H:
+        def __init__(self, words):
+            self.words = words
+
+    def dec(em):
+        lab = em[0].argmax(-1).tolist()
+        out, prev = [], None
+        for v in lab:
+            if v != prev and v != 0:
+                out.append(ngram_charset[v].upper())
+            prev = v
+        return [[_H(out)]]
+    return dec
