@@ -26,6 +26,7 @@
 //                 + residual, ReLU-after-residual (ResNet bottleneck tail), output fp32 or bf16.
 #include "dtlr_common.h"
 #include <cstdlib>
+#include <type_traits>
 
 namespace dtlr {
 
@@ -49,6 +50,7 @@ __device__ __forceinline__ uint4 asm_load16(const char* p) {
 template <int N> __device__ __forceinline__ void wait_vmcnt() {
     if constexpr (N == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     else if constexpr (N == 8) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+    else if constexpr (N == 10) asm volatile("s_waitcnt vmcnt(10)" ::: "memory");
     else if constexpr (N == 12) asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
     __builtin_amdgcn_sched_barrier(0);
 }
@@ -728,6 +730,162 @@ __global__ __launch_bounds__(512, HAS_A2 ? 2 : 4) void gemm_ws_kernel(
     }
 }
 
+// ---------------------------------------------------------------------------------------------
+// "Tall" variant for N <= 64 output channels (ResNet layer1: the 3x3 64 -> 64 convolutions and the 256 -> 64 reductions, a
+// quarter of the backbone's GEMM time): tile = 256 tokens x 64 channels, MFMA wave w owns tokens 64w..64w+63 x all 64 channels.
+// In the 128 x 128 kernel above a 64-channel problem leaves the two wn = 1 MFMA waves multiplying clamped (duplicate) weight
+// rows: half of the matrix-pipe and LDS-read work of every tile is thrown away.  Same loader / two-set pipeline / swizzled LDS
+// image / epilogue; no A2, no split-K; one channel tile, so a chain is just a run of token tiles.
+// ---------------------------------------------------------------------------------------------
+constexpr int TALL_BM = 256, TALL_STAGE = (64 + TALL_BM) * LDS_ROW;       // 40 KB per stage: W tile (64 rows) | X tile (256 rows)
+
+template <typename T, typename OutT, bool CONV, int CF = -1>
+__global__ __launch_bounds__(512, 4) void gemm_ws_tall_kernel(
+    const T* __restrict__ A, const T* __restrict__ W, const float* __restrict__ bias, const OutT* __restrict__ residual,
+    OutT* __restrict__ C, int M, int N, int K, int flags, int ntilesM, int tiles_per_block, ConvP cp)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int wave = threadIdx.x >> 6;
+    constexpr int BK = GT<T>::BK;
+    const int nk = K / BK;
+    const int t_begin = (int)blockIdx.x * tiles_per_block;
+    const int t_end = min(t_begin + tiles_per_block, ntilesM);
+    if (t_begin >= t_end) return;
+    const int total = (t_end - t_begin) * nk;
+
+    if (wave >= 4) {
+        // ================================ loader role ================================
+        const int tid = threadIdx.x - 256;
+        const int srow = tid >> 3, kc = tid & 7;
+        const int lds0 = srow * LDS_ROW + ((kc ^ (srow & 7)) * 16);
+        const int slabs_per_tap = CONV ? (cp.Cin * (int)sizeof(T)) / SLAB : 1;
+        const char* Ab = reinterpret_cast<const char*>(A);
+        const char* Wb = reinterpret_cast<const char*>(W);
+        const char* zero_line = reinterpret_cast<const char*>(g_zero_line);
+        (void)zero_line;
+        long a_off[8], w_off[2];
+        int hi0[8], wi0[8];
+        auto set_tile = [&](int tile) {
+            const int lm0 = tile * TALL_BM;
+#pragma unroll
+            for (int i = 0; i < 2; ++i) w_off[i] = ((long)min(srow + 32 * i, N - 1) * K) * (long)sizeof(T) + kc * 16;
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                const long ar = min(lm0 + srow + 32 * i, M - 1);
+                if (CONV) {
+                    const int hw = cp.Ho * cp.Wo;
+                    const int bimg = (int)(ar / hw), rem = (int)(ar % hw);
+                    hi0[i] = (rem / cp.Wo) * cp.stride - cp.pad;
+                    wi0[i] = (rem % cp.Wo) * cp.stride - cp.pad;
+                    a_off[i] = (long)bimg * cp.H * cp.W * cp.Cin * (long)sizeof(T) + kc * 16;
+                } else {
+                    hi0[i] = wi0[i] = 0;
+                    a_off[i] = (ar * K) * (long)sizeof(T) + kc * 16;
+                }
+            }
+        };
+        uint4 ra[2][8], rw[2][2];
+        auto gload = [&](auto S_, int kt) {
+            constexpr int S = decltype(S_)::value;
+            const long off = (long)kt * SLAB;
+            const int tap = kt / slabs_per_tap;
+            const int kh = CONV ? tap / cp.KW : 0, kw = CONV ? tap % cp.KW : 0;
+            const long coff = (long)(kt % slabs_per_tap) * SLAB;
+#pragma unroll
+            for (int i = 0; i < 2; ++i) rw[S][i] = asm_load16(Wb + w_off[i] + off);
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                if (CONV) {
+                    const int hi = hi0[i] + kh, wi = wi0[i] + kw;
+                    const bool ok = hi >= 0 && hi < cp.H && wi >= 0 && wi < cp.W;
+                    const long po = ((long)hi * cp.W + wi) * cp.Cin * (long)sizeof(T) + coff;
+                    ra[S][i] = asm_load16(ok ? Ab + a_off[i] + po : zero_line);
+                } else {
+                    ra[S][i] = asm_load16(Ab + a_off[i] + off);
+                }
+            }
+        };
+        auto lstore = [&](auto S_, int stage) {
+            constexpr int S = decltype(S_)::value;
+            unsigned char* wt = smem + stage * TALL_STAGE + lds0;
+#pragma unroll
+            for (int i = 0; i < 2; ++i) *reinterpret_cast<uint4*>(wt + i * 32 * LDS_ROW) = rw[S][i];
+#pragma unroll
+            for (int i = 0; i < 8; ++i) *reinterpret_cast<uint4*>(wt + 64 * LDS_ROW + i * 32 * LDS_ROW) = ra[S][i];
+        };
+        int lkt = 0, ltile = t_begin;
+        auto advance_and_load = [&](auto S_) {
+            if (++lkt == nk) { lkt = 0; ++ltile; set_tile(ltile); }
+            gload(S_, lkt);
+        };
+        using P_ = std::integral_constant<int, 0>;
+        using Q_ = std::integral_constant<int, 1>;
+        constexpr int NLOAD = 10;
+        set_tile(t_begin);
+        gload(P_{}, 0);
+        wait_vmcnt<0>();
+        lstore(P_{}, 0);
+        if (total > 1) advance_and_load(Q_{});
+        if (total > 2) advance_and_load(P_{});
+        __syncthreads();
+        int i = 0;
+        while (i < total) {
+            if (i + 1 < total) {
+                if (i + 2 < total) wait_vmcnt<NLOAD>(); else wait_vmcnt<0>();
+                lstore(Q_{}, 1);
+                if (i + 3 < total) advance_and_load(Q_{});
+            }
+            __syncthreads();
+            if (++i >= total) break;
+            if (i + 1 < total) {
+                if (i + 2 < total) wait_vmcnt<NLOAD>(); else wait_vmcnt<0>();
+                lstore(P_{}, 0);
+                if (i + 3 < total) advance_and_load(P_{});
+            }
+            __syncthreads();
+            ++i;
+        }
+        return;
+    }
+
+    // ================================ MFMA role ================================
+    const int lane = threadIdx.x & 63;
+    const int g = lane >> 4, n = lane & 15;
+    f32x4_t acc[4][4];
+#pragma unroll
+    for (int ci = 0; ci < 4; ++ci)
+#pragma unroll
+        for (int ti = 0; ti < 4; ++ti) acc[ci][ti] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+    int kt = 0, tile = t_begin;
+    TR(unsigned long long* tl_none_ = nullptr; int tl_n_none_ = 0; (void)tl_none_; (void)tl_n_none_;)
+    __syncthreads();
+    for (int s = 0; s < total; ++s) {
+        const unsigned char* wt = smem + (s & 1) * TALL_STAGE + n * LDS_ROW;
+        const unsigned char* xt = smem + (s & 1) * TALL_STAGE + (64 + wave * 64 + n) * LDS_ROW;
+        uint4 wf[2][4], xf[2][4];
+#pragma unroll
+        for (int kq = 0; kq < 2; ++kq) {
+            const int sw = (((kq * 4 + g) ^ (n & 7)) * 16);
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                wf[kq][i] = *reinterpret_cast<const uint4*>(wt + i * 16 * LDS_ROW + sw);
+                xf[kq][i] = *reinterpret_cast<const uint4*>(xt + i * 16 * LDS_ROW + sw);
+            }
+        }
+#pragma unroll
+        for (int kq = 0; kq < 2; ++kq)
+#pragma unroll
+            for (int ci = 0; ci < 4; ++ci)
+#pragma unroll
+                for (int ti = 0; ti < 4; ++ti) GT<T>::mma(wf[kq][ci], xf[kq][ti], acc[ci][ti]);
+        __syncthreads();
+        if (++kt == nk) {
+            epilogue_tile<OutT, CF>(acc, C, bias, residual, (const uint8_t*)nullptr, M, N, flags, tile * TALL_BM + wave * 64 + n, 4 * g TL_ARGS_NONE);
+            kt = 0; ++tile;
+        }
+    }
+}
+
 // tiles per block: enough chains to fill the chip (2 resident workgroups x 256 CUs) a few times over
 // wave-specialised kernel: ONE workgroup (8 waves) per CU -> chains sized for 256 x 3 workgroups
 static inline int plan_chain_ws(long ntiles) {
@@ -845,10 +1003,52 @@ static int try_splitk(const void* A, const void* W, const float* bias, const voi
 // the flag sets that get a specialised epilogue (bf16 -> bf16 only; everything else runs the generic one)
 template <typename T, typename OutT> constexpr bool kSpecialise = (sizeof(T) == 2 && sizeof(OutT) == 2);
 
+static inline bool use_tall() {
+    static int v = -1;
+    if (v < 0) { const char* e = getenv("DTLR_GEMM_TALL"); v = (e && e[0] == '0') ? 0 : 1; }   // DTLR_GEMM_TALL=0: 128x128 tiles only (A/B timing)
+    return v == 1;
+}
+
+// N <= 64, bf16 -> bf16, many token tiles: the 256 x 64 tile kernel.  done = false: not applicable.
+template <typename T, typename OutT, bool CONV>
+static int try_tall(const void* X, const void* W, const float* bias, const void* residual, void* C,
+                    int M, int N, int K, int flags, const ConvP& cp, hipStream_t st, bool& done)
+{
+    done = false;
+    if constexpr (!(sizeof(T) == 2 && sizeof(OutT) == 2)) return DTLR_OK;
+    else {
+        if (!use_tall() || N > 64 || (N & 3) || M < 64 * TALL_BM || (flags & ~(EPI_BIAS | EPI_RELU | EPI_RELU_POST | EPI_RESIDUAL | EPI_GELU))) return DTLR_OK;
+        const int nM = (M + TALL_BM - 1) / TALL_BM;
+        const long target = 2 * 256 * 2;
+        int per = (int)((nM + target - 1) / target);
+        if (per < 1) per = 1;
+        const unsigned grid = (unsigned)((nM + per - 1) / per);
+        const size_t lds = 2 * TALL_STAGE;
+#define TALL_LAUNCH(CF)                                                                            \
+        {                                                                                          \
+            static DevOnce once;                                                                   \
+            if (once.first()) { (void)hipFuncSetAttribute((const void*)gemm_ws_tall_kernel<T, OutT, CONV, CF>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); (void)hipGetLastError(); } \
+            hipLaunchKernelGGL((gemm_ws_tall_kernel<T, OutT, CONV, CF>), dim3(grid), dim3(512), lds, st, (const T*)X, (const T*)W, bias, \
+                               (const OutT*)residual, (OutT*)C, M, N, K, flags, nM, per, cp);       \
+        }
+        if (flags == (EPI_BIAS | EPI_RELU_POST)) TALL_LAUNCH((EPI_BIAS | EPI_RELU_POST))
+        else if (flags == EPI_BIAS) TALL_LAUNCH(EPI_BIAS)
+        else TALL_LAUNCH(-1)
+#undef TALL_LAUNCH
+        done = true;
+        return check_launch();
+    }
+}
+
 template <typename T, typename OutT>
 static int launch_conv(const void* X, const void* W, const float* bias, const void* residual, void* C,
                        int M, int N, int K, int flags, const ConvP& cp, hipStream_t st)
 {
+    {
+        bool done = false;
+        const int rc = try_tall<T, OutT, true>(X, W, bias, residual, C, M, N, K, flags, cp, st, done);
+        if (rc != DTLR_OK || done) return rc;
+    }
     const int nM = (M + BM - 1) / BM, nN = (N + BN - 1) / BN;
     const long nwg = (long)nM * nN;
     if (nwg > 0x7fffffffL) return DTLR_ESHAPE;
@@ -885,6 +1085,11 @@ static int launch_gemm(const void* A, const void* A2, const void* W, const float
 {
     ConvP cp{};
     cp.a2_rows = a2_rows;
+    if (!A2 && !row_mask) {
+        bool done = false;
+        const int rc = try_tall<T, OutT, false>(A, W, bias, residual, C, M, N, K, flags, cp, st, done);
+        if (rc != DTLR_OK || done) return rc;
+    }
     const int nN = (N + BN - 1) / BN, nM = (M + BM - 1) / BM;
     const long nwg = (long)nM * nN;
     if (nwg > 0x7fffffffL) return DTLR_ESHAPE;

@@ -869,3 +869,26 @@ def test_gemm_k256_epilogues():
     assert torch.equal(wide[..., 384:768], full)
     assert (wide[..., :384] == 7.0).all() and (wide[..., 768:] == 7.0).all()
     assert (wide[..., 384:768][mask] == 0).all()
+
+
+@pytest.mark.parametrize("B,H,W", [(2, 32, 512), (1, 33, 517)])
+def test_tall_tile_kernel_n64_conv_and_linear(B, H, W):
+    """The 256 x 64 tile variant (N <= 64, bf16, M >= 16384: ResNet layer1's 3x3 64->64 convolutions and 256->64 reductions) against
+    fp64 CPU references: bias + ReLU, residual + ReLU, ragged last tile, zero-padding taps."""
+    import torch.nn.functional as F
+    from dtlr_amd import ops
+    x = _rand((B, H, W, 64), 1).bfloat16()
+    w = (_rand((64, 64, 3, 3), 2) / 24.0).bfloat16()
+    b = _rand((64,), 3)
+    res = _rand((B, H, W, 64), 4).bfloat16()
+    ref = F.conv2d(x.float().permute(0, 3, 1, 2).double(), w.float().double(), b.double(), stride=1, padding=1).permute(0, 2, 3, 1)
+    w_ohwi = w.permute(0, 2, 3, 1).contiguous()
+    for use_res in (False, True):
+        want = (ref + res.double() if use_res else ref).clamp(min=0).float()
+        got = ops.conv2d_nhwc(x.cuda(), w_ohwi.cuda(), b.cuda(), 1, 1, True, res.cuda() if use_res else None).float().cpu()
+        assert (got - want).abs().max() < 2 ** -8 * max(1.0, want.abs().max().item()) + 1e-4, use_res
+    xl = _rand((B * H * W, 256), 5).bfloat16()
+    wl = (_rand((64, 256), 6) / 16.0).bfloat16()
+    want = (xl.float().double() @ wl.float().double().t() + b.double()).clamp(min=0).float()
+    got = ops.linear(xl.cuda(), wl.cuda(), b.cuda(), relu=2).float().cpu()
+    assert (got - want).abs().max() < 2 ** -8 * max(1.0, want.abs().max().item()) + 1e-4
