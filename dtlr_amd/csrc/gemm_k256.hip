@@ -201,9 +201,171 @@ __global__ __launch_bounds__(512, 2) void gemm_k256_kernel(
     }
 }
 
+
+// ---------------------------------------------------------------------------------------------------------------------------
+// Output projection + residual + LayerNorm in the same weight-resident form:   Y = LayerNorm(R + A W^T + b),  all [M, 256] bf16.
+// (`src = norm1(src + self_attn(...))`, the last op of self_attn being output_proj: models/dino/deformable_transformer.py:810-815,
+// ops/modules/ms_deform_attn.py:124.)  ffn.hip's proj_ln_bf16_kernel keeps the TOKENS in registers and re-streams the 128 KB weight
+// from L2 for every 64 tokens (348 MB of L2 -> LDS traffic per encoder call on top of 267 MB of HBM traffic); here the weight stays in
+// registers and the A and R tiles of 64 tokens are DMA'd through a 2-stage LDS ring (64 KB per stage).  W's rows are assigned to MFMA
+// rows so that a lane's two accumulator tiles are 8 CONSECUTIVE channels (row tile e of wave w, MFMA row m <-> channel
+// 32 w + 8 (m >> 2) + 4 e + (m & 3)): the residual is one 16-byte LDS read and the result one 16-byte store per token, no lane
+// exchange.  LayerNorm statistics are two-pass fp32 like ATen's; the 8 waves of a token exchange partial sums through LDS
+// (three barriers per 64 tokens including the one that publishes the tile).
+constexpr int PK_STAGE = 2 * K2_STAGE;                      // A tile | R tile
+constexpr int PK_LN_OFF = 2 * PK_STAGE;                     // two stages, then [2][64 tokens][8 waves] floats
+constexpr int PK_LDS = PK_LN_OFF + 2 * 64 * 8 * 4;
+
+__global__ __launch_bounds__(512, 2) void proj_ln_k256_kernel(
+    const uint16_t* __restrict__ A, const uint16_t* __restrict__ Wp, const float* __restrict__ bias, const uint16_t* __restrict__ R,
+    const float* __restrict__ gamma, const float* __restrict__ beta, float eps, uint16_t* __restrict__ Y, int M, int tiles_per_wg)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char k2_smem[];
+    const unsigned lds_base = (unsigned)(size_t)(__attribute__((address_space(3))) unsigned char*)k2_smem;
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const int n = lane & 15, g = lane >> 4;
+    const int ntiles = (M + K2_TOK - 1) / K2_TOK;
+    const int t_begin = (int)blockIdx.x * tiles_per_wg;
+    const int t_end = min(t_begin + tiles_per_wg, ntiles);
+    if (t_begin >= t_end) return;
+    const int nt = t_end - t_begin;
+    const int dr = lane >> 3, dc = (lane & 7) ^ dr;
+    auto issue = [&](int t, int slot) {                      // 8 DMA instructions per wave: its 4 blocks of the A tile and of the R tile
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int j = 4 * wave + u, tt8 = j >> 2, kb = j & 3;
+            const long tok = min((long)t * K2_TOK + tt8 * 8 + dr, (long)M - 1);
+            k2_glds16(A + tok * 256 + kb * 64 + dc * 8, lds_base + (unsigned)(slot * PK_STAGE + j * 1024));
+            k2_glds16(R + tok * 256 + kb * 64 + dc * 8, lds_base + (unsigned)(slot * PK_STAGE + K2_STAGE + j * 1024));
+        }
+    };
+    issue(t_begin, 0);
+    uint4 wf[2][8];
+#pragma unroll
+    for (int e = 0; e < 2; ++e)
+#pragma unroll
+        for (int ks = 0; ks < 8; ++ks) wf[e][ks] = k2_load16(Wp + ((long)((wave * 2 + e) * 8 + ks) * 64 + lane) * 8);
+    const int ch = 32 * wave + 8 * g;                         // this lane's 8 consecutive channels
+    float bs[8], gm[8], bt[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) { bs[e] = bias[ch + e]; gm[e] = gamma[ch + e]; bt[e] = beta[ch + e]; }
+    k2_wait<0>();
+    const unsigned rd0 = (unsigned)((n >> 3) * 4096 + (n & 7) * 128 + ((g ^ (n & 7)) * 16));
+    const unsigned rd1 = (unsigned)((n >> 3) * 4096 + (n & 7) * 128 + (((4 + g) ^ (n & 7)) * 16));
+    // residual chunk of this lane: 16-byte chunk 4 wave + g of the row -> block kb = wave >> 1, chunk c = 4 (wave & 1) + g
+    const unsigned rres = (unsigned)(K2_STAGE + (n >> 3) * 4096 + (wave >> 1) * 1024 + (n & 7) * 128 + (((4 * (wave & 1) + g) ^ (n & 7)) * 16));
+    float* lnsum = reinterpret_cast<float*>(k2_smem + PK_LN_OFF);
+    float* lnsq = lnsum + 64 * 8;
+
+    for (int i = 0; i < nt; ++i) {
+        const int t = t_begin + i;
+        const int slot = i & 1;
+        __builtin_amdgcn_s_barrier();                         // tile i published; stage (i + 1) & 1 and the LN buffers are free
+        if (i + 1 < nt) issue(t + 1, slot ^ 1);
+        k2_f32x4_t acc[2][4];
+#pragma unroll
+        for (int e = 0; e < 2; ++e)
+#pragma unroll
+            for (int tt = 0; tt < 4; ++tt) acc[e][tt] = k2_f32x4_t{0.f, 0.f, 0.f, 0.f};
+        const unsigned char* sb = k2_smem + slot * PK_STAGE;
+#pragma unroll
+        for (int ks = 0; ks < 8; ++ks) {
+            uint4 bf[4];
+#pragma unroll
+            for (int tt = 0; tt < 4; ++tt)
+                bf[tt] = *reinterpret_cast<const uint4*>(sb + ((ks & 1) ? rd1 : rd0) + tt * 8192 + (ks >> 1) * 1024);
+#pragma unroll
+            for (int e = 0; e < 2; ++e)
+#pragma unroll
+                for (int tt = 0; tt < 4; ++tt) acc[e][tt] = k2_mma(wf[e][ks], bf[tt], acc[e][tt]);
+        }
+        // v = acc + bias + residual ; first pass: row sums
+        float v[4][8], sm[4];
+#pragma unroll
+        for (int tt = 0; tt < 4; ++tt) {
+            const uint4 rr = *reinterpret_cast<const uint4*>(sb + rres + tt * 8192);
+            const uint32_t rw[4] = {rr.x, rr.y, rr.z, rr.w};
+            sm[tt] = 0.f;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                const float r = (e & 1) ? __uint_as_float(rw[e >> 1] & 0xffff0000u) : __uint_as_float(rw[e >> 1] << 16);
+                v[tt][e] = acc[e >> 2][tt][e & 3] + bs[e] + r;
+                sm[tt] += v[tt][e];
+            }
+            sm[tt] += __shfl_xor(sm[tt], 16, 64);
+            sm[tt] += __shfl_xor(sm[tt], 32, 64);
+            if (g == 0) lnsum[(tt * 16 + n) * 8 + wave] = sm[tt];
+        }
+        __syncthreads();
+        float mean[4], q[4];
+#pragma unroll
+        for (int tt = 0; tt < 4; ++tt) {
+            const float4 a = *reinterpret_cast<const float4*>(lnsum + (tt * 16 + n) * 8), c = *reinterpret_cast<const float4*>(lnsum + (tt * 16 + n) * 8 + 4);
+            mean[tt] = ((a.x + a.y) + (a.z + a.w) + (c.x + c.y) + (c.z + c.w)) * (1.0f / 256.0f);
+            q[tt] = 0.f;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) { const float d = v[tt][e] - mean[tt]; q[tt] += d * d; }
+            q[tt] += __shfl_xor(q[tt], 16, 64);
+            q[tt] += __shfl_xor(q[tt], 32, 64);
+            if (g == 0) lnsq[(tt * 16 + n) * 8 + wave] = q[tt];
+        }
+        __syncthreads();
+#pragma unroll
+        for (int tt = 0; tt < 4; ++tt) {
+            const float4 a = *reinterpret_cast<const float4*>(lnsq + (tt * 16 + n) * 8), c = *reinterpret_cast<const float4*>(lnsq + (tt * 16 + n) * 8 + 4);
+            const float rstd = rsqrtf(((a.x + a.y) + (a.z + a.w) + (c.x + c.y) + (c.z + c.w)) * (1.0f / 256.0f) + eps);
+            float o[8];
+#pragma unroll
+            for (int e = 0; e < 8; ++e) o[e] = (v[tt][e] - mean[tt]) * rstd * gm[e] + bt[e];
+            const long tok = (long)t * K2_TOK + tt * 16 + n;
+            if (tok < M)
+                *reinterpret_cast<uint4*>(Y + tok * 256 + ch) =
+                    make_uint4(pack_bf16x2(o[0], o[1]), pack_bf16x2(o[2], o[3]), pack_bf16x2(o[4], o[5]), pack_bf16x2(o[6], o[7]));
+        }
+        // my pieces of tile i + 1 must have landed before the next barrier; this tile's 4 stores may stay in flight
+        if (i + 1 < nt) k2_wait<4>(); else k2_wait<0>();
+    }
+}
+
 }  // namespace dtlr
 
 using namespace dtlr;
+
+// W [256, 256] row-major bf16 (host) -> fragment order with the channel permutation of proj_ln_k256_kernel (host, 65536 elements):
+// block ((wave * 2 + e) * 8 + ks) lane (m, g) <- W[32 wave + 8 (m >> 2) + 4 e + (m & 3)][32 ks + 8 g ..]
+extern "C" int dtlr_proj_ln_k256_pack_weights(const unsigned short* w_host, unsigned short* wp_host)
+{
+    if (!w_host || !wp_host) return DTLR_EINVAL;
+    for (int wave = 0; wave < 8; ++wave)
+        for (int e = 0; e < 2; ++e)
+            for (int ks = 0; ks < 8; ++ks)
+                for (int lane = 0; lane < 64; ++lane) {
+                    const int m = lane & 15, g = lane >> 4;
+                    const int row = 32 * wave + 8 * (m >> 2) + 4 * e + (m & 3);
+                    for (int x = 0; x < 8; ++x)
+                        wp_host[((long)((wave * 2 + e) * 8 + ks) * 64 + lane) * 8 + x] = w_host[(long)row * 256 + ks * 32 + g * 8 + x];
+                }
+    return DTLR_OK;
+}
+
+extern "C" int dtlr_proj_ln_k256(const void* A, const void* Wp, const float* bias, const void* R, const float* gamma, const float* beta,
+                                 float eps, void* Y, int M, void* stream)
+{
+    clear_stale_error();
+    if (!A || !Wp || !bias || !R || !gamma || !beta || !Y) return DTLR_EINVAL;
+    if (M <= 0) return DTLR_EINVAL;
+    const int ntiles = (M + K2_TOK - 1) / K2_TOK;
+    const int ncu = 256;
+    const int grid = ntiles < ncu ? ntiles : ncu;
+    const int per = (ntiles + grid - 1) / grid;
+    const int g2 = (ntiles + per - 1) / per;
+    static DevOnce once;
+    if (once.first()) { (void)hipFuncSetAttribute((const void*)proj_ln_k256_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, PK_LDS); (void)hipGetLastError(); }
+    hipLaunchKernelGGL(proj_ln_k256_kernel, dim3(g2), dim3(512), PK_LDS, (hipStream_t)stream, (const uint16_t*)A, (const uint16_t*)Wp, bias,
+                       (const uint16_t*)R, gamma, beta, eps, (uint16_t*)Y, M, per);
+    return check_launch();
+}
 
 // W [N, 256] row-major bf16 (host memory) -> fragment order (host memory, N * 256 elements).
 extern "C" int dtlr_k256_pack_weights(const unsigned short* w_host, unsigned short* wp_host, int N)

@@ -249,6 +249,10 @@ class DTLREngine:
     def _proj_ln(self, proj, norm, a, residual):
         """output projection of an attention block + residual + post-norm (deformable_transformer.py:810-815, 847-870)."""
         w = self.w
+        if self.use_k256 and a.dtype == torch.bfloat16 and a.shape[-1] == 256 and a.numel() // 256 >= 65536:
+            if proj + ".wk" not in w:                          # large M (the encoder): weight-resident streaming form
+                w[proj + ".wk"] = ops.proj_ln_k256_pack(w[proj + ".w"])
+            return ops.proj_ln_k256(a, w[proj + ".wk"], w[proj + ".b"], residual, w[norm + ".w"], w[norm + ".b"])
         if self.use_fused_ffn and a.dtype == torch.bfloat16 and a.shape[-1] == 256:
             if proj + ".wp" not in w:                          # fragment-major copy of the projection weight, packed once
                 w[proj + ".wp"] = ops.proj_pack_w(w[proj + ".w"])

@@ -245,6 +245,29 @@ def proj_ln(a, wp, b, residual, ln_w, ln_b, eps: float = 1e-5):
     return y
 
 
+def proj_ln_k256_pack(w):
+    """[256, 256] projection weight -> the fragment-order image of dtlr_proj_ln_k256 (rows permuted so that a lane's two accumulator
+    tiles are 8 consecutive channels): block ((wave*2 + e)*8 + ks) lane (m, g) <- W[32 wave + 8 (m>>2) + 4 e + (m&3)][32 ks + 8 g ..]."""
+    assert tuple(w.shape) == (256, 256)
+    return w.detach().to(torch.bfloat16).view(8, 4, 2, 4, 8, 4, 8).permute(0, 2, 4, 5, 1, 3, 6).contiguous().view(-1)
+
+
+def proj_ln_k256(a, wp, b, residual, ln_w, ln_b, eps: float = 1e-5):
+    """LayerNorm(residual + a W^T + b) for many rows (dtlr_proj_ln_k256: weights resident in registers, the a / residual tiles DMA'd
+    through an LDS ring); wp = proj_ln_k256_pack(W).  Same result as proj_ln up to fp32 summation order in the statistics."""
+    require_cuda(a, "a")
+    assert a.dtype == torch.bfloat16 and residual.dtype == torch.bfloat16 and wp.dtype == torch.bfloat16 and a.shape[-1] == 256 and wp.numel() == 65536
+    a = a if a.is_contiguous() else a.contiguous()
+    residual = residual if residual.is_contiguous() else residual.contiguous()
+    y = torch.empty_like(residual)
+    M = a.numel() // 256
+    with _Timed("proj_ln_bf16", 2.0 * M * 256 * 256, 3.0 * M * 256 * 2 + 256 * 256 * 2):
+        code = _lib.lib().dtlr_proj_ln_k256(a.data_ptr(), wp.data_ptr(), b.data_ptr(), residual.data_ptr(), ln_w.data_ptr(), ln_b.data_ptr(),
+                                            eps, y.data_ptr(), M, _lib.current_stream())
+    _lib.check(code, "dtlr_proj_ln_k256")
+    return y
+
+
 def proj_ln_split(a, wp, b, keep, ln_w, ln_b, eps: float = 1e-5):
     """LayerNorm(Linear(a with rows where keep == 0 zeroed)) written as [hi | lo | hi] bf16 (dtlr_proj_ln_split_bf16): a [..., 256]
     bf16, wp = proj_pack_w(W), keep [...] uint8/bool or None -> [..., 768] bf16.  hi + lo reproduces the fp32 LayerNorm output to
@@ -771,7 +794,7 @@ def _device_scoped(fn):
     return wrapper
 
 
-for _name in ("swin_patch_embed", "swin_window_attn", "swin_patch_merge", "geometry", "linear", "gemm_k256", "linear_rowmax", "two_stage_gather", "layernorm", "proj_ln", "proj_ln_split", "ffn_fused", "conv2d_nhwc", "stem_conv7x7", "stem_conv7x7_f32",
+for _name in ("proj_ln_k256", "swin_patch_embed", "swin_window_attn", "swin_patch_merge", "geometry", "linear", "gemm_k256", "linear_rowmax", "two_stage_gather", "layernorm", "proj_ln", "proj_ln_split", "ffn_fused", "conv2d_nhwc", "stem_conv7x7", "stem_conv7x7_f32",
               "maxpool_nhwc", "groupnorm_tokens", "msda", "msda_fused", "msda_encoder", "mha", "decoder_query_prep", "box_mlp_refine",
               "box_head_refine", "box_refine", "topk_rows", "decode_blank", "preprocess_lines", "ctc_loss_interleaved", "nms_batched",
               "topk_flat"):

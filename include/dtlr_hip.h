@@ -192,6 +192,13 @@ int dtlr_k256_pack_weights(const unsigned short *w_host, unsigned short *wp_host
 int dtlr_gemm_k256(const void *A, const void *Wp, const float *bias, const void *resid, int res_rows,
                    const unsigned char *row_mask, void *C, int ldc, int M, int N, void *stream);
 
+/* Y = LayerNorm(R + A W^T + bias) * gamma + beta over [M, 256] bf16 rows, in the weight-resident streaming form (gemm_k256.hip):
+ * the large-M variant of dtlr_proj_ln_bf16 (same reference lines: deformable_transformer.py:810-815, ms_deform_attn.py:124).
+ *   Wp = dtlr_proj_ln_k256_pack_weights(W [256,256]) (device copy). */
+int dtlr_proj_ln_k256_pack_weights(const unsigned short *w_host, unsigned short *wp_host);
+int dtlr_proj_ln_k256(const void *A, const void *Wp, const float *bias, const void *R, const float *gamma, const float *beta,
+                      float eps, void *Y, int M, void *stream);
+
 /* dtlr_gemm_nt with a row-broadcast A2 prologue: C = (A + A2[m % a2_rows]) . W^T + bias.  A2 [a2_rows, K]; M % a2_rows == 0.
  * Replaces: `with_pos_embed(src, pos)` feeding sampling_offsets / attention_weights (models/dino/deformable_transformer.py:
  * 797-812, ops/modules/ms_deform_attn.py:97-98) when the batch is unpadded: the position embedding is then the same [S,256]

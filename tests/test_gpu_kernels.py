@@ -892,3 +892,24 @@ def test_tall_tile_kernel_n64_conv_and_linear(B, H, W):
     want = (xl.float().double() @ wl.float().double().t() + b.double()).clamp(min=0).float()
     got = ops.linear(xl.cuda(), wl.cuda(), b.cuda(), relu=2).float().cpu()
     assert (got - want).abs().max() < 2 ** -8 * max(1.0, want.abs().max().item()) + 1e-4
+
+
+@pytest.mark.parametrize("M", [174080, 65536 + 37, 64, 100])
+def test_proj_ln_k256_vs_reference(M):
+    """The weight-resident output-projection + residual + LayerNorm kernel against an fp32 reference and against the round-1 kernel
+    (same arithmetic up to the summation order of the statistics); host packer == tensor-op packer."""
+    from dtlr_amd import _lib, ops
+    a = _rand((M, 256), 1).bfloat16()
+    r = _rand((M, 256), 2).bfloat16()
+    w = (_rand((256, 256), 3) / 16.0).bfloat16()
+    b, gw, gb = _rand((256,), 4) * 0.1, _rand((256,), 5) * 0.2 + 1.0, _rand((256,), 6) * 0.1
+    want = F.layer_norm(r.float() + a.float() @ w.float().t() + b, (256,), gw, gb, 1e-5)
+    got = ops.proj_ln_k256(a.cuda(), ops.proj_ln_k256_pack(w).cuda(), b.cuda(), r.cuda(), gw.cuda(), gb.cuda())
+    assert (got.float().cpu() - want).abs().max() < 0.04
+    old = ops.proj_ln(a.cuda(), ops.proj_pack_w(w).cuda(), b.cuda(), r.cuda(), gw.cuda(), gb.cuda())
+    assert (got.float() - old.float()).abs().max() <= 0.0315                 # at most one bf16 ulp at |y| < 8
+    assert (got == old).float().mean() > 0.999
+    src = np.ascontiguousarray(w.view(torch.int16).numpy()).view(np.uint16)
+    outp = np.empty(65536, dtype=np.uint16)
+    assert _lib.lib().dtlr_proj_ln_k256_pack_weights(src.ctypes.data, outp.ctypes.data) == 0
+    assert np.array_equal(outp, ops.proj_ln_k256_pack(w).view(torch.int16).numpy().view(np.uint16))
