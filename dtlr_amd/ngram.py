@@ -7,7 +7,7 @@ and sends every word's emissions through torchaudio's lexicon CTC beam decoder w
 
   * the emission tensor is built on the device by the same kernels as the blank decoder (`evaluation.blank_probabilities`);
   * the word-splitting / re-assembly logic is restated here (host logic on one label row per line);
-  * torchaudio / flashlight-text / KenLM are third-party packages that are neither under /root/reference nor installed here: the
+  * torchaudio / flashlight-text / KenLM are third-party packages that are neither in the reference tree nor installed here: the
     decoder is a CALLABLE with torchaudio's interface (`decoder(emissions [1,T,V]) -> [[hypothesis]]`, hypothesis.words), so a
     user holding those packages passes `torchaudio.models.decoder.ctc_decoder(...)` unchanged.  `LexiconCTCDecoder` below is a
     small self-contained stand-in with the same interface -- CTC prefix beam search constrained to a lexicon, scored with an ARPA
