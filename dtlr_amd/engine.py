@@ -51,6 +51,7 @@ class DTLREngine:
         self.use_lds_msda = True       # encoder MSDA with LDS-staged windows (False: gather kernel)
         self.use_fused_ffn = True      # bf16: linear1+ReLU+linear2+residual+LayerNorm in one kernel (False: two GEMMs + LN)
         self.use_k256 = os.environ.get("DTLR_K256", "1") != "0"   # bf16: weight-resident streaming kernel for the K = 256 projections over all tokens
+        self.use_pln_k256 = os.environ.get("DTLR_PLN_K256", "1") != "0"   # ... and for the encoder's output projection + LayerNorm
 
     # ------------------------------------------------------------------------------ packing
     def _put(self, name, t, dtype=None):
@@ -249,7 +250,7 @@ class DTLREngine:
     def _proj_ln(self, proj, norm, a, residual):
         """output projection of an attention block + residual + post-norm (deformable_transformer.py:810-815, 847-870)."""
         w = self.w
-        if self.use_k256 and a.dtype == torch.bfloat16 and a.shape[-1] == 256 and a.numel() // 256 >= 65536:
+        if self.use_pln_k256 and a.dtype == torch.bfloat16 and a.shape[-1] == 256 and a.numel() // 256 >= 65536:
             if proj + ".wk" not in w:                          # large M (the encoder): weight-resident streaming form
                 w[proj + ".wk"] = ops.proj_ln_k256_pack(w[proj + ".w"])
             return ops.proj_ln_k256(a, w[proj + ".wk"], w[proj + ".b"], residual, w[norm + ".w"], w[norm + ".b"])

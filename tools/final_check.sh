@@ -14,7 +14,7 @@ fi
 export TMPDIR=/tmp
 R=$PWD
 mkdir -p gpurun_out/prof_$TAG
-( cd /tmp && timeout 600 rocprofv3 --kernel-trace --stats -d $R/gpurun_out/prof_$TAG -o r -- python $R/bench.py --steps 10 --warmup 2 --no-cpu-baseline > $R/gpurun_out/bench_prof_$TAG.json 2>/dev/null )
-python tools/rocprof_summary.py gpurun_out/prof_$TAG gpurun_out/r01_bench_bf16_b32_$TAG
-head -12 gpurun_out/r01_bench_bf16_b32_${TAG}_kernel_stats.csv
+( cd /tmp && timeout 600 rocprofv3 --kernel-trace --stats -d $R/gpurun_out/prof_$TAG -o r -- python $R/bench.py --steps 10 --warmup 2 --no-cpu-baseline --no-parity > $R/gpurun_out/bench_prof_$TAG.json 2>/dev/null )
+python tools/rocprof_summary.py gpurun_out/prof_$TAG gpurun_out/r02_bench_bf16_b32_$TAG
+head -12 gpurun_out/r02_bench_bf16_b32_${TAG}_kernel_stats.csv
 rm -rf gpurun_out/prof_$TAG
