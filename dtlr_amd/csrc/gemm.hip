@@ -742,13 +742,19 @@ constexpr int TALL_BM = 256, TALL_STAGE = (64 + TALL_BM) * LDS_ROW;       // 40 
 template <typename T, typename OutT, bool CONV, int CF = -1>
 __global__ __launch_bounds__(512, 4) void gemm_ws_tall_kernel(
     const T* __restrict__ A, const T* __restrict__ W, const float* __restrict__ bias, const OutT* __restrict__ residual,
-    OutT* __restrict__ C, int M, int N, int K, int flags, int ntilesM, int tiles_per_block, ConvP cp)
+    OutT* __restrict__ C, int M, int N, int K, int flags, int ntilesM, int tiles_per_block, ConvP cp, int round_robin)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int wave = threadIdx.x >> 6;
     constexpr int BK = GT<T>::BK;
     const int nk = K / BK;
-    const int t_begin = (int)blockIdx.x * tiles_per_block;
+    // workgroup b runs on XCD b % 8: give every XCD a CONTIGUOUS band of token tiles, so that the workgroups resident together in
+    // one XCD convolve adjacent image rows and the halo rows of a 3x3 tap are served by that XCD's L2 (round-robin placement put
+    // rows y-1, y, y+1 on three different XCDs: FETCH_SIZE showed the activation map read 3x, profiles/r02_step_v1_traffic.json)
+    const int nwg = (int)gridDim.x, q8 = nwg >> 3, r8 = nwg & 7, xcd = (int)blockIdx.x & 7;
+    const int logical = round_robin ? (int)blockIdx.x
+                      : (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + ((int)blockIdx.x >> 3);
+    const int t_begin = logical * tiles_per_block;
     const int t_end = min(t_begin + tiles_per_block, ntilesM);
     if (t_begin >= t_end) return;
     const int total = (t_end - t_begin) * nk;
@@ -1024,12 +1030,13 @@ static int try_tall(const void* X, const void* W, const float* bias, const void*
         if (per < 1) per = 1;
         const unsigned grid = (unsigned)((nM + per - 1) / per);
         const size_t lds = 2 * TALL_STAGE;
+        static const int rr = [] { const char* e = getenv("DTLR_TALL_XCD"); return (e && e[0] == '0') ? 1 : 0; }();   // A/B timing only
 #define TALL_LAUNCH(CF)                                                                            \
         {                                                                                          \
             static DevOnce once;                                                                   \
             if (once.first()) { (void)hipFuncSetAttribute((const void*)gemm_ws_tall_kernel<T, OutT, CONV, CF>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); (void)hipGetLastError(); } \
             hipLaunchKernelGGL((gemm_ws_tall_kernel<T, OutT, CONV, CF>), dim3(grid), dim3(512), lds, st, (const T*)X, (const T*)W, bias, \
-                               (const OutT*)residual, (OutT*)C, M, N, K, flags, nM, per, cp);       \
+                               (const OutT*)residual, (OutT*)C, M, N, K, flags, nM, per, cp, rr);   \
         }
         if (flags == (EPI_BIAS | EPI_RELU_POST)) TALL_LAUNCH((EPI_BIAS | EPI_RELU_POST))
         else if (flags == EPI_BIAS) TALL_LAUNCH(EPI_BIAS)

@@ -48,6 +48,17 @@ __device__ __forceinline__ uint2 k2_load8(const void* p) {
     asm volatile("global_load_dwordx2 %0, %1, off" : "=v"(r) : "v"(p) : "memory");
     return r;
 }
+// scalar base + 32-bit lane offset + immediate: one address register per load instead of two, and the per-row-tile column step is free
+template <int OFF> __device__ __forceinline__ uint2 k2_load8_so(const void* sbase, unsigned voff) {
+    uint2 r;
+    asm volatile("global_load_dwordx2 %0, %1, %2 offset:%3" : "=v"(r) : "v"(voff), "s"(sbase), "n"(OFF) : "memory");
+    return r;
+}
+__device__ __forceinline__ unsigned k2_load_u8_so(const void* sbase, unsigned voff) {
+    unsigned r;
+    asm volatile("global_load_ubyte %0, %1, %2" : "=v"(r) : "v"(voff), "s"(sbase) : "memory");
+    return r;
+}
 __device__ __forceinline__ unsigned k2_load_u8(const void* p) {
     unsigned r;
     asm volatile("global_load_ubyte %0, %1, off" : "=v"(r) : "v"(p) : "memory");
@@ -57,11 +68,8 @@ __device__ __forceinline__ k2_f32x4_t k2_mma(const uint4& a, const uint4& b, k2_
     return __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(k2_bf16x8_t, a), __builtin_bit_cast(k2_bf16x8_t, b), c, 0, 0, 0);
 }
 template <int N> __device__ __forceinline__ void k2_wait() {
-    if constexpr (N == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    else if constexpr (N == 4) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
-    else if constexpr (N == 16) asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
-    else if constexpr (N == 24) asm volatile("s_waitcnt vmcnt(24)" ::: "memory");
-    else static_assert(N < 0, "unsupported count");
+    static_assert(N >= 0 && N < 64, "vmcnt is a 6-bit counter");
+    asm volatile("s_waitcnt vmcnt(%0)" :: "n"(N) : "memory");
     __builtin_amdgcn_sched_barrier(0);
 }
 
@@ -71,7 +79,7 @@ template <int NRT, bool RES>
 __global__ __launch_bounds__(512, 2) void gemm_k256_kernel(
     const uint16_t* __restrict__ A, const uint16_t* __restrict__ Wp, const float* __restrict__ bias,
     const uint16_t* __restrict__ resid, int res_rows, const uint8_t* __restrict__ row_mask,
-    uint16_t* __restrict__ C, int ldc, int M, int tiles_per_wg)
+    uint16_t* __restrict__ C, int ldc, int M, int tiles_per_wg, int n_img)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char k2_smem[];
     const unsigned lds_base = (unsigned)(size_t)(__attribute__((address_space(3))) unsigned char*)k2_smem;
@@ -81,10 +89,21 @@ __global__ __launch_bounds__(512, 2) void gemm_k256_kernel(
     const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     const int n = lane & 15, g = lane >> 4;
     const int ntiles = (M + K2_TOK - 1) / K2_TOK;
-    const int t_begin = (int)blockIdx.x * tiles_per_wg;
+    // workgroup b runs on XCD b % 8; logical ids are contiguous inside an XCD
+    const int nwg = (int)gridDim.x, q8 = nwg >> 3, r8 = nwg & 7, xcd = (int)blockIdx.x & 7;
+    const int logical = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + ((int)blockIdx.x >> 3);
+    const int t_begin = logical * tiles_per_wg;
     const int t_end = min(t_begin + tiles_per_wg, ntiles);
     if (t_begin >= t_end) return;
     const int nt = t_end - t_begin;
+    // Tile order.  n_img == 0: tile t = rows [64 t, 64 t + 64).  n_img > 0 (broadcast residual over n_img images of res_rows rows,
+    // res_rows % 64 == 0): tile t = position tile t / n_img of image t % n_img -- a workgroup's run of tiles, and the whole band of
+    // tiles one XCD owns, reuse a few 64-row residual tiles out of L2 instead of sweeping the whole residual once per image
+    // (FETCH_SIZE in row order: 351 MB per launch for 223 MB of operands, the 4 MB residual re-fetched for every image).
+    auto row0 = [&](int t) -> long {
+        if (RES && n_img > 0) { const int pt = t / n_img; return (long)(t - pt * n_img) * res_rows + (long)pt * K2_TOK; }
+        return (long)t * K2_TOK;
+    };
 
     // ---- DMA of token tile t into ring slot: 32 blocks of 8 rows x 128 B; this wave issues blocks j = 4 wave + u ------------
     const int dr = lane >> 3, dc = (lane & 7) ^ dr;           // row within the block; SOURCE chunk that lands in slot (lane & 7)
@@ -92,7 +111,7 @@ __global__ __launch_bounds__(512, 2) void gemm_k256_kernel(
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
             const int j = 4 * wave + u, tt8 = j >> 2, kb = j & 3;
-            const long tok = min((long)t * K2_TOK + tt8 * 8 + dr, (long)M - 1);
+            const long tok = min(row0(t) + tt8 * 8 + dr, (long)M - 1);
             k2_glds16(A + tok * 256 + kb * 64 + dc * 8, lds_base + (unsigned)(slot * K2_STAGE + j * 1024));
         }
     };
@@ -109,48 +128,82 @@ __global__ __launch_bounds__(512, 2) void gemm_k256_kernel(
 #pragma unroll
     for (int rt = 0; rt < NRT; ++rt)
         bv[rt] = bias ? *reinterpret_cast<const float4*>(bias + (wave * NRT + rt) * 16 + 4 * g) : make_float4(0.f, 0.f, 0.f, 0.f);
-    k2_wait<0>();
 
     // B-fragment read addresses: token tile tt, k-step ks: block (2 tt + (n >> 3), ks >> 1), row n & 7, slot ((ks & 1) * 4 + g) ^ (n & 7)
     const unsigned rd0 = (unsigned)((n >> 3) * 4096 + (n & 7) * 128 + ((g ^ (n & 7)) * 16));
     const unsigned rd1 = (unsigned)((n >> 3) * 4096 + (n & 7) * 128 + (((4 + g) ^ (n & 7)) * 16));
 
-    // row of the broadcast residual for this lane's four tokens of the current tile, advanced by 64 per tile (a 64-bit modulo per
-    // token tile cost ~1 us per tile: a quarter of the tile's time)
+    // Row-wise epilogue operands (RES): tile i + 1's residual rows and padding flags are loaded in the epilogue of tile i BEFORE the
+    // next DMA group and tile i's stores, waited for at the end of that epilogue with vmcnt(E + 4) -- everything but those E stores and
+    // that DMA group -- and folded into the INITIAL value of tile i + 1's accumulators (bias + residual), so they occupy no register
+    // across the MFMA phase and are never live in a register the compiler might copy before the data has landed.
+    // (First version: loaded at the top of iteration i and waited for in the same iteration with vmcnt(4); the counter is in order,
+    // so that wait also drained the PREVIOUS tile's stores, a write acknowledgement from HBM per tile: 73 us against 50 us for the
+    // same launch without the residual.)
+    // Row order (n_img == 0): residual row of this lane's tokens advanced by 64 per tile (no 64-bit modulo per tile).
     int rrow[4] = {0, 0, 0, 0};
     if constexpr (RES) {
 #pragma unroll
         for (int tt = 0; tt < 4; ++tt) rrow[tt] = (int)(((long)t_begin * K2_TOK + tt * 16 + n) % res_rows);
     }
-    const int radv = K2_TOK % res_rows;
+    const int radv = (RES && res_rows > 0) ? K2_TOK % res_rows : 0;
+    uint2 rs[NRT][4];
+    unsigned msk[4] = {0, 0, 0, 0};
+    auto load_row_operands = [&](int t, uint2 (&r)[NRT][4], unsigned (&m)[4]) {
+        if (n_img > 0) {
+            const int pt = t / n_img;
+#pragma unroll
+            for (int tt = 0; tt < 4; ++tt) rrow[tt] = pt * K2_TOK + tt * 16 + n;
+        }
+#pragma unroll
+        for (int tt = 0; tt < 4; ++tt) {
+            const unsigned voff = (unsigned)rrow[tt] * (unsigned)(N * 2) + (unsigned)(wave * NRT * 32 + 8 * g);
+            r[0][tt] = k2_load8_so<0>(resid, voff);
+            if constexpr (NRT > 1) r[1][tt] = k2_load8_so<32>(resid, voff);
+            if constexpr (NRT > 2) r[2][tt] = k2_load8_so<64>(resid, voff);
+            rrow[tt] += radv;
+            if (rrow[tt] >= res_rows) rrow[tt] -= res_rows;
+        }
+        if (row_mask) {
+            const int r0 = (int)row0(t);
+#pragma unroll
+            for (int tt = 0; tt < 4; ++tt) m[tt] = k2_load_u8_so(row_mask, (unsigned)min(r0 + tt * 16 + n, M - 1));
+        }
+    };
+    if constexpr (RES) load_row_operands(t_begin, rs, msk);
+    k2_wait<0>();
+
+    k2_f32x4_t acc[NRT][4];
+    unsigned zero_bits = 0;
+    auto seed_accumulators = [&]() {                          // RES: acc <- bias + residual row; padding flags -> bits
+#pragma unroll
+        for (int tt = 0; tt < 4; ++tt) {
+            if (row_mask && msk[tt]) zero_bits |= 1u << tt;
+#pragma unroll
+            for (int rt = 0; rt < NRT; ++rt)
+                acc[rt][tt] = k2_f32x4_t{bv[rt].x + __uint_as_float(rs[rt][tt].x << 16), bv[rt].y + __uint_as_float(rs[rt][tt].x & 0xffff0000u),
+                                         bv[rt].z + __uint_as_float(rs[rt][tt].y << 16), bv[rt].w + __uint_as_float(rs[rt][tt].y & 0xffff0000u)};
+        }
+    };
+    if constexpr (RES) seed_accumulators();
 
     for (int i = 0; i < nt; ++i) {
         const int t = t_begin + i;
         const int slot = i & 3;
         __builtin_amdgcn_s_barrier();                         // tile i published by every wave; stage (i + 3) & 3 no longer read
-        // row-wise epilogue operands of this tile first (they must be OLDER than the next DMA group: waited with vmcnt(4))
-        uint2 rs[NRT][4];
-        unsigned msk[4];
-        if constexpr (RES) {
+        const long trow = row0(t);
+        if constexpr (!RES) {
+            if (row_mask) {
+                // (they must be OLDER than the next DMA group: waited with vmcnt(4))
 #pragma unroll
-            for (int tt = 0; tt < 4; ++tt) {
-#pragma unroll
-                for (int rt = 0; rt < NRT; ++rt) rs[rt][tt] = k2_load8(resid + (long)rrow[tt] * N + (wave * NRT + rt) * 16 + 4 * g);
-                rrow[tt] += radv;
-                if (rrow[tt] >= res_rows) rrow[tt] -= res_rows;
+                for (int tt = 0; tt < 4; ++tt) msk[tt] = k2_load_u8(row_mask + min(trow + tt * 16 + n, (long)M - 1));
             }
+            if (i + 3 < nt) issue(t + 3, (i + 3) & 3);
+#pragma unroll
+            for (int rt = 0; rt < NRT; ++rt)
+#pragma unroll
+                for (int tt = 0; tt < 4; ++tt) acc[rt][tt] = k2_f32x4_t{0.f, 0.f, 0.f, 0.f};
         }
-        if (row_mask) {
-#pragma unroll
-            for (int tt = 0; tt < 4; ++tt) msk[tt] = k2_load_u8(row_mask + min((long)t * K2_TOK + tt * 16 + n, (long)M - 1));
-        }
-        if (i + 3 < nt) issue(t + 3, (i + 3) & 3);
-
-        k2_f32x4_t acc[NRT][4];
-#pragma unroll
-        for (int rt = 0; rt < NRT; ++rt)
-#pragma unroll
-            for (int tt = 0; tt < 4; ++tt) acc[rt][tt] = k2_f32x4_t{0.f, 0.f, 0.f, 0.f};
         const unsigned char* sb = k2_smem + slot * K2_STAGE;
 #pragma unroll
         for (int ks = 0; ks < 8; ++ks) {
@@ -164,21 +217,28 @@ __global__ __launch_bounds__(512, 2) void gemm_k256_kernel(
                 for (int tt = 0; tt < 4; ++tt) acc[rt][tt] = k2_mma(wf[rt][ks], bf[tt], acc[rt][tt]);
         }
         // ---- epilogue: bias, broadcast residual, padding rows, bf16, paired 16-byte stores ---------------------------------
-        if constexpr (RES) { if (i + 3 < nt) k2_wait<4>(); else k2_wait<0>(); }
-        else if (row_mask) { if (i + 3 < nt) k2_wait<4>(); else k2_wait<0>(); }
+        if constexpr (RES) {
+            __builtin_amdgcn_sched_barrier(0);
+            if (i + 1 < nt) load_row_operands(t + 1, rs, msk);
+            if (i + 3 < nt) issue(t + 3, (i + 3) & 3);
+        } else {
+            zero_bits = 0;
+            if (row_mask) {
+                if (i + 3 < nt) k2_wait<4>(); else k2_wait<0>();
+#pragma unroll
+                for (int tt = 0; tt < 4; ++tt) if (msk[tt]) zero_bits |= 1u << tt;
+            }
+        }
 #pragma unroll
         for (int tt = 0; tt < 4; ++tt) {
-            const long tok = (long)t * K2_TOK + tt * 16 + n;
+            const long tok = trow + tt * 16 + n;
             const bool live = tok < M;
-            const bool zero = row_mask && msk[tt];
+            const bool zero = (zero_bits >> tt) & 1u;
             uint32_t pk_lo = 0, pk_hi = 0;
 #pragma unroll
             for (int rt = 0; rt < NRT; ++rt) {
-                float v[4] = {acc[rt][tt][0] + bv[rt].x, acc[rt][tt][1] + bv[rt].y, acc[rt][tt][2] + bv[rt].z, acc[rt][tt][3] + bv[rt].w};
-                if constexpr (RES) {
-                    v[0] += __uint_as_float(rs[rt][tt].x << 16); v[1] += __uint_as_float(rs[rt][tt].x & 0xffff0000u);
-                    v[2] += __uint_as_float(rs[rt][tt].y << 16); v[3] += __uint_as_float(rs[rt][tt].y & 0xffff0000u);
-                }
+                float v[4] = {acc[rt][tt][0], acc[rt][tt][1], acc[rt][tt][2], acc[rt][tt][3]};
+                if constexpr (!RES) { v[0] += bv[rt].x; v[1] += bv[rt].y; v[2] += bv[rt].z; v[3] += bv[rt].w; }
                 if (zero) { v[0] = v[1] = v[2] = v[3] = 0.f; }
                 const uint32_t lo = pack_bf16x2(v[0], v[1]), hi = pack_bf16x2(v[2], v[3]);
                 if ((rt & 1) == 0 && rt + 1 < NRT) { pk_lo = lo; pk_hi = hi; }
@@ -194,10 +254,20 @@ __global__ __launch_bounds__(512, 2) void gemm_k256_kernel(
                 }
             }
         }
-        // tile i + 1 must have landed (mine) before the next barrier: everything but the two newest DMA groups and the
-        // stores issued around them may stay in flight
-        if (i + 3 < nt) k2_wait<2 * E + 8 <= 16 ? 16 : 24>();
-        else k2_wait<0>();
+        if constexpr (RES) {
+            // in flight after this wait: this tile's E stores and the DMA group issued just before them (none in the last three
+            // iterations).  Older, hence landed: the next tile's row operands and DMA groups i + 1, i + 2.  A ragged tile (fewer
+            // stores than E) is always a workgroup's last, where nothing is waited for.
+            zero_bits = 0;
+            if (i + 3 < nt) k2_wait<E + 4>();
+            else if (i + 1 < nt) k2_wait<E>();
+            if (i + 1 < nt) seed_accumulators();
+        } else {
+            // tile i + 1 must have landed (mine) before the next barrier: everything but the two newest DMA groups and the
+            // stores issued around them may stay in flight
+            if (i + 3 < nt) k2_wait<2 * E + 8 <= 16 ? 16 : 24>();
+            else k2_wait<0>();
+        }
     }
 }
 
@@ -391,7 +461,7 @@ extern "C" int dtlr_gemm_k256(const void* A, const void* Wp, const float* bias, 
     clear_stale_error();
     if (!A || !Wp || !C) return DTLR_EINVAL;
     if (M <= 0 || ldc < N || (ldc & 7)) return DTLR_EINVAL;
-    if (resid && (res_rows <= 0)) return DTLR_EINVAL;
+    if (resid && (res_rows <= 0 || (long)res_rows * N * 2 >= (1L << 31))) return DTLR_EINVAL;
     if (N != 256 && N != 384) return DTLR_ESHAPE;
     const int ntiles = (M + K2_TOK - 1) / K2_TOK;
     int ncu = 256;
@@ -404,12 +474,14 @@ extern "C" int dtlr_gemm_k256(const void* A, const void* Wp, const float* bias, 
     const int per = (ntiles + grid - 1) / grid;
     const int g2 = (ntiles + per - 1) / per;
     hipStream_t st = (hipStream_t)stream;
+    static const bool pos_major = [] { const char* e = getenv("DTLR_K256_POS_MAJOR"); return !(e && e[0] == '0'); }();   // A/B timing only
+    const int n_img = (pos_major && resid && res_rows % K2_TOK == 0 && M % res_rows == 0 && M / res_rows > 1) ? M / res_rows : 0;
 #define K2_LAUNCH(NRT, RES)                                                                        \
     {                                                                                              \
         static DevOnce once;                                                                       \
         if (once.first()) { (void)hipFuncSetAttribute((const void*)gemm_k256_kernel<NRT, RES>, hipFuncAttributeMaxDynamicSharedMemorySize, K2_LDS); (void)hipGetLastError(); } \
         hipLaunchKernelGGL((gemm_k256_kernel<NRT, RES>), dim3(g2), dim3(512), K2_LDS, st, (const uint16_t*)A, (const uint16_t*)Wp, bias, \
-                           (const uint16_t*)resid, res_rows, row_mask, (uint16_t*)C, ldc, M, per);  \
+                           (const uint16_t*)resid, res_rows, row_mask, (uint16_t*)C, ldc, M, per, n_img);  \
     }
     if (N == 256) { if (resid) K2_LAUNCH(2, true) else K2_LAUNCH(2, false) }
     else { if (resid) K2_LAUNCH(3, true) else K2_LAUNCH(3, false) }

@@ -850,10 +850,11 @@ def test_gemm_k256_weight_resident_vs_tiled_kernel(M, N):
     assert np.array_equal(outp, ops.k256_pack(w).cpu().view(torch.int16).numpy().view(np.uint16))
 
 
-def test_gemm_k256_epilogues():
-    """Row-broadcast residual (m % rows), padding-row zeroing and strided output (column slice of a wider matrix)."""
+@pytest.mark.parametrize("B,S,N", [(3, 700, 384), (5, 640, 384), (32, 5440, 384), (7, 128, 256)])
+def test_gemm_k256_epilogues(B, S, N):
+    """Row-broadcast residual (m % rows), padding-row zeroing and strided output (column slice of a wider matrix).  S % 64 == 0
+    takes the position-major tile order (a workgroup walks one residual tile across the images); S = 700 the row order."""
     from dtlr_amd import ops
-    B, S, N = 3, 700, 384
     x = _rand((B, S, 256), 1).bfloat16().cuda()
     w = _rand((N, 256), 2, 0.1).bfloat16().cuda()
     b = _rand((N,), 3).cuda()
@@ -863,12 +864,17 @@ def test_gemm_k256_epilogues():
     got = ops.gemm_k256(x, wp, N, None, resid=res)
     want = (x.float() @ w.float().t() + res.float()[None]).bfloat16()
     assert (got.float() - want.float()).abs().max() <= 0.07          # one bf16 ulp at |y| < 16
+    got = ops.gemm_k256(x, wp, N, b, resid=res, row_mask=mask)       # residual and padding rows together
+    want = (x.float() @ w.float().t() + b + res.float()[None]).bfloat16()
+    want[mask] = 0
+    assert (got.float() - want.float()).abs().max() <= 0.07
+    assert (got[mask] == 0).all()
     wide = torch.full((B, S, 1536), 7.0, dtype=torch.bfloat16, device="cuda")
-    ops.gemm_k256(x, wp, N, b, row_mask=mask, out=wide[..., 384:768])
+    ops.gemm_k256(x, wp, N, b, row_mask=mask, out=wide[..., 384:384 + N])
     full = ops.linear(x, w, b, row_mask=mask)
-    assert torch.equal(wide[..., 384:768], full)
-    assert (wide[..., :384] == 7.0).all() and (wide[..., 768:] == 7.0).all()
-    assert (wide[..., 384:768][mask] == 0).all()
+    assert torch.equal(wide[..., 384:384 + N], full)
+    assert (wide[..., :384] == 7.0).all() and (wide[..., 384 + N:] == 7.0).all()
+    assert (wide[..., 384:384 + N][mask] == 0).all()
 
 
 @pytest.mark.parametrize("B,H,W", [(2, 32, 512), (1, 33, 517)])
