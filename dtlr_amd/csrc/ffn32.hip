@@ -1,0 +1,358 @@
+// Fused position-wise feed-forward block, third structure (the encoder call, M >= 64 K tokens), bf16:
+//
+//     Y = LayerNorm( X + relu(X W1^T + b1) W2^T + b2 )            X, Y: [M, 256]   W1: [d_ff, 256]   W2: [256, d_ff]
+// == forward_ffn + norm2 of the encoder layer (models/dino/deformable_transformer.py:804-823).
+//
+// ffn2_bf16_kernel (ffn.hip: one wave per SIMD, 16x16x32 MFMAs, 48 tokens per wave) is ISSUE-bound: 320 instructions per 96 MFMAs of
+// 16 cycles leave ~2.3 filler instructions per 4-slot gap, and the per-chunk timeline showed the body at ~1.65x its MFMA time.
+// Same dataflow here on v_mfma_f32_32x32x16_bf16 (32 cycles per MFMA, i.e. 8 issue slots per gap; MI355X_MICROARCH.md: <= 5 fillers
+// per gap run at the 32.4-cycle floor):
+//   * one wave per SIMD, 64 tokens per wave (two 32-token column tiles), 256 tokens per workgroup;
+//   * a chunk = 32 hidden units.  Phase A: H^T[32 hidden, 64 tokens] = W1c X^T: 16 k-steps x 2 token tiles = 32 MFMAs on 16 weight
+//     fragments; phase B: Y^T[256 ch, 64 tokens] += W2c H^T: 8 channel tiles x 2 k-steps x 2 token tiles = 32 MFMAs on 16 fragments;
+//     64 MFMAs (2048 cycles) per chunk against ~120 other instructions;
+//   * the C/D layout of the 32x32 MFMA (lane = token column, register r = hidden row 8 (r >> 2) + 4 (lane >> 5) + (r & 3)) is made the
+//     B-operand layout of phase B by ORDERING the hidden units inside W2's k-steps (k-slot (s, lane >> 5, e) <-> hidden
+//     8 (2 s + (e >> 2)) + 4 (lane >> 5) + (e & 3)): a lane's accumulator registers 8 s .. 8 s + 7, rounded to bf16, ARE its B-fragment
+//     of k-step s -- H never leaves the wave's registers;
+//   * b1 is the INITIAL value of the phase-A accumulators (read from an LDS table straight into them), so the H epilogue is one
+//     v_max and half a v_cvt_pk per value, spread under phase B of the previous chunk;
+//   * both weights are pre-packed in fragment order (ops.ffn32_pack): a chunk image is 16 linear 1 KB fragments, DMA'd with
+//     global_load_lds_dwordx4 from linear addresses (no per-lane source arithmetic) into two 4-stage rings; the images are padded by
+//     FFN32_PAD chunks so the steady-state iteration issues its eight pieces unconditionally (one basic block, no peeled tail);
+//   * a 4-fragment register buffer is refilled 4 fragments (4 MFMA groups = 256 cycles) ahead of use, in stream order
+//     W1(c) 0..15, W2(c-1) 0..15, W1(c+1) 0..15, ...;
+//   * 256 accumulator registers (AGPRs) for Y^T + 32 for H^T; X^T fragments 128 VGPRs; the residual is taken from those fragments
+//     (two v_permlane32_swap per fragment put each lane's 4-channel groups in its own registers); LayerNorm statistics: 128 channels
+//     per lane + one exchange with lane ^ 32; stores pair the two half-lanes of a token to 16 bytes per lane.
+#include "dtlr_common.h"
+#include <stdlib.h>
+
+namespace dtlr {
+
+typedef __attribute__((ext_vector_type(8))) __bf16 f3_bf16x8_t;
+typedef __attribute__((ext_vector_type(16))) float f3_f32x16_t;
+
+constexpr int F3_NS = 4;                                    // ring stages
+constexpr int F3_RING = 16384;                              // one W1 (or W2) chunk image: 16 fragments of 1 KB
+constexpr int F3_W2_OFF = F3_NS * F3_RING;
+constexpr int F3_B1_OFF = 2 * F3_NS * F3_RING;
+constexpr int F3_MAX_DFF = 2048;
+constexpr int F3_PRM_OFF = F3_B1_OFF + (F3_MAX_DFF + 32) * 4;      // b2 | gamma | beta (3 x 256 floats): the epilogue reads them from LDS
+constexpr int F3_LDS = F3_PRM_OFF + 3 * 256 * 4;
+constexpr int FFN32_PAD = 4;                                // zero chunks behind each packed weight (DMA'd, never multiplied)
+
+// LDS-DMA with a wave-uniform base in SGPRs and a 32-bit per-lane byte offset; completion is counted by hand (vmcnt)
+__device__ __forceinline__ void f3_glds16s(const void* sbase, unsigned voff, unsigned lds_dst) {
+    unsigned keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep) : "v"(voff), "s"(sbase), "s"(lds_dst) : "memory");
+}
+__device__ __forceinline__ uint4 f3_load16(const void* p) {
+    uint4 r;
+    asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(r) : "v"(p) : "memory");
+    return r;
+}
+__device__ __forceinline__ f3_f32x16_t f3_mma(const uint4& a, const uint4& b, f3_f32x16_t c) {
+    return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(f3_bf16x8_t, a), __builtin_bit_cast(f3_bf16x8_t, b), c, 0, 0, 0);
+}
+
+// Phase-A form: accumulator pinned to ARCHITECTURAL VGPRs.  The kernel needs 256 (Y^T) + 32 (H^T) accumulator registers; left to itself
+// hipcc keeps all of them in the 256 AGPRs and shuttles tiles through v_accvgpr moves (448 per chunk).  As inline asm the MFMA is
+// invisible to the hazard recogniser; the uses are arranged so that no software wait states are owed: the two H^T accumulators
+// alternate (the pattern hipcc itself emits back to back), their operands come from ds_read / long-lived registers (waited for by the
+// compiler through the asm operands), and they are first read by VALU two MFMAs (or an explicit s_nop pad) later.
+// ReLU as ONE instruction (fmaxf canonicalises its operand first: two v_max per value)
+__device__ __forceinline__ float f3_relu(float x) { return __builtin_amdgcn_fmed3f(x, 0.f, __builtin_huge_valf()); }
+typedef __attribute__((ext_vector_type(4))) unsigned f3_u32x4_t;
+__device__ __forceinline__ void f3_mma_v(const uint4& a, const uint4& b, f3_f32x16_t& c) {
+    const f3_u32x4_t av = {a.x, a.y, a.z, a.w}, bv = {b.x, b.y, b.z, b.w};
+    asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+v"(c) : "v"(av), "v"(bv));
+}
+
+// DBG (timing experiments only, env DTLR_FFN32_DBG; results are garbage): 1 = no weight DMA inside the chunk loop, 2 = no per-chunk
+// barrier / DMA wait, 4 = no weight-fragment LDS reads inside the chunk loop, 8 = two chunks only (prologue + epilogue cost).  DBG = 0 is the product kernel.
+template <int DBG>
+__global__ __launch_bounds__(256, 1) void ffn3_bf16_kernel(
+    const uint16_t* __restrict__ X, const uint16_t* __restrict__ W1p, const float* __restrict__ b1,
+    const uint16_t* __restrict__ W2p, const float* __restrict__ b2, const float* __restrict__ gamma,
+    const float* __restrict__ beta, float eps, uint16_t* __restrict__ Y, int M, int d_ff)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char f3_smem[];
+    const unsigned lds_base = (unsigned)(size_t)(__attribute__((address_space(3))) unsigned char*)f3_smem;
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const int j = lane & 31, hh = lane >> 5;
+    const int nchunk = d_ff >> 5;
+    const long tok0 = (long)blockIdx.x * 256 + wave * 64;
+
+    // X^T B-fragments: lane (j, hh) of token tile tt holds X[tok0 + 32 tt + j][16 s + 8 hh .. +7]
+    uint4 xf[16][2];
+#pragma unroll
+    for (int tt = 0; tt < 2; ++tt) {
+        const long tok = min(tok0 + tt * 32 + j, (long)M - 1);
+#pragma unroll
+        for (int s = 0; s < 16; ++s) xf[s][tt] = f3_load16(X + tok * 256 + s * 16 + hh * 8);
+    }
+    {   // b1 table (padded with zeros for the chunk read past the end)
+        float* b1s = reinterpret_cast<float*>(f3_smem + F3_B1_OFF);
+        for (int i = (int)threadIdx.x * 4; i < d_ff + 32; i += 256 * 4)
+            *reinterpret_cast<float4*>(b1s + i) = i < d_ff ? *reinterpret_cast<const float4*>(b1 + i) : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+    {   // epilogue parameters: 192 float4 global loads per lane in the epilogue (with every VGPR occupied hipcc issued them a few at a
+        // time: ~24 us of serialised L2 round trips per workgroup, a fifth of its time) -> one LDS table
+        float* prm = reinterpret_cast<float*>(f3_smem + F3_PRM_OFF);
+        prm[threadIdx.x] = b2[threadIdx.x];
+        prm[256 + threadIdx.x] = gamma[threadIdx.x];
+        prm[512 + threadIdx.x] = beta[threadIdx.x];
+    }
+    // ---- weight DMA: wave w moves fragments 4 w .. 4 w + 3 of every chunk image --------------------------------------------------
+    const unsigned vlane = (unsigned)lane * 16u;
+    const char* W1b = reinterpret_cast<const char*>(W1p) + wave * 4096;
+    const char* W2b = reinterpret_cast<const char*>(W2p) + wave * 4096;
+    const unsigned my1 = lds_base + (unsigned)wave * 4096u, my2 = my1 + F3_W2_OFF;
+#define F3_PIECE1(C, U) if (!(DBG & 1) || (C) < 3) f3_glds16s(W1b + (long)(C) * F3_RING + (U) * 1024, vlane, my1 + (unsigned)((C) & (F3_NS - 1)) * F3_RING + (U) * 1024u);
+#define F3_PIECE2(C, U) if (!(DBG & 1) || (C) < 2) f3_glds16s(W2b + (long)(C) * F3_RING + (U) * 1024, vlane, my2 + (unsigned)((C) & (F3_NS - 1)) * F3_RING + (U) * 1024u);
+#define F3_ISSUE1(C) { F3_PIECE1(C, 0) F3_PIECE1(C, 1) F3_PIECE1(C, 2) F3_PIECE1(C, 3) }
+#define F3_ISSUE2(C) { F3_PIECE2(C, 0) F3_PIECE2(C, 1) F3_PIECE2(C, 2) F3_PIECE2(C, 3) }
+    // prologue order: W1(0) W1(1) | W2(0) W2(1) W1(2); iteration c then issues W2(c + 2), W1(c + 3)
+    F3_ISSUE1(0)
+    F3_ISSUE1(1)
+    F3_ISSUE2(0)
+    F3_ISSUE2(1)
+    F3_ISSUE1(2)
+
+    f3_f32x16_t yacc[8][2];
+#pragma unroll
+    for (int ct = 0; ct < 8; ++ct)
+#pragma unroll
+        for (int tt = 0; tt < 2; ++tt)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) yacc[ct][tt][r] = 0.f;
+    f3_f32x16_t he[2];
+    uint4 hb[2][2], hbn[2];                                  // H^T B-fragments [k-step][token tile] of the chunk phase B multiplies; k-step 1 of the next one
+#pragma unroll
+    for (int s2 = 0; s2 < 2; ++s2)
+#pragma unroll
+        for (int tt = 0; tt < 2; ++tt) { hb[s2][tt] = make_uint4(0u, 0u, 0u, 0u); hbn[tt] = make_uint4(0u, 0u, 0u, 0u); }
+    uint4 w[4];
+#define F3_W1F(C, Q) (*reinterpret_cast<const uint4*>(f3_smem + ((C) & (F3_NS - 1)) * F3_RING + (Q) * 1024 + lane * 16))
+#define F3_W2F(C, Q) (*reinterpret_cast<const uint4*>(f3_smem + F3_W2_OFF + ((C) & (F3_NS - 1)) * F3_RING + (Q) * 1024 + lane * 16))
+    // phase-A accumulators <- b1 of chunk C: register r = 4 q + e <-> hidden 32 C + 8 q + 4 hh + e
+#define F3_SEED(C)                                                                                 \
+    {                                                                                              \
+        const float* bsrc_ = reinterpret_cast<const float*>(f3_smem + F3_B1_OFF) + (C) * 32 + 4 * hh; \
+        _Pragma("unroll") for (int q_ = 0; q_ < 4; ++q_) {                                         \
+            const float4 b_ = *reinterpret_cast<const float4*>(bsrc_ + 8 * q_);                    \
+            _Pragma("unroll") for (int tt = 0; tt < 2; ++tt) {                                     \
+                he[tt][4 * q_] = b_.x; he[tt][4 * q_ + 1] = b_.y; he[tt][4 * q_ + 2] = b_.z; he[tt][4 * q_ + 3] = b_.w; } } \
+    }
+    // X, W1(0), W1(1) landed (mine): all but the 12 newest pieces
+    asm volatile("s_waitcnt vmcnt(12) lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    F3_SEED(0)
+#pragma unroll
+    for (int q = 0; q < 4; ++q) w[q] = F3_W1F(0, q);
+
+    // H epilogue slice P (0..15) of the chunk phase A just finished: pair p = P & 7 of token tile P >> 3
+    // H epilogue slice P (0..15) of the chunk phase A just finished: pair p = P & 7 of token tile P >> 3.  Phase B runs k-step 0 in its
+    // groups 0..7 and k-step 1 in groups 8..15, so the new k-step-0 fragments (pairs 0..3) are written in place during groups 8..15 and
+    // only the k-step-1 fragments need a second set of registers.
+#define F3_HEPI(P, INPLACE0)                                                                       \
+    {                                                                                              \
+        const int tt_ = (P) >> 3, p_ = (P) & 7;                                                    \
+        const uint32_t v_ = pack_bf16x2(f3_relu(he[tt_][2 * p_]), f3_relu(he[tt_][2 * p_ + 1]));     \
+        uint4& d_ = (p_ < 4) ? hb[0][tt_] : hbn[tt_];                                              \
+        (void)(INPLACE0);                                                                          \
+        if ((p_ & 3) == 0) d_.x = v_;                                                              \
+        else if ((p_ & 3) == 1) d_.y = v_;                                                         \
+        else if ((p_ & 3) == 2) d_.z = v_;                                                         \
+        else d_.w = v_;                                                                            \
+    }
+    // iteration C (after barrier C: W1(C + 1) and W2(C - 1) are visible; w = W1(C) fragments 0..3):
+    //     phase A(C)    : 16 groups {2 MFMA on slot q & 3; refill the slot with stream fragment q + 4; a W2(C + 2) piece every 4th}
+    //     phase B(C - 1): 16 groups {2 MFMA; refill; a W1(C + 3) piece every 4th; a slice of the H epilogue of chunk C}
+    //                     group q: k-step q >> 3, channel tile q & 7 (W2 image fragment q)
+    // H epilogue slices under phase B: the k-step-1 pairs (p = 4..7 of both token tiles) in groups 0..7, the k-step-0 pairs in groups 8..15
+#define F3_STEP(C, WITH_A, WITH_B, FIRST)                                                          \
+    {                                                                                              \
+        if (!(FIRST) && !((DBG & 2) && (WITH_A))) {                                                \
+            if ((WITH_A) && !(DBG & 1)) asm volatile("s_waitcnt vmcnt(8) lgkmcnt(0)" ::: "memory"); \
+            else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");                       \
+            __builtin_amdgcn_s_barrier();                                                          \
+        }                                                                                          \
+        __builtin_amdgcn_sched_barrier(0);                                                         \
+        if (WITH_A) {                                                                              \
+            asm volatile("s_nop 4" ::: "memory");                                                  \
+            _Pragma("unroll") for (int q = 0; q < 16; ++q) {                                       \
+                f3_mma_v(w[q & 3], xf[q][0], he[0]);                                               \
+                f3_mma_v(w[q & 3], xf[q][1], he[1]);                                               \
+                if ((DBG & 4) && !(FIRST)) {}                                                      \
+                else if (q < 12) w[q & 3] = F3_W1F((C), q + 4);                                    \
+                else if (WITH_B) w[q & 3] = F3_W2F((C) - 1, q - 12);                               \
+                else w[q & 3] = F3_W1F((C) + 1, q - 12);                                           \
+                if ((q & 3) == 1) F3_PIECE2((C) + 2, q >> 2)                                       \
+                __builtin_amdgcn_sched_barrier(0);                                                 \
+            }                                                                                      \
+        }                                                                                          \
+        if ((WITH_B) && !(WITH_A)) {        /* last step: no phase A whose tail pre-loads the first W2 fragments */ \
+            _Pragma("unroll") for (int q = 0; q < 4; ++q) w[q] = F3_W2F((C) - 1, q);               \
+        }                                                                                          \
+        if (WITH_B) {                                                                              \
+            _Pragma("unroll") for (int q = 0; q < 16; ++q) {                                       \
+                yacc[q & 7][0] = f3_mma(w[q & 3], hb[q >> 3][0], yacc[q & 7][0]);                  \
+                yacc[q & 7][1] = f3_mma(w[q & 3], hb[q >> 3][1], yacc[q & 7][1]);                  \
+                if ((DBG & 4) && (WITH_A)) {}                                                      \
+                else if (q < 12) w[q & 3] = F3_W2F((C) - 1, q + 4);                                \
+                else if (WITH_A) w[q & 3] = F3_W1F((C) + 1, q - 12);                               \
+                if (WITH_A) {                                                                      \
+                    if ((q & 3) == 3) F3_PIECE1((C) + 3, q >> 2)                                   \
+                    /* groups 0..7: pairs 4..7 of tile q >> 2 & 1 ... slice index: k-step-1 pairs first */ \
+                    if (q < 8) F3_HEPI(8 * (q >> 2) + 4 + (q & 3), 0)                              \
+                    else F3_HEPI(8 * ((q - 8) >> 2) + ((q - 8) & 3), 1)                            \
+                }                                                                                  \
+                __builtin_amdgcn_sched_barrier(0);                                                 \
+            }                                                                                      \
+        } else {                                                                                   \
+            F3_ISSUE1((C) + 3)                                                                     \
+            asm volatile("s_nop 7\n\ts_nop 7\n\ts_nop 7" ::: "memory");                           \
+            _Pragma("unroll") for (int p = 0; p < 16; ++p) F3_HEPI(p, 1)                           \
+        }                                                                                          \
+        if (WITH_A) {                                                                              \
+            _Pragma("unroll") for (int tt = 0; tt < 2; ++tt) hb[1][tt] = hbn[tt];                  \
+            F3_SEED((C) + 1)                                                                       \
+        }                                                                                          \
+        __builtin_amdgcn_sched_barrier(0);                                                         \
+    }
+
+    F3_STEP(0, true, false, true)
+    for (int c = 1; c < ((DBG & 8) ? 2 : nchunk); ++c) F3_STEP(c, true, true, false)     // DBG 8: prologue + 2 chunks + epilogue only
+    F3_STEP(nchunk, false, true, false)
+#undef F3_STEP
+#undef F3_HEPI
+#undef F3_SEED
+#undef F3_W1F
+#undef F3_W2F
+#undef F3_ISSUE1
+#undef F3_ISSUE2
+#undef F3_PIECE1
+#undef F3_PIECE2
+
+    // ---- epilogue: + b2 + residual, LayerNorm, store ---------------------------------------------------------------------------
+    // residual: after the exchange lane (j, hh) holds, for k-step s, X channels 16 s + 4 hh + {0..3} in (x, y) and 16 s + 8 + 4 hh + {0..3}
+    // in (z, w): exactly the channels of its accumulator registers (tile ct = s >> 1, register group q = 2 (s & 1) + {0, 1})
+#pragma unroll
+    for (int tt = 0; tt < 2; ++tt)
+#pragma unroll
+        for (int s = 0; s < 16; ++s) {
+            const auto r0 = __builtin_amdgcn_permlane32_swap(xf[s][tt].x, xf[s][tt].z, false, false);
+            const auto r1 = __builtin_amdgcn_permlane32_swap(xf[s][tt].y, xf[s][tt].w, false, false);
+            xf[s][tt].x = r0[0]; xf[s][tt].z = r0[1];
+            xf[s][tt].y = r1[0]; xf[s][tt].w = r1[1];
+        }
+    const float* prm_ = reinterpret_cast<const float*>(f3_smem + F3_PRM_OFF);
+#pragma unroll
+    for (int tt = 0; tt < 2; ++tt) {
+        const long tok = tok0 + tt * 32 + j;
+        float sum = 0.f;
+#pragma unroll
+        for (int ct = 0; ct < 8; ++ct)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const float4 bb = *reinterpret_cast<const float4*>(prm_ + 32 * ct + 8 * q + 4 * hh);
+                const uint4& xr = xf[2 * ct + (q >> 1)][tt];
+                const uint32_t lo = (q & 1) ? xr.z : xr.x, hi = (q & 1) ? xr.w : xr.y;
+                yacc[ct][tt][4 * q] += bb.x + __uint_as_float(lo << 16);
+                yacc[ct][tt][4 * q + 1] += bb.y + __uint_as_float(lo & 0xffff0000u);
+                yacc[ct][tt][4 * q + 2] += bb.z + __uint_as_float(hi << 16);
+                yacc[ct][tt][4 * q + 3] += bb.w + __uint_as_float(hi & 0xffff0000u);
+                sum += (yacc[ct][tt][4 * q] + yacc[ct][tt][4 * q + 1]) + (yacc[ct][tt][4 * q + 2] + yacc[ct][tt][4 * q + 3]);
+            }
+        sum += __shfl_xor(sum, 32, 64);
+        const float mean = sum * (1.0f / 256.0f);
+        float sq = 0.f;
+#pragma unroll
+        for (int ct = 0; ct < 8; ++ct)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) { const float d = yacc[ct][tt][r] - mean; sq += d * d; }
+        sq += __shfl_xor(sq, 32, 64);
+        const float rstd = rsqrtf(sq * (1.0f / 256.0f) + eps);
+#pragma unroll
+        for (int ct = 0; ct < 8; ++ct)
+#pragma unroll
+            for (int qp = 0; qp < 2; ++qp) {
+                uint32_t pk[2][2];                                  // [q even / odd][channel pair]
+#pragma unroll
+                for (int qo = 0; qo < 2; ++qo) {
+                    const int q = 2 * qp + qo, ch = 32 * ct + 8 * q + 4 * hh;
+                    const float4 ga = *reinterpret_cast<const float4*>(prm_ + 256 + ch), be = *reinterpret_cast<const float4*>(prm_ + 512 + ch);
+                    const float o0 = (yacc[ct][tt][4 * q] - mean) * rstd * ga.x + be.x, o1 = (yacc[ct][tt][4 * q + 1] - mean) * rstd * ga.y + be.y;
+                    const float o2 = (yacc[ct][tt][4 * q + 2] - mean) * rstd * ga.z + be.z, o3 = (yacc[ct][tt][4 * q + 3] - mean) * rstd * ga.w + be.w;
+                    pk[qo][0] = pack_bf16x2(o0, o1);
+                    pk[qo][1] = pack_bf16x2(o2, o3);
+                }
+                // upper half-lanes of the even group <-> lower half-lanes of the odd group: lane (j, 0) ends up with channels
+                // 8 q_even .. + 7, lane (j, 1) with 8 q_odd .. + 7 of tile ct: one 16-byte store each, 32 contiguous bytes per token
+                const auto s0 = __builtin_amdgcn_permlane32_swap(pk[0][0], pk[1][0], false, false);
+                const auto s1 = __builtin_amdgcn_permlane32_swap(pk[0][1], pk[1][1], false, false);
+                if (tok < M)
+                    *reinterpret_cast<uint4*>(Y + tok * 256 + 32 * ct + 16 * qp + 8 * hh) = make_uint4(s0[0], s1[0], s0[1], s1[1]);
+            }
+    }
+}
+
+// W1 [d_ff, 256] -> [d_ff/32 + PAD][16 s][64 lanes][8]: lane l <- W1[32 c + (l & 31)][16 s + 8 (l >> 5) + e]
+// W2 [256, d_ff] -> [d_ff/32 + PAD][2 s][8 ct][64 lanes][8]: lane l <- W2[32 ct + (l & 31)][32 c + 8 (2 s + (e >> 2)) + 4 (l >> 5) + (e & 3)]
+extern "C" int dtlr_ffn32_pack_weights(const void* w1, const void* w2, void* w1p, void* w2p, int d_ff)
+{
+    if (!w1 || !w2 || !w1p || !w2p || d_ff < 64 || (d_ff & 31)) return DTLR_EINVAL;
+    const uint16_t* a = (const uint16_t*)w1;
+    const uint16_t* b = (const uint16_t*)w2;
+    uint16_t* ap = (uint16_t*)w1p;
+    uint16_t* bp = (uint16_t*)w2p;
+    const int nc = d_ff / 32;
+    for (long i = 0; i < (long)(nc + FFN32_PAD) * 8192; ++i) { ap[i] = 0; bp[i] = 0; }
+    for (int c = 0; c < nc; ++c)
+        for (int f = 0; f < 16; ++f)
+            for (int l = 0; l < 64; ++l)
+                for (int e = 0; e < 8; ++e) {
+                    const long dst = (((long)c * 16 + f) * 64 + l) * 8 + e;
+                    ap[dst] = a[(long)(32 * c + (l & 31)) * 256 + 16 * f + 8 * (l >> 5) + e];
+                    const int ct = f & 7, s = f >> 3;
+                    bp[dst] = b[(long)(32 * ct + (l & 31)) * d_ff + 32 * c + 8 * (2 * s + (e >> 2)) + 4 * (l >> 5) + (e & 3)];
+                }
+    return DTLR_OK;
+}
+
+extern "C" int dtlr_ffn32_pad_chunks(void) { return FFN32_PAD; }
+
+// X, Y [M, 256] bf16; W1p / W2p from dtlr_ffn32_pack_weights (device copies); b1 [d_ff], b2 / gamma / beta [256] fp32.
+extern "C" int dtlr_ffn32_bf16(const void* X, const void* W1p, const float* b1, const void* W2p, const float* b2,
+                               const float* gamma, const float* beta, float eps, void* Y, long M, int d_ff, void* stream)
+{
+    clear_stale_error();
+    if (!X || !W1p || !b1 || !W2p || !b2 || !gamma || !beta || !Y) return DTLR_EINVAL;
+    if (M <= 0 || M > 0x7fffffffL) return DTLR_EINVAL;
+    if (d_ff < 64 || d_ff > F3_MAX_DFF || (d_ff & 31)) return DTLR_ESHAPE;
+    static const int dbg = [] { const char* e = getenv("DTLR_FFN32_DBG"); return e ? atoi(e) : 0; }();      // timing experiments only
+#define F3_LAUNCH(D)                                                                               \
+    {                                                                                              \
+        static DevOnce once;                                                                       \
+        if (once.first()) { (void)hipFuncSetAttribute((const void*)ffn3_bf16_kernel<D>, hipFuncAttributeMaxDynamicSharedMemorySize, F3_LDS); (void)hipGetLastError(); } \
+        hipLaunchKernelGGL(ffn3_bf16_kernel<D>, dim3((unsigned)((M + 255) / 256)), dim3(256), F3_LDS, (hipStream_t)stream,       \
+                           (const uint16_t*)X, (const uint16_t*)W1p, b1, (const uint16_t*)W2p, b2, gamma, beta, eps, (uint16_t*)Y, (int)M, d_ff); \
+    }
+    switch (dbg) {
+        case 1: F3_LAUNCH(1) break;
+        case 2: F3_LAUNCH(2) break;
+        case 3: F3_LAUNCH(3) break;
+        case 4: F3_LAUNCH(4) break;
+        case 7: F3_LAUNCH(7) break;
+        case 8: F3_LAUNCH(8) break;
+        default: F3_LAUNCH(0) break;
+    }
+#undef F3_LAUNCH
+    return check_launch();
+}
+
+}  // namespace dtlr

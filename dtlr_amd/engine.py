@@ -51,7 +51,8 @@ class DTLREngine:
         self.use_lds_msda = True       # encoder MSDA with LDS-staged windows (False: gather kernel)
         self.use_fused_ffn = True      # bf16: linear1+ReLU+linear2+residual+LayerNorm in one kernel (False: two GEMMs + LN)
         self.use_k256 = os.environ.get("DTLR_K256", "1") != "0"   # bf16: weight-resident streaming kernel for the K = 256 projections over all tokens
-        self.use_pln_k256 = os.environ.get("DTLR_PLN_K256", "1") != "0"   # ... and for the encoder's output projection + LayerNorm
+        self.use_pln_k256 = os.environ.get("DTLR_PLN_K256", "1") != "0"
+        self.use_ffn32 = os.environ.get("DTLR_FFN32", "1") != "0"   # ... and for the encoder's output projection + LayerNorm
 
     # ------------------------------------------------------------------------------ packing
     def _put(self, name, t, dtype=None):
@@ -277,6 +278,12 @@ class DTLREngine:
         """forward_ffn + post-norm (deformable_transformer.py:804-823, 876-880).  bf16 engine: one fused kernel, the
         d_ff-wide intermediate stays on chip; fp32 engine: two GEMMs + LayerNorm."""
         w = self.w
+        if self.use_fused_ffn and self.use_ffn32 and x.dtype == torch.bfloat16 and x.numel() // 256 >= 65536 and w[q + "ff1.w"].shape[0] % 32 == 0 \
+                and 64 <= w[q + "ff1.w"].shape[0] <= 2048:
+            if q + "ff.p32" not in w:                           # both weights in the 32x32 fragment order, packed once
+                w[q + "ff.p32"] = ops.ffn32_pack(w[q + "ff1.w"], w[q + "ff2.w"])
+            w1p, w2p = w[q + "ff.p32"]
+            return ops.ffn32(x, w1p, w[q + "ff1.b"], w2p, w[q + "ff2.b"], w[q + norm + ".w"], w[q + norm + ".b"])
         if self.use_fused_ffn and ops.ffn_fused_supported(x, w[q + "ff1.w"]):
             if q + "ff2.wp" not in w:                           # chunk-major copy of linear2.weight, packed once
                 w[q + "ff2.wp"] = ops.ffn_pack_w2(w[q + "ff2.w"])

@@ -315,6 +315,39 @@ def ffn_pack_w2(w2):
     return w2.view(o, dff // 32, 32).permute(1, 0, 2).contiguous()
 
 
+FFN32_PAD = 4            # == dtlr_ffn32_pad_chunks(): zero chunks behind each packed image (streamed, never multiplied)
+
+
+def ffn32_pack(w1, w2):
+    """linear1.weight [d_ff, 256], linear2.weight [256, d_ff] -> the two fragment-order images of dtlr_ffn32_bf16
+    (== dtlr_ffn32_pack_weights).  W1p[c][s][l][e] = W1[32 c + (l & 31)][16 s + 8 (l >> 5) + e];
+    W2p[c][8 s + ct][l][e] = W2[32 ct + (l & 31)][32 c + 8 (2 s + (e >> 2)) + 4 (l >> 5) + (e & 3)]; FFN32_PAD zero chunks appended."""
+    d_ff = w1.shape[0]
+    assert tuple(w1.shape) == (d_ff, 256) and tuple(w2.shape) == (256, d_ff) and d_ff % 32 == 0 and 64 <= d_ff <= 2048
+    nc = d_ff // 32
+    a = w1.detach().to(torch.bfloat16).view(nc, 32, 16, 2, 8).permute(0, 2, 3, 1, 4).reshape(nc, 8192)
+    b = w2.detach().to(torch.bfloat16).view(8, 32, nc, 2, 2, 2, 4).permute(2, 3, 0, 5, 1, 4, 6).reshape(nc, 8192)
+    pad = torch.zeros((FFN32_PAD, 8192), dtype=torch.bfloat16, device=w1.device)
+    return torch.cat([a, pad]).contiguous().view(-1), torch.cat([b, pad]).contiguous().view(-1)
+
+
+def ffn32(x, w1p, b1, w2p, b2, ln_w, ln_b, eps: float = 1e-5):
+    """LayerNorm(x + relu(x W1^T + b1) W2^T + b2) for many rows (dtlr_ffn32_bf16: 32x32x16 MFMAs, one wave per SIMD, 256 rows per
+    workgroup); (w1p, w2p) = ffn32_pack(W1, W2).  Same result as ffn_fused up to fp32 summation order."""
+    require_cuda(x, "x")
+    d_ff = b1.numel()
+    assert x.dtype == torch.bfloat16 and x.shape[-1] == 256 and w1p.dtype == torch.bfloat16 and w2p.dtype == torch.bfloat16
+    assert w1p.numel() == (d_ff // 32 + FFN32_PAD) * 8192 and w2p.numel() == w1p.numel()
+    x = x if x.is_contiguous() else x.contiguous()
+    y = torch.empty_like(x)
+    M = x.numel() // 256
+    with _Timed("ffn_fused_bf16", 4.0 * M * 256 * d_ff, 2.0 * M * 256 * 2 + 2.0 * 256 * d_ff * 2):
+        code = _lib.lib().dtlr_ffn32_bf16(x.data_ptr(), w1p.data_ptr(), b1.data_ptr(), w2p.data_ptr(), b2.data_ptr(),
+                                          ln_w.data_ptr(), ln_b.data_ptr(), eps, y.data_ptr(), M, d_ff, _lib.current_stream())
+    _lib.check(code, "dtlr_ffn32_bf16")
+    return y
+
+
 def ffn_fused(x, w1, b1, w2p, b2, ln_w, ln_b, eps: float = 1e-5):
     """LayerNorm(x + relu(x W1^T + b1) W2^T + b2) in ONE kernel (dtlr_ffn_fused_bf16): the [M, d_ff]
     intermediate never reaches HBM.  x [..., 256] bf16; W1 [d_ff,256] bf16; w2p = ffn_pack_w2(W2) ([d_ff/32,256,32] bf16);
@@ -794,7 +827,7 @@ def _device_scoped(fn):
     return wrapper
 
 
-for _name in ("proj_ln_k256", "swin_patch_embed", "swin_window_attn", "swin_patch_merge", "geometry", "linear", "gemm_k256", "linear_rowmax", "two_stage_gather", "layernorm", "proj_ln", "proj_ln_split", "ffn_fused", "conv2d_nhwc", "stem_conv7x7", "stem_conv7x7_f32",
+for _name in ("ffn32", "proj_ln_k256", "swin_patch_embed", "swin_window_attn", "swin_patch_merge", "geometry", "linear", "gemm_k256", "linear_rowmax", "two_stage_gather", "layernorm", "proj_ln", "proj_ln_split", "ffn_fused", "conv2d_nhwc", "stem_conv7x7", "stem_conv7x7_f32",
               "maxpool_nhwc", "groupnorm_tokens", "msda", "msda_fused", "msda_encoder", "mha", "decoder_query_prep", "box_mlp_refine",
               "box_head_refine", "box_refine", "topk_rows", "decode_blank", "preprocess_lines", "ctc_loss_interleaved", "nms_batched",
               "topk_flat"):

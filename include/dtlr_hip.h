@@ -123,6 +123,21 @@ int dtlr_ffn_fused_bf16(const void *X, const void *W1, const float *b1, const vo
                         int M, int d_model, int d_ff, void *stream);
 
 /* ---------------------------------------------------------------------------------------------
+ * The same fused feed-forward block for MANY rows (the encoder call, M = batch x 5440 tokens), built on the 32x32x16 MFMA with
+ * both weights pre-packed in fragment order:
+ *     Y = LayerNorm( X + relu(X W1^T + b1) W2^T + b2 )            X, Y [M, 256] bf16
+ * Replaces: DeformableTransformerEncoderLayer.forward_ffn + norm2 (models/dino/deformable_transformer.py:804-823).
+ *   dtlr_ffn32_pack_weights: HOST-side packer (all four pointers host memory): linear1.weight [d_ff, 256] and linear2.weight
+ *     [256, d_ff] (bf16) -> two images of (d_ff/32 + dtlr_ffn32_pad_chunks()) x 16 KB; the trailing chunks are zero (they are
+ *     streamed by the kernel's steady-state loop and never multiplied).  d_ff a multiple of 32, 64 <= d_ff <= 2048.
+ *   dtlr_ffn32_bf16: W1p / W2p = device copies of those images; b1 [d_ff], b2 / gamma / beta [256] fp32.
+ */
+int dtlr_ffn32_pack_weights(const void *w1, const void *w2, void *w1p, void *w2p, int d_ff);
+int dtlr_ffn32_pad_chunks(void);
+int dtlr_ffn32_bf16(const void *X, const void *W1p, const float *b1, const void *W2p, const float *b2,
+                    const float *gamma, const float *beta, float eps, void *Y, long M, int d_ff, void *stream);
+
+/* ---------------------------------------------------------------------------------------------
  * Output projection + residual + LayerNorm of an attention block, bf16 (fp32 accumulate / statistics):
  *     Y = LayerNorm( R + A W^T + b )            A, R, Y [M, 256] bf16 ; b, gamma, beta [256] fp32
  *     W: the [256, 256] bf16 weight re-ordered by dtlr_proj_pack_weights (a HOST-side helper, both pointers host memory)

@@ -919,3 +919,31 @@ def test_proj_ln_k256_vs_reference(M):
     outp = np.empty(65536, dtype=np.uint16)
     assert _lib.lib().dtlr_proj_ln_k256_pack_weights(src.ctypes.data, outp.ctypes.data) == 0
     assert np.array_equal(outp, ops.proj_ln_k256_pack(w).view(torch.int16).numpy().view(np.uint16))
+
+
+@pytest.mark.parametrize("M,d_ff", [(256, 128), (1000, 2048), (65536 + 77, 2048), (174080, 2048), (700, 64)])
+def test_ffn32_vs_reference_and_first_structures(M, d_ff):
+    """The 32x32x16-MFMA fused FFN (dtlr_ffn32_bf16) against an fp32 reference that rounds the hidden activations to bf16 like the
+    kernel does, and against the 16x16x32 kernels (same arithmetic up to fp32 summation order); host packer == tensor-op packer."""
+    from dtlr_amd import _lib, ops
+    x = _rand((M, 256), 1).bfloat16()
+    w1 = (_rand((d_ff, 256), 2) / 16.0).bfloat16()
+    w2 = (_rand((256, d_ff), 3) / 45.0).bfloat16()
+    b1, b2 = _rand((d_ff,), 4) * 0.1, _rand((256,), 5) * 0.1
+    gw, gb = _rand((256,), 6) * 0.2 + 1.0, _rand((256,), 7) * 0.1
+    h = torch.relu(x.float() @ w1.float().t() + b1).bfloat16().float()
+    want = F.layer_norm(x.float() + h @ w2.float().t() + b2, (256,), gw, gb, 1e-5)
+    w1p, w2p = ops.ffn32_pack(w1.cuda(), w2.cuda())
+    got = ops.ffn32(x.cuda(), w1p, b1.cuda(), w2p, b2.cuda(), gw.cuda(), gb.cuda())
+    assert (got.float().cpu() - want).abs().max() < 0.05
+    if d_ff >= 128:
+        old = ops.ffn_fused(x.cuda(), w1.cuda(), b1.cuda(), ops.ffn_pack_w2(w2.cuda()), b2.cuda(), gw.cuda(), gb.cuda())
+        assert (got.float() - old.float()).abs().max() <= 0.0315            # at most one bf16 ulp at |y| < 8
+        assert (got == old).float().mean() > 0.995
+    a1 = np.ascontiguousarray(w1.view(torch.int16).numpy()).view(np.uint16)
+    a2 = np.ascontiguousarray(w2.view(torch.int16).numpy()).view(np.uint16)
+    n = (d_ff // 32 + _lib.lib().dtlr_ffn32_pad_chunks()) * 8192
+    o1, o2 = np.empty(n, dtype=np.uint16), np.empty(n, dtype=np.uint16)
+    assert _lib.lib().dtlr_ffn32_pack_weights(a1.ctypes.data, a2.ctypes.data, o1.ctypes.data, o2.ctypes.data, d_ff) == 0
+    assert np.array_equal(o1, w1p.cpu().view(torch.int16).numpy().view(np.uint16))
+    assert np.array_equal(o2, w2p.cpu().view(torch.int16).numpy().view(np.uint16))
