@@ -283,6 +283,19 @@ class DTLREngine:
             if q + "ff.p32" not in w:                           # both weights in the 32x32 fragment order, packed once
                 w[q + "ff.p32"] = ops.ffn32_pack(w[q + "ff1.w"], w[q + "ff2.w"])
             w1p, w2p = w[q + "ff.p32"]
+            # whole rounds of 256 workgroups x 256 rows on the 32x32 kernel; a last partial round that fits 256 workgroups of the 16x16
+            # kernel (192 or 128 rows each: a shorter round than a third full-length one) goes to that kernel
+            M = x.numel() // 256
+            rem = M % 65536
+            if 0 < rem <= 49152 and ops.ffn_fused_supported(x, w[q + "ff1.w"]):
+                if q + "ff2.wp" not in w:
+                    w[q + "ff2.wp"] = ops.ffn_pack_w2(w[q + "ff2.w"])
+                x2 = x.reshape(M, 256)
+                y = torch.empty_like(x2)
+                ops.ffn32(x2[:M - rem], w1p, w[q + "ff1.b"], w2p, w[q + "ff2.b"], w[q + norm + ".w"], w[q + norm + ".b"], out=y[:M - rem])
+                ops.ffn_fused(x2[M - rem:], w[q + "ff1.w"], w[q + "ff1.b"], w[q + "ff2.wp"], w[q + "ff2.b"], w[q + norm + ".w"], w[q + norm + ".b"],
+                              out=y[M - rem:])
+                return y.view(x.shape)
             return ops.ffn32(x, w1p, w[q + "ff1.b"], w2p, w[q + "ff2.b"], w[q + norm + ".w"], w[q + norm + ".b"])
         if self.use_fused_ffn and ops.ffn_fused_supported(x, w[q + "ff1.w"]):
             if q + "ff2.wp" not in w:                           # chunk-major copy of linear2.weight, packed once

@@ -331,7 +331,7 @@ def ffn32_pack(w1, w2):
     return torch.cat([a, pad]).contiguous().view(-1), torch.cat([b, pad]).contiguous().view(-1)
 
 
-def ffn32(x, w1p, b1, w2p, b2, ln_w, ln_b, eps: float = 1e-5):
+def ffn32(x, w1p, b1, w2p, b2, ln_w, ln_b, eps: float = 1e-5, out=None):
     """LayerNorm(x + relu(x W1^T + b1) W2^T + b2) for many rows (dtlr_ffn32_bf16: 32x32x16 MFMAs, one wave per SIMD, 256 rows per
     workgroup); (w1p, w2p) = ffn32_pack(W1, W2).  Same result as ffn_fused up to fp32 summation order."""
     require_cuda(x, "x")
@@ -339,7 +339,8 @@ def ffn32(x, w1p, b1, w2p, b2, ln_w, ln_b, eps: float = 1e-5):
     assert x.dtype == torch.bfloat16 and x.shape[-1] == 256 and w1p.dtype == torch.bfloat16 and w2p.dtype == torch.bfloat16
     assert w1p.numel() == (d_ff // 32 + FFN32_PAD) * 8192 and w2p.numel() == w1p.numel()
     x = x if x.is_contiguous() else x.contiguous()
-    y = torch.empty_like(x)
+    y = torch.empty_like(x) if out is None else out
+    assert y.is_contiguous() and y.shape == x.shape and y.dtype == x.dtype
     M = x.numel() // 256
     with _Timed("ffn_fused_bf16", 4.0 * M * 256 * d_ff, 2.0 * M * 256 * 2 + 2.0 * 256 * d_ff * 2):
         code = _lib.lib().dtlr_ffn32_bf16(x.data_ptr(), w1p.data_ptr(), b1.data_ptr(), w2p.data_ptr(), b2.data_ptr(),
@@ -348,7 +349,7 @@ def ffn32(x, w1p, b1, w2p, b2, ln_w, ln_b, eps: float = 1e-5):
     return y
 
 
-def ffn_fused(x, w1, b1, w2p, b2, ln_w, ln_b, eps: float = 1e-5):
+def ffn_fused(x, w1, b1, w2p, b2, ln_w, ln_b, eps: float = 1e-5, out=None):
     """LayerNorm(x + relu(x W1^T + b1) W2^T + b2) in ONE kernel (dtlr_ffn_fused_bf16): the [M, d_ff]
     intermediate never reaches HBM.  x [..., 256] bf16; W1 [d_ff,256] bf16; w2p = ffn_pack_w2(W2) ([d_ff/32,256,32] bf16);
     biases / LN params fp32."""
@@ -356,7 +357,8 @@ def ffn_fused(x, w1, b1, w2p, b2, ln_w, ln_b, eps: float = 1e-5):
     if w2p.dim() != 3 or w2p.shape[1] != 256 or w2p.shape[2] != 32 or w2p.shape[0] * 32 != w1.shape[0]:
         raise ValueError("ffn_fused: w2p must be ffn_pack_w2(linear2.weight) of shape [d_ff/32, 256, 32]")
     x = x if x.is_contiguous() else x.contiguous()
-    y = torch.empty_like(x)
+    y = torch.empty_like(x) if out is None else out
+    assert y.is_contiguous() and y.shape == x.shape and y.dtype == x.dtype
     M = x.numel() // x.shape[-1]
     with _Timed("ffn_fused_bf16", 4.0 * M * x.shape[-1] * w1.shape[0], 2.0 * M * 256 * 2 + 2.0 * w1.numel() * 2):
         code = _lib.lib().dtlr_ffn_fused_bf16(x.data_ptr(), w1.data_ptr(), b1.data_ptr(), w2p.data_ptr(), b2.data_ptr(),
