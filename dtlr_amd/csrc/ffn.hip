@@ -411,7 +411,9 @@ constexpr int F2_NS = 4;
 constexpr int F2_RING = 16384;                              // one W1 (or W2) chunk image
 constexpr int F2_W2_OFF = F2_NS * F2_RING;
 constexpr int F2_B1_OFF = 2 * F2_NS * F2_RING;
-constexpr int F2_LDS = F2_B1_OFF + FFN_MAX_DFF * 4;
+constexpr int F2_PRM_OFF = F2_B1_OFF + FFN_MAX_DFF * 4;    // b2 | gamma | beta: the epilogue reads them from LDS (as global loads, with every
+                                                            // VGPR occupied, hipcc issued them a few at a time: serialised L2 round trips)
+constexpr int F2_LDS = F2_PRM_OFF + 3 * 256 * 4;
 
 template <int TT>
 __global__ __launch_bounds__(256, 1) void ffn2_bf16_kernel(
@@ -469,6 +471,10 @@ __global__ __launch_bounds__(256, 1) void ffn2_bf16_kernel(
     {
         float* b1s = reinterpret_cast<float*>(smem + F2_B1_OFF);
         for (int i = (int)threadIdx.x * 4; i < d_ff; i += 256 * 4) *reinterpret_cast<float4*>(b1s + i) = *reinterpret_cast<const float4*>(b1 + i);
+        float* prm = reinterpret_cast<float*>(smem + F2_PRM_OFF);
+        prm[threadIdx.x] = b2[threadIdx.x];
+        prm[256 + threadIdx.x] = gamma[threadIdx.x];
+        prm[512 + threadIdx.x] = beta[threadIdx.x];
     }
     // issue order = the steady state's (iteration c issues W1(c+3), W2(c+2)): W1(0) | W1(1) W2(0) | W1(2) W2(1)
     F2_ISSUE1(0)
@@ -569,6 +575,7 @@ __global__ __launch_bounds__(256, 1) void ffn2_bf16_kernel(
 #undef F2_W2F
 
     // ---- epilogue: + b2 + residual (X fragment ks holds exactly the channels of accumulator tiles 2 ks, 2 ks + 1), LayerNorm, store ----
+    const float* prm2_ = reinterpret_cast<const float*>(smem + F2_PRM_OFF);
 #pragma unroll
     for (int tt = 0; tt < TT; ++tt) {
         const long tok = tok0 + tt * 16 + n;
@@ -577,7 +584,7 @@ __global__ __launch_bounds__(256, 1) void ffn2_bf16_kernel(
 #pragma unroll
         for (int kq = 0; kq < 8; ++kq) {
             const int ch = 32 * kq + 8 * g;
-            const float4 ba = *reinterpret_cast<const float4*>(b2 + ch), bc = *reinterpret_cast<const float4*>(b2 + ch + 4);
+            const float4 ba = *reinterpret_cast<const float4*>(prm2_ + ch), bc = *reinterpret_cast<const float4*>(prm2_ + ch + 4);
             const float bias[8] = {ba.x, ba.y, ba.z, ba.w, bc.x, bc.y, bc.z, bc.w};
             float xr[8];
             unpack8(xf[kq][tt], xr);
@@ -602,8 +609,8 @@ __global__ __launch_bounds__(256, 1) void ffn2_bf16_kernel(
 #pragma unroll
         for (int kq = 0; kq < 8; ++kq) {
             const int ch = 32 * kq + 8 * g;
-            const float4 ga = *reinterpret_cast<const float4*>(gamma + ch), gc = *reinterpret_cast<const float4*>(gamma + ch + 4);
-            const float4 ea = *reinterpret_cast<const float4*>(beta + ch), ec = *reinterpret_cast<const float4*>(beta + ch + 4);
+            const float4 ga = *reinterpret_cast<const float4*>(prm2_ + 256 + ch), gc = *reinterpret_cast<const float4*>(prm2_ + 256 + ch + 4);
+            const float4 ea = *reinterpret_cast<const float4*>(prm2_ + 512 + ch), ec = *reinterpret_cast<const float4*>(prm2_ + 512 + ch + 4);
             const float gm[8] = {ga.x, ga.y, ga.z, ga.w, gc.x, gc.y, gc.z, gc.w};
             const float bt[8] = {ea.x, ea.y, ea.z, ea.w, ec.x, ec.y, ec.z, ec.w};
             float o[8];

@@ -26,7 +26,7 @@ sys.path.insert(0, ROOT)
 FAMILIES = {
     "gemm": re.compile(r"dtlr::(gemm_ws_kernel|gemm_ws_tall_kernel|gemm_k256_kernel|gemm_nt_kernel)\b"),
     "proj_ln": re.compile(r"dtlr::proj_ln_\w*kernel\b"),
-    "ffn": re.compile(r"dtlr::(ffn2_bf16_kernel<|ffn_fused_bf16_kernel<0, false>)"),
+    "ffn": re.compile(r"dtlr::(ffn3_bf16_kernel<|ffn2_bf16_kernel<|ffn_fused_bf16_kernel<0, false>)"),
     "msda_enc": re.compile(r"dtlr::msda_enc_lds_kernel\b"),
 }
 KIND_FAMILY = {"gemm_bf16": "gemm", "gemm_f32": "gemm", "proj_ln_bf16": "proj_ln", "ffn_fused_bf16": "ffn"}
