@@ -919,16 +919,20 @@ static inline int plan_chain(long ntiles) {
 // tiles of K = 18432: 0.23 ms on 32 of 256 CUs).  KSPLIT copies of the tile grid each multiply a K range into an fp32
 // partial tile (slice s of a workspace); a second small kernel sums the slices and applies the epilogue.  Deterministic
 // (no atomics): the slices are added in index order.
-static float* g_splitk_ws = nullptr;
-static size_t g_splitk_bytes = 0;
+// one workspace per device (a process may drive several GPUs; the pointer of one is not addressable from another)
+static float* g_splitk_ws[64] = {};
+static size_t g_splitk_bytes[64] = {};
 static float* splitk_workspace(size_t bytes) {
-    if (bytes > g_splitk_bytes) {
-        if (g_splitk_ws) (void)hipFree(g_splitk_ws);
-        g_splitk_ws = nullptr; g_splitk_bytes = 0;
-        if (hipMalloc((void**)&g_splitk_ws, bytes) != hipSuccess) { (void)hipGetLastError(); return nullptr; }
-        g_splitk_bytes = bytes;
+    int d = 0;
+    (void)hipGetDevice(&d);
+    d &= 63;
+    if (bytes > g_splitk_bytes[d]) {
+        if (g_splitk_ws[d]) (void)hipFree(g_splitk_ws[d]);          // hipFree waits for the device: no launch still reads the old buffer
+        g_splitk_ws[d] = nullptr; g_splitk_bytes[d] = 0;
+        if (hipMalloc((void**)&g_splitk_ws[d], bytes) != hipSuccess) { (void)hipGetLastError(); return nullptr; }
+        g_splitk_bytes[d] = bytes;
     }
-    return g_splitk_ws;
+    return g_splitk_ws[d];
 }
 static inline int plan_split(long nwg, int nk) {
     if (nwg >= 96 || nk < 16) return 1;

@@ -1,0 +1,232 @@
+// Weight-resident streaming GEMM with a streamed residual, bf16:   C = relu?( A W^T + b + R ),  A [M, K], W [N, K], R / C [M, ld]
+//
+// The last 1x1 convolution of a ResNet bottleneck (`out = relu(bn3(conv3(out)) + identity)`, torchvision resnet50 as wrapped by
+// models/dino/backbone.py:62-72,97-106; FrozenBN folded into W and b): K = 64 / 128 / 256 input channels, N = 256 / 512 / 1024 output
+// channels, M = B x H x W pixels.  At these shapes the operation is an HBM stream -- per output pixel K x 2 bytes of A, N x 2 of the
+// residual in and N x 2 out -- that the tiled kernel (gemm.hip) runs at 3.4-4.4 TB/s: each 128 x 128 tile ends in an epilogue whose
+// residual loads are two serialised HBM round trips.  Here, as in gemm_k256.hip's proj_ln_k256_kernel:
+//   * the WEIGHT is the resident operand: wave w of 8 keeps 32 NP output channels x K as MFMA A-fragments in registers for the whole
+//     kernel (N = 256 NP per launch column; wider layers run N / (256 NP) column slices as blockIdx.y);
+//   * TOKENS stream: a 64-token tile of A (64 x K) and of R (64 x 256 NP) is DMA'd global -> LDS (global_load_lds_dwordx4, 8 rows x 128 B
+//     per instruction, full lines) through an NS-stage ring, the 16-byte chunks permuted on the source side (chunk c of row r lands in
+//     slot c ^ (r & 7)) so the MFMA B-fragment reads and the 16-byte residual reads are conflict-free;
+//   * W's rows are assigned to MFMA rows so that a lane's two accumulator tiles of a pair are 8 CONSECUTIVE channels (pair p of wave w,
+//     tile e, MFMA row m <-> channel 32 (w NP + p) + 8 (m >> 2) + 4 e + (m & 3)): the residual is one 16-byte LDS read and the result
+//     one 16-byte store per token and pair, no lane exchange;
+//   * ONE barrier per 64 tokens (publishes the tile, frees the stage the next DMA overwrites); DMA groups and stores share the in-order
+//     vmcnt counter and are counted by hand so that a tile's stores are never waited for.
+#include "dtlr_common.h"
+#include <stdlib.h>
+
+namespace dtlr {
+
+typedef __attribute__((ext_vector_type(8))) __bf16 kr_bf16x8_t;
+typedef __attribute__((ext_vector_type(4))) float kr_f32x4_t;
+
+constexpr int KR_TOK = 64;
+
+__device__ __forceinline__ void kr_glds16(const void* gsrc, unsigned lds_dst) {
+    unsigned keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep) : "v"(gsrc), "s"(lds_dst) : "memory");
+}
+__device__ __forceinline__ uint4 kr_load16(const void* p) {
+    uint4 r;
+    asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(r) : "v"(p) : "memory");
+    return r;
+}
+__device__ __forceinline__ kr_f32x4_t kr_mma(const uint4& a, const uint4& b, kr_f32x4_t c) {
+    return __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(kr_bf16x8_t, a), __builtin_bit_cast(kr_bf16x8_t, b), c, 0, 0, 0);
+}
+template <int N> __device__ __forceinline__ void kr_wait() {
+    static_assert(N >= 0 && N < 64, "vmcnt is a 6-bit counter");
+    asm volatile("s_waitcnt vmcnt(%0)" :: "n"(N) : "memory");
+    __builtin_amdgcn_sched_barrier(0);
+}
+
+// KB = K / 64 (128-byte k blocks per token row), NP = row-tile pairs per wave (output columns per launch column = 256 NP), NS = stages.
+// Wp: fragment order, block (((slice * 8 + wave) * NP + p) * 2 + e) * KS + ks (KS = 2 KB k-steps of 32) = 64 lanes x 8 elements.
+template <int KB, int NP, int NS, bool HAS_R>
+__global__ __launch_bounds__(512, 2) void gemm_kres_kernel(
+    const uint16_t* __restrict__ A, const uint16_t* __restrict__ Wp, const float* __restrict__ bias, const uint16_t* __restrict__ R,
+    uint16_t* __restrict__ C, int ld, int M, int tiles_per_wg, int relu)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char kr_smem[];
+    const unsigned lds_base = (unsigned)(size_t)(__attribute__((address_space(3))) unsigned char*)kr_smem;
+    constexpr int K = 64 * KB, KS = 2 * KB, NC = 256 * NP, NB = 4 * NP;          // NB = 128-byte blocks per residual row
+    constexpr int A_BYTES = KR_TOK * K * 2, STAGE = A_BYTES + (HAS_R ? KR_TOK * NC * 2 : 0);
+    constexpr int G = KB + (HAS_R ? NB : 0);                                       // DMA instructions per wave per tile
+    constexpr int E = 4 * NP;                                                      // stores per wave per tile
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const int n = lane & 15, g = lane >> 4;
+    const int col0 = (int)blockIdx.y * NC;                                         // this launch column's first output channel
+    const int ntiles = (M + KR_TOK - 1) / KR_TOK;
+    const int t_begin = (int)blockIdx.x * tiles_per_wg;
+    const int t_end = min(t_begin + tiles_per_wg, ntiles);
+    if (t_begin >= t_end) return;
+    const int nt = t_end - t_begin;
+
+    // DMA of tile t into a stage: wave w moves row group w (token rows 8 w .. 8 w + 7): its KB blocks of A and NB blocks of R
+    const int dr = lane >> 3, dc = (lane & 7) ^ dr;
+    auto issue = [&](int t, int slot) {
+        const long tok = min((long)t * KR_TOK + wave * 8 + dr, (long)M - 1);
+        const unsigned dst = lds_base + (unsigned)(slot * STAGE);
+#pragma unroll
+        for (int kb = 0; kb < KB; ++kb) kr_glds16(A + tok * K + kb * 64 + dc * 8, dst + (unsigned)((wave * KB + kb) * 1024));
+        if constexpr (HAS_R) {
+#pragma unroll
+            for (int nb = 0; nb < NB; ++nb)
+                kr_glds16(R + tok * (long)ld + col0 + nb * 64 + dc * 8, dst + (unsigned)(A_BYTES + (wave * NB + nb) * 1024));
+        }
+    };
+    // prologue: NS - 1 tiles in flight, then the resident operand
+#pragma unroll
+    for (int s = 0; s < NS - 1; ++s)
+        if (s < nt) issue(t_begin + s, s);
+    uint4 wf[NP][2][KS];
+#pragma unroll
+    for (int p = 0; p < NP; ++p)
+#pragma unroll
+        for (int e = 0; e < 2; ++e)
+#pragma unroll
+            for (int ks = 0; ks < KS; ++ks)
+                wf[p][e][ks] = kr_load16(Wp + ((long)((((int)blockIdx.y * 8 + wave) * NP + p) * 2 + e) * KS + ks) * 512 + lane * 8);
+    float bs[NP][8];
+#pragma unroll
+    for (int p = 0; p < NP; ++p)
+#pragma unroll
+        for (int e = 0; e < 8; ++e) bs[p][e] = bias ? bias[col0 + 32 * (wave * NP + p) + 8 * g + e] : 0.f;
+    kr_wait<0>();
+
+    // B-fragment of token tile tt, k-step ks: row group 2 tt + (n >> 3), block ks >> 1, row n & 7, slot (4 (ks & 1) + g) ^ (n & 7)
+    const unsigned rdA = (unsigned)((n >> 3) * KB * 1024 + (n & 7) * 128);
+    const unsigned sw0 = (unsigned)((g ^ (n & 7)) * 16), sw1 = (unsigned)(((4 + g) ^ (n & 7)) * 16);
+    // residual chunk of pair p: channels 32 (w NP + p) + 8 g .. + 7 -> block (w NP + p) >> 1, chunk 4 ((w NP + p) & 1) + g
+    unsigned rdR[NP];
+#pragma unroll
+    for (int p = 0; p < NP; ++p) {
+        const int q = wave * NP + p;
+        rdR[p] = (unsigned)(A_BYTES + ((n >> 3) * NB + (q >> 1)) * 1024 + (n & 7) * 128 + (((4 * (q & 1) + g) ^ (n & 7)) * 16));
+    }
+
+    for (int i = 0; i < nt; ++i) {
+        const int t = t_begin + i;
+        const int slot = i % NS;
+        __builtin_amdgcn_s_barrier();                         // tile i published by every wave; stage (i - 1) % NS no longer read
+        if (i + NS - 1 < nt) issue(t + NS - 1, (i + NS - 1) % NS);
+
+        kr_f32x4_t acc[NP][2][4];
+#pragma unroll
+        for (int p = 0; p < NP; ++p)
+#pragma unroll
+            for (int e = 0; e < 2; ++e)
+#pragma unroll
+                for (int tt = 0; tt < 4; ++tt) acc[p][e][tt] = kr_f32x4_t{0.f, 0.f, 0.f, 0.f};
+        const unsigned char* sb = kr_smem + slot * STAGE;
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) {
+            uint4 bf[4];
+#pragma unroll
+            for (int tt = 0; tt < 4; ++tt)
+                bf[tt] = *reinterpret_cast<const uint4*>(sb + rdA + ((ks & 1) ? sw1 : sw0) + tt * (2 * KB * 1024) + (ks >> 1) * 1024);
+#pragma unroll
+            for (int p = 0; p < NP; ++p)
+#pragma unroll
+                for (int e = 0; e < 2; ++e)
+#pragma unroll
+                    for (int tt = 0; tt < 4; ++tt) acc[p][e][tt] = kr_mma(wf[p][e][ks], bf[tt], acc[p][e][tt]);
+        }
+        // ---- epilogue: + bias + residual (one 16-byte LDS read), ReLU, one 16-byte store per token and pair ---------------------
+#pragma unroll
+        for (int tt = 0; tt < 4; ++tt) {
+            const long tok = (long)t * KR_TOK + tt * 16 + n;
+#pragma unroll
+            for (int p = 0; p < NP; ++p) {
+                float v[8];
+#pragma unroll
+                for (int e = 0; e < 8; ++e) v[e] = acc[p][e >> 2][tt][e & 3] + bs[p][e];
+                if constexpr (HAS_R) {
+                    const uint4 rr = *reinterpret_cast<const uint4*>(sb + rdR[p] + tt * (2 * NB * 1024));
+                    const uint32_t rw[4] = {rr.x, rr.y, rr.z, rr.w};
+#pragma unroll
+                    for (int e = 0; e < 8; ++e)
+                        v[e] += (e & 1) ? __uint_as_float(rw[e >> 1] & 0xffff0000u) : __uint_as_float(rw[e >> 1] << 16);
+                }
+                if (relu) {
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) v[e] = fmaxf(v[e], 0.f);
+                }
+                if (tok < M)
+                    *reinterpret_cast<uint4*>(C + tok * (long)ld + col0 + 32 * (wave * NP + p) + 8 * g) =
+                        make_uint4(pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3]), pack_bf16x2(v[4], v[5]), pack_bf16x2(v[6], v[7]));
+            }
+        }
+        // my pieces of tile i + 1 must have landed before the next barrier.  Issued since: the stores of tile i + 2 - NS, then a DMA group
+        // and a tile's stores in each of the NS - 2 iterations after it (a ragged tile -- fewer stores -- is always a workgroup's last)
+        if (i + NS - 1 < nt) kr_wait<E + (NS - 2) * (G + E)>();
+        else kr_wait<0>();
+    }
+}
+
+// W [N, K] row-major bf16 (host) -> fragment order (host, N * K elements): slice = 256 NP output channels
+// block ((((slice * 8 + wave) * NP + p) * 2 + e) * KS + ks) lane (m, g) <- W[256 NP slice + 32 (wave NP + p) + 8 (m >> 2) + 4 e + (m & 3)][32 ks + 8 g ..]
+extern "C" int dtlr_gemm_kres_pack_weights(const unsigned short* w_host, unsigned short* wp_host, int N, int K)
+{
+    if (!w_host || !wp_host) return DTLR_EINVAL;
+    if ((K != 64 && K != 128 && K != 256) || N <= 0 || (N & 255)) return DTLR_ESHAPE;
+    const int NP = (N % 512 == 0 && K <= 128) ? 2 : 1, KS = K / 32, nslice = N / (256 * NP);
+    for (int sl = 0; sl < nslice; ++sl)
+        for (int wave = 0; wave < 8; ++wave)
+            for (int p = 0; p < NP; ++p)
+                for (int e = 0; e < 2; ++e)
+                    for (int ks = 0; ks < KS; ++ks)
+                        for (int lane = 0; lane < 64; ++lane) {
+                            const int m = lane & 15, g = lane >> 4;
+                            const int row = 256 * NP * sl + 32 * (wave * NP + p) + 8 * (m >> 2) + 4 * e + (m & 3);
+                            const long blk = ((((long)sl * 8 + wave) * NP + p) * 2 + e) * KS + ks;
+                            for (int x = 0; x < 8; ++x) wp_host[(blk * 64 + lane) * 8 + x] = w_host[(long)row * K + ks * 32 + g * 8 + x];
+                        }
+    return DTLR_OK;
+}
+
+// A [M, K] bf16 (K = 64 / 128 / 256), Wp from dtlr_gemm_kres_pack_weights, bias [N] fp32 or null, R [M, N] bf16 or null (row stride N),
+// C [M, N] bf16, relu: 0 / 1 (applied after the residual).  N a multiple of 256.
+extern "C" int dtlr_gemm_kres(const void* A, const void* Wp, const float* bias, const void* R, void* C, int M, int N, int K, int relu, void* stream)
+{
+    clear_stale_error();
+    if (!A || !Wp || !C) return DTLR_EINVAL;
+    if (M <= 0) return DTLR_EINVAL;
+    if ((K != 64 && K != 128 && K != 256) || N <= 0 || (N & 255)) return DTLR_ESHAPE;
+    const int NP = (N % 512 == 0 && K <= 128) ? 2 : 1;
+    const int nslice = N / (256 * NP);
+    const int ntiles = (M + KR_TOK - 1) / KR_TOK;
+    const int ncu = 256;
+    // one workgroup per CU and column slice round (the ring takes most of the LDS); slices of one token range run on neighbouring
+    // workgroup ids so the A tile is fetched from HBM once
+    int per_x = (ntiles * nslice + ncu - 1) / ncu;
+    if (per_x < 1) per_x = 1;
+    const int gx = (ntiles + per_x - 1) / per_x;
+    hipStream_t st = (hipStream_t)stream;
+#define KR_LAUNCH(KB_, NP_, NS_, HR_)                                                              \
+    {                                                                                              \
+        constexpr int lds_ = NS_ * (KR_TOK * 64 * KB_ * 2 + (HR_ ? KR_TOK * 256 * NP_ * 2 : 0));   \
+        static DevOnce once;                                                                       \
+        if (once.first()) { (void)hipFuncSetAttribute((const void*)gemm_kres_kernel<KB_, NP_, NS_, HR_>, hipFuncAttributeMaxDynamicSharedMemorySize, lds_); (void)hipGetLastError(); } \
+        hipLaunchKernelGGL((gemm_kres_kernel<KB_, NP_, NS_, HR_>), dim3(gx, nslice), dim3(512), lds_, st, (const uint16_t*)A, (const uint16_t*)Wp, bias, \
+                           (const uint16_t*)R, (uint16_t*)C, N, M, per_x, relu);                    \
+    }
+    if (K == 64) {
+        if (NP == 2) { if (R) KR_LAUNCH(1, 2, 2, true) else KR_LAUNCH(1, 2, 4, false) }
+        else { if (R) KR_LAUNCH(1, 1, 4, true) else KR_LAUNCH(1, 1, 4, false) }
+    } else if (K == 128) {
+        if (NP == 2) { if (R) KR_LAUNCH(2, 2, 2, true) else KR_LAUNCH(2, 2, 4, false) }
+        else { if (R) KR_LAUNCH(2, 1, 3, true) else KR_LAUNCH(2, 1, 4, false) }
+    } else {
+        if (R) KR_LAUNCH(4, 1, 2, true) else KR_LAUNCH(4, 1, 4, false)
+    }
+#undef KR_LAUNCH
+    return check_launch();
+}
+
+}  // namespace dtlr

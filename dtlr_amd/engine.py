@@ -52,7 +52,8 @@ class DTLREngine:
         self.use_fused_ffn = True      # bf16: linear1+ReLU+linear2+residual+LayerNorm in one kernel (False: two GEMMs + LN)
         self.use_k256 = os.environ.get("DTLR_K256", "1") != "0"   # bf16: weight-resident streaming kernel for the K = 256 projections over all tokens
         self.use_pln_k256 = os.environ.get("DTLR_PLN_K256", "1") != "0"
-        self.use_ffn32 = os.environ.get("DTLR_FFN32", "1") != "0"   # ... and for the encoder's output projection + LayerNorm
+        self.use_ffn32 = os.environ.get("DTLR_FFN32", "1") != "0"
+        self.use_kres = os.environ.get("DTLR_KRES", "1") != "0"   # ... and for the encoder's output projection + LayerNorm
 
     # ------------------------------------------------------------------------------ packing
     def _put(self, name, t, dtype=None):
@@ -239,6 +240,11 @@ class DTLREngine:
         if w.dim() == 2:                              # 1x1: the MFMA GEMM with the whole tail fused
             if stride != 1:                           # strided 1x1 (downsample): the implicit-GEMM kernel gathers the pixels itself
                 return ops.conv2d_nhwc(x, w.view(w.shape[0], 1, 1, w.shape[1]), self.w[name + ".b"], stride, 0, relu, residual)
+            M = x.numel() // x.shape[-1]
+            if self.use_kres and ops.kres_supported(M, w.shape[0], w.shape[1], x.dtype) and (residual is not None or not relu):
+                if name + ".wk" not in self.w:                # weight-resident streaming form (bottleneck tail / layer1 downsample)
+                    self.w[name + ".wk"] = ops.kres_pack(w)
+                return ops.gemm_kres(x, self.w[name + ".wk"], w.shape[0], self.w[name + ".b"], residual, relu=bool(relu))
             return ops.linear(x, w, self.w[name + ".b"], relu=(2 if relu else 0), residual=residual)
         return ops.conv2d_nhwc(x, w, self.w[name + ".b"], stride, padding, relu, residual)
 

@@ -158,6 +158,46 @@ def gemm_k256(x, wp, n_out: int, b=None, resid=None, row_mask=None, out=None):
     return out
 
 
+def kres_supported(M: int, N: int, K: int, dtype) -> bool:
+    """Shapes dtlr_gemm_kres takes (the HBM-streaming 1x1 convolutions of the ResNet bottlenecks)."""
+    return dtype == torch.bfloat16 and K in (64, 128, 256) and N % 256 == 0 and N >= 256 and M >= 16384
+
+
+def kres_pack(w):
+    """[N, K] weight -> the fragment-order image of dtlr_gemm_kres (== dtlr_gemm_kres_pack_weights): column slices of 256 NP channels,
+    block ((((slice 8 + wave) NP + p) 2 + e) KS + ks) lane (m, g) <- W[256 NP slice + 32 (wave NP + p) + 8 (m >> 2) + 4 e + (m & 3)][32 ks + 8 g ..]."""
+    N, K = w.shape
+    assert K in (64, 128, 256) and N % 256 == 0
+    NP = 2 if (N % 512 == 0 and K <= 128) else 1
+    ns, KS = N // (256 * NP), K // 32
+    # row index = 256 NP sl + 32 (wave NP + p) + 8 mh + 4 e + ml  with m = 4 mh + ml ; column = 32 ks + 8 g + x
+    v = w.detach().to(torch.bfloat16).view(ns, 8, NP, 4, 2, 4, KS, 4, 8)          # sl, wave, p, mh, e, ml, ks, g, x
+    return v.permute(0, 1, 2, 4, 6, 7, 3, 5, 8).contiguous().view(-1)             # sl, wave, p, e, ks, [g, mh, ml] = lane, x
+
+
+def gemm_kres(x, wp, n_out: int, b=None, residual=None, relu: bool = False):
+    """relu?(x @ W.T + b + residual) with the weight resident in registers and the rows of x / residual streamed through LDS
+    (dtlr_gemm_kres); wp = kres_pack(W).  x [..., K] bf16, residual [..., n_out] bf16 or None."""
+    require_cuda(x, "x")
+    K = x.shape[-1]
+    assert x.dtype == torch.bfloat16 and wp.dtype == torch.bfloat16 and wp.numel() == n_out * K
+    x = x if x.is_contiguous() else x.contiguous()
+    M = x.numel() // K
+    if residual is not None:
+        assert residual.dtype == torch.bfloat16 and residual.shape[-1] == n_out and residual.numel() == M * n_out
+        residual = residual if residual.is_contiguous() else residual.contiguous()
+    if b is not None and b.dtype != torch.float32:
+        b = b.float()
+    out = torch.empty(x.shape[:-1] + (n_out,), dtype=torch.bfloat16, device=x.device)
+    nbytes = float(M) * K * 2 + float(n_out) * K * 2 + float(M) * n_out * 2 * (2 if residual is not None else 1)
+    with _Timed("gemm_bf16", 2.0 * M * n_out * K, nbytes, f"kres M{M} N{n_out} K{K}" + ("+res" if residual is not None else "")):
+        code = _lib.lib().dtlr_gemm_kres(x.data_ptr(), wp.data_ptr(), 0 if b is None else b.data_ptr(),
+                                         0 if residual is None else residual.data_ptr(), out.data_ptr(), M, n_out, K, 1 if relu else 0,
+                                         _lib.current_stream())
+    _lib.check(code, "dtlr_gemm_kres")
+    return out
+
+
 def linear_rowmax(x, w, b=None):
     """max over the output channels of (x @ w.T + b), without materialising the product (dtlr_gemm_nt_rowmax: the GEMM's
     row-max epilogue): x [..., K], w [N, K] (same dtype, bf16 or fp32), b [N] fp32 -> [...] fp32.  The two-stage selection
@@ -829,7 +869,7 @@ def _device_scoped(fn):
     return wrapper
 
 
-for _name in ("ffn32", "proj_ln_k256", "swin_patch_embed", "swin_window_attn", "swin_patch_merge", "geometry", "linear", "gemm_k256", "linear_rowmax", "two_stage_gather", "layernorm", "proj_ln", "proj_ln_split", "ffn_fused", "conv2d_nhwc", "stem_conv7x7", "stem_conv7x7_f32",
+for _name in ("gemm_kres", "ffn32", "proj_ln_k256", "swin_patch_embed", "swin_window_attn", "swin_patch_merge", "geometry", "linear", "gemm_k256", "linear_rowmax", "two_stage_gather", "layernorm", "proj_ln", "proj_ln_split", "ffn_fused", "conv2d_nhwc", "stem_conv7x7", "stem_conv7x7_f32",
               "maxpool_nhwc", "groupnorm_tokens", "msda", "msda_fused", "msda_encoder", "mha", "decoder_query_prep", "box_mlp_refine",
               "box_head_refine", "box_refine", "topk_rows", "decode_blank", "preprocess_lines", "ctc_loss_interleaved", "nms_batched",
               "topk_flat"):

@@ -123,6 +123,18 @@ int dtlr_ffn_fused_bf16(const void *X, const void *W1, const float *b1, const vo
                         int M, int d_model, int d_ff, void *stream);
 
 /* ---------------------------------------------------------------------------------------------
+ * Weight-resident streaming GEMM with a streamed residual, bf16:   C = relu?( A W^T + b + R )
+ * Replaces: the last 1x1 convolution of a torchvision ResNet bottleneck with its folded FrozenBN, the identity add and the ReLU
+ *           (`out = relu(bn3(conv3(out)) + identity)`; models/dino/backbone.py:62-72,97-106 wrapping torchvision resnet50) and the
+ *           stride-1 1x1 `downsample` convolution of layer1 -- the HBM-streaming shapes K = 64 / 128 / 256, N = 256 / 512 / 1024.
+ *   dtlr_gemm_kres_pack_weights: HOST-side packer: W [N, K] bf16 row-major -> fragment order (N * K elements), N a multiple of 256.
+ *   dtlr_gemm_kres: A [M, K] bf16 ; Wp = device copy of the packed weight ; bias [N] fp32 or NULL ; R [M, N] bf16 or NULL ;
+ *                   C [M, N] bf16 ; relu != 0 applies ReLU after the residual add.
+ */
+int dtlr_gemm_kres_pack_weights(const unsigned short *w_host, unsigned short *wp_host, int N, int K);
+int dtlr_gemm_kres(const void *A, const void *Wp, const float *bias, const void *R, void *C, int M, int N, int K, int relu, void *stream);
+
+/* ---------------------------------------------------------------------------------------------
  * The same fused feed-forward block for MANY rows (the encoder call, M = batch x 5440 tokens), built on the 32x32x16 MFMA with
  * both weights pre-packed in fragment order:
  *     Y = LayerNorm( X + relu(X W1^T + b1) W2^T + b2 )            X, Y [M, 256] bf16
