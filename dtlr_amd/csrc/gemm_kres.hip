@@ -46,15 +46,21 @@ template <int N> __device__ __forceinline__ void kr_wait() {
 
 // KB = K / 64 (128-byte k blocks per token row), NP = row-tile pairs per wave (output columns per launch column = 256 NP), NS = stages.
 // Wp: fragment order, block (((slice * 8 + wave) * NP + p) * 2 + e) * KS + ks (KS = 2 KB k-steps of 32) = 64 lanes x 8 elements.
-template <int KB, int NP, int NS, bool HAS_R>
+// NBR = 128-byte blocks of a residual row that exist (0 = no residual; 4 NP = the full launch column; 6 with NP = 2 = a 384-channel
+// output computed as a zero-padded 512-channel column: the pairs beyond n_valid are skipped).  res_rows > 0: the residual is ONE
+// [res_rows, n_valid] matrix shared by the n_img = M / res_rows images (row m pairs with row m % res_rows; the encoder's pos . W^T
+// term), and tiles are walked position-major (tile t = position tile t / n_img of image t % n_img) so a workgroup, and the band of
+// tiles an XCD owns, re-read a few residual tiles out of L2.
+template <int KB, int NP, int NS, int NBR>
 __global__ __launch_bounds__(512, 2) void gemm_kres_kernel(
     const uint16_t* __restrict__ A, const uint16_t* __restrict__ Wp, const float* __restrict__ bias, const uint16_t* __restrict__ R,
-    uint16_t* __restrict__ C, int ld, int M, int tiles_per_wg, int relu)
+    uint16_t* __restrict__ C, int ld, int M, int tiles_per_wg, int relu, int n_valid, int res_rows, int n_img)
 {
+    constexpr bool HAS_R = NBR > 0;
     extern __shared__ __attribute__((aligned(16))) unsigned char kr_smem[];
     const unsigned lds_base = (unsigned)(size_t)(__attribute__((address_space(3))) unsigned char*)kr_smem;
-    constexpr int K = 64 * KB, KS = 2 * KB, NC = 256 * NP, NB = 4 * NP;          // NB = 128-byte blocks per residual row
-    constexpr int A_BYTES = KR_TOK * K * 2, STAGE = A_BYTES + (HAS_R ? KR_TOK * NC * 2 : 0);
+    constexpr int K = 64 * KB, KS = 2 * KB, NC = 256 * NP, NB = NBR;               // NB = 128-byte blocks per residual row
+    constexpr int A_BYTES = KR_TOK * K * 2, STAGE = A_BYTES + KR_TOK * NB * 128;
     constexpr int G = KB + (HAS_R ? NB : 0);                                       // DMA instructions per wave per tile
     constexpr int E = 4 * NP;                                                      // stores per wave per tile
     const int lane = threadIdx.x & 63;
@@ -62,22 +68,30 @@ __global__ __launch_bounds__(512, 2) void gemm_kres_kernel(
     const int n = lane & 15, g = lane >> 4;
     const int col0 = (int)blockIdx.y * NC;                                         // this launch column's first output channel
     const int ntiles = (M + KR_TOK - 1) / KR_TOK;
-    const int t_begin = (int)blockIdx.x * tiles_per_wg;
+    // workgroup b runs on XCD b % 8; logical ids are contiguous inside an XCD
+    const int nwg = (int)gridDim.x, q8 = nwg >> 3, r8 = nwg & 7, xcd = (int)blockIdx.x & 7;
+    const int logical = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + ((int)blockIdx.x >> 3);
+    const int t_begin = logical * tiles_per_wg;
     const int t_end = min(t_begin + tiles_per_wg, ntiles);
     if (t_begin >= t_end) return;
     const int nt = t_end - t_begin;
+    auto row0 = [&](int t) -> long {
+        if (n_img > 0) { const int pt = t / n_img; return (long)(t - pt * n_img) * res_rows + (long)pt * KR_TOK; }
+        return (long)t * KR_TOK;
+    };
 
     // DMA of tile t into a stage: wave w moves row group w (token rows 8 w .. 8 w + 7): its KB blocks of A and NB blocks of R
     const int dr = lane >> 3, dc = (lane & 7) ^ dr;
     auto issue = [&](int t, int slot) {
-        const long tok = min((long)t * KR_TOK + wave * 8 + dr, (long)M - 1);
+        const long tok = min(row0(t) + wave * 8 + dr, (long)M - 1);
         const unsigned dst = lds_base + (unsigned)(slot * STAGE);
 #pragma unroll
         for (int kb = 0; kb < KB; ++kb) kr_glds16(A + tok * K + kb * 64 + dc * 8, dst + (unsigned)((wave * KB + kb) * 1024));
         if constexpr (HAS_R) {
+            const long rrow = n_img > 0 ? (long)(t / n_img) * KR_TOK + wave * 8 + dr : tok;
 #pragma unroll
             for (int nb = 0; nb < NB; ++nb)
-                kr_glds16(R + tok * (long)ld + col0 + nb * 64 + dc * 8, dst + (unsigned)(A_BYTES + (wave * NB + nb) * 1024));
+                kr_glds16(R + rrow * (long)(n_img > 0 ? n_valid : ld) + col0 + nb * 64 + dc * 8, dst + (unsigned)(A_BYTES + (wave * NB + nb) * 1024));
         }
     };
     // prologue: NS - 1 tiles in flight, then the resident operand
@@ -96,7 +110,7 @@ __global__ __launch_bounds__(512, 2) void gemm_kres_kernel(
 #pragma unroll
     for (int p = 0; p < NP; ++p)
 #pragma unroll
-        for (int e = 0; e < 8; ++e) bs[p][e] = bias ? bias[col0 + 32 * (wave * NP + p) + 8 * g + e] : 0.f;
+        for (int e = 0; e < 8; ++e) bs[p][e] = (bias && col0 + 32 * (wave * NP + p) < n_valid) ? bias[col0 + 32 * (wave * NP + p) + 8 * g + e] : 0.f;
     kr_wait<0>();
 
     // B-fragment of token tile tt, k-step ks: row group 2 tt + (n >> 3), block ks >> 1, row n & 7, slot (4 (ks & 1) + g) ^ (n & 7)
@@ -124,6 +138,7 @@ __global__ __launch_bounds__(512, 2) void gemm_kres_kernel(
 #pragma unroll
                 for (int tt = 0; tt < 4; ++tt) acc[p][e][tt] = kr_f32x4_t{0.f, 0.f, 0.f, 0.f};
         const unsigned char* sb = kr_smem + slot * STAGE;
+        const long trow = row0(t);
 #pragma unroll
         for (int ks = 0; ks < KS; ++ks) {
             uint4 bf[4];
@@ -131,18 +146,21 @@ __global__ __launch_bounds__(512, 2) void gemm_kres_kernel(
             for (int tt = 0; tt < 4; ++tt)
                 bf[tt] = *reinterpret_cast<const uint4*>(sb + rdA + ((ks & 1) ? sw1 : sw0) + tt * (2 * KB * 1024) + (ks >> 1) * 1024);
 #pragma unroll
-            for (int p = 0; p < NP; ++p)
+            for (int p = 0; p < NP; ++p) {
+                if (NBR != 4 * NP && HAS_R && col0 + 32 * (wave * NP + p) >= n_valid) continue;         // zero-padded column: nothing to compute
 #pragma unroll
                 for (int e = 0; e < 2; ++e)
 #pragma unroll
                     for (int tt = 0; tt < 4; ++tt) acc[p][e][tt] = kr_mma(wf[p][e][ks], bf[tt], acc[p][e][tt]);
+            }
         }
         // ---- epilogue: + bias + residual (one 16-byte LDS read), ReLU, one 16-byte store per token and pair ---------------------
 #pragma unroll
         for (int tt = 0; tt < 4; ++tt) {
-            const long tok = (long)t * KR_TOK + tt * 16 + n;
+            const long tok = trow + tt * 16 + n;
 #pragma unroll
             for (int p = 0; p < NP; ++p) {
+                if (col0 + 32 * (wave * NP + p) >= n_valid) continue;
                 float v[8];
 #pragma unroll
                 for (int e = 0; e < 8; ++e) v[e] = acc[p][e >> 2][tt][e & 3] + bs[p][e];
@@ -164,18 +182,20 @@ __global__ __launch_bounds__(512, 2) void gemm_kres_kernel(
         }
         // my pieces of tile i + 1 must have landed before the next barrier.  Issued since: the stores of tile i + 2 - NS, then a DMA group
         // and a tile's stores in each of the NS - 2 iterations after it (a ragged tile -- fewer stores -- is always a workgroup's last)
-        if (i + NS - 1 < nt) kr_wait<E + (NS - 2) * (G + E)>();
-        else kr_wait<0>();
+        // (zero-padded column, NBR != 4 NP: some waves issue fewer stores than E -- only NS = 2 is used there and the count below then
+        // names this tile's stores alone, so such a wave waits with vmcnt(0): stricter, never wrong)
+        if (i + NS - 1 < nt) {
+            if (NBR != 4 * NP && HAS_R && col0 + 32 * (wave * NP + NP) > n_valid) kr_wait<0>();
+            else kr_wait<E + (NS - 2) * (G + E)>();
+        } else kr_wait<0>();
     }
 }
 
 // W [N, K] row-major bf16 (host) -> fragment order (host, N * K elements): slice = 256 NP output channels
 // block ((((slice * 8 + wave) * NP + p) * 2 + e) * KS + ks) lane (m, g) <- W[256 NP slice + 32 (wave NP + p) + 8 (m >> 2) + 4 e + (m & 3)][32 ks + 8 g ..]
-extern "C" int dtlr_gemm_kres_pack_weights(const unsigned short* w_host, unsigned short* wp_host, int N, int K)
+static int kres_pack(const unsigned short* w_host, unsigned short* wp_host, int N, int K, int NP, int n_rows)
 {
-    if (!w_host || !wp_host) return DTLR_EINVAL;
-    if ((K != 64 && K != 128 && K != 256) || N <= 0 || (N & 255)) return DTLR_ESHAPE;
-    const int NP = (N % 512 == 0 && K <= 128) ? 2 : 1, KS = K / 32, nslice = N / (256 * NP);
+    const int KS = K / 32, nslice = N / (256 * NP);
     for (int sl = 0; sl < nslice; ++sl)
         for (int wave = 0; wave < 8; ++wave)
             for (int p = 0; p < NP; ++p)
@@ -185,9 +205,61 @@ extern "C" int dtlr_gemm_kres_pack_weights(const unsigned short* w_host, unsigne
                             const int m = lane & 15, g = lane >> 4;
                             const int row = 256 * NP * sl + 32 * (wave * NP + p) + 8 * (m >> 2) + 4 * e + (m & 3);
                             const long blk = ((((long)sl * 8 + wave) * NP + p) * 2 + e) * KS + ks;
-                            for (int x = 0; x < 8; ++x) wp_host[(blk * 64 + lane) * 8 + x] = w_host[(long)row * K + ks * 32 + g * 8 + x];
+                            for (int x = 0; x < 8; ++x)
+                                wp_host[(blk * 64 + lane) * 8 + x] = row < n_rows ? w_host[(long)row * K + ks * 32 + g * 8 + x] : (unsigned short)0;
                         }
     return DTLR_OK;
+}
+
+extern "C" int dtlr_gemm_kres_pack_weights(const unsigned short* w_host, unsigned short* wp_host, int N, int K)
+{
+    if (!w_host || !wp_host) return DTLR_EINVAL;
+    if ((K != 64 && K != 128 && K != 256) || N <= 0 || (N & 255)) return DTLR_ESHAPE;
+    return kres_pack(w_host, wp_host, N, K, (N % 512 == 0 && K <= 128) ? 2 : 1, N);
+}
+
+// W [384, 256] (host) -> the image dtlr_gemm_kres_bcast384 takes: a 512-channel column (two row-tile pairs per wave), rows 384..511 zero;
+// wp_host holds 512 * 256 elements.
+extern "C" int dtlr_gemm_kres_pack_weights_bcast384(const unsigned short* w_host, unsigned short* wp_host)
+{
+    if (!w_host || !wp_host) return DTLR_EINVAL;
+    return kres_pack(w_host, wp_host, 512, 256, 2, 384);
+}
+
+static int kres_launch(const void* A, const void* Wp, const float* bias, const void* R, void* C, int M, int N, int K, int relu,
+                       int n_valid, int res_rows, hipStream_t st)
+{
+    const int NP = (N % 512 == 0 && K <= 128) || res_rows > 0 ? 2 : 1;
+    const int nslice = N / (256 * NP);
+    const int ntiles = (M + KR_TOK - 1) / KR_TOK;
+    const int ncu = 256;
+    // one workgroup per CU (the ring takes most of the LDS); the column slices of one token range get workgroup ids a multiple of 8
+    // apart (grid.x a multiple of 8 at the shapes of the path): same XCD, so the A tile is fetched from HBM once
+    int per_x = (ntiles * nslice + ncu - 1) / ncu;
+    if (per_x < 1) per_x = 1;
+    const int gx = (ntiles + per_x - 1) / per_x;
+    const int n_img = res_rows > 0 ? M / res_rows : 0;
+    const int ld = res_rows > 0 ? n_valid : N;
+#define KR_LAUNCH(KB_, NP_, NS_, NBR_)                                                             \
+    {                                                                                              \
+        constexpr int lds_ = NS_ * (KR_TOK * 64 * KB_ * 2 + KR_TOK * NBR_ * 128);                  \
+        static DevOnce once;                                                                       \
+        if (once.first()) { (void)hipFuncSetAttribute((const void*)gemm_kres_kernel<KB_, NP_, NS_, NBR_>, hipFuncAttributeMaxDynamicSharedMemorySize, lds_); (void)hipGetLastError(); } \
+        hipLaunchKernelGGL((gemm_kres_kernel<KB_, NP_, NS_, NBR_>), dim3(gx, nslice), dim3(512), lds_, st, (const uint16_t*)A, (const uint16_t*)Wp, bias, \
+                           (const uint16_t*)R, (uint16_t*)C, ld, M, per_x, relu, n_valid, res_rows, n_img); \
+    }
+    if (res_rows > 0) KR_LAUNCH(4, 2, 2, 6)                                 // K = 256, 384 channels as a zero-padded 512 column
+    else if (K == 64) {
+        if (NP == 2) { if (R) KR_LAUNCH(1, 2, 2, 8) else KR_LAUNCH(1, 2, 4, 0) }
+        else { if (R) KR_LAUNCH(1, 1, 4, 4) else KR_LAUNCH(1, 1, 4, 0) }
+    } else if (K == 128) {
+        if (NP == 2) { if (R) KR_LAUNCH(2, 2, 2, 8) else KR_LAUNCH(2, 2, 4, 0) }
+        else { if (R) KR_LAUNCH(2, 1, 3, 4) else KR_LAUNCH(2, 1, 4, 0) }
+    } else {
+        if (R) KR_LAUNCH(4, 1, 2, 4) else KR_LAUNCH(4, 1, 4, 0)
+    }
+#undef KR_LAUNCH
+    return check_launch();
 }
 
 // A [M, K] bf16 (K = 64 / 128 / 256), Wp from dtlr_gemm_kres_pack_weights, bias [N] fp32 or null, R [M, N] bf16 or null (row stride N),
@@ -198,35 +270,21 @@ extern "C" int dtlr_gemm_kres(const void* A, const void* Wp, const float* bias, 
     if (!A || !Wp || !C) return DTLR_EINVAL;
     if (M <= 0) return DTLR_EINVAL;
     if ((K != 64 && K != 128 && K != 256) || N <= 0 || (N & 255)) return DTLR_ESHAPE;
-    const int NP = (N % 512 == 0 && K <= 128) ? 2 : 1;
-    const int nslice = N / (256 * NP);
-    const int ntiles = (M + KR_TOK - 1) / KR_TOK;
-    const int ncu = 256;
-    // one workgroup per CU and column slice round (the ring takes most of the LDS); slices of one token range run on neighbouring
-    // workgroup ids so the A tile is fetched from HBM once
-    int per_x = (ntiles * nslice + ncu - 1) / ncu;
-    if (per_x < 1) per_x = 1;
-    const int gx = (ntiles + per_x - 1) / per_x;
-    hipStream_t st = (hipStream_t)stream;
-#define KR_LAUNCH(KB_, NP_, NS_, HR_)                                                              \
-    {                                                                                              \
-        constexpr int lds_ = NS_ * (KR_TOK * 64 * KB_ * 2 + (HR_ ? KR_TOK * 256 * NP_ * 2 : 0));   \
-        static DevOnce once;                                                                       \
-        if (once.first()) { (void)hipFuncSetAttribute((const void*)gemm_kres_kernel<KB_, NP_, NS_, HR_>, hipFuncAttributeMaxDynamicSharedMemorySize, lds_); (void)hipGetLastError(); } \
-        hipLaunchKernelGGL((gemm_kres_kernel<KB_, NP_, NS_, HR_>), dim3(gx, nslice), dim3(512), lds_, st, (const uint16_t*)A, (const uint16_t*)Wp, bias, \
-                           (const uint16_t*)R, (uint16_t*)C, N, M, per_x, relu);                    \
-    }
-    if (K == 64) {
-        if (NP == 2) { if (R) KR_LAUNCH(1, 2, 2, true) else KR_LAUNCH(1, 2, 4, false) }
-        else { if (R) KR_LAUNCH(1, 1, 4, true) else KR_LAUNCH(1, 1, 4, false) }
-    } else if (K == 128) {
-        if (NP == 2) { if (R) KR_LAUNCH(2, 2, 2, true) else KR_LAUNCH(2, 2, 4, false) }
-        else { if (R) KR_LAUNCH(2, 1, 3, true) else KR_LAUNCH(2, 1, 4, false) }
-    } else {
-        if (R) KR_LAUNCH(4, 1, 2, true) else KR_LAUNCH(4, 1, 4, false)
-    }
-#undef KR_LAUNCH
-    return check_launch();
+    return kres_launch(A, Wp, bias, R, C, M, N, K, relu, N, 0, (hipStream_t)stream);
+}
+
+// The encoder's [offsets | attention logits] projection with the position term as a row-broadcast residual:
+//     C[m, :] = A[m, :] W^T + R[m % res_rows, :]        A [M, 256], W [384, 256], R [res_rows, 384], C [M, 384], all bf16
+// (ops/modules/ms_deform_attn.py:97-98 applied to query = src + pos: (src + pos) W^T + b = src W^T + (pos W^T + b); the second term is
+// the same for every image of an unpadded batch).  Wp = dtlr_gemm_kres_pack_weights of W zero-padded to 512 rows (N = 512, K = 256).
+// res_rows a multiple of 64 and M a multiple of res_rows (DTLR_ESHAPE otherwise: use dtlr_gemm_k256).
+extern "C" int dtlr_gemm_kres_bcast384(const void* A, const void* Wp, const void* R, int res_rows, void* C, int M, void* stream)
+{
+    clear_stale_error();
+    if (!A || !Wp || !R || !C) return DTLR_EINVAL;
+    if (M <= 0 || res_rows <= 0) return DTLR_EINVAL;
+    if ((res_rows % KR_TOK) || (M % res_rows) || (long)res_rows * 384 * 2 >= (1L << 31)) return DTLR_ESHAPE;
+    return kres_launch(A, Wp, nullptr, R, C, M, 512, 256, 0, 384, res_rows, (hipStream_t)stream);
 }
 
 }  // namespace dtlr

@@ -53,7 +53,8 @@ class DTLREngine:
         self.use_k256 = os.environ.get("DTLR_K256", "1") != "0"   # bf16: weight-resident streaming kernel for the K = 256 projections over all tokens
         self.use_pln_k256 = os.environ.get("DTLR_PLN_K256", "1") != "0"
         self.use_ffn32 = os.environ.get("DTLR_FFN32", "1") != "0"
-        self.use_kres = os.environ.get("DTLR_KRES", "1") != "0"   # ... and for the encoder's output projection + LayerNorm
+        self.use_kres = os.environ.get("DTLR_KRES", "1") != "0"
+        self.use_k256_small = self.use_k256 and os.environ.get("DTLR_K256_SMALL", "1") != "0"   # ... and for the encoder's output projection + LayerNorm
 
     # ------------------------------------------------------------------------------ packing
     def _put(self, name, t, dtype=None):
@@ -249,7 +250,11 @@ class DTLREngine:
         return ops.conv2d_nhwc(x, w, self.w[name + ".b"], stride, padding, relu, residual)
 
     def _lin(self, name, x, relu=False, residual=None, a2=None, row_mask=None, out_dtype=None):
-        return ops.linear(x, self.w[name + ".w"], self.w[name + ".b"], relu, residual, a2, row_mask, out_dtype)
+        w = self.w[name + ".w"]
+        if self.use_k256_small and x.dtype == torch.bfloat16 and not relu and residual is None and a2 is None and out_dtype in (None, torch.bfloat16) \
+                and w.shape[1] == 256 and w.shape[0] in (256, 384) and x.numel() // 256 >= 16384 and x.is_contiguous():
+            return ops.gemm_k256(x, self._k256w(name), w.shape[0], self.w[name + ".b"], row_mask=row_mask)     # plain K = 256 projections
+        return ops.linear(x, w, self.w[name + ".b"], relu, residual, a2, row_mask, out_dtype)
 
     def _ln(self, name, x, residual=None):
         return ops.layernorm(x, self.w[name + ".w"], self.w[name + ".b"], 1e-5, residual)
@@ -376,7 +381,13 @@ class DTLREngine:
         if k256 and ow_res is not None:
             # unpadded batch: (src + pos) W^T + b = src W^T + (pos W^T + b), and the second term is ONE [S, 384] matrix for every
             # image (L2-resident): the projection streams src alone and adds the row-broadcast term in its epilogue
-            ow = ops.gemm_k256(query, self._k256w(name + ".ow"), 384, None, resid=ow_res)
+            rows = ow_res.numel() // 384
+            if self.use_kres and rows % 64 == 0 and (query.numel() // 256) % rows == 0 and self.w[name + ".ow.w"].shape[0] == 384:
+                if name + ".ow.kb" not in self.w:               # residual tile DMA'd through LDS with the token tile (dtlr_gemm_kres_bcast384)
+                    self.w[name + ".ow.kb"] = ops.kres_pack_bcast384(self.w[name + ".ow.w"])
+                ow = ops.gemm_kres_bcast384(query, self.w[name + ".ow.kb"], ow_res)
+            else:
+                ow = ops.gemm_k256(query, self._k256w(name + ".ow"), 384, None, resid=ow_res)
         else:
             ow = self._lin(name + ".ow", query, a2=query_pos)
         if L == 4 and P == 4:

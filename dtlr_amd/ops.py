@@ -163,12 +163,12 @@ def kres_supported(M: int, N: int, K: int, dtype) -> bool:
     return dtype == torch.bfloat16 and K in (64, 128, 256) and N % 256 == 0 and N >= 256 and M >= 16384
 
 
-def kres_pack(w):
+def kres_pack(w, np_pairs=None):
     """[N, K] weight -> the fragment-order image of dtlr_gemm_kres (== dtlr_gemm_kres_pack_weights): column slices of 256 NP channels,
     block ((((slice 8 + wave) NP + p) 2 + e) KS + ks) lane (m, g) <- W[256 NP slice + 32 (wave NP + p) + 8 (m >> 2) + 4 e + (m & 3)][32 ks + 8 g ..]."""
     N, K = w.shape
     assert K in (64, 128, 256) and N % 256 == 0
-    NP = 2 if (N % 512 == 0 and K <= 128) else 1
+    NP = np_pairs or (2 if (N % 512 == 0 and K <= 128) else 1)
     ns, KS = N // (256 * NP), K // 32
     # row index = 256 NP sl + 32 (wave NP + p) + 8 mh + 4 e + ml  with m = 4 mh + ml ; column = 32 ks + 8 g + x
     v = w.detach().to(torch.bfloat16).view(ns, 8, NP, 4, 2, 4, KS, 4, 8)          # sl, wave, p, mh, e, ml, ks, g, x
@@ -195,6 +195,30 @@ def gemm_kres(x, wp, n_out: int, b=None, residual=None, relu: bool = False):
                                          0 if residual is None else residual.data_ptr(), out.data_ptr(), M, n_out, K, 1 if relu else 0,
                                          _lib.current_stream())
     _lib.check(code, "dtlr_gemm_kres")
+    return out
+
+
+def kres_pack_bcast384(w):
+    """[384, 256] weight -> the zero-padded 512-channel image of dtlr_gemm_kres_bcast384 (== dtlr_gemm_kres_pack_weights_bcast384)."""
+    assert tuple(w.shape) == (384, 256)
+    wpad = torch.cat([w.detach().to(torch.bfloat16), torch.zeros((128, 256), dtype=torch.bfloat16, device=w.device)])
+    return kres_pack(wpad, np_pairs=2)
+
+
+def gemm_kres_bcast384(x, wp, resid):
+    """x @ W.T + resid[m % rows] for W [384, 256]: the weight-resident streaming kernel with the row-broadcast residual DMA'd through LDS
+    (dtlr_gemm_kres_bcast384); wp = kres_pack_bcast384(W); resid [rows, 384] bf16, rows % 64 == 0, M % rows == 0."""
+    require_cuda(x, "x")
+    assert x.dtype == torch.bfloat16 and x.shape[-1] == 256 and wp.numel() == 512 * 256 and resid.dtype == torch.bfloat16
+    assert resid.is_contiguous() and resid.shape[-1] == 384
+    x = x if x.is_contiguous() else x.contiguous()
+    M = x.numel() // 256
+    rows = resid.numel() // 384
+    out = torch.empty(x.shape[:-1] + (384,), dtype=torch.bfloat16, device=x.device)
+    nbytes = float(M) * 256 * 2 + 384.0 * 256 * 2 + float(M) * 384 * 2
+    with _Timed("gemm_bf16", 2.0 * M * 384 * 256, nbytes, f"kres M{M} N384 K256+resb"):
+        code = _lib.lib().dtlr_gemm_kres_bcast384(x.data_ptr(), wp.data_ptr(), resid.data_ptr(), rows, out.data_ptr(), M, _lib.current_stream())
+    _lib.check(code, "dtlr_gemm_kres_bcast384")
     return out
 
 
@@ -869,7 +893,7 @@ def _device_scoped(fn):
     return wrapper
 
 
-for _name in ("gemm_kres", "ffn32", "proj_ln_k256", "swin_patch_embed", "swin_window_attn", "swin_patch_merge", "geometry", "linear", "gemm_k256", "linear_rowmax", "two_stage_gather", "layernorm", "proj_ln", "proj_ln_split", "ffn_fused", "conv2d_nhwc", "stem_conv7x7", "stem_conv7x7_f32",
+for _name in ("gemm_kres", "gemm_kres_bcast384", "ffn32", "proj_ln_k256", "swin_patch_embed", "swin_window_attn", "swin_patch_merge", "geometry", "linear", "gemm_k256", "linear_rowmax", "two_stage_gather", "layernorm", "proj_ln", "proj_ln_split", "ffn_fused", "conv2d_nhwc", "stem_conv7x7", "stem_conv7x7_f32",
               "maxpool_nhwc", "groupnorm_tokens", "msda", "msda_fused", "msda_encoder", "mha", "decoder_query_prep", "box_mlp_refine",
               "box_head_refine", "box_refine", "topk_rows", "decode_blank", "preprocess_lines", "ctc_loss_interleaved", "nms_batched",
               "topk_flat"):

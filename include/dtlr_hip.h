@@ -133,6 +133,13 @@ int dtlr_ffn_fused_bf16(const void *X, const void *W1, const float *b1, const vo
  */
 int dtlr_gemm_kres_pack_weights(const unsigned short *w_host, unsigned short *wp_host, int N, int K);
 int dtlr_gemm_kres(const void *A, const void *Wp, const float *bias, const void *R, void *C, int M, int N, int K, int relu, void *stream);
+/* The encoder's [sampling offsets | attention logits] projection (ops/modules/ms_deform_attn.py:97-98 on query = src + pos) for an
+ * unpadded batch: (src + pos) W^T + b = src W^T + (pos W^T + b), the second term ONE [res_rows, 384] bf16 matrix shared by all images:
+ *     C[m, :] = A[m, :] W^T + R[m % res_rows, :]        A [M, 256], C [M, 384] bf16
+ *   Wp = device copy of dtlr_gemm_kres_pack_weights_bcast384(W [384, 256]) (512 x 256 elements).  res_rows a multiple of 64 and M a
+ *   multiple of res_rows (DTLR_ESHAPE otherwise; dtlr_gemm_k256 takes any shape). */
+int dtlr_gemm_kres_pack_weights_bcast384(const unsigned short *w_host, unsigned short *wp_host);
+int dtlr_gemm_kres_bcast384(const void *A, const void *Wp, const void *R, int res_rows, void *C, int M, void *stream);
 
 /* ---------------------------------------------------------------------------------------------
  * The same fused feed-forward block for MANY rows (the encoder call, M = batch x 5440 tokens), built on the 32x32x16 MFMA with

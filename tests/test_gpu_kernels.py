@@ -967,3 +967,23 @@ def test_gemm_kres_vs_tiled_kernel(M, N, K, res):
     outp = np.empty(N * K, dtype=np.uint16)
     assert _lib.lib().dtlr_gemm_kres_pack_weights(src.ctypes.data, outp.ctypes.data, N, K) == 0
     assert np.array_equal(outp, wp.cpu().view(torch.int16).numpy().view(np.uint16))
+
+
+@pytest.mark.parametrize("B,S", [(32, 5440), (3, 640), (1, 64)])
+def test_gemm_kres_bcast384_vs_k256_kernel(B, S):
+    """The [offsets | logits] projection with the row-broadcast residual DMA'd through LDS (zero-padded 512-channel column, position-major
+    tiles) against the fp32 reference and the streaming K = 256 kernel; host packer == tensor-op packer."""
+    from dtlr_amd import _lib, ops
+    x = _rand((B, S, 256), 1).bfloat16().cuda()
+    w = _rand((384, 256), 2, 0.1).bfloat16().cuda()
+    res = _rand((S, 384), 4).bfloat16().cuda()
+    wp = ops.kres_pack_bcast384(w)
+    got = ops.gemm_kres_bcast384(x, wp, res)
+    want = (x.float() @ w.float().t() + res.float()[None]).bfloat16()
+    assert (got.float() - want.float()).abs().max() <= 0.07          # one bf16 ulp at |y| < 16
+    old = ops.gemm_k256(x, ops.k256_pack(w), 384, None, resid=res)
+    assert (got.float() - old.float()).abs().max() <= 0.07 and (got == old).float().mean() > 0.99
+    src = np.ascontiguousarray(w.cpu().view(torch.int16).numpy()).view(np.uint16)
+    outp = np.empty(512 * 256, dtype=np.uint16)
+    assert _lib.lib().dtlr_gemm_kres_pack_weights_bcast384(src.ctypes.data, outp.ctypes.data) == 0
+    assert np.array_equal(outp, wp.cpu().view(torch.int16).numpy().view(np.uint16))

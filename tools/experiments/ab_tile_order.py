@@ -41,3 +41,5 @@ res64 = torch.randn((64, 384), generator=g).bfloat16().cuda()
 print(json.dumps({"k256_resb_rows64_us": round(timeit(lambda: ops.gemm_k256(x, wp, 384, None, resid=res64)), 1),
                   "k256_resb_rows5440_us": round(timeit(lambda: ops.gemm_k256(x, wp, 384, None, resid=res)), 1),
                   "k256_plain_us": round(timeit(lambda: ops.gemm_k256(x, wp, 384, None)), 1)}))
+wkb = ops.kres_pack_bcast384(w)
+print(json.dumps({"kres_bcast384_us": round(timeit(lambda: ops.gemm_kres_bcast384(x, wkb, res)), 1)}))
