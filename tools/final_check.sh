@@ -5,7 +5,7 @@ TAG=${1:-vX}
 cd ${GRAFT_REPO_ROOT:-.}
 mkdir -p gpurun_out
 if [ "$2" != "prof-only" ]; then
-  timeout 900 python -m pytest tests -m gpu -q -x 2>&1 | tail -4
+  timeout 900 python -m pytest tests -m gpu -q -x > gpurun_out/pytest_gpu_$TAG.txt 2>&1; tail -3 gpurun_out/pytest_gpu_$TAG.txt
   timeout 300 python -c "import __graft_entry__ as g; g.smoke(); print('SMOKE_RC=0')" 2>&1 | tail -2
   timeout 600 python bench.py --steps 20 --warmup 3 > gpurun_out/bench_$TAG.json 2> gpurun_out/bench_$TAG.err; tail -c 400 gpurun_out/bench_$TAG.json; echo
   timeout 200 python tools/profile_stages.py > gpurun_out/stage_$TAG.json 2>/dev/null; tail -1 gpurun_out/stage_$TAG.json
