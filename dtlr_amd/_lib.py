@@ -34,6 +34,7 @@ _SIGNATURES = {
                                           c_int, c_int, c_void_p, c_void_p]),
     "dtlr_msda_encoder_set_variant": (c_int, [c_int]),
     "dtlr_msda_encoder_plan_ok": (c_int, [c_void_p, c_int, c_int]),
+    "dtlr_msda_encoder_far_samples": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p, c_void_p]),
     "dtlr_swin_patch_embed": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_float, c_int, c_void_p]),
     "dtlr_swin_window_attn": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p]),
     "dtlr_swin_patch_merge": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_float, c_int, c_void_p]),

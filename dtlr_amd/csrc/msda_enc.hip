@@ -638,6 +638,68 @@ __global__ __launch_bounds__(NT, NT / 128) void msda_enc_lds_kernel(
 
 struct EncPlan { EncLevels lv; int S, TW0, R, ntiles, tok_off; size_t lds; };
 
+// ---- far-sample probe: how many of a launch's sampling points would take msda_enc_lds_kernel's global path? -----------------
+// Same tile geometry and the same coordinate arithmetic as the query phase above, nothing else: a lane reads its (query, head, level)
+// slice of the projection row and counts the points that fall inside the map but outside the tile's staged column window.
+// counts[0] += such points, counts[1] += points inside the map.  One wave-instruction stalls on 16 dependent global loads per far
+// point, so a few percent of them cost more than the gather kernel's flat time (tools/msda_sweep.py): the engine runs this probe
+// now and then and picks the kernel per layer (DTLREngine._msda_mode).
+template <typename OT>
+__global__ __launch_bounds__(256) void msda_enc_far_count_kernel(const OT* __restrict__ ow, const float* __restrict__ ref, EncLevels lv,
+                                                                  int S, int M, int TW0, int R, unsigned long long* __restrict__ counts)
+{
+    const int tid = threadIdx.x, p = tid & 3;
+    const int t = blockIdx.x, m = blockIdx.y, b = blockIdx.z;
+    const int W0 = lv.W[0];
+    int qc0[4], qn[4], wc0[4], wc1[4], qbase[5];
+    qbase[0] = 0;
+#pragma unroll
+    for (int l = 0; l < 4; ++l) {
+        qc0[l] = cols_left_of(t, TW0, W0, lv.W[l]);
+        qn[l] = cols_left_of(t + 1, TW0, W0, lv.W[l]) - qc0[l];
+        const int lo = (int)(((long)t * TW0 * lv.W[l]) / W0) - R;
+        const int hi = (int)((((long)(t + 1) * TW0 * lv.W[l]) + W0 - 1) / W0) + R;
+        wc0[l] = max(lo, 0);
+        wc1[l] = min(min(hi, lv.W[l]), wc0[l] + lv.wmax[l]);
+        qbase[l + 1] = qbase[l] + lv.H[l] * qn[l];
+    }
+    const int nq = qbase[4];
+    const int Hl = lv.H[p], Wl = lv.W[p], wc0l = wc0[p], wc1l = wc1[p];
+    const float fH = (float)Hl, fW = (float)Wl, invH = 1.0f / fH, invW = 1.0f / fW;
+    unsigned far = 0, ins = 0;
+    for (int it = tid; it < nq * 4; it += 256) {
+        const int q = it >> 2;
+        const int lq = q >= qbase[3] ? 3 : q >= qbase[2] ? 2 : q >= qbase[1] ? 1 : 0;
+        const int r = q - qbase[lq];
+        const long bq = (long)b * S + lv.start[lq] + (r / qn[lq]) * lv.W[lq] + qc0[lq] + r % qn[lq];
+        RowRaw<OT> row;
+        row.load(ow + bq * (long)(M * 48), M, m, p);
+        const float2 rf = *reinterpret_cast<const float2*>(ref + bq * 8 + 2 * p);
+        float off[8], lg[4];
+        row.get(off, lg);
+#pragma unroll
+        for (int pt = 0; pt < 4; ++pt) {
+            const float lx = rf.x + off[2 * pt] * invW, ly = rf.y + off[2 * pt + 1] * invH;
+            const float h_im = ly * fH - 0.5f, w_im = lx * fW - 0.5f;
+            const bool inside = h_im > -1.f && w_im > -1.f && h_im < fH && w_im < fW;
+            const int w_low = (int)fminf(fmaxf(floorf(w_im), -1.f), fW);
+            const int w0 = min(max(w_low, 0), Wl - 1), w1c = max(min(w_low + 1, Wl - 1), 0);
+            const bool staged = (w0 >= wc0l) && (w1c < wc1l);
+            ins += inside ? 1u : 0u;
+            far += (inside && !staged) ? 1u : 0u;
+        }
+    }
+    __shared__ unsigned red[2][4];
+    far = (unsigned)wave_sum((float)far);                       // <= 64 x 4 x iterations: exact in fp32 for the tile sizes of the plan
+    ins = (unsigned)wave_sum((float)ins);
+    if ((tid & 63) == 0) { red[0][tid >> 6] = far; red[1][tid >> 6] = ins; }
+    __syncthreads();
+    if (tid == 0) {
+        atomicAdd(counts, (unsigned long long)(red[0][0] + red[0][1] + red[0][2] + red[0][3]));
+        atomicAdd(counts + 1, (unsigned long long)(red[1][0] + red[1][1] + red[1][2] + red[1][3]));
+    }
+}
+
 static bool make_plan(const int* hw, int elem, int R, EncPlan& pl) {
     int start = 0;
     for (int l = 0; l < 4; ++l) {
@@ -709,6 +771,26 @@ extern "C" int dtlr_msda_encoder_plan_ok(const int* level_hw, int dtype, int hal
     if (dtype != DTLR_F32 && dtype != DTLR_BF16) return DTLR_EDTYPE;
     EncPlan pl;
     return make_plan(level_hw, dtype == DTLR_F32 ? 4 : 2, halo, pl) ? 1 : 0;
+}
+
+// counts[0] += sampling points of this launch that dtlr_msda_encoder_forward would fetch through its global path (inside the map,
+// outside the tile's staged column window), counts[1] += points inside the map.  counts: 2 x uint64 in device memory (accumulated,
+// not reset).  Same arguments as dtlr_msda_encoder_forward where they are shared; dtype = the VALUE dtype (it sets the window plan).
+extern "C" int dtlr_msda_encoder_far_samples(const void* ow, const float* ref, const int* level_hw, int N, int M, int halo,
+                                             int dtype, int ow_dtype, unsigned long long* counts, void* stream)
+{
+    clear_stale_error();
+    if (!ow || !ref || !level_hw || !counts) return DTLR_EINVAL;
+    if (N <= 0 || M <= 0 || halo < 0) return DTLR_EINVAL;
+    EncPlan pl;
+    if (!make_plan(level_hw, dtype == DTLR_F32 ? 4 : 2, halo, pl)) return DTLR_ESHAPE;
+    hipStream_t st = (hipStream_t)stream;
+    if (ow_dtype == DTLR_F32)
+        hipLaunchKernelGGL(msda_enc_far_count_kernel<float>, dim3(pl.ntiles, M, N), dim3(256), 0, st, (const float*)ow, ref, pl.lv, pl.S, M, pl.TW0, pl.R, counts);
+    else if (ow_dtype == DTLR_BF16)
+        hipLaunchKernelGGL(msda_enc_far_count_kernel<uint16_t>, dim3(pl.ntiles, M, N), dim3(256), 0, st, (const uint16_t*)ow, ref, pl.lv, pl.S, M, pl.TW0, pl.R, counts);
+    else return DTLR_EDTYPE;
+    return check_launch();
 }
 
 extern "C" int dtlr_msda_encoder_forward(const void* value, const void* ow, const float* ref, const int* level_hw,

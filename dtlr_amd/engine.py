@@ -54,6 +54,10 @@ class DTLREngine:
         self.use_pln_k256 = os.environ.get("DTLR_PLN_K256", "1") != "0"
         self.use_ffn32 = os.environ.get("DTLR_FFN32", "1") != "0"
         self.use_kres = os.environ.get("DTLR_KRES", "1") != "0"
+        self.msda_auto = os.environ.get("DTLR_MSDA_AUTO", "1") != "0"      # per-layer choice LDS-window / gather kernel from a far-sample probe
+        self.msda_probe_every = 256
+        self.msda_far_threshold = 0.012
+        self._msda_state = {}
         self.use_k256_small = self.use_k256 and os.environ.get("DTLR_K256_SMALL", "1") != "0"   # ... and for the encoder's output projection + LayerNorm
 
     # ------------------------------------------------------------------------------ packing
@@ -361,6 +365,21 @@ class DTLREngine:
             self.w[key] = ops.k256_pack(self.w[name + ".w"])
         return self.w[key]
 
+    def _msda_mode(self, name, value_dtype, level_hw, ow, ref, n_heads):
+        """'lds' or 'gather' for this encoder layer.  The LDS-window kernel fetches sampling points outside its staged columns through a
+        global path that stalls a wave on 16 dependent loads per point: at ~1.2% of such points it is as slow as the gather kernel
+        (tools/msda_sweep.py: 0.47 ms at 2.7% against 0.31 ms flat).  The fraction depends on the checkpoint's offset heads, so it is
+        MEASURED: a probe (dtlr_msda_encoder_far_samples, one small kernel + a 16-byte read-back) on a layer's first call and every
+        `msda_probe_every` calls after it; DTLR_MSDA_AUTO=0 pins the LDS kernel."""
+        if not self.msda_auto:
+            return "lds"
+        st = self._msda_state.setdefault(name, {"calls": 0, "mode": "lds", "far": None})
+        if st["calls"] % self.msda_probe_every == 0:
+            st["far"] = ops.msda_encoder_far_fraction(value_dtype, level_hw, ow, ref, n_heads)
+            st["mode"] = "gather" if st["far"] > self.msda_far_threshold else "lds"
+        st["calls"] += 1
+        return st["mode"]
+
     def _msda_module(self, name, query, query_pos, ref, value_src, g, n_points, value=None, ow_res=None):
         """MSDeformAttn.forward (ops/modules/ms_deform_attn.py:78-126) without the output
         projection (done by the caller, followed by the fused residual + LayerNorm).
@@ -391,7 +410,8 @@ class DTLREngine:
         else:
             ow = self._lin(name + ".ow", query, a2=query_pos)
         if L == 4 and P == 4:
-            if Lq == S and ref.shape[-1] == 2 and C // M == 32 and self.use_lds_msda and g["lds_msda_fits"]:   # encoder self-attention
+            if Lq == S and ref.shape[-1] == 2 and C // M == 32 and self.use_lds_msda and g["lds_msda_fits"] \
+                    and self._msda_mode(name, value.dtype, g["level_hw"], ow, ref, M) == "lds":        # encoder self-attention
                 return ops.msda_encoder(value.view(B, S, M, C // M), g["level_hw"], ow, ref)
             return ops.msda_fused(value.unflatten(-1, (M, C // M)), g["shapes"], g["lsi"], ow, ref)
         ow = ow.float()

@@ -705,6 +705,21 @@ def msda_encoder(value, level_hw, ow, ref):
     return out
 
 
+def msda_encoder_far_fraction(value_dtype, level_hw, ow, ref, n_heads: int = 8):
+    """Fraction of the in-map sampling points of an encoder MSDA call that msda_encoder would fetch through its global path (outside the
+    staged column window of the query's tile; dtlr_msda_encoder_far_samples).  Synchronises (reads two counters back): a probe."""
+    require_cuda(ow, "ow")
+    assert len(level_hw) == 4 and ow.is_contiguous() and ref.is_contiguous() and ref.dtype == torch.float32
+    import ctypes
+    hw = (ctypes.c_int * 8)(*[int(v) for pair in level_hw for v in pair])
+    counts = torch.zeros(2, dtype=torch.int64, device=ow.device)
+    code = _lib.lib().dtlr_msda_encoder_far_samples(ow.data_ptr(), ref.data_ptr(), hw, ow.shape[0], n_heads, MSDA_HALO, _DT[value_dtype],
+                                                    _DT[ow.dtype], counts.data_ptr(), _lib.current_stream())
+    _lib.check(code, "dtlr_msda_encoder_far_samples")
+    far, inside = counts.tolist()
+    return far / max(inside, 1)
+
+
 def mha(qk, v, n_heads: int):
     """Self-attention core.  qk [B, L, 2C] (projected q | k), v [B, L, C] -> [B, L, C].  Fused flash-style HIP
     kernel on the matrix cores, scores never leave the chip: bf16 (mfma 16x16x32) or exact fp32 (mfma 16x16x4)."""
@@ -893,7 +908,7 @@ def _device_scoped(fn):
     return wrapper
 
 
-for _name in ("gemm_kres", "gemm_kres_bcast384", "ffn32", "proj_ln_k256", "swin_patch_embed", "swin_window_attn", "swin_patch_merge", "geometry", "linear", "gemm_k256", "linear_rowmax", "two_stage_gather", "layernorm", "proj_ln", "proj_ln_split", "ffn_fused", "conv2d_nhwc", "stem_conv7x7", "stem_conv7x7_f32",
+for _name in ("msda_encoder_far_fraction", "gemm_kres", "gemm_kres_bcast384", "ffn32", "proj_ln_k256", "swin_patch_embed", "swin_window_attn", "swin_patch_merge", "geometry", "linear", "gemm_k256", "linear_rowmax", "two_stage_gather", "layernorm", "proj_ln", "proj_ln_split", "ffn_fused", "conv2d_nhwc", "stem_conv7x7", "stem_conv7x7_f32",
               "maxpool_nhwc", "groupnorm_tokens", "msda", "msda_fused", "msda_encoder", "mha", "decoder_query_prep", "box_mlp_refine",
               "box_head_refine", "box_refine", "topk_rows", "decode_blank", "preprocess_lines", "ctc_loss_interleaved", "nms_batched",
               "topk_flat"):

@@ -92,6 +92,13 @@ int dtlr_msda_encoder_forward(const void *value, const void *ow, const float *re
 /* 1 if the LDS window plan of dtlr_msda_encoder_forward fits these level shapes, 0 if not (canvases taller than ~270 px in
  * fp32 / ~550 px in bf16: use dtlr_msda_fused_forward, which has no size limit), negative DTLR_E* on bad arguments. */
 int dtlr_msda_encoder_plan_ok(const int *level_hw /* host, 8 ints */, int dtype, int halo);
+/* Far-sample probe for the choice between dtlr_msda_encoder_forward (LDS windows) and dtlr_msda_fused_forward (gather) on a given
+ * layer: counts[0] += sampling points (ops/modules/ms_deform_attn.py:102-105: reference point + offset / (W_l, H_l)) that lie inside
+ * their map but outside the column window the LDS kernel stages for the query's tile -- each costs that kernel a dependent global
+ * gather; counts[1] += points inside the map.  counts: 2 x uint64 in DEVICE memory, accumulated.  ow / ref / level_hw / halo as for
+ * dtlr_msda_encoder_forward; dtype = the value dtype (it sets the window plan), ow_dtype = the projection row's dtype. */
+int dtlr_msda_encoder_far_samples(const void *ow, const float *ref, const int *level_hw, int N, int M, int halo,
+                                  int dtype, int ow_dtype, unsigned long long *counts, void *stream);
 /* Measurement knob: bf16 query-phase form of dtlr_msda_encoder_forward for subsequent launches (0 = fp32 accumulators /
  * v_fma_mix_f32, 1 = per-level packed-fp16 accumulation with 256-thread workgroups, 2 = the same with 512 threads: the default;
  * env DTLR_MSDA_ENC_V sets the initial value).  Returns the previous value; v outside 0..2 only queries. */

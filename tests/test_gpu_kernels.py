@@ -987,3 +987,22 @@ def test_gemm_kres_bcast384_vs_k256_kernel(B, S):
     outp = np.empty(512 * 256, dtype=np.uint16)
     assert _lib.lib().dtlr_gemm_kres_pack_weights_bcast384(src.ctypes.data, outp.ctypes.data) == 0
     assert np.array_equal(outp, wp.cpu().view(torch.int16).numpy().view(np.uint16))
+
+
+@pytest.mark.parametrize("offscale,lo,hi", [(0.0, 0.0, 0.0), (2.0, 0.0, 0.002), (40.0, 0.2, 1.0)])
+def test_msda_far_sample_probe(offscale, lo, hi):
+    """dtlr_msda_encoder_far_samples: no sampling point at the reference points themselves leaves the staged windows, small offsets stay
+    inside the halo, offsets of tens of pixels mostly do not; bf16 and fp32 projection rows give the same count up to rounding."""
+    from dtlr_amd import ops
+    from oracle import dtlr_oracle as O
+    level_hw = [(16, 256), (8, 128), (4, 64), (2, 32)]
+    N, M, L, P = 2, 8, 4, 4
+    S = sum(h * w for h, w in level_hw)
+    s = torch.tensor(level_hw)
+    ow = _rand((N, S, M * L * P * 3), 15)
+    ow[..., : M * L * P * 2] *= offscale
+    ref = O.encoder_reference_points(s, torch.ones((N, 4, 2))).contiguous()
+    f32 = ops.msda_encoder_far_fraction(torch.bfloat16, level_hw, ow.cuda(), ref.cuda())
+    b16 = ops.msda_encoder_far_fraction(torch.bfloat16, level_hw, ow.bfloat16().cuda(), ref.cuda())
+    assert lo <= f32 <= hi, f32
+    assert abs(f32 - b16) <= 0.01 + 0.05 * f32

@@ -480,3 +480,25 @@ def test_swin_backbone_bf16_close_to_oracle():
         b = b.permute(0, 2, 3, 1)
         rel = (a.float().cpu() - b).abs().mean() / b.abs().mean()
         assert rel < 0.03, rel.item()
+
+
+def test_msda_kernel_choice_follows_the_far_sample_probe():
+    """An encoder layer whose sampling offsets leave the LDS kernel's staged windows is switched to the gather kernel by the probe
+    (DTLREngine._msda_mode), one with small offsets stays on the LDS kernel; both match the oracle either way."""
+    from oracle import dtlr_oracle as O
+    cfg = DTLRConfig.tiny()
+    sd = weights.synthetic_state_dict(cfg, 3)
+    far_layer = "transformer.encoder.layers.1.self_attn.sampling_offsets.bias"
+    sd = dict(sd)
+    b = torch.zeros_like(sd[far_layer])
+    b[0::2] = torch.linspace(-60.0, 60.0, b.numel() // 2)          # x offsets of tens of pixels (y stays inside the 4-row maps)
+    sd[far_layer] = b
+    imgs = synth.noise_lines(2, 32, 2048, seed=9)       # level 0 is 256 columns wide: several window tiles
+    m = _model(cfg, sd)
+    out = m([i.cuda() for i in imgs], return_debug=True)
+    st = m.engine()._msda_state
+    assert st["enc1.attn"]["mode"] == "gather" and st["enc1.attn"]["far"] > 0.05, st
+    assert st["enc0.attn"]["mode"] == "lds" and st["enc0.attn"]["far"] < 0.012, st
+    ref = O.dino_forward(sd, cfg, imgs, forced_topk=out["_debug"]["topk_idx"].cpu())
+    assert (out["pred_logits"].cpu() - ref["pred_logits"]).abs().max() < LOGIT_TOL
+    assert (out["pred_boxes"].cpu() - ref["pred_boxes"]).abs().max() < BOX_TOL
