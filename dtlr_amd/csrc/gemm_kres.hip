@@ -147,7 +147,7 @@ __global__ __launch_bounds__(512, 2) void gemm_kres_kernel(
                 bf[tt] = *reinterpret_cast<const uint4*>(sb + rdA + ((ks & 1) ? sw1 : sw0) + tt * (2 * KB * 1024) + (ks >> 1) * 1024);
 #pragma unroll
             for (int p = 0; p < NP; ++p) {
-                if (NBR != 4 * NP && HAS_R && col0 + 32 * (wave * NP + p) >= n_valid) continue;         // zero-padded column: nothing to compute
+                if (col0 + 32 * (wave * NP + p) >= n_valid) continue;                                   // zero-padded column: nothing to compute
 #pragma unroll
                 for (int e = 0; e < 2; ++e)
 #pragma unroll
@@ -182,10 +182,9 @@ __global__ __launch_bounds__(512, 2) void gemm_kres_kernel(
         }
         // my pieces of tile i + 1 must have landed before the next barrier.  Issued since: the stores of tile i + 2 - NS, then a DMA group
         // and a tile's stores in each of the NS - 2 iterations after it (a ragged tile -- fewer stores -- is always a workgroup's last)
-        // (zero-padded column, NBR != 4 NP: some waves issue fewer stores than E -- only NS = 2 is used there and the count below then
-        // names this tile's stores alone, so such a wave waits with vmcnt(0): stricter, never wrong)
+        // (zero-padded column: a wave with fewer valid pairs issues fewer stores than E and waits with vmcnt(0): stricter, never wrong)
         if (i + NS - 1 < nt) {
-            if (NBR != 4 * NP && HAS_R && col0 + 32 * (wave * NP + NP) > n_valid) kr_wait<0>();
+            if (col0 + 32 * (wave * NP + NP) > n_valid) kr_wait<0>();
             else kr_wait<E + (NS - 2) * (G + E)>();
         } else kr_wait<0>();
     }
@@ -211,11 +210,13 @@ static int kres_pack(const unsigned short* w_host, unsigned short* wp_host, int 
     return DTLR_OK;
 }
 
+// N a multiple of 256, or 64 / 128 / 192 (packed as ONE zero-padded 256-channel column: wp_host then holds 256 * K elements)
 extern "C" int dtlr_gemm_kres_pack_weights(const unsigned short* w_host, unsigned short* wp_host, int N, int K)
 {
     if (!w_host || !wp_host) return DTLR_EINVAL;
-    if ((K != 64 && K != 128 && K != 256) || N <= 0 || (N & 255)) return DTLR_ESHAPE;
-    return kres_pack(w_host, wp_host, N, K, (N % 512 == 0 && K <= 128) ? 2 : 1, N);
+    if ((K != 64 && K != 128 && K != 256) || N <= 0 || (N & 63) || (N > 256 && (N & 255))) return DTLR_ESHAPE;
+    const int Np = N < 256 ? 256 : N;
+    return kres_pack(w_host, wp_host, Np, K, (Np % 512 == 0 && K <= 128) ? 2 : 1, N);
 }
 
 // W [384, 256] (host) -> the image dtlr_gemm_kres_bcast384 takes: a 512-channel column (two row-tile pairs per wave), rows 384..511 zero;
@@ -239,7 +240,7 @@ static int kres_launch(const void* A, const void* Wp, const float* bias, const v
     if (per_x < 1) per_x = 1;
     const int gx = (ntiles + per_x - 1) / per_x;
     const int n_img = res_rows > 0 ? M / res_rows : 0;
-    const int ld = res_rows > 0 ? n_valid : N;
+    const int ld = n_valid;                                    // row stride of R and C (N itself except for the zero-padded column forms)
 #define KR_LAUNCH(KB_, NP_, NS_, NBR_)                                                             \
     {                                                                                              \
         constexpr int lds_ = NS_ * (KR_TOK * 64 * KB_ * 2 + KR_TOK * NBR_ * 128);                  \
@@ -269,8 +270,9 @@ extern "C" int dtlr_gemm_kres(const void* A, const void* Wp, const float* bias, 
     clear_stale_error();
     if (!A || !Wp || !C) return DTLR_EINVAL;
     if (M <= 0) return DTLR_EINVAL;
-    if ((K != 64 && K != 128 && K != 256) || N <= 0 || (N & 255)) return DTLR_ESHAPE;
-    return kres_launch(A, Wp, bias, R, C, M, N, K, relu, N, 0, (hipStream_t)stream);
+    if ((K != 64 && K != 128 && K != 256) || N <= 0 || (N & 63) || (N > 256 && (N & 255))) return DTLR_ESHAPE;
+    if (N < 256 && R) return DTLR_ESHAPE;                       // the zero-padded column form has no residual tile
+    return kres_launch(A, Wp, bias, R, C, M, N < 256 ? 256 : N, K, relu, N, 0, (hipStream_t)stream);
 }
 
 // The encoder's [offsets | attention logits] projection with the position term as a row-broadcast residual:

@@ -54,6 +54,7 @@ class DTLREngine:
         self.use_pln_k256 = os.environ.get("DTLR_PLN_K256", "1") != "0"
         self.use_ffn32 = os.environ.get("DTLR_FFN32", "1") != "0"
         self.use_kres = os.environ.get("DTLR_KRES", "1") != "0"
+        self.use_kres_narrow = os.environ.get("DTLR_KRES_NARROW", "1") != "0"
         self.msda_auto = os.environ.get("DTLR_MSDA_AUTO", "1") != "0"      # per-layer choice LDS-window / gather kernel from a far-sample probe
         self.msda_probe_every = 256
         self.msda_far_threshold = 0.012
@@ -246,7 +247,8 @@ class DTLREngine:
             if stride != 1:                           # strided 1x1 (downsample): the implicit-GEMM kernel gathers the pixels itself
                 return ops.conv2d_nhwc(x, w.view(w.shape[0], 1, 1, w.shape[1]), self.w[name + ".b"], stride, 0, relu, residual)
             M = x.numel() // x.shape[-1]
-            if self.use_kres and ops.kres_supported(M, w.shape[0], w.shape[1], x.dtype) and (residual is not None or not relu):
+            if self.use_kres and ops.kres_supported(M, w.shape[0], w.shape[1], x.dtype) and (residual is None or w.shape[0] >= 256) \
+                    and (w.shape[0] >= 256 or (self.use_kres_narrow and w.shape[1] == 256)):     # narrow outputs: the 256 -> 64 / 128 reductions only
                 if name + ".wk" not in self.w:                # weight-resident streaming form (bottleneck tail / layer1 downsample)
                     self.w[name + ".wk"] = ops.kres_pack(w)
                 return ops.gemm_kres(x, self.w[name + ".wk"], w.shape[0], self.w[name + ".b"], residual, relu=bool(relu))

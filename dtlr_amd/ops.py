@@ -160,13 +160,16 @@ def gemm_k256(x, wp, n_out: int, b=None, resid=None, row_mask=None, out=None):
 
 def kres_supported(M: int, N: int, K: int, dtype) -> bool:
     """Shapes dtlr_gemm_kres takes (the HBM-streaming 1x1 convolutions of the ResNet bottlenecks)."""
-    return dtype == torch.bfloat16 and K in (64, 128, 256) and N % 256 == 0 and N >= 256 and M >= 16384
+    return dtype == torch.bfloat16 and K in (64, 128, 256) and (N % 256 == 0 or N in (64, 128, 192)) and N >= 64 and M >= 16384
 
 
 def kres_pack(w, np_pairs=None):
     """[N, K] weight -> the fragment-order image of dtlr_gemm_kres (== dtlr_gemm_kres_pack_weights): column slices of 256 NP channels,
     block ((((slice 8 + wave) NP + p) 2 + e) KS + ks) lane (m, g) <- W[256 NP slice + 32 (wave NP + p) + 8 (m >> 2) + 4 e + (m & 3)][32 ks + 8 g ..]."""
     N, K = w.shape
+    if N in (64, 128, 192):                    # one zero-padded 256-channel column
+        w = torch.cat([w.detach().to(torch.bfloat16), torch.zeros((256 - N, K), dtype=torch.bfloat16, device=w.device)])
+        N = 256
     assert K in (64, 128, 256) and N % 256 == 0
     NP = np_pairs or (2 if (N % 512 == 0 and K <= 128) else 1)
     ns, KS = N // (256 * NP), K // 32
@@ -180,7 +183,7 @@ def gemm_kres(x, wp, n_out: int, b=None, residual=None, relu: bool = False):
     (dtlr_gemm_kres); wp = kres_pack(W).  x [..., K] bf16, residual [..., n_out] bf16 or None."""
     require_cuda(x, "x")
     K = x.shape[-1]
-    assert x.dtype == torch.bfloat16 and wp.dtype == torch.bfloat16 and wp.numel() == n_out * K
+    assert x.dtype == torch.bfloat16 and wp.dtype == torch.bfloat16 and wp.numel() == max(n_out, 256) * K
     x = x if x.is_contiguous() else x.contiguous()
     M = x.numel() // K
     if residual is not None:

@@ -134,7 +134,9 @@ int dtlr_ffn_fused_bf16(const void *X, const void *W1, const float *b1, const vo
  * Replaces: the last 1x1 convolution of a torchvision ResNet bottleneck with its folded FrozenBN, the identity add and the ReLU
  *           (`out = relu(bn3(conv3(out)) + identity)`; models/dino/backbone.py:62-72,97-106 wrapping torchvision resnet50) and the
  *           stride-1 1x1 `downsample` convolution of layer1 -- the HBM-streaming shapes K = 64 / 128 / 256, N = 256 / 512 / 1024.
- *   dtlr_gemm_kres_pack_weights: HOST-side packer: W [N, K] bf16 row-major -> fragment order (N * K elements), N a multiple of 256.
+ *   dtlr_gemm_kres_pack_weights: HOST-side packer: W [N, K] bf16 row-major -> fragment order; N a multiple of 256 (N * K elements out),
+ *                   or N = 64 / 128 / 192 without residual (the bottleneck's first 1x1 convolution): one zero-padded 256-channel column,
+ *                   256 * K elements out.
  *   dtlr_gemm_kres: A [M, K] bf16 ; Wp = device copy of the packed weight ; bias [N] fp32 or NULL ; R [M, N] bf16 or NULL ;
  *                   C [M, N] bf16 ; relu != 0 applies ReLU after the residual add.
  */
