@@ -737,14 +737,22 @@ __global__ __launch_bounds__(512, HAS_A2 ? 2 : 4) void gemm_ws_kernel(
 // rows: half of the matrix-pipe and LDS-read work of every tile is thrown away.  Same loader / two-set pipeline / swizzled LDS
 // image / epilogue; no A2, no split-K; one channel tile, so a chain is just a run of token tiles.
 // ---------------------------------------------------------------------------------------------
-constexpr int TALL_BM = 256, TALL_STAGE = (64 + TALL_BM) * LDS_ROW;       // 40 KB per stage: W tile (64 rows) | X tile (256 rows)
+// TBN = 128 (round 2): a 256 x 128 tile for the K >= 512 projections.  Those are bound by L2 -> LDS operand delivery, not by HBM or the
+// matrix pipe: with 128 x 128 tiles every slab step moves (128 + 128) x 128 B per workgroup, 512 workgroups deep -- 16 MB per step,
+// ~1.6 us at the ~10 TB/s the L2s deliver (M = 32768, N = 256, K = 1024: 16 steps = 26 us measured 27).  A 256 x 128 tile moves
+// (256 + 128) rows per 2 x the flops: 0.75 x the bytes per flop.  8 MFMA waves (4 token groups x 2 channel halves, 64 x 64 each as
+// before) + 4 loader waves = 768 threads, one workgroup per CU (2 x 48 KB of LDS); grid.y walks the 128-channel tiles.
+constexpr int TALL_BM = 256;
+template <int TBN> struct TallCfg { static constexpr int STAGE = (TBN + TALL_BM) * LDS_ROW, NMW = 4 * (TBN / 64), NT = 64 * (NMW + 4); };
 
-template <typename T, typename OutT, bool CONV, int CF = -1>
-__global__ __launch_bounds__(512, 4) void gemm_ws_tall_kernel(
+template <typename T, typename OutT, bool CONV, int CF = -1, int TBN = 64>
+__global__ __launch_bounds__(TallCfg<TBN>::NT, TBN == 64 ? 4 : 1) void gemm_ws_tall_kernel(
     const T* __restrict__ A, const T* __restrict__ W, const float* __restrict__ bias, const OutT* __restrict__ residual,
     OutT* __restrict__ C, int M, int N, int K, int flags, int ntilesM, int tiles_per_block, ConvP cp, int round_robin)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    constexpr int TALL_STAGE = TallCfg<TBN>::STAGE, NMW = TallCfg<TBN>::NMW, WL = TBN / 32;     // WL = weight rows per loader thread
+    const int n0 = (int)blockIdx.y * TBN;                                // first output channel of this workgroup's tiles
     const int wave = threadIdx.x >> 6;
     constexpr int BK = GT<T>::BK;
     const int nk = K / BK;
@@ -759,9 +767,9 @@ __global__ __launch_bounds__(512, 4) void gemm_ws_tall_kernel(
     if (t_begin >= t_end) return;
     const int total = (t_end - t_begin) * nk;
 
-    if (wave >= 4) {
+    if (wave >= NMW) {
         // ================================ loader role ================================
-        const int tid = threadIdx.x - 256;
+        const int tid = threadIdx.x - NMW * 64;
         const int srow = tid >> 3, kc = tid & 7;
         const int lds0 = srow * LDS_ROW + ((kc ^ (srow & 7)) * 16);
         const int slabs_per_tap = CONV ? (cp.Cin * (int)sizeof(T)) / SLAB : 1;
@@ -769,12 +777,12 @@ __global__ __launch_bounds__(512, 4) void gemm_ws_tall_kernel(
         const char* Wb = reinterpret_cast<const char*>(W);
         const char* zero_line = reinterpret_cast<const char*>(g_zero_line);
         (void)zero_line;
-        long a_off[8], w_off[2];
+        long a_off[8], w_off[WL];
         int hi0[8], wi0[8];
         auto set_tile = [&](int tile) {
             const int lm0 = tile * TALL_BM;
 #pragma unroll
-            for (int i = 0; i < 2; ++i) w_off[i] = ((long)min(srow + 32 * i, N - 1) * K) * (long)sizeof(T) + kc * 16;
+            for (int i = 0; i < WL; ++i) w_off[i] = ((long)min(n0 + srow + 32 * i, N - 1) * K) * (long)sizeof(T) + kc * 16;
 #pragma unroll
             for (int i = 0; i < 8; ++i) {
                 const long ar = min(lm0 + srow + 32 * i, M - 1);
@@ -790,7 +798,7 @@ __global__ __launch_bounds__(512, 4) void gemm_ws_tall_kernel(
                 }
             }
         };
-        uint4 ra[2][8], rw[2][2];
+        uint4 ra[2][8], rw[2][WL];
         auto gload = [&](auto S_, int kt) {
             constexpr int S = decltype(S_)::value;
             const long off = (long)kt * SLAB;
@@ -798,7 +806,7 @@ __global__ __launch_bounds__(512, 4) void gemm_ws_tall_kernel(
             const int kh = CONV ? tap / cp.KW : 0, kw = CONV ? tap % cp.KW : 0;
             const long coff = (long)(kt % slabs_per_tap) * SLAB;
 #pragma unroll
-            for (int i = 0; i < 2; ++i) rw[S][i] = asm_load16(Wb + w_off[i] + off);
+            for (int i = 0; i < WL; ++i) rw[S][i] = asm_load16(Wb + w_off[i] + off);
 #pragma unroll
             for (int i = 0; i < 8; ++i) {
                 if (CONV) {
@@ -815,9 +823,9 @@ __global__ __launch_bounds__(512, 4) void gemm_ws_tall_kernel(
             constexpr int S = decltype(S_)::value;
             unsigned char* wt = smem + stage * TALL_STAGE + lds0;
 #pragma unroll
-            for (int i = 0; i < 2; ++i) *reinterpret_cast<uint4*>(wt + i * 32 * LDS_ROW) = rw[S][i];
+            for (int i = 0; i < WL; ++i) *reinterpret_cast<uint4*>(wt + i * 32 * LDS_ROW) = rw[S][i];
 #pragma unroll
-            for (int i = 0; i < 8; ++i) *reinterpret_cast<uint4*>(wt + 64 * LDS_ROW + i * 32 * LDS_ROW) = ra[S][i];
+            for (int i = 0; i < 8; ++i) *reinterpret_cast<uint4*>(wt + TBN * LDS_ROW + i * 32 * LDS_ROW) = ra[S][i];
         };
         int lkt = 0, ltile = t_begin;
         auto advance_and_load = [&](auto S_) {
@@ -826,7 +834,7 @@ __global__ __launch_bounds__(512, 4) void gemm_ws_tall_kernel(
         };
         using P_ = std::integral_constant<int, 0>;
         using Q_ = std::integral_constant<int, 1>;
-        constexpr int NLOAD = 10;
+        constexpr int NLOAD = 8 + WL;
         set_tile(t_begin);
         gload(P_{}, 0);
         wait_vmcnt<0>();
@@ -866,8 +874,8 @@ __global__ __launch_bounds__(512, 4) void gemm_ws_tall_kernel(
     TR(unsigned long long* tl_none_ = nullptr; int tl_n_none_ = 0; (void)tl_none_; (void)tl_n_none_;)
     __syncthreads();
     for (int s = 0; s < total; ++s) {
-        const unsigned char* wt = smem + (s & 1) * TALL_STAGE + n * LDS_ROW;
-        const unsigned char* xt = smem + (s & 1) * TALL_STAGE + (64 + wave * 64 + n) * LDS_ROW;
+        const unsigned char* wt = smem + (s & 1) * TALL_STAGE + ((wave >> 2) * 64 + n) * LDS_ROW;
+        const unsigned char* xt = smem + (s & 1) * TALL_STAGE + (TBN + (wave & 3) * 64 + n) * LDS_ROW;
         uint4 wf[2][4], xf[2][4];
 #pragma unroll
         for (int kq = 0; kq < 2; ++kq) {
@@ -886,7 +894,8 @@ __global__ __launch_bounds__(512, 4) void gemm_ws_tall_kernel(
                 for (int ti = 0; ti < 4; ++ti) GT<T>::mma(wf[kq][ci], xf[kq][ti], acc[ci][ti]);
         __syncthreads();
         if (++kt == nk) {
-            epilogue_tile<OutT, CF>(acc, C, bias, residual, (const uint8_t*)nullptr, M, N, flags, tile * TALL_BM + wave * 64 + n, 4 * g TL_ARGS_NONE);
+            epilogue_tile<OutT, CF>(acc, C, bias, residual, (const uint8_t*)nullptr, M, N, flags, tile * TALL_BM + (wave & 3) * 64 + n,
+                                    n0 + (wave >> 2) * 64 + 4 * g TL_ARGS_NONE);
             kt = 0; ++tile;
         }
     }
@@ -1019,7 +1028,13 @@ static inline bool use_tall() {
     return v == 1;
 }
 
-// N <= 64, bf16 -> bf16, many token tiles: the 256 x 64 tile kernel.  done = false: not applicable.
+// N <= 64, bf16 -> bf16, many token tiles: the 256 x 64 tile kernel.  N a multiple of 128 with K >= 512 (operand delivery from L2 is
+// the limit): the 256 x 128 tile kernel.  done = false: not applicable.
+static inline bool use_tall128() {
+    static int v = -1;
+    if (v < 0) { const char* e = getenv("DTLR_GEMM_TALL128"); v = (e && e[0] == '0') ? 0 : 1; }   // DTLR_GEMM_TALL128=0: 128 x 128 tiles (A/B timing)
+    return v == 1;
+}
 template <typename T, typename OutT, bool CONV>
 static int try_tall(const void* X, const void* W, const float* bias, const void* residual, void* C,
                     int M, int N, int K, int flags, const ConvP& cp, hipStream_t st, bool& done)
@@ -1027,27 +1042,56 @@ static int try_tall(const void* X, const void* W, const float* bias, const void*
     done = false;
     if constexpr (!(sizeof(T) == 2 && sizeof(OutT) == 2)) return DTLR_OK;
     else {
-        if (!use_tall() || N > 64 || (N & 3) || M < 64 * TALL_BM || (flags & ~(EPI_BIAS | EPI_RELU | EPI_RELU_POST | EPI_RESIDUAL | EPI_GELU))) return DTLR_OK;
+        if (!use_tall() || (N & 3) || (flags & ~(EPI_BIAS | EPI_RELU | EPI_RELU_POST | EPI_RESIDUAL | EPI_GELU))) return DTLR_OK;
         const int nM = (M + TALL_BM - 1) / TALL_BM;
-        const long target = 2 * 256 * 2;
-        int per = (int)((nM + target - 1) / target);
-        if (per < 1) per = 1;
-        const unsigned grid = (unsigned)((nM + per - 1) / per);
-        const size_t lds = 2 * TALL_STAGE;
         static const int rr = [] { const char* e = getenv("DTLR_TALL_XCD"); return (e && e[0] == '0') ? 1 : 0; }();   // A/B timing only
+        if (N <= 64) {
+            if (M < 64 * TALL_BM) return DTLR_OK;
+            const long target = 2 * 256 * 2;
+            int per = (int)((nM + target - 1) / target);
+            if (per < 1) per = 1;
+            const unsigned grid = (unsigned)((nM + per - 1) / per);
+            const size_t lds = 2 * TallCfg<64>::STAGE;
 #define TALL_LAUNCH(CF)                                                                            \
-        {                                                                                          \
-            static DevOnce once;                                                                   \
-            if (once.first()) { (void)hipFuncSetAttribute((const void*)gemm_ws_tall_kernel<T, OutT, CONV, CF>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); (void)hipGetLastError(); } \
-            hipLaunchKernelGGL((gemm_ws_tall_kernel<T, OutT, CONV, CF>), dim3(grid), dim3(512), lds, st, (const T*)X, (const T*)W, bias, \
-                               (const OutT*)residual, (OutT*)C, M, N, K, flags, nM, per, cp, rr);   \
-        }
-        if (flags == (EPI_BIAS | EPI_RELU_POST)) TALL_LAUNCH((EPI_BIAS | EPI_RELU_POST))
-        else if (flags == EPI_BIAS) TALL_LAUNCH(EPI_BIAS)
-        else TALL_LAUNCH(-1)
+            {                                                                                      \
+                static DevOnce once;                                                               \
+                if (once.first()) { (void)hipFuncSetAttribute((const void*)gemm_ws_tall_kernel<T, OutT, CONV, CF, 64>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); (void)hipGetLastError(); } \
+                hipLaunchKernelGGL((gemm_ws_tall_kernel<T, OutT, CONV, CF, 64>), dim3(grid), dim3(512), lds, st, (const T*)X, (const T*)W, bias, \
+                                   (const OutT*)residual, (OutT*)C, M, N, K, flags, nM, per, cp, rr); \
+            }
+            if (flags == (EPI_BIAS | EPI_RELU_POST)) TALL_LAUNCH((EPI_BIAS | EPI_RELU_POST))
+            else if (flags == EPI_BIAS) TALL_LAUNCH(EPI_BIAS)
+            else TALL_LAUNCH(-1)
 #undef TALL_LAUNCH
-        done = true;
-        return check_launch();
+            done = true;
+            return check_launch();
+        }
+        // 256 x 128 tiles: enough tiles to occupy the chip (one workgroup per CU), K deep enough that operand delivery is the limit
+        const int nN = N / 128;
+        // measured (profile_ops, same box): the plain K >= 512 projections over >= 32768 rows gain 8-16%; the implicit-GEMM convolutions
+        // and the 28800-row decoder projections lose 10-20% (one workgroup per CU: no second workgroup to overlap an epilogue with)
+        if (!use_tall128() || CONV || (N & 127) || K < 512 || M < 32768 || (long)nM * nN < 192) return DTLR_OK;
+        {
+            const long target = 256;
+            int per = (int)(((long)nM * nN + target - 1) / target);
+            if (per < 1) per = 1;
+            const unsigned gx = (unsigned)((nM + per - 1) / per);
+            const size_t lds = 2 * TallCfg<128>::STAGE;
+#define TALL_LAUNCH(CF)                                                                            \
+            {                                                                                      \
+                static DevOnce once;                                                               \
+                if (once.first()) { (void)hipFuncSetAttribute((const void*)gemm_ws_tall_kernel<T, OutT, CONV, CF, 128>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); (void)hipGetLastError(); } \
+                hipLaunchKernelGGL((gemm_ws_tall_kernel<T, OutT, CONV, CF, 128>), dim3(gx, nN), dim3(TallCfg<128>::NT), lds, st, (const T*)X, (const T*)W, bias, \
+                                   (const OutT*)residual, (OutT*)C, M, N, K, flags, nM, per, cp, rr); \
+            }
+            if (flags == (EPI_BIAS | EPI_RELU_POST)) TALL_LAUNCH((EPI_BIAS | EPI_RELU_POST))
+            else if (flags == (EPI_BIAS | EPI_RELU_POST | EPI_RESIDUAL)) TALL_LAUNCH((EPI_BIAS | EPI_RELU_POST | EPI_RESIDUAL))
+            else if (flags == EPI_BIAS) TALL_LAUNCH(EPI_BIAS)
+            else TALL_LAUNCH(-1)
+#undef TALL_LAUNCH
+            done = true;
+            return check_launch();
+        }
     }
 }
 

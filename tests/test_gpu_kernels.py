@@ -1008,3 +1008,27 @@ def test_msda_far_sample_probe(offscale, lo, hi):
     b16 = ops.msda_encoder_far_fraction(torch.bfloat16, level_hw, ow.bfloat16().cuda(), ref.cuda())
     assert lo <= f32 <= hi, f32
     assert abs(f32 - b16) <= 0.01 + 0.05 * f32
+
+
+def test_tall128_tile_kernel_linear_and_conv():
+    """The 256 x 128 tile variant (plain GEMM, N a multiple of 128, K >= 512, M >= 32768) against fp64 CPU references: bias only and bias +
+    residual + ReLU on a ragged M, two channel tiles (grid.y); the 3x3 convolution of the same size stays on the 128 x 128 kernel."""
+    import torch.nn.functional as F
+    from dtlr_amd import ops
+    M, N, K = 32768 + 37, 256, 1024
+    x = _rand((M, K), 1).bfloat16()
+    w = (_rand((N, K), 2) / 32.0).bfloat16()
+    b = _rand((N,), 3)
+    r = _rand((M, N), 4).bfloat16()
+    ref = x.double() @ w.double().t() + b.double()
+    got = ops.linear(x.cuda(), w.cuda(), b.cuda()).float().cpu()
+    assert (got - ref.float()).abs().max() < 2 ** -8 * max(1.0, ref.abs().max().item()) + 1e-4
+    want = (ref + r.double()).clamp(min=0).float()
+    got = ops.linear(x.cuda(), w.cuda(), b.cuda(), relu=2, residual=r.cuda()).float().cpu()
+    assert (got - want).abs().max() < 2 ** -8 * max(1.0, want.abs().max().item()) + 1e-4
+    xi = _rand((2, 64, 200, 128), 5).bfloat16()
+    wc = (_rand((256, 128, 3, 3), 6) / 34.0).bfloat16()
+    bc = _rand((256,), 7)
+    want = F.conv2d(xi.float().permute(0, 3, 1, 2).double(), wc.double(), bc.double(), stride=1, padding=1).permute(0, 2, 3, 1).clamp(min=0).float()
+    got = ops.conv2d_nhwc(xi.cuda(), wc.permute(0, 2, 3, 1).contiguous().cuda(), bc.cuda(), 1, 1, True, None).float().cpu()
+    assert (got - want).abs().max() < 2 ** -8 * max(1.0, want.abs().max().item()) + 1e-4
