@@ -99,6 +99,24 @@ __global__ __launch_bounds__(256, 1) void ffn3_bf16_kernel(
     const int nchunk = d_ff >> 5;
     const long tok0 = (long)blockIdx.x * 256 + wave * 64;
 
+    // ---- weight DMA: wave w moves fragments 4 w .. 4 w + 3 of every chunk image --------------------------------------------------
+    const unsigned vlane = (unsigned)lane * 16u;
+    const char* W1b = reinterpret_cast<const char*>(W1p) + wave * 4096;
+    const char* W2b = reinterpret_cast<const char*>(W2p) + wave * 4096;
+    const unsigned my1 = lds_base + (unsigned)wave * 4096u, my2 = my1 + F3_W2_OFF;
+#define F3_PIECE1(C, U) { if (!(DBG & 1) || (C) < 3) f3_glds16so<(U) * 1024>(W1b + (long)(C) * F3_RING, vlane, my1 + (unsigned)((C) & (F3_NS - 1)) * F3_RING); }
+#define F3_PIECE2(C, U) { if (!(DBG & 1) || (C) < 2) f3_glds16so<(U) * 1024>(W2b + (long)(C) * F3_RING, vlane, my2 + (unsigned)((C) & (F3_NS - 1)) * F3_RING); }
+#define F3_ISSUE1(C) { F3_PIECE1(C, 0) F3_PIECE1(C, 1) F3_PIECE1(C, 2) F3_PIECE1(C, 3) }
+#define F3_ISSUE2(C) { F3_PIECE2(C, 0) F3_PIECE2(C, 1) F3_PIECE2(C, 2) F3_PIECE2(C, 3) }
+    // prologue order: W1(0) W1(1) | W2(0) W2(1) W1(2); iteration c then issues W2(c + 2), W1(c + 3)
+    F3_ISSUE1(0)
+    F3_ISSUE1(1)
+    F3_ISSUE2(0)
+    F3_ISSUE2(1)
+    F3_ISSUE1(2)
+
+    // (the weight DMA is issued FIRST: hipcc waits with vmcnt(0) for the parameter loads below before it stores them to LDS, and with the
+    // X loads and tables ahead of the DMA that wait serialised an HBM round trip for X with the L2 round trip of the first chunks)
     // X^T B-fragments: lane (j, hh) of token tile tt holds X[tok0 + 32 tt + j][16 s + 8 hh .. +7]
     uint4 xf[16][2];
 #pragma unroll
@@ -119,22 +137,6 @@ __global__ __launch_bounds__(256, 1) void ffn3_bf16_kernel(
         prm[256 + threadIdx.x] = gamma[threadIdx.x];
         prm[512 + threadIdx.x] = beta[threadIdx.x];
     }
-    // ---- weight DMA: wave w moves fragments 4 w .. 4 w + 3 of every chunk image --------------------------------------------------
-    const unsigned vlane = (unsigned)lane * 16u;
-    const char* W1b = reinterpret_cast<const char*>(W1p) + wave * 4096;
-    const char* W2b = reinterpret_cast<const char*>(W2p) + wave * 4096;
-    const unsigned my1 = lds_base + (unsigned)wave * 4096u, my2 = my1 + F3_W2_OFF;
-#define F3_PIECE1(C, U) { if (!(DBG & 1) || (C) < 3) f3_glds16so<(U) * 1024>(W1b + (long)(C) * F3_RING, vlane, my1 + (unsigned)((C) & (F3_NS - 1)) * F3_RING); }
-#define F3_PIECE2(C, U) { if (!(DBG & 1) || (C) < 2) f3_glds16so<(U) * 1024>(W2b + (long)(C) * F3_RING, vlane, my2 + (unsigned)((C) & (F3_NS - 1)) * F3_RING); }
-#define F3_ISSUE1(C) { F3_PIECE1(C, 0) F3_PIECE1(C, 1) F3_PIECE1(C, 2) F3_PIECE1(C, 3) }
-#define F3_ISSUE2(C) { F3_PIECE2(C, 0) F3_PIECE2(C, 1) F3_PIECE2(C, 2) F3_PIECE2(C, 3) }
-    // prologue order: W1(0) W1(1) | W2(0) W2(1) W1(2); iteration c then issues W2(c + 2), W1(c + 3)
-    F3_ISSUE1(0)
-    F3_ISSUE1(1)
-    F3_ISSUE2(0)
-    F3_ISSUE2(1)
-    F3_ISSUE1(2)
-
     // Y^T accumulators start as X (the residual) -- through the matrix pipe: Y^T[32 ct + i, tok] = sum_k I[i, k] X^T[k, tok] over the two
     // k-steps that hold channels 32 ct .. 32 ct + 31 (exact: 1.0 x in an fp32 accumulator).  32 MFMAs per workgroup lifetime while the
     // first weight chunks are in flight; the epilogue then needs no X fragments and no separate residual pass, and the accumulators are
@@ -153,7 +155,7 @@ __global__ __launch_bounds__(256, 1) void ffn3_bf16_kernel(
         f3_f32x16_t zero;
 #pragma unroll
         for (int r = 0; r < 16; ++r) zero[r] = 0.f;
-        asm volatile("s_waitcnt vmcnt(20)" ::: "memory");           // the X loads are older than the 20 DMA pieces
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");            // X (and, being older, the first weight chunks) landed
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
         for (int ct = 0; ct < 8; ++ct)
@@ -172,8 +174,8 @@ __global__ __launch_bounds__(256, 1) void ffn3_bf16_kernel(
     uint4 w[4];
 #define F3_W1F(C, Q) (*reinterpret_cast<const uint4*>(f3_smem + ((C) & (F3_NS - 1)) * F3_RING + (Q) * 1024 + lane * 16))
 #define F3_W2F(C, Q) (*reinterpret_cast<const uint4*>(f3_smem + F3_W2_OFF + ((C) & (F3_NS - 1)) * F3_RING + (Q) * 1024 + lane * 16))
-    // X, W1(0), W1(1) landed (mine): all but the 12 newest pieces
-    asm volatile("s_waitcnt vmcnt(12) lgkmcnt(0)" ::: "memory");
+    // everything the prologue issued has landed (mine)
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
 #pragma unroll
     for (int q = 0; q < 4; ++q) w[q] = F3_W1F(0, q);
