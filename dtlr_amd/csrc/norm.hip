@@ -266,7 +266,12 @@ __global__ __launch_bounds__(256) void maxpool3x3s2_kernel(const T* __restrict__
             if (wi < 0 || wi >= W) continue;
             float v[VEC];
             const T* src = x + ((b * H + hi) * W + wi) * C + c0;
-            if (VEC == 4) IO<T>::load4(src, *reinterpret_cast<float (*)[4]>(v));
+            if constexpr (VEC == 8 && sizeof(T) == 2) {               // one 16-byte load (8-byte accesses run at ~0.6x the 16-byte rate)
+                const uint4 t = *reinterpret_cast<const uint4*>(src);
+                const uint32_t w4[4] = {t.x, t.y, t.z, t.w};
+#pragma unroll
+                for (int i = 0; i < 4; ++i) { v[2 * i] = __uint_as_float(w4[i] << 16); v[2 * i + 1] = __uint_as_float(w4[i] & 0xffff0000u); }
+            } else if (VEC == 4) IO<T>::load4(src, *reinterpret_cast<float (*)[4]>(v));
             else { IO<T>::load4(src, *reinterpret_cast<float (*)[4]>(v)); IO<T>::load4(src + 4, *reinterpret_cast<float (*)[4]>(v + 4)); }
 #pragma unroll
             for (int i = 0; i < VEC; ++i) m[i] = fmaxf(m[i], v[i]);
@@ -284,8 +289,12 @@ __global__ __launch_bounds__(256) void maxpool3x3s2_kernel(const T* __restrict__
         for (int i = 0; i < VEC; ++i) m[i] = fmaxf(m[i], 0.f);
     }
     T* dst = y + ((b * Ho + ho) * Wo + wo) * C + c0;
-    IO<T>::store4(dst, *reinterpret_cast<float (*)[4]>(m));
-    if (VEC == 8) IO<T>::store4(dst + 4, *reinterpret_cast<float (*)[4]>(m + 4));
+    if constexpr (VEC == 8 && sizeof(T) == 2) {
+        *reinterpret_cast<uint4*>(dst) = make_uint4(pack_bf16x2(m[0], m[1]), pack_bf16x2(m[2], m[3]), pack_bf16x2(m[4], m[5]), pack_bf16x2(m[6], m[7]));
+    } else {
+        IO<T>::store4(dst, *reinterpret_cast<float (*)[4]>(m));
+        if (VEC == 8) IO<T>::store4(dst + 4, *reinterpret_cast<float (*)[4]>(m + 4));
+    }
 }
 
 }  // namespace dtlr

@@ -53,6 +53,7 @@ class DTLREngine:
         self.use_k256 = os.environ.get("DTLR_K256", "1") != "0"   # bf16: weight-resident streaming kernel for the K = 256 projections over all tokens
         self.use_pln_k256 = os.environ.get("DTLR_PLN_K256", "1") != "0"
         self.use_ffn32 = os.environ.get("DTLR_FFN32", "1") != "0"
+        self.pln_k256_min_rows = int(os.environ.get("DTLR_PLN_K256_MIN", "16384"))
         self.use_kres = os.environ.get("DTLR_KRES", "1") != "0"
         self.use_kres_narrow = os.environ.get("DTLR_KRES_NARROW", "1") != "0"
         self.msda_auto = os.environ.get("DTLR_MSDA_AUTO", "1") != "0"      # per-layer choice LDS-window / gather kernel from a far-sample probe
@@ -268,7 +269,7 @@ class DTLREngine:
     def _proj_ln(self, proj, norm, a, residual):
         """output projection of an attention block + residual + post-norm (deformable_transformer.py:810-815, 847-870)."""
         w = self.w
-        if self.use_pln_k256 and a.dtype == torch.bfloat16 and a.shape[-1] == 256 and a.numel() // 256 >= 65536:
+        if self.use_pln_k256 and a.dtype == torch.bfloat16 and a.shape[-1] == 256 and a.numel() // 256 >= self.pln_k256_min_rows:
             if proj + ".wk" not in w:                          # large M (the encoder): weight-resident streaming form
                 w[proj + ".wk"] = ops.proj_ln_k256_pack(w[proj + ".w"])
             return ops.proj_ln_k256(a, w[proj + ".wk"], w[proj + ".b"], residual, w[norm + ".w"], w[norm + ".b"])

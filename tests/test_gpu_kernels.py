@@ -1032,3 +1032,33 @@ def test_tall128_tile_kernel_linear_and_conv():
     want = F.conv2d(xi.float().permute(0, 3, 1, 2).double(), wc.double(), bc.double(), stride=1, padding=1).permute(0, 2, 3, 1).clamp(min=0).float()
     got = ops.conv2d_nhwc(xi.cuda(), wc.permute(0, 2, 3, 1).contiguous().cuda(), bc.cuda(), 1, 1, True, None).float().cpu()
     assert (got - want).abs().max() < 2 ** -8 * max(1.0, want.abs().max().item()) + 1e-4
+
+
+def test_gemm_kres_and_k256_random_shapes():
+    """Seeded sweep over the shape space the engine can hand the streaming kernels: ragged row counts, every K / N class, residual and
+    ReLU on and off, padding masks -- all bit-equal to the tiled kernel."""
+    from dtlr_amd import ops
+    rng = np.random.Generator(np.random.PCG64(11))
+    for case in range(14):
+        K = int(rng.choice([64, 128, 256]))
+        N = int(rng.choice([64, 128, 192, 256, 512, 768, 1024]))
+        M = int(rng.integers(16384, 41000))
+        res = bool(rng.integers(0, 2)) and N >= 256
+        relu = bool(rng.integers(0, 2))
+        x = _rand((M, K), 100 + case).bfloat16().cuda()
+        w = (_rand((N, K), 200 + case) / (K ** 0.5)).bfloat16().cuda()
+        b = _rand((N,), 300 + case).cuda() if rng.integers(0, 4) else None
+        r = _rand((M, N), 400 + case).bfloat16().cuda() if res else None
+        want = ops.linear(x, w, b, relu=(2 if relu else 0), residual=r)
+        got = ops.gemm_kres(x, ops.kres_pack(w), N, b, r, relu=relu)
+        assert torch.equal(got, want), (case, M, N, K, res, relu)
+    for case in range(6):
+        N = int(rng.choice([256, 384]))
+        M = int(rng.integers(1, 30000))
+        x = _rand((M, 256), 500 + case).bfloat16().cuda()
+        w = _rand((N, 256), 600 + case, 0.1).bfloat16().cuda()
+        b = _rand((N,), 700 + case).cuda()
+        mask = (torch.rand((M,)) < 0.3).cuda() if case % 2 else None
+        want = ops.linear(x, w, b, row_mask=mask)
+        got = ops.gemm_k256(x, ops.k256_pack(w), N, b, row_mask=mask)
+        assert torch.equal(got, want), (case, M, N)
