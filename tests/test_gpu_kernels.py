@@ -921,7 +921,7 @@ def test_proj_ln_k256_vs_reference(M):
     assert np.array_equal(outp, ops.proj_ln_k256_pack(w).view(torch.int16).numpy().view(np.uint16))
 
 
-@pytest.mark.parametrize("M,d_ff", [(256, 128), (1000, 2048), (65536 + 77, 2048), (174080, 2048), (700, 64)])
+@pytest.mark.parametrize("M,d_ff", [(256, 128), (1000, 2048), (65536 + 77, 2048), (174080, 2048), (700, 64), (513, 96), (300, 160), (1, 1024)])
 def test_ffn32_vs_reference_and_first_structures(M, d_ff):
     """The 32x32x16-MFMA fused FFN (dtlr_ffn32_bf16) against an fp32 reference that rounds the hidden activations to bf16 like the
     kernel does, and against the 16x16x32 kernels (same arithmetic up to fp32 summation order); host packer == tensor-op packer."""
