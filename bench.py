@@ -327,7 +327,7 @@ def main():
         if tag and kind.startswith("gemm"):
             s_ = shapes.setdefault((kind, tag), [0.0, 0.0, 0, 0.0])
             s_[0] += dt; s_[1] += flops; s_[2] += 1; s_[3] += nbytes
-    names = {"gemm_bf16": "gemm_ws_kernel<bf16> / gemm_k256_kernel / gemm_kres_kernel (every Linear / 1x1 conv / implicit-GEMM 3x3 conv, fused epilogues)",
+    names = {"gemm_bf16": "gemm_ws_kernel<bf16> / gemm_k256_kernel / gemm_kres_kernel / conv3x3_patch_kernel (every Linear / 1x1 conv / 3x3 conv, fused epilogues)",
              "gemm_f32": "gemm_ws_kernel<f32> (fp32 heads and selection scores, exact-fp32 MFMA 16x16x4)",
              "ffn_fused_bf16": "ffn3_bf16_kernel / ffn2_bf16_kernel / ffn_fused_bf16_kernel (linear1+ReLU+linear2+residual+LayerNorm, intermediate on chip)",
              "proj_ln_bf16": "proj_ln_bf16_kernel (attention output projection + residual + LayerNorm)"}

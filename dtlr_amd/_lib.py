@@ -43,6 +43,8 @@ _SIGNATURES = {
     "dtlr_layernorm": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, ctypes.c_long, c_int, c_float, c_int, c_void_p]),
     "dtlr_ffn_fused_bf16": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_float, c_void_p,
                                     c_int, c_int, c_int, c_void_p]),
+    "dtlr_conv3x3_patch_supported": (c_int, [c_int, c_int]),
+    "dtlr_conv3x3_patch_bf16": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p]),
     "dtlr_gemm_kres_pack_weights": (c_int, [c_void_p, c_void_p, c_int, c_int]),
     "dtlr_gemm_kres_pack_weights_bcast384": (c_int, [c_void_p, c_void_p]),
     "dtlr_gemm_kres_bcast384": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_int, c_void_p]),

@@ -1278,6 +1278,10 @@ extern "C" int dtlr_debug_gemm_trace(unsigned long long* out, int clear_only)
 }
 #endif
 
+extern "C" int dtlr_conv3x3_patch_supported(int Cin, int Cout);
+extern "C" int dtlr_conv3x3_patch_bf16(const void* X, const void* Wt, const float* bias, void* Y, int B, int H, int W, int Cin, int Cout,
+                                       int relu, void* stream);
+
 extern "C" int dtlr_conv2d_nhwc(const void* X, const void* W, const float* bias, const void* residual, void* Y,
                                 int B, int H, int Wd, int Cin, int Cout, int KH, int KW, int stride, int pad,
                                 int relu, int dtype, void* stream)
@@ -1298,6 +1302,11 @@ extern "C" int dtlr_conv2d_nhwc(const void* X, const void* W, const float* bias,
     const int K = KH * KW * Cin;
     int flags = (bias ? EPI_BIAS : 0) | (relu == 1 ? EPI_RELU : 0) | (relu == 2 ? EPI_RELU_POST : 0) | (residual ? EPI_RESIDUAL : 0);
     hipStream_t st = (hipStream_t)stream;
+    // 3x3 / stride 1 / pad 1 without residual on enough pixels to fill the chip: the kernel that keeps the input patch in LDS (conv3x3.hip)
+    static const bool use_patch = [] { const char* e = getenv("DTLR_CONV_PATCH"); return !(e && e[0] == '0'); }();      // =0: implicit GEMM (A/B timing)
+    if (use_patch && dtype == DTLR_BF16 && KH == 3 && KW == 3 && stride == 1 && pad == 1 && !residual && M >= 16384
+        && dtlr_conv3x3_patch_supported(Cin, Cout) == 1)
+        return dtlr_conv3x3_patch_bf16(X, W, bias, Y, B, H, Wd, Cin, Cout, relu ? 1 : 0, stream);
     if (dtype == DTLR_BF16) return launch_conv<uint16_t, uint16_t>(X, W, bias, residual, Y, (int)M, Cout, K, flags, cp, st);
     return launch_conv<float, float>(X, W, bias, residual, Y, (int)M, Cout, K, flags, cp, st);
 }

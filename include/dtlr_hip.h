@@ -264,6 +264,13 @@ int dtlr_gemm_nt_rowmax(const void *A, const void *W, const float *bias, float *
 int dtlr_conv2d_nhwc(const void *X, const void *W, const float *bias, const void *residual, void *Y,
                      int B, int H, int Wd, int Cin, int Cout, int KH, int KW, int stride, int pad,
                      int relu, int dtype, void *stream);
+/* The 3x3 / stride 1 / pad 1 bf16 case of dtlr_conv2d_nhwc without residual (the middle convolution of a ResNet bottleneck,
+ * models/dino/backbone.py:62-72,97-106) as its own entry: the (8+2) x (16+2) input patch of a workgroup's pixel tile stays resident in
+ * LDS and only the weights stream.  Cin in {64, 128, 256}, Cout a multiple of 64 (dtlr_conv3x3_patch_supported); dtlr_conv2d_nhwc
+ * routes here by itself.  X [B,H,W,Cin], Wt [Cout,3,3,Cin], Y [B,H,W,Cout] bf16; bias [Cout] fp32 or NULL; relu != 0: ReLU after the bias. */
+int dtlr_conv3x3_patch_supported(int Cin, int Cout);
+int dtlr_conv3x3_patch_bf16(const void *X, const void *Wt, const float *bias, void *Y, int B, int H, int W, int Cin, int Cout,
+                            int relu, void *stream);
 
 /* ---------------------------------------------------------------------------------------------
  * Per-decoder-layer query preparation, fused.

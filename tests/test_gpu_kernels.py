@@ -1062,3 +1062,24 @@ def test_gemm_kres_and_k256_random_shapes():
         want = ops.linear(x, w, b, row_mask=mask)
         got = ops.gemm_k256(x, ops.k256_pack(w), N, b, row_mask=mask)
         assert torch.equal(got, want), (case, M, N)
+
+
+@pytest.mark.parametrize("B,H,W,Cin,Cout", [(4, 37, 131, 64, 64), (2, 64, 200, 128, 128), (32, 8, 128, 256, 256), (3, 40, 150, 64, 128),
+                                            (2, 50, 170, 256, 64), (1, 128, 130, 128, 256)])
+def test_conv3x3_patch_kernel_vs_reference(B, H, W, Cin, Cout):
+    """The LDS-resident-patch 3x3 convolution (dtlr_conv3x3_patch_bf16, reached through conv2d_nhwc) against an fp64 reference and the
+    implicit-GEMM kernel's entry on a smaller crop: image borders (zero padding), tiles cut by the right / bottom edge, bias and ReLU."""
+    import torch.nn.functional as F
+    from dtlr_amd import _lib, ops
+    assert _lib.lib().dtlr_conv3x3_patch_supported(Cin, Cout) == 1 and B * H * W >= 16384
+    x = _rand((B, H, W, Cin), 1).bfloat16()
+    w = (_rand((Cout, Cin, 3, 3), 2) / (3.0 * Cin ** 0.5)).bfloat16()
+    b = _rand((Cout,), 3)
+    ref = F.conv2d(x.float().permute(0, 3, 1, 2).double(), w.double(), b.double(), stride=1, padding=1).permute(0, 2, 3, 1)
+    w_ohwi = w.permute(0, 2, 3, 1).contiguous().cuda()
+    for relu in (True, False):
+        want = (ref.clamp(min=0) if relu else ref).float()
+        got = ops.conv2d_nhwc(x.cuda(), w_ohwi, b.cuda(), 1, 1, relu, None).float().cpu()
+        assert (got - want).abs().max() < 2 ** -8 * max(1.0, want.abs().max().item()) + 1e-4, relu
+    got = ops.conv2d_nhwc(x.cuda(), w_ohwi, None, 1, 1, False, None).float().cpu()
+    assert (got - (ref - b.double()).float()).abs().max() < 2 ** -8 * max(1.0, ref.abs().max().item()) + 1e-4
