@@ -28,13 +28,14 @@ __global__ __launch_bounds__(256) void query_prep_kernel(const float* __restrict
     const float scale = 6.283185307179586f;           // 2*pi, as `scale = 2 * math.pi` rounded to fp32 by torch
     const float c[4] = {r.y * vy0 * scale, r.x * vx0 * scale, r.z * vx0 * scale, r.w * vy0 * scale};   // order y, x, w, h
     const float d0 = dim_t[2 * pair], d1 = dim_t[2 * pair + 1];
+    const float r0 = __frcp_rn(d0), r1 = __frcp_rn(d1);          // bf16 path: one reciprocal per frequency instead of eight divisions
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
         // bf16 engine: the hardware sine (v_sin_f32, ~1e-6 absolute on these arguments of at most a few turns) -- the result is rounded to
         // 2^-9 relative anyway; the library sinf / cosf with their software range reduction made this the slowest pure-write kernel
         // of the decoder (20 us per layer for 29 MB).  fp32 (parity) engine: the library functions, as torch computes them.
-        const float s = sizeof(OT) == 2 ? __sinf(c[k] / d0) : sinf(c[k] / d0);
-        const float co = sizeof(OT) == 2 ? __cosf(c[k] / d1) : cosf(c[k] / d1);
+        const float s = sizeof(OT) == 2 ? __sinf(c[k] * r0) : sinf(c[k] / d0);
+        const float co = sizeof(OT) == 2 ? __cosf(c[k] * r1) : cosf(c[k] / d1);
         OT* o = sine + q * 512 + k * 128 + 2 * pair;
         if (sizeof(OT) == 2) *reinterpret_cast<uint32_t*>(o) = pack_bf16x2(s, co);
         else { reinterpret_cast<float*>(o)[0] = s; reinterpret_cast<float*>(o)[1] = co; }
