@@ -224,9 +224,27 @@ def main():
     x, mask = to_batch(imgs)
     padded = chinese
 
+    # --single-device (the 2-ranks-on-one-GPU test): the ranks TIME-SHARE one GPU, which is not a deployment mode (one process per GPU).
+    # Their steps are serialised through a file lock: with two processes' kernels interleaved on the device, ~1% of forwards differ in
+    # a few decoder outputs from the same process's own earlier result (first differing operator: the decoder's deformable sampling;
+    # never seen with one process per GPU: tools/experiments/forward_determinism.py) -- the test is about the
+    # sharding / gather plumbing, which the lock leaves untouched.
+    gpu_lock = None
+    if args.single_device and world > 1:
+        import fcntl
+        gpu_lock = open(os.path.join("/tmp", f"dtlr_bench_gpu_{os.environ.get('MASTER_PORT', '0')}.lock"), "w")
+
     def local_step(xx=None, mm=None, debug=False):
-        out = eng.forward(x if xx is None else xx, mask if mm is None else mm, has_padding=padded, return_debug=debug)
-        rec = decode_blank_records(out)
+        if gpu_lock is not None:
+            fcntl.flock(gpu_lock, fcntl.LOCK_EX)
+        try:
+            out = eng.forward(x if xx is None else xx, mask if mm is None else mm, has_padding=padded, return_debug=debug)
+            rec = decode_blank_records(out)
+            if gpu_lock is not None:
+                torch.cuda.synchronize()
+        finally:
+            if gpu_lock is not None:
+                fcntl.flock(gpu_lock, fcntl.LOCK_UN)
         return (rec, out) if debug else rec
 
     def step():
@@ -268,7 +286,12 @@ def main():
             a, b = ddist.shard_bounds(n_total, r, world)
             xs, ms = (x, mask) if r == 0 else to_batch(make_lines(a, b))
             lab, ln = local_step(xs, ms)
-            ok &= bool(torch.equal(lab.cpu(), rec[0][a:b].cpu()) and torch.equal(ln.cpu(), rec[1][a:b].cpu()))
+            same = bool(torch.equal(lab.cpu(), rec[0][a:b].cpu()) and torch.equal(ln.cpu(), rec[1][a:b].cpu()))
+            if not same:
+                diff = (lab.cpu() != rec[0][a:b].cpu())
+                log(f"dp self-check: shard {r} differs: {int(diff.sum())} label slots in lines {sorted(set(diff.nonzero()[:, 0].tolist()))}, "
+                    f"lengths equal: {bool(torch.equal(ln.cpu(), rec[1][a:b].cpu()))}")
+            ok &= same
         dp_verified = ok
         log(f"dp_verified = {ok}")
 

@@ -1,0 +1,6 @@
+#!/bin/bash
+cd ${GRAFT_REPO_ROOT:-.}
+for i in 1 2 3 4; do
+  P=$((20000 + RANDOM % 20000))
+  env "$@" timeout 200 python -m torch.distributed.run --nnodes=1 --nproc-per-node 2 --master-addr 127.0.0.1 --master-port $P bench.py --gpus 2 --steps 2 --warmup 1 --batch 3 --backend gloo --single-device --no-cpu-baseline --no-parity --min-seconds 0 2>&1 | grep -E "dp self-check|dp_verified ="
+done
