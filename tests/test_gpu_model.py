@@ -403,7 +403,9 @@ def test_data_parallel_two_ranks_on_one_gpu_equals_single_process():
     """SURVEY.md 8(e) correctness definition on hardware: two ranks of the REAL bench step (each with its own engine, shard of one
     global seeded batch) exchange their decode records, and rank 0 recomputes both shards itself: gathered == single-process
     records, bit for bit, in order.  Two ranks share the one GPU of the test box, so the process group is gloo (RCCL refuses
-    duplicate devices); the code path is otherwise the one the 8-GPU run takes."""
+    duplicate devices) and `--single-device` makes the ranks take turns on it (a file lock around each step: two processes' kernels
+    interleaved on one device are not a deployment mode, and under that contention ~1% of forwards show a few flipped near-tie labels --
+    DESIGN.md section 6, open issue); the sharding, the record exchange and the comparison are the code the 8-GPU run takes."""
     import json
     import socket
     import subprocess
