@@ -379,10 +379,19 @@ __global__ __launch_bounds__(256, sizeof(T) == 2 ? 2 : 3) void msda_fused_l4p4_k
 // every lane gets the other levels' 32 values by quad-broadcast DPP.  Each corner is then ONE 16-byte load per lane and
 // the four lanes of a quad read the 64 contiguous bytes of a pixel row (coalesced -- a first attempt that gave each lane a
 // whole level of its own made every load touch a private cache line and was 30% slower than the original).
+#ifdef DTLR_QUAD_SHFL        // experiment build (tools/experiments): the quad exchanges through ds_bpermute instead of DPP
+template <int CTRL> __device__ __forceinline__ int quad_src_lane() {
+    const int l = (int)(threadIdx.x & 63), q = l & 3;
+    return (l & ~3) | ((CTRL >> (2 * q)) & 3);
+}
+template <int CTRL> __device__ __forceinline__ float quad_bcast_f(float v) { return __shfl(v, quad_src_lane<CTRL>(), 64); }
+template <int CTRL> __device__ __forceinline__ int quad_bcast_i(int v) { return __shfl(v, quad_src_lane<CTRL>(), 64); }
+#else
 template <int CTRL> __device__ __forceinline__ float quad_bcast_f(float v) {
     return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, 0xf, 0xf, false));
 }
 template <int CTRL> __device__ __forceinline__ int quad_bcast_i(int v) { return __builtin_amdgcn_update_dpp(0, v, CTRL, 0xf, 0xf, false); }
+#endif
 __device__ __forceinline__ void unpack8_bf16(const uint4& t, float (&v)[8]) {
     const uint32_t w[4] = {t.x, t.y, t.z, t.w};
 #pragma unroll

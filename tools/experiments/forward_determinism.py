@@ -13,8 +13,10 @@ x = torch.stack(synth.noise_lines(3, 128, 2048, seed=1000)).to(dev)
 mask = torch.zeros((3, 128, 2048), dtype=torch.bool, device=dev)
 def digest(t): return hashlib.md5(t.detach().float().cpu().numpy().tobytes()).hexdigest()[:8]
 N = int(sys.argv[1]) if len(sys.argv) > 1 else 25
+only = sys.argv[2].split(",") if len(sys.argv) > 2 else None
 for name, flags in [("default", {}), ("k256 off", {"use_k256": False, "use_k256_small": False}), ("kres off", {"use_kres": False}),
                     ("lds msda off", {"use_lds_msda": False}), ("fused ffn off", {"use_fused_ffn": False}), ("pln k256 off", {"use_pln_k256": False})]:
+    if only and name not in only: continue
     eng = DTLREngine(cfg, sd, dev, torch.bfloat16)
     for k, v in flags.items(): setattr(eng, k, v)
     seen = {}
