@@ -424,7 +424,13 @@ __device__ __forceinline__ void quad_level(const uint16_t* __restrict__ lbase, c
         for (int c = 0; c < 4; ++c) {
             const int o = quad_bcast_i<CTRL>(og[pt][c]);
             k[c] = quad_bcast_f<CTRL>(kg[pt][c]);
+#ifdef DTLR_GATHER_NT        // experiment build: the gather bypasses the vector L1 (non-temporal loads are served by the L2)
+            typedef unsigned q_u32x4 __attribute__((ext_vector_type(4)));
+            const q_u32x4 t_ = __builtin_nontemporal_load(reinterpret_cast<const q_u32x4*>(lbase + o));
+            d[c] = make_uint4(t_[0], t_[1], t_[2], t_[3]);
+#else
             d[c] = *reinterpret_cast<const uint4*>(lbase + o);
+#endif
         }
 #pragma unroll
         for (int c = 0; c < 4; ++c) {
