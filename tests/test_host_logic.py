@@ -369,3 +369,44 @@ def test_g8_ngram_glue_oracle_and_product_vs_reference_vectors(golden_dir, tmp_p
     lm = NG.ArpaLM(str(tmp_path / "lm.arpa"))
     assert abs(lm.score((), "car") + 0.3) < 1e-9
     assert NG.LexiconCTCDecoder(tokens, lex, lm=lm, lm_weight=2.0, beam_size=20)(em)[0][0].words == ["car"]
+
+
+def test_weight_packers_tensor_ops_match_the_library_host_packers():
+    """The tensor-op packers the engine uses (ops.*_pack, any device) and the HOST-side packers of the C ABI produce the same images:
+    the streaming K = 256 kernel, the projection + LayerNorm kernel, the residual GEMM (every K / N class, zero-padded columns) and the
+    32x32 FFN (fragment order of both weights, zero chunks appended).  No GPU: the packers are plain host functions."""
+    import numpy as np
+    from dtlr_amd import _lib, ops
+
+    def u16(t):
+        return np.ascontiguousarray(t.contiguous().view(torch.int16).numpy()).view(np.uint16)
+
+    g = torch.Generator().manual_seed(5)
+    L = _lib.lib()
+    for N in (256, 384):
+        w = torch.randn((N, 256), generator=g).bfloat16()
+        out = np.empty(N * 256, dtype=np.uint16)
+        assert L.dtlr_k256_pack_weights(u16(w).ctypes.data, out.ctypes.data, N) == 0
+        assert np.array_equal(out, u16(ops.k256_pack(w)))
+    w = torch.randn((256, 256), generator=g).bfloat16()
+    out = np.empty(65536, dtype=np.uint16)
+    assert L.dtlr_proj_ln_k256_pack_weights(u16(w).ctypes.data, out.ctypes.data) == 0
+    assert np.array_equal(out, u16(ops.proj_ln_k256_pack(w)))
+    for N, K in ((256, 64), (512, 128), (1024, 256), (2048, 256), (64, 256), (128, 256), (192, 128), (512, 64), (768, 256)):
+        w = torch.randn((N, K), generator=g).bfloat16()
+        out = np.empty(max(N, 256) * K, dtype=np.uint16)
+        assert L.dtlr_gemm_kres_pack_weights(u16(w).ctypes.data, out.ctypes.data, N, K) == 0
+        assert np.array_equal(out, u16(ops.kres_pack(w))), (N, K)
+    w = torch.randn((384, 256), generator=g).bfloat16()
+    out = np.empty(512 * 256, dtype=np.uint16)
+    assert L.dtlr_gemm_kres_pack_weights_bcast384(u16(w).ctypes.data, out.ctypes.data) == 0
+    assert np.array_equal(out, u16(ops.kres_pack_bcast384(w)))
+    for d_ff in (64, 160, 2048):
+        w1, w2 = torch.randn((d_ff, 256), generator=g).bfloat16(), torch.randn((256, d_ff), generator=g).bfloat16()
+        n = (d_ff // 32 + L.dtlr_ffn32_pad_chunks()) * 8192
+        o1, o2 = np.empty(n, dtype=np.uint16), np.empty(n, dtype=np.uint16)
+        assert L.dtlr_ffn32_pack_weights(u16(w1).ctypes.data, u16(w2).ctypes.data, o1.ctypes.data, o2.ctypes.data, d_ff) == 0
+        p1, p2 = ops.ffn32_pack(w1, w2)
+        assert np.array_equal(o1, u16(p1)) and np.array_equal(o2, u16(p2)), d_ff
+    assert L.dtlr_gemm_kres_pack_weights(u16(w).ctypes.data, out.ctypes.data, 100, 256) != 0          # bad shape -> error code, no write
+    assert L.dtlr_conv3x3_patch_supported(64, 64) == 1 and L.dtlr_conv3x3_patch_supported(512, 512) == 0
