@@ -18,7 +18,7 @@ import torch
 
 from . import _lib
 
-_DT = {torch.float32: _lib.DTLR_F32, torch.float64: _lib.DTLR_F64, torch.bfloat16: _lib.DTLR_BF16}
+_DT = {torch.float32: _lib.DTLR_F32, torch.float64: _lib.DTLR_F64, torch.bfloat16: _lib.DTLR_BF16, torch.float16: _lib.DTLR_F16}
 
 
 def _assert(cond: bool, msg: str) -> None:
@@ -45,11 +45,11 @@ def ms_deform_attn_forward(value, spatial_shapes, level_start_index, sampling_lo
     _assert(step > 0 and N % step == 0, f"batch({N}) must divide im2col_step({step})")   # cu:50-52
     if value.dtype not in _DT:
         raise RuntimeError(f'"ms_deform_attn_forward_cuda" not implemented for \'{value.dtype}\'')
-    lt = torch.float32 if value.dtype == torch.bfloat16 else value.dtype
+    lt = torch.float32 if value.dtype in (torch.bfloat16, torch.float16) else value.dtype
     _assert(sampling_loc.dtype == lt and attn_weight.dtype == lt, "sampling_loc / attn_weight dtype mismatch")
     out = torch.empty((N, Lq, M * D), dtype=value.dtype, device=value.device)
     with torch.cuda.device(value.device):
-        code = _lib.lib().dtlr_msda_forward(value.data_ptr(), spatial_shapes.data_ptr(), level_start_index.data_ptr(),
+        code = _lib.lib(value.dtype).dtlr_msda_forward(value.data_ptr(), spatial_shapes.data_ptr(), level_start_index.data_ptr(),
                                             sampling_loc.data_ptr(), attn_weight.data_ptr(),
                                             N, S, M, D, L, Lq, P, _DT[value.dtype], out.data_ptr(),
                                             _lib.current_stream())

@@ -9,10 +9,14 @@ from ctypes import c_char_p, c_int, c_int64, c_void_p, c_float, POINTER
 HERE = os.path.dirname(os.path.abspath(__file__))
 # DTLR_HIP_LIB: profiling tools point this at the instrumented build (dtlr_amd/build.py --instr)
 LIB_PATH = os.environ.get("DTLR_HIP_LIB") or os.path.join(HERE, "libdtlr_hip.so")
+# the same sources compiled with IEEE fp16 as the library's 16-bit format (csrc/dtlr_common.h, DTLR_HALF_IS_F16): identical
+# symbols, accepts DTLR_F16 wherever libdtlr_hip.so accepts DTLR_BF16
+LIB_PATH_F16 = os.environ.get("DTLR_HIP_LIB_F16") or os.path.join(HERE, "libdtlr_hip_f16.so")
 
-DTLR_F32, DTLR_F64, DTLR_BF16 = 0, 1, 2
+DTLR_F32, DTLR_F64, DTLR_BF16, DTLR_F16 = 0, 1, 2, 3
 
 _lib = None
+_lib_f16 = None
 
 
 class DTLRError(RuntimeError):
@@ -89,22 +93,33 @@ _SIGNATURES = {
 }
 
 
-def lib() -> ctypes.CDLL:
-    global _lib
+def _load(path: str) -> ctypes.CDLL:
+    if not os.path.exists(path):
+        raise DTLRError(f"{path} not built: run `python -m dtlr_amd.build` (needs hipcc); "
+                        "the DTLR HIP path has no CPU/PyTorch fallback")
+    # torch must own the process's HIP runtime: libdtlr_hip.so NEEDs libamdhip64.so.7 and, loaded
+    # first, would pull a second runtime from /opt/rocm beside torch's bundled one (kernels then
+    # launch on a runtime that has no device initialised: hipErrorNoDevice).  Importing torch
+    # first makes the loader resolve our dependency to the copy torch already mapped.
+    import torch  # noqa: F401
+    L = ctypes.CDLL(path)                  # RTLD_LOCAL: the two builds export the same symbol names and never see each other
+    for name, (res, args) in _SIGNATURES.items():
+        fn = getattr(L, name)          # AttributeError if the .so is stale -> loud
+        fn.restype, fn.argtypes = res, args
+    return L
+
+
+def lib(dtype=None) -> ctypes.CDLL:
+    """libdtlr_hip.so (fp32 / fp64 / bf16 operands), or -- lib(torch.float16) -- libdtlr_hip_f16.so (fp16 operands)."""
+    global _lib, _lib_f16
+    if dtype is not None:
+        import torch
+        if dtype == torch.float16:
+            if _lib_f16 is None:
+                _lib_f16 = _load(LIB_PATH_F16)
+            return _lib_f16
     if _lib is None:
-        if not os.path.exists(LIB_PATH):
-            raise DTLRError(f"{LIB_PATH} not built: run `python -m dtlr_amd.build` (needs hipcc); "
-                            "the DTLR HIP path has no CPU/PyTorch fallback")
-        # torch must own the process's HIP runtime: libdtlr_hip.so NEEDs libamdhip64.so.7 and, loaded
-        # first, would pull a second runtime from /opt/rocm beside torch's bundled one (kernels then
-        # launch on a runtime that has no device initialised: hipErrorNoDevice).  Importing torch
-        # first makes the loader resolve our dependency to the copy torch already mapped.
-        import torch  # noqa: F401
-        L = ctypes.CDLL(LIB_PATH)
-        for name, (res, args) in _SIGNATURES.items():
-            fn = getattr(L, name)          # AttributeError if the .so is stale -> loud
-            fn.restype, fn.argtypes = res, args
-        _lib = L
+        _lib = _load(LIB_PATH)
     return _lib
 
 

@@ -32,34 +32,52 @@ def _fingerprint() -> str:
     return h.hexdigest()
 
 
-def build(force: bool = False, verbose: bool = True) -> str:
-    fp = _fingerprint()
-    if not force and os.path.exists(LIB) and os.path.exists(STAMP) and open(STAMP).read().strip() == fp:
-        return LIB
-    objs = []
+LIB_F16 = os.path.join(HERE, "libdtlr_hip_f16.so")
+
+
+def _compile_all(defs, objdir, out, verbose):
+    """every csrc/*.hip -> objdir/*.o (in parallel: one hipcc per source), linked into `out`."""
+    from concurrent.futures import ThreadPoolExecutor
+    os.makedirs(objdir, exist_ok=True)
+    jobs = []
     for src in _sources():
-        obj = os.path.join(CSRC, os.path.basename(src)[:-4] + ".o")
-        cmd = [HIPCC, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-function", "-c", src, "-o", obj]
+        obj = os.path.join(objdir, os.path.basename(src)[:-4] + ".o")
+        jobs.append(([HIPCC, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-function"] + defs + ["-c", src, "-o", obj], obj))
+
+    def run(job):
         if verbose:
-            print("[dtlr build]", " ".join(cmd), flush=True)
-        subprocess.check_call(cmd)
-        objs.append(obj)
-    cmd = [HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB] + objs
+            print("[dtlr build]", " ".join(job[0]), flush=True)
+        subprocess.check_call(job[0])
+        return job[1]
+
+    with ThreadPoolExecutor(max_workers=min(8, os.cpu_count() or 2)) as ex:
+        objs = list(ex.map(run, jobs))
+    cmd = [HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", out] + objs
     if verbose:
         print("[dtlr build]", " ".join(cmd), flush=True)
     subprocess.check_call(cmd)
+
+
+def build(force: bool = False, verbose: bool = True) -> str:
+    """libdtlr_hip.so (16-bit format = bf16) and libdtlr_hip_f16.so (the same sources with -DDTLR_HALF_IS_F16: 16-bit format = IEEE
+    fp16, the parity build -- csrc/dtlr_common.h).  Returns the path of the first; both are rebuilt when any source changes."""
+    fp = _fingerprint()
+    if not force and os.path.exists(LIB) and os.path.exists(LIB_F16) and os.path.exists(STAMP) and open(STAMP).read().strip() == fp:
+        return LIB
+    _compile_all([], CSRC, LIB, verbose)
+    _compile_all(["-DDTLR_HALF_IS_F16"], os.path.join(CSRC, "f16"), LIB_F16, verbose)
     with open(STAMP, "w") as f:
         f.write(fp)
     return LIB
 
 
 def build_instrumented(verbose: bool = True, trace: bool = False) -> str:
-    """Profiling-only variants: same sources with -DDTLR_GEMM_ABLATION (phase switches in the GEMM; env
+    """Profiling-only variants: same sources with -DDTLR_EXPERIMENT (the env A/B switches of csrc/dtlr_common.h), -DDTLR_GEMM_ABLATION (phase switches in the GEMM; env
     DTLR_GEMM_ABLATE) and, with trace, -DDTLR_GEMM_TRACE (per-role cycle attribution; perturbs the kernel).
     Never loaded by the product; select with DTLR_HIP_LIB."""
     out = os.path.join(HERE, "libdtlr_hip_trace.so" if trace else "libdtlr_hip_instr.so")
     cmd = [HIPCC, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-Wall", "-Wno-unused-function",
-           "-DDTLR_GEMM_ABLATION"] + (["-DDTLR_GEMM_TRACE"] if trace else []) + _sources() + ["-o", out]
+           "-DDTLR_GEMM_ABLATION", "-DDTLR_EXPERIMENT"] + (["-DDTLR_GEMM_TRACE"] if trace else []) + _sources() + ["-o", out]
     if verbose:
         print("[dtlr build]", " ".join(cmd), flush=True)
     subprocess.check_call(cmd)

@@ -18,7 +18,7 @@
 
 namespace dtlr {
 
-typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
+typedef __attribute__((ext_vector_type(8))) h16_hw_t bf16x8;
 typedef __attribute__((ext_vector_type(4))) float f32x4;
 
 __device__ __forceinline__ uint32_t pack2(float a, float b) { return pack_bf16x2(a, b); }
@@ -68,7 +68,7 @@ __global__ __launch_bounds__(256) void mha_fwd_bf16_kernel(const uint16_t* __res
             f32x4 s[2];
 #pragma unroll
             for (int kt = 0; kt < 2; ++kt)
-                s[kt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf[kt], qf[qt], f32x4{0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
+                s[kt] = DTLR_MFMA_16x16x32_H16(kf[kt], qf[qt], f32x4{0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
             float mx = -INFINITY;
 #pragma unroll
             for (int kt = 0; kt < 2; ++kt)
@@ -95,7 +95,7 @@ __global__ __launch_bounds__(256) void mha_fwd_bf16_kernel(const uint16_t* __res
 #pragma unroll
             for (int dt = 0; dt < 2; ++dt) {
                 o[qt][dt] *= alpha;
-                o[qt][dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vf[dt], pf, o[qt][dt], 0, 0, 0);
+                o[qt][dt] = DTLR_MFMA_16x16x32_H16(vf[dt], pf, o[qt][dt], 0, 0, 0);
             }
         }
     }
@@ -207,7 +207,7 @@ __global__ __launch_bounds__(1024) void mha_fwd_bf16_lds_kernel(const uint16_t* 
             _Pragma("unroll") for (int qt = 0; qt < 2; ++qt) {                                     \
                 f32x4 sc[2];                                                                       \
                 _Pragma("unroll") for (int kt = 0; kt < 2; ++kt)                                   \
-                    sc[kt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf[kt], qf[qt], f32x4{0.f, 0.f, 0.f, 0.f}, 0, 0, 0); \
+                    sc[kt] = DTLR_MFMA_16x16x32_H16(kf[kt], qf[qt], f32x4{0.f, 0.f, 0.f, 0.f}, 0, 0, 0); \
                 if (MASKED) {                                                                      \
                     _Pragma("unroll") for (int kt = 0; kt < 2; ++kt)                               \
                         _Pragma("unroll") for (int r = 0; r < 4; ++r)                              \
@@ -230,7 +230,7 @@ __global__ __launch_bounds__(1024) void mha_fwd_bf16_lds_kernel(const uint16_t* 
                                                                         pack2(sc[1][0], sc[1][1]), pack2(sc[1][2], sc[1][3]))); \
                 _Pragma("unroll") for (int dt = 0; dt < 2; ++dt) {                                 \
                     o[qt][dt] *= alpha;                                                            \
-                    o[qt][dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vf[dt], pf, o[qt][dt], 0, 0, 0); \
+                    o[qt][dt] = DTLR_MFMA_16x16x32_H16(vf[dt], pf, o[qt][dt], 0, 0, 0); \
                 }                                                                                  \
             }                                                                                      \
         }
@@ -412,7 +412,7 @@ extern "C" int dtlr_mha_forward(const void* qk, const void* v, void* vt_workspac
     if (!qk || !v || !vt_workspace || !out) return DTLR_EINVAL;
     if (B <= 0 || L <= 0 || H <= 0) return DTLR_EINVAL;
     if (head_dim != 32) return DTLR_ESHAPE;
-    if (dtype != DTLR_BF16 && dtype != DTLR_F32) return DTLR_EDTYPE;
+    if (dtype != DTLR_H16 && dtype != DTLR_F32) return DTLR_EDTYPE;
     hipStream_t st = (hipStream_t)stream;
     const int Lpad = (L + 31) / 32 * 32;
     const int C = H * 32;

@@ -18,7 +18,7 @@
 
 namespace dtlr {
 
-typedef __attribute__((ext_vector_type(8))) __bf16 cp_bf16x8_t;
+typedef __attribute__((ext_vector_type(8))) h16_hw_t cp_bf16x8_t;
 typedef __attribute__((ext_vector_type(4))) float cp_f32x4_t;
 
 constexpr int CP_TH = 8, CP_TW = 16, CP_PW = CP_TW + 2, CP_PH = CP_TH + 2, CP_NPIX = CP_PW * CP_PH;      // 18 x 10 = 180 patch pixels
@@ -118,7 +118,7 @@ __global__ __launch_bounds__(64 * NW, 1) void conv3x3_patch_kernel(const uint16_
             for (int ci = 0; ci < CI; ++ci)
 #pragma unroll
                 for (int ti = 0; ti < 4; ++ti)
-                    acc[ci][ti] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(cp_bf16x8_t, wf[ci]), __builtin_bit_cast(cp_bf16x8_t, xf[ti]),
+                    acc[ci][ti] = DTLR_MFMA_16x16x32_H16(__builtin_bit_cast(cp_bf16x8_t, wf[ci]), __builtin_bit_cast(cp_bf16x8_t, xf[ti]),
                                                                           acc[ci][ti], 0, 0, 0);
         }
         // my pieces of slab s + 1 must have landed before the next barrier; the (NS - 2) slabs issued after it may stay in flight
@@ -182,7 +182,7 @@ extern "C" int dtlr_conv3x3_patch_bf16(const void* X, const void* Wt, const floa
         if (once.first()) { (void)hipFuncSetAttribute((const void*)conv3x3_patch_kernel<CB_, BN_, NW_>, hipFuncAttributeMaxDynamicSharedMemorySize, lds_); (void)hipGetLastError(); } \
         hipLaunchKernelGGL((conv3x3_patch_kernel<CB_, BN_, NW_>), grid, dim3(64 * NW_), lds_, st, (const uint16_t*)X, (const uint16_t*)Wt, bias, (uint16_t*)Y, H, W, Cout, relu); \
     }
-    static const int nw8 = [] { const char* e = getenv("DTLR_CONV_PATCH_NW8"); return (e && e[0] == '0') ? 0 : 1; }();     // =0: four waves everywhere (A/B timing)
+    static const int nw8 = exp_env_int("DTLR_CONV_PATCH_NW8", 1);     // experiment builds: =0 four waves everywhere (A/B timing)
     if (BN == 128) {
         if (Cin == 64) CP_LAUNCH(1, 128, 4)
         else if (Cin == 128) { if (nw8) CP_LAUNCH(2, 128, 8) else CP_LAUNCH(2, 128, 4) }

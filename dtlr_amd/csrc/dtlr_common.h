@@ -34,17 +34,58 @@ struct DevOnce {
     }
 };
 
-// ---- bf16 <-> f32: gfx950 converts in hardware (v_cvt_pk_bf16_f32: round-to-nearest-even, NaN stays a quiet NaN).
-// The first version rounded in software (~10 VALU instructions per pair); in the K = 256 GEMMs that made the
-// epilogue's VALU time equal to the tile's MFMA time.
+// ---- the 16-bit storage / MFMA-operand format of this library ------------------------------------------------------------
+// libdtlr_hip.so is compiled with bf16 as "the" 16-bit format; the same sources compiled with -DDTLR_HALF_IS_F16 give
+// libdtlr_hip_f16.so, whose 16-bit format is IEEE fp16 (unit roundoff 2^-11 against bf16's 2^-8: 8x finer, same MFMA rate, same
+// bytes -- the parity build; range 65504, which every post-normalisation activation of this network fits).  Everything that
+// depends on the format goes through the helpers below: the dtype code the entry points accept (DTLR_H16), the conversions
+// (hardware on gfx950: v_cvt_pk_bf16_f32 / v_cvt_pk_f16_f32, round-to-nearest-even; NaN stays a quiet NaN), the unpacking
+// of the halves of a 32-bit word, and the MFMA instructions.  The first bf16 version rounded in software (~10 VALU
+// instructions per pair); in the K = 256 GEMMs that made the epilogue's VALU time equal to the tile's MFMA time.
 typedef float f32x2_hw_t __attribute__((ext_vector_type(2)));
-typedef __bf16 bf16x2_hw_t __attribute__((ext_vector_type(2)));
-__device__ __forceinline__ float bf16_to_f32(uint16_t h) { return __uint_as_float(((uint32_t)h) << 16); }
+#ifdef DTLR_HALF_IS_F16
+typedef _Float16 h16_hw_t;
+constexpr int DTLR_H16 = DTLR_F16;
+#define DTLR_MFMA_16x16x32_H16 __builtin_amdgcn_mfma_f32_16x16x32_f16
+#define DTLR_MFMA_32x32x16_H16 __builtin_amdgcn_mfma_f32_32x32x16_f16
+#define DTLR_H16_ASM_SUFFIX "f16"
+constexpr uint32_t H16_ONE = 0x3c00u;        // 1.0 as a 16-bit pattern
+__host__ __device__ __forceinline__ float h16_lo(uint32_t w) { return (float)__builtin_bit_cast(_Float16, (uint16_t)(w & 0xffffu)); }
+__host__ __device__ __forceinline__ float h16_hi(uint32_t w) { return (float)__builtin_bit_cast(_Float16, (uint16_t)(w >> 16)); }
+inline uint16_t f32_to_h16_host(float f) { return __builtin_bit_cast(uint16_t, (_Float16)f); }      // RNE (compiler-rt / F16C)
+#else
+typedef __bf16 h16_hw_t;
+constexpr int DTLR_H16 = DTLR_BF16;
+#define DTLR_MFMA_16x16x32_H16 __builtin_amdgcn_mfma_f32_16x16x32_bf16
+#define DTLR_MFMA_32x32x16_H16 __builtin_amdgcn_mfma_f32_32x32x16_bf16
+#define DTLR_H16_ASM_SUFFIX "bf16"
+constexpr uint32_t H16_ONE = 0x3f80u;
+__host__ __device__ __forceinline__ float h16_lo(uint32_t w) { return __builtin_bit_cast(float, w << 16); }
+__host__ __device__ __forceinline__ float h16_hi(uint32_t w) { return __builtin_bit_cast(float, w & 0xffff0000u); }
+inline uint16_t f32_to_h16_host(float f) {
+    uint32_t u = __builtin_bit_cast(uint32_t, f);
+    if ((u & 0x7fffffffu) > 0x7f800000u) return (uint16_t)((u >> 16) | 0x40u);      // NaN stays NaN
+    u += 0x7fffu + ((u >> 16) & 1u);                                                // round to nearest even
+    return (uint16_t)(u >> 16);
+}
+#endif
+typedef h16_hw_t h16x2_hw_t __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ float bf16_to_f32(uint16_t h) { return h16_lo((uint32_t)h); }        // (historic names: "bf16" = the library's 16-bit format)
 __device__ __forceinline__ uint32_t pack_bf16x2(float lo, float hi) {
     const f32x2_hw_t f = {lo, hi};
-    return __builtin_bit_cast(uint32_t, __builtin_convertvector(f, bf16x2_hw_t));
+    return __builtin_bit_cast(uint32_t, __builtin_convertvector(f, h16x2_hw_t));
 }
 __device__ __forceinline__ uint16_t f32_to_bf16(float f) { return (uint16_t)(pack_bf16x2(f, 0.f) & 0xffffu); }
+
+// ---- A/B switches of the measurement builds.  The product libraries are compiled WITHOUT -DDTLR_EXPERIMENT: every switch below is then
+// its default, a compile-time constant, and no environment variable can change what a kernel launch does.  `python -m dtlr_amd.build
+// --instr` (never loaded by the product) defines DTLR_EXPERIMENT and reads them from the environment, once per process.
+#ifdef DTLR_EXPERIMENT
+#include <stdlib.h>
+inline int exp_env_int(const char* name, int dflt) { const char* e = getenv(name); return (e && e[0]) ? atoi(e) : dflt; }
+#else
+constexpr int exp_env_int(const char*, int dflt) { return dflt; }
+#endif
 
 // ---- wave reductions (all 64 lanes participate) ----------------------------------------------
 __device__ __forceinline__ float wave_sum(float v) {

@@ -33,7 +33,7 @@
 
 namespace dtlr {
 
-typedef __attribute__((ext_vector_type(8))) __bf16 ffn_bf16x8_t;
+typedef __attribute__((ext_vector_type(8))) h16_hw_t ffn_bf16x8_t;
 typedef __attribute__((ext_vector_type(4))) float ffn_f32x4_t;
 
 constexpr int FFN_NS = 4;                                   // ring stages
@@ -69,13 +69,13 @@ __device__ __forceinline__ uint4 ffn_load16(const void* p) {
 template <int DBG = 0>
 __device__ __forceinline__ ffn_f32x4_t ffn_mma(const uint4& a, const uint4& b, ffn_f32x4_t c) {
     if constexpr (DBG & 2) { asm volatile("" :: "v"(a.x), "v"(b.x)); return c; }
-    return __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(ffn_bf16x8_t, a), __builtin_bit_cast(ffn_bf16x8_t, b), c, 0, 0, 0);
+    return DTLR_MFMA_16x16x32_H16(__builtin_bit_cast(ffn_bf16x8_t, a), __builtin_bit_cast(ffn_bf16x8_t, b), c, 0, 0, 0);
 }
 
 __device__ __forceinline__ void unpack8(const uint4& t, float (&v)[8]) {
     const uint32_t w[4] = {t.x, t.y, t.z, t.w};
 #pragma unroll
-    for (int i = 0; i < 4; ++i) { v[2 * i] = __uint_as_float(w[i] << 16); v[2 * i + 1] = __uint_as_float(w[i] & 0xffff0000u); }
+    for (int i = 0; i < 4; ++i) { v[2 * i] = h16_lo(w[i]); v[2 * i + 1] = h16_hi(w[i]); }
 }
 
 // DBG (timing experiments only, env DTLR_FFN_DBG; results are garbage): 1 = no weight DMA after the prologue,
@@ -808,15 +808,14 @@ extern "C" int dtlr_ffn_fused_bf16(const void* X, const void* W1, const float* b
     if (!X || !W1 || !b1 || !W2 || !b2 || !gamma || !beta || !Y) return DTLR_EINVAL;
     if (M <= 0 || d_ff <= 0) return DTLR_EINVAL;
     if (d_model != 256 || (d_ff & 31) || d_ff < 64 || d_ff > FFN_MAX_DFF) return DTLR_ESHAPE;     // >= 2 chunks: phase B trails by one
-    static int dbg = -1;
-    if (dbg < 0) { const char* e = getenv("DTLR_FFN_DBG"); dbg = e ? atoi(e) : 0; }
+    static const int dbg = exp_env_int("DTLR_FFN_DBG", 0);          // experiment builds only: ablated variants (results are garbage)
     // Second structure (one wave per SIMD, H in registers; see ffn2_bf16_kernel) whenever it has its >= 4 chunks:
     //   * whole rounds of 256 workgroups x 192 tokens (TT = 3), then the remainder as 128-token workgroups (TT = 2) when those
     //     fit one round -- at M = 174080 that is 3 full rounds + 208 workgroups of 2/3 the length instead of a fourth round
     //     that would be 54% full;
     //   * M <= 32768 (the decoder call, M = 28800: a single partial round) stays on the first structure, which is as fast there.
-    // env DTLR_FFN_V = 1 forces the first structure, 2 the second with TT = 3 only (measurements / tests).
-    static const int ver = [] { const char* ev = getenv("DTLR_FFN_V"); return ev ? atoi(ev) : 0; }();   // read once per process
+    // experiment builds: DTLR_FFN_V = 1 forces the first structure, 2 the second with TT = 3 only (measurements / tests).
+    static const int ver = exp_env_int("DTLR_FFN_V", 0);               // experiment builds only
     if (dbg == 0 && d_ff >= 128 && ver != 1 && (ver == 2 || M > 256 * 128)) {          // one partial round or less: the first structure is as fast
         static DevOnce attr2;
         if (attr2.first()) {

@@ -32,7 +32,7 @@
 
 namespace dtlr {
 
-typedef __attribute__((ext_vector_type(8))) __bf16 f3_bf16x8_t;
+typedef __attribute__((ext_vector_type(8))) h16_hw_t f3_bf16x8_t;
 typedef __attribute__((ext_vector_type(16))) float f3_f32x16_t;
 
 constexpr int F3_NS = 4;                                    // ring stages
@@ -63,7 +63,7 @@ __device__ __forceinline__ uint4 f3_load16(const void* p) {
     return r;
 }
 __device__ __forceinline__ f3_f32x16_t f3_mma(const uint4& a, const uint4& b, f3_f32x16_t c) {
-    return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(f3_bf16x8_t, a), __builtin_bit_cast(f3_bf16x8_t, b), c, 0, 0, 0);
+    return DTLR_MFMA_32x32x16_H16(__builtin_bit_cast(f3_bf16x8_t, a), __builtin_bit_cast(f3_bf16x8_t, b), c, 0, 0, 0);
 }
 
 // Phase-A form: accumulator pinned to ARCHITECTURAL VGPRs.  The kernel needs 256 (Y^T) + 32 (H^T) accumulator registers; left to itself
@@ -76,11 +76,11 @@ __device__ __forceinline__ float f3_relu(float x) { return __builtin_amdgcn_fmed
 typedef __attribute__((ext_vector_type(4))) unsigned f3_u32x4_t;
 __device__ __forceinline__ void f3_mma_v0(const uint4& a, const uint4& b, f3_f32x16_t& c) {        // c = a b (first k-step of a chunk)
     const f3_u32x4_t av = {a.x, a.y, a.z, a.w}, bv = {b.x, b.y, b.z, b.w};
-    asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, 0" : "=&v"(c) : "v"(av), "v"(bv));
+    asm volatile("v_mfma_f32_32x32x16_" DTLR_H16_ASM_SUFFIX " %0, %1, %2, 0" : "=&v"(c) : "v"(av), "v"(bv));
 }
 __device__ __forceinline__ void f3_mma_v(const uint4& a, const uint4& b, f3_f32x16_t& c) {
     const f3_u32x4_t av = {a.x, a.y, a.z, a.w}, bv = {b.x, b.y, b.z, b.w};
-    asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+v"(c) : "v"(av), "v"(bv));
+    asm volatile("v_mfma_f32_32x32x16_" DTLR_H16_ASM_SUFFIX " %0, %1, %2, %0" : "+v"(c) : "v"(av), "v"(bv));
 }
 
 // DBG (timing experiments only, env DTLR_FFN32_DBG; results are garbage): 1 = no weight DMA inside the chunk loop, 2 = no per-chunk
@@ -148,8 +148,8 @@ __global__ __launch_bounds__(256, 1) void ffn3_bf16_kernel(
 #pragma unroll
         for (int e2 = 0; e2 < 4; ++e2) {
             const int r0 = j - 8 * hh - 2 * e2, r1 = r0 - 16;             // element pair (2 e2, 2 e2 + 1): low half / high half of the dword
-            ia[e2] = (r0 == 0 ? 0x00003f80u : 0u) | (r0 == 1 ? 0x3f800000u : 0u);
-            ib[e2] = (r1 == 0 ? 0x00003f80u : 0u) | (r1 == 1 ? 0x3f800000u : 0u);
+            ia[e2] = (r0 == 0 ? H16_ONE : 0u) | (r0 == 1 ? (H16_ONE << 16) : 0u);
+            ib[e2] = (r1 == 0 ? H16_ONE : 0u) | (r1 == 1 ? (H16_ONE << 16) : 0u);
         }
         const uint4 Ia = make_uint4(ia[0], ia[1], ia[2], ia[3]), Ib = make_uint4(ib[0], ib[1], ib[2], ib[3]);
         f3_f32x16_t zero;
@@ -360,7 +360,7 @@ extern "C" int dtlr_ffn32_bf16(const void* X, const void* W1p, const float* b1, 
     if (!X || !W1p || !b1 || !W2p || !b2 || !gamma || !beta || !Y) return DTLR_EINVAL;
     if (M <= 0 || M > 0x7fffffffL) return DTLR_EINVAL;
     if (d_ff < 64 || d_ff > F3_MAX_DFF || (d_ff & 31)) return DTLR_ESHAPE;
-    static const int dbg = [] { const char* e = getenv("DTLR_FFN32_DBG"); return e ? atoi(e) : 0; }();      // timing experiments only
+    static const int dbg = exp_env_int("DTLR_FFN32_DBG", 0);      // experiment builds only: ablated variants whose results are garbage
 #define F3_LAUNCH(D)                                                                               \
     {                                                                                              \
         static DevOnce once;                                                                       \

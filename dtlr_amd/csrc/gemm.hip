@@ -30,7 +30,7 @@
 
 namespace dtlr {
 
-typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8_t;
+typedef __attribute__((ext_vector_type(8))) h16_hw_t bf16x8_t;
 typedef __attribute__((ext_vector_type(4))) float f32x4_t;
 
 constexpr int BM = 128, BN = 128, SLAB = 128, LDS_ROW = 128;      // bytes (rows unpadded; XOR-swizzled 16-byte chunks)
@@ -100,12 +100,12 @@ template <> struct GT<uint16_t> {   // bf16
         uint32_t o[4];
 #pragma unroll
         for (int i = 0; i < 4; ++i)
-            o[i] = pack_bf16x2(__uint_as_float(x[i] << 16) + __uint_as_float(y[i] << 16),
-                               __uint_as_float(x[i] & 0xffff0000u) + __uint_as_float(y[i] & 0xffff0000u));
+            o[i] = pack_bf16x2(h16_lo(x[i]) + h16_lo(y[i]),
+                               h16_hi(x[i]) + h16_hi(y[i]));
         return make_uint4(o[0], o[1], o[2], o[3]);
     }
     static __device__ __forceinline__ void mma(const uint4& w, const uint4& x, f32x4_t& acc) {
-        acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, w), __builtin_bit_cast(bf16x8_t, x), acc, 0, 0, 0);
+        acc = DTLR_MFMA_16x16x32_H16(__builtin_bit_cast(bf16x8_t, w), __builtin_bit_cast(bf16x8_t, x), acc, 0, 0, 0);
     }
 };
 template <> struct GT<float> {
@@ -134,10 +134,10 @@ template <> struct Out<float> {
 template <> struct Out<uint16_t> {
     using raw4 = uint2;
     static __device__ __forceinline__ void unpack4(const uint2& t, float (&v)[4]) {
-        v[0] = __uint_as_float(t.x << 16); v[1] = __uint_as_float(t.x & 0xffff0000u); v[2] = __uint_as_float(t.y << 16); v[3] = __uint_as_float(t.y & 0xffff0000u); }
+        v[0] = h16_lo(t.x); v[1] = h16_hi(t.x); v[2] = h16_lo(t.y); v[3] = h16_hi(t.y); }
     static __device__ __forceinline__ void ld4(const uint16_t* p, float (&v)[4]) {
         const uint2 t = *reinterpret_cast<const uint2*>(p);
-        v[0] = __uint_as_float(t.x << 16); v[1] = __uint_as_float(t.x & 0xffff0000u); v[2] = __uint_as_float(t.y << 16); v[3] = __uint_as_float(t.y & 0xffff0000u); }
+        v[0] = h16_lo(t.x); v[1] = h16_hi(t.x); v[2] = h16_lo(t.y); v[3] = h16_hi(t.y); }
     static __device__ __forceinline__ void st4(uint16_t* p, const float (&v)[4]) { *reinterpret_cast<uint2*>(p) = make_uint2(pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3])); }
     static __device__ __forceinline__ float ld(const uint16_t* p) { return bf16_to_f32(*p); }
     static __device__ __forceinline__ void st(uint16_t* p, float v) { *p = f32_to_bf16(v); }
@@ -911,8 +911,7 @@ static inline int plan_chain_ws(long ntiles) {
     return (int)per;
 }
 static inline bool use_ws() {
-    static int v = -1;
-    if (v < 0) { const char* e = getenv("DTLR_GEMM_WS"); v = (e && e[0] == '0') ? 0 : 1; }   // DTLR_GEMM_WS=0: uniform kernel (A/B timing)
+    static const int v = exp_env_int("DTLR_GEMM_WS", 1);      // experiment builds: =0 uniform kernel (A/B timing)
     return v == 1;
 }
 
@@ -1023,16 +1022,14 @@ static int try_splitk(const void* A, const void* W, const float* bias, const voi
 template <typename T, typename OutT> constexpr bool kSpecialise = (sizeof(T) == 2 && sizeof(OutT) == 2);
 
 static inline bool use_tall() {
-    static int v = -1;
-    if (v < 0) { const char* e = getenv("DTLR_GEMM_TALL"); v = (e && e[0] == '0') ? 0 : 1; }   // DTLR_GEMM_TALL=0: 128x128 tiles only (A/B timing)
+    static const int v = exp_env_int("DTLR_GEMM_TALL", 1);    // experiment builds: =0 128x128 tiles only (A/B timing)
     return v == 1;
 }
 
 // N <= 64, bf16 -> bf16, many token tiles: the 256 x 64 tile kernel.  N a multiple of 128 with K >= 512 (operand delivery from L2 is
 // the limit): the 256 x 128 tile kernel.  done = false: not applicable.
 static inline bool use_tall128() {
-    static int v = -1;
-    if (v < 0) { const char* e = getenv("DTLR_GEMM_TALL128"); v = (e && e[0] == '0') ? 0 : 1; }   // DTLR_GEMM_TALL128=0: 128 x 128 tiles (A/B timing)
+    static const int v = exp_env_int("DTLR_GEMM_TALL128", 1); // experiment builds: =0 128 x 128 tiles (A/B timing)
     return v == 1;
 }
 template <typename T, typename OutT, bool CONV>
@@ -1044,7 +1041,7 @@ static int try_tall(const void* X, const void* W, const float* bias, const void*
     else {
         if (!use_tall() || (N & 3) || (flags & ~(EPI_BIAS | EPI_RELU | EPI_RELU_POST | EPI_RESIDUAL | EPI_GELU))) return DTLR_OK;
         const int nM = (M + TALL_BM - 1) / TALL_BM;
-        static const int rr = [] { const char* e = getenv("DTLR_TALL_XCD"); return (e && e[0] == '0') ? 1 : 0; }();   // A/B timing only
+        static const int rr = exp_env_int("DTLR_TALL_XCD", 1) == 0 ? 1 : 0;   // experiment builds: =0 round-robin placement (A/B timing)
         if (N <= 64) {
             if (M < 64 * TALL_BM) return DTLR_OK;
             const long target = 2 * 256 * 2;
@@ -1205,12 +1202,12 @@ extern "C" int dtlr_gemm_nt(const void* A, const void* A2, const void* W, const 
     int flags = (bias ? EPI_BIAS : 0) | (relu == 1 ? EPI_RELU : 0) | (relu == 2 ? EPI_RELU_POST : 0) | (relu == 3 ? EPI_GELU : 0) |
                 (residual ? EPI_RESIDUAL : 0) | (row_mask ? EPI_ROWMASK : 0);
 #ifdef DTLR_GEMM_ABLATION
-    if (const char* ab = getenv("DTLR_GEMM_ABLATE")) flags |= (atoi(ab) & (DBG_NO_LOAD | DBG_NO_MMA | DBG_NO_LDS | DBG_NO_EPI | DBG_NO_STORE));   // timing experiments only
+    flags |= (exp_env_int("DTLR_GEMM_ABLATE", 0) & (DBG_NO_LOAD | DBG_NO_MMA | DBG_NO_LDS | DBG_NO_EPI | DBG_NO_STORE));   // timing experiments only
 #endif
     hipStream_t st = (hipStream_t)stream;
-    if (in_dtype == DTLR_BF16) {
+    if (in_dtype == DTLR_H16) {
         if (K % 64) return DTLR_ESHAPE;
-        if (out_dtype == DTLR_BF16) return launch_gemm<uint16_t, uint16_t>(A, A2, W, bias, residual, row_mask, C, M, N, K, flags, st);
+        if (out_dtype == DTLR_H16) return launch_gemm<uint16_t, uint16_t>(A, A2, W, bias, residual, row_mask, C, M, N, K, flags, st);
         if (out_dtype == DTLR_F32) return launch_gemm<uint16_t, float>(A, A2, W, bias, residual, row_mask, C, M, N, K, flags, st);
         return DTLR_EDTYPE;
     }
@@ -1232,7 +1229,7 @@ extern "C" int dtlr_gemm_nt_a2bcast(const void* A, const void* A2, int a2_rows, 
     if (!A || !A2 || !W || !C) return DTLR_EINVAL;
     if (M <= 0 || N <= 0 || K <= 0 || a2_rows <= 0 || M % a2_rows) return DTLR_EINVAL;
     const int flags = bias ? EPI_BIAS : 0;
-    if (dtype == DTLR_BF16) {
+    if (dtype == DTLR_H16) {
         if (K % 64) return DTLR_ESHAPE;
         return launch_gemm<uint16_t, uint16_t>(A, A2, W, bias, nullptr, nullptr, C, M, N, K, flags, (hipStream_t)stream, a2_rows);
     }
@@ -1253,7 +1250,7 @@ extern "C" int dtlr_gemm_nt_rowmax(const void* A, const void* W, const float* bi
     hipStream_t st = (hipStream_t)stream;
     if (hipMemsetD32Async((hipDeviceptr_t)rowmax, (int)0xff800000u, (size_t)M, st) != hipSuccess) { g_last_hip_error = (int)hipGetLastError(); return DTLR_ELAUNCH; }
     const int flags = (bias ? EPI_BIAS : 0) | EPI_ROWMAX;
-    if (in_dtype == DTLR_BF16) {
+    if (in_dtype == DTLR_H16) {
         if (K % 64) return DTLR_ESHAPE;
         return launch_gemm<uint16_t, float>(A, nullptr, W, bias, nullptr, nullptr, rowmax, M, N, K, flags, st);
     }
@@ -1289,7 +1286,7 @@ extern "C" int dtlr_conv2d_nhwc(const void* X, const void* W, const float* bias,
     clear_stale_error();
     if (!X || !W || !Y) return DTLR_EINVAL;
     if (B <= 0 || H <= 0 || Wd <= 0 || Cin <= 0 || Cout <= 0 || KH <= 0 || KW <= 0 || stride <= 0 || pad < 0) return DTLR_EINVAL;
-    const int elem = dtype == DTLR_BF16 ? 2 : dtype == DTLR_F32 ? 4 : 0;
+    const int elem = dtype == DTLR_H16 ? 2 : dtype == DTLR_F32 ? 4 : 0;
     if (!elem) return DTLR_EDTYPE;
     if ((Cin * elem) % SLAB) return DTLR_ESHAPE;                 // a K slab must stay inside one tap
     ConvP cp;
@@ -1303,10 +1300,10 @@ extern "C" int dtlr_conv2d_nhwc(const void* X, const void* W, const float* bias,
     int flags = (bias ? EPI_BIAS : 0) | (relu == 1 ? EPI_RELU : 0) | (relu == 2 ? EPI_RELU_POST : 0) | (residual ? EPI_RESIDUAL : 0);
     hipStream_t st = (hipStream_t)stream;
     // 3x3 / stride 1 / pad 1 without residual on enough pixels to fill the chip: the kernel that keeps the input patch in LDS (conv3x3.hip)
-    static const bool use_patch = [] { const char* e = getenv("DTLR_CONV_PATCH"); return !(e && e[0] == '0'); }();      // =0: implicit GEMM (A/B timing)
-    if (use_patch && dtype == DTLR_BF16 && KH == 3 && KW == 3 && stride == 1 && pad == 1 && !residual && M >= 16384
+    static const bool use_patch = exp_env_int("DTLR_CONV_PATCH", 1) != 0;      // experiment builds: =0 implicit GEMM (A/B timing)
+    if (use_patch && dtype == DTLR_H16 && KH == 3 && KW == 3 && stride == 1 && pad == 1 && !residual && M >= 16384
         && dtlr_conv3x3_patch_supported(Cin, Cout) == 1)
         return dtlr_conv3x3_patch_bf16(X, W, bias, Y, B, H, Wd, Cin, Cout, relu ? 1 : 0, stream);
-    if (dtype == DTLR_BF16) return launch_conv<uint16_t, uint16_t>(X, W, bias, residual, Y, (int)M, Cout, K, flags, cp, st);
+    if (dtype == DTLR_H16) return launch_conv<uint16_t, uint16_t>(X, W, bias, residual, Y, (int)M, Cout, K, flags, cp, st);
     return launch_conv<float, float>(X, W, bias, residual, Y, (int)M, Cout, K, flags, cp, st);
 }

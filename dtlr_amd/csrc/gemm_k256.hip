@@ -24,7 +24,7 @@
 
 namespace dtlr {
 
-typedef __attribute__((ext_vector_type(8))) __bf16 k2_bf16x8_t;
+typedef __attribute__((ext_vector_type(8))) h16_hw_t k2_bf16x8_t;
 typedef __attribute__((ext_vector_type(4))) float k2_f32x4_t;
 
 constexpr int K2_TOK = 64;                       // tokens per stage
@@ -65,7 +65,7 @@ __device__ __forceinline__ unsigned k2_load_u8(const void* p) {
     return r;
 }
 __device__ __forceinline__ k2_f32x4_t k2_mma(const uint4& a, const uint4& b, k2_f32x4_t c) {
-    return __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(k2_bf16x8_t, a), __builtin_bit_cast(k2_bf16x8_t, b), c, 0, 0, 0);
+    return DTLR_MFMA_16x16x32_H16(__builtin_bit_cast(k2_bf16x8_t, a), __builtin_bit_cast(k2_bf16x8_t, b), c, 0, 0, 0);
 }
 template <int N> __device__ __forceinline__ void k2_wait() {
     static_assert(N >= 0 && N < 64, "vmcnt is a 6-bit counter");
@@ -181,8 +181,8 @@ __global__ __launch_bounds__(512, 2) void gemm_k256_kernel(
             if (row_mask && msk[tt]) zero_bits |= 1u << tt;
 #pragma unroll
             for (int rt = 0; rt < NRT; ++rt)
-                acc[rt][tt] = k2_f32x4_t{bv[rt].x + __uint_as_float(rs[rt][tt].x << 16), bv[rt].y + __uint_as_float(rs[rt][tt].x & 0xffff0000u),
-                                         bv[rt].z + __uint_as_float(rs[rt][tt].y << 16), bv[rt].w + __uint_as_float(rs[rt][tt].y & 0xffff0000u)};
+                acc[rt][tt] = k2_f32x4_t{bv[rt].x + h16_lo(rs[rt][tt].x), bv[rt].y + h16_hi(rs[rt][tt].x),
+                                         bv[rt].z + h16_lo(rs[rt][tt].y), bv[rt].w + h16_hi(rs[rt][tt].y)};
         }
     };
     if constexpr (RES) seed_accumulators();
@@ -359,7 +359,7 @@ __global__ __launch_bounds__(512, 2) void proj_ln_k256_kernel(
             sm[tt] = 0.f;
 #pragma unroll
             for (int e = 0; e < 8; ++e) {
-                const float r = (e & 1) ? __uint_as_float(rw[e >> 1] & 0xffff0000u) : __uint_as_float(rw[e >> 1] << 16);
+                const float r = (e & 1) ? h16_hi(rw[e >> 1]) : h16_lo(rw[e >> 1]);
                 v[tt][e] = acc[e >> 2][tt][e & 3] + bs[e] + r;
                 sm[tt] += v[tt][e];
             }
@@ -474,7 +474,7 @@ extern "C" int dtlr_gemm_k256(const void* A, const void* Wp, const float* bias, 
     const int per = (ntiles + grid - 1) / grid;
     const int g2 = (ntiles + per - 1) / per;
     hipStream_t st = (hipStream_t)stream;
-    static const bool pos_major = [] { const char* e = getenv("DTLR_K256_POS_MAJOR"); return !(e && e[0] == '0'); }();   // A/B timing only
+    static const bool pos_major = exp_env_int("DTLR_K256_POS_MAJOR", 1) != 0;   // experiment builds: A/B timing only
     const int n_img = (pos_major && resid && res_rows % K2_TOK == 0 && M % res_rows == 0 && M / res_rows > 1) ? M / res_rows : 0;
 #define K2_LAUNCH(NRT, RES)                                                                        \
     {                                                                                              \

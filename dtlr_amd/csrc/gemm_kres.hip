@@ -20,7 +20,7 @@
 
 namespace dtlr {
 
-typedef __attribute__((ext_vector_type(8))) __bf16 kr_bf16x8_t;
+typedef __attribute__((ext_vector_type(8))) h16_hw_t kr_bf16x8_t;
 typedef __attribute__((ext_vector_type(4))) float kr_f32x4_t;
 
 constexpr int KR_TOK = 64;
@@ -36,7 +36,7 @@ __device__ __forceinline__ uint4 kr_load16(const void* p) {
     return r;
 }
 __device__ __forceinline__ kr_f32x4_t kr_mma(const uint4& a, const uint4& b, kr_f32x4_t c) {
-    return __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(kr_bf16x8_t, a), __builtin_bit_cast(kr_bf16x8_t, b), c, 0, 0, 0);
+    return DTLR_MFMA_16x16x32_H16(__builtin_bit_cast(kr_bf16x8_t, a), __builtin_bit_cast(kr_bf16x8_t, b), c, 0, 0, 0);
 }
 template <int N> __device__ __forceinline__ void kr_wait() {
     static_assert(N >= 0 && N < 64, "vmcnt is a 6-bit counter");
@@ -169,7 +169,7 @@ __global__ __launch_bounds__(512, 2) void gemm_kres_kernel(
                     const uint32_t rw[4] = {rr.x, rr.y, rr.z, rr.w};
 #pragma unroll
                     for (int e = 0; e < 8; ++e)
-                        v[e] += (e & 1) ? __uint_as_float(rw[e >> 1] & 0xffff0000u) : __uint_as_float(rw[e >> 1] << 16);
+                        v[e] += (e & 1) ? h16_hi(rw[e >> 1]) : h16_lo(rw[e >> 1]);
                 }
                 if (relu) {
 #pragma unroll

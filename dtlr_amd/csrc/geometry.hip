@@ -207,7 +207,7 @@ extern "C" int dtlr_geometry(const unsigned char* mask, int B, int H, int W, con
     }
     if (B > 65535) return DTLR_ESHAPE;
     const dim3 grid(rows, B);
-    if (pos_dtype == DTLR_BF16)
+    if (pos_dtype == DTLR_H16)
         hipLaunchKernelGGL(geometry_kernel<uint16_t>, grid, dim3(256), 0, (hipStream_t)stream, mask, H, W, lv, S, level_embed, dim_ty, dim_tx,
                            mask_flat, keep, (uint16_t*)pos, valid_ratios, enc_ref, proposals);
     else if (pos_dtype == DTLR_F32)

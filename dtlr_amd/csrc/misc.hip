@@ -116,8 +116,8 @@ __global__ __launch_bounds__(256) void two_stage_gather_kernel(const void* __res
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
             const uint32_t lo = (uint32_t)__shfl(av[e], (lane & 31) + 32, 64);
-            const float x0 = __uint_as_float(av[e] << 16) + __uint_as_float(lo << 16);
-            const float x1 = __uint_as_float(av[e] & 0xffff0000u) + __uint_as_float(lo & 0xffff0000u);
+            const float x0 = h16_lo(av[e]) + h16_lo(lo);
+            const float x1 = h16_hi(av[e]) + h16_hi(lo);
             o[e] = pack_bf16x2(x0, x1);
         }
         if (lane < 32) reinterpret_cast<uint4*>(sel_x + r * 256)[lane] = make_uint4(o[0], o[1], o[2], o[3]);
@@ -145,7 +145,7 @@ extern "C" int dtlr_two_stage_gather(const void* om, const float* proposals, con
     if (B <= 0 || S <= 0 || k <= 0) return DTLR_EINVAL;
     const long rows = (long)B * k;
     const unsigned grid = (unsigned)((rows + 3) / 4);
-    if (dtype == DTLR_BF16) {
+    if (dtype == DTLR_H16) {
         if (!sel_x) return DTLR_EINVAL;
         hipLaunchKernelGGL(two_stage_gather_kernel<true>, dim3(grid), dim3(256), 0, (hipStream_t)stream, om, proposals, idx, sel_raw,
                            (uint16_t*)sel_x, prop_sel, init_box, S, k, rows);
@@ -176,7 +176,7 @@ extern "C" int dtlr_decoder_query_prep(const float* ref, const float* valid_rati
     const long total = (long)B * nq * 64;
     const long grid = (total + 255) / 256;
     hipStream_t st = (hipStream_t)stream;
-    if (sine_dtype == DTLR_BF16)
+    if (sine_dtype == DTLR_H16)
         hipLaunchKernelGGL((query_prep_kernel<uint16_t>), dim3((unsigned)grid), dim3(256), 0, st, ref, valid_ratios, dim_t, ref_in, (uint16_t*)sine, nq, L, total);
     else if (sine_dtype == DTLR_F32)
         hipLaunchKernelGGL((query_prep_kernel<float>), dim3((unsigned)grid), dim3(256), 0, st, ref, valid_ratios, dim_t, ref_in, (float*)sine, nq, L, total);

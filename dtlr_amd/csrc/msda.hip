@@ -66,7 +66,7 @@ template <> struct Vec<uint16_t, 8> {
         const uint4 t = *reinterpret_cast<const uint4*>(p);
         const uint32_t w[4] = {t.x, t.y, t.z, t.w};
 #pragma unroll
-        for (int i = 0; i < 4; ++i) { v[2 * i] = __uint_as_float(w[i] << 16); v[2 * i + 1] = __uint_as_float(w[i] & 0xffff0000u); }
+        for (int i = 0; i < 4; ++i) { v[2 * i] = h16_lo(w[i]); v[2 * i + 1] = h16_hi(w[i]); }
     }
     static __device__ __forceinline__ void store(uint16_t* p, const float (&v)[8]) {
         *reinterpret_cast<uint4*>(p) = make_uint4(pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3]),
@@ -75,21 +75,21 @@ template <> struct Vec<uint16_t, 8> {
         const uint4 t = *reinterpret_cast<const uint4*>(p);
         const uint32_t w[4] = {ok ? t.x : 0u, ok ? t.y : 0u, ok ? t.z : 0u, ok ? t.w : 0u};   // select on packed words
 #pragma unroll
-        for (int i = 0; i < 4; ++i) { v[2 * i] = __uint_as_float(w[i] << 16); v[2 * i + 1] = __uint_as_float(w[i] & 0xffff0000u); }
+        for (int i = 0; i < 4; ++i) { v[2 * i] = h16_lo(w[i]); v[2 * i + 1] = h16_hi(w[i]); }
     }
 };
 template <> struct Vec<uint16_t, 4> {
     static __device__ __forceinline__ void load(const uint16_t* p, float (&v)[4]) {
         const uint2 t = *reinterpret_cast<const uint2*>(p);
-        v[0] = __uint_as_float(t.x << 16); v[1] = __uint_as_float(t.x & 0xffff0000u);
-        v[2] = __uint_as_float(t.y << 16); v[3] = __uint_as_float(t.y & 0xffff0000u); }
+        v[0] = h16_lo(t.x); v[1] = h16_hi(t.x);
+        v[2] = h16_lo(t.y); v[3] = h16_hi(t.y); }
     static __device__ __forceinline__ void store(uint16_t* p, const float (&v)[4]) {
         *reinterpret_cast<uint2*>(p) = make_uint2(pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3])); }
     static __device__ __forceinline__ void load_sel(const uint16_t* p, bool ok, float (&v)[4]) {
         const uint2 t = *reinterpret_cast<const uint2*>(p);
         const uint32_t a = ok ? t.x : 0u, b = ok ? t.y : 0u;
-        v[0] = __uint_as_float(a << 16); v[1] = __uint_as_float(a & 0xffff0000u);
-        v[2] = __uint_as_float(b << 16); v[3] = __uint_as_float(b & 0xffff0000u); }
+        v[0] = h16_lo(a); v[1] = h16_hi(a);
+        v[2] = h16_lo(b); v[3] = h16_hi(b); }
 };
 template <> struct Vec<uint16_t, 1> {
     static __device__ __forceinline__ void load(const uint16_t* p, float (&v)[1]) { v[0] = bf16_to_f32(*p); }
@@ -152,8 +152,8 @@ template <> struct Raw<uint16_t, 4> {      // bf16: 4 channels = one 8-byte load
     static __device__ __forceinline__ raw_t ld(const uint16_t* p) { return *reinterpret_cast<const uint2*>(p); }
     static __device__ __forceinline__ void unpack(raw_t t, bool ok, float (&v)[4]) {
         const uint32_t a = ok ? t.x : 0u, b = ok ? t.y : 0u;          // select on the packed words
-        v[0] = __uint_as_float(a << 16); v[1] = __uint_as_float(a & 0xffff0000u);
-        v[2] = __uint_as_float(b << 16); v[3] = __uint_as_float(b & 0xffff0000u); }
+        v[0] = h16_lo(a); v[1] = h16_hi(a);
+        v[2] = h16_lo(b); v[3] = h16_hi(b); }
 };
 
 template <typename T, int VEC>
@@ -312,7 +312,7 @@ template <> __device__ __forceinline__ void load_row16<uint16_t>(const uint16_t*
     for (int i = 0; i < 2; ++i) { const uint4 t = reinterpret_cast<const uint4*>(p)[i];
         const uint32_t w[4] = {t.x, t.y, t.z, t.w};
 #pragma unroll
-        for (int j = 0; j < 4; ++j) { v[8 * i + 2 * j] = __uint_as_float(w[j] << 16); v[8 * i + 2 * j + 1] = __uint_as_float(w[j] & 0xffff0000u); } }
+        for (int j = 0; j < 4; ++j) { v[8 * i + 2 * j] = h16_lo(w[j]); v[8 * i + 2 * j + 1] = h16_hi(w[j]); } }
 }
 
 template <typename T, typename OT, int VEC, int REFD>
@@ -379,23 +379,14 @@ __global__ __launch_bounds__(256, sizeof(T) == 2 ? 2 : 3) void msda_fused_l4p4_k
 // every lane gets the other levels' 32 values by quad-broadcast DPP.  Each corner is then ONE 16-byte load per lane and
 // the four lanes of a quad read the 64 contiguous bytes of a pixel row (coalesced -- a first attempt that gave each lane a
 // whole level of its own made every load touch a private cache line and was 30% slower than the original).
-#ifdef DTLR_QUAD_SHFL        // experiment build (tools/experiments): the quad exchanges through ds_bpermute instead of DPP
-template <int CTRL> __device__ __forceinline__ int quad_src_lane() {
-    const int l = (int)(threadIdx.x & 63), q = l & 3;
-    return (l & ~3) | ((CTRL >> (2 * q)) & 3);
-}
-template <int CTRL> __device__ __forceinline__ float quad_bcast_f(float v) { return __shfl(v, quad_src_lane<CTRL>(), 64); }
-template <int CTRL> __device__ __forceinline__ int quad_bcast_i(int v) { return __shfl(v, quad_src_lane<CTRL>(), 64); }
-#else
 template <int CTRL> __device__ __forceinline__ float quad_bcast_f(float v) {
     return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, 0xf, 0xf, false));
 }
 template <int CTRL> __device__ __forceinline__ int quad_bcast_i(int v) { return __builtin_amdgcn_update_dpp(0, v, CTRL, 0xf, 0xf, false); }
-#endif
 __device__ __forceinline__ void unpack8_bf16(const uint4& t, float (&v)[8]) {
     const uint32_t w[4] = {t.x, t.y, t.z, t.w};
 #pragma unroll
-    for (int i = 0; i < 4; ++i) { v[2 * i] = __uint_as_float(w[i] << 16); v[2 * i + 1] = __uint_as_float(w[i] & 0xffff0000u); }
+    for (int i = 0; i < 4; ++i) { v[2 * i] = h16_lo(w[i]); v[2 * i + 1] = h16_hi(w[i]); }
 }
 template <typename OT> __device__ __forceinline__ void load8f(const OT* p, float (&v)[8]);
 template <> __device__ __forceinline__ void load8f<float>(const float* p, float (&v)[8]) {
@@ -409,7 +400,7 @@ template <> __device__ __forceinline__ void load4f<float>(const float* p, float 
 }
 template <> __device__ __forceinline__ void load4f<uint16_t>(const uint16_t* p, float (&v)[4]) {
     const uint2 t = *reinterpret_cast<const uint2*>(p);
-    v[0] = __uint_as_float(t.x << 16); v[1] = __uint_as_float(t.x & 0xffff0000u); v[2] = __uint_as_float(t.y << 16); v[3] = __uint_as_float(t.y & 0xffff0000u);
+    v[0] = h16_lo(t.x); v[1] = h16_hi(t.x); v[2] = h16_lo(t.y); v[3] = h16_hi(t.y);
 }
 
 template <int L_, typename OT, int REFD>
@@ -424,13 +415,7 @@ __device__ __forceinline__ void quad_level(const uint16_t* __restrict__ lbase, c
         for (int c = 0; c < 4; ++c) {
             const int o = quad_bcast_i<CTRL>(og[pt][c]);
             k[c] = quad_bcast_f<CTRL>(kg[pt][c]);
-#ifdef DTLR_GATHER_NT        // experiment build: the gather bypasses the vector L1 (non-temporal loads are served by the L2)
-            typedef unsigned q_u32x4 __attribute__((ext_vector_type(4)));
-            const q_u32x4 t_ = __builtin_nontemporal_load(reinterpret_cast<const q_u32x4*>(lbase + o));
-            d[c] = make_uint4(t_[0], t_[1], t_[2], t_[3]);
-#else
             d[c] = *reinterpret_cast<const uint4*>(lbase + o);
-#endif
         }
 #pragma unroll
         for (int c = 0; c < 4; ++c) {
@@ -598,7 +583,7 @@ extern "C" int dtlr_msda_forward(const void* value, const int64_t* shapes, const
     case DTLR_F64:
         if (D % 2 == 0) return launch_generic<double, double, double, 2>(value, shapes, lsi, loc, attn, N, S, M, D, L, Lq, P, out, st);
         return launch_generic<double, double, double, 1>(value, shapes, lsi, loc, attn, N, S, M, D, L, Lq, P, out, st);
-    case DTLR_BF16:
+    case DTLR_H16:
         if (hot && D % 4 == 0) return launch_l4p4<uint16_t, 4>(value, shapes, lsi, loc, attn, N, S, M, D, Lq, out, st);
         if (D % 8 == 0) return launch_generic<uint16_t, float, float, 8>(value, shapes, lsi, loc, attn, N, S, M, D, L, Lq, P, out, st);
         return launch_generic<uint16_t, float, float, 1>(value, shapes, lsi, loc, attn, N, S, M, D, L, Lq, P, out, st);
@@ -631,17 +616,17 @@ extern "C" int dtlr_msda_fused_forward_strided(const void* value, int value_row_
         if (ow_dtype == DTLR_F32) return launch_fused<float, float, 4>(value, shapes, lsi, ow, ref, ref_dim, N, S, M, D, Lq, out, st, vstride);
         return DTLR_EDTYPE;
     }
-    if (dtype == DTLR_BF16 && D == 32 && (long)S * vstride < (1L << 31)) {       // the hot configuration
+    if (dtype == DTLR_H16 && D == 32 && (long)S * vstride < (1L << 31)) {       // the hot configuration
         if (ow_dtype == DTLR_F32) return launch_fused_quad<float>(value, shapes, lsi, ow, ref, ref_dim, N, S, M, Lq, out, st, vstride);
-        if (ow_dtype == DTLR_BF16) return launch_fused_quad<uint16_t>(value, shapes, lsi, ow, ref, ref_dim, N, S, M, Lq, out, st, vstride);
+        if (ow_dtype == DTLR_H16) return launch_fused_quad<uint16_t>(value, shapes, lsi, ow, ref, ref_dim, N, S, M, Lq, out, st, vstride);
         return DTLR_EDTYPE;
     }
-    if (dtype == DTLR_BF16 && D % 4 == 0) {
+    if (dtype == DTLR_H16 && D % 4 == 0) {
         if (ow_dtype == DTLR_F32) return launch_fused<uint16_t, float, 4>(value, shapes, lsi, ow, ref, ref_dim, N, S, M, D, Lq, out, st, vstride);
-        if (ow_dtype == DTLR_BF16) return launch_fused<uint16_t, uint16_t, 4>(value, shapes, lsi, ow, ref, ref_dim, N, S, M, D, Lq, out, st, vstride);
+        if (ow_dtype == DTLR_H16) return launch_fused<uint16_t, uint16_t, 4>(value, shapes, lsi, ow, ref, ref_dim, N, S, M, D, Lq, out, st, vstride);
         return DTLR_EDTYPE;
     }
-    return (dtype == DTLR_F32 || dtype == DTLR_BF16) ? DTLR_ESHAPE : DTLR_EDTYPE;
+    return (dtype == DTLR_F32 || dtype == DTLR_H16) ? DTLR_ESHAPE : DTLR_EDTYPE;
 }
 
 extern "C" const char* dtlr_strerror(int code) {

@@ -36,7 +36,7 @@ template <> struct ET<uint16_t> {
     static __device__ __forceinline__ void unpack(uint4 t, float (&v)[8]) {
         const uint32_t w[4] = {t.x, t.y, t.z, t.w};
 #pragma unroll
-        for (int i = 0; i < 4; ++i) { v[2 * i] = __uint_as_float(w[i] << 16); v[2 * i + 1] = __uint_as_float(w[i] & 0xffff0000u); } }
+        for (int i = 0; i < 4; ++i) { v[2 * i] = h16_lo(w[i]); v[2 * i + 1] = h16_hi(w[i]); } }
     static __device__ __forceinline__ uint4 pack(const float (&v)[8]) {
         return make_uint4(pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3]), pack_bf16x2(v[4], v[5]), pack_bf16x2(v[6], v[7])); }
 };
@@ -52,7 +52,7 @@ template <> __device__ __forceinline__ void ld16f<uint16_t>(const uint16_t* p, f
     for (int i = 0; i < 2; ++i) { const uint4 t = reinterpret_cast<const uint4*>(p)[i];
         const uint32_t w[4] = {t.x, t.y, t.z, t.w};
 #pragma unroll
-        for (int j = 0; j < 4; ++j) { v[8 * i + 2 * j] = __uint_as_float(w[j] << 16); v[8 * i + 2 * j + 1] = __uint_as_float(w[j] & 0xffff0000u); } }
+        for (int j = 0; j < 4; ++j) { v[8 * i + 2 * j] = h16_lo(w[j]); v[8 * i + 2 * j + 1] = h16_hi(w[j]); } }
 }
 
 // number of columns j of a W_l-wide level whose centre (j+0.5)/W_l lies left of tile boundary t*TW0/W_0:
@@ -71,6 +71,9 @@ __device__ __forceinline__ int cols_left_of(int t, int TW0, int W0, int Wl) {
 // (|x| >= 65520 would become inf and |x| < 6e-8 zero; the sampled tensor is value_proj(LayerNorm output): O(1).)
 template <typename T> __device__ __forceinline__ uint4 stage_convert(const uint4& d);
 template <> __device__ __forceinline__ uint4 stage_convert<float>(const uint4& d) { return d; }
+#ifdef DTLR_HALF_IS_F16
+template <> __device__ __forceinline__ uint4 stage_convert<uint16_t>(const uint4& d) { return d; }      // the fp16 library's values ARE fp16
+#else
 template <> __device__ __forceinline__ uint4 stage_convert<uint16_t>(const uint4& d) {
     typedef _Float16 h2_t __attribute__((ext_vector_type(2)));
     typedef float f2_t __attribute__((ext_vector_type(2)));
@@ -78,11 +81,12 @@ template <> __device__ __forceinline__ uint4 stage_convert<uint16_t>(const uint4
     uint32_t o[4];
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
-        const f2_t f = {__uint_as_float(w[j] << 16), __uint_as_float(w[j] & 0xffff0000u)};
+        const f2_t f = {h16_lo(w[j]), h16_hi(w[j])};
         o[j] = __builtin_bit_cast(uint32_t, __builtin_convertvector(f, h2_t));
     }
     return make_uint4(o[0], o[1], o[2], o[3]);
 }
+#endif
 // acc += w * fp16 half of `data` (plain asm, not volatile: a pure function of its inputs, the compiler schedules it freely)
 __device__ __forceinline__ float fma_mix_lo(float w, uint32_t data, float acc) {
     float d;
@@ -120,7 +124,7 @@ template <> __device__ __forceinline__ void ld4f<float>(const float* p, float (&
 }
 template <> __device__ __forceinline__ void ld4f<uint16_t>(const uint16_t* p, float (&v)[4]) {
     const uint2 t = *reinterpret_cast<const uint2*>(p);
-    v[0] = __uint_as_float(t.x << 16); v[1] = __uint_as_float(t.x & 0xffff0000u); v[2] = __uint_as_float(t.y << 16); v[3] = __uint_as_float(t.y & 0xffff0000u);
+    v[0] = h16_lo(t.x); v[1] = h16_hi(t.x); v[2] = h16_lo(t.y); v[3] = h16_hi(t.y);
 }
 
 template <typename OT>
@@ -284,8 +288,8 @@ template <> struct RowRaw<uint16_t> {
     }
     __device__ __forceinline__ void get(float (&o)[8], float (&l)[4]) const {
         ET<uint16_t>::unpack(off, o);
-        l[0] = __uint_as_float(lg.x << 16); l[1] = __uint_as_float(lg.x & 0xffff0000u);
-        l[2] = __uint_as_float(lg.y << 16); l[3] = __uint_as_float(lg.y & 0xffff0000u);
+        l[0] = h16_lo(lg.x); l[1] = h16_hi(lg.x);
+        l[2] = h16_lo(lg.y); l[3] = h16_hi(lg.y);
     }
 };
 template <> struct RowRaw<float> {
@@ -746,7 +750,7 @@ static int launch_enc(const void* value, const void* ow, const float* ref, void*
 // 2 the same with 512 threads per workgroup (default); read once per process.
 static int g_enc_variant = -1;
 static int enc_variant() {
-    if (g_enc_variant < 0) { const char* e = getenv("DTLR_MSDA_ENC_V"); g_enc_variant = e ? atoi(e) : 2; }
+    if (g_enc_variant < 0) { const int v = exp_env_int("DTLR_MSDA_ENC_V", 2); g_enc_variant = (v >= 0 && v <= 2) ? v : 2; }
     return g_enc_variant;
 }
 
@@ -768,7 +772,7 @@ extern "C" int dtlr_msda_encoder_set_variant(int v)
 extern "C" int dtlr_msda_encoder_plan_ok(const int* level_hw, int dtype, int halo)
 {
     if (!level_hw || halo < 0) return DTLR_EINVAL;
-    if (dtype != DTLR_F32 && dtype != DTLR_BF16) return DTLR_EDTYPE;
+    if (dtype != DTLR_F32 && dtype != DTLR_H16) return DTLR_EDTYPE;
     EncPlan pl;
     return make_plan(level_hw, dtype == DTLR_F32 ? 4 : 2, halo, pl) ? 1 : 0;
 }
@@ -787,7 +791,7 @@ extern "C" int dtlr_msda_encoder_far_samples(const void* ow, const float* ref, c
     hipStream_t st = (hipStream_t)stream;
     if (ow_dtype == DTLR_F32)
         hipLaunchKernelGGL(msda_enc_far_count_kernel<float>, dim3(pl.ntiles, M, N), dim3(256), 0, st, (const float*)ow, ref, pl.lv, pl.S, M, pl.TW0, pl.R, counts);
-    else if (ow_dtype == DTLR_BF16)
+    else if (ow_dtype == DTLR_H16)
         hipLaunchKernelGGL(msda_enc_far_count_kernel<uint16_t>, dim3(pl.ntiles, M, N), dim3(256), 0, st, (const uint16_t*)ow, ref, pl.lv, pl.S, M, pl.TW0, pl.R, counts);
     else return DTLR_EDTYPE;
     return check_launch();
@@ -806,12 +810,12 @@ extern "C" int dtlr_msda_encoder_forward(const void* value, const void* ow, cons
     if (!make_plan(level_hw, elem, halo, pl)) return DTLR_ESHAPE;
     hipStream_t st = (hipStream_t)stream;
     if (dtype == DTLR_F32 && ow_dtype == DTLR_F32) return launch_enc<float, float>(value, ow, ref, out, pl, N, M, st);
-    if (dtype == DTLR_BF16 && ow_dtype == DTLR_F32) {
+    if (dtype == DTLR_H16 && ow_dtype == DTLR_F32) {
         if (enc_variant() == 0) return launch_enc<uint16_t, float>(value, ow, ref, out, pl, N, M, st);
         if (enc_variant() == 1) return launch_enc<uint16_t, float, 1, 256>(value, ow, ref, out, pl, N, M, st);
         return launch_enc<uint16_t, float, 1, 512>(value, ow, ref, out, pl, N, M, st);
     }
-    if (dtype == DTLR_BF16 && ow_dtype == DTLR_BF16) {
+    if (dtype == DTLR_H16 && ow_dtype == DTLR_H16) {
         if (enc_variant() == 0) return launch_enc<uint16_t, uint16_t>(value, ow, ref, out, pl, N, M, st);
         if (enc_variant() == 1) return launch_enc<uint16_t, uint16_t, 1, 256>(value, ow, ref, out, pl, N, M, st);
         return launch_enc<uint16_t, uint16_t, 1, 512>(value, ow, ref, out, pl, N, M, st);

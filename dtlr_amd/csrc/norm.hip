@@ -19,8 +19,8 @@ template <> struct IO<float> {
 template <> struct IO<uint16_t> {   // bf16
     static __device__ __forceinline__ void load4(const uint16_t* p, float (&v)[4]) {
         const uint2 t = *reinterpret_cast<const uint2*>(p);
-        v[0] = __uint_as_float(t.x << 16); v[1] = __uint_as_float(t.x & 0xffff0000u);
-        v[2] = __uint_as_float(t.y << 16); v[3] = __uint_as_float(t.y & 0xffff0000u); }
+        v[0] = h16_lo(t.x); v[1] = h16_hi(t.x);
+        v[2] = h16_lo(t.y); v[3] = h16_hi(t.y); }
     static __device__ __forceinline__ void store4(uint16_t* p, const float (&v)[4]) {
         *reinterpret_cast<uint2*>(p) = make_uint2(pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3])); }
 };
@@ -149,14 +149,14 @@ extern "C" int dtlr_layernorm(const void* x, const void* residual, const float* 
         if (grid > 0x7fffffffL) return DTLR_ESHAPE;
         if (dtype == DTLR_F32)
             hipLaunchKernelGGL(layernorm_any_kernel<float>, dim3((unsigned)grid), dim3(256), 0, st, (const float*)x, (const float*)residual, gamma, beta, (float*)y, rows, C, eps);
-        else if (dtype == DTLR_BF16)
+        else if (dtype == DTLR_H16)
             hipLaunchKernelGGL(layernorm_any_kernel<uint16_t>, dim3((unsigned)grid), dim3(256), 0, st, (const uint16_t*)x, (const uint16_t*)residual, gamma, beta, (uint16_t*)y, rows, C, eps);
         else return DTLR_EDTYPE;
         return check_launch();
     }
     switch (dtype) {
     case DTLR_F32: return launch_ln<float>(x, residual, gamma, beta, y, rows, C, eps, st);
-    case DTLR_BF16: return launch_ln<uint16_t>(x, residual, gamma, beta, y, rows, C, eps, st);
+    case DTLR_H16: return launch_ln<uint16_t>(x, residual, gamma, beta, y, rows, C, eps, st);
     default: return DTLR_EDTYPE;
     }
 }
@@ -270,7 +270,7 @@ __global__ __launch_bounds__(256) void maxpool3x3s2_kernel(const T* __restrict__
                 const uint4 t = *reinterpret_cast<const uint4*>(src);
                 const uint32_t w4[4] = {t.x, t.y, t.z, t.w};
 #pragma unroll
-                for (int i = 0; i < 4; ++i) { v[2 * i] = __uint_as_float(w4[i] << 16); v[2 * i + 1] = __uint_as_float(w4[i] & 0xffff0000u); }
+                for (int i = 0; i < 4; ++i) { v[2 * i] = h16_lo(w4[i]); v[2 * i + 1] = h16_hi(w4[i]); }
             } else if (VEC == 4) IO<T>::load4(src, *reinterpret_cast<float (*)[4]>(v));
             else { IO<T>::load4(src, *reinterpret_cast<float (*)[4]>(v)); IO<T>::load4(src + 4, *reinterpret_cast<float (*)[4]>(v + 4)); }
 #pragma unroll
@@ -329,7 +329,7 @@ extern "C" int dtlr_groupnorm_tokens_strided(const void* x, const float* gamma, 
     if (dtype == DTLR_F32) {
         hipLaunchKernelGGL((gn_partial_kernel<float>), dim3(nslab, B), dim3(256), 0, st, (const float*)x, (float2*)workspace, T_tokens, rows_per_slab);
         hipLaunchKernelGGL((gn_apply_kernel<float>), dim3(nblk, B), dim3(256), 0, st, (const float*)x, (const float2*)workspace, gamma, beta, (float*)y, T_tokens, nslab, rows_per_block, eps, ybs);
-    } else if (dtype == DTLR_BF16) {
+    } else if (dtype == DTLR_H16) {
         hipLaunchKernelGGL((gn_partial_kernel<uint16_t>), dim3(nslab, B), dim3(256), 0, st, (const uint16_t*)x, (float2*)workspace, T_tokens, rows_per_slab);
         hipLaunchKernelGGL((gn_apply_kernel<uint16_t>), dim3(nblk, B), dim3(256), 0, st, (const uint16_t*)x, (const float2*)workspace, gamma, beta, (uint16_t*)y, T_tokens, nslab, rows_per_block, eps, ybs);
     } else return DTLR_EDTYPE;
@@ -343,7 +343,7 @@ extern "C" int dtlr_maxpool3x3s2_nhwc(const void* x, void* y, const float* bias,
     if (B <= 0 || H <= 0 || W <= 0 || C <= 0) return DTLR_EINVAL;
     const int Ho = (H + 2 - 3) / 2 + 1, Wo = (W + 2 - 3) / 2 + 1;
     hipStream_t st = (hipStream_t)stream;
-    if (dtype == DTLR_BF16 && C % 8 == 0) {
+    if (dtype == DTLR_H16 && C % 8 == 0) {
         const long total = (long)B * Ho * Wo * (C / 8);
         hipLaunchKernelGGL((maxpool3x3s2_kernel<uint16_t, 8>), dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st,
                            (const uint16_t*)x, (uint16_t*)y, bias, relu, H, W, C, Ho, Wo, total);
@@ -351,6 +351,6 @@ extern "C" int dtlr_maxpool3x3s2_nhwc(const void* x, void* y, const float* bias,
         const long total = (long)B * Ho * Wo * (C / 4);
         hipLaunchKernelGGL((maxpool3x3s2_kernel<float, 4>), dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st,
                            (const float*)x, (float*)y, bias, relu, H, W, C, Ho, Wo, total);
-    } else return (dtype == DTLR_BF16 || dtype == DTLR_F32) ? DTLR_ESHAPE : DTLR_EDTYPE;
+    } else return (dtype == DTLR_H16 || dtype == DTLR_F32) ? DTLR_ESHAPE : DTLR_EDTYPE;
     return check_launch();
 }

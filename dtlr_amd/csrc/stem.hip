@@ -21,7 +21,7 @@
 
 namespace dtlr {
 
-typedef __attribute__((ext_vector_type(8))) __bf16 stem_bf16x8_t;
+typedef __attribute__((ext_vector_type(8))) h16_hw_t stem_bf16x8_t;
 typedef __attribute__((ext_vector_type(4))) float stem_f32x4_t;
 
 constexpr int STEM_ROWS = 4, STEM_COLS = 256;               // conv outputs per workgroup
@@ -32,7 +32,7 @@ constexpr int STEM_LDS = 3 * STEM_IN_ROWS * STEM_PITCH * 2; // 49920 B
 
 __device__ __forceinline__ stem_f32x4_t stem_mma(const uint4& a, uint32_t b0, uint32_t b1, uint32_t b2, uint32_t b3, stem_f32x4_t c) {
     const uint4 b = make_uint4(b0, b1, b2, b3);
-    return __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(stem_bf16x8_t, a), __builtin_bit_cast(stem_bf16x8_t, b), c, 0, 0, 0);
+    return DTLR_MFMA_16x16x32_H16(__builtin_bit_cast(stem_bf16x8_t, a), __builtin_bit_cast(stem_bf16x8_t, b), c, 0, 0, 0);
 }
 
 // x [B,3,H,W] fp32 ; wfrag [4][6][64][8] bf16 (fragment-major, see dtlr_stem_pack_weights) ; y [B,Ho,Wo,64] bf16
@@ -211,11 +211,7 @@ extern "C" int dtlr_stem_pack_weights(const float* w_oihw_host, unsigned short* 
                 for (int e = 0; e < 8; ++e) {
                     float v = 0.f;
                     if (pair < 21 && e < 7) v = w_oihw_host[(((16 * i + m) * 3 + pair / 7) * 7 + pair % 7) * 7 + e];
-                    uint32_t u;
-                    __builtin_memcpy(&u, &v, 4);
-                    if ((u & 0x7fffffffu) > 0x7f800000u) u = (u >> 16) | 0x40u;      // NaN stays NaN
-                    else { u += 0x7fffu + ((u >> 16) & 1u); u >>= 16; }               // round to nearest even
-                    wfrag_host[((i * 6 + ks) * 64 + lane) * 8 + e] = (unsigned short)u;
+                    wfrag_host[((i * 6 + ks) * 64 + lane) * 8 + e] = f32_to_h16_host(v);      // round to nearest even, NaN stays NaN
                 }
             }
     return DTLR_OK;
@@ -226,7 +222,7 @@ extern "C" int dtlr_stem_conv7x7(const float* x, const void* wfrag, void* y, int
     clear_stale_error();
     if (!x || !wfrag || !y) return DTLR_EINVAL;
     if (B <= 0 || H <= 0 || W <= 0) return DTLR_EINVAL;
-    if (out_dtype != DTLR_BF16) return DTLR_EDTYPE;
+    if (out_dtype != DTLR_H16) return DTLR_EDTYPE;
     const int Ho = (H + 6 - 7) / 2 + 1, Wo = (W + 6 - 7) / 2 + 1;
     static DevOnce attr;
     if (attr.first()) { (void)hipFuncSetAttribute((const void*)stem_conv7x7_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, STEM_LDS); (void)hipGetLastError(); }

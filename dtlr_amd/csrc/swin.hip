@@ -14,7 +14,7 @@
 
 namespace dtlr {
 
-typedef __attribute__((ext_vector_type(8))) __bf16 sw_bf16x8_t;
+typedef __attribute__((ext_vector_type(8))) h16_hw_t sw_bf16x8_t;
 typedef __attribute__((ext_vector_type(4))) float sw_f32x4_t;
 
 // ------------------------------------------------------------------------------------------------------------- patch embed
@@ -99,8 +99,8 @@ __global__ __launch_bounds__(256) void swin_patch_merge_kernel(const T* __restri
                 const T* p = x + ((b * H + yy) * W + xx) * (long)C + c;
                 if constexpr (sizeof(T) == 2) {
                     const uint2 t = *reinterpret_cast<const uint2*>(p);
-                    v[g][0] = __uint_as_float(t.x << 16); v[g][1] = __uint_as_float(t.x & 0xffff0000u);
-                    v[g][2] = __uint_as_float(t.y << 16); v[g][3] = __uint_as_float(t.y & 0xffff0000u);
+                    v[g][0] = h16_lo(t.x); v[g][1] = h16_hi(t.x);
+                    v[g][2] = h16_lo(t.y); v[g][3] = h16_hi(t.y);
                 } else {
                     const float4 t = *reinterpret_cast<const float4*>(p);
                     v[g][0] = t.x; v[g][1] = t.y; v[g][2] = t.z; v[g][3] = t.w;
@@ -198,7 +198,7 @@ __global__ __launch_bounds__(256) void swin_window_attn_kernel(const T* __restri
                 const uint4 d = *reinterpret_cast<const uint4*>(p);
                 const uint32_t wv[4] = {d.x, d.y, d.z, d.w};
 #pragma unroll
-                for (int e = 0; e < 4; ++e) { v[2 * e] = __uint_as_float(wv[e] << 16); v[2 * e + 1] = __uint_as_float(wv[e] & 0xffff0000u); }
+                for (int e = 0; e < 4; ++e) { v[2 * e] = h16_lo(wv[e]); v[2 * e + 1] = h16_hi(wv[e]); }
             } else {
                 const float4 d0 = reinterpret_cast<const float4*>(p)[0], d1 = reinterpret_cast<const float4*>(p)[1];
                 v[0] = d0.x; v[1] = d0.y; v[2] = d0.z; v[3] = d0.w; v[4] = d1.x; v[5] = d1.y; v[6] = d1.z; v[7] = d1.w;
@@ -254,7 +254,7 @@ __global__ __launch_bounds__(256) void swin_window_attn_kernel(const T* __restri
                     const int km = 16 * kt + n;                   // A-operand row = key (lane index n plays m)
                     const uint4 kf = *reinterpret_cast<const uint4*>(Ks + km * 64 + ((g ^ ((km >> 2) & 3)) * 16));
                     const uint4 qf = *reinterpret_cast<const uint4*>(Qs + qi * 64 + ((g ^ ((qi >> 2) & 3)) * 16));
-                    acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(sw_bf16x8_t, kf), __builtin_bit_cast(sw_bf16x8_t, qf), acc, 0, 0, 0);
+                    acc = DTLR_MFMA_16x16x32_H16(__builtin_bit_cast(sw_bf16x8_t, kf), __builtin_bit_cast(sw_bf16x8_t, qf), acc, 0, 0, 0);
                 } else {
                     const float* kr = reinterpret_cast<const float*>(Ks) + (16 * kt + n) * 33;
                     const float* qr = reinterpret_cast<const float*>(Qs) + qi * 33;
@@ -300,7 +300,7 @@ __global__ __launch_bounds__(256) void swin_window_attn_kernel(const T* __restri
                         const uint16_t* vr = vt + (16 * dt + n) * stride + 32 * kb + 4 * g;          // V^T row d = 16 dt + n
                         const uint2 lo = *reinterpret_cast<const uint2*>(vr), hi = *reinterpret_cast<const uint2*>(vr + 16);
                         const uint4 vf = make_uint4(lo.x, lo.y, hi.x, hi.y);
-                        o[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(sw_bf16x8_t, vf), __builtin_bit_cast(sw_bf16x8_t, pf), o[dt], 0, 0, 0);
+                        o[dt] = DTLR_MFMA_16x16x32_H16(__builtin_bit_cast(sw_bf16x8_t, vf), __builtin_bit_cast(sw_bf16x8_t, pf), o[dt], 0, 0, 0);
                     }
                 }
             }
@@ -340,14 +340,14 @@ extern "C" int dtlr_swin_patch_embed(const float* x, const float* w_kE, const fl
     clear_stale_error();
     if (!x || !w_kE || !bias || !gamma || !beta || !out) return DTLR_EINVAL;
     if (B <= 0 || H <= 0 || W <= 0) return DTLR_EINVAL;
-    if (out_dtype != DTLR_F32 && out_dtype != DTLR_BF16) return DTLR_EDTYPE;
+    if (out_dtype != DTLR_F32 && out_dtype != DTLR_H16) return DTLR_EDTYPE;
     const int Hp = (H + 3) / 4, Wp = (W + 3) / 4;
     if (Hp > 65535 || B > 65535) return DTLR_ESHAPE;
     const dim3 grid((Wp + 63) / 64, Hp, B);
     const size_t lds = (size_t)(64 * 49 + 48 * E) * 4;
     hipStream_t st = (hipStream_t)stream;
 #define PE_LAUNCH(OT, EQ) hipLaunchKernelGGL((swin_patch_embed_kernel<OT, EQ>), grid, dim3(256), lds, st, x, w_kE, bias, gamma, beta, (OT*)out, H, W, Hp, Wp, eps)
-#define PE_CASE(EQ) case 4 * EQ: if (out_dtype == DTLR_BF16) PE_LAUNCH(uint16_t, EQ); else PE_LAUNCH(float, EQ); break;
+#define PE_CASE(EQ) case 4 * EQ: if (out_dtype == DTLR_H16) PE_LAUNCH(uint16_t, EQ); else PE_LAUNCH(float, EQ); break;
     switch (E) {
         PE_CASE(8) PE_CASE(16) PE_CASE(24) PE_CASE(32) PE_CASE(48)
     default: return DTLR_ESHAPE;                               // embed_dim 32 / 64 / 96 / 128 / 192
@@ -368,7 +368,7 @@ extern "C" int dtlr_swin_patch_merge(const void* x, const float* gamma, const fl
     const long rows = (long)B * H2 * W2;
     const unsigned grid = (unsigned)((rows + 3) / 4);
     hipStream_t st = (hipStream_t)stream;
-    if (dtype == DTLR_BF16)
+    if (dtype == DTLR_H16)
         hipLaunchKernelGGL(swin_patch_merge_kernel<uint16_t>, dim3(grid), dim3(256), 0, st, (const uint16_t*)x, gamma, beta, (uint16_t*)y, H, W, C, H2, W2, rows, eps);
     else if (dtype == DTLR_F32)
         hipLaunchKernelGGL(swin_patch_merge_kernel<float>, dim3(grid), dim3(256), 0, st, (const float*)x, gamma, beta, (float*)y, H, W, C, H2, W2, rows, eps);
@@ -393,7 +393,7 @@ extern "C" int dtlr_swin_window_attn(const void* qkv, const float* qkv_bias, con
     const int nW = (P.Hp / window) * P.nWw;
     if (n_heads > 65535 || B > 65535) return DTLR_ESHAPE;
     hipStream_t st = (hipStream_t)stream;
-    if (dtype == DTLR_BF16) {
+    if (dtype == DTLR_H16) {
         const int lds = SwinLds<uint16_t>::bytes(P.NQ, P.NK);
         hipLaunchKernelGGL(swin_window_attn_kernel<uint16_t>, dim3(nW, n_heads, B), dim3(256), lds, st, (const uint16_t*)qkv, qkv_bias, rpb, (uint16_t*)out, P);
     } else if (dtype == DTLR_F32) {

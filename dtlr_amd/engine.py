@@ -13,13 +13,12 @@ section 3.1; every method cites the reference lines it replaces) but is laid out
   * aux heads for decoder layers 0..4 are skipped unless asked for (dino.py:339-354 computes all 6).
 
 All compute goes through dtlr_amd.ops (HIP kernels / ROCm libraries on the GPU).  `dtype` is the
-storage/compute type of activations and GEMM operands (float32 = parity path, bfloat16 = bench
-path); selection scores, softmax, normalisation statistics and box arithmetic are always fp32.
+storage/compute type of activations and GEMM operands (float32 = parity path; bfloat16 / float16 = the 16-bit
+MFMA paths, served by libdtlr_hip.so / libdtlr_hip_f16.so); selection scores, softmax, normalisation statistics and box arithmetic are always fp32.
 """
 from __future__ import annotations
 
 import math
-import os
 from typing import Dict, List, Optional, Sequence
 
 import torch
@@ -50,24 +49,24 @@ class DTLREngine:
         self._level_cache: Dict[tuple, tuple] = {}
         self.use_lds_msda = True       # encoder MSDA with LDS-staged windows (False: gather kernel)
         self.use_fused_ffn = True      # bf16: linear1+ReLU+linear2+residual+LayerNorm in one kernel (False: two GEMMs + LN)
-        self.use_k256 = os.environ.get("DTLR_K256", "1") != "0"   # bf16: weight-resident streaming kernel for the K = 256 projections over all tokens
-        self.use_pln_k256 = os.environ.get("DTLR_PLN_K256", "1") != "0"
-        self.use_ffn32 = os.environ.get("DTLR_FFN32", "1") != "0"
-        self.pln_k256_min_rows = int(os.environ.get("DTLR_PLN_K256_MIN", "16384"))
-        self.use_kres = os.environ.get("DTLR_KRES", "1") != "0"
-        self.use_kres_narrow = os.environ.get("DTLR_KRES_NARROW", "1") != "0"
-        self.msda_auto = os.environ.get("DTLR_MSDA_AUTO", "1") != "0"      # per-layer choice LDS-window / gather kernel from a far-sample probe
+        self.use_k256 = True   # bf16: weight-resident streaming kernel for the K = 256 projections over all tokens
+        self.use_pln_k256 = True
+        self.use_ffn32 = True
+        self.pln_k256_min_rows = 16384
+        self.use_kres = True
+        self.use_kres_narrow = True
+        self.msda_auto = True      # per-layer choice LDS-window / gather kernel from a far-sample probe
         self.msda_probe_every = 256
         self.msda_far_threshold = 0.012
         self._msda_state = {}
-        self.use_k256_small = self.use_k256 and os.environ.get("DTLR_K256_SMALL", "1") != "0"   # ... and for the encoder's output projection + LayerNorm
+        self.use_k256_small = True   # ... and for the encoder's output projection + LayerNorm
 
     # ------------------------------------------------------------------------------ packing
     def _put(self, name, t, dtype=None):
         self.w[name] = t.to(device=self.device, dtype=dtype or self.dtype).contiguous()
 
     def _put_conv(self, name, w, b):
-        elem = 2 if self.dtype == torch.bfloat16 else 4
+        elem = 2 if self.dtype in ops.H16 else 4
         if w.shape[2] == 1 and w.shape[3] == 1:      # 1x1 conv == linear over NHWC pixels: [Cout, Cin]
             self.w[name + ".w"] = w.flatten(1).to(device=self.device, dtype=self.dtype).contiguous()
         elif (w.shape[1] * elem) % 128 == 0:         # implicit-GEMM HIP kernel: [Cout, KH, KW, Cin]
@@ -86,7 +85,7 @@ class DTLREngine:
         cfg, f32 = self.cfg, torch.float32
         sp = cfg.swin_params()
         E, ws = sp["embed_dim"], sp["window_size"]
-        if self.dtype == torch.bfloat16 and E % 64:
+        if self.dtype in ops.H16 and E % 64:
             raise NotImplementedError(f"swin backbone with embed_dim {E}: the bf16 GEMM needs K a multiple of 64 (swin_B / swin_L); "
                                       "run this variant with the fp32 engine")
         b = "backbone.0."
@@ -155,8 +154,8 @@ class DTLREngine:
         b = "backbone.0.body."
         w1, b1 = _fold_bn(sd, b + "conv1.weight", b + "bn1")
         self.w["conv1.b"] = b1.to(device=self.device, dtype=torch.float32).contiguous()
-        if self.dtype == torch.bfloat16:               # bf16 engine: MFMA stem kernel, weights as a fragment image in registers
-            self.w["conv1.frag"] = ops.stem_pack_weights(w1).to(self.device)
+        if self.dtype in ops.H16:               # bf16 engine: MFMA stem kernel, weights as a fragment image in registers
+            self.w["conv1.frag"] = ops.stem_pack_weights(w1, self.dtype).to(self.device)
         else:                                          # fp32 engine: exact-fp32 direct-convolution stem kernel, k-major weights
             self.w["conv1.wk"] = ops.stem_pack_weights_f32(w1).to(self.device)
         for li, nblocks in enumerate(cfg.backbone_blocks, start=1):
@@ -225,7 +224,7 @@ class DTLREngine:
             self._put(f"enc_bbox{i}.b", sd[f"{t}enc_out_bbox_embed.layers.{i}.bias"], f32)
             self._put(f"bbox{i}.w", sd[f"bbox_embed.0.layers.{i}.weight"], f32)
             self._put(f"bbox{i}.b", sd[f"bbox_embed.0.layers.{i}.bias"], f32)
-            if i < 2 and self.dtype == torch.bfloat16:
+            if i < 2 and self.dtype in ops.H16:
                 # bf16 engine: the two hidden layers of the box MLPs run on the bf16 MFMA path (their input, the decoder
                 # state, is bf16 already); accumulation, the 256->4 output layer and all box arithmetic stay fp32.
                 # (As fp32-MFMA GEMMs these 16 launches of M = 28800 cost 43 us each: 0.7 ms of a 14.4 ms step.)
@@ -258,7 +257,7 @@ class DTLREngine:
 
     def _lin(self, name, x, relu=False, residual=None, a2=None, row_mask=None, out_dtype=None):
         w = self.w[name + ".w"]
-        if self.use_k256_small and x.dtype == torch.bfloat16 and not relu and residual is None and a2 is None and out_dtype in (None, torch.bfloat16) \
+        if self.use_k256_small and x.dtype in ops.H16 and not relu and residual is None and a2 is None and out_dtype in (None, x.dtype) \
                 and w.shape[1] == 256 and w.shape[0] in (256, 384) and x.numel() // 256 >= 16384 and x.is_contiguous():
             return ops.gemm_k256(x, self._k256w(name), w.shape[0], self.w[name + ".b"], row_mask=row_mask)     # plain K = 256 projections
         return ops.linear(x, w, self.w[name + ".b"], relu, residual, a2, row_mask, out_dtype)
@@ -269,11 +268,11 @@ class DTLREngine:
     def _proj_ln(self, proj, norm, a, residual):
         """output projection of an attention block + residual + post-norm (deformable_transformer.py:810-815, 847-870)."""
         w = self.w
-        if self.use_pln_k256 and a.dtype == torch.bfloat16 and a.shape[-1] == 256 and a.numel() // 256 >= self.pln_k256_min_rows:
+        if self.use_pln_k256 and a.dtype in ops.H16 and a.shape[-1] == 256 and a.numel() // 256 >= self.pln_k256_min_rows:
             if proj + ".wk" not in w:                          # large M (the encoder): weight-resident streaming form
                 w[proj + ".wk"] = ops.proj_ln_k256_pack(w[proj + ".w"])
             return ops.proj_ln_k256(a, w[proj + ".wk"], w[proj + ".b"], residual, w[norm + ".w"], w[norm + ".b"])
-        if self.use_fused_ffn and a.dtype == torch.bfloat16 and a.shape[-1] == 256:
+        if self.use_fused_ffn and a.dtype in ops.H16 and a.shape[-1] == 256:
             if proj + ".wp" not in w:                          # fragment-major copy of the projection weight, packed once
                 w[proj + ".wp"] = ops.proj_pack_w(w[proj + ".w"])
             return ops.proj_ln(a, w[proj + ".wp"], w[proj + ".b"], residual, w[norm + ".w"], w[norm + ".b"])
@@ -284,11 +283,11 @@ class DTLREngine:
         values, so [hs | hs] . [W_hi | W_lo]^T on the bf16 matrix cores is the fp32-weight product to ~2^-16 relative -- the
         fp32 MFMA path (a quarter of the rate, plus an fp32 copy of hs) is only used by the fp32 engine."""
         w = self.w
-        if self.use_fused_ffn and hs.dtype == torch.bfloat16:
+        if self.use_fused_ffn and hs.dtype in ops.H16:
             if "class.w2" not in w:
                 wf = w["class.w"].float()
-                hi = wf.bfloat16()
-                w["class.w2"] = torch.cat([hi, (wf - hi.float()).bfloat16()], 1).contiguous()
+                hi = wf.to(hs.dtype)
+                w["class.w2"] = torch.cat([hi, (wf - hi.float()).to(hs.dtype)], 1).contiguous()
             return ops.linear(torch.cat([hs, hs], -1), w["class.w2"], w["class.b"], out_dtype=torch.float32)
         return ops.linear(hs.float(), w["class.w"], w["class.b"])
 
@@ -296,7 +295,7 @@ class DTLREngine:
         """forward_ffn + post-norm (deformable_transformer.py:804-823, 876-880).  bf16 engine: one fused kernel, the
         d_ff-wide intermediate stays on chip; fp32 engine: two GEMMs + LayerNorm."""
         w = self.w
-        if self.use_fused_ffn and self.use_ffn32 and x.dtype == torch.bfloat16 and x.numel() // 256 >= 65536 and w[q + "ff1.w"].shape[0] % 32 == 0 \
+        if self.use_fused_ffn and self.use_ffn32 and x.dtype in ops.H16 and x.numel() // 256 >= 65536 and w[q + "ff1.w"].shape[0] % 32 == 0 \
                 and 64 <= w[q + "ff1.w"].shape[0] <= 2048:
             if q + "ff.p32" not in w:                           # both weights in the 32x32 fragment order, packed once
                 w[q + "ff.p32"] = ops.ffn32_pack(w[q + "ff1.w"], w[q + "ff2.w"])
@@ -328,7 +327,7 @@ class DTLREngine:
         # stem: own kernels for both engines, reading the NCHW fp32 image directly (bf16: MFMA; fp32: exact direct convolution);
         # the folded-BN shift, the ReLU and the max-pool run as ONE pass over the full-resolution map
         if "conv1.frag" in self.w:
-            x = ops.stem_conv7x7(x_nchw, self.w["conv1.frag"])
+            x = ops.stem_conv7x7(x_nchw, self.w["conv1.frag"], self.dtype)
         else:
             x = ops.stem_conv7x7_f32(x_nchw, self.w["conv1.wk"])
         x = ops.maxpool_nhwc(x, bias=self.w["conv1.b"], relu=True)
@@ -373,7 +372,7 @@ class DTLREngine:
         global path that stalls a wave on 16 dependent loads per point: at ~1.2% of such points it is as slow as the gather kernel
         (tools/msda_sweep.py: 0.47 ms at 2.7% against 0.31 ms flat).  The fraction depends on the checkpoint's offset heads, so it is
         MEASURED: a probe (dtlr_msda_encoder_far_samples, one small kernel + a 16-byte read-back) on a layer's first call and every
-        `msda_probe_every` calls after it; DTLR_MSDA_AUTO=0 pins the LDS kernel."""
+        `msda_probe_every` calls after it; `msda_auto = False` pins the LDS kernel."""
         if not self.msda_auto:
             return "lds"
         st = self._msda_state.setdefault(name, {"calls": 0, "mode": "lds", "far": None})
@@ -391,7 +390,7 @@ class DTLREngine:
         B, Lq, C = query.shape
         S = value_src.shape[1]
         M, L, P = cfg.nheads, cfg.num_feature_levels, n_points
-        k256 = self.use_k256 and query.dtype == torch.bfloat16 and C == 256 and Lq == S
+        k256 = self.use_k256 and query.dtype in ops.H16 and C == 256 and Lq == S
         if value is None:
             if k256:
                 value = ops.gemm_k256(value_src, self._k256w(name + ".value"), 256, self.w[name + ".value.b"],
@@ -434,7 +433,7 @@ class DTLREngine:
         ow_res = [None] * self.cfg.enc_layers
         if not g["has_padding"]:
             pos = pos[0]                                 # unpadded batch: one [S, 256] matrix for every image (L2-resident A2 operand)
-            if self.use_k256 and src.dtype == torch.bfloat16:
+            if self.use_k256 and src.dtype in ops.H16:
                 if "enc_ow_res" not in g:                # pos W^T + b per layer, [S, 384] bf16: computed once per shape (g is cached)
                     g["enc_ow_res"] = [self._lin(f"enc{n}.attn.ow", pos) for n in range(self.cfg.enc_layers)]
                 ow_res = g["enc_ow_res"]
@@ -450,14 +449,14 @@ class DTLREngine:
         The box MLP runs only on the selected rows (selection uses class scores only)."""
         cfg = self.cfg
         w = self.w
-        if self.use_fused_ffn and memory.dtype == torch.bfloat16 and cfg.hidden_dim == 256:
+        if self.use_fused_ffn and memory.dtype in ops.H16 and cfg.hidden_dim == 256:
             # bf16 engine: ONE kernel masks, projects and normalises, and writes output_memory as [hi | lo | hi] bf16; the class
             # head then runs on the bf16 matrix cores against [W_hi | W_hi | W_lo] (three-term split product, ~2^-16 relative:
             # selection scores as good as the fp32 MFMA path at a third of its time), and output_memory of the 900 selected rows
             # is rebuilt as hi + lo.
             if "enc_output.wp" not in w:
                 w["enc_output.wp"] = ops.proj_pack_w(w["enc_output.w"])
-                w["enc_class.w3"], w["enc_class.b3"] = ops.split_head_weight(w["enc_class.w"], w["enc_class.b"])
+                w["enc_class.w3"], w["enc_class.b3"] = ops.split_head_weight(w["enc_class.w"], w["enc_class.b"], dtype=memory.dtype)
             om = ops.proj_ln_split(memory, w["enc_output.wp"], w["enc_output.b"], g["keep"], w["enc_output_norm.w"], w["enc_output_norm.b"])
             # only max_c of the class head feeds the top-k: the GEMM's row-max epilogue (no [T, C] matrix, no reduction pass)
             scores = ops.linear_rowmax(om, w["enc_class.w3"], w["enc_class.b3"])
@@ -512,7 +511,7 @@ class DTLREngine:
         """sigmoid(bbox_embed(x) + inverse_sigmoid(ref)) (deformable_transformer.py:734-756; dino.py:339-354)."""
         return self._box_mlp("bbox", x, ref, mode=0)
 
-    def decoder(self, memory, ts, g, want_aux=False):
+    def decoder(self, memory, ts, g, want_aux=False, dbg=None):
         """TransformerDecoder.forward + DeformableTransformerDecoderLayer
         (deformable_transformer.py:652-766, 882-997), batch-first."""
         cfg = self.cfg
@@ -526,7 +525,7 @@ class DTLREngine:
         C = cfg.hidden_dim
         rmask = g["mask_flat"] if g["has_padding"] else None
         Nall = self.w["dec.value_all.w"].shape[0]
-        if self.use_k256 and memory.dtype == torch.bfloat16 and C == 256 and Nall % 384 == 0:
+        if self.use_k256 and memory.dtype in ops.H16 and C == 256 and Nall % 384 == 0:
             # weight-resident streaming kernel, 384 output channels per launch, written as column slices of one [B, S, N] buffer
             vall = torch.empty(memory.shape[:-1] + (Nall,), dtype=memory.dtype, device=memory.device)
             for j in range(Nall // 384):
@@ -554,25 +553,23 @@ class DTLREngine:
             # iterative box refinement (734-756)
             ref = self._refine(tgt, ref)
             refs.append(ref)
+            if dbg is not None:                                        # tools/error_budget.py: per-layer state
+                dbg.setdefault("tgt", []).append(tgt)
             if want_aux or n == cfg.dec_layers - 1:
                 hs.append(self._ln("dec.norm", tgt))
             else:
                 hs.append(None)
         return hs, refs
 
-    # ------------------------------------------------------------------------------ forward
-    @torch.no_grad()
-    def forward(self, x: torch.Tensor, mask: torch.Tensor, forced_topk: Optional[torch.Tensor] = None,
-                want_aux: bool = False, return_debug: bool = False, has_padding: bool = True) -> Dict[str, torch.Tensor]:
-        """x [B,3,H,W] fp32 (zero-padded), mask [B,H,W] bool (True = padding)  ->  DINO.forward's
-        dict (models/dino/dino.py:270-415): pred_logits [B,nq,C] raw, pred_boxes [B,nq,4] cxcywh."""
-        ops.require_cuda(x, "images")
-        cfg = self.cfg
-        B = x.shape[0]
-        feats = self.backbone_swin(x.float()) if cfg.is_swin else self.backbone(x.float())
+    def features(self, x):
+        """backbone maps (NHWC) + the extra stride-2 level's convolution (dino.py:290-311) and the level sizes."""
+        feats = self.backbone_swin(x.float()) if self.cfg.is_swin else self.backbone(x.float())
         level_hw = [(f.shape[1], f.shape[2]) for f in feats]
         last = self._conv(f"ip{len(feats)}", feats[-1], 2, 1)
         level_hw.append((last.shape[1], last.shape[2]))
+        return feats, last, level_hw
+
+    def geometry_for(self, x, mask, level_hw, has_padding=True):
         # geometry depends only on the canvas shape and the padding masks: for an unpadded batch it is
         # the same for every forward of that shape -> cached (SURVEY.md appendix C, legal savings)
         gkey = (tuple(x.shape), tuple(level_hw)) if not has_padding else None
@@ -583,18 +580,26 @@ class DTLREngine:
                 if len(self._shape_cache) > 8:
                     self._shape_cache.clear()
                 self._shape_cache[gkey] = g
-        # each level is normalised straight into its rows of the concatenated token matrix (no torch.cat pass)
+        return g
+
+    def tokens(self, feats, last, level_hw):
+        """input_proj + GroupNorm of every level (dino.py:115-136), each level normalised straight into its rows of the
+        concatenated token matrix (no torch.cat pass)."""
+        B = last.shape[0]
         S_tot = sum(h * w for h, w in level_hw)
-        src = torch.empty((B, S_tot, cfg.hidden_dim), dtype=self.dtype, device=x.device)
+        src = torch.empty((B, S_tot, self.cfg.hidden_dim), dtype=self.dtype, device=last.device)
         off = 0
-        for l, f in enumerate(feats + [last]):
+        for l, f in enumerate(list(feats) + [last]):
             t = self._lin(f"ip{l}", f.flatten(1, 2)) if l < len(feats) else f.flatten(1, 2)
             T_l = t.shape[1]
             ops.groupnorm_tokens(t, 32, self.w[f"ip{l}.gn.w"], self.w[f"ip{l}.gn.b"], out=src[:, off:off + T_l])
             off += T_l
-        memory = self.encoder(src, g)
-        ts = self.two_stage(memory, g, forced_topk)
-        hs, refs = self.decoder(memory, ts, g, want_aux)
+        return src
+
+    def heads(self, hs, refs, ts, want_aux=False):
+        """DINO.forward's tail (models/dino/dino.py:339-415): class / box heads of the last (and, on request, every) decoder layer
+        and the two-stage intermediate outputs."""
+        cfg = self.cfg
         n = cfg.dec_layers - 1
         out = {
             "pred_logits": self._class_head(hs[n]),
@@ -611,6 +616,24 @@ class DTLREngine:
         out["interm_outputs"] = {"pred_logits": interm_class, "pred_boxes": ts["ref_unsig"].sigmoid()}
         out["interm_outputs_for_matching_pre"] = {"pred_logits": interm_class, "pred_boxes": ts["init_box"]}
         out["dn_meta"] = None
+        return out
+
+    # ------------------------------------------------------------------------------ forward
+    @torch.no_grad()
+    def forward(self, x: torch.Tensor, mask: torch.Tensor, forced_topk: Optional[torch.Tensor] = None,
+                want_aux: bool = False, return_debug: bool = False, has_padding: bool = True) -> Dict[str, torch.Tensor]:
+        """x [B,3,H,W] fp32 (zero-padded), mask [B,H,W] bool (True = padding)  ->  DINO.forward's
+        dict (models/dino/dino.py:270-415): pred_logits [B,nq,C] raw, pred_boxes [B,nq,4] cxcywh."""
+        ops.require_cuda(x, "images")
+        cfg = self.cfg
+        B = x.shape[0]
+        feats, last, level_hw = self.features(x)
+        g = self.geometry_for(x, mask, level_hw, has_padding)
+        src = self.tokens(feats, last, level_hw)
+        memory = self.encoder(src, g)
+        ts = self.two_stage(memory, g, forced_topk)
+        hs, refs = self.decoder(memory, ts, g, want_aux)
+        out = self.heads(hs, refs, ts, want_aux)
         if return_debug:
             out["_debug"] = dict(memory=memory, topk_idx=ts["topk_idx"], topk_scores=ts["topk_scores"], src=src,
                                  feats=feats, geometry=g)

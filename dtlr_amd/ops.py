@@ -23,7 +23,23 @@ from . import _lib
 # checkpoint with an unusual head size can never bench on a library without anyone noticing.  bench.py prints this set.
 LIBRARY_BACKED: set = set()
 
-_DT = {torch.float32: _lib.DTLR_F32, torch.bfloat16: _lib.DTLR_BF16, torch.float64: _lib.DTLR_F64}
+_DT = {torch.float32: _lib.DTLR_F32, torch.bfloat16: _lib.DTLR_BF16, torch.float64: _lib.DTLR_F64, torch.float16: _lib.DTLR_F16}
+# The two 16-bit storage / MFMA-operand formats.  bf16 tensors are served by libdtlr_hip.so, fp16 tensors by libdtlr_hip_f16.so (the
+# same sources compiled with fp16 as "the" 16-bit format, csrc/dtlr_common.h): an operator picks the library from its operands.
+H16 = (torch.bfloat16, torch.float16)
+
+
+def _L(*ts):
+    """the library that serves these tensors / dtypes: the fp16 build if any of them is fp16, else the bf16 build."""
+    for t in ts:
+        if (t.dtype if torch.is_tensor(t) else t) == torch.float16:
+            return _lib.lib(torch.float16)
+    return _lib.lib()
+
+
+def _hdt(w):
+    """16-bit dtype a weight is packed in: its own if it already is one (the engine stores weights in its format), else bf16."""
+    return w.dtype if w.dtype in H16 else torch.bfloat16
 
 
 def require_cuda(t: torch.Tensor, what: str = "input") -> None:
@@ -71,10 +87,10 @@ def linear(x, w, b=None, relu=False, residual=None, a2=None, row_mask=None, out_
     K = x.shape[-1]
     N = w.shape[0]
     out_dtype = out_dtype or x.dtype
-    slab = 64 if x.dtype == torch.bfloat16 else 32
+    slab = 64 if x.dtype in H16 else 32
     if a2 is not None and a2.numel() != x.numel():
         # row-broadcast A2 ([S, K] against [B, S, K]: the position embedding of an unpadded batch): its own entry point
-        if not (x.dtype in (torch.bfloat16, torch.float32) and w.dtype == x.dtype and a2.dtype == x.dtype and out_dtype == x.dtype and K % slab == 0
+        if not (x.dtype in H16 + (torch.float32,) and w.dtype == x.dtype and a2.dtype == x.dtype and out_dtype == x.dtype and K % slab == 0
                 and not relu and residual is None and row_mask is None and a2.shape[-1] == K and (x.numel() // K) % (a2.numel() // K) == 0):
             raise _lib.DTLRError("ops.linear: a row-broadcast a2 needs same-dtype operands, K a slab multiple, M a multiple of a2's rows, "
                                  "and no ReLU / residual / row mask")
@@ -85,14 +101,14 @@ def linear(x, w, b=None, relu=False, residual=None, a2=None, row_mask=None, out_
         M, R2 = x.numel() // K, a2.numel() // K
         y = torch.empty(x.shape[:-1] + (N,), dtype=out_dtype, device=x.device)
         es = x.element_size()
-        with _Timed("gemm_bf16" if x.dtype == torch.bfloat16 else "gemm_f32", 2.0 * M * N * K,
+        with _Timed("gemm_bf16" if x.dtype in H16 else "gemm_f32", 2.0 * M * N * K,
                     float(M) * K * es + float(R2) * K * es + float(N) * K * es + float(M) * N * es, f"linear M{M} N{N} K{K}+a2bcast{R2}"):
-            code = _lib.lib().dtlr_gemm_nt_a2bcast(x.data_ptr(), a2.data_ptr(), R2, w.data_ptr(), 0 if b is None else b.data_ptr(), y.data_ptr(),
+            code = _L(x).dtlr_gemm_nt_a2bcast(x.data_ptr(), a2.data_ptr(), R2, w.data_ptr(), 0 if b is None else b.data_ptr(), y.data_ptr(),
                                                    M, N, K, _DT[x.dtype], _lib.current_stream())
         _lib.check(code, "dtlr_gemm_nt_a2bcast")
         return y
-    if x.dtype in (torch.bfloat16, torch.float32) and w.dtype == x.dtype and K % slab == 0 \
-            and (x.dtype == torch.bfloat16 or out_dtype == torch.float32):
+    if x.dtype in H16 + (torch.float32,) and w.dtype == x.dtype and K % slab == 0 \
+            and (x.dtype in H16 or out_dtype == torch.float32):
         x = x if x.is_contiguous() else x.contiguous()
         if a2 is not None and not a2.is_contiguous():
             a2 = a2.contiguous()
@@ -103,11 +119,11 @@ def linear(x, w, b=None, relu=False, residual=None, a2=None, row_mask=None, out_
             b = b.float()
         M = x.numel() // K
         y = torch.empty(x.shape[:-1] + (N,), dtype=out_dtype, device=x.device)
-        es, eo = x.element_size(), (2 if out_dtype == torch.bfloat16 else 4)
+        es, eo = x.element_size(), (2 if out_dtype in H16 else 4)
         nbytes = float(M) * K * es * (2 if a2 is not None else 1) + float(N) * K * es + float(M) * N * eo * (2 if residual is not None else 1)
         tag = f"linear M{M} N{N} K{K}" + ("+a2" if a2 is not None else "") + ("+res" if residual is not None else "") + ("" if out_dtype == x.dtype else "->f32")
-        with _Timed("gemm_bf16" if x.dtype == torch.bfloat16 else "gemm_f32", 2.0 * M * N * K, nbytes, tag):
-            code = _lib.lib().dtlr_gemm_nt(x.data_ptr(), 0 if a2 is None else a2.data_ptr(), w.data_ptr(),
+        with _Timed("gemm_bf16" if x.dtype in H16 else "gemm_f32", 2.0 * M * N * K, nbytes, tag):
+            code = _L(x).dtlr_gemm_nt(x.data_ptr(), 0 if a2 is None else a2.data_ptr(), w.data_ptr(),
                                            0 if b is None else b.data_ptr(), 0 if residual is None else residual.data_ptr(),
                                            0 if row_mask is None else row_mask.data_ptr(), y.data_ptr(),
                                            M, N, K, int(relu), _DT[x.dtype], _DT[out_dtype], _lib.current_stream())
@@ -124,7 +140,7 @@ def k256_pack(w):
     N, K = w.shape
     assert K == 256 and N in (256, 384)
     nrt = N // 128
-    return w.detach().to(torch.bfloat16).view(8, nrt, 16, 8, 4, 8).permute(0, 1, 3, 4, 2, 5).contiguous().view(-1)
+    return w.detach().to(_hdt(w)).view(8, nrt, 16, 8, 4, 8).permute(0, 1, 3, 4, 2, 5).contiguous().view(-1)
 
 
 def gemm_k256(x, wp, n_out: int, b=None, resid=None, row_mask=None, out=None):
@@ -132,18 +148,18 @@ def gemm_k256(x, wp, n_out: int, b=None, resid=None, row_mask=None, out=None):
     x [..., 256] bf16 contiguous; wp = k256_pack(W); resid [rows, n_out] bf16; row_mask [...] bool/uint8;
     out: optional [..., n_out] bf16 view whose last dim is contiguous (a column slice of a wider matrix)."""
     require_cuda(x, "x")
-    assert x.dtype == torch.bfloat16 and x.shape[-1] == 256 and wp.dtype == torch.bfloat16 and wp.numel() == n_out * 256
+    assert x.dtype in H16 and x.shape[-1] == 256 and wp.dtype in H16 and wp.numel() == n_out * 256
     x = x if x.is_contiguous() else x.contiguous()
     M = x.numel() // 256
     if out is None:
-        out = torch.empty(x.shape[:-1] + (n_out,), dtype=torch.bfloat16, device=x.device)
+        out = torch.empty(x.shape[:-1] + (n_out,), dtype=x.dtype, device=x.device)
         ldc = n_out
     else:
-        assert out.dtype == torch.bfloat16 and out.shape == x.shape[:-1] + (n_out,) and out.stride(-1) == 1
+        assert out.dtype in H16 and out.shape == x.shape[:-1] + (n_out,) and out.stride(-1) == 1
         ldc = out.stride(-2)
         assert all(out.stride(d) == out.stride(d + 1) * out.shape[d + 1] for d in range(out.dim() - 2)), "out: rows must be evenly strided"
     if resid is not None:
-        assert resid.dtype == torch.bfloat16 and resid.is_contiguous() and resid.shape[-1] == n_out
+        assert resid.dtype in H16 and resid.is_contiguous() and resid.shape[-1] == n_out
     if b is not None and b.dtype != torch.float32:
         b = b.float()
     if row_mask is not None:
@@ -151,7 +167,7 @@ def gemm_k256(x, wp, n_out: int, b=None, resid=None, row_mask=None, out=None):
         assert row_mask.numel() == M and row_mask.is_contiguous() and row_mask.dtype in (torch.bool, torch.uint8)
     nbytes = float(M) * 256 * 2 + float(n_out) * 256 * 2 + float(M) * n_out * 2
     with _Timed("gemm_bf16", 2.0 * M * n_out * 256, nbytes, f"k256 M{M} N{n_out} K256" + ("+resb" if resid is not None else "")):
-        code = _lib.lib().dtlr_gemm_k256(x.data_ptr(), wp.data_ptr(), 0 if b is None else b.data_ptr(),
+        code = _L(x).dtlr_gemm_k256(x.data_ptr(), wp.data_ptr(), 0 if b is None else b.data_ptr(),
                                          0 if resid is None else resid.data_ptr(), 0 if resid is None else resid.numel() // n_out,
                                          0 if row_mask is None else row_mask.data_ptr(), out.data_ptr(), ldc, M, n_out, _lib.current_stream())
     _lib.check(code, "dtlr_gemm_k256")
@@ -160,7 +176,7 @@ def gemm_k256(x, wp, n_out: int, b=None, resid=None, row_mask=None, out=None):
 
 def kres_supported(M: int, N: int, K: int, dtype) -> bool:
     """Shapes dtlr_gemm_kres takes (the HBM-streaming 1x1 convolutions of the ResNet bottlenecks)."""
-    return dtype == torch.bfloat16 and K in (64, 128, 256) and (N % 256 == 0 or N in (64, 128, 192)) and N >= 64 and M >= 16384
+    return dtype in H16 and K in (64, 128, 256) and (N % 256 == 0 or N in (64, 128, 192)) and N >= 64 and M >= 16384
 
 
 def kres_pack(w, np_pairs=None):
@@ -168,13 +184,13 @@ def kres_pack(w, np_pairs=None):
     block ((((slice 8 + wave) NP + p) 2 + e) KS + ks) lane (m, g) <- W[256 NP slice + 32 (wave NP + p) + 8 (m >> 2) + 4 e + (m & 3)][32 ks + 8 g ..]."""
     N, K = w.shape
     if N in (64, 128, 192):                    # one zero-padded 256-channel column
-        w = torch.cat([w.detach().to(torch.bfloat16), torch.zeros((256 - N, K), dtype=torch.bfloat16, device=w.device)])
+        w = torch.cat([w.detach().to(_hdt(w)), torch.zeros((256 - N, K), dtype=_hdt(w), device=w.device)])
         N = 256
     assert K in (64, 128, 256) and N % 256 == 0
     NP = np_pairs or (2 if (N % 512 == 0 and K <= 128) else 1)
     ns, KS = N // (256 * NP), K // 32
     # row index = 256 NP sl + 32 (wave NP + p) + 8 mh + 4 e + ml  with m = 4 mh + ml ; column = 32 ks + 8 g + x
-    v = w.detach().to(torch.bfloat16).view(ns, 8, NP, 4, 2, 4, KS, 4, 8)          # sl, wave, p, mh, e, ml, ks, g, x
+    v = w.detach().to(_hdt(w)).view(ns, 8, NP, 4, 2, 4, KS, 4, 8)          # sl, wave, p, mh, e, ml, ks, g, x
     return v.permute(0, 1, 2, 4, 6, 7, 3, 5, 8).contiguous().view(-1)             # sl, wave, p, e, ks, [g, mh, ml] = lane, x
 
 
@@ -183,18 +199,18 @@ def gemm_kres(x, wp, n_out: int, b=None, residual=None, relu: bool = False):
     (dtlr_gemm_kres); wp = kres_pack(W).  x [..., K] bf16, residual [..., n_out] bf16 or None."""
     require_cuda(x, "x")
     K = x.shape[-1]
-    assert x.dtype == torch.bfloat16 and wp.dtype == torch.bfloat16 and wp.numel() == max(n_out, 256) * K
+    assert x.dtype in H16 and wp.dtype in H16 and wp.numel() == max(n_out, 256) * K
     x = x if x.is_contiguous() else x.contiguous()
     M = x.numel() // K
     if residual is not None:
-        assert residual.dtype == torch.bfloat16 and residual.shape[-1] == n_out and residual.numel() == M * n_out
+        assert residual.dtype in H16 and residual.shape[-1] == n_out and residual.numel() == M * n_out
         residual = residual if residual.is_contiguous() else residual.contiguous()
     if b is not None and b.dtype != torch.float32:
         b = b.float()
-    out = torch.empty(x.shape[:-1] + (n_out,), dtype=torch.bfloat16, device=x.device)
+    out = torch.empty(x.shape[:-1] + (n_out,), dtype=x.dtype, device=x.device)
     nbytes = float(M) * K * 2 + float(n_out) * K * 2 + float(M) * n_out * 2 * (2 if residual is not None else 1)
     with _Timed("gemm_bf16", 2.0 * M * n_out * K, nbytes, f"kres M{M} N{n_out} K{K}" + ("+res" if residual is not None else "")):
-        code = _lib.lib().dtlr_gemm_kres(x.data_ptr(), wp.data_ptr(), 0 if b is None else b.data_ptr(),
+        code = _L(x).dtlr_gemm_kres(x.data_ptr(), wp.data_ptr(), 0 if b is None else b.data_ptr(),
                                          0 if residual is None else residual.data_ptr(), out.data_ptr(), M, n_out, K, 1 if relu else 0,
                                          _lib.current_stream())
     _lib.check(code, "dtlr_gemm_kres")
@@ -204,7 +220,7 @@ def gemm_kres(x, wp, n_out: int, b=None, residual=None, relu: bool = False):
 def kres_pack_bcast384(w):
     """[384, 256] weight -> the zero-padded 512-channel image of dtlr_gemm_kres_bcast384 (== dtlr_gemm_kres_pack_weights_bcast384)."""
     assert tuple(w.shape) == (384, 256)
-    wpad = torch.cat([w.detach().to(torch.bfloat16), torch.zeros((128, 256), dtype=torch.bfloat16, device=w.device)])
+    wpad = torch.cat([w.detach().to(_hdt(w)), torch.zeros((128, 256), dtype=_hdt(w), device=w.device)])
     return kres_pack(wpad, np_pairs=2)
 
 
@@ -212,15 +228,15 @@ def gemm_kres_bcast384(x, wp, resid):
     """x @ W.T + resid[m % rows] for W [384, 256]: the weight-resident streaming kernel with the row-broadcast residual DMA'd through LDS
     (dtlr_gemm_kres_bcast384); wp = kres_pack_bcast384(W); resid [rows, 384] bf16, rows % 64 == 0, M % rows == 0."""
     require_cuda(x, "x")
-    assert x.dtype == torch.bfloat16 and x.shape[-1] == 256 and wp.numel() == 512 * 256 and resid.dtype == torch.bfloat16
+    assert x.dtype in H16 and x.shape[-1] == 256 and wp.numel() == 512 * 256 and resid.dtype in H16
     assert resid.is_contiguous() and resid.shape[-1] == 384
     x = x if x.is_contiguous() else x.contiguous()
     M = x.numel() // 256
     rows = resid.numel() // 384
-    out = torch.empty(x.shape[:-1] + (384,), dtype=torch.bfloat16, device=x.device)
+    out = torch.empty(x.shape[:-1] + (384,), dtype=x.dtype, device=x.device)
     nbytes = float(M) * 256 * 2 + 384.0 * 256 * 2 + float(M) * 384 * 2
     with _Timed("gemm_bf16", 2.0 * M * 384 * 256, nbytes, f"kres M{M} N384 K256+resb"):
-        code = _lib.lib().dtlr_gemm_kres_bcast384(x.data_ptr(), wp.data_ptr(), resid.data_ptr(), rows, out.data_ptr(), M, _lib.current_stream())
+        code = _L(x).dtlr_gemm_kres_bcast384(x.data_ptr(), wp.data_ptr(), resid.data_ptr(), rows, out.data_ptr(), M, _lib.current_stream())
     _lib.check(code, "dtlr_gemm_kres_bcast384")
     return out
 
@@ -231,16 +247,16 @@ def linear_rowmax(x, w, b=None):
     only needs this maximum of the class head (deformable_transformer.py:341-345)."""
     require_cuda(x, "x")
     K, N = x.shape[-1], w.shape[0]
-    slab = 64 if x.dtype == torch.bfloat16 else 32
-    if x.dtype not in (torch.bfloat16, torch.float32) or w.dtype != x.dtype or K % slab:
+    slab = 64 if x.dtype in H16 else 32
+    if x.dtype not in H16 + (torch.float32,) or w.dtype != x.dtype or K % slab:
         raise _lib.DTLRError(f"ops.linear_rowmax: no HIP kernel for x {tuple(x.shape)} {x.dtype} @ w {tuple(w.shape)} {w.dtype}")
     x = x if x.is_contiguous() else x.contiguous()
     M = x.numel() // K
     out = torch.empty(x.shape[:-1], dtype=torch.float32, device=x.device)
     es = x.element_size()
-    with _Timed("gemm_bf16" if x.dtype == torch.bfloat16 else "gemm_f32", 2.0 * M * N * K, float(M) * K * es + float(N) * K * es + 4.0 * M,
+    with _Timed("gemm_bf16" if x.dtype in H16 else "gemm_f32", 2.0 * M * N * K, float(M) * K * es + float(N) * K * es + 4.0 * M,
                 f"rowmax M{M} N{N} K{K}"):
-        code = _lib.lib().dtlr_gemm_nt_rowmax(x.data_ptr(), w.data_ptr(), 0 if b is None else b.data_ptr(), out.data_ptr(),
+        code = _L(x).dtlr_gemm_nt_rowmax(x.data_ptr(), w.data_ptr(), 0 if b is None else b.data_ptr(), out.data_ptr(),
                                               M, N, K, _DT[x.dtype], _lib.current_stream())
     _lib.check(code, "dtlr_gemm_nt_rowmax")
     return out
@@ -253,15 +269,15 @@ def two_stage_gather(om, proposals, idx):
     require_cuda(om, "om")
     B, S, Wd = om.shape
     k = idx.shape[1]
-    split = om.dtype == torch.bfloat16
+    split = om.dtype in H16
     assert (split and Wd == 768) or (om.dtype == torch.float32 and Wd == 256), "om: [B,S,768] bf16 or [B,S,256] fp32"
     assert om.is_contiguous() and proposals.is_contiguous() and proposals.dtype == torch.float32 and idx.dtype == torch.int64
     idx = idx if idx.is_contiguous() else idx.contiguous()
     sel_raw = torch.empty((B, k, Wd), dtype=om.dtype, device=om.device)
-    sel_x = torch.empty((B, k, 256), dtype=torch.bfloat16, device=om.device) if split else None
+    sel_x = torch.empty((B, k, 256), dtype=om.dtype, device=om.device) if split else None
     prop_sel = torch.empty((B, k, 4), dtype=torch.float32, device=om.device)
     init_box = torch.empty((B, k, 4), dtype=torch.float32, device=om.device)
-    code = _lib.lib().dtlr_two_stage_gather(om.data_ptr(), proposals.data_ptr(), idx.data_ptr(), sel_raw.data_ptr(),
+    code = _L(om).dtlr_two_stage_gather(om.data_ptr(), proposals.data_ptr(), idx.data_ptr(), sel_raw.data_ptr(),
                                             None if sel_x is None else sel_x.data_ptr(), prop_sel.data_ptr(), init_box.data_ptr(),
                                             B, S, k, _DT[om.dtype], _lib.current_stream())
     _lib.check(code, "dtlr_two_stage_gather")
@@ -278,7 +294,7 @@ def layernorm(x, w, b, eps: float = 1e-5, residual=None):
         residual = residual.contiguous()
     y = torch.empty_like(x)
     rows = x.numel() // C
-    code = _lib.lib().dtlr_layernorm(x.data_ptr(), 0 if residual is None else residual.data_ptr(), w.data_ptr(), b.data_ptr(),
+    code = _L(x).dtlr_layernorm(x.data_ptr(), 0 if residual is None else residual.data_ptr(), w.data_ptr(), b.data_ptr(),
                                      y.data_ptr(), rows, C, eps, _DT[x.dtype], _lib.current_stream())
     _lib.check(code, "dtlr_layernorm")
     return y
@@ -288,25 +304,25 @@ def proj_pack_w(w):
     """[256,256] projection weight (bf16, any device) -> the fragment-major image dtlr_proj_ln_bf16 streams (bf16, same device)."""
     import numpy as np
     assert tuple(w.shape) == (256, 256)
-    src = np.ascontiguousarray(w.detach().to(torch.bfloat16).cpu().view(torch.int16).numpy()).view(np.uint16)
+    src = np.ascontiguousarray(w.detach().to(_hdt(w)).cpu().view(torch.int16).numpy()).view(np.uint16)
     out = np.empty(256 * 256, dtype=np.uint16)
-    code = _lib.lib().dtlr_proj_pack_weights(src.ctypes.data, out.ctypes.data)
+    code = _L(w).dtlr_proj_pack_weights(src.ctypes.data, out.ctypes.data)
     _lib.check(code, "dtlr_proj_pack_weights")
-    return torch.from_numpy(out.view(np.int16)).view(torch.bfloat16).to(w.device)
+    return torch.from_numpy(out.view(np.int16)).view(_hdt(w)).to(w.device)
 
 
 def proj_ln(a, wp, b, residual, ln_w, ln_b, eps: float = 1e-5):
     """LayerNorm(residual + a W^T + b) in ONE kernel (dtlr_proj_ln_bf16): the attention block's output projection with its
     post-norm; a, residual [..., 256] bf16, wp = proj_pack_w(W) (bf16, 65536 elements), b / LN params fp32."""
     require_cuda(a, "a")
-    assert a.dtype == torch.bfloat16 and residual.dtype == torch.bfloat16 and wp.dtype == torch.bfloat16 and a.shape[-1] == 256
+    assert a.dtype in H16 and residual.dtype in H16 and wp.dtype in H16 and a.shape[-1] == 256
     assert wp.numel() == 256 * 256 and wp.is_contiguous()
     a = a if a.is_contiguous() else a.contiguous()
     residual = residual if residual.is_contiguous() else residual.contiguous()
     y = torch.empty_like(residual)
     M = a.numel() // 256
     with _Timed("proj_ln_bf16", 2.0 * M * 256 * 256, 3.0 * M * 256 * 2 + 256 * 256 * 2):
-        code = _lib.lib().dtlr_proj_ln_bf16(a.data_ptr(), wp.data_ptr(), b.data_ptr(), residual.data_ptr(), ln_w.data_ptr(), ln_b.data_ptr(),
+        code = _L(a).dtlr_proj_ln_bf16(a.data_ptr(), wp.data_ptr(), b.data_ptr(), residual.data_ptr(), ln_w.data_ptr(), ln_b.data_ptr(),
                                             eps, y.data_ptr(), M, 256, _lib.current_stream())
     _lib.check(code, "dtlr_proj_ln_bf16")
     return y
@@ -316,20 +332,20 @@ def proj_ln_k256_pack(w):
     """[256, 256] projection weight -> the fragment-order image of dtlr_proj_ln_k256 (rows permuted so that a lane's two accumulator
     tiles are 8 consecutive channels): block ((wave*2 + e)*8 + ks) lane (m, g) <- W[32 wave + 8 (m>>2) + 4 e + (m&3)][32 ks + 8 g ..]."""
     assert tuple(w.shape) == (256, 256)
-    return w.detach().to(torch.bfloat16).view(8, 4, 2, 4, 8, 4, 8).permute(0, 2, 4, 5, 1, 3, 6).contiguous().view(-1)
+    return w.detach().to(_hdt(w)).view(8, 4, 2, 4, 8, 4, 8).permute(0, 2, 4, 5, 1, 3, 6).contiguous().view(-1)
 
 
 def proj_ln_k256(a, wp, b, residual, ln_w, ln_b, eps: float = 1e-5):
     """LayerNorm(residual + a W^T + b) for many rows (dtlr_proj_ln_k256: weights resident in registers, the a / residual tiles DMA'd
     through an LDS ring); wp = proj_ln_k256_pack(W).  Same result as proj_ln up to fp32 summation order in the statistics."""
     require_cuda(a, "a")
-    assert a.dtype == torch.bfloat16 and residual.dtype == torch.bfloat16 and wp.dtype == torch.bfloat16 and a.shape[-1] == 256 and wp.numel() == 65536
+    assert a.dtype in H16 and residual.dtype in H16 and wp.dtype in H16 and a.shape[-1] == 256 and wp.numel() == 65536
     a = a if a.is_contiguous() else a.contiguous()
     residual = residual if residual.is_contiguous() else residual.contiguous()
     y = torch.empty_like(residual)
     M = a.numel() // 256
     with _Timed("proj_ln_bf16", 2.0 * M * 256 * 256, 3.0 * M * 256 * 2 + 256 * 256 * 2):
-        code = _lib.lib().dtlr_proj_ln_k256(a.data_ptr(), wp.data_ptr(), b.data_ptr(), residual.data_ptr(), ln_w.data_ptr(), ln_b.data_ptr(),
+        code = _L(a).dtlr_proj_ln_k256(a.data_ptr(), wp.data_ptr(), b.data_ptr(), residual.data_ptr(), ln_w.data_ptr(), ln_b.data_ptr(),
                                             eps, y.data_ptr(), M, _lib.current_stream())
     _lib.check(code, "dtlr_proj_ln_k256")
     return y
@@ -340,31 +356,31 @@ def proj_ln_split(a, wp, b, keep, ln_w, ln_b, eps: float = 1e-5):
     bf16, wp = proj_pack_w(W), keep [...] uint8/bool or None -> [..., 768] bf16.  hi + lo reproduces the fp32 LayerNorm output to
     2^-17 relative; see split_head_weight for the matching class-head layout."""
     require_cuda(a, "a")
-    assert a.dtype == torch.bfloat16 and wp.dtype == torch.bfloat16 and a.shape[-1] == 256 and wp.numel() == 256 * 256
+    assert a.dtype in H16 and wp.dtype in H16 and a.shape[-1] == 256 and wp.numel() == 256 * 256
     a = a if a.is_contiguous() else a.contiguous()
     M = a.numel() // 256
     if keep is not None:
         keep = keep.reshape(-1)
         keep = (keep if keep.dtype in (torch.uint8, torch.bool) else (keep != 0)).contiguous()
         assert keep.numel() == M and keep.is_cuda
-    y = torch.empty(a.shape[:-1] + (768,), dtype=torch.bfloat16, device=a.device)
+    y = torch.empty(a.shape[:-1] + (768,), dtype=a.dtype, device=a.device)
     with _Timed("proj_ln_bf16", 2.0 * M * 256 * 256, 4.0 * M * 256 * 2 + 256 * 256 * 2):
-        code = _lib.lib().dtlr_proj_ln_split_bf16(a.data_ptr(), wp.data_ptr(), b.data_ptr(), keep.data_ptr() if keep is not None else None,
+        code = _L(a).dtlr_proj_ln_split_bf16(a.data_ptr(), wp.data_ptr(), b.data_ptr(), keep.data_ptr() if keep is not None else None,
                                                   ln_w.data_ptr(), ln_b.data_ptr(), eps, y.data_ptr(), M, 256, _lib.current_stream())
     _lib.check(code, "dtlr_proj_ln_split_bf16")
     return y
 
 
-def split_head_weight(w, b, pad_to: int = 64):
+def split_head_weight(w, b, pad_to: int = 64, dtype=torch.bfloat16):
     """fp32 head [C, 256] -> bf16 [Cp, 768] = [W_hi | W_hi | W_lo] (+ zero rows up to a multiple of `pad_to`) and an fp32 bias
     [Cp] whose padding is -inf, for use on a proj_ln_split activation: sum_k [hi|lo|hi][k] * [W_hi|W_hi|W_lo][k] =
     hi.W_hi + lo.W_hi + hi.W_lo, the three leading terms of the exact product."""
     C = w.shape[0]
     Cp = -(-C // pad_to) * pad_to
     wf = w.float()
-    hi = wf.bfloat16()
-    lo = (wf - hi.float()).bfloat16()
-    out = torch.zeros((Cp, 768), dtype=torch.bfloat16, device=w.device)
+    hi = wf.to(dtype)
+    lo = (wf - hi.float()).to(dtype)
+    out = torch.zeros((Cp, 768), dtype=dtype, device=w.device)
     out[:C, :256], out[:C, 256:512], out[:C, 512:] = hi, hi, lo
     bias = torch.full((Cp,), float("-inf"), dtype=torch.float32, device=w.device)
     bias[:C] = b.float()
@@ -373,7 +389,7 @@ def split_head_weight(w, b, pad_to: int = 64):
 
 def ffn_fused_supported(x, w1) -> bool:
     """The fused FFN kernel covers the bf16 engine at d_model 256, d_ff <= 2048 (multiple of 32)."""
-    return x.dtype == torch.bfloat16 and x.shape[-1] == 256 and w1.shape[0] % 32 == 0 and w1.shape[0] <= 2048
+    return x.dtype in H16 and x.shape[-1] == 256 and w1.shape[0] % 32 == 0 and w1.shape[0] <= 2048
 
 
 def ffn_pack_w2(w2):
@@ -392,9 +408,9 @@ def ffn32_pack(w1, w2):
     d_ff = w1.shape[0]
     assert tuple(w1.shape) == (d_ff, 256) and tuple(w2.shape) == (256, d_ff) and d_ff % 32 == 0 and 64 <= d_ff <= 2048
     nc = d_ff // 32
-    a = w1.detach().to(torch.bfloat16).view(nc, 32, 16, 2, 8).permute(0, 2, 3, 1, 4).reshape(nc, 8192)
-    b = w2.detach().to(torch.bfloat16).view(8, 32, nc, 2, 2, 2, 4).permute(2, 3, 0, 5, 1, 4, 6).reshape(nc, 8192)
-    pad = torch.zeros((FFN32_PAD, 8192), dtype=torch.bfloat16, device=w1.device)
+    a = w1.detach().to(_hdt(w1)).view(nc, 32, 16, 2, 8).permute(0, 2, 3, 1, 4).reshape(nc, 8192)
+    b = w2.detach().to(_hdt(w1)).view(8, 32, nc, 2, 2, 2, 4).permute(2, 3, 0, 5, 1, 4, 6).reshape(nc, 8192)
+    pad = torch.zeros((FFN32_PAD, 8192), dtype=a.dtype, device=w1.device)
     return torch.cat([a, pad]).contiguous().view(-1), torch.cat([b, pad]).contiguous().view(-1)
 
 
@@ -403,14 +419,14 @@ def ffn32(x, w1p, b1, w2p, b2, ln_w, ln_b, eps: float = 1e-5, out=None):
     workgroup); (w1p, w2p) = ffn32_pack(W1, W2).  Same result as ffn_fused up to fp32 summation order."""
     require_cuda(x, "x")
     d_ff = b1.numel()
-    assert x.dtype == torch.bfloat16 and x.shape[-1] == 256 and w1p.dtype == torch.bfloat16 and w2p.dtype == torch.bfloat16
+    assert x.dtype in H16 and x.shape[-1] == 256 and w1p.dtype in H16 and w2p.dtype in H16
     assert w1p.numel() == (d_ff // 32 + FFN32_PAD) * 8192 and w2p.numel() == w1p.numel()
     x = x if x.is_contiguous() else x.contiguous()
     y = torch.empty_like(x) if out is None else out
     assert y.is_contiguous() and y.shape == x.shape and y.dtype == x.dtype
     M = x.numel() // 256
     with _Timed("ffn_fused_bf16", 4.0 * M * 256 * d_ff, 2.0 * M * 256 * 2 + 2.0 * 256 * d_ff * 2):
-        code = _lib.lib().dtlr_ffn32_bf16(x.data_ptr(), w1p.data_ptr(), b1.data_ptr(), w2p.data_ptr(), b2.data_ptr(),
+        code = _L(x).dtlr_ffn32_bf16(x.data_ptr(), w1p.data_ptr(), b1.data_ptr(), w2p.data_ptr(), b2.data_ptr(),
                                           ln_w.data_ptr(), ln_b.data_ptr(), eps, y.data_ptr(), M, d_ff, _lib.current_stream())
     _lib.check(code, "dtlr_ffn32_bf16")
     return y
@@ -428,7 +444,7 @@ def ffn_fused(x, w1, b1, w2p, b2, ln_w, ln_b, eps: float = 1e-5, out=None):
     assert y.is_contiguous() and y.shape == x.shape and y.dtype == x.dtype
     M = x.numel() // x.shape[-1]
     with _Timed("ffn_fused_bf16", 4.0 * M * x.shape[-1] * w1.shape[0], 2.0 * M * 256 * 2 + 2.0 * w1.numel() * 2):
-        code = _lib.lib().dtlr_ffn_fused_bf16(x.data_ptr(), w1.data_ptr(), b1.data_ptr(), w2p.data_ptr(), b2.data_ptr(),
+        code = _L(x).dtlr_ffn_fused_bf16(x.data_ptr(), w1.data_ptr(), b1.data_ptr(), w2p.data_ptr(), b2.data_ptr(),
                                               ln_w.data_ptr(), ln_b.data_ptr(), eps, y.data_ptr(), M, x.shape[-1], w1.shape[0],
                                               _lib.current_stream())
     _lib.check(code, "dtlr_ffn_fused_bf16")
@@ -451,8 +467,8 @@ def conv2d_nhwc(x, w, bias, stride: int, padding: int, relu=False, residual=None
         es = x.element_size()
         nbytes = (float(x.numel()) / (stride * stride if KH == 1 else 1) + float(w.numel()) + float(B) * Ho * Wo * Cout * (2 if residual is not None else 1)) * es
         tag = f"conv{KH}x{KW}s{stride} M{B * Ho * Wo} N{Cout} K{KH * KW * Cin}" + ("+res" if residual is not None else "")
-        with _Timed("gemm_bf16" if x.dtype == torch.bfloat16 else "gemm_f32", 2.0 * B * Ho * Wo * Cout * KH * KW * Cin, nbytes, tag):
-            code = _lib.lib().dtlr_conv2d_nhwc(x.data_ptr(), w.data_ptr(), 0 if bias is None else bias.data_ptr(),
+        with _Timed("gemm_bf16" if x.dtype in H16 else "gemm_f32", 2.0 * B * Ho * Wo * Cout * KH * KW * Cin, nbytes, tag):
+            code = _L(x).dtlr_conv2d_nhwc(x.data_ptr(), w.data_ptr(), 0 if bias is None else bias.data_ptr(),
                                                0 if residual is None else residual.data_ptr(), y.data_ptr(),
                                                B, H, W, Cin, Cout, KH, KW, stride, padding, 2 if relu else 0,
                                                _DT[x.dtype], _lib.current_stream())
@@ -463,14 +479,14 @@ def conv2d_nhwc(x, w, bias, stride: int, padding: int, relu=False, residual=None
                          "own kernels: stem_conv7x7 / stem_conv7x7_f32); there is no library fallback")
 
 
-def stem_pack_weights(w_oihw):
+def stem_pack_weights(w_oihw, dtype=torch.bfloat16):
     """conv1.weight with the FrozenBN scale folded, [64,3,7,7] (any float dtype, any device) -> the 24 KB fragment-major
     bf16 weight image dtlr_stem_conv7x7 keeps in registers (uint16 tensor on the CPU; move it to the device once)."""
     import numpy as np
     w = np.ascontiguousarray(w_oihw.detach().float().cpu().numpy())
     assert w.shape == (64, 3, 7, 7)
     out = np.zeros(4 * 6 * 64 * 8, dtype=np.uint16)
-    code = _lib.lib().dtlr_stem_pack_weights(w.ctypes.data, out.ctypes.data)
+    code = _L(dtype).dtlr_stem_pack_weights(w.ctypes.data, out.ctypes.data)
     _lib.check(code, "dtlr_stem_pack_weights")
     return torch.from_numpy(out.view(np.int16)).clone()
 
@@ -491,20 +507,20 @@ def stem_conv7x7_f32(x_nchw, wk):
     x = x_nchw if x_nchw.is_contiguous() else x_nchw.contiguous()
     B, _, H, W = x.shape
     y = torch.empty((B, (H - 1) // 2 + 1, (W - 1) // 2 + 1, 64), dtype=torch.float32, device=x.device)
-    code = _lib.lib().dtlr_stem_conv7x7_f32(x.data_ptr(), wk.data_ptr(), y.data_ptr(), B, H, W, _lib.current_stream())
+    code = _L(x_nchw).dtlr_stem_conv7x7_f32(x.data_ptr(), wk.data_ptr(), y.data_ptr(), B, H, W, _lib.current_stream())
     _lib.check(code, "dtlr_stem_conv7x7_f32")
     return y
 
 
-def stem_conv7x7(x_nchw, wfrag):
+def stem_conv7x7(x_nchw, wfrag, out_dtype=torch.bfloat16):
     """ResNet stem 7x7/s2/p3 convolution 3 -> 64 on the bf16 MFMA (HIP kernel): x [B,3,H,W] fp32 NCHW -> [B,Ho,Wo,64] bf16
     NHWC, no bias (the max-pool pass applies the folded-BN shift + ReLU)."""
     require_cuda(x_nchw, "images")
     assert x_nchw.dtype == torch.float32 and x_nchw.dim() == 4 and x_nchw.shape[1] == 3
     x = x_nchw if x_nchw.is_contiguous() else x_nchw.contiguous()
     B, _, H, W = x.shape
-    y = torch.empty((B, (H - 1) // 2 + 1, (W - 1) // 2 + 1, 64), dtype=torch.bfloat16, device=x.device)
-    code = _lib.lib().dtlr_stem_conv7x7(x.data_ptr(), wfrag.data_ptr(), y.data_ptr(), B, H, W, _DT[torch.bfloat16], _lib.current_stream())
+    y = torch.empty((B, (H - 1) // 2 + 1, (W - 1) // 2 + 1, 64), dtype=out_dtype, device=x.device)
+    code = _L(out_dtype).dtlr_stem_conv7x7(x.data_ptr(), wfrag.data_ptr(), y.data_ptr(), B, H, W, _DT[out_dtype], _lib.current_stream())
     _lib.check(code, "dtlr_stem_conv7x7")
     return y
 
@@ -515,7 +531,7 @@ def maxpool_nhwc(x, k: int = 3, stride: int = 2, padding: int = 1, bias=None, re
     B, H, W, C = x.shape
     x = x if x.is_contiguous() else x.contiguous()
     y = torch.empty((B, (H - 1) // 2 + 1, (W - 1) // 2 + 1, C), dtype=x.dtype, device=x.device)
-    code = _lib.lib().dtlr_maxpool3x3s2_nhwc(x.data_ptr(), y.data_ptr(), 0 if bias is None else bias.data_ptr(), 1 if relu else 0,
+    code = _L(x).dtlr_maxpool3x3s2_nhwc(x.data_ptr(), y.data_ptr(), 0 if bias is None else bias.data_ptr(), 1 if relu else 0,
                                              B, H, W, C, _DT[x.dtype], _lib.current_stream())
     _lib.check(code, "dtlr_maxpool3x3s2_nhwc")
     return y
@@ -526,7 +542,7 @@ def groupnorm_tokens(x, groups: int, w, b, eps: float = 1e-5, out=None):
     group) over (C/groups channels x T positions) -- models/dino/dino.py:121-134 (HIP kernels)."""
     B, T, C = x.shape
     x = x if x.is_contiguous() else x.contiguous()
-    L_ = _lib.lib()
+    L_ = _L(x)
     ws = torch.empty(L_.dtlr_groupnorm_workspace_bytes(B, T), dtype=torch.uint8, device=x.device)
     # out: a [B, T, C] slice (dim 1) of a larger contiguous [B, S, C] token matrix -- the level is normalised straight into place
     y = torch.empty_like(x) if out is None else out
@@ -573,7 +589,7 @@ def msda_fused(value, spatial_shapes, level_start_index, ow, ref):
         st = torch.cuda.current_stream()
         a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         a.record(st)
-    code = _lib.lib().dtlr_msda_fused_forward_strided(value.data_ptr(), vs[1], spatial_shapes.data_ptr(), level_start_index.data_ptr(),
+    code = _L(value).dtlr_msda_fused_forward_strided(value.data_ptr(), vs[1], spatial_shapes.data_ptr(), level_start_index.data_ptr(),
                                                       ow.data_ptr(), ref.data_ptr(), ref.shape[-1], N, S, M, D, L, Lq, 4,
                                                       _DT[value.dtype], _DT[ow.dtype], out.data_ptr(), _lib.current_stream())
     _lib.check(code, "dtlr_msda_fused_forward_strided")
@@ -583,7 +599,7 @@ def msda_fused(value, spatial_shapes, level_start_index, ow, ref):
     return out
 
 
-MSDA_HALO = int(__import__("os").environ.get("DTLR_MSDA_HALO", "8"))
+MSDA_HALO = 8            # columns staged beyond a tile's own (level-0 pixels); tools/msda_sweep.py varies it
 
 
 def swin_patch_embed(x_nchw, w_kE, b, ln_w, ln_b, out_dtype, eps: float = 1e-5):
@@ -595,7 +611,7 @@ def swin_patch_embed(x_nchw, w_kE, b, ln_w, ln_b, out_dtype, eps: float = 1e-5):
     B, _, H, W = x.shape
     E = w_kE.shape[1]
     out = torch.empty((B, (H + 3) // 4, (W + 3) // 4, E), dtype=out_dtype, device=x.device)
-    code = _lib.lib().dtlr_swin_patch_embed(x.data_ptr(), w_kE.data_ptr(), b.data_ptr(), ln_w.data_ptr(), ln_b.data_ptr(), out.data_ptr(),
+    code = _L(out_dtype).dtlr_swin_patch_embed(x.data_ptr(), w_kE.data_ptr(), b.data_ptr(), ln_w.data_ptr(), ln_b.data_ptr(), out.data_ptr(),
                                             B, H, W, E, eps, _DT[out_dtype], _lib.current_stream())
     _lib.check(code, "dtlr_swin_patch_embed")
     return out
@@ -608,7 +624,7 @@ def swin_window_attn(qkv, qkv_bias, rpb, n_heads: int, window: int, shift: int):
     C = C3 // 3
     assert qkv.is_contiguous() and qkv_bias.dtype == torch.float32 and rpb.dtype == torch.float32 and rpb.is_contiguous()
     out = torch.empty((B, H, W, C), dtype=qkv.dtype, device=qkv.device)
-    code = _lib.lib().dtlr_swin_window_attn(qkv.data_ptr(), qkv_bias.data_ptr(), rpb.data_ptr(), out.data_ptr(), B, H, W, C, n_heads, window, shift,
+    code = _L(qkv).dtlr_swin_window_attn(qkv.data_ptr(), qkv_bias.data_ptr(), rpb.data_ptr(), out.data_ptr(), B, H, W, C, n_heads, window, shift,
                                             _DT[qkv.dtype], _lib.current_stream())
     _lib.check(code, "dtlr_swin_window_attn")
     return out
@@ -636,7 +652,7 @@ def swin_patch_merge(x, ln_w, ln_b, eps: float = 1e-5):
     B, H, W, C = x.shape
     x = x if x.is_contiguous() else x.contiguous()
     y = torch.empty((B, (H + 1) // 2, (W + 1) // 2, 4 * C), dtype=x.dtype, device=x.device)
-    code = _lib.lib().dtlr_swin_patch_merge(x.data_ptr(), ln_w.data_ptr(), ln_b.data_ptr(), y.data_ptr(), B, H, W, C, eps, _DT[x.dtype], _lib.current_stream())
+    code = _L(x).dtlr_swin_patch_merge(x.data_ptr(), ln_w.data_ptr(), ln_b.data_ptr(), y.data_ptr(), B, H, W, C, eps, _DT[x.dtype], _lib.current_stream())
     _lib.check(code, "dtlr_swin_patch_merge")
     return y
 
@@ -668,7 +684,7 @@ def geometry(mask, level_hw, level_embed, temperature_h: float, temperature_w: f
     vr = torch.empty((B, 4, 2), dtype=torch.float32, device=dev)
     enc_ref = torch.empty((B, S, 4, 2), dtype=torch.float32, device=dev)
     prop = torch.empty((B, S, 4), dtype=torch.float32, device=dev)
-    code = _lib.lib().dtlr_geometry(mask.data_ptr(), B, H, W, ctypes.cast(hw, ctypes.c_void_p), level_embed.data_ptr(),
+    code = _L(pos_dtype).dtlr_geometry(mask.data_ptr(), B, H, W, ctypes.cast(hw, ctypes.c_void_p), level_embed.data_ptr(),
                                     dim_ty.data_ptr(), dim_tx.data_ptr(), _DT[pos_dtype], mask_flat.data_ptr(), keep.data_ptr(),
                                     pos.data_ptr(), vr.data_ptr(), enc_ref.data_ptr(), prop.data_ptr(), _lib.current_stream())
     _lib.check(code, "dtlr_geometry")
@@ -679,7 +695,7 @@ def msda_encoder_fits(level_hw, dtype) -> bool:
     """Whether the LDS-window encoder kernel's plan fits these level shapes (it stages full-height column windows: canvases
     taller than ~270 px in fp32 / ~550 px in bf16 do not fit, and the caller uses msda_fused, the gather kernel, instead)."""
     hw = (ctypes.c_int * 8)(*[int(v) for pair in level_hw for v in pair])
-    rc = _lib.lib().dtlr_msda_encoder_plan_ok(ctypes.cast(hw, ctypes.c_void_p), _DT[dtype], MSDA_HALO)
+    rc = _L(dtype).dtlr_msda_encoder_plan_ok(ctypes.cast(hw, ctypes.c_void_p), _DT[dtype], MSDA_HALO)
     if rc < 0:
         _lib.check(rc, "dtlr_msda_encoder_plan_ok")
     return rc == 1
@@ -699,7 +715,7 @@ def msda_encoder(value, level_hw, ow, ref):
         st = torch.cuda.current_stream()
         a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         a.record(st)
-    code = _lib.lib().dtlr_msda_encoder_forward(value.data_ptr(), ow.data_ptr(), ref.data_ptr(), hw, N, M, D, 4, 4, MSDA_HALO,
+    code = _L(value).dtlr_msda_encoder_forward(value.data_ptr(), ow.data_ptr(), ref.data_ptr(), hw, N, M, D, 4, 4, MSDA_HALO,
                                                 _DT[value.dtype], _DT[ow.dtype], out.data_ptr(), _lib.current_stream())
     _lib.check(code, "dtlr_msda_encoder_forward")
     if ev is not None:
@@ -716,7 +732,7 @@ def msda_encoder_far_fraction(value_dtype, level_hw, ow, ref, n_heads: int = 8):
     import ctypes
     hw = (ctypes.c_int * 8)(*[int(v) for pair in level_hw for v in pair])
     counts = torch.zeros(2, dtype=torch.int64, device=ow.device)
-    code = _lib.lib().dtlr_msda_encoder_far_samples(ow.data_ptr(), ref.data_ptr(), hw, ow.shape[0], n_heads, MSDA_HALO, _DT[value_dtype],
+    code = _L(value_dtype).dtlr_msda_encoder_far_samples(ow.data_ptr(), ref.data_ptr(), hw, ow.shape[0], n_heads, MSDA_HALO, _DT[value_dtype],
                                                     _DT[ow.dtype], counts.data_ptr(), _lib.current_stream())
     _lib.check(code, "dtlr_msda_encoder_far_samples")
     far, inside = counts.tolist()
@@ -729,10 +745,10 @@ def mha(qk, v, n_heads: int):
     B, L, C2 = qk.shape
     C = C2 // 2
     hd = C // n_heads
-    if qk.dtype not in (torch.bfloat16, torch.float32) or hd != 32:
+    if qk.dtype not in H16 + (torch.float32,) or hd != 32:
         raise RuntimeError(f"dtlr_amd.ops.mha: unsupported dtype/head_dim {qk.dtype}/{hd}")
     qk, v = qk.contiguous(), v.contiguous()
-    L_ = _lib.lib()
+    L_ = _L(qk)
     ws = torch.empty(L_.dtlr_mha_workspace_bytes(B, L, n_heads, hd), dtype=torch.uint8, device=qk.device)
     out = torch.empty((B, L, C), dtype=qk.dtype, device=qk.device)
     code = L_.dtlr_mha_forward(qk.data_ptr(), v.data_ptr(), ws.data_ptr(), out.data_ptr(), B, L, n_heads, hd,
@@ -756,7 +772,7 @@ def decoder_query_prep(ref, valid_ratios, out_dtype):
     valid_ratios = valid_ratios.contiguous()
     ref_in = torch.empty((B, nq, L, 4), dtype=torch.float32, device=ref.device)
     sine = torch.empty((B, nq, 512), dtype=out_dtype, device=ref.device)
-    code = _lib.lib().dtlr_decoder_query_prep(ref.data_ptr(), valid_ratios.data_ptr(), _DIM_T[key].data_ptr(), ref_in.data_ptr(),
+    code = _L(out_dtype).dtlr_decoder_query_prep(ref.data_ptr(), valid_ratios.data_ptr(), _DIM_T[key].data_ptr(), ref_in.data_ptr(),
                                               sine.data_ptr(), B, nq, L, _DT[out_dtype], _lib.current_stream())
     _lib.check(code, "dtlr_decoder_query_prep")
     return ref_in, sine
@@ -767,11 +783,11 @@ def box_mlp_refine(x, w1, b1, w2p, b2, w3, b3, ref, mode: int = 0):
     w2p = ffn_pack_w2(W2) bf16, W3 [4,256] / biases fp32, ref [..,4] fp32 -> [..,4] fp32.
     mode 0: sigmoid(mlp(x) + inverse_sigmoid(ref)); mode 1: mlp(x) + ref."""
     require_cuda(x, "x")
-    assert x.dtype == torch.bfloat16 and x.shape[-1] == 256 and ref.dtype == torch.float32 and w3.dtype == torch.float32
+    assert x.dtype in H16 and x.shape[-1] == 256 and ref.dtype == torch.float32 and w3.dtype == torch.float32
     x = x if x.is_contiguous() else x.contiguous()
     ref = ref if ref.is_contiguous() else ref.contiguous()
     out = torch.empty_like(ref)
-    code = _lib.lib().dtlr_box_mlp_refine_bf16(x.data_ptr(), w1.data_ptr(), b1.data_ptr(), w2p.data_ptr(), b2.data_ptr(), w3.data_ptr(),
+    code = _L(x).dtlr_box_mlp_refine_bf16(x.data_ptr(), w1.data_ptr(), b1.data_ptr(), w2p.data_ptr(), b2.data_ptr(), w3.data_ptr(),
                                                b3.data_ptr(), ref.data_ptr(), out.data_ptr(), x.numel() // 256, mode, _lib.current_stream())
     _lib.check(code, "dtlr_box_mlp_refine_bf16")
     return out
@@ -785,7 +801,7 @@ def box_head_refine(h, w, b, ref, mode: int = 0):
     h = h if h.is_contiguous() else h.contiguous()
     ref = ref if ref.is_contiguous() else ref.contiguous()
     out = torch.empty_like(ref)
-    code = _lib.lib().dtlr_box_head_refine(h.data_ptr(), w.data_ptr(), b.data_ptr(), ref.data_ptr(), out.data_ptr(),
+    code = _L(h).dtlr_box_head_refine(h.data_ptr(), w.data_ptr(), b.data_ptr(), ref.data_ptr(), out.data_ptr(),
                                            h.numel() // 256, 256, mode, _lib.current_stream())
     _lib.check(code, "dtlr_box_head_refine")
     return out
@@ -795,7 +811,7 @@ def box_refine(delta, ref):
     """sigmoid(delta + inverse_sigmoid(ref)) (fp32)."""
     delta, ref = delta.contiguous(), ref.contiguous()
     out = torch.empty_like(ref)
-    code = _lib.lib().dtlr_box_refine(delta.data_ptr(), ref.data_ptr(), out.data_ptr(), ref.numel(), _lib.current_stream())
+    code = _L(delta).dtlr_box_refine(delta.data_ptr(), ref.data_ptr(), out.data_ptr(), ref.numel(), _lib.current_stream())
     _lib.check(code, "dtlr_box_refine")
     return out
 
@@ -806,7 +822,7 @@ def topk_rows(scores, k: int):
     B, S = scores.shape
     scores = scores.float().contiguous()
     idx = torch.empty((B, k), dtype=torch.int64, device=scores.device)
-    code = _lib.lib().dtlr_topk_rows(scores.data_ptr(), idx.data_ptr(), B, S, k, _lib.current_stream())
+    code = _L(scores).dtlr_topk_rows(scores.data_ptr(), idx.data_ptr(), B, S, k, _lib.current_stream())
     _lib.check(code, "dtlr_topk_rows")
     return idx
 
@@ -820,7 +836,7 @@ def decode_blank(logits, boxes, eps: float):
     boxes = boxes.float().contiguous()
     labels = torch.empty((B, nq), dtype=torch.int32, device=logits.device)
     lengths = torch.empty((B,), dtype=torch.int32, device=logits.device)
-    code = _lib.lib().dtlr_decode_blank(logits.data_ptr(), boxes.data_ptr(), labels.data_ptr(), lengths.data_ptr(), B, nq, C,
+    code = _L(logits).dtlr_decode_blank(logits.data_ptr(), boxes.data_ptr(), labels.data_ptr(), lengths.data_ptr(), B, nq, C,
                                         float(eps), _lib.current_stream())
     _lib.check(code, "dtlr_decode_blank")
     return labels, lengths
@@ -837,7 +853,7 @@ def preprocess_lines(src_u8, offsets, dims, Hc: int, Wc: int, max_downscale: flo
     mask = torch.empty((B, Hc, Wc), dtype=torch.bool, device=src_u8.device)
     m = (ctypes.c_float * 3)(*[float(v) for v in mean])
     s = (ctypes.c_float * 3)(*[float(v) for v in std])
-    code = _lib.lib().dtlr_preprocess_lines(src_u8.data_ptr(), offsets.data_ptr(), dims.data_ptr(), B, Hc, Wc, float(max_downscale),
+    code = _L(src_u8).dtlr_preprocess_lines(src_u8.data_ptr(), offsets.data_ptr(), dims.data_ptr(), B, Hc, Wc, float(max_downscale),
                                             ctypes.cast(m, ctypes.c_void_p), ctypes.cast(s, ctypes.c_void_p),
                                             canvas.data_ptr(), mask.data_ptr(), _lib.current_stream())
     _lib.check(code, "dtlr_preprocess_lines")
@@ -856,7 +872,7 @@ def ctc_loss_interleaved(logits, boxes, targets, target_lengths, max_target_leng
     Lmax = targets.shape[1]
     nll = torch.empty((B,), dtype=torch.float32, device=logits.device)
     ws = torch.empty((B * nq,), dtype=torch.float32, device=logits.device)
-    code = _lib.lib().dtlr_ctc_loss_interleaved(logits.data_ptr(), boxes.data_ptr(), targets.data_ptr() if Lmax > 0 else None,
+    code = _L(logits).dtlr_ctc_loss_interleaved(logits.data_ptr(), boxes.data_ptr(), targets.data_ptr() if Lmax > 0 else None,
                                                 target_lengths.data_ptr(), nll.data_ptr(), ws.data_ptr(), B, nq, C, Lmax,
                                                 int(max_target_length), float(eps), float(filler), _lib.current_stream())
     _lib.check(code, "dtlr_ctc_loss_interleaved")
@@ -872,7 +888,7 @@ def nms_batched(boxes, scores, iou_threshold: float):
     scores = scores.float().contiguous()
     keep = torch.empty((B, n), dtype=torch.int64, device=boxes.device)
     counts = torch.empty((B,), dtype=torch.int32, device=boxes.device)
-    code = _lib.lib().dtlr_nms(boxes.data_ptr(), scores.data_ptr(), float(iou_threshold), keep.data_ptr(), counts.data_ptr(), B, n,
+    code = _L(boxes).dtlr_nms(boxes.data_ptr(), scores.data_ptr(), float(iou_threshold), keep.data_ptr(), counts.data_ptr(), B, n,
                                _lib.current_stream())
     _lib.check(code, "dtlr_nms")
     return keep, counts
@@ -887,7 +903,7 @@ def topk_flat(x, k: int, apply_sigmoid: bool = False):
     B, n = x.shape
     values = torch.empty((B, k), dtype=torch.float32, device=x.device)
     idx = torch.empty((B, k), dtype=torch.int64, device=x.device)
-    code = _lib.lib().dtlr_topk_flat(x.data_ptr(), values.data_ptr(), idx.data_ptr(), B, n, int(k), int(bool(apply_sigmoid)), _lib.current_stream())
+    code = _L(x).dtlr_topk_flat(x.data_ptr(), values.data_ptr(), idx.data_ptr(), B, n, int(k), int(bool(apply_sigmoid)), _lib.current_stream())
     _lib.check(code, "dtlr_topk_flat")
     return values, idx
 

@@ -28,6 +28,7 @@ extern "C" {
 #define DTLR_F32 0
 #define DTLR_F64 1
 #define DTLR_BF16 2
+#define DTLR_F16 3    /* IEEE fp16: accepted by libdtlr_hip_f16.so (the same sources built with -DDTLR_HALF_IS_F16) wherever libdtlr_hip.so accepts DTLR_BF16 */
 
 const char *dtlr_strerror(int code);
 int dtlr_last_hip_error(void);          /* last hipError_t seen by this library (thread-local) */

@@ -24,12 +24,31 @@ def test_library_exports_every_declared_symbol():
     hdr = open(os.path.join(ROOT, "include", "dtlr_hip.h")).read()
     declared = set(re.findall(r"\b(dtlr_[a-z0-9_]+)\s*\(", hdr))
     assert declared, "no declarations found"
-    L = ctypes.CDLL(_lib.LIB_PATH)
-    for name in declared:
-        assert hasattr(L, name), f"{name} declared in include/dtlr_hip.h but not exported"
+    for path in (_lib.LIB_PATH, _lib.LIB_PATH_F16):               # the bf16 build and the fp16 build of the same sources
+        L = ctypes.CDLL(path)
+        for name in declared:
+            assert hasattr(L, name), f"{name} declared in include/dtlr_hip.h but not exported by {path}"
     assert declared == set(_lib.declared_symbols())
-    assert _lib.lib().dtlr_abi_version() >= 1
-    assert _lib.lib().dtlr_strerror(-2).decode().startswith("unsupported dtype")
+    import torch
+    for L in (_lib.lib(), _lib.lib(torch.float16)):
+        assert L.dtlr_abi_version() >= 1
+        assert L.dtlr_strerror(-2).decode().startswith("unsupported dtype")
+    assert _lib.lib() is not _lib.lib(torch.float16)
+
+
+def test_product_kernels_read_no_environment():
+    """Round-2 advice: A/B switches must not live in the product build.  Every switch goes through exp_env_int(), which is a
+    compile-time constant unless the (never shipped) instrumented build defines DTLR_EXPERIMENT."""
+    csrc = os.path.join(ROOT, "dtlr_amd", "csrc")
+    for fn in os.listdir(csrc):
+        if fn.endswith(".hip"):
+            assert "getenv" not in open(os.path.join(csrc, fn)).read(), fn
+    common = open(os.path.join(csrc, "dtlr_common.h")).read()
+    assert common.count("getenv") == 1 and "#ifdef DTLR_EXPERIMENT" in common
+    from dtlr_amd import build
+    assert not any("DTLR_EXPERIMENT" in f for f in build.FLAGS)
+    for fn in ("engine.py", "ops.py"):
+        assert "environ" not in open(os.path.join(ROOT, "dtlr_amd", fn)).read(), fn
 
 
 def test_product_never_imports_oracle_and_has_no_cpu_path():
