@@ -19,9 +19,10 @@ timing       : W warm-up steps, then blocks of exactly K steps, each bracketed b
 data-parallel: the global batch is ONE seeded list of n_gpus x 32 lines; rank r owns the contiguous shard shard_bounds(r)
                (dtlr_amd/dist.py).  After the timed region rank 0 recomputes every shard itself and compares the all-gathered
                records bit for bit (`dp_verified`): N-rank output == single-process output on the same lines, in order.
-parity       : `cer_vs_oracle`: two lines of the benched batch are decoded by the CPU oracle (following the engine's own query
-               selection); the decoded strings are compared on the queries whose oracle decision margin exceeds the measured
-               bf16 logit error (tests/util.py), CER of the engine's strings against the oracle's is reported.
+parity       : `cer_vs_oracle`: --parity-lines (8) lines of the benched batch are decoded by the CPU oracle (following the engine's
+               own query selection): max logit / box / cx error and the CER of the engine's strings against the oracle's over ALL
+               queries.  `by_dtype`: the same batch through the other two engines (bf16 = libdtlr_hip.so, f16 = libdtlr_hip_f16.so,
+               f32 = the exact-fp32 parity engine): a short timed block (lines/s) and the same parity leg each.
 roofline     : per kernel class, measured live with HIP events on the launch stream: MSDA inside the timed blocks, the MFMA
                classes (GEMM / fused FFN / projection+norm) in a replay of the same steps right after them (an event pair per
                launch inside the timed region would cost ~2.5 ms of stream time per step).  GEMM launches are also listed
@@ -161,10 +162,16 @@ def main():
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--batch", type=int, default=32, help="lines per GPU")
-    ap.add_argument("--config", default="latin", choices=["latin", "chinese"], help="latin = BASELINE configs[1] (the metric); chinese = configs[4]")
+    ap.add_argument("--config", default="latin", choices=["latin", "chinese", "latin-mixed", "latin-eval"],
+                    help="latin = BASELINE configs[1] (the metric); chinese = configs[4]; latin-mixed = Latin model on seeded mixed widths "
+                         "{1280..2048} zero-padded to 128x2048 with masks (what a real dataset looks like); latin-eval = uint8 128x2048 lines "
+                         "through the reference's eval transform (short side 800 capped at 1333: 83x1328 canvases, datasets/transforms.py:78-142)")
     ap.add_argument("--height", type=int, default=128)
     ap.add_argument("--width", type=int, default=0, help="0 = 2048 (latin) / 2560 canvas with mixed widths (chinese)")
-    ap.add_argument("--dtype", default="bf16", choices=["bf16", "f32"])
+    ap.add_argument("--dtype", default="bf16", choices=["bf16", "f16", "f32"],
+                    help="the timed engine: bf16 (BASELINE configs[1]), f16 (the fp16 build of the same kernels: same rate, 8x finer rounding), f32 (parity engine)")
+    ap.add_argument("--no-other-dtypes", action="store_true", help="skip the short lines/s + parity legs of the two engines that are not --dtype")
+    ap.add_argument("--parity-lines", type=int, default=8, help="lines of the benched batch decoded by the CPU oracle (cer_vs_oracle)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-parity", action="store_true", help="skip the cer_vs_oracle leg (two oracle forwards on the host)")
     ap.add_argument("--backend", default=None, help="torch.distributed backend (default nccl = RCCL); gloo for the single-GPU DP test")
@@ -190,9 +197,12 @@ def main():
         local = 0
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
-    dtype = torch.bfloat16 if args.dtype == "bf16" else torch.float32
+    placement = ddist.pin_to_local_cpus(local, world) if (world > 1 and not args.single_device) else None
+    DT = {"bf16": torch.bfloat16, "f16": torch.float16, "f32": torch.float32}
+    dtype = DT[args.dtype]
 
     chinese = args.config == "chinese"
+    mixed, evalshape = args.config == "latin-mixed", args.config == "latin-eval"
     cfg = DTLRConfig.chinese() if chinese else DTLRConfig.latin()
     sd = weights.synthetic_state_dict(cfg, seed=0)
     eng = DTLREngine(cfg, sd, dev, dtype)
@@ -205,6 +215,10 @@ def main():
         canvas_w = args.width or 2560
         widths = synth.mixed_widths(n_total, [canvas_w - 1024, canvas_w - 768, canvas_w - 512, canvas_w - 256, canvas_w], seed=7)
         widths[::B] = [canvas_w] * len(widths[::B])                    # every shard has a full-width line: same canvas on every rank
+    elif mixed:
+        canvas_w = args.width or 2048
+        widths = synth.mixed_widths(n_total, [canvas_w - 768, canvas_w - 512, canvas_w - 256, canvas_w], seed=11)
+        widths[::B] = [canvas_w] * len(widths[::B])
     else:
         canvas_w = args.width or 2048
         widths = [canvas_w] * n_total
@@ -220,31 +234,38 @@ def main():
             m[i, :, : im.shape[2]] = False
         return x.to(dev), m.to(dev)
 
-    imgs = make_lines(lo, hi)
-    x, mask = to_batch(imgs)
-    padded = chinese
+    preproc_ms = None
+    if evalshape:
+        # the reference's eval pipeline on the device: uint8 lines -> resize (Pillow's fixed-point bilinear, bit-exact) -> /255 -> normalise
+        # -> pad + mask, ONE launch (dtlr_preprocess_lines); the timed step then runs on the resulting 83x1328 canvas
+        from dtlr_amd.transforms import preprocess_lines
+        raw = synth.uint8_lines(hi - lo, args.height, widths[lo:hi], seed=1000, start=lo)
+        nt = preprocess_lines(raw, device=dev)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(5):
+            nt = preprocess_lines(raw, device=dev)
+        torch.cuda.synchronize()
+        preproc_ms = (time.perf_counter() - t0) / 5 * 1e3
+        x, mask = nt.tensors, nt.mask
 
-    # --single-device (the 2-ranks-on-one-GPU test): the ranks TIME-SHARE one GPU, which is not a deployment mode (one process per GPU).
-    # Their steps are serialised through a file lock: with two processes' kernels interleaved on the device, ~1% of forwards differ in
-    # a few decoder outputs from the same process's own earlier result (first differing operator: the decoder's deformable sampling;
-    # never seen with one process per GPU: tools/experiments/forward_determinism.py) -- the test is about the
-    # sharding / gather plumbing, which the lock leaves untouched.
-    gpu_lock = None
-    if args.single_device and world > 1:
-        import fcntl
-        gpu_lock = open(os.path.join("/tmp", f"dtlr_bench_gpu_{os.environ.get('MASTER_PORT', '0')}.lock"), "w")
+        def to_batch(lines):                                  # noqa: F811  (dp self-check of this config: other shards through the same transform)
+            t = preprocess_lines(lines, device=dev)
+            return t.tensors, t.mask
 
+        def make_lines(a, b):                                 # noqa: F811
+            return synth.uint8_lines(b - a, args.height, widths[a:b], seed=1000, start=a)
+    else:
+        imgs = make_lines(lo, hi)
+        x, mask = to_batch(imgs)
+    padded = chinese or mixed or bool(mask.any().item())
+
+    # --single-device: all ranks drive cuda:0 (the 2-ranks-on-one-GPU test; gloo, because RCCL refuses duplicate devices).  Their kernels
+    # interleave freely on the device -- round 2 serialised the ranks through a file lock here because ~10% of forwards then differed;
+    # the cause (a lane-mask sequence of the decoder's deformable-sampling kernel) is fixed and the lock is gone.
     def local_step(xx=None, mm=None, debug=False):
-        if gpu_lock is not None:
-            fcntl.flock(gpu_lock, fcntl.LOCK_EX)
-        try:
-            out = eng.forward(x if xx is None else xx, mask if mm is None else mm, has_padding=padded, return_debug=debug)
-            rec = decode_blank_records(out)
-            if gpu_lock is not None:
-                torch.cuda.synchronize()
-        finally:
-            if gpu_lock is not None:
-                fcntl.flock(gpu_lock, fcntl.LOCK_UN)
+        out = eng.forward(x if xx is None else xx, mask if mm is None else mm, has_padding=padded, return_debug=debug)
+        rec = decode_blank_records(out)
         return (rec, out) if debug else rec
 
     def step():
@@ -311,7 +332,7 @@ def main():
     total_steps = args.steps * len(blocks)
     enc = [(a.elapsed_time(b), n, lq, s) for (a, b, n, lq, s) in events if lq == s]
     dec = [(a.elapsed_time(b), n, lq, s) for (a, b, n, lq, s) in events if lq != s]
-    velem = 2 if dtype == torch.bfloat16 else 4
+    velem = 2 if dtype in (torch.bfloat16, torch.float16) else 4
     traffic_db = {}
     for fn in sorted(os.listdir(os.path.join(ROOT, "profiles"))) if os.path.isdir(os.path.join(ROOT, "profiles")) else []:
         if fn.endswith("_traffic.json"):
@@ -319,13 +340,15 @@ def main():
                 traffic_db.update(json.load(open(os.path.join(ROOT, "profiles", fn))))
             except Exception:
                 pass
+    # PMC traffic figures were measured on the Latin bf16 B = 32 step (profiles/*_traffic.json): attach them to that configuration only
+    traffic_ok = args.config == "latin" and B == 32 and args.dtype == "bf16" and canvas_w == 2048 and args.height == 128
     roof = None
     if enc:
         ms = sum(e[0] for e in enc) / len(enc)
         n, lq, s = enc[0][1], enc[0][2], enc[0][3]
         alg = msda_algorithmic_bytes_per_line(s, lq, velem) * n
         achieved = alg / (ms * 1e-3) / 1e9
-        traffic = traffic_db.get(f"{args.dtype}_enc_bytes_per_launch") if (not chinese and n == 32) else None
+        traffic = traffic_db.get(f"{args.dtype}_enc_bytes_per_launch") if traffic_ok else None
         roof = {"bound": "hbm", "kernel": f"msda_enc_lds_kernel (deformable sampling, encoder call, Lq=S={s}/line)", "achieved": round(achieved, 1),
                 "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
                 "algorithmic_bytes_per_launch": alg, "mean_launch_ms": round(ms, 4), "launches_timed": len(enc)}
@@ -369,7 +392,7 @@ def main():
             head = {"bound": "hbm", "kernel": names.get(kind, kind), "achieved": round(gbps, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(hf, 4)}
         else:
             head = {"bound": "mfma", "kernel": names.get(kind, kind), "achieved": round(ach, 1), "peak": peak, "unit": "TFLOP/s", "frac": round(mf, 4)}
-        by_kernel.append({**head, "traffic": traffic_db.get(f"{kind}_bytes_per_launch_mean"), "mfma_tflops": round(ach, 1), "mfma_frac": round(mf, 4),
+        by_kernel.append({**head, "traffic": traffic_db.get(f"{kind}_bytes_per_launch_mean") if traffic_ok else None, "mfma_tflops": round(ach, 1), "mfma_frac": round(mf, 4),
                           "hbm_gbps_algorithmic": round(gbps, 1), "hbm_frac": round(hf, 4),
                           "algorithmic_flops_per_launch": round(flops / cnt), "algorithmic_bytes_per_launch": round(nbytes / cnt),
                           "mean_launch_ms": round(ms / cnt, 4), "launches_timed": cnt, "ms_per_step": round(ms / replay_steps, 3),
@@ -380,17 +403,24 @@ def main():
         peak, ach, gbps, mf, hf = both_roofs(kind, ms, flops, nbytes)
         gemm_by_shape.append({"shape": tag, "kind": kind, "launches_per_step": round(cnt / replay_steps, 1), "mean_launch_us": round(1e3 * ms / cnt, 1),
                               "ms_per_step": round(ms / replay_steps, 3), "mfma_tflops": round(ach, 1), "mfma_frac": round(mf, 4),
-                              "hbm_gbps_algorithmic": round(gbps, 1), "hbm_frac": round(hf, 4), "traffic": traffic_db.get(f"gemm:{tag}")})
+                              "hbm_gbps_algorithmic": round(gbps, 1), "hbm_frac": round(hf, 4), "traffic": traffic_db.get(f"gemm:{tag}") if traffic_ok else None})
     gemm_by_shape.sort(key=lambda r: -r["ms_per_step"])
     dominant = by_kernel[0] if by_kernel else None
     line = {
-        "metric": "text-lines/sec (128x2048, bs=32)" if not chinese else "text-lines/sec (Chinese 7356-class head, mixed-length 128x2560, bs=32)",
+        "metric": ("text-lines/sec (Chinese 7356-class head, mixed-length 128x2560, bs=32)" if chinese else
+                   "text-lines/sec (Latin, mixed widths padded to 128x2048, bs=32)" if mixed else
+                   f"text-lines/sec (Latin, eval transform: 128x2048 uint8 lines -> {x.shape[2]}x{x.shape[3]} canvases, bs=32)" if evalshape else
+                   "text-lines/sec (128x2048, bs=32)"),
         "value": round(n_total * args.steps / elapsed, 2), "unit": "lines/s",
         "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": round(elapsed / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak",
         "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
         "timed_blocks": len(blocks), "block_ms": [round(b * 1e3, 2) for b in blocks],
-        "config": {"workload": (f"Latin DTLR (ResNet-50 + 6/6 deformable DETR, C=166) forward+decode, {B} synthetic {args.height}x{canvas_w} lines per GPU"
+        "config": {"workload": (f"Latin DTLR (C=166) forward+decode, {B} synthetic lines per GPU, widths seeded from {{{canvas_w - 768}..{canvas_w}}}, zero-padded to {args.height}x{canvas_w} with masks"
+                                if mixed else
+                                f"Latin DTLR (C=166) forward+decode on the eval-transformed canvas ({x.shape[2]}x{x.shape[3]}; preprocessing {preproc_ms:.3f} ms per batch, outside the timed step), {B} synthetic uint8 {args.height}x{canvas_w} lines per GPU"
+                                if evalshape else
+                                f"Latin DTLR (ResNet-50 + 6/6 deformable DETR, C=166) forward+decode, {B} synthetic {args.height}x{canvas_w} lines per GPU"
                                 if not chinese else
                                 f"Chinese DTLR (C=7356) forward+decode, {B} synthetic lines per GPU, widths seeded from {{{canvas_w - 1024}..{canvas_w}}}, zero-padded to {args.height}x{canvas_w} with masks")
                                + f", random-init name-seeded weights (generator v{weights.GENERATOR_VERSION})",
@@ -398,14 +428,14 @@ def main():
                    "library_backed_ops": sorted(ops.LIBRARY_BACKED)},
         "distributed": {"backend": tdist.get_backend() if (tdist.is_available() and tdist.is_initialized()) else None,
                         "world_size": tdist.get_world_size() if (tdist.is_available() and tdist.is_initialized()) else 1,
-                        "dp_verified": dp_verified},
+                        "dp_verified": dp_verified, "host_placement": placement},
         "roofline": dominant,
         "roofline_by_kernel": by_kernel,
         "gemm_by_shape": gemm_by_shape[:24],
     }
+    rows = sorted({int(round(i * (B - 1) / max(args.parity_lines - 1, 1))) for i in range(min(args.parity_lines, B))})
     if not args.no_parity:
         try:
-            rows = [0, min(17, B - 1)] if B > 1 else [0]
             (_, out) = local_step(debug=True)
             torch.cuda.synchronize()
             t0 = time.perf_counter()
@@ -414,7 +444,44 @@ def main():
             del out
         except Exception as e:                                   # the parity leg must never cost the throughput line
             line["cer_vs_oracle"] = {"error": repr(e)}
-    if world == 1 and not args.no_cpu_baseline and not chinese:
+    # ---- the other two engines on the SAME batch: a short timed block each + the same parity leg.  `value` above is --dtype's. ----
+    by_dtype = {args.dtype: {"lines_per_s": line["value"], "ms_per_step": line["ms_per_step"], "steps_timed": total_steps,
+                             "cer_vs_oracle": line.get("cer_vs_oracle")}}
+    if world == 1 and not args.no_other_dtypes:
+        del eng
+        torch.cuda.empty_cache()
+        for name in ("bf16", "f16", "f32"):
+            if name == args.dtype:
+                continue
+            try:
+                e2 = DTLREngine(cfg, sd, dev, DT[name])
+
+                def step2(debug=False):
+                    o = e2.forward(x, mask, has_padding=padded, return_debug=debug)
+                    return (decode_blank_records(o), o)
+                for _ in range(2):
+                    step2()
+                torch.cuda.synchronize()
+                k2 = args.steps if name != "f32" else max(3, args.steps // 5)
+                t0 = time.perf_counter()
+                for _ in range(k2):
+                    step2()
+                torch.cuda.synchronize()
+                dt2 = time.perf_counter() - t0
+                ent = {"lines_per_s": round(B * k2 / dt2, 2), "ms_per_step": round(dt2 / k2 * 1e3, 3), "steps_timed": k2}
+                if not args.no_parity:
+                    _, o = step2(debug=True)
+                    torch.cuda.synchronize()
+                    ent["cer_vs_oracle"] = cer_vs_oracle(cfg, sd, x, mask, o, rows)
+                    del o
+                by_dtype[name] = ent
+                log(f"engine {name}: {ent}")
+                del e2
+                torch.cuda.empty_cache()
+            except Exception as e:
+                by_dtype[name] = {"error": repr(e)}
+    line["by_dtype"] = by_dtype
+    if world == 1 and not args.no_cpu_baseline and args.config == "latin":
         line["cpu_baseline"] = cpu_baseline()
         line["speedup_vs_cpu"] = round(line["value"] / line["cpu_baseline"]["value"], 1)
     print(json.dumps(line), flush=True)

@@ -35,20 +35,37 @@ def _fingerprint() -> str:
 LIB_F16 = os.path.join(HERE, "libdtlr_hip_f16.so")
 
 
-def _compile_all(defs, objdir, out, verbose):
-    """every csrc/*.hip -> objdir/*.o (in parallel: one hipcc per source), linked into `out`."""
+def _src_hash(src, defs) -> str:
+    h = hashlib.sha256()
+    for p in [src] + sorted(glob.glob(os.path.join(CSRC, "*.h"))) + [os.path.join(HERE, "..", "include", "dtlr_hip.h")]:
+        with open(p, "rb") as f:
+            h.update(f.read())
+    h.update(" ".join(defs).encode())
+    return h.hexdigest()
+
+
+def _compile_all(defs, objdir, out, verbose, force=False):
+    """every csrc/*.hip -> objdir/*.o (in parallel: one hipcc per source; an object whose source, headers and flags are unchanged
+    is kept), linked into `out`."""
     from concurrent.futures import ThreadPoolExecutor
     os.makedirs(objdir, exist_ok=True)
     jobs = []
     for src in _sources():
         obj = os.path.join(objdir, os.path.basename(src)[:-4] + ".o")
-        jobs.append(([HIPCC, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-function"] + defs + ["-c", src, "-o", obj], obj))
+        jobs.append(([HIPCC, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-function"] + defs + ["-c", src, "-o", obj], obj,
+                     _src_hash(src, defs)))
 
     def run(job):
+        cmd, obj, hsh = job
+        tag = obj + ".hash"
+        if not force and os.path.exists(obj) and os.path.exists(tag) and open(tag).read() == hsh:
+            return obj
         if verbose:
-            print("[dtlr build]", " ".join(job[0]), flush=True)
-        subprocess.check_call(job[0])
-        return job[1]
+            print("[dtlr build]", " ".join(cmd), flush=True)
+        subprocess.check_call(cmd)
+        with open(tag, "w") as f:
+            f.write(hsh)
+        return obj
 
     with ThreadPoolExecutor(max_workers=min(8, os.cpu_count() or 2)) as ex:
         objs = list(ex.map(run, jobs))
@@ -64,8 +81,8 @@ def build(force: bool = False, verbose: bool = True) -> str:
     fp = _fingerprint()
     if not force and os.path.exists(LIB) and os.path.exists(LIB_F16) and os.path.exists(STAMP) and open(STAMP).read().strip() == fp:
         return LIB
-    _compile_all([], CSRC, LIB, verbose)
-    _compile_all(["-DDTLR_HALF_IS_F16"], os.path.join(CSRC, "f16"), LIB_F16, verbose)
+    _compile_all([], CSRC, LIB, verbose, force)
+    _compile_all(["-DDTLR_HALF_IS_F16"], os.path.join(CSRC, "f16"), LIB_F16, verbose, force)
     with open(STAMP, "w") as f:
         f.write(fp)
     return LIB

@@ -468,18 +468,26 @@ __global__ __launch_bounds__(128, 2) void msda_fused_quad_bf16_kernel(
         float lx, ly;
         if (REFD == 2) { lx = rf[0] + off[2 * pt] / fW; ly = rf[1] + off[2 * pt + 1] / fH; }
         else { lx = rf[0] + off[2 * pt] / 4.0f * rf[2] * 0.5f; ly = rf[1] + off[2 * pt + 1] / 4.0f * rf[3] * 0.5f; }
-        const float h_im = ly * fH - 0.5f, w_im = lx * fW - 0.5f;
-        const bool inside = h_im > -1.f && w_im > -1.f && h_im < fH && w_im < fW;
+        // Bilinear corners and their validity, one UNSIGNED compare per select (cuh:33-84: a corner counts iff it is inside the map and the
+        // point satisfies -1 < h_im < H, -1 < w_im < W).  The coordinate is first clamped to [-1, size]: inside that range nothing
+        // changes (same floor, same fractions -- bit-identical weights); at or beyond -1 the clamped point sits ON row/column -1 (its
+        // only in-map neighbour, 0, gets the fraction 0) and at or beyond `size` both neighbours are outside, so the reference's
+        // `inside` test needs no separate lane mask.  Each weight then depends on ONE comparison (v_cmp -> VCC -> v_cndmask).  The first
+        // version combined five comparisons per corner with s_and_b64 into lane masks that lived in SGPR pairs across the whole
+        // kernel; under GPU contention (two processes on one device) lanes 48..63 of scattered waves then dropped corner terms --
+        // DESIGN.md section 6 -- and this form never has.
+        const float h_im = fminf(fmaxf(ly * fH - 0.5f, -1.f), fH), w_im = fminf(fmaxf(lx * fW - 0.5f, -1.f), fW);
         const float hf = floorf(h_im), wf = floorf(w_im);
-        const int h_low = (int)fminf(fmaxf(hf, -1.f), fH), w_low = (int)fminf(fmaxf(wf, -1.f), fW);
+        const int h_low = (int)hf, w_low = (int)wf;
         const int h_high = h_low + 1, w_high = w_low + 1;
         const float lh = h_im - hf, lw = w_im - wf, hh = 1.f - lh, hw = 1.f - lw;
-        const bool top = inside && h_low >= 0, bot = inside && h_high <= Hl - 1, left = w_low >= 0, right = w_high <= Wl - 1;
+        const float wy0 = (unsigned)h_low < (unsigned)Hl ? hh : 0.f, wy1 = (unsigned)h_high < (unsigned)Hl ? lh : 0.f;
+        const float wx0 = (unsigned)w_low < (unsigned)Wl ? hw : 0.f, wx1 = (unsigned)w_high < (unsigned)Wl ? lw : 0.f;
         const int h0 = min(max(h_low, 0), Hl - 1), h1 = max(min(h_high, Hl - 1), 0);
         const int w0 = min(max(w_low, 0), Wl - 1), w1c = max(min(w_high, Wl - 1), 0);
         const float a = lg[pt] * inv;
-        kg[pt][0] = (top && left) ? hh * hw * a : 0.f;  kg[pt][1] = (top && right) ? hh * lw * a : 0.f;
-        kg[pt][2] = (bot && left) ? lh * hw * a : 0.f;  kg[pt][3] = (bot && right) ? lh * lw * a : 0.f;
+        kg[pt][0] = wy0 * wx0 * a;  kg[pt][1] = wy0 * wx1 * a;
+        kg[pt][2] = wy1 * wx0 * a;  kg[pt][3] = wy1 * wx1 * a;
         og[pt][0] = (h0 * Wl + w0) * vstride;  og[pt][1] = (h0 * Wl + w1c) * vstride;
         og[pt][2] = (h1 * Wl + w0) * vstride;  og[pt][3] = (h1 * Wl + w1c) * vstride;
     }

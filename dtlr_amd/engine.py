@@ -55,10 +55,10 @@ class DTLREngine:
         self.pln_k256_min_rows = 16384
         self.use_kres = True
         self.use_kres_narrow = True
-        self.msda_auto = True      # per-layer choice LDS-window / gather kernel from a far-sample probe
-        self.msda_probe_every = 256
+        self.msda_auto = True      # per-layer choice LDS-window / gather kernel, calibrated once per canvas shape (see _msda_mode)
         self.msda_far_threshold = 0.012
-        self._msda_state = {}
+        self._msda_state = {}      # (layer, canvas shape) -> {"mode", "far"}; keyed by nothing that depends on the data or the call history
+        self._msda_calibrating = None
         self.use_k256_small = True   # ... and for the encoder's output projection + LayerNorm
 
     # ------------------------------------------------------------------------------ packing
@@ -371,16 +371,36 @@ class DTLREngine:
         """'lds' or 'gather' for this encoder layer.  The LDS-window kernel fetches sampling points outside its staged columns through a
         global path that stalls a wave on 16 dependent loads per point: at ~1.2% of such points it is as slow as the gather kernel
         (tools/msda_sweep.py: 0.47 ms at 2.7% against 0.31 ms flat).  The fraction depends on the checkpoint's offset heads, so it is
-        MEASURED: a probe (dtlr_msda_encoder_far_samples, one small kernel + a 16-byte read-back) on a layer's first call and every
-        `msda_probe_every` calls after it; `msda_auto = False` pins the LDS kernel."""
+        MEASURED -- but the two kernels are not bit-identical (packed-fp16 against fp32 accumulation), so the choice must not depend on
+        the data or on the call history (round 2 probed the running batch every 256 calls: a result could depend on which batch had
+        been probed, and data-parallel ranks could choose differently).  It is now a function of (weights, canvas shape) only: the
+        first forward of a canvas shape runs ONE calibration pass of the encoder on a seeded noise batch of that shape
+        (`_calibrate_msda`), probing every layer (dtlr_msda_encoder_far_samples: one small kernel + a 16-byte read-back); every rank
+        holds the same weights and generates the same noise, so every rank chooses the same kernels.  `msda_auto = False` pins the LDS
+        kernel; `_msda_state[(layer, level_hw)] = {"mode": ...}` overrides a layer."""
         if not self.msda_auto:
             return "lds"
-        st = self._msda_state.setdefault(name, {"calls": 0, "mode": "lds", "far": None})
-        if st["calls"] % self.msda_probe_every == 0:
-            st["far"] = ops.msda_encoder_far_fraction(value_dtype, level_hw, ow, ref, n_heads)
-            st["mode"] = "gather" if st["far"] > self.msda_far_threshold else "lds"
-        st["calls"] += 1
-        return st["mode"]
+        key = (name, tuple(level_hw))
+        if self._msda_calibrating is not None:               # inside the calibration pass: measure, run the (always correct) LDS kernel
+            far = ops.msda_encoder_far_fraction(value_dtype, level_hw, ow, ref, n_heads)
+            self._msda_calibrating[key] = {"far": far, "mode": "gather" if far > self.msda_far_threshold else "lds"}
+            return "lds"
+        st = self._msda_state.get(key)
+        return st["mode"] if st is not None else "lds"
+
+    def _calibrate_msda(self, x_shape, level_hw):
+        """One encoder pass on a seeded noise batch (2 lines of this canvas shape, unpadded) -> the per-layer kernel choice."""
+        gen = torch.Generator().manual_seed(20260927)
+        xc = torch.randn((min(2, int(x_shape[0])),) + tuple(x_shape[1:]), generator=gen).to(self.device)
+        mc = torch.zeros((xc.shape[0],) + tuple(x_shape[2:]), dtype=torch.bool, device=self.device)
+        self._msda_calibrating = {}
+        try:
+            feats, last, lhw = self.features(xc)
+            g = self._geometry(mc, lhw, has_padding=True)          # not cached: the calibration batch has its own size
+            self.encoder(self.tokens(feats, last, lhw), g)
+            self._msda_state.update(self._msda_calibrating)
+        finally:
+            self._msda_calibrating = None
 
     def _msda_module(self, name, query, query_pos, ref, value_src, g, n_points, value=None, ow_res=None):
         """MSDeformAttn.forward (ops/modules/ms_deform_attn.py:78-126) without the output
@@ -630,6 +650,8 @@ class DTLREngine:
         feats, last, level_hw = self.features(x)
         g = self.geometry_for(x, mask, level_hw, has_padding)
         src = self.tokens(feats, last, level_hw)
+        if self.msda_auto and self.use_lds_msda and ("enc0.attn", tuple((int(h), int(w)) for h, w in level_hw)) not in self._msda_state:
+            self._calibrate_msda(x.shape, level_hw)            # once per canvas shape
         memory = self.encoder(src, g)
         ts = self.two_stage(memory, g, forced_topk)
         hs, refs = self.decoder(memory, ts, g, want_aux)

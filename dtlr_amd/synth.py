@@ -60,3 +60,17 @@ def mixed_widths(n: int, choices: Sequence[int], seed: int = 0) -> List[int]:
     """cfg5 of BASELINE.json: widths drawn (seeded) from a set, e.g. {1536,...,2560}."""
     r = _rng(seed + 991)
     return [int(choices[int(k)]) for k in r.integers(0, len(choices), n)]
+
+
+def uint8_lines(n: int, height: int, widths: Sequence[int] | int, seed: int = 0, start: int = 0) -> List[torch.Tensor]:
+    """Seeded RGB uint8 line images [h, w, 3] (light paper with dark runs, like tests/util.preproc_image's odd seeds): the input of
+    the eval-time preprocessing (datasets/transforms.py:78-109) in `bench.py --config latin-eval`."""
+    if isinstance(widths, int):
+        widths = [widths] * n
+    out = []
+    for i, w in zip(range(n), widths):
+        g = _rng(seed * 1000003 + start + i + 555)
+        base = g.integers(0, 256, (height, int(w), 3), dtype=np.uint8)
+        img = np.where(g.random((height, int(w), 1)) < 0.15, base // 4, 200 + base // 5).astype(np.uint8)
+        out.append(torch.from_numpy(img))
+    return out

@@ -34,6 +34,20 @@ from .config import DTLRConfig
 # are blank (every class logit << 0), like the output of a trained recogniser.  beta_q varies per query, so margins range from
 # a few tenths of a logit to many logits.
 GENERATOR_VERSION = 2
+# Version 3 (round 3, `synthetic_state_dict(..., version=3)`: a STRESS set, not the parity reference).  The round-2 review objected that
+# the x 0.3 damping shrinks exactly the error path the parity gates measure.  v3 removes it and makes explicit what it stood in for: a
+# trained decoder keeps a query's identity across its 18 post-norm sublayers because its weights keep re-writing it, while an i.i.d.
+# decoder at natural branch gain (each sublayer adds a branch of the stream's own norm, the LayerNorm rescales) washes any planted
+# content out as 2^(-18/2).  v3 gives every decoder FFN a small PROTOTYPE MEMORY (the key-value structure trained FFNs are known to
+# hold): for each code a query is designated to carry (its class code, the blank code), V3_MEM_COPIES hidden units whose linear1 row
+# is that code (bias = -threshold: the unit fires only for a stream pointing along the code) and whose linear2 column writes the code
+# back; every other hidden unit, attention projection and output projection is i.i.d. at NATURAL gain.  Measured (MI355X, round 3,
+# profiles/r03_error_budget_*_v3w.json): the content survives (99.4% of the queries decode to their designation, margins of the
+# character queries: median 3.3 logits), mean 16-bit errors are BELOW v2's (the memory re-writes the content cleanly), but the threshold
+# units make the network a strong error amplifier for the few queries near a unit's firing threshold: the exact-fp32 HIP engine and the
+# reference's own CPU forward -- two correct fp32 evaluations -- already differ by 1.0e-3 in the logits (3e-5 on v2).  A network
+# that amplifies fp32 summation-order noise to the north-star tolerance cannot be the yardstick for "logits within 1e-3", so v2 stays
+# the generator of the goldens; v3 is exercised by tools/error_budget.py --weights 3 and a GPU stress test.
 
 
 def _rng(name: str, seed: int) -> np.random.Generator:
@@ -88,22 +102,51 @@ def _msda(sd, p, cfg: DTLRConfig, n_points: int, seed: int):
     _linear(sd, p + ".output_proj", d, d, seed)
 
 
-def _codes(cfg: DTLRConfig, seed: int):
-    """Generator v2: unit-norm sign codes, one per class plus the blank code, and the per-query designation
-    (class id or -1 = blank, strength beta)."""
+V3_MEM_COPIES = 6          # hidden units per stored code
+V3_MEM_THETA = (3.5, 4.0, 4.5, 5.0, 5.5, 6.0)      # firing thresholds of the copies (projection of a unit-variance stream on a unit code ~ N(0,1))
+V3_MEM_GAIN = 12.0         # write-back strength: out = gain * sum_r relu(<x, code> - theta_r) / copies * code
+
+
+def _prototype_memory(sd, cfg: DTLRConfig, code, q_cls, d: int, ff: int):
+    """Generator v3: overwrite the first (#stored codes x V3_MEM_COPIES) hidden units of every decoder FFN with code detectors /
+    emitters (see GENERATOR_VERSION).  Stored codes = the blank code and the class code of every designated character query."""
+    C = cfg.num_classes
+    stored = [C] + sorted(set(int(c) for c in q_cls if c >= 0))
+    n_units = len(stored) * V3_MEM_COPIES
+    if n_units > ff:
+        raise ValueError(f"generator v3: {len(stored)} stored codes x {V3_MEM_COPIES} copies do not fit dim_feedforward = {ff}")
+    K = torch.from_numpy(code[stored].astype(np.float32))                       # [n_codes, d], unit rows
+    rows = K.repeat_interleave(V3_MEM_COPIES, 0)                                # detector rows (a post-norm stream has ~unit variance per channel)
+    theta = torch.tensor(V3_MEM_THETA[:V3_MEM_COPIES], dtype=torch.float32).repeat(len(stored))
+    for n in range(cfg.dec_layers):
+        p = f"transformer.decoder.layers.{n}."
+        sd[p + "linear1.weight"][:n_units] = rows
+        sd[p + "linear1.bias"][:n_units] = -theta
+        sd[p + "linear2.weight"][:, :n_units] = (V3_MEM_GAIN / V3_MEM_COPIES) * rows.t()
+
+
+def _codes(cfg: DTLRConfig, seed: int, version: int = GENERATOR_VERSION):
+    """Generator v2/v3: unit-norm sign codes, one per class plus the blank code, and the per-query designation
+    (class id or -1 = blank, strength beta; v3 starts every query at beta >= 0.8: near the edge of the memory's capture range a
+    query's content decays layer by layer and an arbitrarily small perturbation decides whether it survives -- a bistability a
+    trained query does not have, and one that turns rounding errors of 1e-4 into logit differences of several units)."""
     d, C, nq = cfg.hidden_dim, cfg.num_classes, cfg.num_queries
     r = _rng("v2.codes", seed)
     code = (r.integers(0, 2, (C + 1, d)).astype(np.float32) * 2 - 1) / math.sqrt(d)      # rows 0..C-1: classes, row C: blank
     r = _rng("v2.designation", seed)
     is_char = r.random(nq) < 0.08
     cls = np.where(is_char, r.integers(0, C, nq), -1)
-    beta = np.where(is_char, r.uniform(0.15, 1.0, nq), r.uniform(0.5, 1.0, nq)).astype(np.float32)
+    beta = (np.where(is_char, r.uniform(0.15, 1.0, nq), r.uniform(0.5, 1.0, nq)) if version == 2 else
+            np.where(is_char, r.uniform(0.85, 1.0, nq), r.uniform(0.8, 1.0, nq))).astype(np.float32)
     return code, cls, beta
 
 
-def synthetic_state_dict(cfg: DTLRConfig, seed: int = 0) -> "OrderedDict[str, torch.Tensor]":
-    """fp32 CPU tensors keyed exactly like the reference's `model.state_dict()` (generator version GENERATOR_VERSION)."""
+def synthetic_state_dict(cfg: DTLRConfig, seed: int = 0, version: int = GENERATOR_VERSION) -> "OrderedDict[str, torch.Tensor]":
+    """fp32 CPU tensors keyed exactly like the reference's `model.state_dict()` (generator version GENERATOR_VERSION; version=2
+    reproduces round 2's damped-branch weights for A/B studies)."""
     cfg.validate()
+    if version not in (2, 3):
+        raise ValueError(f"synthetic_state_dict: unknown generator version {version}")
     sd: "OrderedDict[str, torch.Tensor]" = OrderedDict()
     d, C, ff = cfg.hidden_dim, cfg.num_classes, cfg.dim_feedforward
 
@@ -113,7 +156,7 @@ def synthetic_state_dict(cfg: DTLRConfig, seed: int = 0) -> "OrderedDict[str, to
     b = "backbone.0.body."
     if not cfg.is_swin:
         _resnet(sd, cfg, seed)
-    _rest(sd, cfg, seed, d, C, ff)
+    _rest(sd, cfg, seed, d, C, ff, version)
     return sd
 
 
@@ -173,7 +216,7 @@ def _resnet(sd, cfg: DTLRConfig, seed: int):
 
 
 
-def _rest(sd, cfg: DTLRConfig, seed: int, d: int, C: int, ff: int):
+def _rest(sd, cfg: DTLRConfig, seed: int, d: int, C: int, ff: int, version: int = GENERATOR_VERSION):
     # ---- input_proj (models/dino/dino.py:115-136) ---------------------------------------------
     for l, cin in enumerate(cfg.backbone_channels):
         _conv(sd, f"input_proj.{l}.0.weight", d, cin, 1, seed, gain=1.0)
@@ -205,12 +248,13 @@ def _rest(sd, cfg: DTLRConfig, seed: int, d: int, C: int, ff: int):
         _linear(sd, p + "linear1", ff, d, seed, gain=math.sqrt(2.0))
         _linear(sd, p + "linear2", d, ff, seed)
         _norm(sd, p + "norm3", d, seed)
-        for k in ("self_attn.out_proj.weight", "cross_attn.output_proj.weight", "linear2.weight"):
-            sd[p + k] = sd[p + k] * 0.3                      # v2: damped residual branches (see GENERATOR_VERSION)
+        if version == 2:
+            for k in ("self_attn.out_proj.weight", "cross_attn.output_proj.weight", "linear2.weight"):
+                sd[p + k] = sd[p + k] * 0.3                  # v2: damped residual branches (see GENERATOR_VERSION)
     _norm(sd, t + "decoder.norm", d, seed)
     _linear(sd, t + "decoder.ref_point_head.layers.0", d, 2 * d, seed, gain=math.sqrt(2.0))
     _linear(sd, t + "decoder.ref_point_head.layers.1", d, d, seed)
-    code, q_cls, q_beta = _codes(cfg, seed)
+    code, q_cls, q_beta = _codes(cfg, seed, version)
     # a character query points along (its class code + 0.7 blank code): the blank part pushes every OTHER class down, as a trained
     # head does (sum of the sigmoids stays below 1, the blank channel of the decoders is 1 - sum); a blank query along the blank code
     kappa = 0.7
@@ -218,6 +262,8 @@ def _rest(sd, cfg: DTLRConfig, seed: int, d: int, C: int, ff: int):
                       code[cfg.num_classes][None]).astype(np.float32)
     sd[t + "tgt_embed.weight"] = (_normal(t + "tgt_embed.weight", seed, (cfg.num_queries, d), 0.5)
                                   + torch.from_numpy(q_beta[:, None] * math.sqrt(d) * q_code))
+    if version >= 3:
+        _prototype_memory(sd, cfg, code, q_cls, d, ff)
     _linear(sd, t + "enc_output", d, d, seed)
     _norm(sd, t + "enc_output_norm", d, seed)
     # Tokens whose proposal is invalid/padded have their memory row zeroed (models/dino/utils.py:
@@ -244,7 +290,9 @@ def _rest(sd, cfg: DTLRConfig, seed: int, d: int, C: int, ff: int):
     _linear(shared, "bbox_embed.layers.1", d, d, seed, gain=math.sqrt(2.0))
     _linear(shared, "bbox_embed.layers.2", 4, d, seed, gain=0.3)
     # v2 class head: row c = g * code_c - g_b * code_blank + noise; bias = the reference's -log(99)
-    g_cls, g_blank = 2.5, 1.0
+    g_blank = 1.0
+    # v3: per-class gains (a trained head is more confident about some characters than others) -> a spread of decision margins
+    g_cls = 2.5 if version == 2 else _rng("v3.class_gain", seed).uniform(1.4, 2.6, (C, 1)).astype(np.float32)
     shared["class_embed.weight"] = (torch.from_numpy(g_cls * code[:C] - g_blank * code[C:C + 1])
                                     + _normal("class_embed.weight", seed, (C, d), 0.25 / math.sqrt(d)))
     # bias: the reference's init -log(99) = -4.6 (dino.py:164-166), lowered by log(C / 166) for larger charsets so that the summed

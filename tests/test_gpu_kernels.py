@@ -11,6 +11,17 @@ from tests.util import msda_inputs
 pytestmark = pytest.mark.gpu
 
 
+@pytest.fixture(params=[torch.bfloat16, torch.float16], ids=["bf16", "f16"])
+def half(request):
+    """the 16-bit format under test: bf16 (libdtlr_hip.so) and IEEE fp16 (libdtlr_hip_f16.so, the same sources)"""
+    return request.param
+
+
+def ulp(half, bf16_exp):
+    """2^-bf16_exp for bf16 results, 8x tighter for fp16 (three more significand bits): tolerances below are written for bf16"""
+    return 2.0 ** -(bf16_exp + (3 if half == torch.float16 else 0))
+
+
 def _rand(shape, seed, scale=1.0):
     return torch.from_numpy((np.random.Generator(np.random.PCG64(seed)).standard_normal(shape) * scale).astype(np.float32))
 
@@ -26,20 +37,20 @@ def test_layernorm_f32(C, with_res):
     assert (got - want).abs().max() < 5e-6
 
 
-def test_layernorm_bf16_and_ragged_rows():
+def test_layernorm_bf16_and_ragged_rows(half):
     from dtlr_amd import ops
     C = 256
     for rows in (1, 3, 4, 5, 1023):
-        x, r = _rand((rows, C), rows, 2.0).bfloat16(), _rand((rows, C), rows + 1).bfloat16()
+        x, r = _rand((rows, C), rows, 2.0).to(half), _rand((rows, C), rows + 1).to(half)
         w, b = _rand((C,), 3) * 0.2 + 1.0, _rand((C,), 4) * 0.1
         want = F.layer_norm(x.float() + r.float(), (C,), w, b, 1e-5)
         got = ops.layernorm(x.cuda(), w.cuda(), b.cuda(), 1e-5, r.cuda()).cpu()
-        assert got.dtype == torch.bfloat16 and got.shape == x.shape
+        assert got.dtype == half and got.shape == x.shape
         assert (got.float() - want).abs().max() < 0.03       # one bf16 ulp at |y| <= 4
 
 
 @pytest.mark.parametrize("ref_dim", [2, 4])
-def test_msda_fused_front_end_vs_oracle(ref_dim):
+def test_msda_fused_front_end_vs_oracle(ref_dim, half):
     """dtlr_msda_fused_forward == MSDeformAttn.forward lines 97-124 (softmax, locations, sampling)."""
     from dtlr_amd import ops
     from oracle import dtlr_oracle as O
@@ -60,37 +71,37 @@ def test_msda_fused_front_end_vs_oracle(ref_dim):
     got = ops.msda_fused(v.cuda(), s.cuda(), lsi.cuda(), ow.cuda(), ref.cuda()).cpu()
     assert (got - want).abs().max() < 5e-6
     # bf16 value (+ fp32 or bf16 projection row)
-    gotb = ops.msda_fused(v.bfloat16().cuda(), s.cuda(), lsi.cuda(), ow.cuda(), ref.cuda()).cpu()
-    wantb = O.ms_deform_attn_core(v.bfloat16().float(), s, loc, aw)
-    assert (gotb.float() - wantb).abs().max() <= wantb.abs().max() * 2 ** -8 + 1e-6
-    gotbb = ops.msda_fused(v.bfloat16().cuda(), s.cuda(), lsi.cuda(), ow.bfloat16().cuda(), ref.cuda()).cpu()
-    owb = ow.bfloat16().float()
+    gotb = ops.msda_fused(v.to(half).cuda(), s.cuda(), lsi.cuda(), ow.cuda(), ref.cuda()).cpu()
+    wantb = O.ms_deform_attn_core(v.to(half).float(), s, loc, aw)
+    assert (gotb.float() - wantb).abs().max() <= wantb.abs().max() * ulp(half, 8) + 1e-6
+    gotbb = ops.msda_fused(v.to(half).cuda(), s.cuda(), lsi.cuda(), ow.to(half).cuda(), ref.cuda()).cpu()
+    owb = ow.to(half).float()
     offb = owb[..., : M * L * P * 2].view(N, Lq, M, L, P, 2)
     awb = torch.softmax(owb[..., M * L * P * 2:].view(N, Lq, M, L * P), -1).view(N, Lq, M, L, P)
-    wantbb = O.ms_deform_attn_core(v.bfloat16().float(), s, O.msda_sampling_locations(ref, offb, s, P), awb)
-    assert (gotbb.float() - wantbb).abs().max() <= wantbb.abs().max() * 2 ** -8 + 1e-5
+    wantbb = O.ms_deform_attn_core(v.to(half).float(), s, O.msda_sampling_locations(ref, offb, s, P), awb)
+    assert (gotbb.float() - wantbb).abs().max() <= wantbb.abs().max() * ulp(half, 8) + 1e-5
 
 
 @pytest.mark.parametrize("B,L", [(2, 900), (1, 37), (3, 128), (1, 1)])
-def test_mha_bf16_vs_fp32_reference(B, L):
+def test_mha_bf16_vs_fp32_reference(B, L, half):
     """Fused attention kernel vs plain fp32 softmax(QK^T/sqrt(d))V on the same bf16-rounded inputs.
     Tolerance: P and O are rounded to bf16 (2^-8 relative) -> |err| <= 2^-6 * max|v|."""
     import math
     from dtlr_amd import ops
     H, hd = 8, 32
     C = H * hd
-    qk = (_rand((B, L, 2 * C), 11) * 1.5).bfloat16()
-    v = _rand((B, L, C), 12).bfloat16()
+    qk = (_rand((B, L, 2 * C), 11) * 1.5).to(half)
+    v = _rand((B, L, C), 12).to(half)
     q = qk[..., :C].float().view(B, L, H, hd).transpose(1, 2)
     k = qk[..., C:].float().view(B, L, H, hd).transpose(1, 2)
     vv = v.float().view(B, L, H, hd).transpose(1, 2)
     want = (torch.softmax(q @ k.transpose(-1, -2) / math.sqrt(hd), -1) @ vv).transpose(1, 2).reshape(B, L, C)
     got = ops.mha(qk.cuda(), v.cuda(), H).float().cpu()
     assert got.shape == want.shape
-    assert (got - want).abs().max() <= 2 ** -6 * v.float().abs().max() + 1e-3, (got - want).abs().max()
+    assert (got - want).abs().max() <= ulp(half, 6) * v.float().abs().max() + 1e-3, (got - want).abs().max()
 
 
-def test_mha_softmax_extremes():
+def test_mha_softmax_extremes(half):
     """Large score spread (online-softmax rescale path) and a dominant key."""
     import math
     from dtlr_amd import ops
@@ -98,15 +109,15 @@ def test_mha_softmax_extremes():
     C = H * hd
     qk = (_rand((B, L, 2 * C), 21) * 4.0)
     qk[:, 150, C:] *= 6.0                       # one key with huge scores late in the sequence
-    qk = qk.bfloat16()
-    v = _rand((B, L, C), 22).bfloat16()
+    qk = qk.to(half)
+    v = _rand((B, L, C), 22).to(half)
     q = qk[..., :C].float().view(B, L, H, hd).transpose(1, 2)
     k = qk[..., C:].float().view(B, L, H, hd).transpose(1, 2)
     vv = v.float().view(B, L, H, hd).transpose(1, 2)
     want = (torch.softmax(q @ k.transpose(-1, -2) / math.sqrt(hd), -1) @ vv).transpose(1, 2).reshape(B, L, C)
     got = ops.mha(qk.cuda(), v.cuda(), H).float().cpu()
     assert torch.isfinite(got).all()
-    assert (got - want).abs().max() <= 2 ** -6 * v.float().abs().max() + 1e-3
+    assert (got - want).abs().max() <= ulp(half, 6) * v.float().abs().max() + 1e-3
 
 
 def _gemm_ref(x, w, b, relu, res, a2, mask):
@@ -149,25 +160,25 @@ def test_gemm_f32_exact_mfma(M, N, K):
 
 @pytest.mark.parametrize("M,N,K", [s for s in GEMM_SHAPES if s[2] % 64 == 0])
 @pytest.mark.parametrize("out_f32", [False, True])
-def test_gemm_bf16(M, N, K, out_f32):
+def test_gemm_bf16(M, N, K, out_f32, half):
     """bf16 MFMA GEMM, fp32 accumulation: vs fp64 reference on the same bf16-rounded operands.
     Tolerance: bf16 rounding of the a+a2 prologue (2^-8 relative per element, averaged over K) and of
     the bf16 output (2^-8 relative)."""
     from dtlr_amd import ops
-    x, a2 = _rand((M, K), 1).bfloat16(), _rand((M, K), 2).bfloat16()
-    w, b = (_rand((N, K), 3) / np.sqrt(K)).bfloat16(), _rand((N,), 4)
-    od = torch.float32 if out_f32 else torch.bfloat16
+    x, a2 = _rand((M, K), 1).to(half), _rand((M, K), 2).to(half)
+    w, b = (_rand((N, K), 3) / np.sqrt(K)).to(half), _rand((N,), 4)
+    od = torch.float32 if out_f32 else half
     res = _rand((M, N), 5).to(od)
     mask = torch.from_numpy(np.random.Generator(np.random.PCG64(6)).random(M) < 0.3)
     for relu, use_b, use_res, use_a2, use_mask in ((0, False, False, False, False), (1, True, False, False, False),
                                                    (0, True, True, True, True), (2, True, True, False, False)):
-        xa = (x.float() + a2.float()).bfloat16().float() if use_a2 else x.float()
+        xa = (x.float() + a2.float()).to(half).float() if use_a2 else x.float()
         want = _gemm_ref(xa, w.float(), b if use_b else None, relu, res.float() if use_res else None, None, mask if use_mask else None)
         got = ops.linear(x.cuda(), w.cuda(), b.cuda() if use_b else None, relu, res.cuda() if use_res else None,
                          a2.cuda() if use_a2 else None, mask.cuda() if use_mask else None, out_dtype=od).cpu()
         assert got.dtype == od and got.shape == want.shape
         scale = max(1.0, want.abs().max().item())
-        tol = (2e-5 if out_f32 else 2 ** -8) * scale + 1e-4
+        tol = (2e-5 if out_f32 else ulp(half, 8)) * scale + 1e-4
         assert (got.float() - want).abs().max() < tol, (relu, use_b, use_res, use_a2, use_mask, (got.float() - want).abs().max().item())
 
 
@@ -176,7 +187,7 @@ def test_gemm_bf16(M, N, K, out_f32):
                                                ([(5, 83), (3, 42), (2, 21), (1, 11)], 3.0),          # odd sizes (not exact halves)
                                                ([(4, 32), (2, 16), (1, 8), (1, 4)], 1.5),
                                                ([(1, 7), (1, 4), (1, 2), (1, 1)], 1.0)])
-def test_msda_encoder_lds_vs_oracle(level_hw, offscale):
+def test_msda_encoder_lds_vs_oracle(level_hw, offscale, half):
     """LDS-staged encoder kernel == oracle MSDeformAttn (softmax + locations + sampling) for every query
     of every level, including samples that leave the staged window (global path) and level shapes that
     are not exact halves; checked for the default halo and halo 0 (window = tile only)."""
@@ -200,9 +211,11 @@ def test_msda_encoder_lds_vs_oracle(level_hw, offscale):
             got = ops.msda_encoder(v.cuda(), level_hw, ow.cuda(), ref.cuda()).cpu()
             assert (got - want).abs().max() < 5e-6, (halo, (got - want).abs().max().item())
         ops.MSDA_HALO = 8
-        gotb = ops.msda_encoder(v.bfloat16().cuda(), level_hw, ow.cuda(), ref.cuda()).float().cpu()
-        wantb = O.ms_deform_attn_core(v.bfloat16().float(), s, O.msda_sampling_locations(ref, off, s, P), aw)
-        assert (gotb - wantb).abs().max() <= wantb.abs().max() * 2 ** -8 + 1e-6
+        gotb = ops.msda_encoder(v.to(half).cuda(), level_hw, ow.cuda(), ref.cuda()).float().cpu()
+        wantb = O.ms_deform_attn_core(v.to(half).float(), s, O.msda_sampling_locations(ref, off, s, P), aw)
+        # the 16-bit query phase accumulates each level's 16 corner terms in packed fp16 (~2^-11 per term) whatever the storage format:
+        # bf16 results are dominated by their own output rounding (2^-9), fp16 results by that accumulation (a few 2^-11)
+        assert (gotb - wantb).abs().max() <= wantb.abs().max() * (ulp(half, 8) if half == torch.bfloat16 else 2.0 ** -9) + 1e-6
         # must agree with the gather kernel bit-for-bit in fp32 (same arithmetic order)
         g2 = ops.msda_fused(v.cuda(), s.cuda(), lsi.cuda(), ow.cuda(), ref.cuda()).cpu()
         assert (g2 - got).abs().max() < 1e-6
@@ -213,7 +226,7 @@ def test_msda_encoder_lds_vs_oracle(level_hw, offscale):
 @pytest.mark.parametrize("B,H,W,Cin,Cout,k,stride,pad", [(2, 16, 40, 64, 64, 3, 1, 1), (3, 9, 33, 128, 128, 3, 2, 1),
                                                          (1, 4, 64, 2048, 256, 3, 2, 1), (2, 5, 7, 32, 48, 3, 1, 1),
                                                          (2, 6, 10, 64, 96, 1, 1, 0)])
-def test_conv2d_nhwc_implicit_gemm(B, H, W, Cin, Cout, k, stride, pad):
+def test_conv2d_nhwc_implicit_gemm(B, H, W, Cin, Cout, k, stride, pad, half):
     """Implicit-GEMM NHWC convolution vs torch CPU conv2d (fp64 reference), with bias / residual / ReLU;
     includes stride 2, odd sizes (tile tails) and zero padding taps."""
     import torch.nn.functional as F
@@ -231,14 +244,14 @@ def test_conv2d_nhwc_implicit_gemm(B, H, W, Cin, Cout, k, stride, pad):
         assert got.shape == want.shape
         assert (got - want.float()).abs().max() < 3e-5 * max(1.0, want.abs().max().item()), (relu, use_res)
     if (Cin * 2) % 128 == 0:
-        xb, wb = x.bfloat16(), w_ohwi.bfloat16()
+        xb, wb = x.to(half), w_ohwi.to(half)
         refb = F.conv2d(xb.float().permute(0, 3, 1, 2).double(), wb.float().permute(0, 3, 1, 2).double(), b.double(),
                         stride=stride, padding=pad).permute(0, 2, 3, 1).clamp(min=0).float()
         gotb = ops.conv2d_nhwc(xb.cuda(), wb.cuda(), b.cuda(), stride, pad, True, None).float().cpu()
-        assert (gotb - refb).abs().max() < 2 ** -8 * max(1.0, refb.abs().max().item()) + 1e-4
+        assert (gotb - refb).abs().max() < ulp(half, 8) * max(1.0, refb.abs().max().item()) + 1e-4
 
 
-def test_decoder_query_prep_and_box_refine_vs_oracle():
+def test_decoder_query_prep_and_box_refine_vs_oracle(half):
     """Fused decoder glue == oracle gen_sineembed_for_position / reference scaling / inverse_sigmoid refinement."""
     from dtlr_amd import ops
     from oracle import dtlr_oracle as O
@@ -252,8 +265,8 @@ def test_decoder_query_prep_and_box_refine_vs_oracle():
     assert (ref_in.cpu() - want_in).abs().max() < 1e-7
     want_sine = O.gen_sineembed_for_position(want_in[:, :, 0, :])
     assert (sine.cpu() - want_sine).abs().max() < 2e-6
-    _, sine_b = ops.decoder_query_prep(ref.cuda(), vr.cuda(), torch.bfloat16)
-    assert (sine_b.float().cpu() - want_sine).abs().max() < 2 ** -8
+    _, sine_b = ops.decoder_query_prep(ref.cuda(), vr.cuda(), half)
+    assert (sine_b.float().cpu() - want_sine).abs().max() < ulp(half, 8)
     delta = torch.from_numpy(g.standard_normal((B, nq, 4)).astype(np.float32))
     got = ops.box_refine(delta.cuda(), ref.cuda()).cpu()
     want = (delta + O.inverse_sigmoid(ref)).sigmoid()
@@ -281,7 +294,7 @@ def test_box_head_refine_vs_reference():
 
 
 @pytest.mark.parametrize("B,T", [(2, 4096), (3, 37), (1, 1), (2, 128)])
-def test_groupnorm_tokens(B, T):
+def test_groupnorm_tokens(B, T, half):
     import torch.nn.functional as F
     from dtlr_amd import ops
     x = _rand((B, T, 256), 1, 2.0) + 0.7
@@ -289,27 +302,27 @@ def test_groupnorm_tokens(B, T):
     want = F.group_norm(x.double().transpose(1, 2), 32, w.double(), b.double(), 1e-5).transpose(1, 2).float()
     got = ops.groupnorm_tokens(x.cuda(), 32, w.cuda(), b.cuda()).cpu()
     assert (got - want).abs().max() < 2e-5
-    xb = x.bfloat16()
+    xb = x.to(half)
     wantb = F.group_norm(xb.double().transpose(1, 2), 32, w.double(), b.double(), 1e-5).transpose(1, 2).float()
     gotb = ops.groupnorm_tokens(xb.cuda(), 32, w.cuda(), b.cuda()).float().cpu()
-    assert (gotb - wantb).abs().max() < 2 ** -7 * max(1.0, wantb.abs().max().item())
+    assert (gotb - wantb).abs().max() < ulp(half, 7) * max(1.0, wantb.abs().max().item())
 
 
 @pytest.mark.parametrize("B,H,W,C", [(2, 64, 96, 64), (1, 7, 9, 64), (2, 1, 1, 8), (1, 5, 4, 16)])
-def test_maxpool_nhwc(B, H, W, C):
+def test_maxpool_nhwc(B, H, W, C, half):
     import torch.nn.functional as F
     from dtlr_amd import ops
     x = _rand((B, H, W, C), 5)
     want = F.max_pool2d(x.permute(0, 3, 1, 2), 3, 2, 1).permute(0, 2, 3, 1)
     assert torch.equal(ops.maxpool_nhwc(x.cuda()).cpu(), want)
-    xb = x.bfloat16()
+    xb = x.to(half)
     wantb = F.max_pool2d(xb.float().permute(0, 3, 1, 2), 3, 2, 1).permute(0, 2, 3, 1)
     assert torch.equal(ops.maxpool_nhwc(xb.cuda()).float().cpu(), wantb)
     # fused stem tail: maxpool(relu(x + bias)) -- bit-exact in fp32 (max and +bias commute under monotone rounding)
     b = _rand((C,), 6)
     wantf = F.max_pool2d(torch.relu(x + b).permute(0, 3, 1, 2), 3, 2, 1).permute(0, 2, 3, 1)
     assert torch.equal(ops.maxpool_nhwc(x.cuda(), bias=b.cuda(), relu=True).cpu(), wantf)
-    wantfb = F.max_pool2d(torch.relu(xb.float() + b).permute(0, 3, 1, 2), 3, 2, 1).permute(0, 2, 3, 1).bfloat16().float()
+    wantfb = F.max_pool2d(torch.relu(xb.float() + b).permute(0, 3, 1, 2), 3, 2, 1).permute(0, 2, 3, 1).to(half).float()
     assert torch.equal(ops.maxpool_nhwc(xb.cuda(), bias=b.cuda(), relu=True).float().cpu(), wantfb)
 
 
@@ -371,7 +384,7 @@ def test_mha_f32_vs_fp64_reference(B, L):
 
 @pytest.mark.parametrize("M,dff", [(128, 2048), (300, 2048), (1000, 512), (4097, 2048), (37, 64), (4097, 512),
                                    (50152, 128), (89152, 128), (40000, 128), (33000, 2048), (49153, 512)])
-def test_ffn_fused_bf16_vs_reference(M, dff):
+def test_ffn_fused_bf16_vs_reference(M, dff, half):
     """Fused FFN + residual + LayerNorm (dtlr_ffn_fused_bf16) vs an fp64 restatement of
     norm(x + linear2(relu(linear1(x)))) (deformable_transformer.py:804-823) on the same bf16-rounded
     inputs, with the intermediate rounded to bf16 as the kernel (and the unfused path) does; and vs the
@@ -380,18 +393,18 @@ def test_ffn_fused_bf16_vs_reference(M, dff):
     128- or 192-token remainder launch).  (The product library reads no environment variables: the dispatch is a function of the
     shape only.)"""
     from dtlr_amd import ops
-    x = _rand((M, 256), 1).bfloat16()
-    w1 = (_rand((dff, 256), 2) / 16).bfloat16()
-    w2 = (_rand((256, dff), 3) / np.sqrt(dff)).bfloat16()
+    x = _rand((M, 256), 1).to(half)
+    w1 = (_rand((dff, 256), 2) / 16).to(half)
+    w2 = (_rand((256, dff), 3) / np.sqrt(dff)).to(half)
     b1, b2 = _rand((dff,), 4) * 0.5, _rand((256,), 5) * 0.5
     gw, gb = 1 + 0.2 * _rand((256,), 6), 0.3 * _rand((256,), 7)
-    h = torch.relu(x.double() @ w1.double().t() + b1.double()).bfloat16().double()
+    h = torch.relu(x.double() @ w1.double().t() + b1.double()).to(half).double()
     pre = x.double() + h @ w2.double().t() + b2.double()
     want = torch.nn.functional.layer_norm(pre, (256,), gw.double(), gb.double(), 1e-5).float()
     got = ops.ffn_fused(x.cuda(), w1.cuda(), b1.cuda(), ops.ffn_pack_w2(w2.cuda()), b2.cuda(), gw.cuda(), gb.cuda()).float().cpu()
     assert got.shape == want.shape
     # bf16 output rounding (2^-9 relative) + occasional 1-ulp flips of the bf16 intermediate
-    tol = 2 ** -8 * max(1.0, want.abs().max().item()) + 2e-2
+    tol = ulp(half, 8) * max(1.0, want.abs().max().item()) + 2e-2
     assert (got - want).abs().max() < tol, (got - want).abs().max().item()
     assert (got - want).abs().mean() < 4e-3
     hh = ops.linear(x.cuda(), w1.cuda(), b1.cuda(), relu=True)
@@ -400,52 +413,52 @@ def test_ffn_fused_bf16_vs_reference(M, dff):
 
 
 @pytest.mark.parametrize("B,H,W", [(2, 128, 2048), (1, 37, 531), (3, 8, 16), (1, 128, 2560)])
-def test_stem_conv7x7_vs_reference(B, H, W):
+def test_stem_conv7x7_vs_reference(B, H, W, half):
     """Own stem kernel (7x7/s2/p3, 3->64, NCHW fp32 in, NHWC bf16 out) vs torch conv2d in fp64 on the same
     bf16-rounded image and weights; odd sizes exercise the zero padding and the column/row tails."""
     import torch.nn.functional as F
     from dtlr_amd import ops
     x = _rand((B, 3, H, W), 1)
     w = _rand((64, 3, 7, 7), 2) / 12
-    frag = ops.stem_pack_weights(w)
-    got = ops.stem_conv7x7(x.cuda(), frag.cuda()).float().cpu()
-    want = F.conv2d(x.bfloat16().double(), w.bfloat16().double(), None, stride=2, padding=3).permute(0, 2, 3, 1).float()
+    frag = ops.stem_pack_weights(w, half)
+    got = ops.stem_conv7x7(x.cuda(), frag.cuda(), half).float().cpu()
+    want = F.conv2d(x.to(half).double(), w.to(half).double(), None, stride=2, padding=3).permute(0, 2, 3, 1).float()
     assert got.shape == want.shape
-    assert (got - want).abs().max() <= 2 ** -8 * max(1.0, want.abs().max().item()) + 1e-5
+    assert (got - want).abs().max() <= ulp(half, 8) * max(1.0, want.abs().max().item()) + 1e-5
 
 
 @pytest.mark.parametrize("M", [128, 300, 4097, 37])
-def test_proj_ln_bf16_vs_reference(M):
+def test_proj_ln_bf16_vs_reference(M, half):
     """Fused output projection + residual + LayerNorm (dtlr_proj_ln_bf16) vs fp64 on the same bf16 inputs, and vs the
     unfused HIP path (GEMM with residual epilogue + LayerNorm kernel)."""
     from dtlr_amd import ops
-    a, r = _rand((M, 256), 1).bfloat16(), _rand((M, 256), 2).bfloat16()
-    w = (_rand((256, 256), 3) / 16).bfloat16()
+    a, r = _rand((M, 256), 1).to(half), _rand((M, 256), 2).to(half)
+    w = (_rand((256, 256), 3) / 16).to(half)
     b = _rand((256,), 4) * 0.5
     gw, gb = 1 + 0.2 * _rand((256,), 6), 0.3 * _rand((256,), 7)
     pre = r.double() + a.double() @ w.double().t() + b.double()
     want = torch.nn.functional.layer_norm(pre, (256,), gw.double(), gb.double(), 1e-5).float()
     got = ops.proj_ln(a.cuda(), ops.proj_pack_w(w.cuda()), b.cuda(), r.cuda(), gw.cuda(), gb.cuda()).float().cpu()
-    tol = 2 ** -8 * max(1.0, want.abs().max().item()) + 1e-3
+    tol = ulp(half, 8) * max(1.0, want.abs().max().item()) + 1e-3
     assert (got - want).abs().max() < tol, (got - want).abs().max().item()
     un = ops.layernorm(ops.linear(a.cuda(), w.cuda(), b.cuda()), gw.cuda(), gb.cuda(), 1e-5, residual=r.cuda()).float().cpu()
     assert (got - un).abs().max() < 3 * tol
 
 
 @pytest.mark.parametrize("mode", [0, 1])
-def test_box_mlp_refine_bf16_vs_reference(mode):
+def test_box_mlp_refine_bf16_vs_reference(mode, half):
     """One-launch box MLP (256->256->256->4) + refinement vs fp64 on bf16-rounded inputs/weights (hidden layer 1 rounded to
     bf16 as the kernel does), and vs the three-launch HIP path."""
     from dtlr_amd import ops
     from oracle import dtlr_oracle as O
     M = 2 * 900 + 5
-    x = _rand((M, 256), 1).bfloat16()
-    w1, w2 = (_rand((256, 256), 2) / 16).bfloat16(), (_rand((256, 256), 3) / 16).bfloat16()
+    x = _rand((M, 256), 1).to(half)
+    w1, w2 = (_rand((256, 256), 2) / 16).to(half), (_rand((256, 256), 3) / 16).to(half)
     b1, b2 = _rand((256,), 4) * 0.3, _rand((256,), 5) * 0.3
     w3, b3 = _rand((4, 256), 6) / 16, _rand((4,), 7) * 0.1
     g = np.random.Generator(np.random.PCG64(5))
     ref = torch.from_numpy(g.uniform(-0.1, 1.1, (M, 4)).astype(np.float32))
-    h1 = torch.relu(x.double() @ w1.double().t() + b1.double()).bfloat16().double()
+    h1 = torch.relu(x.double() @ w1.double().t() + b1.double()).to(half).double()
     h2 = torch.relu(h1 @ w2.double().t() + b2.double())
     delta = h2 @ w3.double().t() + b3.double()
     want = (torch.sigmoid(delta + O.inverse_sigmoid(ref).double()) if mode == 0 else delta + ref.double()).float()
@@ -547,15 +560,15 @@ def test_evaluate_ctc_step_matches_oracle():
 
 
 @pytest.mark.parametrize("M", [128, 300, 4097])
-def test_proj_ln_split_and_split_head(M):
+def test_proj_ln_split_and_split_head(M, half):
     """Two-stage front end of the bf16 engine: dtlr_proj_ln_split_bf16 = LayerNorm(Linear(masked a)) as [hi | lo | hi], and the
     class head on [W_hi | W_hi | W_lo].  (1) hi + lo == the fp64 LayerNorm of the same bf16 inputs up to fp32-accumulation noise;
     (2) images 0 and 2 are identical and lo is at most half a bf16 ulp of hi; (3) the split-product scores equal
     (hi + lo) W^T + b computed in fp64 to ~2^-16 relative -- the precision the fp32 MFMA head was kept for; (4) padded head rows
     come out as -inf so a max over the padded width is the max over the real classes."""
     from dtlr_amd import ops
-    a = _rand((M, 256), 1).bfloat16()
-    w = (_rand((256, 256), 3) / 16).bfloat16()
+    a = _rand((M, 256), 1).to(half)
+    w = (_rand((256, 256), 3) / 16).to(half)
     b = _rand((256,), 4) * 0.5
     gw, gb = 1 + 0.2 * _rand((256,), 6), 0.3 * _rand((256,), 7)
     keep = (torch.arange(M) % 7 != 3)
@@ -566,12 +579,12 @@ def test_proj_ln_split_and_split_head(M):
     hi, lo, hi2 = y3[:, :256].cpu(), y3[:, 256:512].cpu(), y3[:, 512:].cpu()
     assert torch.equal(hi, hi2)
     rec = hi.double() + lo.double()
-    assert (lo.double().abs() <= hi.double().abs() * 2.0 ** -8 + 1e-30).all()       # lo is the rounding residue of hi: at most half an ulp
+    assert (lo.double().abs() <= hi.double().abs() * ulp(half, 8) + 1e-7).all()       # lo is the rounding residue of hi: at most half an ulp (fp16: + its subnormal floor)
     assert (rec - want).abs().max() < 2e-3 * max(1.0, want.abs().max().item())
     assert (rec[~keep] - rec[~keep][0]).abs().max() == 0            # masked rows: LayerNorm of the bias alone, all identical
     C = 166
     hw, hb = _rand((C, 256), 8) / 8, _rand((C,), 9) - 4.6
-    w3, b3 = ops.split_head_weight(hw.cuda(), hb.cuda())
+    w3, b3 = ops.split_head_weight(hw.cuda(), hb.cuda(), dtype=half)
     assert tuple(w3.shape) == (192, 768) and torch.isinf(b3[C:]).all()
     sc = ops.linear(y3, w3, b3, out_dtype=torch.float32).cpu()
     ref = rec @ hw.double().t() + hb.double()
@@ -671,7 +684,7 @@ def _geometry_masks(B, H, W, kind, seed):
 
 
 @pytest.mark.parametrize("H,W,kind", [(128, 2048, "none"), (128, 2048, "rect"), (128, 2560, "rect"), (64, 200, "random"), (448, 1344, "rect")])
-@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16, torch.float16])
 def test_geometry_kernel_vs_oracle(H, W, kind, dtype):
     """dtlr_geometry == the oracle's restatements of interpolate_mask / PositionEmbeddingSineHW / get_valid_ratio /
     get_reference_points / gen_encoder_output_proposals, for unpadded, collate-style and arbitrary masks (incl. a tall canvas and a
@@ -719,12 +732,13 @@ def test_stem_conv7x7_f32_vs_reference(B, H, W):
     assert (got - want).abs().max() < 2e-5
 
 
-@pytest.mark.parametrize("M,N,K,dt", [(5440 * 2, 192, 768, torch.bfloat16), (1000, 7356, 768, torch.bfloat16), (777, 166, 256, torch.float32),
+@pytest.mark.parametrize("M,N,K,dt", [(5440 * 2, 192, 768, "h16"), (1000, 7356, 768, "h16"), (777, 166, 256, torch.float32),
                                       (130, 23, 256, torch.float32)])
-def test_linear_rowmax_vs_reference(M, N, K, dt):
+def test_linear_rowmax_vs_reference(M, N, K, dt, half):
     """The GEMM's row-max epilogue == (x @ w.T + b).max(-1) computed from the full product of the same kernel (so the comparison is
     exact up to nothing: max is order-independent) and close to the fp32 CPU product; -inf padded bias rows never win."""
     from dtlr_amd import ops
+    dt = half if dt == "h16" else dt
     x = _rand((M, K), 1).to(dt)
     w = _rand((N, K), 2, 0.1).to(dt)
     b = _rand((N,), 3)
@@ -737,11 +751,12 @@ def test_linear_rowmax_vs_reference(M, N, K, dt):
     assert (got.cpu() - want).abs().max() < (1e-4 if dt == torch.float32 else 2e-3)
 
 
-@pytest.mark.parametrize("dt", [torch.bfloat16, torch.float32])
-def test_two_stage_gather(dt):
+@pytest.mark.parametrize("dt", ["h16", torch.float32])
+def test_two_stage_gather(dt, half):
     from dtlr_amd import ops
+    dt = half if dt == "h16" else dt
     B, S, k = 3, 700, 90
-    om = _rand((B, S, 768 if dt == torch.bfloat16 else 256), 5).to(dt)
+    om = _rand((B, S, 768 if dt == half else 256), 5).to(dt)
     prop = _rand((B, S, 4), 6)
     prop[0, 5] = float("inf")
     g = np.random.Generator(np.random.PCG64(2))
@@ -753,8 +768,8 @@ def test_two_stage_gather(dt):
     wp = torch.gather(prop, 1, idx[..., None].expand(-1, -1, 4))
     assert torch.equal(ps.cpu(), wp)
     assert (ib.cpu() - wp.sigmoid()).abs().max() < 1e-6
-    if dt == torch.bfloat16:
-        assert torch.equal(sx.cpu(), (want[..., :256].float() + want[..., 256:512].float()).bfloat16())
+    if dt == half:
+        assert torch.equal(sx.cpu(), (want[..., :256].float() + want[..., 256:512].float()).to(half))
     else:
         assert sx is None
 
@@ -790,7 +805,7 @@ def test_no_library_fallbacks():
         ops.conv2d_nhwc(_rand((1, 8, 8, 3), 1).cuda(), _rand((4, 3, 3, 3), 2).cuda(), None, 1, 1)
 
 
-def test_tall_canvas_falls_back_to_gather_msda_and_global_topk():
+def test_tall_canvas_falls_back_to_gather_msda_and_global_topk(half):
     """A 448x1344 line (eval transform: short side 800 / max 1333 for aspect ratio < 5): the LDS-window encoder kernel's plan does
     not fit (fp32) and S = 9408+... tokens; the engine must fall back to the gather kernel and still match the oracle."""
     from dtlr_amd import ops
@@ -813,10 +828,11 @@ def test_tall_canvas_falls_back_to_gather_msda_and_global_topk():
     assert (out["pred_boxes"].cpu() - ref["pred_boxes"]).abs().max() < 1e-4
 
 
-@pytest.mark.parametrize("dt", [torch.bfloat16, torch.float32])
-def test_linear_row_broadcast_a2(dt):
+@pytest.mark.parametrize("dt", ["h16", torch.float32])
+def test_linear_row_broadcast_a2(dt, half):
     """(x + a2[m % S]) @ w.T + b with a2 = one [S, K] matrix shared by every image of the batch == the full-size a2 path."""
     from dtlr_amd import ops
+    dt = half if dt == "h16" else dt
     B, S, K, N = 3, 333, 256, 384
     x, a2 = _rand((B, S, K), 1).to(dt), _rand((S, K), 2).to(dt)
     w, b = _rand((N, K), 3, 0.1).to(dt), _rand((N,), 4)
@@ -828,12 +844,12 @@ def test_linear_row_broadcast_a2(dt):
 
 
 @pytest.mark.parametrize("M,N", [(174080, 256), (5440 * 3, 384), (1000, 384), (63, 256), (64 * 257 + 5, 256)])
-def test_gemm_k256_weight_resident_vs_tiled_kernel(M, N):
+def test_gemm_k256_weight_resident_vs_tiled_kernel(M, N, half):
     """dtlr_gemm_k256 (weights in registers, tokens streamed through an LDS ring by DMA) == the tiled GEMM on the same operands:
     same MFMA, same k order -> the bf16 results are identical; ragged M, one tile, many tiles per workgroup."""
     from dtlr_amd import ops
-    x = _rand((M, 256), 1).bfloat16().cuda()
-    w = _rand((N, 256), 2, 0.1).bfloat16().cuda()
+    x = _rand((M, 256), 1).to(half).cuda()
+    w = _rand((N, 256), 2, 0.1).to(half).cuda()
     b = _rand((N,), 3).cuda()
     want = ops.linear(x, w, b)
     got = ops.gemm_k256(x, ops.k256_pack(w), N, b)
@@ -848,25 +864,25 @@ def test_gemm_k256_weight_resident_vs_tiled_kernel(M, N):
 
 
 @pytest.mark.parametrize("B,S,N", [(3, 700, 384), (5, 640, 384), (32, 5440, 384), (7, 128, 256)])
-def test_gemm_k256_epilogues(B, S, N):
+def test_gemm_k256_epilogues(B, S, N, half):
     """Row-broadcast residual (m % rows), padding-row zeroing and strided output (column slice of a wider matrix).  S % 64 == 0
     takes the position-major tile order (a workgroup walks one residual tile across the images); S = 700 the row order."""
     from dtlr_amd import ops
-    x = _rand((B, S, 256), 1).bfloat16().cuda()
-    w = _rand((N, 256), 2, 0.1).bfloat16().cuda()
+    x = _rand((B, S, 256), 1).to(half).cuda()
+    w = _rand((N, 256), 2, 0.1).to(half).cuda()
     b = _rand((N,), 3).cuda()
-    res = _rand((S, N), 4).bfloat16().cuda()
+    res = _rand((S, N), 4).to(half).cuda()
     mask = (torch.rand((B, S)) < 0.2).cuda()
     wp = ops.k256_pack(w)
     got = ops.gemm_k256(x, wp, N, None, resid=res)
-    want = (x.float() @ w.float().t() + res.float()[None]).bfloat16()
+    want = (x.float() @ w.float().t() + res.float()[None]).to(half)
     assert (got.float() - want.float()).abs().max() <= 0.07          # one bf16 ulp at |y| < 16
     got = ops.gemm_k256(x, wp, N, b, resid=res, row_mask=mask)       # residual and padding rows together
-    want = (x.float() @ w.float().t() + b + res.float()[None]).bfloat16()
+    want = (x.float() @ w.float().t() + b + res.float()[None]).to(half)
     want[mask] = 0
     assert (got.float() - want.float()).abs().max() <= 0.07
     assert (got[mask] == 0).all()
-    wide = torch.full((B, S, 1536), 7.0, dtype=torch.bfloat16, device="cuda")
+    wide = torch.full((B, S, 1536), 7.0, dtype=half, device="cuda")
     ops.gemm_k256(x, wp, N, b, row_mask=mask, out=wide[..., 384:384 + N])
     full = ops.linear(x, w, b, row_mask=mask)
     assert torch.equal(wide[..., 384:384 + N], full)
@@ -875,36 +891,36 @@ def test_gemm_k256_epilogues(B, S, N):
 
 
 @pytest.mark.parametrize("B,H,W", [(2, 32, 512), (1, 33, 517)])
-def test_tall_tile_kernel_n64_conv_and_linear(B, H, W):
+def test_tall_tile_kernel_n64_conv_and_linear(B, H, W, half):
     """The 256 x 64 tile variant (N <= 64, bf16, M >= 16384: ResNet layer1's 3x3 64->64 convolutions and 256->64 reductions) against
     fp64 CPU references: bias + ReLU, residual + ReLU, ragged last tile, zero-padding taps."""
     import torch.nn.functional as F
     from dtlr_amd import ops
-    x = _rand((B, H, W, 64), 1).bfloat16()
-    w = (_rand((64, 64, 3, 3), 2) / 24.0).bfloat16()
+    x = _rand((B, H, W, 64), 1).to(half)
+    w = (_rand((64, 64, 3, 3), 2) / 24.0).to(half)
     b = _rand((64,), 3)
-    res = _rand((B, H, W, 64), 4).bfloat16()
+    res = _rand((B, H, W, 64), 4).to(half)
     ref = F.conv2d(x.float().permute(0, 3, 1, 2).double(), w.float().double(), b.double(), stride=1, padding=1).permute(0, 2, 3, 1)
     w_ohwi = w.permute(0, 2, 3, 1).contiguous()
     for use_res in (False, True):
         want = (ref + res.double() if use_res else ref).clamp(min=0).float()
         got = ops.conv2d_nhwc(x.cuda(), w_ohwi.cuda(), b.cuda(), 1, 1, True, res.cuda() if use_res else None).float().cpu()
-        assert (got - want).abs().max() < 2 ** -8 * max(1.0, want.abs().max().item()) + 1e-4, use_res
-    xl = _rand((B * H * W, 256), 5).bfloat16()
-    wl = (_rand((64, 256), 6) / 16.0).bfloat16()
+        assert (got - want).abs().max() < ulp(half, 8) * max(1.0, want.abs().max().item()) + 1e-4, use_res
+    xl = _rand((B * H * W, 256), 5).to(half)
+    wl = (_rand((64, 256), 6) / 16.0).to(half)
     want = (xl.float().double() @ wl.float().double().t() + b.double()).clamp(min=0).float()
     got = ops.linear(xl.cuda(), wl.cuda(), b.cuda(), relu=2).float().cpu()
-    assert (got - want).abs().max() < 2 ** -8 * max(1.0, want.abs().max().item()) + 1e-4
+    assert (got - want).abs().max() < ulp(half, 8) * max(1.0, want.abs().max().item()) + 1e-4
 
 
 @pytest.mark.parametrize("M", [174080, 65536 + 37, 64, 100])
-def test_proj_ln_k256_vs_reference(M):
+def test_proj_ln_k256_vs_reference(M, half):
     """The weight-resident output-projection + residual + LayerNorm kernel against an fp32 reference and against the round-1 kernel
     (same arithmetic up to the summation order of the statistics); host packer == tensor-op packer."""
     from dtlr_amd import _lib, ops
-    a = _rand((M, 256), 1).bfloat16()
-    r = _rand((M, 256), 2).bfloat16()
-    w = (_rand((256, 256), 3) / 16.0).bfloat16()
+    a = _rand((M, 256), 1).to(half)
+    r = _rand((M, 256), 2).to(half)
+    w = (_rand((256, 256), 3) / 16.0).to(half)
     b, gw, gb = _rand((256,), 4) * 0.1, _rand((256,), 5) * 0.2 + 1.0, _rand((256,), 6) * 0.1
     want = F.layer_norm(r.float() + a.float() @ w.float().t() + b, (256,), gw, gb, 1e-5)
     got = ops.proj_ln_k256(a.cuda(), ops.proj_ln_k256_pack(w).cuda(), b.cuda(), r.cuda(), gw.cuda(), gb.cuda())
@@ -919,24 +935,24 @@ def test_proj_ln_k256_vs_reference(M):
 
 
 @pytest.mark.parametrize("M,d_ff", [(256, 128), (1000, 2048), (65536 + 77, 2048), (174080, 2048), (700, 64), (513, 96), (300, 160), (1, 1024)])
-def test_ffn32_vs_reference_and_first_structures(M, d_ff):
+def test_ffn32_vs_reference_and_first_structures(M, d_ff, half):
     """The 32x32x16-MFMA fused FFN (dtlr_ffn32_bf16) against an fp32 reference that rounds the hidden activations to bf16 like the
     kernel does, and against the 16x16x32 kernels (same arithmetic up to fp32 summation order); host packer == tensor-op packer."""
     from dtlr_amd import _lib, ops
-    x = _rand((M, 256), 1).bfloat16()
-    w1 = (_rand((d_ff, 256), 2) / 16.0).bfloat16()
-    w2 = (_rand((256, d_ff), 3) / 45.0).bfloat16()
+    x = _rand((M, 256), 1).to(half)
+    w1 = (_rand((d_ff, 256), 2) / 16.0).to(half)
+    w2 = (_rand((256, d_ff), 3) / 45.0).to(half)
     b1, b2 = _rand((d_ff,), 4) * 0.1, _rand((256,), 5) * 0.1
     gw, gb = _rand((256,), 6) * 0.2 + 1.0, _rand((256,), 7) * 0.1
-    h = torch.relu(x.float() @ w1.float().t() + b1).bfloat16().float()
+    h = torch.relu(x.float() @ w1.float().t() + b1).to(half).float()
     want = F.layer_norm(x.float() + h @ w2.float().t() + b2, (256,), gw, gb, 1e-5)
     w1p, w2p = ops.ffn32_pack(w1.cuda(), w2.cuda())
     got = ops.ffn32(x.cuda(), w1p, b1.cuda(), w2p, b2.cuda(), gw.cuda(), gb.cuda())
     assert (got.float().cpu() - want).abs().max() < 0.05
     if d_ff >= 128:
         old = ops.ffn_fused(x.cuda(), w1.cuda(), b1.cuda(), ops.ffn_pack_w2(w2.cuda()), b2.cuda(), gw.cuda(), gb.cuda())
-        assert (got.float() - old.float()).abs().max() <= 0.0315            # at most one bf16 ulp at |y| < 8
-        assert (got == old).float().mean() > 0.995
+        assert (got.float() - old.float()).abs().max() <= 0.0315            # at most one bf16 ulp at |y| < 8 (fp16: 8x finer, same bound holds)
+        assert (got == old).float().mean() > (0.995 if half == torch.bfloat16 else 0.98)     # fp16's finer grid: two summation orders round apart more often
     a1 = np.ascontiguousarray(w1.view(torch.int16).numpy()).view(np.uint16)
     a2 = np.ascontiguousarray(w2.view(torch.int16).numpy()).view(np.uint16)
     n = (d_ff // 32 + _lib.lib().dtlr_ffn32_pad_chunks()) * 8192
@@ -949,14 +965,14 @@ def test_ffn32_vs_reference_and_first_structures(M, d_ff):
 @pytest.mark.parametrize("M,N,K,res", [(524288, 256, 64, True), (131072, 512, 128, True), (32768, 1024, 256, True), (16384 + 37, 256, 64, False),
                                          (20000, 2048, 256, True), (16500, 256, 128, True), (17000, 512, 64, True),
                                          (524288, 64, 256, False), (131072 + 5, 128, 256, False), (20000, 64, 64, False), (16400, 192, 128, False)])
-def test_gemm_kres_vs_tiled_kernel(M, N, K, res):
+def test_gemm_kres_vs_tiled_kernel(M, N, K, res, half):
     """dtlr_gemm_kres (weights resident, A and residual tiles DMA'd through an LDS ring) == the tiled GEMM on the same operands: same MFMA,
     same k order, same fp32 epilogue order (bias, residual, ReLU) -> identical bf16 results; ragged M; host packer == tensor-op packer."""
     from dtlr_amd import _lib, ops
-    x = _rand((M, K), 1).bfloat16().cuda()
-    w = (_rand((N, K), 2) / (K ** 0.5)).bfloat16().cuda()
+    x = _rand((M, K), 1).to(half).cuda()
+    w = (_rand((N, K), 2) / (K ** 0.5)).to(half).cuda()
     b = _rand((N,), 3).cuda()
-    r = _rand((M, N), 4).bfloat16().cuda() if res else None
+    r = _rand((M, N), 4).to(half).cuda() if res else None
     do_relu = res or N < 256                                         # narrow outputs: the bottleneck's first convolution (bias + ReLU)
     want = ops.linear(x, w, b, relu=(2 if do_relu else 0), residual=r)
     wp = ops.kres_pack(w)
@@ -969,16 +985,16 @@ def test_gemm_kres_vs_tiled_kernel(M, N, K, res):
 
 
 @pytest.mark.parametrize("B,S", [(32, 5440), (3, 640), (1, 64)])
-def test_gemm_kres_bcast384_vs_k256_kernel(B, S):
+def test_gemm_kres_bcast384_vs_k256_kernel(B, S, half):
     """The [offsets | logits] projection with the row-broadcast residual DMA'd through LDS (zero-padded 512-channel column, position-major
     tiles) against the fp32 reference and the streaming K = 256 kernel; host packer == tensor-op packer."""
     from dtlr_amd import _lib, ops
-    x = _rand((B, S, 256), 1).bfloat16().cuda()
-    w = _rand((384, 256), 2, 0.1).bfloat16().cuda()
-    res = _rand((S, 384), 4).bfloat16().cuda()
+    x = _rand((B, S, 256), 1).to(half).cuda()
+    w = _rand((384, 256), 2, 0.1).to(half).cuda()
+    res = _rand((S, 384), 4).to(half).cuda()
     wp = ops.kres_pack_bcast384(w)
     got = ops.gemm_kres_bcast384(x, wp, res)
-    want = (x.float() @ w.float().t() + res.float()[None]).bfloat16()
+    want = (x.float() @ w.float().t() + res.float()[None]).to(half)
     assert (got.float() - want.float()).abs().max() <= 0.07          # one bf16 ulp at |y| < 16
     old = ops.gemm_k256(x, ops.k256_pack(w), 384, None, resid=res)
     assert (got.float() - old.float()).abs().max() <= 0.07 and (got == old).float().mean() > 0.99
@@ -989,7 +1005,7 @@ def test_gemm_kres_bcast384_vs_k256_kernel(B, S):
 
 
 @pytest.mark.parametrize("offscale,lo,hi", [(0.0, 0.0, 0.0), (2.0, 0.0, 0.002), (40.0, 0.2, 1.0)])
-def test_msda_far_sample_probe(offscale, lo, hi):
+def test_msda_far_sample_probe(offscale, lo, hi, half):
     """dtlr_msda_encoder_far_samples: no sampling point at the reference points themselves leaves the staged windows, small offsets stay
     inside the halo, offsets of tens of pixels mostly do not; bf16 and fp32 projection rows give the same count up to rounding."""
     from dtlr_amd import ops
@@ -1001,37 +1017,37 @@ def test_msda_far_sample_probe(offscale, lo, hi):
     ow = _rand((N, S, M * L * P * 3), 15)
     ow[..., : M * L * P * 2] *= offscale
     ref = O.encoder_reference_points(s, torch.ones((N, 4, 2))).contiguous()
-    f32 = ops.msda_encoder_far_fraction(torch.bfloat16, level_hw, ow.cuda(), ref.cuda())
-    b16 = ops.msda_encoder_far_fraction(torch.bfloat16, level_hw, ow.bfloat16().cuda(), ref.cuda())
+    f32 = ops.msda_encoder_far_fraction(half, level_hw, ow.cuda(), ref.cuda())
+    b16 = ops.msda_encoder_far_fraction(half, level_hw, ow.to(half).cuda(), ref.cuda())
     assert lo <= f32 <= hi, f32
     assert abs(f32 - b16) <= 0.01 + 0.05 * f32
 
 
-def test_tall128_tile_kernel_linear_and_conv():
+def test_tall128_tile_kernel_linear_and_conv(half):
     """The 256 x 128 tile variant (plain GEMM, N a multiple of 128, K >= 512, M >= 32768) against fp64 CPU references: bias only and bias +
     residual + ReLU on a ragged M, two channel tiles (grid.y); the 3x3 convolution of the same size stays on the 128 x 128 kernel."""
     import torch.nn.functional as F
     from dtlr_amd import ops
     M, N, K = 32768 + 37, 256, 1024
-    x = _rand((M, K), 1).bfloat16()
-    w = (_rand((N, K), 2) / 32.0).bfloat16()
+    x = _rand((M, K), 1).to(half)
+    w = (_rand((N, K), 2) / 32.0).to(half)
     b = _rand((N,), 3)
-    r = _rand((M, N), 4).bfloat16()
+    r = _rand((M, N), 4).to(half)
     ref = x.double() @ w.double().t() + b.double()
     got = ops.linear(x.cuda(), w.cuda(), b.cuda()).float().cpu()
-    assert (got - ref.float()).abs().max() < 2 ** -8 * max(1.0, ref.abs().max().item()) + 1e-4
+    assert (got - ref.float()).abs().max() < ulp(half, 8) * max(1.0, ref.abs().max().item()) + 1e-4
     want = (ref + r.double()).clamp(min=0).float()
     got = ops.linear(x.cuda(), w.cuda(), b.cuda(), relu=2, residual=r.cuda()).float().cpu()
-    assert (got - want).abs().max() < 2 ** -8 * max(1.0, want.abs().max().item()) + 1e-4
-    xi = _rand((2, 64, 200, 128), 5).bfloat16()
-    wc = (_rand((256, 128, 3, 3), 6) / 34.0).bfloat16()
+    assert (got - want).abs().max() < ulp(half, 8) * max(1.0, want.abs().max().item()) + 1e-4
+    xi = _rand((2, 64, 200, 128), 5).to(half)
+    wc = (_rand((256, 128, 3, 3), 6) / 34.0).to(half)
     bc = _rand((256,), 7)
     want = F.conv2d(xi.float().permute(0, 3, 1, 2).double(), wc.double(), bc.double(), stride=1, padding=1).permute(0, 2, 3, 1).clamp(min=0).float()
     got = ops.conv2d_nhwc(xi.cuda(), wc.permute(0, 2, 3, 1).contiguous().cuda(), bc.cuda(), 1, 1, True, None).float().cpu()
-    assert (got - want).abs().max() < 2 ** -8 * max(1.0, want.abs().max().item()) + 1e-4
+    assert (got - want).abs().max() < ulp(half, 8) * max(1.0, want.abs().max().item()) + 1e-4
 
 
-def test_gemm_kres_and_k256_random_shapes():
+def test_gemm_kres_and_k256_random_shapes(half):
     """Seeded sweep over the shape space the engine can hand the streaming kernels: ragged row counts, every K / N class, residual and
     ReLU on and off, padding masks -- all bit-equal to the tiled kernel."""
     from dtlr_amd import ops
@@ -1042,18 +1058,18 @@ def test_gemm_kres_and_k256_random_shapes():
         M = int(rng.integers(16384, 41000))
         res = bool(rng.integers(0, 2)) and N >= 256
         relu = bool(rng.integers(0, 2))
-        x = _rand((M, K), 100 + case).bfloat16().cuda()
-        w = (_rand((N, K), 200 + case) / (K ** 0.5)).bfloat16().cuda()
+        x = _rand((M, K), 100 + case).to(half).cuda()
+        w = (_rand((N, K), 200 + case) / (K ** 0.5)).to(half).cuda()
         b = _rand((N,), 300 + case).cuda() if rng.integers(0, 4) else None
-        r = _rand((M, N), 400 + case).bfloat16().cuda() if res else None
+        r = _rand((M, N), 400 + case).to(half).cuda() if res else None
         want = ops.linear(x, w, b, relu=(2 if relu else 0), residual=r)
         got = ops.gemm_kres(x, ops.kres_pack(w), N, b, r, relu=relu)
         assert torch.equal(got, want), (case, M, N, K, res, relu)
     for case in range(6):
         N = int(rng.choice([256, 384]))
         M = int(rng.integers(1, 30000))
-        x = _rand((M, 256), 500 + case).bfloat16().cuda()
-        w = _rand((N, 256), 600 + case, 0.1).bfloat16().cuda()
+        x = _rand((M, 256), 500 + case).to(half).cuda()
+        w = _rand((N, 256), 600 + case, 0.1).to(half).cuda()
         b = _rand((N,), 700 + case).cuda()
         mask = (torch.rand((M,)) < 0.3).cuda() if case % 2 else None
         want = ops.linear(x, w, b, row_mask=mask)
@@ -1063,20 +1079,20 @@ def test_gemm_kres_and_k256_random_shapes():
 
 @pytest.mark.parametrize("B,H,W,Cin,Cout", [(4, 37, 131, 64, 64), (2, 64, 200, 128, 128), (32, 8, 128, 256, 256), (3, 40, 150, 64, 128),
                                             (2, 50, 170, 256, 64), (1, 128, 130, 128, 256)])
-def test_conv3x3_patch_kernel_vs_reference(B, H, W, Cin, Cout):
+def test_conv3x3_patch_kernel_vs_reference(B, H, W, Cin, Cout, half):
     """The LDS-resident-patch 3x3 convolution (dtlr_conv3x3_patch_bf16, reached through conv2d_nhwc) against an fp64 reference and the
     implicit-GEMM kernel's entry on a smaller crop: image borders (zero padding), tiles cut by the right / bottom edge, bias and ReLU."""
     import torch.nn.functional as F
     from dtlr_amd import _lib, ops
     assert _lib.lib().dtlr_conv3x3_patch_supported(Cin, Cout) == 1 and B * H * W >= 16384
-    x = _rand((B, H, W, Cin), 1).bfloat16()
-    w = (_rand((Cout, Cin, 3, 3), 2) / (3.0 * Cin ** 0.5)).bfloat16()
+    x = _rand((B, H, W, Cin), 1).to(half)
+    w = (_rand((Cout, Cin, 3, 3), 2) / (3.0 * Cin ** 0.5)).to(half)
     b = _rand((Cout,), 3)
     ref = F.conv2d(x.float().permute(0, 3, 1, 2).double(), w.double(), b.double(), stride=1, padding=1).permute(0, 2, 3, 1)
     w_ohwi = w.permute(0, 2, 3, 1).contiguous().cuda()
     for relu in (True, False):
         want = (ref.clamp(min=0) if relu else ref).float()
         got = ops.conv2d_nhwc(x.cuda(), w_ohwi, b.cuda(), 1, 1, relu, None).float().cpu()
-        assert (got - want).abs().max() < 2 ** -8 * max(1.0, want.abs().max().item()) + 1e-4, relu
+        assert (got - want).abs().max() < ulp(half, 8) * max(1.0, want.abs().max().item()) + 1e-4, relu
     got = ops.conv2d_nhwc(x.cuda(), w_ohwi, None, 1, 1, False, None).float().cpu()
-    assert (got - (ref - b.double()).float()).abs().max() < 2 ** -8 * max(1.0, ref.abs().max().item()) + 1e-4
+    assert (got - (ref - b.double()).float()).abs().max() < ulp(half, 8) * max(1.0, ref.abs().max().item()) + 1e-4

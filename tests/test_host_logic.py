@@ -429,3 +429,17 @@ def test_weight_packers_tensor_ops_match_the_library_host_packers():
         assert np.array_equal(o1, u16(p1)) and np.array_equal(o2, u16(p2)), d_ff
     assert L.dtlr_gemm_kres_pack_weights(u16(w).ctypes.data, out.ctypes.data, 100, 256) != 0          # bad shape -> error code, no write
     assert L.dtlr_conv3x3_patch_supported(64, 64) == 1 and L.dtlr_conv3x3_patch_supported(512, 512) == 0
+
+
+def test_cpu_placement_helpers():
+    """dist.parse_cpulist / split_cpus: the per-rank CPU sets of the multi-GPU launch (one Python process per GPU)."""
+    from dtlr_amd import dist as D
+    assert D.parse_cpulist("0-3,8,10-11\n") == [0, 1, 2, 3, 8, 10, 11]
+    assert D.parse_cpulist("") == []
+    cpus = list(range(96))
+    parts = [D.split_cpus(cpus, r, 4) for r in range(4)]
+    assert sum(parts, []) == cpus and all(len(p) == 24 for p in parts)
+    assert D.split_cpus([5, 7], 3, 8) == [5, 7]                  # fewer CPUs than ranks: share them
+    assert D.split_cpus(cpus, 0, 1) == cpus
+    info = D.pin_to_local_cpus(0, 1)                              # no GPU here: falls back to the current affinity, never raises
+    assert "error" in info or info["cpus"] is not None

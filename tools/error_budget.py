@@ -37,6 +37,7 @@ def main():
     ap.add_argument("--oracle-lines", type=int, default=2)
     ap.add_argument("--strokes", action="store_true", help="stroke lines instead of the bench's noise lines")
     ap.add_argument("--out", default=None)
+    ap.add_argument("--weights", type=int, default=None, help="generator version (default: weights.GENERATOR_VERSION; 3 = the undamped stress set)")
     ap.add_argument("--half", default="bf16", choices=["bf16", "f16"], help="the 16-bit engine under test")
     args = ap.parse_args()
     from dtlr_amd import synth, weights
@@ -48,7 +49,7 @@ def main():
     dev = torch.device("cuda:0")
     chinese = args.config == "chinese"
     cfg = DTLRConfig.chinese() if chinese else DTLRConfig.latin()
-    sd = weights.synthetic_state_dict(cfg, seed=0)
+    sd = weights.synthetic_state_dict(cfg, seed=0, version=args.weights or weights.GENERATOR_VERSION)
     e32 = DTLREngine(cfg, sd, dev, torch.float32)
     e16 = DTLREngine(cfg, sd, dev, torch.bfloat16 if args.half == 'bf16' else torch.float16)
     n = args.lines
@@ -102,7 +103,7 @@ def main():
         return cap
 
     rep = {"half": args.half, "config": args.config, "lines": n, "input": "stroke" if args.strokes else "noise (bench batch)",
-           "generator_version": weights.GENERATOR_VERSION}
+           "generator_version": args.weights or weights.GENERATOR_VERSION}
     with torch.no_grad():
         ref = run(e32, e32, "all")
         forced = ref["topk_idx"]
