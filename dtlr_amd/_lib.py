@@ -89,6 +89,8 @@ _SIGNATURES = {
     "dtlr_ctc_loss_interleaved": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_float, c_float, c_void_p]),
     "dtlr_topk_flat": (c_int, [c_void_p, c_void_p, c_void_p, c_int, ctypes.c_long, c_int, c_int, c_void_p]),
     "dtlr_nms": (c_int, [c_void_p, c_void_p, c_float, c_void_p, c_void_p, c_int, c_int, c_void_p]),
+    "dtlr_blank_emissions": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_float, c_float, c_void_p]),
+    "dtlr_blank_emissions_workspace_bytes": (ctypes.c_long, [c_int, c_int]),
     "dtlr_decode_blank": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_float, c_void_p]),
 }
 

@@ -270,6 +270,41 @@ __global__ __launch_bounds__(1024) void decode_blank_kernel(const float* __restr
     if (threadIdx.x == 0) lengths[b] = running;
 }
 
+// ---- CTC-style emissions of the n-gram re-scoring path (ngram/prediction_helpers.py:5-46, get_new_pred_logits; with scale = 1 the
+// blank construction of SetCriterion.loss_CTC, models/dino/dino.py:466-502) -------------------------------------------------------
+// out[b, r, :] = [blank | classes] of the r-th query of line b IN READING ORDER (sorted by box cx): p = scale * sigmoid(logit),
+// s = sum_c p; s < 1 - eps: blank = 1 - s, classes = p; else blank = eps, classes = (1 - eps) p / s.
+// Step 1 (query_sum_kernel above): s / scale for every query, chip-wide.  Step 2, one workgroup per line: the reading order
+// (bitonic sort of (cx, index) keys in LDS, the decoders' own sort) -> order[b, r].  Step 3, chip-wide: one wave per output row.
+__global__ __launch_bounds__(256) void query_sum_kernel(const float* __restrict__ logits, float* __restrict__ sums, long nrows, int C);
+__global__ __launch_bounds__(1024) void reading_order_kernel(const float* __restrict__ boxes, int* __restrict__ order, int nq, int npow2)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned long long keys[];
+    const int b = blockIdx.x;
+    for (int i = threadIdx.x; i < npow2; i += blockDim.x)
+        keys[i] = i < nq ? (((unsigned long long)f32_sortable(boxes[((long)b * nq + i) * 4])) << 32) | (unsigned)i : ~0ull;
+    bitonic_sort_u64(keys, npow2);                                             // ascending cx, ties: lower index first
+    for (int p = threadIdx.x; p < nq; p += blockDim.x) order[(long)b * nq + p] = (int)(keys[p] & 0xffffffffull);
+}
+
+__global__ __launch_bounds__(256) void blank_emissions_kernel(const float* __restrict__ logits, const float* __restrict__ sums,
+                                                               const int* __restrict__ order, float* __restrict__ out,
+                                                               long nrows, int nq, int C, float scale, float eps)
+{
+    const int lane = threadIdx.x & 63;
+    const long row = (long)blockIdx.x * 4 + (threadIdx.x >> 6);               // output row = (line, rank)
+    if (row >= nrows) return;
+    const long b = row / nq;
+    const long q = b * nq + order[row];
+    const float s = sums[q] * scale;
+    const bool low = s < 1.f - eps;
+    const float mul = low ? scale : (1.f - eps) * scale / s;
+    const float* lr = logits + q * C;
+    float* o = out + row * (long)(C + 1);
+    if (lane == 0) o[0] = low ? 1.f - s : eps;
+    for (int c = lane; c < C; c += 64) o[1 + c] = mul / (1.f + expf(-lr[c]));
+}
+
 // ---- evaluation-time CTC loss value (models/dino/dino.py:457-551, SetCriterion.loss_CTC) ------------------------------------
 // Step 1, chip-wide: sum over classes of sigmoid(logit) for every query (16 lanes per query, DPP reductions).
 __global__ __launch_bounds__(256) void query_sum_kernel(const float* __restrict__ logits, float* __restrict__ sums, long nrows, int C)
@@ -508,6 +543,29 @@ extern "C" int dtlr_ctc_loss_interleaved(const float* logits, const float* boxes
                        target_lengths, nll, nq, C, Lmax, eps, filler, np);
     return check_launch();
 }
+
+extern "C" int dtlr_blank_emissions(const float* logits, const float* boxes, float* out, float* workspace,
+                                    int B, int nq, int C, float scale, float eps, void* stream)
+{
+    clear_stale_error();
+    if (!logits || !boxes || !out || !workspace) return DTLR_EINVAL;
+    if (B <= 0 || nq <= 0 || C <= 0) return DTLR_EINVAL;
+    const int np = next_pow2(nq);
+    const size_t lds = (size_t)np * 8;
+    if (lds > 150 * 1024) return DTLR_ESHAPE;
+    if (lds > 60 * 1024) (void)hipFuncSetAttribute((const void*)reading_order_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    (void)hipGetLastError();
+    const long nrows = (long)B * nq;
+    float* sums = workspace;                                  // [B * nq] fp32, then [B * nq] int32 (dtlr_blank_emissions_workspace_bytes)
+    int* order = reinterpret_cast<int*>(workspace + nrows);
+    hipLaunchKernelGGL(query_sum_kernel, dim3((unsigned)((nrows + 15) / 16)), dim3(256), 0, (hipStream_t)stream, logits, sums, nrows, C);
+    hipLaunchKernelGGL(reading_order_kernel, dim3(B), dim3(1024), lds, (hipStream_t)stream, boxes, order, nq, np);
+    hipLaunchKernelGGL(blank_emissions_kernel, dim3((unsigned)((nrows + 3) / 4)), dim3(256), 0, (hipStream_t)stream, logits, sums, order, out,
+                       nrows, nq, C, scale, eps);
+    return check_launch();
+}
+
+extern "C" long dtlr_blank_emissions_workspace_bytes(int B, int nq) { return (long)B * nq * 8; }
 
 extern "C" int dtlr_nms(const float* boxes, const float* scores, float iou_threshold, long* keep, int* counts, int B, int n, void* stream)
 {

@@ -16,7 +16,12 @@ What differs from the reference loop, and why the numbers do not:
   * lines are sharded over the ranks of a torch.distributed job (contiguous shards of the size-sorted list), decoded records
     are all-gathered, rank 0 computes the metrics in dataset order -- the running CER series (the figure the reference reports
     is the MEAN of the running sum(dist)/sum(len) series, evaluation.py:521-529,547) is order dependent;
-  * a line whose forward fails is skipped by the reference (evaluation.py:500-505); here errors propagate.
+  * a line whose forward raises is skipped by the reference (evaluation.py:498-504: message, `continue`, the line enters no
+    metric).  Same here: a failing batch is retried line by line, a line that still fails (or whose image file cannot be read)
+    is reported on stderr and left out of every list -- one bad image does not end a 2915-line run, and does not take its
+    batch neighbours with it;
+  * every rank reads only the image HEADERS of the whole set (sizes, for the batch plan) and decodes only the lines of its own
+    shard -- not N copies of the dataset in host memory.
 """
 from __future__ import annotations
 
@@ -100,34 +105,68 @@ def plan_batches(sizes: Sequence[Tuple[int, int]], batch: int, exact: bool, size
     return batches
 
 
+def image_size(path: str) -> Tuple[int, int]:
+    """(h, w) from the file header (no pixel decode)."""
+    from PIL import Image
+    with Image.open(path) as im:
+        w, h = im.size
+    return int(h), int(w)
+
+
 @torch.no_grad()
-def predict_labels(model, images: Sequence[np.ndarray], batch: int = 32, exact: bool = True, TH: Optional[float] = None,
+def predict_labels(model, images, batch: int = 32, exact: bool = True, TH: Optional[float] = None,
                    NM: Optional[float] = None, postprocessor=None, device="cuda", size: int = EVAL_SIZE,
-                   max_size: int = EVAL_MAX_SIZE, rank: int = 0, world: int = 1) -> List[List[int]]:
+                   max_size: int = EVAL_MAX_SIZE, rank: int = 0, world: int = 1, sizes: Optional[Sequence[Tuple[int, int]]] = None,
+                   skip_errors: bool = True) -> List[Optional[List[int]]]:
     """convert_output_to_pred (evaluation.py:94-158) for a list of RGB uint8 images -> one label list per image, dataset
-    order.  TH / NM given: the NMS decoder; otherwise the blank/argmax decoder with eps = 0.03 / C."""
-    n = len(images)
-    batches = plan_batches([im.shape[:2] for im in images], batch, exact, size, max_size)
+    order.  TH / NM given: the NMS decoder; otherwise the blank/argmax decoder with eps = 0.03 / C.
+    `images`: a sequence of [h, w, 3] uint8 arrays, or (with `sizes` = the (h, w) of every line) a callable i -> array that is
+    invoked only for the lines of this rank's shard.  skip_errors (the reference's behaviour, evaluation.py:498-504): a line whose
+    load / forward / decode raises is reported and returned as None; KeyboardInterrupt always propagates."""
+    lazy = callable(images)
+    if lazy and sizes is None:
+        raise ValueError("predict_labels: a loader callable needs `sizes`")
+    sizes = list(sizes) if sizes is not None else [im.shape[:2] for im in images]
+    n = len(sizes)
+    load = images if lazy else (lambda i: images[i])
+    batches = plan_batches(sizes, batch, exact, size, max_size)
     lo, hi = ddist.shard_bounds(len(batches), rank, world)
     tf = EvalTransform(size, max_size)
     nq = model.num_queries
-    rec = torch.full((n, nq + 1), -1, dtype=torch.int32)
-    for b in batches[lo:hi]:
-        samples = tf([images[i] for i in b], device=device)
+    rec = torch.full((n, nq + 2), -1, dtype=torch.int32)          # labels[nq] | length | status (-1 not mine, 0 decoded, 1 skipped)
+
+    def run(idx):
+        samples = tf([load(i) for i in idx], device=device)
         out = model(samples)
-        if TH is not None and NM is not None:
-            preds = E.decode_nms(out, postprocessor, TH, NM)
-        else:
-            preds = E.decode_blank(out)
-        for i, p in zip(b, preds):
+        preds = E.decode_nms(out, postprocessor, TH, NM) if (TH is not None and NM is not None) else E.decode_blank(out)
+        for i, p in zip(idx, preds):
             rec[i, : len(p)] = torch.tensor(p, dtype=torch.int32)
-            rec[i, nq] = len(p)
+            rec[i, nq], rec[i, nq + 1] = len(p), 0
+
+    for b in batches[lo:hi]:
+        try:
+            run(b)
+        except KeyboardInterrupt:
+            raise
+        except Exception as e:
+            if not skip_errors:
+                raise
+            for i in b:                                          # retry alone: only the offending line is lost
+                try:
+                    run([i])
+                except KeyboardInterrupt:
+                    raise
+                except Exception as e1:
+                    print(f"An error occurred affecting the metrics computation (line {i}: {type(e1).__name__}: {e1})", file=sys.stderr)
+                    rec[i, :nq] = -1
+                    rec[i, nq], rec[i, nq + 1] = 0, 1
+            del e
     if world > 1:                               # every line is owned by exactly one rank: element-wise max merges the shards
         import torch.distributed as dist
         t = rec.to(device) if dist.get_backend() == "nccl" else rec
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         rec = t.cpu()
-    return [rec[i, : int(rec[i, nq])].tolist() for i in range(n)]
+    return [None if int(rec[i, nq + 1]) == 1 else rec[i, : int(rec[i, nq])].tolist() for i in range(n)]
 
 
 def evaluate_predictions(pred_labels: Sequence[Sequence[int]], gt_texts: Sequence[str], charset: Sequence, dataset: str = "IAM",
@@ -139,6 +178,8 @@ def evaluate_predictions(pred_labels: Sequence[Sequence[int]], gt_texts: Sequenc
     preds_str, gts_str, dists, lens = [], [], [], []
     conv = (lambda c: chr(c)) if unicode_charset else (lambda c: c)
     for pred, text in zip(pred_labels, gt_texts):
+        if pred is None:                                                           # skipped line (evaluation.py:501-504: `continue`)
+            continue
         gt = [cs.index(ord(c) if unicode_charset else c) for c in text]            # datasets/IAM.py:66-72
         if len(pred) > 0:                                                          # evaluation.py:340-352
             cer_it, dict_char, _ = E.character_error_rate_with_impact(list(pred), gt, dict_char)
@@ -215,7 +256,7 @@ def build_parser() -> argparse.ArgumentParser:
     ap.add_argument("--out", default="stats_dect")
     ap.add_argument("--batch", type=int, default=32)
     ap.add_argument("--batching", default="exact", choices=["exact", "padded"])
-    ap.add_argument("--dtype", default="bf16", choices=["bf16", "f32"])
+    ap.add_argument("--dtype", default="bf16", choices=["bf16", "f16", "f32"])
     ap.add_argument("--limit", type=int, default=0, help="evaluate only the first N lines")
     ap.add_argument("--size", type=int, default=EVAL_SIZE, help="eval resize: short side (config/coco_transformer.py:1)")
     ap.add_argument("--max_size", type=int, default=EVAL_MAX_SIZE, help="eval resize: long-side cap (config/coco_transformer.py:2)")
@@ -240,7 +281,7 @@ def main(argv: Optional[Sequence[str]] = None) -> Dict:
     rows = load_labels(args.labels, args.mode)
     if args.limit:
         rows = rows[: args.limit]
-    model = DINO(cfg, compute_dtype=torch.bfloat16 if args.dtype == "bf16" else torch.float32)
+    model = DINO(cfg, compute_dtype={"bf16": torch.bfloat16, "f16": torch.float16, "f32": torch.float32}[args.dtype])
     model = E.load_model(model, args.weights, device=dev, new_class_embedding=args.new_class_embedding, charset_size=len(charset),
                          new_label_enc=args.new_label_enc, fix_enc_out_class=args.fix_enc_out_class)
     # TH / NM grids exactly as evaluation.py:38-49
@@ -251,14 +292,22 @@ def main(argv: Optional[Sequence[str]] = None) -> Dict:
     else:
         list_TH = list_NM = [0.1, 0.2, 0.3, 0.4, 0.5, 0.6, 0.7, 0.8, 0.9]
         nms_inference = True
-    images = [read_rgb(find_image(args.images, name)) for name, _ in rows]
+    paths = [find_image(args.images, name) for name, _ in rows]
+    def header_size(p):                                        # an unreadable file is a per-sample error: it fails (and is skipped) when its shard decodes it
+        try:
+            return image_size(p)
+        except Exception:
+            return (size_fallback, size_fallback)
+    size_fallback = 32
+    sizes = [header_size(p) for p in paths]                    # headers only; pixels are decoded per shard, inside predict_labels
+    images = lambda i: read_rgb(paths[i])                      # noqa: E731
     texts = [t for _, t in rows]
     post = PostProcess(num_select=cfg.num_select, nms_iou_threshold=cfg.nms_iou_threshold)
     last = {}
     for TH in list_TH:
         for NM in list_NM:
             preds = predict_labels(model, images, args.batch, args.batching == "exact", TH, NM, post, dev, args.size, args.max_size,
-                                   rank=rank, world=world)
+                                   rank=rank, world=world, sizes=sizes)
             if rank == 0:
                 res = evaluate_predictions(preds, texts, charset, args.dataset, args.metrics, args.unicode)
                 d = write_outputs(res, args.out, args.dataset, TH, NM)

@@ -56,16 +56,10 @@ def load_model(model, weights, device="cuda", new_class_embedding: bool = False,
 
 
 @torch.no_grad()
-def blank_probabilities(outputs: Dict[str, torch.Tensor], eps: float) -> torch.Tensor:
-    """[B, nq, C+1] probabilities with the blank channel at index 0, queries sorted by box cx."""
-    logits, boxes = outputs["pred_logits"].float(), outputs["pred_boxes"].float()
-    _, idx = torch.sort(boxes[:, :, 0])
-    p = torch.gather(logits, 1, idx.unsqueeze(-1).expand(-1, -1, logits.shape[-1])).sigmoid()
-    s = p.sum(-1, keepdim=True)
-    low = s < 1 - eps
-    blank = torch.where(low, 1 - s, torch.full_like(s, eps))
-    cls = torch.where(low, p, (1 - eps) * p / s)
-    return torch.cat([blank, cls], -1)
+def blank_probabilities(outputs: Dict[str, torch.Tensor], eps: float, scale: float = 1.0) -> torch.Tensor:
+    """[B, nq, C+1] probabilities with the blank channel at index 0, queries sorted by box cx (HIP kernels: dtlr_blank_emissions)."""
+    from . import ops
+    return ops.blank_emissions(outputs["pred_logits"], outputs["pred_boxes"], eps, scale)
 
 
 @torch.no_grad()

@@ -842,6 +842,23 @@ def decode_blank(logits, boxes, eps: float):
     return labels, lengths
 
 
+def blank_emissions(logits, boxes, eps: float, scale: float = 1.0):
+    """[B, nq, C+1] CTC-style emissions, blank channel first, queries in reading order (dtlr_blank_emissions: per-query sigmoid sums
+    chip-wide, the decoders' cx sort per line, one wave per output row) -- get_new_pred_logits (ngram/prediction_helpers.py:5-46) /
+    the blank construction of loss_CTC (dino.py:466-502)."""
+    require_cuda(logits, "pred_logits")
+    logits = logits.float().contiguous()
+    boxes = boxes.float().contiguous()
+    B, nq, C = logits.shape
+    L_ = _lib.lib()
+    ws = torch.empty(L_.dtlr_blank_emissions_workspace_bytes(B, nq) // 4, dtype=torch.float32, device=logits.device)
+    out = torch.empty((B, nq, C + 1), dtype=torch.float32, device=logits.device)
+    code = L_.dtlr_blank_emissions(logits.data_ptr(), boxes.data_ptr(), out.data_ptr(), ws.data_ptr(), B, nq, C, float(scale), float(eps),
+                                   _lib.current_stream())
+    _lib.check(code, "dtlr_blank_emissions")
+    return out
+
+
 def preprocess_lines(src_u8, offsets, dims, Hc: int, Wc: int, max_downscale: float, mean, std):
     """Resize + ToTensor + Normalize + pad of a batch of uint8 RGB images in ONE launch (dtlr_preprocess_lines).
     src_u8: flat uint8 CUDA tensor (images back to back, HWC); offsets [B] int64 CUDA; dims [B,4] int32 CUDA = (h, w, oh, ow).

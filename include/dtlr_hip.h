@@ -441,6 +441,16 @@ int dtlr_ctc_loss_interleaved(const float *logits, const float *boxes, const int
                               float *nll, float *workspace, int B, int nq, int C, int Lmax, int max_target_length,
                               float eps, float filler, void *stream);
 
+/* ---------------------------------------------------------------------------------------------
+ * CTC-style emissions for the n-gram re-scoring path.
+ * Replaces: get_new_pred_logits (ngram/prediction_helpers.py:5-46): queries sorted by box cx, p = scale * sigmoid(logits),
+ *           blank channel first with the rule of SetCriterion.loss_CTC (models/dino/dino.py:466-502; eps = 0.003 there).
+ * logits [B,nq,C] fp32, boxes [B,nq,4] fp32 -> out [B,nq,C+1] fp32 (row r = the r-th query in reading order).
+ * workspace: dtlr_blank_emissions_workspace_bytes(B, nq) bytes of device memory.  Asynchronous on `stream`. */
+int dtlr_blank_emissions(const float *logits, const float *boxes, float *out, float *workspace,
+                         int B, int nq, int C, float scale, float eps, void *stream);
+long dtlr_blank_emissions_workspace_bytes(int B, int nq);
+
 /* Greedy non-maximum suppression, batched: image b keeps, in descending score order (equal scores: lower index first), every
  * box whose IoU with an already kept box is <= iou_threshold.
  * Replaces: `torchvision.ops.nms(b, s, iou_threshold)` as PostProcess calls it per image (models/dino/dino.py:1029-1033), i.e.

@@ -409,6 +409,13 @@ def test_evaluation_cli_on_synthetic_assets(tmp_path):
     d = tmp_path / "stats" / "IAM"
     assert sorted(os.listdir(d)) == ["cer_TH_None_NMS_None.txt", "cer_list.npy", "dict_char.json", "list_gt.txt", "list_preds.txt"]
     assert (d / "list_gt.txt").read_text().splitlines() == texts
+    # per-sample error isolation (evaluation.py:498-504): an unreadable image is reported and skipped, the other lines are unaffected
+    (img_dir / "l05.png").write_bytes(b"not a png at all")
+    (tmp_path / "labels6.json").write_text(json.dumps([[f"l{k:02d}", t] for k, t in enumerate(texts + ["lost line"])]))
+    res6 = H.main(["--config", "tiny", "--weights", str(tmp_path / "checkpoint.pth"), "--images", str(img_dir),
+                   "--labels", str(tmp_path / "labels6.json"), "--dataset", "IAM", "--out", str(tmp_path / "stats6"),
+                   "--dtype", "f32", "--batch", "3", "--size", "32", "--max_size", "256"])
+    assert res6["list_preds_str"] == got_str and res6["list_gt_str"] == res["list_gt_str"] and res6["CER_list"] == res["CER_list"]
     # the NMS decoder path of the scripts (--NMS 0.5 --TH 0.3) runs too and writes its own CER file
     H.main(["--config", "tiny", "--weights", str(tmp_path / "checkpoint.pth"), "--images", str(img_dir), "--labels", str(tmp_path / "labels.json"),
             "--out", str(tmp_path / "stats"), "--dtype", "bf16", "--NMS", "0.5", "--TH", "0.3", "--size", "32", "--max_size", "256", "--batching", "padded"])
@@ -439,6 +446,55 @@ def test_data_parallel_two_ranks_on_one_gpu_equals_single_process():
     assert line["n_gpus"] == 2 and line["config"]["global_batch"] == 6
     d = line["distributed"]
     assert (d["backend"], d["world_size"], d["dp_verified"]) == ("gloo", 2, True), d
+
+
+def test_ngram_emissions_and_rescoring_on_device(golden_dir):
+    """SURVEY 8 f.4 on the GPU: the CTC-style emissions of the n-gram path (get_new_pred_logits, ngram/prediction_helpers.py:5-46) are
+    produced by dtlr_blank_emissions (per-query sums chip-wide, the decoders' reading-order sort, one wave per row): (1) the vectors
+    the reference's own function bodies produced (G8: sum, argmax row, the assembled strings through a fake decoder); (2) equal to
+    the oracle for multiplier 1 and != 1 on both blank branches; (3) on real ENGINE outputs: emissions == oracle on the same
+    logits, and get_ngram_prediction (with the self-contained lexicon beam decoder standing in for torchaudio's) returns the same
+    string as the oracle's assembly driven by the same decoder."""
+    import json
+    from dtlr_amd import ngram as NG
+    from oracle import dtlr_oracle as O
+    from tests.util import fake_ctc_decoder, ngram_case
+    g = json.load(open(os.path.join(golden_dir, "g8_ngram.json")))
+    flags = ((True, False, True), (False, True, True), (True, True, False))
+    for rec in g["cases"]:
+        outputs, charset, ngc, ign = ngram_case(rec["seed"])
+        dev = {k: v.cuda() for k, v in outputs.items()}
+        new = NG.get_new_pred_logits(dev).cpu()
+        assert abs(float(new.double().sum()) - rec["new_sum"]) < 1e-4 and new[0].argmax(-1).tolist() == rec["new_argmax"]
+        assert (new - O.ngram_new_pred_logits(outputs)).abs().max() < 1e-6
+        for k, (up, dg, ds) in enumerate(flags):
+            assert NG.get_ngram_prediction(dev, fake_ctc_decoder(ngc), ign, charset, ngc, True, up, dg, ds) == rec[f"word_per_word_2_{k}"]
+    # both blank branches, a multiplier, many lines
+    r = np.random.Generator(np.random.PCG64(77))
+    for C, bias, mult in ((23, -5.0, 1.0), (23, -1.0, 1.0), (166, -3.0, 1.7), (166, -7.0, 0.5)):
+        out = {"pred_logits": torch.from_numpy((r.standard_normal((5, 900, C)) + bias).astype(np.float32)),
+               "pred_boxes": torch.from_numpy(r.uniform(0.02, 0.98, (5, 900, 4)).astype(np.float32))}
+        got = NG.get_new_pred_logits({k: v.cuda() for k, v in out.items()}, mult).cpu()
+        want = O.ngram_new_pred_logits(out, mult)
+        assert got.shape == want.shape and (got - want).abs().max() < 1e-6, (C, bias, mult)
+    # engine outputs
+    cfg = DTLRConfig.tiny(num_classes=23)
+    sd = weights.synthetic_state_dict(cfg, 3)
+    imgs = synth.stroke_lines(2, 32, [256, 224], seed=9)
+    out = _model(cfg, sd)([i.cuda() for i in imgs])
+    host = _cpu(out)
+    assert (NG.get_new_pred_logits(out).cpu() - O.ngram_new_pred_logits(host)).abs().max() < 1e-6
+    charset = [chr(ord("a") + i) for i in range(21)] + [" ", "-"]
+    ngc = ["<ctc>"] + charset
+    ign = [ngc.index(" ")]
+    lex = {w: list(w) for w in ("ab", "abc", "cab", "bad", "dab", "a", "b")}
+    dec = NG.LexiconCTCDecoder(ngc, lex, beam_size=8)
+    for b in range(2):
+        one_dev = {k: v[b:b + 1] for k, v in out.items() if k in ("pred_logits", "pred_boxes")}
+        one_host = {k: v[b:b + 1] for k, v in host.items()}
+        got = NG.get_ngram_prediction(one_dev, dec, ign, charset, ngc, True, True, False, True)
+        want = O.ngram_word_per_word_pred_2(O.ngram_new_pred_logits(one_host), dec, ign, ngc, True, False, True)
+        assert got == want
 
 
 @pytest.mark.parametrize("half", ["bf16", "f16"])
