@@ -166,6 +166,7 @@ def main():
                     help="latin = BASELINE configs[1] (the metric); chinese = configs[4]; latin-mixed = Latin model on seeded mixed widths "
                          "{1280..2048} zero-padded to 128x2048 with masks (what a real dataset looks like); latin-eval = uint8 128x2048 lines "
                          "through the reference's eval transform (short side 800 capped at 1333: 83x1328 canvases, datasets/transforms.py:78-142)")
+    ap.add_argument("--backbone", default=None, help="override the config's backbone (e.g. swin_T_224_1k, swin_B_224_22k: models/dino/backbone.py:172-205)")
     ap.add_argument("--height", type=int, default=128)
     ap.add_argument("--width", type=int, default=0, help="0 = 2048 (latin) / 2560 canvas with mixed widths (chinese)")
     ap.add_argument("--dtype", default="bf16", choices=["bf16", "f16", "f32"],
@@ -204,6 +205,9 @@ def main():
     chinese = args.config == "chinese"
     mixed, evalshape = args.config == "latin-mixed", args.config == "latin-eval"
     cfg = DTLRConfig.chinese() if chinese else DTLRConfig.latin()
+    if args.backbone:
+        import dataclasses
+        cfg = dataclasses.replace(cfg, backbone=args.backbone)
     sd = weights.synthetic_state_dict(cfg, seed=0)
     eng = DTLREngine(cfg, sd, dev, dtype)
     log(f"engine packed ({args.dtype}, {args.config}), rank {rank}/{world}")
@@ -341,7 +345,7 @@ def main():
             except Exception:
                 pass
     # PMC traffic figures were measured on the Latin bf16 B = 32 step (profiles/*_traffic.json): attach them to that configuration only
-    traffic_ok = args.config == "latin" and B == 32 and args.dtype == "bf16" and canvas_w == 2048 and args.height == 128
+    traffic_ok = args.config == "latin" and not args.backbone and B == 32 and args.dtype == "bf16" and canvas_w == 2048 and args.height == 128
     roof = None
     if enc:
         ms = sum(e[0] for e in enc) / len(enc)
@@ -424,7 +428,7 @@ def main():
                                 if not chinese else
                                 f"Chinese DTLR (C=7356) forward+decode, {B} synthetic lines per GPU, widths seeded from {{{canvas_w - 1024}..{canvas_w}}}, zero-padded to {args.height}x{canvas_w} with masks")
                                + f", random-init name-seeded weights (generator v{weights.GENERATOR_VERSION})",
-                   "global_batch": n_total, "parallelism": f"dp{world}",
+                   "backbone": cfg.backbone, "global_batch": n_total, "parallelism": f"dp{world}",
                    "library_backed_ops": sorted(ops.LIBRARY_BACKED)},
         "distributed": {"backend": tdist.get_backend() if (tdist.is_available() and tdist.is_initialized()) else None,
                         "world_size": tdist.get_world_size() if (tdist.is_available() and tdist.is_initialized()) else 1,
@@ -481,7 +485,7 @@ def main():
             except Exception as e:
                 by_dtype[name] = {"error": repr(e)}
     line["by_dtype"] = by_dtype
-    if world == 1 and not args.no_cpu_baseline and args.config == "latin":
+    if world == 1 and not args.no_cpu_baseline and args.config == "latin" and not args.backbone:
         line["cpu_baseline"] = cpu_baseline()
         line["speedup_vs_cpu"] = round(line["value"] / line["cpu_baseline"]["value"], 1)
     print(json.dumps(line), flush=True)

@@ -85,9 +85,9 @@ class DTLREngine:
         cfg, f32 = self.cfg, torch.float32
         sp = cfg.swin_params()
         E, ws = sp["embed_dim"], sp["window_size"]
-        if self.dtype in ops.H16 and E % 64:
-            raise NotImplementedError(f"swin backbone with embed_dim {E}: the bf16 GEMM needs K a multiple of 64 (swin_B / swin_L); "
-                                      "run this variant with the fp32 engine")
+        # 16-bit engines: the MFMA GEMM consumes K in 128-byte slabs (64 elements).  swin_T's first stage has C = 96: its three K = 96
+        # projections (qkv, proj, fc1) get zero-padded weight columns here and a zero-padded activation copy at run time (_padk).
+        self._swin_kpad = (lambda k: -(-k // 64) * 64) if self.dtype in ops.H16 else (lambda k: k)
         b = "backbone.0."
         self._put("swin.pe.w", sd[b + "patch_embed.proj.weight"].float().reshape(E, 48).t(), f32)      # [48, E], k-major
         self._put("swin.pe.b", sd[b + "patch_embed.proj.bias"], f32)
@@ -99,16 +99,20 @@ class DTLREngine:
                 for nm in ("norm1", "norm2"):
                     self._put(q + nm + ".w", sd[p + nm + ".weight"], f32)
                     self._put(q + nm + ".b", sd[p + nm + ".bias"], f32)
-                self._put_linear(q + "qkv", sd[p + "attn.qkv.weight"], sd[p + "attn.qkv.bias"])
-                self._put_linear(q + "proj", sd[p + "attn.proj.weight"], sd[p + "attn.proj.bias"])
-                self._put_linear(q + "fc1", sd[p + "mlp.fc1.weight"], sd[p + "mlp.fc1.bias"])
-                self._put_linear(q + "fc2", sd[p + "mlp.fc2.weight"], sd[p + "mlp.fc2.bias"])
+                for nm, key in (("qkv", "attn.qkv"), ("proj", "attn.proj"), ("fc1", "mlp.fc1"), ("fc2", "mlp.fc2")):
+                    wt = sd[p + key + ".weight"]
+                    kp = self._swin_kpad(wt.shape[1])
+                    if kp != wt.shape[1]:
+                        wt = torch.nn.functional.pad(wt, (0, kp - wt.shape[1]))
+                    self._put_linear(q + nm, wt, sd[p + key + ".bias"])
                 self.w[q + "rpb"] = ops.swin_dense_bias(sd[p + "attn.relative_position_bias_table"].to(self.device), ws)
             if i < 3:
                 p, q = f"{b}layers.{i}.downsample.", f"swin.{i}.merge."
                 self._put(q + "ln.w", sd[p + "norm.weight"], f32)
                 self._put(q + "ln.b", sd[p + "norm.bias"], f32)
-                self._put(q + "w", sd[p + "reduction.weight"])
+                wt = sd[p + "reduction.weight"]
+                kp = self._swin_kpad(wt.shape[1])
+                self._put(q + "w", wt if kp == wt.shape[1] else torch.nn.functional.pad(wt, (0, kp - wt.shape[1])))
             if i in cfg.return_interm_indices:
                 self._put(f"swin.norm{i}.w", sd[f"{b}norm{i}.weight"], f32)
                 self._put(f"swin.norm{i}.b", sd[f"{b}norm{i}.bias"], f32)
@@ -119,6 +123,14 @@ class DTLREngine:
         sp = cfg.swin_params()
         ws = sp["window_size"]
         x = ops.swin_patch_embed(x_nchw, w["swin.pe.w"], w["swin.pe.b"], w["swin.pe.ln.w"], w["swin.pe.ln.b"], self.dtype)
+
+        def padk(t, wname):                       # zero-pad the last dim to the packed weight's K (16-bit engines, C = 96: see _pack_swin)
+            kp = w[wname].shape[1]
+            if kp == t.shape[-1]:
+                return t
+            tp = t.new_zeros(t.shape[:-1] + (kp,))
+            tp[..., : t.shape[-1]] = t
+            return tp
         outs = []
         for i in range(4):
             nh = sp["num_heads"][i]
@@ -127,18 +139,18 @@ class DTLREngine:
                 # x = x + proj(window_attention(norm1(x)))  (swin_transformer.py:191-243): shift / partition / padding / reverse are
                 # index arithmetic inside the attention kernel; the residual add is the projection's epilogue
                 y = ops.layernorm(x, w[q + "norm1.w"], w[q + "norm1.b"], 1e-5)
-                qkv = ops.linear(y, w[q + "qkv.w"], w[q + "qkv.b"])
+                qkv = ops.linear(padk(y, q + "qkv.w"), w[q + "qkv.w"], w[q + "qkv.b"])
                 a = ops.swin_window_attn(qkv, w[q + "qkv.b"], w[q + "rpb"], nh, ws, 0 if j % 2 == 0 else ws // 2)
-                x = ops.linear(a, w[q + "proj.w"], w[q + "proj.b"], residual=x)
+                x = ops.linear(padk(a, q + "proj.w"), w[q + "proj.w"], w[q + "proj.b"], residual=x)
                 # x = x + fc2(gelu(fc1(norm2(x))))  (:244-247)
                 y = ops.layernorm(x, w[q + "norm2.w"], w[q + "norm2.b"], 1e-5)
-                hdn = ops.linear(y, w[q + "fc1.w"], w[q + "fc1.b"], relu=3)
-                x = ops.linear(hdn, w[q + "fc2.w"], w[q + "fc2.b"], residual=x)
+                hdn = ops.linear(padk(y, q + "fc1.w"), w[q + "fc1.w"], w[q + "fc1.b"], relu=3)
+                x = ops.linear(padk(hdn, q + "fc2.w"), w[q + "fc2.w"], w[q + "fc2.b"], residual=x)
             if i in cfg.return_interm_indices:
                 outs.append(ops.layernorm(x, w[f"swin.norm{i}.w"], w[f"swin.norm{i}.b"], 1e-5))
             if i < 3:
                 q = f"swin.{i}.merge."
-                x = ops.linear(ops.swin_patch_merge(x, w[q + "ln.w"], w[q + "ln.b"]), w[q + "w"], None)
+                x = ops.linear(padk(ops.swin_patch_merge(x, w[q + "ln.w"], w[q + "ln.b"]), q + "w"), w[q + "w"], None)
         return outs
 
     def _pack(self, sd):
