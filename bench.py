@@ -167,6 +167,8 @@ def main():
                          "{1280..2048} zero-padded to 128x2048 with masks (what a real dataset looks like); latin-eval = uint8 128x2048 lines "
                          "through the reference's eval transform (short side 800 capped at 1333: 83x1328 canvases, datasets/transforms.py:78-142)")
     ap.add_argument("--backbone", default=None, help="override the config's backbone (e.g. swin_T_224_1k, swin_B_224_22k: models/dino/backbone.py:172-205)")
+    ap.add_argument("--engine-opt", action="append", default=[], metavar="NAME=VALUE",
+                    help="set a DTLREngine attribute for an A/B run (e.g. sort_queries=0, use_kres=0); recorded in config.engine_opts")
     ap.add_argument("--height", type=int, default=128)
     ap.add_argument("--width", type=int, default=0, help="0 = 2048 (latin) / 2560 canvas with mixed widths (chinese)")
     ap.add_argument("--dtype", default="bf16", choices=["bf16", "f16", "f32"],
@@ -210,6 +212,11 @@ def main():
         cfg = dataclasses.replace(cfg, backbone=args.backbone)
     sd = weights.synthetic_state_dict(cfg, seed=0)
     eng = DTLREngine(cfg, sd, dev, dtype)
+    for kv in args.engine_opt:
+        k, _, v = kv.partition("=")
+        if not hasattr(eng, k):
+            raise SystemExit(f"--engine-opt: DTLREngine has no attribute {k!r}")
+        setattr(eng, k, type(getattr(eng, k))(int(v)) if isinstance(getattr(eng, k), (bool, int)) else float(v))
     log(f"engine packed ({args.dtype}, {args.config}), rank {rank}/{world}")
     B = args.batch
     n_total = B * world
@@ -428,7 +435,7 @@ def main():
                                 if not chinese else
                                 f"Chinese DTLR (C=7356) forward+decode, {B} synthetic lines per GPU, widths seeded from {{{canvas_w - 1024}..{canvas_w}}}, zero-padded to {args.height}x{canvas_w} with masks")
                                + f", random-init name-seeded weights (generator v{weights.GENERATOR_VERSION})",
-                   "backbone": cfg.backbone, "global_batch": n_total, "parallelism": f"dp{world}",
+                   "backbone": cfg.backbone, "engine_opts": args.engine_opt, "global_batch": n_total, "parallelism": f"dp{world}",
                    "library_backed_ops": sorted(ops.LIBRARY_BACKED)},
         "distributed": {"backend": tdist.get_backend() if (tdist.is_available() and tdist.is_initialized()) else None,
                         "world_size": tdist.get_world_size() if (tdist.is_available() and tdist.is_initialized()) else 1,

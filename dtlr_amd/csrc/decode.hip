@@ -567,6 +567,7 @@ extern "C" int dtlr_blank_emissions(const float* logits, const float* boxes, flo
 
 extern "C" long dtlr_blank_emissions_workspace_bytes(int B, int nq) { return (long)B * nq * 8; }
 
+
 extern "C" int dtlr_nms(const float* boxes, const float* scores, float iou_threshold, long* keep, int* counts, int B, int n, void* stream)
 {
     clear_stale_error();

@@ -323,7 +323,8 @@ __device__ __forceinline__ void epilogue_tile(f32x4_t (&acc)[4][4], OutT* __rest
 // one filter tap (Cin*sizeof(T) % 128 == 0) and is one contiguous, 16-byte-aligned run of channels;
 // taps that fall into the zero padding contribute zeros.  Weights are packed [Cout][KH][KW][Cin].
 struct ConvP { int H, W, Cin, Ho, Wo, KH, KW, stride, pad;
-               int a2_rows; };      // plain GEMM with an A2 prologue: A2 has a2_rows rows, row m of A pairs with row m % a2_rows (0 = M rows)
+               int a2_rows;         // plain GEMM with an A2 prologue: A2 has a2_rows rows, row m of A pairs with row m % a2_rows (0 = M rows)
+               int lda; };          // plain GEMM: elements between consecutive rows of A (0 = K: contiguous); K columns of a wider matrix otherwise
 __device__ __attribute__((aligned(16))) unsigned int g_zero_line[4] = {0u, 0u, 0u, 0u};   // what a padding tap reads
 
 // Tile chains.  A workgroup owns `tiles_per_block` consecutive TOKEN tiles (tm) of ONE channel tile (tn) and
@@ -406,7 +407,7 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(
                 a_off[i] = (long)bimg * cp.H * cp.W * cp.Cin * (long)sizeof(T) + kc * 16;          \
             } else {                                                                               \
                 hi0[i] = wi0[i] = 0;                                                               \
-                a_off[i] = (ar * K) * (long)sizeof(T) + kc * 16;                                   \
+                a_off[i] = (ar * (long)(cp.lda > 0 ? cp.lda : K)) * (long)sizeof(T) + kc * 16;                                   \
             }                                                                                      \
             a2_off[i] = HAS_A2 ? (((cp.a2_rows > 0 ? ar % cp.a2_rows : ar) * K) * (long)sizeof(T) + kc * 16) : 0; \
         }                                                                                          \
@@ -593,7 +594,7 @@ __global__ __launch_bounds__(512, HAS_A2 ? 2 : 4) void gemm_ws_kernel(
                     a_off[i] = (long)bimg * cp.H * cp.W * cp.Cin * (long)sizeof(T) + kc * 16;      \
                 } else {                                                                           \
                     hi0[i] = wi0[i] = 0;                                                           \
-                    a_off[i] = (ar * K) * (long)sizeof(T) + kc * 16;                               \
+                    a_off[i] = (ar * (long)(cp.lda > 0 ? cp.lda : K)) * (long)sizeof(T) + kc * 16;                               \
                 }                                                                                  \
                 a2_off[i] = HAS_A2 ? (((cp.a2_rows > 0 ? ar % cp.a2_rows : ar) * K) * (long)sizeof(T) + kc * 16) : 0; \
             }                                                                                      \
@@ -794,7 +795,7 @@ __global__ __launch_bounds__(TallCfg<TBN>::NT, TBN == 64 ? 4 : 1) void gemm_ws_t
                     a_off[i] = (long)bimg * cp.H * cp.W * cp.Cin * (long)sizeof(T) + kc * 16;
                 } else {
                     hi0[i] = wi0[i] = 0;
-                    a_off[i] = (ar * K) * (long)sizeof(T) + kc * 16;
+                    a_off[i] = (ar * (long)(cp.lda > 0 ? cp.lda : K)) * (long)sizeof(T) + kc * 16;
                 }
             }
         };
@@ -1133,10 +1134,11 @@ static int launch_conv(const void* X, const void* W, const float* bias, const vo
 
 template <typename T, typename OutT>
 static int launch_gemm(const void* A, const void* A2, const void* W, const float* bias, const void* residual,
-                       const uint8_t* row_mask, void* C, int M, int N, int K, int flags, hipStream_t st, int a2_rows = 0)
+                       const uint8_t* row_mask, void* C, int M, int N, int K, int flags, hipStream_t st, int a2_rows = 0, int lda = 0)
 {
     ConvP cp{};
     cp.a2_rows = a2_rows;
+    cp.lda = lda;
     if (!A2 && !row_mask) {
         bool done = false;
         const int rc = try_tall<T, OutT, false>(A, W, bias, residual, C, M, N, K, flags, cp, st, done);
@@ -1244,19 +1246,26 @@ extern "C" int dtlr_gemm_nt_a2bcast(const void* A, const void* A2, int a2_rows, 
 extern "C" int dtlr_gemm_nt_rowmax(const void* A, const void* W, const float* bias, float* rowmax,
                                    int M, int N, int K, int in_dtype, void* stream)
 {
+    return dtlr_gemm_nt_rowmax_lda(A, K, W, bias, rowmax, M, N, K, in_dtype, stream);
+}
+
+extern "C" int dtlr_gemm_nt_rowmax_lda(const void* A, int lda, const void* W, const float* bias, float* rowmax,
+                                       int M, int N, int K, int in_dtype, void* stream)
+{
     clear_stale_error();
     if (!A || !W || !rowmax) return DTLR_EINVAL;
-    if (M <= 0 || N <= 0 || K <= 0) return DTLR_EINVAL;
+    if (M <= 0 || N <= 0 || K <= 0 || lda < K) return DTLR_EINVAL;
+    if ((lda * (in_dtype == DTLR_F32 ? 4 : 2)) & 15) return DTLR_ESHAPE;          // rows must stay 16-byte aligned
     hipStream_t st = (hipStream_t)stream;
     if (hipMemsetD32Async((hipDeviceptr_t)rowmax, (int)0xff800000u, (size_t)M, st) != hipSuccess) { g_last_hip_error = (int)hipGetLastError(); return DTLR_ELAUNCH; }
     const int flags = (bias ? EPI_BIAS : 0) | EPI_ROWMAX;
     if (in_dtype == DTLR_H16) {
         if (K % 64) return DTLR_ESHAPE;
-        return launch_gemm<uint16_t, float>(A, nullptr, W, bias, nullptr, nullptr, rowmax, M, N, K, flags, st);
+        return launch_gemm<uint16_t, float>(A, nullptr, W, bias, nullptr, nullptr, rowmax, M, N, K, flags, st, 0, lda == K ? 0 : lda);
     }
     if (in_dtype == DTLR_F32) {
         if (K % 32) return DTLR_ESHAPE;
-        return launch_gemm<float, float>(A, nullptr, W, bias, nullptr, nullptr, rowmax, M, N, K, flags, st);
+        return launch_gemm<float, float>(A, nullptr, W, bias, nullptr, nullptr, rowmax, M, N, K, flags, st, 0, lda == K ? 0 : lda);
     }
     return DTLR_EDTYPE;
 }

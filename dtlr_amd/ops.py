@@ -243,22 +243,29 @@ def gemm_kres_bcast384(x, wp, resid):
 
 def linear_rowmax(x, w, b=None):
     """max over the output channels of (x @ w.T + b), without materialising the product (dtlr_gemm_nt_rowmax: the GEMM's
-    row-max epilogue): x [..., K], w [N, K] (same dtype, bf16 or fp32), b [N] fp32 -> [...] fp32.  The two-stage selection
-    only needs this maximum of the class head (deformable_transformer.py:341-345)."""
+    row-max epilogue): x [..., K], w [N, K] (same dtype, 16-bit or fp32), b [N] fp32 -> [...] fp32.  The two-stage selection
+    only needs this maximum of the class head (deformable_transformer.py:341-345).  x may be the first K columns of wider rows
+    (a [..., :K] view of a contiguous [..., lda] tensor): the kernel then walks A with that row stride."""
     require_cuda(x, "x")
     K, N = x.shape[-1], w.shape[0]
     slab = 64 if x.dtype in H16 else 32
     if x.dtype not in H16 + (torch.float32,) or w.dtype != x.dtype or K % slab:
         raise _lib.DTLRError(f"ops.linear_rowmax: no HIP kernel for x {tuple(x.shape)} {x.dtype} @ w {tuple(w.shape)} {w.dtype}")
-    x = x if x.is_contiguous() else x.contiguous()
+    lda = K
+    if not x.is_contiguous():
+        st = x.stride()
+        if x.dim() >= 2 and st[-1] == 1 and st[-2] >= K and all(st[d] == st[d + 1] * x.shape[d + 1] for d in range(x.dim() - 2)):
+            lda = st[-2]                                  # K leading columns of wider, evenly strided rows
+        else:
+            x = x.contiguous()
     M = x.numel() // K
     out = torch.empty(x.shape[:-1], dtype=torch.float32, device=x.device)
     es = x.element_size()
     with _Timed("gemm_bf16" if x.dtype in H16 else "gemm_f32", 2.0 * M * N * K, float(M) * K * es + float(N) * K * es + 4.0 * M,
                 f"rowmax M{M} N{N} K{K}"):
-        code = _L(x).dtlr_gemm_nt_rowmax(x.data_ptr(), w.data_ptr(), 0 if b is None else b.data_ptr(), out.data_ptr(),
-                                              M, N, K, _DT[x.dtype], _lib.current_stream())
-    _lib.check(code, "dtlr_gemm_nt_rowmax")
+        code = _L(x).dtlr_gemm_nt_rowmax_lda(x.data_ptr(), lda, w.data_ptr(), 0 if b is None else b.data_ptr(), out.data_ptr(),
+                                             M, N, K, _DT[x.dtype], _lib.current_stream())
+    _lib.check(code, "dtlr_gemm_nt_rowmax_lda")
     return out
 
 

@@ -251,6 +251,10 @@ int dtlr_gemm_nt_a2bcast(const void *A, const void *A2, int a2_rows, const void 
                          int M, int N, int K, int dtype, void *stream);
 int dtlr_gemm_nt_rowmax(const void *A, const void *W, const float *bias, float *rowmax,
                         int M, int N, int K, int in_dtype, void *stream);
+/* the same with A = K columns of a wider row-major matrix (lda elements between rows, lda >= K, rows 16-byte aligned): the first
+ * pass of the two-stage selection scores the `hi` image of the [hi|lo|hi] activation only (see DTLREngine.two_stage) */
+int dtlr_gemm_nt_rowmax_lda(const void *A, int lda, const void *W, const float *bias, float *rowmax,
+                            int M, int N, int K, int in_dtype, void *stream);
 
 /* ---------------------------------------------------------------------------------------------
  * NHWC convolution as an implicit GEMM on the matrix cores, with the FrozenBN-folded bias, optional

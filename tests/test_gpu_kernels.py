@@ -749,6 +749,9 @@ def test_linear_rowmax_vs_reference(M, N, K, dt, half):
     assert torch.equal(got, full.max(-1)[0])
     want = (x.float() @ w.float().t() + b).max(-1)[0]
     assert (got.cpu() - want).abs().max() < (1e-4 if dt == torch.float32 else 2e-3)
+    # A = the leading K columns of wider rows (dtlr_gemm_nt_rowmax_lda): identical to the contiguous copy
+    wide = torch.cat([x, _rand((M, 2 * K), 9).to(dt)], -1).cuda()
+    assert torch.equal(ops.linear_rowmax(wide[:, :K], w.cuda(), b.cuda()), got)
 
 
 @pytest.mark.parametrize("dt", ["h16", torch.float32])
