@@ -134,6 +134,58 @@ def cpu_baseline(n_lines: int = 16, height: int = 128, width: int = 2048, timed:
                       f"all {nphys} physical cores; `value` is the faster leg"}
 
 
+def msda_offset_sensitivity(eng, B, dtype, level_hw, sigmas=(0.0, 8.0, 32.0), iters=10):
+    """The encoder's deformable-sampling call as a function of how far a checkpoint's offset heads look (the synthetic weights plant
+    <= 4 px; a trained line recogniser may look further along the line): offsets N(0, sigma^2) pixels of the sampled level, B lines,
+    the bench's level shapes.  Per sigma: the kernel the engine's calibration rule picks (LDS windows at a halo of 8 / 16 / 24 columns,
+    or the gather kernel), its time, and the two fixed choices beside it."""
+    import math
+    from dtlr_amd import ops
+    dev = eng.device
+    M, L, P = 8, 4, 4
+    S = sum(h * w for h, w in level_hw)
+    shapes = torch.as_tensor(level_hw, dtype=torch.long, device=dev)
+    lsi = torch.cat((shapes.new_zeros((1,)), shapes.prod(1).cumsum(0)[:-1]))
+    g = torch.Generator(device="cpu").manual_seed(0)
+    value = (torch.rand((B, S, M, 32), generator=g) * 2 - 1).to(dev).to(dtype)
+    rp = torch.cat([torch.stack(torch.meshgrid(torch.linspace(0.5, h - 0.5, h) / h, torch.linspace(0.5, w - 0.5, w) / w, indexing="ij")[::-1], -1).reshape(-1, 2)
+                    for h, w in level_hw], 0)
+    refg = rp[None, :, None, :].expand(B, S, L, 2).contiguous().to(dev)
+    alg = msda_algorithmic_bytes_per_line(S, S, 2) * B
+
+    def timeit(fn):
+        for _ in range(2):
+            fn()
+        a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        a.record()
+        for _ in range(iters):
+            fn()
+        b.record()
+        torch.cuda.synchronize()
+        return a.elapsed_time(b) / iters
+
+    rows = []
+    for sigma in sigmas:
+        ow = torch.randn((B, S, M * L * P * 3), generator=g).to(dev)
+        ow[..., : M * L * P * 2] *= sigma
+        ow = ow.to(dtype)
+        best = ("gather", None, 1.0)
+        far = {}
+        for halo, base in eng.msda_halo_base.items():
+            if ops.msda_encoder_fits(level_hw, dtype, halo):
+                far[halo] = ops.msda_encoder_far_fraction(dtype, level_hw, ow, refg, M, halo)
+                c = base + eng.msda_far_slope * math.sqrt(far[halo])
+                if c < best[2]:
+                    best = ("lds", halo, c)
+        t_lds8 = timeit(lambda: ops.msda_encoder(value, level_hw, ow, refg, 8))
+        t_gather = timeit(lambda: ops.msda_fused(value, shapes, lsi, ow, refg))
+        t_pick = t_gather if best[0] == "gather" else (t_lds8 if best[1] == 8 else timeit(lambda: ops.msda_encoder(value, level_hw, ow, refg, best[1])))
+        rows.append({"offset_sigma_px": sigma, "far_fraction_halo8": round(far.get(8, float("nan")), 5), "picked": best[0] + (f"@halo{best[1]}" if best[1] else ""),
+                     "picked_ms": round(t_pick, 4), "picked_gbps_algorithmic": round(alg / t_pick / 1e6, 1), "frac_of_hbm_peak": round(alg / t_pick / 1e6 / HBM_PEAK_GBS, 4),
+                     "lds_halo8_ms": round(t_lds8, 4), "gather_ms": round(t_gather, 4)})
+    return rows
+
+
 def cer_vs_oracle(cfg, sd, x, mask, out, rows):
     """Lines `rows` of the benched batch against the CPU oracle on the same canvas / masks, following the engine's own selection."""
     from oracle import dtlr_oracle as O          # checker only
@@ -444,6 +496,15 @@ def main():
         "roofline_by_kernel": by_kernel,
         "gemm_by_shape": gemm_by_shape[:24],
     }
+    if world == 1 and args.dtype != "f32" and not cfg.is_swin:
+        try:                                                    # the MSDA figure above is the synthetic weights' best case: show the other cases beside it
+            lhw = [tuple(int(v) for v in hw) for hw in eng._shape_cache[next(iter(eng._shape_cache))]["level_hw"]] if eng._shape_cache else None
+            if lhw is None:
+                lhw = [(16, canvas_w // 8), (8, canvas_w // 16), (4, canvas_w // 32), (2, canvas_w // 64)]
+            line["msda_encoder_by_offset_scale"] = msda_offset_sensitivity(eng, B, dtype, lhw)
+            log(f"msda_encoder_by_offset_scale: {line['msda_encoder_by_offset_scale']}")
+        except Exception as e:
+            line["msda_encoder_by_offset_scale"] = {"error": repr(e)}
     rows = sorted({int(round(i * (B - 1) / max(args.parity_lines - 1, 1))) for i in range(min(args.parity_lines, B))})
     if not args.no_parity:
         try:

@@ -56,7 +56,10 @@ class DTLREngine:
         self.use_kres = True
         self.use_kres_narrow = True
         self.msda_auto = True      # per-layer choice LDS-window / gather kernel, calibrated once per canvas shape (see _msda_mode)
-        self.msda_far_threshold = 0.012
+        # cost model of the encoder MSDA kernels, in units of the gather kernel's time (profiles/r03_msda_offset_halo_sweep_v1.json, B = 32,
+        # 128x2048): LDS-window kernel with a halo of 8 / 16 / 24 columns = base + 4.8 sqrt(far fraction); gather kernel = 1
+        self.msda_halo_base = {8: 0.51, 16: 0.635, 24: 0.71}
+        self.msda_far_slope = 4.8
         self._msda_state = {}      # (layer, canvas shape) -> {"mode", "far"}; keyed by nothing that depends on the data or the call history
         self._msda_calibrating = None
         self.use_k256_small = True   # ... and for the encoder's output projection + LayerNorm
@@ -387,18 +390,29 @@ class DTLREngine:
         the data or on the call history (round 2 probed the running batch every 256 calls: a result could depend on which batch had
         been probed, and data-parallel ranks could choose differently).  It is now a function of (weights, canvas shape) only: the
         first forward of a canvas shape runs ONE calibration pass of the encoder on a seeded noise batch of that shape
-        (`_calibrate_msda`), probing every layer (dtlr_msda_encoder_far_samples: one small kernel + a 16-byte read-back); every rank
-        holds the same weights and generates the same noise, so every rank chooses the same kernels.  `msda_auto = False` pins the LDS
+        (`_calibrate_msda`), probing every layer at window halos of 8 / 16 / 24 columns (dtlr_msda_encoder_far_samples: one small kernel
+        + a 16-byte read-back each) and choosing the cheapest of {LDS kernel at one of those halos, gather kernel} under the cost model
+        fitted to profiles/r03_msda_offset_halo_sweep_v1.json (a wider halo stages more columns -- 0.159 / 0.197 / 0.219 ms per call at
+        no far samples -- but at sigma = 8 px offsets turns 0.365 ms into 0.234 ms, below the gather kernel's 0.307); every rank holds
+        the same weights and generates the same noise, so every rank makes the same choice.  `msda_auto = False` pins the LDS
         kernel; `_msda_state[(layer, level_hw)] = {"mode": ...}` overrides a layer."""
         if not self.msda_auto:
-            return "lds"
+            return "lds", None
         key = (name, tuple(level_hw))
         if self._msda_calibrating is not None:               # inside the calibration pass: measure, run the (always correct) LDS kernel
-            far = ops.msda_encoder_far_fraction(value_dtype, level_hw, ow, ref, n_heads)
-            self._msda_calibrating[key] = {"far": far, "mode": "gather" if far > self.msda_far_threshold else "lds"}
-            return "lds"
+            best = {"mode": "gather", "halo": None, "cost": 1.0, "far": {}}
+            for halo, base in self.msda_halo_base.items():
+                if not ops.msda_encoder_fits(level_hw, value_dtype, halo):
+                    continue
+                far = ops.msda_encoder_far_fraction(value_dtype, level_hw, ow, ref, n_heads, halo)
+                best["far"][halo] = far
+                cost = base + self.msda_far_slope * math.sqrt(far)
+                if cost < best["cost"]:
+                    best.update(mode="lds", halo=halo, cost=cost)
+            self._msda_calibrating[key] = best
+            return "lds", None
         st = self._msda_state.get(key)
-        return st["mode"] if st is not None else "lds"
+        return (st["mode"], st.get("halo")) if st is not None else ("lds", None)
 
     def _calibrate_msda(self, x_shape, level_hw):
         """One encoder pass on a seeded noise batch (2 lines of this canvas shape, unpadded) -> the per-layer kernel choice."""
@@ -444,9 +458,10 @@ class DTLREngine:
         else:
             ow = self._lin(name + ".ow", query, a2=query_pos)
         if L == 4 and P == 4:
-            if Lq == S and ref.shape[-1] == 2 and C // M == 32 and self.use_lds_msda and g["lds_msda_fits"] \
-                    and self._msda_mode(name, value.dtype, g["level_hw"], ow, ref, M) == "lds":        # encoder self-attention
-                return ops.msda_encoder(value.view(B, S, M, C // M), g["level_hw"], ow, ref)
+            if Lq == S and ref.shape[-1] == 2 and C // M == 32 and self.use_lds_msda and g["lds_msda_fits"]:   # encoder self-attention
+                mode, halo = self._msda_mode(name, value.dtype, g["level_hw"], ow, ref, M)
+                if mode == "lds":
+                    return ops.msda_encoder(value.view(B, S, M, C // M), g["level_hw"], ow, ref, halo)
             return ops.msda_fused(value.unflatten(-1, (M, C // M)), g["shapes"], g["lsi"], ow, ref)
         ow = ow.float()
         off = ow[..., : M * L * P * 2].reshape(B, Lq, M, L, P, 2)

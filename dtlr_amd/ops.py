@@ -698,17 +698,17 @@ def geometry(mask, level_hw, level_embed, temperature_h: float, temperature_w: f
     return dict(mask_flat=mask_flat, keep=keep, pos=pos, valid_ratios=vr, enc_ref=enc_ref, proposals=prop)
 
 
-def msda_encoder_fits(level_hw, dtype) -> bool:
+def msda_encoder_fits(level_hw, dtype, halo: Optional[int] = None) -> bool:
     """Whether the LDS-window encoder kernel's plan fits these level shapes (it stages full-height column windows: canvases
     taller than ~270 px in fp32 / ~550 px in bf16 do not fit, and the caller uses msda_fused, the gather kernel, instead)."""
     hw = (ctypes.c_int * 8)(*[int(v) for pair in level_hw for v in pair])
-    rc = _L(dtype).dtlr_msda_encoder_plan_ok(ctypes.cast(hw, ctypes.c_void_p), _DT[dtype], MSDA_HALO)
+    rc = _L(dtype).dtlr_msda_encoder_plan_ok(ctypes.cast(hw, ctypes.c_void_p), _DT[dtype], MSDA_HALO if halo is None else int(halo))
     if rc < 0:
         _lib.check(rc, "dtlr_msda_encoder_plan_ok")
     return rc == 1
 
 
-def msda_encoder(value, level_hw, ow, ref):
+def msda_encoder(value, level_hw, ow, ref, halo: Optional[int] = None):
     """Encoder MSDA (Lq == S, queries are the level pixels) with LDS-staged value windows.
     value [N,S,M,32] fp32/bf16; level_hw: HOST list of (H_l, W_l); ow [N,S,M*48]; ref [N,S,4,2] fp32."""
     N, S, M, D = value.shape
@@ -722,7 +722,7 @@ def msda_encoder(value, level_hw, ow, ref):
         st = torch.cuda.current_stream()
         a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         a.record(st)
-    code = _L(value).dtlr_msda_encoder_forward(value.data_ptr(), ow.data_ptr(), ref.data_ptr(), hw, N, M, D, 4, 4, MSDA_HALO,
+    code = _L(value).dtlr_msda_encoder_forward(value.data_ptr(), ow.data_ptr(), ref.data_ptr(), hw, N, M, D, 4, 4, MSDA_HALO if halo is None else int(halo),
                                                 _DT[value.dtype], _DT[ow.dtype], out.data_ptr(), _lib.current_stream())
     _lib.check(code, "dtlr_msda_encoder_forward")
     if ev is not None:
@@ -731,7 +731,7 @@ def msda_encoder(value, level_hw, ow, ref):
     return out
 
 
-def msda_encoder_far_fraction(value_dtype, level_hw, ow, ref, n_heads: int = 8):
+def msda_encoder_far_fraction(value_dtype, level_hw, ow, ref, n_heads: int = 8, halo: Optional[int] = None):
     """Fraction of the in-map sampling points of an encoder MSDA call that msda_encoder would fetch through its global path (outside the
     staged column window of the query's tile; dtlr_msda_encoder_far_samples).  Synchronises (reads two counters back): a probe."""
     require_cuda(ow, "ow")
@@ -739,7 +739,7 @@ def msda_encoder_far_fraction(value_dtype, level_hw, ow, ref, n_heads: int = 8):
     import ctypes
     hw = (ctypes.c_int * 8)(*[int(v) for pair in level_hw for v in pair])
     counts = torch.zeros(2, dtype=torch.int64, device=ow.device)
-    code = _L(value_dtype).dtlr_msda_encoder_far_samples(ow.data_ptr(), ref.data_ptr(), hw, ow.shape[0], n_heads, MSDA_HALO, _DT[value_dtype],
+    code = _L(value_dtype).dtlr_msda_encoder_far_samples(ow.data_ptr(), ref.data_ptr(), hw, ow.shape[0], n_heads, MSDA_HALO if halo is None else int(halo), _DT[value_dtype],
                                                     _DT[ow.dtype], counts.data_ptr(), _lib.current_stream())
     _lib.check(code, "dtlr_msda_encoder_far_samples")
     far, inside = counts.tolist()

@@ -667,8 +667,8 @@ def test_msda_kernel_choice_follows_the_far_sample_probe():
     m = _model(cfg, sd)
     out = m([i.cuda() for i in imgs], return_debug=True)
     st = {k[0]: v for k, v in m.engine()._msda_state.items()}
-    assert st["enc1.attn"]["mode"] == "gather" and st["enc1.attn"]["far"] > 0.05, st
-    assert st["enc0.attn"]["mode"] == "lds" and st["enc0.attn"]["far"] < 0.012, st
+    assert st["enc1.attn"]["mode"] == "gather" and min(st["enc1.attn"]["far"].values()) > 0.05, st
+    assert st["enc0.attn"]["mode"] == "lds" and st["enc0.attn"]["halo"] == 8 and st["enc0.attn"]["far"][8] < 0.012, st
     # the choice is a function of (weights, canvas shape): a second engine with the same weights, fed DIFFERENT data first, agrees
     m2 = _model(cfg, sd)
     m2([i.cuda() for i in synth.stroke_lines(2, 32, 2048, seed=77)])

@@ -70,6 +70,7 @@ def main():
     ap.add_argument("--iters", type=int, default=20)
     ap.add_argument("--batch", type=int, default=32)
     ap.add_argument("--sigmas", default="0,2,8,32,128")
+    ap.add_argument("--halos", default="8", help="comma list of window halos (columns per level beyond the tile); the engine default is 8")
     args = ap.parse_args()
     dev = torch.device("cuda:0")
     B, M, D, L, P = args.batch, 8, 32, 4, 4
@@ -100,6 +101,19 @@ def main():
             rec[name + "_ms"] = round(ms, 4)
             rec[name + "_GBps_algorithmic"] = round(alg / ms / 1e6, 1)
         L_.dtlr_msda_encoder_set_variant(2)
+        for halo in [int(v) for v in args.halos.split(",")]:
+            if halo == 8:
+                continue
+            old = ops.MSDA_HALO
+            ops.MSDA_HALO = halo
+            try:
+                if ops.msda_encoder_fits(shapes_l, torch.bfloat16):
+                    rec[f"halo{halo}_ms"] = round(timeit(lambda: ops.msda_encoder(value, shapes_l, owb, refg), args.iters), 4)
+                    rec[f"halo{halo}_global_path_fraction"] = round(global_path_fraction(owb, refg, shapes_l, 32, halo), 5)
+                else:
+                    rec[f"halo{halo}_ms"] = None
+            finally:
+                ops.MSDA_HALO = old
         gather = ops.msda_fused(value, shapes, lsi, owb, refg).float()
         rec["gather_kernel_ms"] = round(timeit(lambda: ops.msda_fused(value, shapes, lsi, owb, refg), max(3, args.iters // 4)), 4)
         rec["max_abs_diff_packed_vs_fp32acc"] = round((outs[2] - outs[0]).abs().max().item(), 5)
