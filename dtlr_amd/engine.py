@@ -63,6 +63,7 @@ class DTLREngine:
         self._msda_state = {}      # (layer, canvas shape) -> {"mode", "far"}; keyed by nothing that depends on the data or the call history
         self._msda_calibrating = None
         self.use_k256_small = True   # ... and for the encoder's output projection + LayerNorm
+        self.use_dec_query_stage = True   # 16-bit: a decoder layer's query stage (sine, ref_point_head, q | k, v) in one launch
 
     # ------------------------------------------------------------------------------ packing
     def _put(self, name, t, dtype=None):
@@ -594,11 +595,19 @@ class DTLREngine:
             vall = ops.linear(memory, self.w["dec.value_all.w"], self.w["dec.value_all.b"], row_mask=rmask)
         for n in range(cfg.dec_layers):
             q = f"dec{n}."
-            ref_in, sine = ops.decoder_query_prep(ref, g["valid_ratios"], self.dtype)      # [B,nq,L,4], [B,nq,512]
-            qpos = self._lin("dec.rph1", self._lin("dec.rph0", sine, relu=True))
-            # self attention (q = k = tgt + query_pos, v = tgt)
-            qk = self._lin(q + "sa.qk", tgt, a2=qpos)
-            v = self._lin(q + "sa.v", tgt)
+            w = self.w
+            if self.use_dec_query_stage and tgt.dtype in ops.H16 and C == 256 and w["dec.rph0.w"].shape == (256, 512):
+                for nm in ("dec.rph0", "dec.rph1", q + "sa.qk", q + "sa.v"):
+                    if nm + ".dq" not in w:                    # fragment-order images, packed once
+                        w[nm + ".dq"] = ops.dq_pack(w[nm + ".w"])
+                ref_in, qpos, qk, v = ops.dec_query_stage(ref, g["valid_ratios"], tgt, w["dec.rph0.dq"], w["dec.rph0.b"], w["dec.rph1.dq"],
+                                                          w["dec.rph1.b"], w[q + "sa.qk.dq"], w[q + "sa.qk.b"], w[q + "sa.v.dq"], w[q + "sa.v.b"])
+            else:
+                ref_in, sine = ops.decoder_query_prep(ref, g["valid_ratios"], self.dtype)      # [B,nq,L,4], [B,nq,512]
+                qpos = self._lin("dec.rph1", self._lin("dec.rph0", sine, relu=True))
+                # self attention (q = k = tgt + query_pos, v = tgt)
+                qk = self._lin(q + "sa.qk", tgt, a2=qpos)
+                v = self._lin(q + "sa.v", tgt)
             a = ops.mha(qk, v, cfg.nheads)
             tgt = self._proj_ln(q + "sa.out", q + "norm2", a, tgt)
             # deformable cross attention

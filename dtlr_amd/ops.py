@@ -785,6 +785,47 @@ def decoder_query_prep(ref, valid_ratios, out_dtype):
     return ref_in, sine
 
 
+def dq_pack(w):
+    """[N, K] weight (N, K multiples of 32) -> the fragment-order image dtlr_dec_query_stage streams (== dtlr_dq_pack_weights):
+    [unit = N/32][k-step = K/32][tile 2][lane (m, g)][8] <- W[32 u + 16 t + m][32 ks + 8 g ..]."""
+    N, K = w.shape
+    assert N % 32 == 0 and K % 32 == 0
+    v = w.detach().to(_hdt(w)).view(N // 32, 2, 16, K // 32, 4, 8)             # u, t, m, ks, g, e
+    return v.permute(0, 3, 1, 4, 2, 5).contiguous().view(-1)                   # u, ks, t, [g, m] = lane, e
+
+
+def dec_query_stage(ref, valid_ratios, tgt, w0, b0, w1, b1, wqk, bqk, wv, bv):
+    """The query stage of a decoder layer in ONE launch (dtlr_dec_query_stage, 16-bit engines): reference boxes per level, sine
+    embedding, ref_point_head MLP, and the q | k (on tgt + query_pos) and v (on tgt) input projections of the self-attention.
+    ref [B,nq,4] fp32, valid_ratios [B,L,2] fp32, tgt [B,nq,256] 16-bit; weights = dq_pack of the 16-bit [256,512] / [256,256] /
+    [512,256] / [256,256] matrices, biases fp32 -> (ref_in [B,nq,L,4] fp32, qpos [B,nq,256], qk [B,nq,512], v [B,nq,256])."""
+    require_cuda(tgt, "tgt")
+    B, nq, C = tgt.shape
+    L = valid_ratios.shape[1]
+    assert tgt.dtype in H16 and C == 256 and ref.dtype == torch.float32 and tuple(ref.shape) == (B, nq, 4)
+    assert w0.numel() == 256 * 512 and w1.numel() == 256 * 256 and wqk.numel() == 512 * 256 and wv.numel() == 256 * 256
+    assert all(t.dtype == tgt.dtype and t.is_contiguous() for t in (w0, w1, wqk, wv))
+    key = ref.device
+    if key not in _DIM_T:
+        t = torch.arange(128, dtype=torch.float32, device=ref.device)
+        _DIM_T[key] = (10000 ** (2 * torch.div(t, 2, rounding_mode="floor") / 128)).contiguous()
+    ref, valid_ratios, tgt = ref.contiguous(), valid_ratios.contiguous(), tgt.contiguous()
+    dev = tgt.device
+    ref_in = torch.empty((B, nq, L, 4), dtype=torch.float32, device=dev)
+    qpos = torch.empty((B, nq, 256), dtype=tgt.dtype, device=dev)
+    qk = torch.empty((B, nq, 512), dtype=tgt.dtype, device=dev)
+    v = torch.empty((B, nq, 256), dtype=tgt.dtype, device=dev)
+    M = B * nq
+    with _Timed("gemm_bf16", 2.0 * M * (512 * 256 + 256 * 256 + 256 * 512 + 256 * 256), float(M) * (256 + 256 + 512 + 256) * 2 + 393216.0 * 2,
+                f"dec_query_stage M{M}"):
+        code = _L(tgt).dtlr_dec_query_stage(ref.data_ptr(), valid_ratios.data_ptr(), _DIM_T[key].data_ptr(), tgt.data_ptr(),
+                                            w0.data_ptr(), b0.data_ptr(), w1.data_ptr(), b1.data_ptr(), wqk.data_ptr(), bqk.data_ptr(),
+                                            wv.data_ptr(), bv.data_ptr(), ref_in.data_ptr(), qpos.data_ptr(), qk.data_ptr(), v.data_ptr(),
+                                            B, nq, L, _DT[tgt.dtype], _lib.current_stream())
+    _lib.check(code, "dtlr_dec_query_stage")
+    return ref_in, qpos, qk, v
+
+
 def box_mlp_refine(x, w1, b1, w2p, b2, w3, b3, ref, mode: int = 0):
     """3-layer box MLP + refinement in ONE launch (dtlr_box_mlp_refine_bf16): x [..,256] bf16, W1 [256,256] bf16,
     w2p = ffn_pack_w2(W2) bf16, W3 [4,256] / biases fp32, ref [..,4] fp32 -> [..,4] fp32.

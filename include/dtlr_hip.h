@@ -278,6 +278,22 @@ int dtlr_conv3x3_patch_bf16(const void *X, const void *Wt, const float *bias, vo
                             int relu, void *stream);
 
 /* ---------------------------------------------------------------------------------------------
+ * The query stage of one decoder layer in one launch (16-bit engines; csrc/dec_query.hip).
+ * Replaces: TransformerDecoder.forward's per-layer preparation -- reference_points * valid_ratios, gen_sineembed_for_position,
+ *           ref_point_head (models/dino/deformable_transformer.py:684-692, models/dino/utils.py:141-167) -- and the q / k / v
+ *           input projections of DeformableTransformerDecoderLayer's self-attention (nn.MultiheadAttention in_proj on
+ *           q = k = tgt + query_pos, v = tgt; deformable_transformer.py:904-907).
+ * ref [B*nq,4] fp32 (sigmoided), valid_ratios [B,L,2] fp32, dim_t [128] fp32 (10000^(2(i//2)/128)), tgt [B*nq,256] 16-bit;
+ * W0 [256,512] b0, W1 [256,256] b1 (ref_point_head), Wqk [512,256] bqk, Wv [256,256] bv (in_proj split); weights 16-bit, biases fp32.
+ * The four weights are handed over in the kernel's fragment order (dtlr_dq_pack_weights, once per model).
+ * Outputs: ref_in [B*nq,L,4] fp32, qpos [B*nq,256], qk [B*nq,512], v [B*nq,256] (16-bit).  dtype = the library's 16-bit code. */
+int dtlr_dq_pack_weights(const unsigned short *w_host, unsigned short *out_host, int N, int K);   /* [N,K] row-major -> fragment order (host) */
+int dtlr_dec_query_stage(const float *ref, const float *valid_ratios, const float *dim_t, const void *tgt,
+                         const void *W0, const float *b0, const void *W1, const float *b1,
+                         const void *Wqk, const float *bqk, const void *Wv, const float *bv,
+                         float *ref_in, void *qpos, void *qk, void *v, int B, int nq, int L, int dtype, void *stream);
+
+/* ---------------------------------------------------------------------------------------------
  * Per-decoder-layer query preparation, fused.
  * Replaces: TransformerDecoder.forward lines 684-690 (reference_points[:, :, None] * cat(valid_ratios,
  *           valid_ratios)) + gen_sineembed_for_position (models/dino/utils.py:141-167).

@@ -1099,3 +1099,30 @@ def test_conv3x3_patch_kernel_vs_reference(B, H, W, Cin, Cout, half):
         assert (got - want).abs().max() < ulp(half, 8) * max(1.0, want.abs().max().item()) + 1e-4, relu
     got = ops.conv2d_nhwc(x.cuda(), w_ohwi, None, 1, 1, False, None).float().cpu()
     assert (got - (ref - b.double()).float()).abs().max() < ulp(half, 8) * max(1.0, ref.abs().max().item()) + 1e-4
+
+
+@pytest.mark.parametrize("B,nq", [(32, 900), (3, 900), (2, 100), (1, 37)])
+def test_dec_query_stage_equals_the_unfused_path(B, nq, half):
+    """dtlr_dec_query_stage (reference boxes per level, sine embedding, ref_point_head, q | k and v projections in one launch) ==
+    the operators it replaces (decoder_query_prep, two GEMMs, the [q|k] GEMM with its A + A2 prologue, the v GEMM), bit for bit --
+    same MFMA, k ascending, the same roundings at the same places -- including a ragged last workgroup; and close to an fp64
+    restatement of deformable_transformer.py:684-692, 904-907."""
+    from dtlr_amd import ops
+    ref = torch.sigmoid(_rand((B, nq, 4), 1)).cuda()
+    vr = (0.5 + 0.5 * torch.rand((B, 4, 2), generator=torch.Generator().manual_seed(2))).cuda()
+    tgt = _rand((B, nq, 256), 3).to(half).cuda()
+    w0, w1 = (_rand((256, 512), 4) / 22).to(half).cuda(), (_rand((256, 256), 5) / 16).to(half).cuda()
+    wqk, wv = (_rand((512, 256), 6) / 16).to(half).cuda(), (_rand((256, 256), 7) / 16).to(half).cuda()
+    b0, b1, bqk, bv = _rand((256,), 8).cuda() * 0.1, _rand((256,), 9).cuda() * 0.1, _rand((512,), 10).cuda() * 0.1, _rand((256,), 11).cuda() * 0.1
+    ref_in, qpos, qk, v = ops.dec_query_stage(ref, vr, tgt, ops.dq_pack(w0), b0, ops.dq_pack(w1), b1, ops.dq_pack(wqk), bqk, ops.dq_pack(wv), bv)
+    ref_in2, sine = ops.decoder_query_prep(ref, vr, half)
+    qpos2 = ops.linear(ops.linear(sine, w0, b0, relu=True), w1, b1)
+    qk2 = ops.linear(tgt, wqk, bqk, a2=qpos2)
+    v2 = ops.linear(tgt, wv, bv)
+    assert torch.equal(ref_in, ref_in2)
+    assert torch.equal(qpos, qpos2) and torch.equal(qk, qk2) and torch.equal(v, v2)
+    # fp64 restatement on the same 16-bit inputs (loose: three chained roundings)
+    s64 = sine.double().cpu()
+    q64 = torch.relu(s64 @ w0.double().cpu().t() + b0.double().cpu()) @ w1.double().cpu().t() + b1.double().cpu()
+    k64 = (tgt.double().cpu() + q64) @ wqk.double().cpu().t() + bqk.double().cpu()
+    assert (qpos.double().cpu() - q64).abs().max() < 0.05 and (qk.double().cpu() - k64).abs().max() < 0.1

@@ -406,6 +406,11 @@ def test_weight_packers_tensor_ops_match_the_library_host_packers():
         out = np.empty(N * 256, dtype=np.uint16)
         assert L.dtlr_k256_pack_weights(u16(w).ctypes.data, out.ctypes.data, N) == 0
         assert np.array_equal(out, u16(ops.k256_pack(w)))
+    for N, K in ((256, 512), (512, 256), (256, 256)):                       # the decoder query-stage kernel's fragment order
+        w = torch.randn((N, K), generator=g).bfloat16()
+        out = np.empty(N * K, dtype=np.uint16)
+        assert L.dtlr_dq_pack_weights(u16(w).ctypes.data, out.ctypes.data, N, K) == 0
+        assert np.array_equal(out, u16(ops.dq_pack(w))), (N, K)
     w = torch.randn((256, 256), generator=g).bfloat16()
     out = np.empty(65536, dtype=np.uint16)
     assert L.dtlr_proj_ln_k256_pack_weights(u16(w).ctypes.data, out.ctypes.data) == 0
