@@ -24,7 +24,7 @@
 // the decoder loop) against 113 us for the six launches; without the MFMAs 39 us, without the weight fetch 44 us (it was 40 of 57 us
 // before the weights were packed in fragment order and requested a stage ahead), without MFMAs, fetch, LDS reads and sine 28 us: the
 // remainder is the launch itself (~8 us for any 225-workgroup kernel here), the dependent chain of reference-box loads, barriers and
-// epilogues, and 262 KB of 32-byte output pieces per workgroup -- the next step is 16-byte paired stores as in gemm.hip.
+// epilogues, and the 262 KB of output per workgroup (written as 16-byte pieces, 64 contiguous bytes per query: dq_store_pair).
 // Arithmetic identical to the unfused path (same MFMA, k ascending, same roundings: sine, H, qpos, tgt + qpos and the outputs are
 // rounded to the 16-bit format exactly where the separate kernels stored them), so the results are bit-identical to it.
 #include "dtlr_common.h"
@@ -76,6 +76,19 @@ __device__ __forceinline__ void dq_gemm(dq_f32x4_t (&acc)[NT][8], const uint4 (&
             for (int t = 0; t < NT; ++t) acc[t][tt] = dq_mma(a[ks][t], b, acc[t][tt]);
         }
     }
+}
+
+// Store the wave's two row tiles (32 channels) of one query tile as 16-byte pieces: the tiles are paired with v_permlane16_swap so that a
+// lane holds 8 consecutive channels (even g: channels 8 (g/2).. of tile 0, odd g: the same 8 channels of tile 1) -- 64 contiguous bytes
+// per query and instruction instead of two 32-byte pieces (the output of a workgroup is 262 KB).
+__device__ __forceinline__ void dq_store_pair(uint16_t* __restrict__ row /* &out[q][ch0] */, const dq_f32x4_t& c0, const dq_f32x4_t& c1,
+                                              const float4& b0, const float4& b1, int g, bool live)
+{
+    const uint32_t lo0 = pack_bf16x2(c0[0] + b0.x, c0[1] + b0.y), hi0 = pack_bf16x2(c0[2] + b0.z, c0[3] + b0.w);
+    const uint32_t lo1 = pack_bf16x2(c1[0] + b1.x, c1[1] + b1.y), hi1 = pack_bf16x2(c1[2] + b1.z, c1[3] + b1.w);
+    const auto s0 = __builtin_amdgcn_permlane16_swap(lo0, lo1, false, false);
+    const auto s1 = __builtin_amdgcn_permlane16_swap(hi0, hi1, false, false);
+    if (live) *reinterpret_cast<uint4*>(row + (g & 1) * 16 + 8 * (g >> 1)) = make_uint4(s0[0], s1[0], s0[1], s1[1]);
 }
 
 template <int NT>
@@ -221,15 +234,11 @@ __global__ __launch_bounds__(512) void dec_query_stage_kernel(
         dq_f32x4_t acc[2][8];                                                                      \
         dq_zero<2>(acc);                                                                           \
         dq_gemm<256, 2>(acc, WF, XT, DQ_PITCH, lane);                                              \
-        _Pragma("unroll") for (int t = 0; t < 2; ++t) {                                            \
-            const int ch = (CH0) + 16 * t + 4 * g;                                                 \
-            const float4 bb = *reinterpret_cast<const float4*>((BIAS) + ch);                       \
-            _Pragma("unroll") for (int tt = 0; tt < 8; ++tt) {                                     \
-                const long q = q0 + 16 * tt + n;                                                   \
-                const dq_f32x4_t c = acc[t][tt];                                                   \
-                if (q < Q) *reinterpret_cast<uint2*>((OUT) + q * (LDO) + ch) =                     \
-                    make_uint2(pack_bf16x2(c[0] + bb.x, c[1] + bb.y), pack_bf16x2(c[2] + bb.z, c[3] + bb.w)); \
-            }                                                                                      \
+        const float4 bb0 = *reinterpret_cast<const float4*>((BIAS) + (CH0) + 4 * g);               \
+        const float4 bb1 = *reinterpret_cast<const float4*>((BIAS) + (CH0) + 16 + 4 * g);          \
+        _Pragma("unroll") for (int tt = 0; tt < 8; ++tt) {                                         \
+            const long q = q0 + 16 * tt + n;                                                       \
+            dq_store_pair((OUT) + min(q, Q - 1) * (LDO) + (CH0), acc[0][tt], acc[1][tt], bb0, bb1, g, q < Q); \
         }                                                                                          \
     }
     uint4 wg[8][2];

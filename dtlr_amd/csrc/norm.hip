@@ -256,16 +256,19 @@ __global__ __launch_bounds__(256) void maxpool3x3s2_kernel(const T* __restrict__
     float m[VEC];
 #pragma unroll
     for (int i = 0; i < VEC; ++i) m[i] = -INFINITY;
+    // branch-free: the nine loads are always issued (addresses clamped into the map) and an out-of-map tap is replaced by -inf with a
+    // select -- with `if (outside) continue` hipcc put every load in its own exec-masked block behind a wait (nine serialised round trips)
 #pragma unroll
     for (int kh = 0; kh < 3; ++kh) {
         const int hi = 2 * ho - 1 + kh;
-        if (hi < 0 || hi >= H) continue;
+        const bool hok = hi >= 0 && hi < H;
+        const int hc = min(max(hi, 0), H - 1);
 #pragma unroll
         for (int kw = 0; kw < 3; ++kw) {
             const int wi = 2 * wo - 1 + kw;
-            if (wi < 0 || wi >= W) continue;
+            const bool ok = hok && wi >= 0 && wi < W;
             float v[VEC];
-            const T* src = x + ((b * H + hi) * W + wi) * C + c0;
+            const T* src = x + ((b * H + hc) * W + min(max(wi, 0), W - 1)) * C + c0;
             if constexpr (VEC == 8 && sizeof(T) == 2) {               // one 16-byte load (8-byte accesses run at ~0.6x the 16-byte rate)
                 const uint4 t = *reinterpret_cast<const uint4*>(src);
                 const uint32_t w4[4] = {t.x, t.y, t.z, t.w};
@@ -274,7 +277,7 @@ __global__ __launch_bounds__(256) void maxpool3x3s2_kernel(const T* __restrict__
             } else if (VEC == 4) IO<T>::load4(src, *reinterpret_cast<float (*)[4]>(v));
             else { IO<T>::load4(src, *reinterpret_cast<float (*)[4]>(v)); IO<T>::load4(src + 4, *reinterpret_cast<float (*)[4]>(v + 4)); }
 #pragma unroll
-            for (int i = 0; i < VEC; ++i) m[i] = fmaxf(m[i], v[i]);
+            for (int i = 0; i < VEC; ++i) m[i] = fmaxf(m[i], ok ? v[i] : -INFINITY);
         }
     }
     // optional per-channel bias + ReLU applied AFTER the max: max_i(x_i + b) == max_i(x_i) + b exactly (rounding is

@@ -46,26 +46,40 @@ __global__ __launch_bounds__(512, 2) void stem_conv7x7_kernel(const float* __res
     const int ow_b0 = blockIdx.x * STEM_COLS, oh0 = blockIdx.y * STEM_ROWS, b = blockIdx.z;
     const int ir0 = 2 * oh0 - 3, ic0 = 2 * ow_b0 - 3;
 
-    // ---- weights: 24 fragments, lane's 16 bytes each, held for the whole kernel ------------------------------
+    // ---- stage 3 x 13 input rows x 520 columns as 16-bit pairs (zero outside the image).  ALL of a thread's loads are issued before the
+    // first conversion (clamped addresses, the zero padding applied by a select): as a load -> convert -> LDS-store loop the 20
+    // iterations were 20 dependent HBM round trips per workgroup and the kernel ran at 1.6 TB/s of its output bytes.
+    const float* xb = x + (long)b * 3 * H * W;
+    constexpr int NP = 3 * STEM_IN_ROWS * (STEM_IN_COLS / 2);
+    constexpr int NIT = (NP + 511) / 512;
+    float v0[NIT], v1[NIT];
+#pragma unroll
+    for (int it = 0; it < NIT; ++it) {
+        const int p = min((int)threadIdx.x + 512 * it, NP - 1);
+        const int row = p / (STEM_IN_COLS / 2), cc = (p % (STEM_IN_COLS / 2)) * 2;
+        const int ci = row / STEM_IN_ROWS, ir = ir0 + row % STEM_IN_ROWS, ic = ic0 + cc;
+        const float* src = xb + ((long)ci * H + min(max(ir, 0), H - 1)) * W;
+        const float a0 = src[min(max(ic, 0), W - 1)], a1 = src[min(max(ic + 1, 0), W - 1)];
+        const bool rok = ir >= 0 && ir < H;
+        v0[it] = (rok && ic >= 0 && ic < W) ? a0 : 0.f;
+        v1[it] = (rok && ic + 1 >= 0 && ic + 1 < W) ? a1 : 0.f;
+    }
+#pragma unroll
+    for (int it = 0; it < NIT; ++it) {
+        const int p = (int)threadIdx.x + 512 * it;
+        if (p < NP) {
+            const int row = p / (STEM_IN_COLS / 2), cc = (p % (STEM_IN_COLS / 2)) * 2;
+            *reinterpret_cast<uint32_t*>(img + row * STEM_PITCH + cc) = pack_bf16x2(v0[it], v1[it]);
+        }
+    }
+    // ---- weights: 24 fragments, lane's 16 bytes each, held for the rest of the kernel (requested after the staging values have left
+    // their registers -- together they would exceed the 128 VGPRs of two workgroups per CU -- and landing behind the barrier) ----
+    __builtin_amdgcn_sched_barrier(0);
     uint4 wa[4][6];
 #pragma unroll
     for (int i = 0; i < 4; ++i)
 #pragma unroll
         for (int ks = 0; ks < 6; ++ks) wa[i][ks] = *reinterpret_cast<const uint4*>(wfrag + ((i * 6 + ks) * 64 + lane) * 8);
-
-    // ---- stage 3 x 13 input rows x 520 columns as bf16 pairs (zero outside the image) -------------------------
-    const float* xb = x + (long)b * 3 * H * W;
-    for (int p = threadIdx.x; p < 3 * STEM_IN_ROWS * (STEM_IN_COLS / 2); p += 512) {
-        const int row = p / (STEM_IN_COLS / 2), cc = (p % (STEM_IN_COLS / 2)) * 2;
-        const int ci = row / STEM_IN_ROWS, ir = ir0 + row % STEM_IN_ROWS, ic = ic0 + cc;
-        float v0 = 0.f, v1 = 0.f;
-        if (ir >= 0 && ir < H) {
-            const float* src = xb + ((long)ci * H + ir) * W;
-            if (ic >= 0 && ic < W) v0 = src[ic];
-            if (ic + 1 >= 0 && ic + 1 < W) v1 = src[ic + 1];
-        }
-        *reinterpret_cast<uint32_t*>(img + row * STEM_PITCH + cc) = pack_bf16x2(v0, v1);
-    }
     __syncthreads();
 
     // per-lane LDS row of pair 4 ks + g at output-row offset 0 (pairs >= 21 have zero weights: any finite row will do)
