@@ -74,7 +74,6 @@ _SIGNATURES = {
     "dtlr_two_stage_gather": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p]),
     "dtlr_conv2d_nhwc": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
                                  c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p]),
-    "dtlr_dec_attn_tail": (c_int, [c_void_p] * 7 + [c_float, c_void_p, c_void_p, c_void_p, c_void_p, ctypes.c_long, c_int, c_void_p]),
     "dtlr_dq_pack_weights": (c_int, [c_void_p, c_void_p, c_int, c_int]),
     "dtlr_dec_query_stage": (c_int, [c_void_p] * 16 + [c_int, c_int, c_int, c_int, c_void_p]),
     "dtlr_decoder_query_prep": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p]),

@@ -25,6 +25,9 @@
 // before the weights were packed in fragment order and requested a stage ahead), without MFMAs, fetch, LDS reads and sine 28 us: the
 // remainder is the launch itself (~8 us for any 225-workgroup kernel here), the dependent chain of reference-box loads, barriers and
 // epilogues, and the 262 KB of output per workgroup (written as 16-byte pieces, 64 contiguous bytes per query: dq_store_pair).
+// (Round 3 also fused the NEXT pair of operators the same way -- out_proj + residual + LayerNorm followed by the cross-attention's
+// [offsets|logits] projection of (tgt + qpos), statistics exchanged between the waves through LDS: 40.7 us against 17.6 + 23.8 us for the
+// two launches, i.e. nothing gained; with the second GEMM as three single-tile passes 54.9 us.  Removed.)
 // Arithmetic identical to the unfused path (same MFMA, k ascending, same roundings: sine, H, qpos, tgt + qpos and the outputs are
 // rounded to the 16-bit format exactly where the separate kernels stored them), so the results are bit-identical to it.
 #include "dtlr_common.h"
@@ -115,20 +118,6 @@ __device__ __forceinline__ void dq_sine_quarter(unsigned char* dst, float c, con
         *reinterpret_cast<uint4*>(row + j * 4) = make_uint4(w[0], w[1], w[2], w[3]);
     }
 }
-
-// one output GEMM stage of a wave (2 row tiles x 8 query tiles, K = 256) from an LDS tile, + bias, 16-byte paired stores to global
-#define DQ_OUT_STAGE(WF, XT, OUT, LDO, CH0, BIAS)                                                  \
-{                                                                                              \
-        dq_f32x4_t acc[2][8];                                                                      \
-        dq_zero<2>(acc);                                                                           \
-        dq_gemm<256, 2>(acc, WF, XT, DQ_PITCH, lane);                                              \
-        const float4 bb0 = *reinterpret_cast<const float4*>((BIAS) + (CH0) + 4 * g);               \
-        const float4 bb1 = *reinterpret_cast<const float4*>((BIAS) + (CH0) + 16 + 4 * g);          \
-        _Pragma("unroll") for (int tt = 0; tt < 8; ++tt) {                                         \
-            const long q = q0 + 16 * tt + n;                                                       \
-            dq_store_pair((OUT) + min(q, Q - 1) * (LDO) + (CH0), acc[0][tt], acc[1][tt], bb0, bb1, g, q < Q); \
-        }                                                                                          \
-    }
 
 __global__ __launch_bounds__(512) void dec_query_stage_kernel(
     const float* __restrict__ ref, const float* __restrict__ vr, const float* __restrict__ dim_t, const uint16_t* __restrict__ tgt,
@@ -243,170 +232,25 @@ __global__ __launch_bounds__(512) void dec_query_stage_kernel(
 
     // ---- [q | k] = A Wqk^T + bqk (N = 512: the wave's 64 channels as two halves of two row tiles), then v = tgt Wv^T + bv; the next
     //      stage's weights are always in flight behind the current one -------------------------------------------------------------
+#define DQ_OUT_STAGE(WF, XT, OUT, LDO, CH0, BIAS)                                                  \
+    {                                                                                              \
+        dq_f32x4_t acc[2][8];                                                                      \
+        dq_zero<2>(acc);                                                                           \
+        dq_gemm<256, 2>(acc, WF, XT, DQ_PITCH, lane);                                              \
+        const float4 bb0 = *reinterpret_cast<const float4*>((BIAS) + (CH0) + 4 * g);               \
+        const float4 bb1 = *reinterpret_cast<const float4*>((BIAS) + (CH0) + 16 + 4 * g);          \
+        _Pragma("unroll") for (int tt = 0; tt < 8; ++tt) {                                         \
+            const long q = q0 + 16 * tt + n;                                                       \
+            dq_store_pair((OUT) + min(q, Q - 1) * (LDO) + (CH0), acc[0][tt], acc[1][tt], bb0, bb1, g, q < Q); \
+        }                                                                                          \
+    }
     uint4 wg[8][2];
     dq_fetch<256>(wg, Wqk, 2 * wave + 1, 8, 0, lane);
     DQ_OUT_STAGE(wf, r0, qk, 512, wave * 64, bqk)
     dq_fetch<256>(wf, Wv, wave, 8, 0, lane);
     DQ_OUT_STAGE(wg, r0, qk, 512, wave * 64 + 32, bqk)
     DQ_OUT_STAGE(wf, r1, v, 256, wave * 32, bv)
-}
-
-// ---- the tail of a decoder layer's self-attention and the head of its cross-attention in ONE launch ---------------------------------
-//     tgt1 = LayerNorm(tgt + a Wo^T + bo)                       self_attn.out_proj + dropout2 (identity) + norm2, deformable_transformer.py:904-909
-//     ow   = (tgt1 + qpos) Wow^T + bow                          sampling_offsets | attention_weights of cross_attn on the query
-//                                                               with_pos_embed(tgt, query_pos), ops/modules/ms_deform_attn.py:97-98
-// (was proj_ln 17.6 us + the [offsets|logits] GEMM with its A + A2 prologue 22.8 us per layer).  Same structure as the query stage: 128
-// queries per workgroup, the attention output `a` and then tgt1 + qpos as LDS tiles, wave w owns 32 channels of the projection; the
-// LayerNorm statistics (two-pass, fp32) are exchanged between the eight waves through LDS; the 384 output channels of the second GEMM
-// are 12 units of 32: wave w takes unit w, waves 0..3 also unit 8 + w.
-constexpr int DT_R0 = DQ_ROWS * DQ_PITCH;            // the `a` tile, later unused
-constexpr int DT_R1 = DQ_ROWS * DQ_PITCH;            // the tgt1 + qpos tile
-constexpr int DT_STAT = DT_R0 + DT_R1;               // [8 waves][128 queries] floats
-constexpr int DT_TOT = DT_STAT + 8 * DQ_ROWS * 4;   // [2][128 queries] floats: mean, rstd
-constexpr int DT_LDS = DT_TOT + 2 * DQ_ROWS * 4;
-
-__global__ __launch_bounds__(512) void dec_attn_tail_kernel(
-    const uint16_t* __restrict__ a, const uint16_t* __restrict__ tgt, const uint16_t* __restrict__ qpos,
-    const uint16_t* __restrict__ Wo, const float* __restrict__ bo, const float* __restrict__ gamma, const float* __restrict__ beta, float eps,
-    const uint16_t* __restrict__ Wow, const float* __restrict__ bow, uint16_t* __restrict__ tgt1, uint16_t* __restrict__ ow, long Q)
-{
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    unsigned char* r0 = smem;
-    unsigned char* r1 = smem + DT_R0;
-    float* stat = reinterpret_cast<float*>(smem + DT_STAT);
-    float* tot = reinterpret_cast<float*>(smem + DT_TOT);
-    const int tid = threadIdx.x, lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int n = lane & 15, g = lane >> 4;
-    const long q0 = (long)blockIdx.x * DQ_ROWS;
-
-    uint4 wf[8][2], wg[8][2];
-    dq_fetch<256>(wf, Wo, wave, 8, 0, lane);
-    // ---- the `a` tile: 128 rows x 512 B, 16-byte pieces, a row's 32 pieces read by 32 consecutive threads ---------------------------
-    {
-        uint4 piece[8];
-#pragma unroll
-        for (int i = 0; i < 8; ++i) {
-            const int idx = tid + 512 * i, row = idx >> 5, c16 = idx & 31;
-            piece[i] = *reinterpret_cast<const uint4*>(a + min(q0 + row, Q - 1) * 256 + c16 * 8);
-        }
-#pragma unroll
-        for (int i = 0; i < 8; ++i) {
-            const int idx = tid + 512 * i, row = idx >> 5, c16 = idx & 31;
-            *reinterpret_cast<uint4*>(r0 + row * DQ_PITCH + c16 * 16) = piece[i];
-        }
-    }
-    // residual and position rows of this lane's accumulator positions, requested ahead of the GEMM
-    uint2 tq[2][8], pq[2][8];
-#pragma unroll
-    for (int t = 0; t < 2; ++t)
-#pragma unroll
-        for (int tt = 0; tt < 8; ++tt)
-            tq[t][tt] = *reinterpret_cast<const uint2*>(tgt + min(q0 + 16 * tt + n, Q - 1) * 256 + wave * 32 + 16 * t + 4 * g);
-    __syncthreads();
-
-    dq_f32x4_t acc[2][8];
-    dq_zero<2>(acc);
-    dq_gemm<256, 2>(acc, wf, r0, DQ_PITCH, lane);
-    // ---- y = acc + bo + tgt ; LayerNorm over the 256 channels of a query: this wave holds 32 of them ------------------------------
-    float mean[8], rstd[8];
-    {
-        float4 b4[2];
-#pragma unroll
-        for (int t = 0; t < 2; ++t) b4[t] = *reinterpret_cast<const float4*>(bo + wave * 32 + 16 * t + 4 * g);
-        float psum[8];
-#pragma unroll
-        for (int tt = 0; tt < 8; ++tt) {
-            float s = 0.f;
-#pragma unroll
-            for (int t = 0; t < 2; ++t) {
-                dq_f32x4_t& c = acc[t][tt];
-                c[0] += b4[t].x + h16_lo(tq[t][tt].x); c[1] += b4[t].y + h16_hi(tq[t][tt].x);
-                c[2] += b4[t].z + h16_lo(tq[t][tt].y); c[3] += b4[t].w + h16_hi(tq[t][tt].y);
-                s += (c[0] + c[1]) + (c[2] + c[3]);
-            }
-            psum[tt] = s;
-        }
-        // the residual values and the first GEMM's weights are dead: their registers take the position rows and the second GEMM's weights,
-        // whose latency the two statistics exchanges below cover
-        __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-        for (int t = 0; t < 2; ++t)
-#pragma unroll
-            for (int tt = 0; tt < 8; ++tt)
-                pq[t][tt] = *reinterpret_cast<const uint2*>(qpos + min(q0 + 16 * tt + n, Q - 1) * 256 + wave * 32 + 16 * t + 4 * g);
-        dq_fetch<256>(wg, Wow, wave, 8, 0, lane);
-#pragma unroll
-        for (int tt = 0; tt < 8; ++tt) {
-            float s = psum[tt];
-            s += __shfl_xor(s, 16, 64);
-            s += __shfl_xor(s, 32, 64);
-            if (g == 0) stat[wave * DQ_ROWS + 16 * tt + n] = s;
-        }
-        __syncthreads();
-        if (tid < DQ_ROWS) {                                       // one thread per query adds the eight wave partials (64 reads per lane otherwise)
-            float s = 0.f;
-#pragma unroll
-            for (int w = 0; w < 8; ++w) s += stat[w * DQ_ROWS + tid];
-            tot[tid] = s * (1.f / 256.f);
-        }
-        __syncthreads();
-#pragma unroll
-        for (int tt = 0; tt < 8; ++tt) mean[tt] = tot[16 * tt + n];
-#pragma unroll
-        for (int tt = 0; tt < 8; ++tt) {
-            float s = 0.f;
-#pragma unroll
-            for (int t = 0; t < 2; ++t)
-#pragma unroll
-                for (int r = 0; r < 4; ++r) { const float d = acc[t][tt][r] - mean[tt]; s += d * d; }
-            s += __shfl_xor(s, 16, 64);
-            s += __shfl_xor(s, 32, 64);
-            if (g == 0) stat[wave * DQ_ROWS + 16 * tt + n] = s;
-        }
-        __syncthreads();
-        if (tid < DQ_ROWS) {
-            float s = 0.f;
-#pragma unroll
-            for (int w = 0; w < 8; ++w) s += stat[w * DQ_ROWS + tid];
-            tot[DQ_ROWS + tid] = rsqrtf(s * (1.f / 256.f) + eps);
-        }
-        __syncthreads();
-#pragma unroll
-        for (int tt = 0; tt < 8; ++tt) rstd[tt] = tot[DQ_ROWS + 16 * tt + n];
-    }
-    // ---- tgt1 -> global (16-byte paired pieces) ; tgt1 + qpos -> region 1 -----------------------------------------------------------
-    {
-        float4 g4[2], e4[2];
-#pragma unroll
-        for (int t = 0; t < 2; ++t) {
-            g4[t] = *reinterpret_cast<const float4*>(gamma + wave * 32 + 16 * t + 4 * g);
-            e4[t] = *reinterpret_cast<const float4*>(beta + wave * 32 + 16 * t + 4 * g);
-        }
-        const float4 z4 = make_float4(0.f, 0.f, 0.f, 0.f);
-#pragma unroll
-        for (int tt = 0; tt < 8; ++tt) {
-            const long q = q0 + 16 * tt + n;
-            dq_f32x4_t y[2];
-#pragma unroll
-            for (int t = 0; t < 2; ++t) {
-                y[t][0] = (acc[t][tt][0] - mean[tt]) * rstd[tt] * g4[t].x + e4[t].x;
-                y[t][1] = (acc[t][tt][1] - mean[tt]) * rstd[tt] * g4[t].y + e4[t].y;
-                y[t][2] = (acc[t][tt][2] - mean[tt]) * rstd[tt] * g4[t].z + e4[t].z;
-                y[t][3] = (acc[t][tt][3] - mean[tt]) * rstd[tt] * g4[t].w + e4[t].w;
-                const uint2 yw = make_uint2(pack_bf16x2(y[t][0], y[t][1]), pack_bf16x2(y[t][2], y[t][3]));
-                const uint2 aw = make_uint2(pack_bf16x2(h16_lo(yw.x) + h16_lo(pq[t][tt].x), h16_hi(yw.x) + h16_hi(pq[t][tt].x)),
-                                            pack_bf16x2(h16_lo(yw.y) + h16_lo(pq[t][tt].y), h16_hi(yw.y) + h16_hi(pq[t][tt].y)));
-                *reinterpret_cast<uint2*>(r1 + (16 * tt + n) * DQ_PITCH + (wave * 32 + 16 * t + 4 * g) * 2) = aw;
-            }
-            dq_store_pair(tgt1 + min(q, Q - 1) * 256 + wave * 32, y[0], y[1], z4, z4, g, q < Q);
-        }
-    }
-    __syncthreads();
-    // ---- ow = (tgt1 + qpos) Wow^T + bow: unit `wave`, then unit 8 + wave on waves 0..3 ---------------------------------------------
-    if (wave < 4) dq_fetch<256>(wf, Wow, 8 + wave, 8, 0, lane);            // second unit of waves 0..3, in flight behind the first
-    DQ_OUT_STAGE(wg, r1, ow, 384, wave * 32, bow)
-    if (wave < 4) { DQ_OUT_STAGE(wf, r1, ow, 384, 256 + wave * 32, bow) }
+#undef DQ_OUT_STAGE
 }
 
 }  // namespace dtlr
@@ -448,23 +292,5 @@ extern "C" int dtlr_dec_query_stage(const float* ref, const float* valid_ratios,
     hipLaunchKernelGGL(dec_query_stage_kernel, dim3((unsigned)grid), dim3(512), DQ_LDS, (hipStream_t)stream,
                        ref, valid_ratios, dim_t, (const uint16_t*)tgt, (const uint16_t*)W0, b0, (const uint16_t*)W1, b1,
                        (const uint16_t*)Wqk, bqk, (const uint16_t*)Wv, bv, ref_in, (uint16_t*)qpos, (uint16_t*)qk, (uint16_t*)v, Q, nq, L);
-    return check_launch();
-}
-
-extern "C" int dtlr_dec_attn_tail(const void* a, const void* tgt, const void* qpos, const void* Wo, const float* bo,
-                                  const float* gamma, const float* beta, float eps, const void* Wow, const float* bow,
-                                  void* tgt1, void* ow, long Q, int dtype, void* stream)
-{
-    clear_stale_error();
-    if (!a || !tgt || !qpos || !Wo || !bo || !gamma || !beta || !Wow || !bow || !tgt1 || !ow) return DTLR_EINVAL;
-    if (Q <= 0) return DTLR_EINVAL;
-    if (dtype != DTLR_H16) return DTLR_EDTYPE;
-    const long grid = (Q + DQ_ROWS - 1) / DQ_ROWS;
-    if (grid > 0x7fffffffL) return DTLR_ESHAPE;
-    static DevOnce attr;
-    if (attr.first()) { (void)hipFuncSetAttribute((const void*)dec_attn_tail_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, DT_LDS); (void)hipGetLastError(); }
-    hipLaunchKernelGGL(dec_attn_tail_kernel, dim3((unsigned)grid), dim3(512), DT_LDS, (hipStream_t)stream,
-                       (const uint16_t*)a, (const uint16_t*)tgt, (const uint16_t*)qpos, (const uint16_t*)Wo, bo, gamma, beta, eps,
-                       (const uint16_t*)Wow, bow, (uint16_t*)tgt1, (uint16_t*)ow, Q);
     return check_launch();
 }

@@ -429,7 +429,7 @@ class DTLREngine:
         finally:
             self._msda_calibrating = None
 
-    def _msda_module(self, name, query, query_pos, ref, value_src, g, n_points, value=None, ow_res=None, ow=None):
+    def _msda_module(self, name, query, query_pos, ref, value_src, g, n_points, value=None, ow_res=None):
         """MSDeformAttn.forward (ops/modules/ms_deform_attn.py:78-126) without the output
         projection (done by the caller, followed by the fused residual + LayerNorm).
         query + query_pos is formed in the GEMM prologue; the padding fill of `value` is its epilogue."""
@@ -446,9 +446,7 @@ class DTLREngine:
                 value = self._lin(name + ".value", value_src, row_mask=g["mask_flat"] if g["has_padding"] else None)
         # the [offsets|logits] row stays in the activation dtype: in the bf16 engine its 2^-8 relative rounding
         # moves a sampling point by < 0.02 px, far below the bf16 noise of the sampled values themselves
-        if ow is not None:
-            pass                                                  # the [offsets|logits] row came with the previous operator (ops.dec_attn_tail)
-        elif k256 and ow_res is not None:
+        if k256 and ow_res is not None:
             # unpadded batch: (src + pos) W^T + b = src W^T + (pos W^T + b), and the second term is ONE [S, 384] matrix for every
             # image (L2-resident): the projection streams src alone and adds the row-broadcast term in its epilogue
             rows = ow_res.numel() // 384
@@ -611,18 +609,9 @@ class DTLREngine:
                 qk = self._lin(q + "sa.qk", tgt, a2=qpos)
                 v = self._lin(q + "sa.v", tgt)
             a = ops.mha(qk, v, cfg.nheads)
-            ow = None
-            if self.use_dec_query_stage and tgt.dtype in ops.H16 and C == 256 and w[q + "attn.ow.w"].shape == (384, 256):
-                for nm in (q + "sa.out", q + "attn.ow"):
-                    if nm + ".dq" not in w:
-                        w[nm + ".dq"] = ops.dq_pack(w[nm + ".w"])
-                # out_proj + residual + norm2 and the cross-attention's [offsets|logits] projection of (tgt + query_pos): one launch
-                tgt, ow = ops.dec_attn_tail(a, tgt, qpos, w[q + "sa.out.dq"], w[q + "sa.out.b"], w[q + "norm2.w"], w[q + "norm2.b"],
-                                            w[q + "attn.ow.dq"], w[q + "attn.ow.b"])
-            else:
-                tgt = self._proj_ln(q + "sa.out", q + "norm2", a, tgt)
+            tgt = self._proj_ln(q + "sa.out", q + "norm2", a, tgt)
             # deformable cross attention
-            a = self._msda_module(q + "attn", tgt, qpos, ref_in, memory, g, cfg.dec_n_points, value=vall[..., n * C:(n + 1) * C], ow=ow)
+            a = self._msda_module(q + "attn", tgt, qpos, ref_in, memory, g, cfg.dec_n_points, value=vall[..., n * C:(n + 1) * C])
             tgt = self._proj_ln(q + "attn.out", q + "norm1", a, tgt)
             # ffn
             tgt = self._ffn(q, "norm3", tgt)

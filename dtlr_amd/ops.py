@@ -826,24 +826,6 @@ def dec_query_stage(ref, valid_ratios, tgt, w0, b0, w1, b1, wqk, bqk, wv, bv):
     return ref_in, qpos, qk, v
 
 
-def dec_attn_tail(a, tgt, qpos, wo_p, bo, ln_w, ln_b, wow_p, bow, eps: float = 1e-5):
-    """LayerNorm(tgt + a Wo^T + bo) and the [offsets|logits] projection of (that + qpos) in ONE launch (dtlr_dec_attn_tail, 16-bit
-    engines): a, tgt, qpos [..., 256]; wo_p = dq_pack(out_proj.weight), wow_p = dq_pack([sampling_offsets; attention_weights].weight
-    [384, 256]); biases / LN parameters fp32 -> (tgt1 [..., 256], ow [..., 384])."""
-    require_cuda(a, "a")
-    assert a.dtype in H16 and tgt.dtype == a.dtype and qpos.dtype == a.dtype and a.shape[-1] == 256 and a.shape == tgt.shape == qpos.shape
-    assert wo_p.numel() == 65536 and wow_p.numel() == 384 * 256 and wo_p.dtype == a.dtype and wow_p.dtype == a.dtype and bow.numel() == 384
-    a, tgt, qpos = a.contiguous(), tgt.contiguous(), qpos.contiguous()
-    Q = a.numel() // 256
-    t1 = torch.empty_like(tgt)
-    ow = torch.empty(a.shape[:-1] + (384,), dtype=a.dtype, device=a.device)
-    with _Timed("gemm_bf16", 2.0 * Q * 256 * (256 + 384), float(Q) * (256 * 4 + 384) * 2 + 640 * 256 * 2.0, f"dec_attn_tail M{Q}"):
-        code = _L(a).dtlr_dec_attn_tail(a.data_ptr(), tgt.data_ptr(), qpos.data_ptr(), wo_p.data_ptr(), bo.data_ptr(), ln_w.data_ptr(), ln_b.data_ptr(),
-                                        float(eps), wow_p.data_ptr(), bow.data_ptr(), t1.data_ptr(), ow.data_ptr(), Q, _DT[a.dtype], _lib.current_stream())
-    _lib.check(code, "dtlr_dec_attn_tail")
-    return t1, ow
-
-
 def box_mlp_refine(x, w1, b1, w2p, b2, w3, b3, ref, mode: int = 0):
     """3-layer box MLP + refinement in ONE launch (dtlr_box_mlp_refine_bf16): x [..,256] bf16, W1 [256,256] bf16,
     w2p = ffn_pack_w2(W2) bf16, W3 [4,256] / biases fp32, ref [..,4] fp32 -> [..,4] fp32.

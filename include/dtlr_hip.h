@@ -287,14 +287,6 @@ int dtlr_conv3x3_patch_bf16(const void *X, const void *Wt, const float *bias, vo
  * W0 [256,512] b0, W1 [256,256] b1 (ref_point_head), Wqk [512,256] bqk, Wv [256,256] bv (in_proj split); weights 16-bit, biases fp32.
  * The four weights are handed over in the kernel's fragment order (dtlr_dq_pack_weights, once per model).
  * Outputs: ref_in [B*nq,L,4] fp32, qpos [B*nq,256], qk [B*nq,512], v [B*nq,256] (16-bit).  dtype = the library's 16-bit code. */
-/* The tail of a decoder layer's self-attention + the head of its cross-attention in one launch (16-bit engines):
- *   tgt1 = LayerNorm(tgt + a Wo^T + bo)          self_attn.out_proj + norm2 (models/dino/deformable_transformer.py:904-909)
- *   ow   = (tgt1 + qpos) Wow^T + bow             sampling_offsets | attention_weights on with_pos_embed(tgt, query_pos)
- *                                                 (ops/modules/ms_deform_attn.py:97-98; Wow = the two weights stacked, [384,256])
- * a, tgt, qpos [Q,256]; Wo / Wow in dtlr_dq_pack_weights order; bo [256], gamma / beta [256], bow [384] fp32 -> tgt1 [Q,256], ow [Q,384]. */
-int dtlr_dec_attn_tail(const void *a, const void *tgt, const void *qpos, const void *Wo, const float *bo,
-                       const float *gamma, const float *beta, float eps, const void *Wow, const float *bow,
-                       void *tgt1, void *ow, long Q, int dtype, void *stream);
 int dtlr_dq_pack_weights(const unsigned short *w_host, unsigned short *out_host, int N, int K);   /* [N,K] row-major -> fragment order (host) */
 int dtlr_dec_query_stage(const float *ref, const float *valid_ratios, const float *dim_t, const void *tgt,
                          const void *W0, const float *b0, const void *W1, const float *b1,
