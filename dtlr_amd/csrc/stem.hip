@@ -132,6 +132,167 @@ __global__ __launch_bounds__(512, 2) void stem_conv7x7_kernel(const float* __res
 }
 
 
+// ---- stem convolution + folded-BN shift + ReLU + 3x3 / stride-2 max-pool in ONE kernel (round 3) ------------------------------------------
+// torchvision resnet50: conv1 -> bn1 -> relu -> maxpool (models/dino/backbone.py:97-106).  As two kernels the 64-channel full-resolution
+// map (268 MB for 32 lines of 128 x 2048) is written by the convolution and read back by the pooling pass; here it never leaves the CU:
+// a workgroup produces 2 pooled rows x 120 pooled columns from the 5 x 244 convolution outputs under them.
+//   * the convolution is the kernel above (same staging, same MFMA formulation, same roundings: the conv output is rounded to the 16-bit
+//     format exactly where the separate kernel stored it), as (conv row, 64-column strip) wave units; strips start every 60 conv columns
+//     (a multiple of 4, so the window reads stay 16-byte aligned) and own 30 pooled columns each;
+//   * horizontal max in registers: a lane holds 4 consecutive conv columns j = 4 n .. 4 n + 3 of its strip, pooled column k covers
+//     j = 2 k .. 2 k + 2: k = 2 n is in-lane, k = 2 n + 1 takes j = 4 n + 4 from lane n + 1 (one DPP row shift per accumulator);
+//     conv columns / rows outside the map count as -inf, like the pooling's padding;
+//   * the row-pooled strips (5 x 120 x 64 channels, 86 KB with the bank padding) go to LDS; after one barrier every thread takes the vertical max of three
+//     rows for its 8 channels, adds the folded-BN shift, applies the ReLU (max first, then + bias and ReLU: exact, see maxpool3x3s2_kernel)
+//     and stores 16 bytes.
+constexpr int SP_PROWS = 2, SP_STRIPS = 4, SP_SCOLS = 30;   // pooled rows per workgroup, strips, pooled columns per strip
+constexpr int SP_PCOLS = SP_STRIPS * SP_SCOLS;              // 120 pooled columns per workgroup
+constexpr int SP_CROWS = 2 * SP_PROWS + 1;                  // 5 conv rows
+constexpr int SP_IN_ROWS = 2 * SP_CROWS + 5;                // 15 input rows per channel
+constexpr int SP_IMG = 3 * SP_IN_ROWS * STEM_PITCH * 2;     // 57600 B staged input
+constexpr int SP_CP = 144;                                  // bytes per pooled column in LDS: 128 + 16, so that the 8-byte stores of a wave
+                                                            // (address 2 n SP_CP + 8 g) cover all banks: with 128 the 16 lanes of a group collide
+constexpr int SP_HB = SP_CROWS * SP_PCOLS * SP_CP;          // 86400 B row-pooled conv outputs
+constexpr int SP_LDS = SP_IMG + SP_HB;
+
+template <int CTRL> __device__ __forceinline__ float sp_dpp(float v) {
+    return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, 0xf, 0xf, false));
+}
+
+__global__ __launch_bounds__(512, 2) void stem_pool_kernel(const float* __restrict__ x, const uint16_t* __restrict__ wfrag,
+                                                           const float* __restrict__ bias, uint16_t* __restrict__ y,
+                                                           int H, int W, int Ho, int Wo, int Hp, int Wp)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_stem[];
+    uint16_t* img = reinterpret_cast<uint16_t*>(smem_stem);
+    unsigned char* hb = smem_stem + SP_IMG;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int n = lane & 15, g = lane >> 4;
+    const int pwb = blockIdx.x * SP_PCOLS, ph0 = blockIdx.y * SP_PROWS, b = blockIdx.z;
+    const int cbW = 2 * pwb - 1, cr0 = 2 * ph0 - 1;             // first conv column / row of the workgroup (may be -1)
+    const int ir0 = 2 * cr0 - 3, ic0 = 2 * cbW - 3;
+
+    const float* xb = x + (long)b * 3 * H * W;
+    constexpr int NP = 3 * SP_IN_ROWS * (STEM_IN_COLS / 2);
+    constexpr int NIT = (NP + 511) / 512;
+    float v0[NIT], v1[NIT];
+#pragma unroll
+    for (int it = 0; it < NIT; ++it) {
+        const int p = min((int)threadIdx.x + 512 * it, NP - 1);
+        const int row = p / (STEM_IN_COLS / 2), cc = (p % (STEM_IN_COLS / 2)) * 2;
+        const int ci = row / SP_IN_ROWS, ir = ir0 + row % SP_IN_ROWS, ic = ic0 + cc;
+        const float* src = xb + ((long)ci * H + min(max(ir, 0), H - 1)) * W;
+        const float a0 = src[min(max(ic, 0), W - 1)], a1 = src[min(max(ic + 1, 0), W - 1)];
+        const bool rok = ir >= 0 && ir < H;
+        v0[it] = (rok && ic >= 0 && ic < W) ? a0 : 0.f;
+        v1[it] = (rok && ic + 1 >= 0 && ic + 1 < W) ? a1 : 0.f;
+    }
+#pragma unroll
+    for (int it = 0; it < NIT; ++it) {
+        const int p = (int)threadIdx.x + 512 * it;
+        if (p < NP) {
+            const int row = p / (STEM_IN_COLS / 2), cc = (p % (STEM_IN_COLS / 2)) * 2;
+            *reinterpret_cast<uint32_t*>(img + row * STEM_PITCH + cc) = pack_bf16x2(v0[it], v1[it]);
+        }
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    uint4 wa[4][6];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int ks = 0; ks < 6; ++ks) wa[i][ks] = *reinterpret_cast<const uint4*>(wfrag + ((i * 6 + ks) * 64 + lane) * 8);
+    __syncthreads();
+
+    int rowoff[6];
+#pragma unroll
+    for (int ks = 0; ks < 6; ++ks) {
+        const int pair = min(4 * ks + g, 20);
+        rowoff[ks] = ((pair / 7) * SP_IN_ROWS + pair % 7) * STEM_PITCH;
+    }
+    const uint32_t ninf2 = pack_bf16x2(-INFINITY, -INFINITY);
+    for (int u = wave; u < SP_CROWS * SP_STRIPS; u += 8) {
+        const int ro = u >> 2, s = u & 3;                         // conv row ro of the workgroup, strip s
+        const int cr = cr0 + ro;
+        unsigned char* hrow = hb + (ro * SP_PCOLS + SP_SCOLS * s) * SP_CP + (4 * g) * 2;
+        if (cr < 0 || cr >= Ho) {                                 // wave-uniform: a padding row of the pooling
+            if (n < 15) {
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    *reinterpret_cast<uint2*>(hrow + (2 * n) * SP_CP + i * 32) = make_uint2(ninf2, ninf2);
+                    *reinterpret_cast<uint2*>(hrow + (2 * n + 1) * SP_CP + i * 32) = make_uint2(ninf2, ninf2);
+                }
+            }
+            continue;
+        }
+        stem_f32x4_t acc[4][4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int t = 0; t < 4; ++t) acc[i][t] = stem_f32x4_t{0.f, 0.f, 0.f, 0.f};
+        const uint16_t* base = img + 2 * ro * STEM_PITCH + (60 * s + 4 * n) * 2;
+#pragma unroll
+        for (int ks = 0; ks < 6; ++ks) {
+            const uint4 p0 = *reinterpret_cast<const uint4*>(base + rowoff[ks]);
+            const uint4 p1 = *reinterpret_cast<const uint4*>(base + rowoff[ks] + 8);
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                acc[i][0] = stem_mma(wa[i][ks], p0.x, p0.y, p0.z, p0.w, acc[i][0]);
+                acc[i][1] = stem_mma(wa[i][ks], p0.y, p0.z, p0.w, p1.x, acc[i][1]);
+                acc[i][2] = stem_mma(wa[i][ks], p0.z, p0.w, p1.x, p1.y, acc[i][2]);
+                acc[i][3] = stem_mma(wa[i][ks], p0.w, p1.x, p1.y, p1.z, acc[i][3]);
+            }
+        }
+        // conv columns of this lane: c = cbW + 60 s + 4 n + t; outside [0, Wo) they are the pooling's padding
+        const int c0 = cbW + 60 * s + 4 * n;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            float e[4][4];                                        // [t][r]: rounded to the 16-bit format like the stored conv output
+#pragma unroll
+            for (int t = 0; t < 4; ++t) {
+                const bool ok = (unsigned)(c0 + t) < (unsigned)Wo;
+                const uint32_t lo = pack_bf16x2(acc[i][t][0], acc[i][t][1]), hi = pack_bf16x2(acc[i][t][2], acc[i][t][3]);
+                e[t][0] = ok ? h16_lo(lo) : -INFINITY; e[t][1] = ok ? h16_hi(lo) : -INFINITY;
+                e[t][2] = ok ? h16_lo(hi) : -INFINITY; e[t][3] = ok ? h16_hi(hi) : -INFINITY;
+            }
+            float m0[4], m1[4];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const float nx = sp_dpp<0x101>(e[0][r]);          // row_shl:1 -- lane n receives lane n + 1's first column
+                m0[r] = fmaxf(fmaxf(e[0][r], e[1][r]), e[2][r]);
+                m1[r] = fmaxf(fmaxf(e[2][r], e[3][r]), nx);
+            }
+            if (n < 15) {
+                *reinterpret_cast<uint2*>(hrow + (2 * n) * SP_CP + i * 32) = make_uint2(pack_bf16x2(m0[0], m0[1]), pack_bf16x2(m0[2], m0[3]));
+                *reinterpret_cast<uint2*>(hrow + (2 * n + 1) * SP_CP + i * 32) = make_uint2(pack_bf16x2(m1[0], m1[1]), pack_bf16x2(m1[2], m1[3]));
+            }
+        }
+    }
+    __syncthreads();
+    // ---- vertical max of three row-pooled rows, + folded-BN shift, ReLU, 16-byte stores ------------------------------------------------
+    for (int idx = threadIdx.x; idx < SP_PROWS * SP_PCOLS * 8; idx += 512) {
+        const int c8 = idx & 7, col = (idx >> 3) % SP_PCOLS, pr = idx / (8 * SP_PCOLS);
+        const int ph = ph0 + pr, pw = pwb + col;
+        if (ph >= Hp || pw >= Wp) continue;
+        float m[8];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) m[k] = -INFINITY;
+#pragma unroll
+        for (int dr = 0; dr < 3; ++dr) {
+            const uint4 t = *reinterpret_cast<const uint4*>(hb + ((2 * pr + dr) * SP_PCOLS + col) * SP_CP + c8 * 16);
+            const uint32_t w4[4] = {t.x, t.y, t.z, t.w};
+#pragma unroll
+            for (int k = 0; k < 4; ++k) { m[2 * k] = fmaxf(m[2 * k], h16_lo(w4[k])); m[2 * k + 1] = fmaxf(m[2 * k + 1], h16_hi(w4[k])); }
+        }
+        const float4 b0 = *reinterpret_cast<const float4*>(bias + c8 * 8), b1 = *reinterpret_cast<const float4*>(bias + c8 * 8 + 4);
+        const float bb[8] = {b0.x, b0.y, b0.z, b0.w, b1.x, b1.y, b1.z, b1.w};
+#pragma unroll
+        for (int k = 0; k < 8; ++k) m[k] = fmaxf(m[k] + bb[k], 0.f);
+        *reinterpret_cast<uint4*>(y + (((long)b * Hp + ph) * Wp + pw) * 64 + c8 * 8) =
+            make_uint4(pack_bf16x2(m[0], m[1]), pack_bf16x2(m[2], m[3]), pack_bf16x2(m[4], m[5]), pack_bf16x2(m[6], m[7]));
+    }
+}
+
+
 // ---- exact-fp32 stem (the parity engine).  Direct convolution on the vector ALUs: 2 * 147 * 64 flop per output pixel is
 // 39 GFLOP for 32 lines of 128 x 2048 -- a millisecond at the fp32 vector rate; the fp32 MFMA (16x16x4) would need the taps
 // as 4-wide k-steps of one (ci, kh) row, i.e. the same LDS staging for a kernel only the fp32 parity path runs.
@@ -229,6 +390,23 @@ extern "C" int dtlr_stem_pack_weights(const float* w_oihw_host, unsigned short* 
                 }
             }
     return DTLR_OK;
+}
+
+extern "C" int dtlr_stem_conv7x7_pool(const float* x, const void* wfrag, const float* bias, void* y, int B, int H, int W, int out_dtype, void* stream)
+{
+    clear_stale_error();
+    if (!x || !wfrag || !bias || !y) return DTLR_EINVAL;
+    if (B <= 0 || H <= 0 || W <= 0) return DTLR_EINVAL;
+    if (out_dtype != DTLR_H16) return DTLR_EDTYPE;
+    const int Ho = (H + 6 - 7) / 2 + 1, Wo = (W + 6 - 7) / 2 + 1;
+    const int Hp = (Ho + 2 - 3) / 2 + 1, Wp = (Wo + 2 - 3) / 2 + 1;
+    static DevOnce attr;
+    if (attr.first()) { (void)hipFuncSetAttribute((const void*)stem_pool_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, SP_LDS); (void)hipGetLastError(); }
+    const dim3 grid((Wp + SP_PCOLS - 1) / SP_PCOLS, (Hp + SP_PROWS - 1) / SP_PROWS, B);
+    if (grid.y > 65535u || grid.z > 65535u) return DTLR_ESHAPE;
+    hipLaunchKernelGGL(stem_pool_kernel, grid, dim3(512), SP_LDS, (hipStream_t)stream,
+                       x, (const uint16_t*)wfrag, bias, (uint16_t*)y, H, W, Ho, Wo, Hp, Wp);
+    return check_launch();
 }
 
 extern "C" int dtlr_stem_conv7x7(const float* x, const void* wfrag, void* y, int B, int H, int W, int out_dtype, void* stream)

@@ -63,6 +63,7 @@ class DTLREngine:
         self._msda_state = {}      # (layer, canvas shape) -> {"mode", "far"}; keyed by nothing that depends on the data or the call history
         self._msda_calibrating = None
         self.use_k256_small = True   # ... and for the encoder's output projection + LayerNorm
+        self.use_stem_pool = True         # 16-bit: stem convolution + FrozenBN shift + ReLU + max-pool in one kernel
         self.use_dec_query_stage = True   # 16-bit: a decoder layer's query stage (sine, ref_point_head, q | k, v) in one launch
 
     # ------------------------------------------------------------------------------ packing
@@ -342,11 +343,14 @@ class DTLREngine:
         (models/dino/backbone.py:97-106,118-120)."""
         # stem: own kernels for both engines, reading the NCHW fp32 image directly (bf16: MFMA; fp32: exact direct convolution);
         # the folded-BN shift, the ReLU and the max-pool run as ONE pass over the full-resolution map
-        if "conv1.frag" in self.w:
-            x = ops.stem_conv7x7(x_nchw, self.w["conv1.frag"], self.dtype)
+        if "conv1.frag" in self.w and self.use_stem_pool:      # 16-bit engines: convolution + shift + ReLU + max-pool in one kernel
+            x = ops.stem_conv7x7_pool(x_nchw, self.w["conv1.frag"], self.w["conv1.b"], self.dtype)
         else:
-            x = ops.stem_conv7x7_f32(x_nchw, self.w["conv1.wk"])
-        x = ops.maxpool_nhwc(x, bias=self.w["conv1.b"], relu=True)
+            if "conv1.frag" in self.w:
+                x = ops.stem_conv7x7(x_nchw, self.w["conv1.frag"], self.dtype)
+            else:
+                x = ops.stem_conv7x7_f32(x_nchw, self.w["conv1.wk"])
+            x = ops.maxpool_nhwc(x, bias=self.w["conv1.b"], relu=True)
         outs = []
         for li, nblocks in enumerate(self.cfg.backbone_blocks, start=1):
             for bi in range(nblocks):

@@ -532,6 +532,20 @@ def stem_conv7x7(x_nchw, wfrag, out_dtype=torch.bfloat16):
     return y
 
 
+def stem_conv7x7_pool(x_nchw, wfrag, bias, out_dtype=torch.bfloat16):
+    """conv1 (7x7/s2/p3, folded-BN scale in the weights) + shift + ReLU + 3x3/s2/p1 max-pool in ONE kernel (dtlr_stem_conv7x7_pool, 16-bit
+    engines): x [B,3,H,W] fp32 NCHW -> [B,Hp,Wp,64] NHWC.  The full-resolution 64-channel map never reaches HBM."""
+    require_cuda(x_nchw, "images")
+    assert x_nchw.dtype == torch.float32 and x_nchw.dim() == 4 and x_nchw.shape[1] == 3 and bias.dtype == torch.float32 and bias.numel() == 64
+    x = x_nchw if x_nchw.is_contiguous() else x_nchw.contiguous()
+    B, _, H, W = x.shape
+    Ho, Wo = (H - 1) // 2 + 1, (W - 1) // 2 + 1
+    y = torch.empty((B, (Ho - 1) // 2 + 1, (Wo - 1) // 2 + 1, 64), dtype=out_dtype, device=x.device)
+    code = _L(out_dtype).dtlr_stem_conv7x7_pool(x.data_ptr(), wfrag.data_ptr(), bias.data_ptr(), y.data_ptr(), B, H, W, _DT[out_dtype], _lib.current_stream())
+    _lib.check(code, "dtlr_stem_conv7x7_pool")
+    return y
+
+
 def maxpool_nhwc(x, k: int = 3, stride: int = 2, padding: int = 1, bias=None, relu: bool = False):
     """3x3/s2/p1 max pooling on NHWC (HIP kernel); with bias/relu: maxpool(relu(x + bias)) in the same pass."""
     assert (k, stride, padding) == (3, 2, 1)

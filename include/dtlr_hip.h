@@ -407,6 +407,10 @@ int dtlr_geometry(const unsigned char *mask, int B, int H, int W, const int *lev
  *          both of its pointers are host memory; w_oihw = conv1.weight * bn_scale, [64,3,7,7] fp32). */
 int dtlr_stem_pack_weights(const float *w_oihw_host, unsigned short *wfrag_host /* [4*6*64*8] */);
 int dtlr_stem_conv7x7(const float *x, const void *wfrag, void *y, int B, int H, int W, int out_dtype, void *stream);
+/* conv1 + bn1 (folded: weights carry the scale, `bias` [64] fp32 the shift) + ReLU + 3x3 / stride-2 / pad-1 max-pool in one kernel
+ * (torchvision resnet50 stem as run by models/dino/backbone.py:97-106): x [B,3,H,W] fp32 NCHW -> y [B,Hp,Wp,64] 16-bit NHWC with
+ * Hp = floor((Ho - 1) / 2) + 1, Ho = floor((H - 1) / 2) + 1 (same for W).  Bit-identical to dtlr_stem_conv7x7 + dtlr_maxpool3x3s2_nhwc. */
+int dtlr_stem_conv7x7_pool(const float *x, const void *wfrag, const float *bias, void *y, int B, int H, int W, int out_dtype, void *stream);
 /* The same convolution in exact fp32 (the parity engine; direct convolution on the vector ALUs, patch + weights in LDS).
  *   wk: device [147][64] fp32, k-major image of conv1.weight * bn_scale (k = (ci*7 + kh)*7 + kw) ; y [B,Ho,Wo,64] fp32 NHWC. */
 int dtlr_stem_conv7x7_f32(const float *x, const float *wk, float *y, int B, int H, int W, void *stream);

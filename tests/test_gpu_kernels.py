@@ -1126,3 +1126,19 @@ def test_dec_query_stage_equals_the_unfused_path(B, nq, half):
     q64 = torch.relu(s64 @ w0.double().cpu().t() + b0.double().cpu()) @ w1.double().cpu().t() + b1.double().cpu()
     k64 = (tgt.double().cpu() + q64) @ wqk.double().cpu().t() + bqk.double().cpu()
     assert (qpos.double().cpu() - q64).abs().max() < 0.05 and (qk.double().cpu() - k64).abs().max() < 0.1
+
+
+@pytest.mark.parametrize("B,H,W", [(2, 128, 2048), (1, 37, 531), (3, 8, 16), (1, 128, 2560), (2, 83, 1328), (1, 130, 1000)])
+def test_stem_conv_pool_fused_equals_the_two_kernels(B, H, W, half):
+    """dtlr_stem_conv7x7_pool (conv1 + FrozenBN shift + ReLU + max-pool in one kernel) == dtlr_stem_conv7x7 followed by the pooling
+    pass, BIT FOR BIT (same roundings at the same places), on sizes that exercise every edge: odd conv / pooled sizes, maps narrower
+    than one strip, the last partial workgroup in both directions."""
+    from dtlr_amd import ops
+    x = _rand((B, 3, H, W), 1).cuda()
+    w = _rand((64, 3, 7, 7), 2) / 12
+    bias = (_rand((64,), 3) * 0.3).cuda()
+    frag = ops.stem_pack_weights(w, half).cuda()
+    want = ops.maxpool_nhwc(ops.stem_conv7x7(x, frag, half), bias=bias, relu=True)
+    got = ops.stem_conv7x7_pool(x, frag, bias, half)
+    assert got.shape == want.shape
+    assert torch.equal(got, want), (got.float() - want.float()).abs().max().item()
