@@ -81,7 +81,9 @@ template <> __device__ __forceinline__ uint4 stage_convert<uint16_t>(const uint4
     uint32_t o[4];
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
-        const f2_t f = {h16_lo(w[j]), h16_hi(w[j])};
+        // saturate at fp16's largest finite value: a bf16 value beyond it (never seen: the sampled tensor is value_proj of a
+        // LayerNorm output) must not turn into inf and poison a whole window through 0 * inf
+        const f2_t f = {fminf(fmaxf(h16_lo(w[j]), -65504.f), 65504.f), fminf(fmaxf(h16_hi(w[j]), -65504.f), 65504.f)};
         o[j] = __builtin_bit_cast(uint32_t, __builtin_convertvector(f, h2_t));
     }
     return make_uint4(o[0], o[1], o[2], o[3]);

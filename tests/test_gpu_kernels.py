@@ -216,6 +216,18 @@ def test_msda_encoder_lds_vs_oracle(level_hw, offscale, half):
         # the 16-bit query phase accumulates each level's 16 corner terms in packed fp16 (~2^-11 per term) whatever the storage format:
         # bf16 results are dominated by their own output rounding (2^-9), fp16 results by that accumulation (a few 2^-11)
         assert (gotb - wantb).abs().max() <= wantb.abs().max() * (ulp(half, 8) if half == torch.bfloat16 else 2.0 ** -9) + 1e-6
+        # the BENCHED instantiation -- 16-bit value AND 16-bit [offsets|logits] row, 512 threads, packed-fp16 accumulation -- at three value
+        # scales: 1e-3 (products near fp16's subnormal range: accumulated as fp16 pairs, so the absolute error floor is ~2^-24 per term)
+        # and 1e3 (sums of 16 terms up to 1e3: far inside fp16's range of 65504)
+        owh = ow.to(half)
+        offh = owh.float()[..., : M * L * P * 2].view(N, S, M, L, P, 2)
+        awh = torch.softmax(owh.float()[..., M * L * P * 2:].view(N, S, M, L * P), -1).view(N, S, M, L, P)
+        for vs in (1e-3, 1.0, 1e3):
+            vv = (v * vs).to(half)
+            goth = ops.msda_encoder(vv.cuda(), level_hw, owh.cuda(), ref.cuda()).float().cpu()
+            wanth = O.ms_deform_attn_core(vv.float(), s, O.msda_sampling_locations(ref, offh, s, P), awh)
+            tol = wanth.abs().max() * (ulp(half, 8) if half == torch.bfloat16 else 2.0 ** -9) + 16 * 2.0 ** -24
+            assert (goth - wanth).abs().max() <= tol, (vs, (goth - wanth).abs().max().item(), tol.item())
         # must agree with the gather kernel bit-for-bit in fp32 (same arithmetic order)
         g2 = ops.msda_fused(v.cuda(), s.cuda(), lsi.cuda(), ow.cuda(), ref.cuda()).cpu()
         assert (g2 - got).abs().max() < 1e-6

@@ -24,7 +24,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 
 FAMILIES = {
-    "gemm": re.compile(r"dtlr::(gemm_ws_kernel|gemm_ws_tall_kernel|gemm_k256_kernel|gemm_kres_kernel|conv3x3_patch_kernel|gemm_nt_kernel)\b"),
+    "gemm": re.compile(r"dtlr::(gemm_ws_kernel|gemm_ws_tall_kernel|gemm_k256_kernel|gemm_kres_kernel|conv3x3_patch_kernel|gemm_nt_kernel|dec_query_stage_kernel)\b"),
     "proj_ln": re.compile(r"dtlr::proj_ln_\w*kernel\b"),
     "ffn": re.compile(r"dtlr::(ffn3_bf16_kernel<|ffn2_bf16_kernel<|ffn_fused_bf16_kernel<0, false>)"),
     "msda_enc": re.compile(r"dtlr::msda_enc_lds_kernel\b"),
