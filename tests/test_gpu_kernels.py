@@ -226,7 +226,10 @@ def test_msda_encoder_lds_vs_oracle(level_hw, offscale, half):
             vv = (v * vs).to(half)
             goth = ops.msda_encoder(vv.cuda(), level_hw, owh.cuda(), ref.cuda()).float().cpu()
             wanth = O.ms_deform_attn_core(vv.float(), s, O.msda_sampling_locations(ref, offh, s, P), awh)
-            tol = wanth.abs().max() * (ulp(half, 8) if half == torch.bfloat16 else 2.0 ** -9) + 16 * 2.0 ** -24
+            # bf16: output rounding alone reaches max * 2^-8 (half an ulp just above a power of two); the fp16 accumulation adds a few 2^-11
+            # fp16: the running sums of a level's 16 corner terms are rounded to fp16 at every step (half an ulp = 2^-12 of the sum each):
+            # measured up to 3.0 x 2^-11 of the maximum
+            tol = wanth.abs().max() * (ulp(half, 8) + 2.0 ** -9 if half == torch.bfloat16 else 2.0 ** -8) + 16 * 2.0 ** -24
             assert (goth - wanth).abs().max() <= tol, (vs, (goth - wanth).abs().max().item(), tol.item())
         # must agree with the gather kernel bit-for-bit in fp32 (same arithmetic order)
         g2 = ops.msda_fused(v.cuda(), s.cuda(), lsi.cuda(), ow.cuda(), ref.cuda()).cpu()
