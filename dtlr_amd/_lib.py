@@ -53,6 +53,8 @@ _SIGNATURES = {
     "dtlr_gemm_kres_pack_weights_bcast384": (c_int, [c_void_p, c_void_p]),
     "dtlr_gemm_kres_bcast384": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_int, c_void_p]),
     "dtlr_gemm_kres": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p]),
+    "dtlr_gemm_kres_chain": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int,
+                                     c_void_p, c_void_p, c_void_p, c_int, c_void_p]),
     "dtlr_ffn32_pack_weights": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int]),
     "dtlr_ffn32_pad_chunks": (c_int, []),
     "dtlr_ffn32_bf16": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_float, c_void_p,

@@ -51,18 +51,34 @@ template <int N> __device__ __forceinline__ void kr_wait() {
 // [res_rows, n_valid] matrix shared by the n_img = M / res_rows images (row m pairs with row m % res_rows; the encoder's pos . W^T
 // term), and tiles are walked position-major (tile t = position tile t / n_img of image t % n_img) so a workgroup, and the band of
 // tiles an XCD owns, re-read a few residual tiles out of L2.
-template <int KB, int NP, int NS, int NBR>
-__global__ __launch_bounds__(512, 2) void gemm_kres_kernel(
+//
+// CAT: the K axis is the concatenation of TWO activation matrices, A [M, K/2] | A2 [M, K/2] (k blocks KB/2.. come from A2): the first
+// bottleneck of layer1, whose shortcut is itself a 1x1 convolution of the block input -- relu(conv3(t) + b3 + downsample(x) + bd) is ONE
+// GEMM over [t | x] with the weights [W3 | Wd] and the bias b3 + bd: no shortcut map is written (268 MB at B = 32) or read back.
+// NQ2 > 0 (needs NP = 1: a 256-channel launch column = the whole output row): the NEXT bottleneck's first 1x1 convolution runs on the
+// tile while it is on chip -- C2 = relu(C W2^T + b2), N2 = 64 NQ2 channels.  The rounded 16-bit results of a tile are also written to an
+// LDS image laid out exactly like a K = 256 activation tile (so they are read back as MFMA B-fragments with the same conflict-free
+// formula), a second barrier publishes it, and wave w computes token tile w & 3 x channel pairs NQ2 (w >> 2) .. of C2 with W2's fragments
+// resident in registers (Wp2 = dtlr_gemm_kres_pack_weights of W2 [N2, 256]: the zero-padded 256-column image the unfused launch takes).
+// Same operands, same k order as the unfused launch on the stored C: C2 is bit-identical to it; the 268 MB read of C is gone.
+template <int KB, int NP, int NS, int NBR, bool CAT = false, int NQ2 = 0>
+__global__ __launch_bounds__(512, NQ2 > 0 ? 1 : 2) void gemm_kres_kernel(
     const uint16_t* __restrict__ A, const uint16_t* __restrict__ Wp, const float* __restrict__ bias, const uint16_t* __restrict__ R,
-    uint16_t* __restrict__ C, int ld, int M, int tiles_per_wg, int relu, int n_valid, int res_rows, int n_img)
+    uint16_t* __restrict__ C, int ld, int M, int tiles_per_wg, int relu, int n_valid, int res_rows, int n_img,
+    const uint16_t* __restrict__ A2 = nullptr, const uint16_t* __restrict__ Wp2 = nullptr, const float* __restrict__ bias2 = nullptr,
+    uint16_t* __restrict__ C2 = nullptr)
 {
     constexpr bool HAS_R = NBR > 0;
+    static_assert(NQ2 == 0 || NP == 1, "the fused second GEMM reads whole 256-channel rows of the tile");
+    static_assert(!CAT || (KB % 2 == 0), "two sources of KB / 2 k blocks each");
     extern __shared__ __attribute__((aligned(16))) unsigned char kr_smem[];
     const unsigned lds_base = (unsigned)(size_t)(__attribute__((address_space(3))) unsigned char*)kr_smem;
     constexpr int K = 64 * KB, KS = 2 * KB, NC = 256 * NP, NB = NBR;               // NB = 128-byte blocks per residual row
     constexpr int A_BYTES = KR_TOK * K * 2, STAGE = A_BYTES + KR_TOK * NB * 128;
     constexpr int G = KB + (HAS_R ? NB : 0);                                       // DMA instructions per wave per tile
-    constexpr int E = 4 * NP;                                                      // stores per wave per tile
+    constexpr int E = 4 * NP + NQ2;                                                // stores per wave per tile (+ the second GEMM's)
+    constexpr int YT = NS * STAGE;                                                 // the tile's 16-bit output image [64 tokens][256 channels], 32 KB
+    constexpr int N2 = 64 * NQ2;
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     const int n = lane & 15, g = lane >> 4;
@@ -86,7 +102,11 @@ __global__ __launch_bounds__(512, 2) void gemm_kres_kernel(
         const long tok = min(row0(t) + wave * 8 + dr, (long)M - 1);
         const unsigned dst = lds_base + (unsigned)(slot * STAGE);
 #pragma unroll
-        for (int kb = 0; kb < KB; ++kb) kr_glds16(A + tok * K + kb * 64 + dc * 8, dst + (unsigned)((wave * KB + kb) * 1024));
+        for (int kb = 0; kb < KB; ++kb) {
+            const uint16_t* src = A + tok * K + kb * 64 + dc * 8;
+            if constexpr (CAT) src = kb < KB / 2 ? A + tok * (K / 2) + kb * 64 + dc * 8 : A2 + tok * (K / 2) + (kb - KB / 2) * 64 + dc * 8;
+            kr_glds16(src, dst + (unsigned)((wave * KB + kb) * 1024));
+        }
         if constexpr (HAS_R) {
             const long rrow = n_img > 0 ? (long)(t / n_img) * KR_TOK + wave * 8 + dr : tok;
 #pragma unroll
@@ -111,6 +131,21 @@ __global__ __launch_bounds__(512, 2) void gemm_kres_kernel(
     for (int p = 0; p < NP; ++p)
 #pragma unroll
         for (int e = 0; e < 8; ++e) bs[p][e] = (bias && col0 + 32 * (wave * NP + p) < n_valid) ? bias[col0 + 32 * (wave * NP + p) + 8 * g + e] : 0.f;
+    // second GEMM: wave w owns token tile w & 3 and the channel pairs NQ2 (w >> 2) + j of C2
+    uint4 w2f[NQ2 > 0 ? NQ2 : 1][2][8];
+    float bs2[NQ2 > 0 ? NQ2 : 1][8];
+    if constexpr (NQ2 > 0) {
+#pragma unroll
+        for (int j = 0; j < NQ2; ++j) {
+            const int q2 = NQ2 * (wave >> 2) + j;
+#pragma unroll
+            for (int e = 0; e < 2; ++e)
+#pragma unroll
+                for (int ks = 0; ks < 8; ++ks) w2f[j][e][ks] = kr_load16(Wp2 + ((long)(q2 * 2 + e) * 8 + ks) * 512 + lane * 8);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) bs2[j][e] = bias2 ? bias2[32 * q2 + 8 * g + e] : 0.f;
+        }
+    }
     kr_wait<0>();
 
     // B-fragment of token tile tt, k-step ks: row group 2 tt + (n >> 3), block ks >> 1, row n & 7, slot (4 (ks & 1) + g) ^ (n & 7)
@@ -123,6 +158,11 @@ __global__ __launch_bounds__(512, 2) void gemm_kres_kernel(
         const int q = wave * NP + p;
         rdR[p] = (unsigned)(A_BYTES + ((n >> 3) * NB + (q >> 1)) * 1024 + (n & 7) * 128 + (((4 * (q & 1) + g) ^ (n & 7)) * 16));
     }
+
+    // the output image: channel block q = wave (32 channels) of token n of tile tt is chunk 4 (q & 1) + g of k block q >> 1 -- the address the
+    // second GEMM's B-fragment of k-step q reads; its own reads: token tile w & 3, k-step ks
+    const unsigned ywr = (unsigned)(YT + (n >> 3) * 4096 + (wave >> 1) * 1024 + (n & 7) * 128 + (((4 * (wave & 1) + g) ^ (n & 7)) * 16));
+    const unsigned yrd = (unsigned)(YT + (wave & 3) * 8192 + (n >> 3) * 4096 + (n & 7) * 128);
 
     for (int i = 0; i < nt; ++i) {
         const int t = t_begin + i;
@@ -175,8 +215,36 @@ __global__ __launch_bounds__(512, 2) void gemm_kres_kernel(
 #pragma unroll
                     for (int e = 0; e < 8; ++e) v[e] = fmaxf(v[e], 0.f);
                 }
-                if (tok < M)
-                    *reinterpret_cast<uint4*>(C + tok * (long)ld + col0 + 32 * (wave * NP + p) + 8 * g) =
+                const uint4 pk = make_uint4(pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3]), pack_bf16x2(v[4], v[5]), pack_bf16x2(v[6], v[7]));
+                if (tok < M) *reinterpret_cast<uint4*>(C + tok * (long)ld + col0 + 32 * (wave * NP + p) + 8 * g) = pk;
+                if constexpr (NQ2 > 0) *reinterpret_cast<uint4*>(kr_smem + ywr + tt * 8192) = pk;
+            }
+        }
+        if constexpr (NQ2 > 0) {
+            // ---- the next block's 1x1 convolution on the tile: C2[64, N2] = relu(Y[64, 256] W2^T + b2) -------------------------------
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();                     // the tile's image is complete (the next tile's is written after the next top barrier)
+            asm volatile("" ::: "memory");
+            kr_f32x4_t acc2[NQ2][2];
+#pragma unroll
+            for (int j = 0; j < NQ2; ++j) { acc2[j][0] = kr_f32x4_t{0.f, 0.f, 0.f, 0.f}; acc2[j][1] = kr_f32x4_t{0.f, 0.f, 0.f, 0.f}; }
+#pragma unroll
+            for (int ks = 0; ks < 8; ++ks) {
+                const uint4 yb = *reinterpret_cast<const uint4*>(kr_smem + yrd + ((ks & 1) ? sw1 : sw0) + (ks >> 1) * 1024);
+#pragma unroll
+                for (int j = 0; j < NQ2; ++j) {
+                    acc2[j][0] = kr_mma(w2f[j][0][ks], yb, acc2[j][0]);
+                    acc2[j][1] = kr_mma(w2f[j][1][ks], yb, acc2[j][1]);
+                }
+            }
+            const long tok2 = trow + (wave & 3) * 16 + n;
+#pragma unroll
+            for (int j = 0; j < NQ2; ++j) {
+                float v[8];
+#pragma unroll
+                for (int e = 0; e < 8; ++e) v[e] = fmaxf(acc2[j][e >> 2][e & 3] + bs2[j][e], 0.f);
+                if (tok2 < M)
+                    *reinterpret_cast<uint4*>(C2 + tok2 * (long)N2 + 32 * (NQ2 * (wave >> 2) + j) + 8 * g) =
                         make_uint4(pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3]), pack_bf16x2(v[4], v[5]), pack_bf16x2(v[6], v[7]));
             }
         }
@@ -273,6 +341,40 @@ extern "C" int dtlr_gemm_kres(const void* A, const void* Wp, const float* bias, 
     if ((K != 64 && K != 128 && K != 256) || N <= 0 || (N & 63) || (N > 256 && (N & 255))) return DTLR_ESHAPE;
     if (N < 256 && R) return DTLR_ESHAPE;                       // the zero-padded column form has no residual tile
     return kres_launch(A, Wp, bias, R, C, M, N < 256 ? 256 : N, K, relu, N, 0, (hipStream_t)stream);
+}
+
+// The bottleneck tails of layer1 with their neighbours fused (the kernel's CAT / NQ2 notes):  N = 256 output channels, 64-channel inputs.
+//   C  = relu?( [A | A2] Wp^T + bias (+ R) )      A [M, 64]; A2 [M, 64] or null; R [M, 256] or null -- exactly one of A2 and R;
+//                                                 Wp = dtlr_gemm_kres_pack_weights of W [256, 128] = [W3 | Wd] with A2, of W [256, 64] with R
+//   C2 = relu( C Wp2^T + bias2 )                  Wp2 = dtlr_gemm_kres_pack_weights of W2 [N2, 256], N2 = 64 or 128; null: no second GEMM (A2 form only)
+// C2 is bit-identical to dtlr_gemm_kres run on the stored C; with R, C is bit-identical to dtlr_gemm_kres; with A2, the shortcut
+// convolution is accumulated in fp32 instead of being rounded to 16 bits first.
+extern "C" int dtlr_gemm_kres_chain(const void* A, const void* A2, const void* Wp, const float* bias, const void* R, void* C, int M, int relu,
+                                    const void* Wp2, const float* bias2, void* C2, int N2, void* stream)
+{
+    clear_stale_error();
+    if (!A || !Wp || !C || M <= 0) return DTLR_EINVAL;
+    if ((A2 != nullptr) == (R != nullptr)) return DTLR_EINVAL;
+    if (Wp2 ? (!C2 || (N2 != 64 && N2 != 128)) : (!A2)) return DTLR_EINVAL;
+    if (Wp2 && A2 && N2 != 64) return DTLR_ESHAPE;
+    const int ntiles = (M + KR_TOK - 1) / KR_TOK;
+    int per_x = (ntiles + 255) / 256;
+    if (per_x < 1) per_x = 1;
+    const int gx = (ntiles + per_x - 1) / per_x;
+    hipStream_t st = (hipStream_t)stream;
+#define KR_CHAIN(KB_, NS_, NBR_, CAT_, NQ2_)                                                       \
+    {                                                                                              \
+        constexpr int lds_ = NS_ * (KR_TOK * 64 * KB_ * 2 + KR_TOK * NBR_ * 128) + (NQ2_ > 0 ? KR_TOK * 512 : 0); \
+        static DevOnce once;                                                                       \
+        if (once.first()) { (void)hipFuncSetAttribute((const void*)gemm_kres_kernel<KB_, 1, NS_, NBR_, CAT_, NQ2_>, hipFuncAttributeMaxDynamicSharedMemorySize, lds_); (void)hipGetLastError(); } \
+        hipLaunchKernelGGL((gemm_kres_kernel<KB_, 1, NS_, NBR_, CAT_, NQ2_>), dim3(gx, 1), dim3(512), lds_, st, (const uint16_t*)A, (const uint16_t*)Wp, bias, \
+                           (const uint16_t*)R, (uint16_t*)C, 256, M, per_x, relu, 256, 0, 0, (const uint16_t*)A2, (const uint16_t*)Wp2, bias2, (uint16_t*)C2); \
+    }
+    if (A2) { if (Wp2) KR_CHAIN(2, 4, 0, true, 1) else KR_CHAIN(2, 4, 0, true, 0) }
+    else if (N2 == 64) KR_CHAIN(1, 3, 4, false, 1)
+    else KR_CHAIN(1, 3, 4, false, 2)
+#undef KR_CHAIN
+    return check_launch();
 }
 
 // The encoder's [offsets | attention logits] projection with the position term as a row-broadcast residual:

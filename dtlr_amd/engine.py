@@ -65,6 +65,8 @@ class DTLREngine:
         self.use_k256_small = True   # ... and for the encoder's output projection + LayerNorm
         self.use_stem_pool = True         # 16-bit: stem convolution + FrozenBN shift + ReLU + max-pool in one kernel
         self.use_dec_query_stage = True   # 16-bit: a decoder layer's query stage (sine, ref_point_head, q | k, v) in one launch
+        self.use_l1_chain = True          # 16-bit: layer1's 1x1 convolutions chained (shortcut conv as extra K columns; tail + next conv1 in one launch)
+        self.use_l1_chain_out = True      #         ... including the last tail -> layer2.0.conv1
 
     # ------------------------------------------------------------------------------ packing
     def _put(self, name, t, dtype=None):
@@ -352,17 +354,53 @@ class DTLREngine:
                 x = ops.stem_conv7x7_f32(x_nchw, self.w["conv1.wk"])
             x = ops.maxpool_nhwc(x, bias=self.w["conv1.b"], relu=True)
         outs = []
+        pre = None                       # the NEXT bottleneck's conv1 output when the previous tail already computed it (layer1 chain)
         for li, nblocks in enumerate(self.cfg.backbone_blocks, start=1):
+            if li == 1 and self.use_l1_chain and x.dtype in ops.H16 and x.shape[-1] == 64 and x.numel() // 64 >= 16384:
+                x, pre = self._layer1_chain(x, nblocks)
+                continue
             for bi in range(nblocks):
                 q = f"l{li}.{bi}."
                 stride = 2 if (bi == 0 and li > 1) else 1
                 idt = self._conv(q + "ds", x, stride, 0) if bi == 0 else x
-                o = self._conv(q + "c1", x, 1, 0, relu=True)
+                o = pre if pre is not None else self._conv(q + "c1", x, 1, 0, relu=True)
+                pre = None
                 o = self._conv(q + "c2", o, stride, 1, relu=True)
                 x = self._conv(q + "c3", o, 1, 0, relu=True, residual=idt)
             if li >= 2:
                 outs.append(x)
         return outs
+
+    def _layer1_chain(self, x0, nblocks):
+        """layer1 (64-channel bottlenecks on the full-resolution pooled map: the HBM-heaviest part of the backbone) with the 1x1
+        convolutions chained (ops.gemm_kres_chain): the first block's `downsample` shortcut is K columns 64..127 of its conv3 GEMM
+        ([t | x] . [W3 | Wd]^T, bias b3 + bd: the 256-channel shortcut map is neither written nor read back), and every tail also
+        produces the NEXT bottleneck's conv1 output from the tile it has on chip (the 256-channel map is written once and not re-read
+        by conv1; the last tail feeds layer2.0.conv1).  torchvision Bottleneck.forward: out = relu(bn3(conv3(.)) + identity)."""
+        w = self.w
+
+        def wk(name):
+            if name + ".wk" not in w:
+                w[name + ".wk"] = ops.kres_pack(w[name + ".w"])
+            return w[name + ".wk"]
+        if "l1.0.cat.wk" not in w:
+            w["l1.0.cat.wk"] = ops.kres_pack(torch.cat([w["l1.0.c3.w"], w["l1.0.ds.w"]], 1).contiguous())
+            w["l1.0.cat.b"] = (w["l1.0.c3.b"].float() + w["l1.0.ds.b"].float()).contiguous()
+        nxt = [f"l1.{bi + 1}.c1" for bi in range(nblocks - 1)] + (["l2.0.c1"] if self.use_l1_chain_out else [None])
+        n2 = [64] * (nblocks - 1) + [128]
+        o = self._conv("l1.0.c1", x0, 1, 0, relu=True)
+        x = None
+        for bi in range(nblocks):
+            o = self._conv(f"l1.{bi}.c2", o, 1, 1, relu=True)
+            nm = nxt[bi]
+            kw = dict(wp2=wk(nm), b2=w[nm + ".b"], n2=n2[bi]) if nm is not None else {}
+            if bi == 0:
+                x, o = ops.gemm_kres_chain(o, w["l1.0.cat.wk"], w["l1.0.cat.b"], x2=x0, relu=True, **kw)
+            elif nm is not None:
+                x, o = ops.gemm_kres_chain(o, wk(f"l1.{bi}.c3"), w[f"l1.{bi}.c3.b"], residual=x, relu=True, **kw)
+            else:
+                x, o = self._conv(f"l1.{bi}.c3", o, 1, 0, relu=True, residual=x), None
+        return x, o
 
     def _geometry(self, mask, level_hw, has_padding=True):
         """Everything that depends only on the padding masks, ONE HIP launch per forward (ops.geometry): per-level masks

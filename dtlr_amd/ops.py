@@ -217,6 +217,44 @@ def gemm_kres(x, wp, n_out: int, b=None, residual=None, relu: bool = False):
     return out
 
 
+def gemm_kres_chain(x, wp, b=None, x2=None, residual=None, relu: bool = True, wp2=None, b2=None, n2: int = 0):
+    """A layer1 bottleneck tail chained with its neighbours (dtlr_gemm_kres_chain):
+        y  = relu?([x | x2] @ W.T + b (+ residual))     x [..., 64]; exactly one of x2 [..., 64] (first bottleneck: the 1x1 shortcut
+                                                         convolution as K columns 64..127, W = [W3 | Wd], b = b3 + bd) and residual [..., 256]
+        t  = relu(y @ W2.T + b2)                         the next bottleneck's first 1x1 convolution (n2 = 64 or 128), when wp2 is given
+    wp = kres_pack(W [256, 64 or 128]), wp2 = kres_pack(W2 [n2, 256]).  Returns (y, t or None)."""
+    require_cuda(x, "x")
+    assert x.dtype in H16 and wp.dtype == x.dtype and x.shape[-1] == 64 and (x2 is None) != (residual is None)
+    x = x if x.is_contiguous() else x.contiguous()
+    M = x.numel() // 64
+    K = 64
+    if x2 is not None:
+        assert x2.dtype == x.dtype and x2.shape[-1] == 64 and x2.numel() == x.numel()
+        x2 = x2 if x2.is_contiguous() else x2.contiguous()
+        K = 128
+    else:
+        assert residual.dtype == x.dtype and residual.shape[-1] == 256 and residual.numel() == M * 256
+        residual = residual if residual.is_contiguous() else residual.contiguous()
+    assert wp.numel() == 256 * K
+    if wp2 is not None:
+        assert wp2.dtype == x.dtype and n2 in (64, 128) and wp2.numel() == 256 * 256 and (x2 is None or n2 == 64)
+    else:
+        assert x2 is not None
+    b = None if b is None else (b if b.dtype == torch.float32 else b.float())
+    b2 = None if b2 is None else (b2 if b2.dtype == torch.float32 else b2.float())
+    y = torch.empty(x.shape[:-1] + (256,), dtype=x.dtype, device=x.device)
+    t = torch.empty(x.shape[:-1] + (n2,), dtype=x.dtype, device=x.device) if wp2 is not None else None
+    nbytes = float(M) * K * 2 + 256.0 * K * 2 + float(M) * 256 * 2 * (2 if residual is not None else 1) + (float(M) * n2 * 2 + 512.0 * n2 if t is not None else 0.0)
+    flops = 2.0 * M * 256 * K + (2.0 * M * n2 * 256 if t is not None else 0.0)
+    with _Timed("gemm_bf16", flops, nbytes, f"kres_chain M{M} K{K}" + ("+res" if residual is not None else "+cat") + (f" ->N{n2}" if t is not None else "")):
+        code = _L(x).dtlr_gemm_kres_chain(x.data_ptr(), 0 if x2 is None else x2.data_ptr(), wp.data_ptr(), 0 if b is None else b.data_ptr(),
+                                          0 if residual is None else residual.data_ptr(), y.data_ptr(), M, 1 if relu else 0,
+                                          0 if wp2 is None else wp2.data_ptr(), 0 if b2 is None else b2.data_ptr(),
+                                          0 if t is None else t.data_ptr(), n2, _lib.current_stream())
+    _lib.check(code, "dtlr_gemm_kres_chain")
+    return y, t
+
+
 def kres_pack_bcast384(w):
     """[384, 256] weight -> the zero-padded 512-channel image of dtlr_gemm_kres_bcast384 (== dtlr_gemm_kres_pack_weights_bcast384)."""
     assert tuple(w.shape) == (384, 256)
@@ -1006,7 +1044,7 @@ def _device_scoped(fn):
     return wrapper
 
 
-for _name in ("msda_encoder_far_fraction", "gemm_kres", "gemm_kres_bcast384", "ffn32", "proj_ln_k256", "swin_patch_embed", "swin_window_attn", "swin_patch_merge", "geometry", "linear", "gemm_k256", "linear_rowmax", "two_stage_gather", "layernorm", "proj_ln", "proj_ln_split", "ffn_fused", "conv2d_nhwc", "stem_conv7x7", "stem_conv7x7_f32",
+for _name in ("msda_encoder_far_fraction", "gemm_kres", "gemm_kres_chain", "gemm_kres_bcast384", "ffn32", "proj_ln_k256", "swin_patch_embed", "swin_window_attn", "swin_patch_merge", "geometry", "linear", "gemm_k256", "linear_rowmax", "two_stage_gather", "layernorm", "proj_ln", "proj_ln_split", "ffn_fused", "conv2d_nhwc", "stem_conv7x7", "stem_conv7x7_f32",
               "maxpool_nhwc", "groupnorm_tokens", "msda", "msda_fused", "msda_encoder", "mha", "decoder_query_prep", "box_mlp_refine",
               "box_head_refine", "box_refine", "topk_rows", "decode_blank", "preprocess_lines", "ctc_loss_interleaved", "nms_batched",
               "topk_flat"):

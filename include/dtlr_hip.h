@@ -143,6 +143,17 @@ int dtlr_ffn_fused_bf16(const void *X, const void *W1, const float *b1, const vo
  */
 int dtlr_gemm_kres_pack_weights(const unsigned short *w_host, unsigned short *wp_host, int N, int K);
 int dtlr_gemm_kres(const void *A, const void *Wp, const float *bias, const void *R, void *C, int M, int N, int K, int relu, void *stream);
+/* Layer1's bottleneck tails chained with their neighbours (torchvision resnet50 `layer1`, models/dino/backbone.py:97-106), 64-channel
+ * inputs, 256 output channels:
+ *     C  = relu?( [A | A2] W^T + bias (+ R) )     exactly one of A2 [M, 64] (the block input x of the FIRST bottleneck: its 1x1 `downsample`
+ *                                                 shortcut becomes K columns 64..127 of the same GEMM, W = [W3 | Wd], bias = b3 + bd, and
+ *                                                 no shortcut map is written or read) and R [M, 256] (identity shortcut)
+ *     C2 = relu( C W2^T + bias2 )                 the NEXT bottleneck's first 1x1 convolution (N2 = 64 inside layer1, 128 for layer2.0),
+ *                                                 computed while the 64-row tile of C is on chip; Wp2 NULL: not computed (A2 form only)
+ *   Wp / Wp2: device copies of dtlr_gemm_kres_pack_weights(W [256, 64 or 128]) / (W2 [N2, 256]).  C2 is bit-identical to dtlr_gemm_kres
+ *   on the stored C; with R, C is bit-identical to dtlr_gemm_kres. */
+int dtlr_gemm_kres_chain(const void *A, const void *A2, const void *Wp, const float *bias, const void *R, void *C, int M, int relu,
+                         const void *Wp2, const float *bias2, void *C2, int N2, void *stream);
 /* The encoder's [sampling offsets | attention logits] projection (ops/modules/ms_deform_attn.py:97-98 on query = src + pos) for an
  * unpadded batch: (src + pos) W^T + b = src W^T + (pos W^T + b), the second term ONE [res_rows, 384] bf16 matrix shared by all images:
  *     C[m, :] = A[m, :] W^T + R[m % res_rows, :]        A [M, 256], C [M, 384] bf16

@@ -1157,3 +1157,38 @@ def test_stem_conv_pool_fused_equals_the_two_kernels(B, H, W, half):
     got = ops.stem_conv7x7_pool(x, frag, bias, half)
     assert got.shape == want.shape
     assert torch.equal(got, want), (got.float() - want.float()).abs().max().item()
+
+
+@pytest.mark.parametrize("M", [524288, 16384 + 64 * 5, 1000, 64, 37])
+def test_gemm_kres_chain_equals_the_separate_launches(M, half):
+    """dtlr_gemm_kres_chain: (a) identity-shortcut tail + the next bottleneck's conv1 (N2 = 64 and 128) == dtlr_gemm_kres twice, BIT FOR
+    BIT (same operands, same k order; the second GEMM reads the rounded tile from LDS instead of HBM); (b) the first bottleneck's form
+    -- the 1x1 shortcut convolution as K columns 64..127 -- against an fp64 restatement (it is MORE exact than the separate launches:
+    the shortcut is not rounded to 16 bits before the add), its second GEMM bit-equal to dtlr_gemm_kres on the stored tile; ragged
+    and tiny M included."""
+    from dtlr_amd import ops
+    t = torch.relu(_rand((M, 64), 1)).to(half).cuda()
+    x0 = torch.relu(_rand((M, 64), 2)).to(half).cuda()
+    idt = torch.relu(_rand((M, 256), 3)).to(half).cuda()
+    w3, wd = (_rand((256, 64), 4) / 8).to(half).cuda(), (_rand((256, 64), 5) / 8).to(half).cuda()
+    b3, bd = (_rand((256,), 6) * 0.2).cuda(), (_rand((256,), 7) * 0.2).cuda()
+    for n2 in (64, 128):
+        w2, b2 = (_rand((n2, 256), 8) / 16).to(half).cuda(), (_rand((n2,), 9) * 0.2).cuda()
+        y, c2 = ops.gemm_kres_chain(t, ops.kres_pack(w3), b3, residual=idt, relu=True, wp2=ops.kres_pack(w2), b2=b2, n2=n2)
+        y_ref = ops.gemm_kres(t, ops.kres_pack(w3), 256, b3, idt, relu=True)
+        assert torch.equal(y, y_ref), (n2, (y.float() - y_ref.float()).abs().max().item())
+        c2_ref = ops.gemm_kres(y_ref, ops.kres_pack(w2), n2, b2, None, relu=True)
+        assert torch.equal(c2, c2_ref), (n2, (c2.float() - c2_ref.float()).abs().max().item())
+    # first-bottleneck form: [t | x0] . [W3 | Wd]^T + (b3 + bd)
+    w2, b2 = (_rand((64, 256), 8) / 16).to(half).cuda(), (_rand((64,), 9) * 0.2).cuda()
+    wcat = ops.kres_pack(torch.cat([w3, wd], 1).contiguous())
+    y, c2 = ops.gemm_kres_chain(t, wcat, b3 + bd, x2=x0, relu=True, wp2=ops.kres_pack(w2), b2=b2, n2=64)
+    y_only, none = ops.gemm_kres_chain(t, wcat, b3 + bd, x2=x0, relu=True)
+    assert none is None and torch.equal(y, y_only)
+    want = torch.relu(t.double().cpu() @ w3.double().cpu().t() + x0.double().cpu() @ wd.double().cpu().t() + (b3 + bd).double().cpu())
+    err = (y.double().cpu() - want).abs().max().item()
+    assert err <= want.abs().max().item() * ulp(half, 8) + 1e-6, err
+    assert torch.equal(c2, ops.gemm_kres(y, ops.kres_pack(w2), 64, b2, None, relu=True))
+    # and close to the separate launches (which round the shortcut map first)
+    y_sep = ops.gemm_kres(t, ops.kres_pack(w3), 256, b3, ops.gemm_kres(x0, ops.kres_pack(wd), 256, bd, None, relu=False), relu=True)
+    assert (y.float() - y_sep.float()).abs().max().item() <= want.abs().max().item() * ulp(half, 7)

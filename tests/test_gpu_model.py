@@ -524,6 +524,37 @@ def test_undamped_stress_weights_16bit_vs_fp32_engine(half):
     assert agree >= (0.995 if half == "bf16" else 0.999), agree
 
 
+@pytest.mark.parametrize("half", ["bf16", "f16"])
+def test_layer1_chain_backbone_equals_the_separate_convolutions(half):
+    """engine.use_l1_chain (layer1's 1x1 convolutions chained: dtlr_gemm_kres_chain) against the same engine with one launch per
+    convolution, on the backbone maps C3 / C4 / C5 of stroke + noise lines.  The chain changes ONE rounding -- the first bottleneck's
+    shortcut convolution is no longer rounded to 16 bits before the add -- so the maps agree to a few 16-bit ulps of their scale, not
+    bit for bit; both sit equally close to the fp32 engine's maps."""
+    from dtlr_amd.engine import DTLREngine
+    cfg = DTLRConfig.latin()
+    sd = weights.synthetic_state_dict(cfg, 0)
+    x = torch.stack(synth.stroke_lines(2, 128, 2048, seed=41) + synth.noise_lines(1, 128, 2048, seed=42)).cuda()
+    eng = DTLREngine(cfg, sd, "cuda:0", HALF[half])
+    assert eng.use_l1_chain and eng.use_l1_chain_out
+    got = [f.float() for f in eng.backbone(x)]
+    eng.use_l1_chain = False
+    sep = [f.float() for f in eng.backbone(x)]
+    ref = DTLREngine(cfg, sd, "cuda:0", torch.float32).backbone(x)
+    u = 2.0 ** (-8 if half == "bf16" else -11)
+    for g, s_, r in zip(got, sep, ref):
+        scale = r.abs().max().item()
+        eg, es = (g - r).abs(), (s_ - r).abs()
+        print(f"[l1 chain, {half}] map {tuple(g.shape)}: |chain - sep| max {(g - s_).abs().max().item():.4g}, vs fp32: chain {eg.max().item():.4g} / "
+              f"{eg.mean().item():.4g}, separate {es.max().item():.4g} / {es.mean().item():.4g} (scale {scale:.3g})")
+        assert torch.isfinite(g).all()
+        assert eg.mean().item() <= 1.1 * es.mean().item() + 1e-6                   # no further from the exact maps than the separate launches
+        assert eg.max().item() <= 64 * u * scale
+    # the chain without its last link (layer2.0.conv1 from its own launch): bit-identical maps (that link changes no rounding)
+    eng.use_l1_chain, eng.use_l1_chain_out = True, False
+    for g, h in zip(got, eng.backbone(x)):
+        assert torch.equal(g, h.float())
+
+
 def test_rccl_collectives_on_a_one_rank_group():
     """The `nccl` (= RCCL) branch of dtlr_amd.dist -- all_gather_into_tensor of the decode records, the MAX all-reduce of the timing,
     the barrier -- on a world-size-1 group on the one GPU of the test box: the code path of the 8-GPU job has then executed before
