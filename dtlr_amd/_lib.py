@@ -55,6 +55,7 @@ _SIGNATURES = {
     "dtlr_gemm_kres": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p]),
     "dtlr_gemm_kres_chain": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int,
                                      c_void_p, c_void_p, c_void_p, c_int, c_void_p]),
+    "dtlr_gemm_kres_cat_s2": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p]),
     "dtlr_ffn32_pack_weights": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int]),
     "dtlr_ffn32_pad_chunks": (c_int, []),
     "dtlr_ffn32_bf16": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_float, c_void_p,

@@ -61,16 +61,22 @@ template <int N> __device__ __forceinline__ void kr_wait() {
 // formula), a second barrier publishes it, and wave w computes token tile w & 3 x channel pairs NQ2 (w >> 2) .. of C2 with W2's fragments
 // resident in registers (Wp2 = dtlr_gemm_kres_pack_weights of W2 [N2, 256]: the zero-padded 256-column image the unfused launch takes).
 // Same operands, same k order as the unfused launch on the stored C: C2 is bit-identical to it; the 268 MB read of C is gone.
-template <int KB, int NP, int NS, int NBR, bool CAT = false, int NQ2 = 0>
+// KB1 > 0 generalises CAT: k blocks 0 .. KB1 - 1 come from A [M, 64 KB1], the rest from A2 (64 (KB - KB1) channels per row).  With
+// s2 = {Hout, Wout, Hin, Win} (Wout > 0) row m = (b, i, j) of the Hout x Wout output grid reads A2 at pixel (b, 2 i, 2 j) of an
+// Hin x Win map: the STRIDED 1x1 shortcut convolution of layer2's first bottleneck (`downsample`: conv1x1 stride 2) as K columns
+// 128..383 of its tail GEMM -- neither the 512-channel shortcut map nor its gather launch exist any more.
+struct KrS2 { int hout, wout, hin, win; };
+template <int KB, int NP, int NS, int NBR, int KB1 = 0, int NQ2 = 0>
 __global__ __launch_bounds__(512, NQ2 > 0 ? 1 : 2) void gemm_kres_kernel(
     const uint16_t* __restrict__ A, const uint16_t* __restrict__ Wp, const float* __restrict__ bias, const uint16_t* __restrict__ R,
     uint16_t* __restrict__ C, int ld, int M, int tiles_per_wg, int relu, int n_valid, int res_rows, int n_img,
     const uint16_t* __restrict__ A2 = nullptr, const uint16_t* __restrict__ Wp2 = nullptr, const float* __restrict__ bias2 = nullptr,
-    uint16_t* __restrict__ C2 = nullptr)
+    uint16_t* __restrict__ C2 = nullptr, KrS2 s2 = KrS2{0, 0, 0, 0})
 {
     constexpr bool HAS_R = NBR > 0;
+    constexpr bool CAT = KB1 > 0;
     static_assert(NQ2 == 0 || NP == 1, "the fused second GEMM reads whole 256-channel rows of the tile");
-    static_assert(!CAT || (KB % 2 == 0), "two sources of KB / 2 k blocks each");
+    static_assert(KB1 < KB, "at least one k block from the second source");
     extern __shared__ __attribute__((aligned(16))) unsigned char kr_smem[];
     const unsigned lds_base = (unsigned)(size_t)(__attribute__((address_space(3))) unsigned char*)kr_smem;
     constexpr int K = 64 * KB, KS = 2 * KB, NC = 256 * NP, NB = NBR;               // NB = 128-byte blocks per residual row
@@ -101,10 +107,17 @@ __global__ __launch_bounds__(512, NQ2 > 0 ? 1 : 2) void gemm_kres_kernel(
     auto issue = [&](int t, int slot) {
         const long tok = min(row0(t) + wave * 8 + dr, (long)M - 1);
         const unsigned dst = lds_base + (unsigned)(slot * STAGE);
+        long tok2 = tok;
+        if constexpr (CAT) {
+            if (s2.wout > 0) {                                  // (b, i, j) of the output grid -> pixel (b, 2 i, 2 j) of the input map
+                const int hw = s2.hout * s2.wout, ti = (int)tok, bi = ti / hw, rem = ti - bi * hw, ii = rem / s2.wout, jj = rem - ii * s2.wout;
+                tok2 = ((long)bi * s2.hin + 2 * ii) * s2.win + 2 * jj;
+            }
+        }
 #pragma unroll
         for (int kb = 0; kb < KB; ++kb) {
             const uint16_t* src = A + tok * K + kb * 64 + dc * 8;
-            if constexpr (CAT) src = kb < KB / 2 ? A + tok * (K / 2) + kb * 64 + dc * 8 : A2 + tok * (K / 2) + (kb - KB / 2) * 64 + dc * 8;
+            if constexpr (CAT) src = kb < KB1 ? A + tok * (64 * KB1) + kb * 64 + dc * 8 : A2 + tok2 * (64 * (KB - KB1)) + (kb - KB1) * 64 + dc * 8;
             kr_glds16(src, dst + (unsigned)((wave * KB + kb) * 1024));
         }
         if constexpr (HAS_R) {
@@ -282,7 +295,7 @@ static int kres_pack(const unsigned short* w_host, unsigned short* wp_host, int 
 extern "C" int dtlr_gemm_kres_pack_weights(const unsigned short* w_host, unsigned short* wp_host, int N, int K)
 {
     if (!w_host || !wp_host) return DTLR_EINVAL;
-    if ((K != 64 && K != 128 && K != 256) || N <= 0 || (N & 63) || (N > 256 && (N & 255))) return DTLR_ESHAPE;
+    if ((K != 64 && K != 128 && K != 256 && K != 384) || N <= 0 || (N & 63) || (N > 256 && (N & 255))) return DTLR_ESHAPE;     // 384: dtlr_gemm_kres_cat_s2
     const int Np = N < 256 ? 256 : N;
     return kres_pack(w_host, wp_host, Np, K, (Np % 512 == 0 && K <= 128) ? 2 : 1, N);
 }
@@ -362,18 +375,44 @@ extern "C" int dtlr_gemm_kres_chain(const void* A, const void* A2, const void* W
     if (per_x < 1) per_x = 1;
     const int gx = (ntiles + per_x - 1) / per_x;
     hipStream_t st = (hipStream_t)stream;
-#define KR_CHAIN(KB_, NS_, NBR_, CAT_, NQ2_)                                                       \
+#define KR_CHAIN(KB_, NS_, NBR_, KB1_, NQ2_)                                                       \
     {                                                                                              \
         constexpr int lds_ = NS_ * (KR_TOK * 64 * KB_ * 2 + KR_TOK * NBR_ * 128) + (NQ2_ > 0 ? KR_TOK * 512 : 0); \
         static DevOnce once;                                                                       \
-        if (once.first()) { (void)hipFuncSetAttribute((const void*)gemm_kres_kernel<KB_, 1, NS_, NBR_, CAT_, NQ2_>, hipFuncAttributeMaxDynamicSharedMemorySize, lds_); (void)hipGetLastError(); } \
-        hipLaunchKernelGGL((gemm_kres_kernel<KB_, 1, NS_, NBR_, CAT_, NQ2_>), dim3(gx, 1), dim3(512), lds_, st, (const uint16_t*)A, (const uint16_t*)Wp, bias, \
+        if (once.first()) { (void)hipFuncSetAttribute((const void*)gemm_kres_kernel<KB_, 1, NS_, NBR_, KB1_, NQ2_>, hipFuncAttributeMaxDynamicSharedMemorySize, lds_); (void)hipGetLastError(); } \
+        hipLaunchKernelGGL((gemm_kres_kernel<KB_, 1, NS_, NBR_, KB1_, NQ2_>), dim3(gx, 1), dim3(512), lds_, st, (const uint16_t*)A, (const uint16_t*)Wp, bias, \
                            (const uint16_t*)R, (uint16_t*)C, 256, M, per_x, relu, 256, 0, 0, (const uint16_t*)A2, (const uint16_t*)Wp2, bias2, (uint16_t*)C2); \
     }
-    if (A2) { if (Wp2) KR_CHAIN(2, 4, 0, true, 1) else KR_CHAIN(2, 4, 0, true, 0) }
-    else if (N2 == 64) KR_CHAIN(1, 3, 4, false, 1)
-    else KR_CHAIN(1, 3, 4, false, 2)
+    if (A2) { if (Wp2) KR_CHAIN(2, 4, 0, 1, 1) else KR_CHAIN(2, 4, 0, 1, 0) }
+    else if (N2 == 64) KR_CHAIN(1, 3, 4, 0, 1)
+    else KR_CHAIN(1, 3, 4, 0, 2)
 #undef KR_CHAIN
+    return check_launch();
+}
+
+// layer2's first bottleneck tail with its STRIDED shortcut convolution as extra K columns (the kernel's KB1 / s2 notes):
+//     C[(b, i, j), :] = relu?( [A[(b, i, j), :] | X[b, 2 i, 2 j, :]] Wp^T + bias )
+// A [B Hout Wout, 128] (the 3x3 stride-2 convolution's output), X [B, Hin, Win, 256] (the block input), Hout = (Hin - 1) / 2 + 1 (same for
+// W), Wp = dtlr_gemm_kres_pack_weights of W [512, 384] = [W3 | Wd], bias = b3 + bd, C [B Hout Wout, 512].
+extern "C" int dtlr_gemm_kres_cat_s2(const void* A, const void* X, const void* Wp, const float* bias, void* C, int B, int Hin, int Win, int relu,
+                                     void* stream)
+{
+    clear_stale_error();
+    if (!A || !X || !Wp || !C || B <= 0 || Hin <= 0 || Win <= 0) return DTLR_EINVAL;
+    const int Hout = (Hin - 1) / 2 + 1, Wout = (Win - 1) / 2 + 1;
+    const long Ml = (long)B * Hout * Wout;
+    if (Ml >= (1L << 31) || (long)B * Hin * Win >= (1L << 31)) return DTLR_ESHAPE;
+    const int M = (int)Ml, nslice = 2;
+    const int ntiles = (M + KR_TOK - 1) / KR_TOK;
+    int per_x = (ntiles * nslice + 255) / 256;
+    if (per_x < 1) per_x = 1;
+    const int gx = (ntiles + per_x - 1) / per_x;
+    constexpr int lds_ = 3 * (KR_TOK * 64 * 6 * 2);
+    static DevOnce once;
+    if (once.first()) { (void)hipFuncSetAttribute((const void*)gemm_kres_kernel<6, 1, 3, 0, 2, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, lds_); (void)hipGetLastError(); }
+    hipLaunchKernelGGL((gemm_kres_kernel<6, 1, 3, 0, 2, 0>), dim3(gx, nslice), dim3(512), lds_, (hipStream_t)stream, (const uint16_t*)A, (const uint16_t*)Wp, bias,
+                       (const uint16_t*)nullptr, (uint16_t*)C, 512, M, per_x, relu, 512, 0, 0, (const uint16_t*)X, (const uint16_t*)nullptr, (const float*)nullptr,
+                       (uint16_t*)nullptr, KrS2{Hout, Wout, Hin, Win});
     return check_launch();
 }
 

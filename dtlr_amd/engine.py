@@ -67,6 +67,7 @@ class DTLREngine:
         self.use_dec_query_stage = True   # 16-bit: a decoder layer's query stage (sine, ref_point_head, q | k, v) in one launch
         self.use_l1_chain = True          # 16-bit: layer1's 1x1 convolutions chained (shortcut conv as extra K columns; tail + next conv1 in one launch)
         self.use_l1_chain_out = True      #         ... including the last tail -> layer2.0.conv1
+        self.use_l2_cat = True            # 16-bit: layer2.0's strided shortcut convolution as extra K columns of its tail GEMM
 
     # ------------------------------------------------------------------------------ packing
     def _put(self, name, t, dtype=None):
@@ -362,11 +363,18 @@ class DTLREngine:
             for bi in range(nblocks):
                 q = f"l{li}.{bi}."
                 stride = 2 if (bi == 0 and li > 1) else 1
-                idt = self._conv(q + "ds", x, stride, 0) if bi == 0 else x
+                cat = li == 2 and bi == 0 and self.use_l2_cat and x.dtype in ops.H16 and x.shape[-1] == 256 and self.w[q + "c3.w"].shape == (512, 128)
+                idt = None if cat else (self._conv(q + "ds", x, stride, 0) if bi == 0 else x)
                 o = pre if pre is not None else self._conv(q + "c1", x, 1, 0, relu=True)
                 pre = None
                 o = self._conv(q + "c2", o, stride, 1, relu=True)
-                x = self._conv(q + "c3", o, 1, 0, relu=True, residual=idt)
+                if cat:       # the strided shortcut convolution as K columns 128..383 of the tail GEMM: no shortcut map, no gather launch
+                    if q + "cat.wk" not in self.w:
+                        self.w[q + "cat.wk"] = ops.kres_pack(torch.cat([self.w[q + "c3.w"], self.w[q + "ds.w"]], 1).contiguous())
+                        self.w[q + "cat.b"] = (self.w[q + "c3.b"].float() + self.w[q + "ds.b"].float()).contiguous()
+                    x = ops.gemm_kres_cat_s2(o, x, self.w[q + "cat.wk"], self.w[q + "cat.b"], relu=True)
+                else:
+                    x = self._conv(q + "c3", o, 1, 0, relu=True, residual=idt)
             if li >= 2:
                 outs.append(x)
         return outs

@@ -186,7 +186,7 @@ def kres_pack(w, np_pairs=None):
     if N in (64, 128, 192):                    # one zero-padded 256-channel column
         w = torch.cat([w.detach().to(_hdt(w)), torch.zeros((256 - N, K), dtype=_hdt(w), device=w.device)])
         N = 256
-    assert K in (64, 128, 256) and N % 256 == 0
+    assert K in (64, 128, 256, 384) and N % 256 == 0
     NP = np_pairs or (2 if (N % 512 == 0 and K <= 128) else 1)
     ns, KS = N // (256 * NP), K // 32
     # row index = 256 NP sl + 32 (wave NP + p) + 8 mh + 4 e + ml  with m = 4 mh + ml ; column = 32 ks + 8 g + x
@@ -253,6 +253,27 @@ def gemm_kres_chain(x, wp, b=None, x2=None, residual=None, relu: bool = True, wp
                                           0 if t is None else t.data_ptr(), n2, _lib.current_stream())
     _lib.check(code, "dtlr_gemm_kres_chain")
     return y, t
+
+
+def gemm_kres_cat_s2(t, x, wp, b=None, relu: bool = True):
+    """layer2's first bottleneck tail with the strided shortcut convolution as extra K columns (dtlr_gemm_kres_cat_s2):
+        y[b, i, j] = relu?([t[b, i, j] | x[b, 2 i, 2 j]] @ W.T + b),   W = [W3 | Wd] [512, 384], b = b3 + bd
+    t [B, Hout, Wout, 128], x [B, Hin, Win, 256] NHWC 16-bit, Hout = (Hin - 1) // 2 + 1; wp = kres_pack(W).  Returns y [B, Hout, Wout, 512]."""
+    require_cuda(t, "t")
+    assert t.dtype in H16 and x.dtype == t.dtype and wp.dtype == t.dtype and t.dim() == 4 and x.dim() == 4
+    B, Hin, Win, Cx = x.shape
+    Hout, Wout = (Hin - 1) // 2 + 1, (Win - 1) // 2 + 1
+    assert Cx == 256 and tuple(t.shape) == (B, Hout, Wout, 128) and wp.numel() == 512 * 384
+    t = t if t.is_contiguous() else t.contiguous()
+    x = x if x.is_contiguous() else x.contiguous()
+    b = None if b is None else (b if b.dtype == torch.float32 else b.float())
+    y = torch.empty((B, Hout, Wout, 512), dtype=t.dtype, device=t.device)
+    M = B * Hout * Wout
+    with _Timed("gemm_bf16", 2.0 * M * 512 * 384, float(M) * (128 + 256 + 512) * 2 + 512.0 * 384 * 2, f"kres_cat_s2 M{M} N512 K128+256s2"):
+        code = _L(t).dtlr_gemm_kres_cat_s2(t.data_ptr(), x.data_ptr(), wp.data_ptr(), 0 if b is None else b.data_ptr(), y.data_ptr(),
+                                           B, Hin, Win, 1 if relu else 0, _lib.current_stream())
+    _lib.check(code, "dtlr_gemm_kres_cat_s2")
+    return y
 
 
 def kres_pack_bcast384(w):
@@ -1044,7 +1065,7 @@ def _device_scoped(fn):
     return wrapper
 
 
-for _name in ("msda_encoder_far_fraction", "gemm_kres", "gemm_kres_chain", "gemm_kres_bcast384", "ffn32", "proj_ln_k256", "swin_patch_embed", "swin_window_attn", "swin_patch_merge", "geometry", "linear", "gemm_k256", "linear_rowmax", "two_stage_gather", "layernorm", "proj_ln", "proj_ln_split", "ffn_fused", "conv2d_nhwc", "stem_conv7x7", "stem_conv7x7_f32",
+for _name in ("msda_encoder_far_fraction", "gemm_kres", "gemm_kres_chain", "gemm_kres_cat_s2", "gemm_kres_bcast384", "ffn32", "proj_ln_k256", "swin_patch_embed", "swin_window_attn", "swin_patch_merge", "geometry", "linear", "gemm_k256", "linear_rowmax", "two_stage_gather", "layernorm", "proj_ln", "proj_ln_split", "ffn_fused", "conv2d_nhwc", "stem_conv7x7", "stem_conv7x7_f32",
               "maxpool_nhwc", "groupnorm_tokens", "msda", "msda_fused", "msda_encoder", "mha", "decoder_query_prep", "box_mlp_refine",
               "box_head_refine", "box_refine", "topk_rows", "decode_blank", "preprocess_lines", "ctc_loss_interleaved", "nms_batched",
               "topk_flat"):

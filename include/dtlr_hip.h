@@ -154,6 +154,13 @@ int dtlr_gemm_kres(const void *A, const void *Wp, const float *bias, const void 
  *   on the stored C; with R, C is bit-identical to dtlr_gemm_kres. */
 int dtlr_gemm_kres_chain(const void *A, const void *A2, const void *Wp, const float *bias, const void *R, void *C, int M, int relu,
                          const void *Wp2, const float *bias2, void *C2, int N2, void *stream);
+/* layer2's first bottleneck tail (torchvision resnet50 `layer2[0]`, stride on the 3x3: `out = relu(bn3(conv3(t)) + downsample(x))` with
+ * downsample = conv1x1 stride 2 + FrozenBN) as ONE GEMM: the strided shortcut convolution is K columns 128..383,
+ *     C[(b, i, j), :] = relu?( [A[(b, i, j), :] | X[b, 2 i, 2 j, :]] W^T + bias ),   W = [W3 | Wd] [512, 384], bias = b3 + bd
+ *   A [B Hout Wout, 128], X [B, Hin, Win, 256] NHWC, Hout = (Hin - 1) / 2 + 1, Wout likewise, C [B Hout Wout, 512];
+ *   Wp = device copy of dtlr_gemm_kres_pack_weights(W, 512, 384). */
+int dtlr_gemm_kres_cat_s2(const void *A, const void *X, const void *Wp, const float *bias, void *C, int B, int Hin, int Win, int relu,
+                          void *stream);
 /* The encoder's [sampling offsets | attention logits] projection (ops/modules/ms_deform_attn.py:97-98 on query = src + pos) for an
  * unpadded batch: (src + pos) W^T + b = src W^T + (pos W^T + b), the second term ONE [res_rows, 384] bf16 matrix shared by all images:
  *     C[m, :] = A[m, :] W^T + R[m % res_rows, :]        A [M, 256], C [M, 384] bf16

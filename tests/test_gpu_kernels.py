@@ -1192,3 +1192,27 @@ def test_gemm_kres_chain_equals_the_separate_launches(M, half):
     # and close to the separate launches (which round the shortcut map first)
     y_sep = ops.gemm_kres(t, ops.kres_pack(w3), 256, b3, ops.gemm_kres(x0, ops.kres_pack(wd), 256, bd, None, relu=False), relu=True)
     assert (y.float() - y_sep.float()).abs().max().item() <= want.abs().max().item() * ulp(half, 7)
+
+
+@pytest.mark.parametrize("B,Hin,Win", [(32, 32, 512), (2, 21, 332), (1, 5, 7), (3, 2, 2)])
+def test_gemm_kres_cat_s2_vs_reference(B, Hin, Win, half):
+    """dtlr_gemm_kres_cat_s2 (layer2.0's tail with the stride-2 shortcut convolution as K columns 128..383) against an fp64 restatement
+    of relu(bn3(conv3(t)) + downsample(x)) on the same 16-bit operands, and against the two separate launches (which round the shortcut
+    map to 16 bits first); odd input sizes (the eval canvas gives a 21 x 332 map), maps smaller than a 64-row tile."""
+    from dtlr_amd import ops
+    Hout, Wout = (Hin - 1) // 2 + 1, (Win - 1) // 2 + 1
+    t = torch.relu(_rand((B, Hout, Wout, 128), 1)).to(half).cuda()
+    x = torch.relu(_rand((B, Hin, Win, 256), 2)).to(half).cuda()
+    w3, wd = (_rand((512, 128), 3) / 11).to(half).cuda(), (_rand((512, 256), 4) / 16).to(half).cuda()
+    b3, bd = (_rand((512,), 5) * 0.2).cuda(), (_rand((512,), 6) * 0.2).cuda()
+    y = ops.gemm_kres_cat_s2(t, x, ops.kres_pack(torch.cat([w3, wd], 1).contiguous()), b3 + bd, relu=True)
+    assert tuple(y.shape) == (B, Hout, Wout, 512)
+    xs = x[:, ::2, ::2].double().cpu()
+    assert tuple(xs.shape[1:3]) == (Hout, Wout)
+    want = torch.relu(t.double().cpu() @ w3.double().cpu().t() + xs @ wd.double().cpu().t() + (b3 + bd).double().cpu())
+    scale = want.abs().max().item()
+    err = (y.double().cpu() - want).abs().max().item()
+    assert err <= scale * ulp(half, 8) + 1e-6, (err, scale)
+    idt = ops.conv2d_nhwc(x, wd.view(512, 1, 1, 256), bd, 2, 0, False, None)
+    y_sep = ops.gemm_kres(t.view(-1, 128), ops.kres_pack(w3), 512, b3, idt.reshape(-1, 512), relu=True).view_as(y)
+    assert (y.float() - y_sep.float()).abs().max().item() <= scale * ulp(half, 7)

@@ -555,6 +555,35 @@ def test_layer1_chain_backbone_equals_the_separate_convolutions(half):
         assert torch.equal(g, h.float())
 
 
+@pytest.mark.parametrize("half", ["bf16", "f16"])
+def test_layer2_cat_backbone_close_to_the_separate_convolutions(half):
+    """engine.use_l2_cat (layer2.0's strided shortcut convolution as extra K columns of its tail GEMM: dtlr_gemm_kres_cat_s2) against the
+    same engine with the shortcut as its own launch: the only numerical change is that the shortcut is no longer rounded to 16 bits
+    before the add, so the maps agree to a few 16-bit ulps and are no further from the fp32 engine's; full canvas and the odd-sized
+    eval canvas (83 x 1328 -> a 21 x 332 layer1 map)."""
+    from dtlr_amd.engine import DTLREngine
+    cfg = DTLRConfig.latin()
+    sd = weights.synthetic_state_dict(cfg, 0)
+    eng = DTLREngine(cfg, sd, "cuda:0", HALF[half])
+    e32 = DTLREngine(cfg, sd, "cuda:0", torch.float32)
+    u = 2.0 ** (-8 if half == "bf16" else -11)
+    for (H, W) in ((128, 2048), (83, 1328)):
+        x = torch.stack(synth.stroke_lines(2, H, W, seed=51) + synth.noise_lines(1, H, W, seed=52)).cuda()
+        eng.use_l2_cat = True
+        got = [f.float() for f in eng.backbone(x)]
+        eng.use_l2_cat = False
+        sep = [f.float() for f in eng.backbone(x)]
+        ref = e32.backbone(x)
+        for g, s_, r in zip(got, sep, ref):
+            scale = r.abs().max().item()
+            eg, es = (g - r).abs(), (s_ - r).abs()
+            print(f"[l2 cat, {half}, {H}x{W}] map {tuple(g.shape)}: |cat - sep| max {(g - s_).abs().max().item():.4g}, vs fp32: cat {eg.max().item():.4g} / "
+                  f"{eg.mean().item():.4g}, separate {es.max().item():.4g} / {es.mean().item():.4g} (scale {scale:.3g})")
+            assert g.shape == s_.shape and torch.isfinite(g).all()
+            assert eg.mean().item() <= 1.1 * es.mean().item() + 1e-6
+            assert eg.max().item() <= 64 * u * scale
+
+
 def test_rccl_collectives_on_a_one_rank_group():
     """The `nccl` (= RCCL) branch of dtlr_amd.dist -- all_gather_into_tensor of the decode records, the MAX all-reduce of the timing,
     the barrier -- on a world-size-1 group on the one GPU of the test box: the code path of the 8-GPU job has then executed before

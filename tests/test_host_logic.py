@@ -416,7 +416,7 @@ def test_weight_packers_tensor_ops_match_the_library_host_packers():
     assert L.dtlr_proj_ln_k256_pack_weights(u16(w).ctypes.data, out.ctypes.data) == 0
     assert np.array_equal(out, u16(ops.proj_ln_k256_pack(w)))
     for N, K in ((256, 64), (512, 128), (1024, 256), (2048, 256), (64, 256), (128, 256), (192, 128), (512, 64), (768, 256),
-                 (256, 128)):                  # [W3 | Wd] of the chained first bottleneck (dtlr_gemm_kres_chain)
+                 (256, 128), (512, 384)):      # [W3 | Wd] of the chained first bottleneck (dtlr_gemm_kres_chain) / of layer2.0 (dtlr_gemm_kres_cat_s2)
         w = torch.randn((N, K), generator=g).bfloat16()
         out = np.empty(max(N, 256) * K, dtype=np.uint16)
         assert L.dtlr_gemm_kres_pack_weights(u16(w).ctypes.data, out.ctypes.data, N, K) == 0
