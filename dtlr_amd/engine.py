@@ -357,7 +357,8 @@ class DTLREngine:
         outs = []
         pre = None                       # the NEXT bottleneck's conv1 output when the previous tail already computed it (layer1 chain)
         for li, nblocks in enumerate(self.cfg.backbone_blocks, start=1):
-            if li == 1 and self.use_l1_chain and x.dtype in ops.H16 and x.shape[-1] == 64 and x.numel() // 64 >= 16384:
+            if li == 1 and self.use_l1_chain and x.dtype in ops.H16 and x.shape[-1] == 64 and x.numel() // 64 >= 16384 \
+                    and self.w["l1.0.c3.w"].shape == (256, 64) and self.w["l1.0.ds.w"].shape == (256, 64):
                 x, pre = self._layer1_chain(x, nblocks)
                 continue
             for bi in range(nblocks):
@@ -399,8 +400,12 @@ class DTLREngine:
         o = self._conv("l1.0.c1", x0, 1, 0, relu=True)
         x = None
         for bi in range(nblocks):
+            if o is None:                       # the previous tail could not produce this block's conv1
+                o = self._conv(f"l1.{bi}.c1", x, 1, 0, relu=True)
             o = self._conv(f"l1.{bi}.c2", o, 1, 1, relu=True)
             nm = nxt[bi]
+            if nm is not None and (w[nm + ".w"].shape != (n2[bi], 256) or (bi == 0 and n2[bi] != 64)):
+                nm = None                       # a next conv1 the chain kernel has no form for (other widths; a one-block layer1): separate launch
             kw = dict(wp2=wk(nm), b2=w[nm + ".b"], n2=n2[bi]) if nm is not None else {}
             if bi == 0:
                 x, o = ops.gemm_kres_chain(o, w["l1.0.cat.wk"], w["l1.0.cat.b"], x2=x0, relu=True, **kw)
