@@ -448,3 +448,87 @@ def test_cpu_placement_helpers():
     assert D.split_cpus(cpus, 0, 1) == cpus
     info = D.pin_to_local_cpus(0, 1)                              # no GPU here: falls back to the current affinity, never raises
     assert "error" in info or info["cpus"] is not None
+
+
+@pytest.mark.parametrize("blocks,H,W", [((3, 2), 128, 128), ((1, 1), 128, 130), ((2, 1), 126, 134)])
+def test_backbone_chain_wiring_with_cpu_stand_ins_for_the_kernels(monkeypatch, blocks, H, W):
+    """The ENGINE side of the layer1 chain / layer2.0 K-concatenation (which tail feeds which conv1, the [W3 | Wd] weights and b3 + bd
+    biases, the strided shortcut's pixel map, the fall-backs for shapes the kernels have no form for), run on CPU with torch stand-ins
+    for the HIP operators: the chained backbone must equal the plain one-launch-per-convolution backbone up to the ONE rounding the
+    K-concatenation removes.  (The kernels themselves are checked on the GPU: test_gemm_kres_chain_*, test_gemm_kres_cat_s2_*.)"""
+    import torch.nn.functional as F
+    from dtlr_amd import ops
+    from dtlr_amd.engine import DTLREngine
+    g = torch.Generator().manual_seed(5)
+    bf = torch.bfloat16
+    w = {}
+
+    def conv_w(name, cout, cin, k):
+        t = torch.randn((cout, cin, k, k), generator=g) / (cin * k * k) ** 0.5
+        w[name + ".w"] = (t.flatten(1) if k == 1 else t.permute(0, 2, 3, 1).contiguous()).to(bf)       # 1x1: [Cout, Cin]; 3x3: OHWI
+        w[name + ".b"] = torch.randn((cout,), generator=g) * 0.1
+    widths = [(64, 64, 256), (256, 128, 512)]
+    for li, nb in enumerate(blocks, start=1):
+        cin, mid, cout = widths[li - 1]
+        for bi in range(nb):
+            conv_w(f"l{li}.{bi}.c1", mid, cin if bi == 0 else cout, 1)
+            conv_w(f"l{li}.{bi}.c2", mid, mid, 3)
+            conv_w(f"l{li}.{bi}.c3", cout, mid, 1)
+            if bi == 0:
+                conv_w(f"l{li}.{bi}.ds", cout, cin, 1)
+    calls = []
+
+    def lin(x, wt, b, residual=None, relu=True):           # fp32 accumulate, one 16-bit rounding at the end: what every kernel does
+        y = x.float() @ wt.float().t() + b
+        y = y + residual.float() if residual is not None else y
+        return (torch.relu(y) if relu else y).to(bf)
+
+    def fake_conv(self, name, x, stride, padding, relu=False, residual=None):
+        wt = self.w[name + ".w"]
+        calls.append(name)
+        if wt.dim() == 2:
+            return lin(x[:, ::stride, ::stride], wt, self.w[name + ".b"], residual, relu)
+        y = F.conv2d(x.float().permute(0, 3, 1, 2), wt.float().permute(0, 3, 1, 2), self.w[name + ".b"], stride=stride, padding=padding).permute(0, 2, 3, 1)
+        return (torch.relu(y) if relu else y).to(bf)
+
+    def fake_chain(x, wp, b=None, x2=None, residual=None, relu=True, wp2=None, b2=None, n2=0):
+        calls.append(f"chain{'+cat' if x2 is not None else '+res'}->{n2}")
+        assert (x2 is None) != (residual is None) and wp.shape == (256, 128 if x2 is not None else 64)
+        y = lin(torch.cat([x, x2], -1) if x2 is not None else x, wp, b, residual, relu)
+        if wp2 is None:
+            return y, None
+        assert wp2.shape == (n2, 256) and (x2 is None or n2 == 64)
+        return y, lin(y, wp2, b2)
+
+    def fake_cat_s2(t, x, wp, b=None, relu=True):
+        calls.append("cat_s2")
+        assert wp.shape == (512, 384) and t.shape[1:3] == ((x.shape[1] - 1) // 2 + 1, (x.shape[2] - 1) // 2 + 1)
+        return lin(torch.cat([t, x[:, ::2, ::2]], -1), wp, b, None, relu)
+    monkeypatch.setattr(ops, "kres_pack", lambda wt, np_pairs=None: wt)
+    monkeypatch.setattr(ops, "gemm_kres_chain", fake_chain)
+    monkeypatch.setattr(ops, "gemm_kres_cat_s2", fake_cat_s2)
+    x0 = torch.relu(torch.randn((1, H, W, 64), generator=g)).to(bf)
+    monkeypatch.setattr(ops, "stem_conv7x7_pool", lambda *a, **k: x0)
+    monkeypatch.setattr(DTLREngine, "_conv", fake_conv)
+    eng = object.__new__(DTLREngine)
+    eng.w, eng.dtype, eng.use_stem_pool = dict(w, **{"conv1.frag": None, "conv1.b": None}), bf, True
+    eng.cfg = type("Cfg", (), {"backbone_blocks": blocks})()
+
+    def run(chain, chain_out, cat):
+        eng.use_l1_chain, eng.use_l1_chain_out, eng.use_l2_cat = chain, chain_out, cat
+        calls.clear()
+        return [t.float() for t in eng.backbone(None)], list(calls)
+    plain, plain_calls = run(False, False, False)
+    assert not any(c.startswith(("chain", "cat")) for c in plain_calls) and "l1.0.ds" in plain_calls and "l2.0.ds" in plain_calls
+    for flags in ((True, True, True), (True, False, True), (True, True, False), (False, False, True)):
+        got, cl = run(*flags)
+        chain, chain_out, cat = flags
+        assert len(got) == len(plain) == 1 and got[0].shape == plain[0].shape
+        scale = plain[0].abs().max().item()
+        assert (got[0] - plain[0]).abs().max().item() <= 2.0 ** -5 * scale, (flags, (got[0] - plain[0]).abs().max().item(), scale)
+        if chain:
+            assert "l1.0.ds" not in cl and sum(c.startswith("chain") for c in cl) >= 1 and cl.count("chain+cat->64" if blocks[0] > 1 else "chain+cat->0") == 1
+            assert ("l2.0.c1" in cl) != (chain_out and blocks[0] > 1)          # the last tail feeds layer2.0.conv1 -- except from a one-block layer1
+            for bi in range(1, blocks[0]):
+                assert f"l1.{bi}.c1" not in cl                                 # every inner conv1 came out of the previous tail
+        assert ("cat_s2" in cl) == cat and ("l2.0.ds" in cl) == (not cat)
