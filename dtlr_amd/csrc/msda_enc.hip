@@ -445,6 +445,165 @@ __device__ __forceinline__ void enc_queries_bf16_h(
     }
 }
 
+// ---- bf16 query phase, third form: the second form with fewer VALU instructions per lane -------------------------------------
+// NOT the default: selected only through dtlr_msda_encoder_set_variant(3) (tools/msda_sweep.py, tests) until it has been timed.  The
+// kernel is VALU-issue-bound (SQ counters: ~96% of its duration), so the instruction count of this loop is its cost model
+// (tools/isa_mix.py).  Changes against the second form, none of which touches the data layout:
+//   * geometry as in msda_fused_quad_bf16_kernel: the coordinate is clamped to [-1, size] (one v_med3), a corner's validity is ONE
+//     unsigned compare per axis, applied to the separable weights -- no `inside` mask, no per-corner compare / s_and chains; a point
+//     outside the map gets zero weights on valid (clamped) addresses, and a NaN offset clamps to -1 = zero weights as before;
+//   * the softmax normalisation is v_rcp_f32 (1 ulp) instead of the IEEE division sequence (12 instructions);
+//   * two corner weights per v_cvt_pk_f16_f32, broadcast into v_pk_fma_f16 through op_sel instead of four splat conversions.
+// Results: same tolerance against the oracle as the second form; not bit-identical to it (fp32 product order of the weights).
+__device__ __forceinline__ uint32_t pk_fma_h2_bl(uint32_t w2, uint32_t d, uint32_t acc) {      // both halves of d times the LOW half of w2
+    uint32_t r;
+    asm("v_pk_fma_f16 %0, %1, %2, %3 op_sel:[0,0,0] op_sel_hi:[0,1,1]" : "=v"(r) : "v"(w2), "v"(d), "v"(acc));
+    return r;
+}
+__device__ __forceinline__ uint32_t pk_fma_h2_bh(uint32_t w2, uint32_t d, uint32_t acc) {      // ... times the HIGH half of w2
+    uint32_t r;
+    asm("v_pk_fma_f16 %0, %1, %2, %3 op_sel:[1,0,0] op_sel_hi:[1,1,1]" : "=v"(r) : "v"(w2), "v"(d), "v"(acc));
+    return r;
+}
+__device__ __forceinline__ uint32_t h2_pair(float a, float b) {
+    const enc_f2_t f = {a, b};
+    return __builtin_bit_cast(uint32_t, __builtin_convertvector(f, enc_h2_t));
+}
+__device__ __forceinline__ int clamp0_i32(int v, int hi) {                                    // min(max(v, 0), hi), hi >= 0: one v_med3_i32
+    int r;
+    asm("v_med3_i32 %0, %1, 0, %2" : "=v"(r) : "v"(v), "v"(hi));
+    return r;
+}
+
+template <typename OT, int NT>
+__device__ __forceinline__ void enc_queries_bf16_h3(
+    const unsigned char* smem, const int* tok, const uint16_t* __restrict__ vimg, const OT* __restrict__ ow, const float* __restrict__ ref,
+    uint16_t* __restrict__ out, const EncLevels lv, const int (&wc0)[4], const int (&wc1)[4], int nq, int S, int M, int m, int b)
+{
+    const int tid = threadIdx.x, p = tid & 3;
+    const int MD = M * 32;
+    const int Hl = p == 0 ? lv.H[0] : p == 1 ? lv.H[1] : p == 2 ? lv.H[2] : lv.H[3];
+    const int Wl = p == 0 ? lv.W[0] : p == 1 ? lv.W[1] : p == 2 ? lv.W[2] : lv.W[3];
+    const int startl = p == 0 ? lv.start[0] : p == 1 ? lv.start[1] : p == 2 ? lv.start[2] : lv.start[3];
+    const int loffl = p == 0 ? lv.loff[0] : p == 1 ? lv.loff[1] : p == 2 ? lv.loff[2] : lv.loff[3];
+    const int wstride = p == 0 ? lv.wmax[0] : p == 1 ? lv.wmax[1] : p == 2 ? lv.wmax[2] : lv.wmax[3];
+    const int wc0l = p == 0 ? wc0[0] : p == 1 ? wc0[1] : p == 2 ? wc0[2] : wc0[3];
+    const int wc1l = p == 0 ? wc1[0] : p == 1 ? wc1[1] : p == 2 ? wc1[2] : wc1[3];
+    const int wwl = wc1l - wc0l;
+    const float fH = (float)Hl, fW = (float)Wl;
+    const float invH = 1.0f / fH, invW = 1.0f / fW;
+    const unsigned char* win = smem + (long)loffl * 64;
+    const uint16_t* gsrc = vimg + (long)startl * MD;
+    int rot[4];
+#pragma unroll
+    for (int jj = 0; jj < 4; ++jj) rot[jj] = ((jj + p) & 3) * 16;
+
+    auto token_of = [&](int it) -> long { return (long)b * S + tok[it >> 2]; };
+    const int total = nq * 4;
+    if (tid >= total) return;
+    long bq = token_of(tid);
+    RowRaw<OT> cur, nxt;
+    float2 rf, rf_n;
+    cur.load(ow + bq * (long)(M * 48), M, m, p);
+    rf = *reinterpret_cast<const float2*>(ref + bq * 8 + 2 * p);
+
+    for (int it = tid; it < total; it += NT) {
+        const int itn = it + NT < total ? it + NT : it;
+        const long bqn = token_of(itn);
+        nxt.load(ow + bqn * (long)(M * 48), M, m, p);
+        rf_n = *reinterpret_cast<const float2*>(ref + bqn * 8 + 2 * p);
+
+        float off[8], lg[4];
+        cur.get(off, lg);
+        float mx = fmaxf(fmaxf(lg[0], lg[1]), fmaxf(lg[2], lg[3]));
+        mx = fmaxf(mx, quad_dpp<0xB1>(mx));
+        mx = fmaxf(mx, quad_dpp<0x4E>(mx));
+        float sum = 0.f;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) { lg[i] = __expf(lg[i] - mx); sum += lg[i]; }
+        sum += quad_dpp<0xB1>(sum);
+        sum += quad_dpp<0x4E>(sum);
+        const float inv = __builtin_amdgcn_rcpf(sum);
+
+        uint32_t acc[4][4];
+#pragma unroll
+        for (int jj = 0; jj < 4; ++jj)
+#pragma unroll
+            for (int i = 0; i < 4; ++i) acc[jj][i] = 0u;
+#define DTLR_ACC_H3(FMA, D, W2)                                                                    \
+        _Pragma("unroll") for (int jj = 0; jj < 4; ++jj) {                                         \
+            acc[jj][0] = FMA((W2), D[jj].x, acc[jj][0]);                                           \
+            acc[jj][1] = FMA((W2), D[jj].y, acc[jj][1]);                                           \
+            acc[jj][2] = FMA((W2), D[jj].z, acc[jj][2]);                                           \
+            acc[jj][3] = FMA((W2), D[jj].w, acc[jj][3]);                                           \
+        }
+#pragma unroll
+        for (int pt = 0; pt < 4; ++pt) {
+            const float lx = rf.x + off[2 * pt] * invW;
+            const float ly = rf.y + off[2 * pt + 1] * invH;
+            // v_med3_f32: a NaN operand yields min3 of the others = -1 (zero weights), like fminf(fmaxf(x, -1), size)
+            const float h_im = __builtin_amdgcn_fmed3f(ly * fH - 0.5f, -1.f, fH), w_im = __builtin_amdgcn_fmed3f(lx * fW - 0.5f, -1.f, fW);
+            const float hf = floorf(h_im), wf = floorf(w_im);
+            const int h_low = (int)hf, w_low = (int)wf;
+            const float lh = h_im - hf, lw = w_im - wf;
+            const float a = lg[pt] * inv;
+            const float wy0 = (unsigned)h_low < (unsigned)Hl ? 1.f - lh : 0.f, wy1 = (unsigned)(h_low + 1) < (unsigned)Hl ? lh : 0.f;
+            const float wx0 = (unsigned)w_low < (unsigned)Wl ? (1.f - lw) * a : 0.f, wx1 = (unsigned)(w_low + 1) < (unsigned)Wl ? lw * a : 0.f;
+            const uint32_t k12 = h2_pair(wy0 * wx0, wy0 * wx1), k34 = h2_pair(wy1 * wx0, wy1 * wx1);
+            const int h0 = clamp0_i32(h_low, Hl - 1), h1 = clamp0_i32(h_low + 1, Hl - 1);
+            const int w0 = clamp0_i32(w_low, Wl - 1), w1c = clamp0_i32(w_low + 1, Wl - 1);
+            if ((w0 >= wc0l) && (w1c < wc1l)) {
+                const unsigned char* r0 = win + (h0 * wstride) * 64;
+                const unsigned char* r1 = win + (h1 * wstride) * 64;
+                const int a0 = (w0 - wc0l) * 64, a1 = (w1c - wc0l) * 64;
+                {
+                    uint4 d1[4], d2[4];
+#pragma unroll
+                    for (int jj = 0; jj < 4; ++jj) {
+                        d1[jj] = *reinterpret_cast<const uint4*>(r0 + a0 + rot[jj]);
+                        d2[jj] = *reinterpret_cast<const uint4*>(r0 + a1 + rot[jj]);
+                    }
+                    DTLR_ACC_H3(pk_fma_h2_bl, d1, k12) DTLR_ACC_H3(pk_fma_h2_bh, d2, k12)
+                }
+                __builtin_amdgcn_sched_barrier(0);
+                {
+                    uint4 d3[4], d4[4];
+#pragma unroll
+                    for (int jj = 0; jj < 4; ++jj) {
+                        d3[jj] = *reinterpret_cast<const uint4*>(r1 + a0 + rot[jj]);
+                        d4[jj] = *reinterpret_cast<const uint4*>(r1 + a1 + rot[jj]);
+                    }
+                    DTLR_ACC_H3(pk_fma_h2_bl, d3, k34) DTLR_ACC_H3(pk_fma_h2_bh, d4, k34)
+                }
+            } else {                                            // outside the staged window: global path (clamped, valid addresses)
+#pragma unroll
+                for (int jj = 0; jj < 4; ++jj) {
+                    const int pe = rot[jj] >> 1;
+                    const uint4 e1 = stage_convert<uint16_t>(*reinterpret_cast<const uint4*>(gsrc + (long)(h0 * Wl + w0) * MD + pe));
+                    const uint4 e2 = stage_convert<uint16_t>(*reinterpret_cast<const uint4*>(gsrc + (long)(h0 * Wl + w1c) * MD + pe));
+                    const uint4 e3 = stage_convert<uint16_t>(*reinterpret_cast<const uint4*>(gsrc + (long)(h1 * Wl + w0) * MD + pe));
+                    const uint4 e4 = stage_convert<uint16_t>(*reinterpret_cast<const uint4*>(gsrc + (long)(h1 * Wl + w1c) * MD + pe));
+                    acc[jj][0] = pk_fma_h2_bh(k34, e4.x, pk_fma_h2_bl(k34, e3.x, pk_fma_h2_bh(k12, e2.x, pk_fma_h2_bl(k12, e1.x, acc[jj][0]))));
+                    acc[jj][1] = pk_fma_h2_bh(k34, e4.y, pk_fma_h2_bl(k34, e3.y, pk_fma_h2_bh(k12, e2.y, pk_fma_h2_bl(k12, e1.y, acc[jj][1]))));
+                    acc[jj][2] = pk_fma_h2_bh(k34, e4.z, pk_fma_h2_bl(k34, e3.z, pk_fma_h2_bh(k12, e2.z, pk_fma_h2_bl(k12, e1.z, acc[jj][2]))));
+                    acc[jj][3] = pk_fma_h2_bh(k34, e4.w, pk_fma_h2_bl(k34, e3.w, pk_fma_h2_bh(k12, e2.w, pk_fma_h2_bl(k12, e1.w, acc[jj][3]))));
+                }
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        }
+#undef DTLR_ACC_H3
+        float res[8];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const uint32_t t3 = quad_dpp_u<0x39>(acc[3][i]), t2 = quad_dpp_u<0x4E>(acc[2][i]), t1 = quad_dpp_u<0x93>(acc[1][i]);
+            res[2 * i] = fma_mix_lo(1.f, t1, fma_mix_lo(1.f, t2, fma_mix_lo(1.f, t3, fma_mix_lo(1.f, acc[0][i], 0.f))));
+            res[2 * i + 1] = fma_mix_hi(1.f, t1, fma_mix_hi(1.f, t2, fma_mix_hi(1.f, t3, fma_mix_hi(1.f, acc[0][i], 0.f))));
+        }
+        *reinterpret_cast<uint4*>(out + bq * MD + m * 32 + p * 8) = ET<uint16_t>::pack(res);
+        cur = nxt; rf = rf_n; bq = bqn;
+    }
+}
+
 template <typename T, typename OT, int VAR = 0, int NT = 256>
 __global__ __launch_bounds__(NT, NT / 128) void msda_enc_lds_kernel(
     const T* __restrict__ value, const OT* __restrict__ ow, const float* __restrict__ ref, T* __restrict__ out,
@@ -517,7 +676,8 @@ __global__ __launch_bounds__(NT, NT / 128) void msda_enc_lds_kernel(
 
     if constexpr (sizeof(T) == 2) {
         if constexpr (VAR == 0) enc_queries_bf16<OT>(smem, vimg, ow, ref, out, lv, qc0, qn, wc0, wc1, qbase, nq, S, M, m, b);
-        else enc_queries_bf16_h<OT, NT>(smem, reinterpret_cast<const int*>(smem + tok_off), vimg, ow, ref, out, lv, qc0, qn, wc0, wc1, qbase, nq, S, M, m, b);
+        else if constexpr (VAR == 1) enc_queries_bf16_h<OT, NT>(smem, reinterpret_cast<const int*>(smem + tok_off), vimg, ow, ref, out, lv, qc0, qn, wc0, wc1, qbase, nq, S, M, m, b);
+        else enc_queries_bf16_h3<OT, NT>(smem, reinterpret_cast<const int*>(smem + tok_off), vimg, ow, ref, out, lv, wc0, wc1, nq, S, M, m, b);
         return;
     }
     static_assert(sizeof(T) == 2 || NT == 256, "the fp32 query phase strides by 256");
@@ -749,10 +909,10 @@ static int launch_enc(const void* value, const void* ow, const float* ref, void*
     return check_launch();
 }
 // bf16 query-phase variant: env DTLR_MSDA_ENC_V = 0 first form (fp32 accumulators, v_fma_mix), 1 packed-fp16 form with 256 threads,
-// 2 the same with 512 threads per workgroup (default); read once per process.
+// 2 the same with 512 threads per workgroup (default), 3 the third form (fewer VALU instructions, 512 threads; not yet timed); read once per process.
 static int g_enc_variant = -1;
 static int enc_variant() {
-    if (g_enc_variant < 0) { const int v = exp_env_int("DTLR_MSDA_ENC_V", 2); g_enc_variant = (v >= 0 && v <= 2) ? v : 2; }
+    if (g_enc_variant < 0) { const int v = exp_env_int("DTLR_MSDA_ENC_V", 2); g_enc_variant = (v >= 0 && v <= 3) ? v : 2; }
     return g_enc_variant;
 }
 
@@ -764,7 +924,7 @@ using namespace dtlr;
 extern "C" int dtlr_msda_encoder_set_variant(int v)
 {
     const int old = enc_variant();
-    if (v >= 0 && v <= 2) g_enc_variant = v;
+    if (v >= 0 && v <= 3) g_enc_variant = v;
     return old;
 }
 
@@ -815,11 +975,13 @@ extern "C" int dtlr_msda_encoder_forward(const void* value, const void* ow, cons
     if (dtype == DTLR_H16 && ow_dtype == DTLR_F32) {
         if (enc_variant() == 0) return launch_enc<uint16_t, float>(value, ow, ref, out, pl, N, M, st);
         if (enc_variant() == 1) return launch_enc<uint16_t, float, 1, 256>(value, ow, ref, out, pl, N, M, st);
+        if (enc_variant() == 3) return launch_enc<uint16_t, float, 2, 512>(value, ow, ref, out, pl, N, M, st);
         return launch_enc<uint16_t, float, 1, 512>(value, ow, ref, out, pl, N, M, st);
     }
     if (dtype == DTLR_H16 && ow_dtype == DTLR_H16) {
         if (enc_variant() == 0) return launch_enc<uint16_t, uint16_t>(value, ow, ref, out, pl, N, M, st);
         if (enc_variant() == 1) return launch_enc<uint16_t, uint16_t, 1, 256>(value, ow, ref, out, pl, N, M, st);
+        if (enc_variant() == 3) return launch_enc<uint16_t, uint16_t, 2, 512>(value, ow, ref, out, pl, N, M, st);
         return launch_enc<uint16_t, uint16_t, 1, 512>(value, ow, ref, out, pl, N, M, st);
     }
     return DTLR_EDTYPE;

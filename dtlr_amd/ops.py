@@ -781,6 +781,13 @@ def msda_encoder_fits(level_hw, dtype, halo: Optional[int] = None) -> bool:
     return rc == 1
 
 
+def msda_encoder_set_variant(v: int, dtype=None) -> int:
+    """Select the 16-bit query-phase form of the LDS-window encoder kernel for subsequent launches of the library that serves `dtype`
+    (dtlr_msda_encoder_set_variant: 0 fp32 accumulators, 1 / 2 packed-fp16 accumulation with 256 / 512 threads -- 2 is the default --,
+    3 the instruction-lean form that has not been timed yet); a measurement / test knob, never called by the engine.  Returns the previous value."""
+    return int(_lib.lib(dtype).dtlr_msda_encoder_set_variant(int(v)))
+
+
 def msda_encoder(value, level_hw, ow, ref, halo: Optional[int] = None):
     """Encoder MSDA (Lq == S, queries are the level pixels) with LDS-staged value windows.
     value [N,S,M,32] fp32/bf16; level_hw: HOST list of (H_l, W_l); ow [N,S,M*48]; ref [N,S,4,2] fp32."""

@@ -1216,3 +1216,41 @@ def test_gemm_kres_cat_s2_vs_reference(B, Hin, Win, half):
     idt = ops.conv2d_nhwc(x, wd.view(512, 1, 1, 256), bd, 2, 0, False, None)
     y_sep = ops.gemm_kres(t.view(-1, 128), ops.kres_pack(w3), 512, b3, idt.reshape(-1, 512), relu=True).view_as(y)
     assert (y.float() - y_sep.float()).abs().max().item() <= scale * ulp(half, 7)
+
+
+@pytest.mark.skipif(os.environ.get("DTLR_TEST_UNTIMED_VARIANTS") != "1",
+                    reason="variant 3 of the encoder MSDA query phase was written after the round's GPU budget was spent: it is not the default "
+                           "and has not run on hardware yet; set DTLR_TEST_UNTIMED_VARIANTS=1 to test it")
+@pytest.mark.parametrize("level_hw,offscale", [([(16, 256), (8, 128), (4, 64), (2, 32)], 2.0), ([(16, 256), (8, 128), (4, 64), (2, 32)], 40.0),
+                                               ([(5, 83), (3, 42), (2, 21), (1, 11)], 3.0), ([(1, 7), (1, 4), (1, 2), (1, 1)], 1.0)])
+def test_msda_encoder_lds_variant3_vs_oracle(level_hw, offscale, half):
+    """Variant 3 of the 16-bit query phase (dtlr_msda_encoder_set_variant(3): coordinate clamp + one unsigned compare per axis, v_rcp_f32
+    softmax normalisation, paired weight conversions broadcast through op_sel; 654 VALU instructions per lane-iteration against 747,
+    tools/isa_mix.py) against the oracle at the tolerance of the default form, for both projection-row dtypes, including samples
+    outside the map and outside the staged windows; and close to the default form."""
+    from dtlr_amd import ops
+    from oracle import dtlr_oracle as O
+    N, M, D, L, P = 2, 8, 32, 4, 4
+    S = sum(h * w for h, w in level_hw)
+    v, s, lsi, _, _ = msda_inputs(N, M, D, S, P, level_hw, seed=13)
+    ow = _rand((N, S, M * L * P * 3), 15)
+    ow[..., : M * L * P * 2] *= offscale
+    vr = torch.tensor([[[1.0, 1.0]] * 4, [[0.75, 1.0]] * 4])
+    ref = O.encoder_reference_points(s, vr).contiguous()
+    vv = v.to(half)
+    old = ops.msda_encoder_set_variant(3, half)
+    try:
+        for owx in (ow, ow.to(half)):
+            off = owx.float()[..., : M * L * P * 2].view(N, S, M, L, P, 2)
+            aw = torch.softmax(owx.float()[..., M * L * P * 2:].view(N, S, M, L * P), -1).view(N, S, M, L, P)
+            want = O.ms_deform_attn_core(vv.float(), s, O.msda_sampling_locations(ref, off, s, P), aw)
+            ops.msda_encoder_set_variant(3, half)
+            got = ops.msda_encoder(vv.cuda(), level_hw, owx.cuda(), ref.cuda()).float().cpu()
+            ops.msda_encoder_set_variant(2, half)
+            dflt = ops.msda_encoder(vv.cuda(), level_hw, owx.cuda(), ref.cuda()).float().cpu()
+            tol = want.abs().max() * (ulp(half, 8) + 2.0 ** -9 if half == torch.bfloat16 else 2.0 ** -8) + 16 * 2.0 ** -24
+            assert torch.isfinite(got).all()
+            assert (got - want).abs().max() <= tol, (owx.dtype, (got - want).abs().max().item(), tol.item())
+            assert (got - dflt).abs().max() <= tol
+    finally:
+        ops.msda_encoder_set_variant(old, half)

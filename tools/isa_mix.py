@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Static instruction mix of a kernel's loops from the gfx950 assembly hipcc emits (no GPU needed).
-    python tools/isa_mix.py dtlr_amd/csrc/msda_enc.hip msda_enc_lds_kernelIttLi1ELi512E [--defs -DDTLR_HALF_IS_F16] [--top 40]
+    python tools/isa_mix.py dtlr_amd/csrc/msda_enc.hip msda_enc_lds_kernelIttLi1ELi512E [--defs=-DDTLR_HALF_IS_F16] [--top 40]
 Compiles the file with --save-temps into a scratch directory, finds the first kernel whose mangled name contains the pattern,
 lists its loops (backward branches) with VALU / SALU / LDS / VMEM counts and prints the opcode histogram of the longest one.
 For a VALU-issue-bound kernel (msda_enc_lds_kernel: SQ counters put VALU issue at ~96% of its duration) the VALU count of the

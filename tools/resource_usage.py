@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Static resource table of every kernel in dtlr_amd/csrc (no GPU): VGPRs, AGPRs, SGPR / VGPR spills, scratch bytes, LDS, occupancy, as
 hipcc's -Rpass-analysis=kernel-resource-usage reports them for gfx950.
-    python tools/resource_usage.py [--defs -DDTLR_HALF_IS_F16] [--min-vgprs 0] > profiles/rNN_kernel_resources.txt
+    python tools/resource_usage.py [--defs=-DDTLR_HALF_IS_F16] [--min-vgprs 0] > profiles/rNN_kernel_resources.txt
 A kernel with scratch > 0 spills registers to memory: none of the hot kernels may (the last column flags it)."""
 import argparse
 import concurrent.futures as cf
