@@ -65,6 +65,7 @@ _SIGNATURES = {
     "dtlr_proj_ln_split_bf16": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_float, c_void_p, c_int, c_int, c_void_p]),
     "dtlr_mha_forward": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p]),
     "dtlr_mha_workspace_bytes": (ctypes.c_long, [c_int, c_int, c_int, c_int]),
+    "dtlr_mha_set_variant": (c_int, [c_int]),
     "dtlr_gemm_nt": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
                              c_int, c_int, c_int, c_int, c_int, c_int, c_void_p]),
     "dtlr_k256_pack_weights": (c_int, [c_void_p, c_void_p, c_int]),

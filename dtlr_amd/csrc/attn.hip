@@ -255,6 +255,141 @@ __global__ __launch_bounds__(1024) void mha_fwd_bf16_lds_kernel(const uint16_t* 
     }
 }
 
+// ---- the same kernel with a TWO-PASS softmax (dtlr_mha_set_variant(1); NOT the default, not timed yet) ------------------------------
+// The LDS-staged kernel is bound by the softmax's VALU work (tools/isa_mix.py: 125 VALU instructions against 8 MFMAs per 32-key block,
+// the matrix pipe idles ~80%), and a good third of that work exists only because the row maximum is not known in advance: the per-block
+// cross-lane max reduction, exp2 of the correction, the rescaling of the 16 accumulator registers and of the running sum.  Pass 1
+// recomputes Q K^T (4 MFMAs per block, on the idle pipe) and keeps only the row maximum; pass 2 is exp2(s c - m) with the FINAL
+// maximum and (V^T | 1) P -- the row sums come out of the matrix pipe as a third output tile: the softmax the reference computes (one
+// subtraction of the global maximum), with fewer roundings than the online form.  Staging and operand layouts are those of mha_fwd_bf16_lds_kernel (kept as a separate copy so that the default
+// kernel's instruction stream does not change: tools/isa_diff.py).
+__global__ __launch_bounds__(1024) void mha_fwd_bf16_lds2_kernel(const uint16_t* __restrict__ qk, const uint16_t* __restrict__ v,
+                                                               uint16_t* __restrict__ out, int L, int Lpad, int H,
+                                                               float scale_log2e)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_att[];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int g = lane >> 4, n = lane & 15;
+    const int h = blockIdx.x, b = blockIdx.y;
+    const int C = H * 32;
+    const uint16_t* qkb = qk + (long)b * L * (2 * C);
+    const uint16_t* vb = v + (long)b * L * C;
+    const int nkb = Lpad / 32;                               // key blocks
+    unsigned char* kimg = smem_att;                          // nkb * 2 KB
+    unsigned char* vimg = smem_att + (long)nkb * 2048;       // nkb * 2 KB
+    // ---- stage: fragment f of the K image = (tile t = f), of the V^T image = (j, dt); 16 waves-worth per pass ----
+    for (int f = wave; f < 2 * nkb; f += 16) {
+        const int key = min(f * 16 + n, L - 1);
+        const uint4 kd = *reinterpret_cast<const uint4*>(qkb + (long)key * (2 * C) + C + h * 32 + 8 * g);
+        *reinterpret_cast<uint4*>(kimg + f * 1024 + lane * 16) = kd;
+        // V^T fragment (j, dt) gathered straight from v [B, L, C] (the transpose happens here, once per workgroup: no separate
+        // transpose pass): lane (g, n) <- V[32 j + 4 g + r][16 dt + n] (r = 0..3) | V[32 j + 16 + 4 g + r][16 dt + n]; keys >= L -> 0
+        const int j = f >> 1, dt = f & 1;
+        const uint16_t* vc = vb + h * 32 + dt * 16 + n;
+        uint32_t e[8];
+#pragma unroll
+        for (int r = 0; r < 8; ++r) {
+            const int key = j * 32 + (r >> 2) * 16 + 4 * g + (r & 3);
+            e[r] = key < L ? (uint32_t)vc[(long)key * C] : 0u;
+        }
+        *reinterpret_cast<uint4*>(vimg + f * 1024 + lane * 16) =
+            make_uint4(e[0] | (e[1] << 16), e[2] | (e[3] << 16), e[4] | (e[5] << 16), e[6] | (e[7] << 16));
+    }
+    __syncthreads();
+    const int nqb = (L + 31) / 32;                           // query blocks of 32
+    // a third "d tile" of V^T whose row 0 is all ones: (V^T | 1) P yields the row sums of the ROUNDED probabilities -- the very values the
+    // numerator multiplies -- from the idle matrix pipe instead of 16 v_add_f32 per key block
+    const uint32_t one2 = n == 0 ? ((uint32_t)H16_ONE | ((uint32_t)H16_ONE << 16)) : 0u;
+    const bf16x8 ones_f = __builtin_bit_cast(bf16x8, make_uint4(one2, one2, one2, one2));
+    for (int qb = wave; qb < nqb; qb += 16) {
+        const int q0 = qb * 32;
+        bf16x8 qf[2];
+#pragma unroll
+        for (int qt = 0; qt < 2; ++qt) {
+            const int q = min(q0 + qt * 16 + n, L - 1);
+            qf[qt] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const uint4*>(qkb + (long)q * (2 * C) + h * 32 + 8 * g));
+        }
+        f32x4 o[2][2];
+#pragma unroll
+        for (int qt = 0; qt < 2; ++qt)
+#pragma unroll
+            for (int dt = 0; dt < 2; ++dt) o[qt][dt] = f32x4{0.f, 0.f, 0.f, 0.f};
+        float m[2];
+        f32x4 osum[2] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};    // row 0 = the row sums of P (see ones_f)
+        // ---- pass 1: row maxima (raw scores; the scale is positive, so it commutes with the maximum) ----
+        float mraw[2] = {-INFINITY, -INFINITY};
+#define MHA_MAX_BLOCK(J, MASKED)                                                                   \
+        {                                                                                      \
+            const int kb = (J) * 32;                                                           \
+            bf16x8 kf[2];                                                                      \
+            _Pragma("unroll") for (int t = 0; t < 2; ++t)                                      \
+                kf[t] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const uint4*>(kimg + (2 * (J) + t) * 1024 + lane * 16)); \
+            _Pragma("unroll") for (int qt = 0; qt < 2; ++qt) {                                 \
+                f32x4 sc[2];                                                                   \
+                _Pragma("unroll") for (int kt = 0; kt < 2; ++kt)                               \
+                    sc[kt] = DTLR_MFMA_16x16x32_H16(kf[kt], qf[qt], f32x4{0.f, 0.f, 0.f, 0.f}, 0, 0, 0); \
+                if (MASKED) {                                                                  \
+                    _Pragma("unroll") for (int kt = 0; kt < 2; ++kt)                           \
+                        _Pragma("unroll") for (int r = 0; r < 4; ++r)                          \
+                            if (kb + kt * 16 + 4 * g + r >= L) sc[kt][r] = -INFINITY;          \
+                }                                                                              \
+                mraw[qt] = fmaxf(fmaxf(fmaxf(fmaxf(sc[0][0], sc[0][1]), fmaxf(sc[0][2], sc[0][3])), \
+                                       fmaxf(fmaxf(sc[1][0], sc[1][1]), fmaxf(sc[1][2], sc[1][3]))), mraw[qt]); \
+            }                                                                                  \
+        }
+        for (int j = 0; j + 1 < nkb; ++j) MHA_MAX_BLOCK(j, false)
+        MHA_MAX_BLOCK(nkb - 1, true)
+#undef MHA_MAX_BLOCK
+#pragma unroll
+        for (int qt = 0; qt < 2; ++qt) m[qt] = g4_max(mraw[qt]) * scale_log2e;      // finite: every row has >= 1 valid key
+        // ---- pass 2: p = exp2(s c - m), row sums, O^T += V^T P ----
+#define MHA_PV_BLOCK(J, MASKED)                                                                    \
+        {                                                                                      \
+            const int kb = (J) * 32;                                                           \
+            bf16x8 kf[2], vf[2];                                                               \
+            _Pragma("unroll") for (int t = 0; t < 2; ++t) {                                    \
+                kf[t] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const uint4*>(kimg + (2 * (J) + t) * 1024 + lane * 16)); \
+                vf[t] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const uint4*>(vimg + (2 * (J) + t) * 1024 + lane * 16)); \
+            }                                                                                  \
+            _Pragma("unroll") for (int qt = 0; qt < 2; ++qt) {                                 \
+                f32x4 sc[2];                                                                   \
+                _Pragma("unroll") for (int kt = 0; kt < 2; ++kt)                               \
+                    sc[kt] = DTLR_MFMA_16x16x32_H16(kf[kt], qf[qt], f32x4{0.f, 0.f, 0.f, 0.f}, 0, 0, 0); \
+                if (MASKED) {                                                                  \
+                    _Pragma("unroll") for (int kt = 0; kt < 2; ++kt)                           \
+                        _Pragma("unroll") for (int r = 0; r < 4; ++r)                          \
+                            if (kb + kt * 16 + 4 * g + r >= L) sc[kt][r] = -INFINITY;          \
+                }                                                                              \
+                _Pragma("unroll") for (int kt = 0; kt < 2; ++kt)                               \
+                    _Pragma("unroll") for (int r = 0; r < 4; ++r)                              \
+                        sc[kt][r] = __builtin_amdgcn_exp2f(__builtin_fmaf(sc[kt][r], scale_log2e, -m[qt])); \
+                const bf16x8 pf = __builtin_bit_cast(bf16x8, make_uint4(pack2(sc[0][0], sc[0][1]), pack2(sc[0][2], sc[0][3]), \
+                                                                        pack2(sc[1][0], sc[1][1]), pack2(sc[1][2], sc[1][3]))); \
+                _Pragma("unroll") for (int dt = 0; dt < 2; ++dt)                               \
+                    o[qt][dt] = DTLR_MFMA_16x16x32_H16(vf[dt], pf, o[qt][dt], 0, 0, 0);        \
+                osum[qt] = DTLR_MFMA_16x16x32_H16(ones_f, pf, osum[qt], 0, 0, 0);              \
+            }                                                                                  \
+        }
+        for (int j = 0; j + 1 < nkb; ++j) MHA_PV_BLOCK(j, false)
+        MHA_PV_BLOCK(nkb - 1, true)
+#undef MHA_PV_BLOCK
+#pragma unroll
+        for (int qt = 0; qt < 2; ++qt) {
+            const float l = __shfl(osum[qt][0], n, 64);       // row 0 of the sum tile lives in lanes (g = 0, n): query n's denominator
+            const float inv = 1.0f / l;
+            const int q = q0 + qt * 16 + n;
+            if (q < L) {
+#pragma unroll
+                for (int dt = 0; dt < 2; ++dt) {
+                    const f32x4 v = o[qt][dt] * inv;
+                    *reinterpret_cast<uint2*>(out + ((long)b * L + q) * C + h * 32 + dt * 16 + 4 * g) =
+                        make_uint2(pack2(v[0], v[1]), pack2(v[2], v[3]));
+                }
+            }
+        }
+    }
+}
+
 // v [B, L, C] -> vt [B, H, 32, Lpad] (zero padded): the transposed image the attention kernel reads.
 __global__ __launch_bounds__(256) void v_transpose_kernel(const uint16_t* __restrict__ v, uint16_t* __restrict__ vt,
                                                           int L, int Lpad, int H)
@@ -405,6 +540,15 @@ __global__ __launch_bounds__(256) void v_transpose_f32_kernel(const float* __res
 
 using namespace dtlr;
 
+// tuning / measurement knob: 0 = online softmax (default), 1 = the two-pass form of the LDS-staged 16-bit kernel; returns the previous value
+static int g_mha_variant = 0;
+extern "C" int dtlr_mha_set_variant(int v)
+{
+    const int old = g_mha_variant;
+    if (v == 0 || v == 1) g_mha_variant = v;
+    return old;
+}
+
 extern "C" int dtlr_mha_forward(const void* qk, const void* v, void* vt_workspace, void* out,
                                 int B, int L, int H, int head_dim, int dtype, void* stream)
 {
@@ -429,6 +573,13 @@ extern "C" int dtlr_mha_forward(const void* qk, const void* v, void* vt_workspac
     const float scale_log2e = 1.4426950408889634f / sqrtf((float)head_dim);
     const size_t lds = (size_t)(Lpad / 32) * 4096;               // K image + V^T image
     if (lds <= 152 * 1024) {                                     // transposes V while staging: no separate pass, no workspace
+        if (g_mha_variant == 1) {
+            static DevOnce attr2;
+            if (attr2.first()) { (void)hipFuncSetAttribute((const void*)mha_fwd_bf16_lds2_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 152 * 1024); (void)hipGetLastError(); }
+            hipLaunchKernelGGL(mha_fwd_bf16_lds2_kernel, dim3(H, B), dim3(1024), lds, st,
+                               (const uint16_t*)qk, (const uint16_t*)v, (uint16_t*)out, L, Lpad, H, scale_log2e);
+            return check_launch();
+        }
         static DevOnce attr;
         if (attr.first()) { (void)hipFuncSetAttribute((const void*)mha_fwd_bf16_lds_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 152 * 1024); (void)hipGetLastError(); }
         hipLaunchKernelGGL(mha_fwd_bf16_lds_kernel, dim3(H, B), dim3(1024), lds, st,

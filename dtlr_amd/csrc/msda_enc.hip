@@ -489,7 +489,6 @@ __device__ __forceinline__ void enc_queries_bf16_h3(
     const int wstride = p == 0 ? lv.wmax[0] : p == 1 ? lv.wmax[1] : p == 2 ? lv.wmax[2] : lv.wmax[3];
     const int wc0l = p == 0 ? wc0[0] : p == 1 ? wc0[1] : p == 2 ? wc0[2] : wc0[3];
     const int wc1l = p == 0 ? wc1[0] : p == 1 ? wc1[1] : p == 2 ? wc1[2] : wc1[3];
-    const int wwl = wc1l - wc0l;
     const float fH = (float)Hl, fW = (float)Wl;
     const float invH = 1.0f / fH, invW = 1.0f / fW;
     const unsigned char* win = smem + (long)loffl * 64;

@@ -781,6 +781,13 @@ def msda_encoder_fits(level_hw, dtype, halo: Optional[int] = None) -> bool:
     return rc == 1
 
 
+def mha_set_variant(v: int, dtype=None) -> int:
+    """Select the softmax form of the LDS-staged 16-bit attention kernel for subsequent launches of the library that serves `dtype`
+    (dtlr_mha_set_variant: 0 online softmax -- the default --, 1 two-pass, not timed yet); a measurement / test knob, never called by
+    the engine.  Returns the previous value."""
+    return int(_lib.lib(dtype).dtlr_mha_set_variant(int(v)))
+
+
 def msda_encoder_set_variant(v: int, dtype=None) -> int:
     """Select the 16-bit query-phase form of the LDS-window encoder kernel for subsequent launches of the library that serves `dtype`
     (dtlr_msda_encoder_set_variant: 0 fp32 accumulators, 1 / 2 packed-fp16 accumulation with 256 / 512 threads -- 2 is the default --,

@@ -221,6 +221,9 @@ int dtlr_proj_ln_split_bf16(const void *A, const void *W_packed, const float *bi
 int dtlr_mha_forward(const void *qk, const void *v, void *vt_workspace, void *out,
                      int B, int L, int H, int head_dim, int dtype, void *stream);
 long dtlr_mha_workspace_bytes(int B, int L, int H, int head_dim);
+/* tuning / measurement knob (like dtlr_msda_encoder_set_variant): 0 = online softmax (default), 1 = the two-pass form of the
+ * LDS-staged 16-bit kernel (row maxima first, then exp2 with the final maximum; row sums from the matrix pipe).  Returns the previous value. */
+int dtlr_mha_set_variant(int v);
 
 /* ---------------------------------------------------------------------------------------------
  * C[M,N] = epilogue( (A [+ A2])[M,K] . W[N,K]^T )   -- every nn.Linear and 1x1 convolution on the path.

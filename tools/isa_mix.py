@@ -16,6 +16,8 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
 def category(op: str) -> str:
+    if op.startswith("v_mfma") or op.startswith("v_smfmac"):
+        return "mfma"
     if op.startswith("v_"):
         return "valu"
     if op.startswith("s_"):
