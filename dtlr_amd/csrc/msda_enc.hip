@@ -89,6 +89,24 @@ template <> __device__ __forceinline__ uint4 stage_convert<uint16_t>(const uint4
     return make_uint4(o[0], o[1], o[2], o[3]);
 }
 #endif
+// the same conversion for a kernel that runs with MODE.FP16_OVFL = 1: v_cvt_pk_f16_f32 itself saturates at +-65504
+template <typename T> __device__ __forceinline__ uint4 stage_convert_ovfl(const uint4& d);
+#ifdef DTLR_HALF_IS_F16
+template <> __device__ __forceinline__ uint4 stage_convert_ovfl<uint16_t>(const uint4& d) { return d; }
+#else
+template <> __device__ __forceinline__ uint4 stage_convert_ovfl<uint16_t>(const uint4& d) {
+    typedef _Float16 h2_t __attribute__((ext_vector_type(2)));
+    typedef float f2_t __attribute__((ext_vector_type(2)));
+    const uint32_t w[4] = {d.x, d.y, d.z, d.w};
+    uint32_t o[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const f2_t f = {h16_lo(w[j]), h16_hi(w[j])};
+        o[j] = __builtin_bit_cast(uint32_t, __builtin_convertvector(f, h2_t));
+    }
+    return make_uint4(o[0], o[1], o[2], o[3]);
+}
+#endif
 // acc += w * fp16 half of `data` (plain asm, not volatile: a pure function of its inputs, the compiler schedules it freely)
 __device__ __forceinline__ float fma_mix_lo(float w, uint32_t data, float acc) {
     float d;
@@ -574,14 +592,14 @@ __device__ __forceinline__ void enc_queries_bf16_h3(
                     }
                     DTLR_ACC_H3(pk_fma_h2_bl, d3, k34) DTLR_ACC_H3(pk_fma_h2_bh, d4, k34)
                 }
-            } else {                                            // outside the staged window: global path (clamped, valid addresses)
+            } else {                                            // outside the staged window: global path (clamped, valid addresses; MODE.FP16_OVFL is set)
 #pragma unroll
                 for (int jj = 0; jj < 4; ++jj) {
                     const int pe = rot[jj] >> 1;
-                    const uint4 e1 = stage_convert<uint16_t>(*reinterpret_cast<const uint4*>(gsrc + (long)(h0 * Wl + w0) * MD + pe));
-                    const uint4 e2 = stage_convert<uint16_t>(*reinterpret_cast<const uint4*>(gsrc + (long)(h0 * Wl + w1c) * MD + pe));
-                    const uint4 e3 = stage_convert<uint16_t>(*reinterpret_cast<const uint4*>(gsrc + (long)(h1 * Wl + w0) * MD + pe));
-                    const uint4 e4 = stage_convert<uint16_t>(*reinterpret_cast<const uint4*>(gsrc + (long)(h1 * Wl + w1c) * MD + pe));
+                    const uint4 e1 = stage_convert_ovfl<uint16_t>(*reinterpret_cast<const uint4*>(gsrc + (long)(h0 * Wl + w0) * MD + pe));
+                    const uint4 e2 = stage_convert_ovfl<uint16_t>(*reinterpret_cast<const uint4*>(gsrc + (long)(h0 * Wl + w1c) * MD + pe));
+                    const uint4 e3 = stage_convert_ovfl<uint16_t>(*reinterpret_cast<const uint4*>(gsrc + (long)(h1 * Wl + w0) * MD + pe));
+                    const uint4 e4 = stage_convert_ovfl<uint16_t>(*reinterpret_cast<const uint4*>(gsrc + (long)(h1 * Wl + w1c) * MD + pe));
                     acc[jj][0] = pk_fma_h2_bh(k34, e4.x, pk_fma_h2_bl(k34, e3.x, pk_fma_h2_bh(k12, e2.x, pk_fma_h2_bl(k12, e1.x, acc[jj][0]))));
                     acc[jj][1] = pk_fma_h2_bh(k34, e4.y, pk_fma_h2_bl(k34, e3.y, pk_fma_h2_bh(k12, e2.y, pk_fma_h2_bl(k12, e1.y, acc[jj][1]))));
                     acc[jj][2] = pk_fma_h2_bh(k34, e4.z, pk_fma_h2_bl(k34, e3.z, pk_fma_h2_bh(k12, e2.z, pk_fma_h2_bl(k12, e1.z, acc[jj][2]))));
@@ -647,6 +665,38 @@ __global__ __launch_bounds__(NT, NT / 128) void msda_enc_lds_kernel(
 
     // ---- stage the four windows of head m: coalesced 16-byte chunks, CP chunks per pixel ------------
     const T* vimg = value + (long)b * S * MD + m * 32;
+    if constexpr (VAR == 2) {
+        // Variant 3 stages with ~45% of the default loop's VALU instructions (270 per four chunks there: two divisions by the runtime window
+        // width per chunk, and the fp16 saturation guard as v_max + v_med3 per element): a lane walks its chunks as (row, chunk-in-row)
+        // advanced by the constant step (NT / rowlen, NT % rowlen) -- ONE division per level per lane --, and the conversion saturates in
+        // hardware: MODE.FP16_OVFL clamps an overflowing fp16 result to +-65504 (it also covers the packed accumulation of the query phase).
+        asm volatile("s_setreg_imm32_b32 hwreg(HW_REG_MODE, 23, 1), 1");
+#pragma unroll
+        for (int l = 0; l < 4; ++l) {
+            const unsigned ww = (unsigned)(wc1[l] - wc0[l]), rowlen = ww * CP, nchunk = (unsigned)lv.H[l] * rowlen;
+            const unsigned dq = (unsigned)NT / rowlen, dr = (unsigned)NT - dq * rowlen;
+            const T* src = vimg + ((long)lv.start[l] + wc0[l]) * MD;
+            unsigned char* dst = smem + (long)lv.loff[l] * PIX_BYTES;
+            unsigned row = (unsigned)tid / rowlen, x = (unsigned)tid - row * rowlen;
+            for (unsigned c0 = (unsigned)tid; c0 < nchunk; c0 += NT * 4) {
+                uint4 d[4];
+                unsigned dst_off[4];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    const bool live = c0 + NT * u < nchunk;                    // tail lanes re-read chunk (0, 0): a valid address
+                    const unsigned r_ = live ? row : 0u, x_ = live ? x : 0u;
+                    const unsigned col = x_ / CP, part = x_ % CP;              // CP is a power of two
+                    d[u] = *reinterpret_cast<const uint4*>(src + (long)(r_ * (unsigned)lv.W[l] + col) * MD + part * VEC);
+                    dst_off[u] = (r_ * (unsigned)lv.wmax[l] + col) * PIX_BYTES + part * 16;
+                    x += dr; row += dq;
+                    if (x >= rowlen) { x -= rowlen; ++row; }
+                }
+#pragma unroll
+                for (int u = 0; u < 4; ++u)
+                    if (c0 + NT * u < nchunk) *reinterpret_cast<uint4*>(dst + dst_off[u]) = stage_convert_ovfl<T>(d[u]);
+            }
+        }
+    } else
 #pragma unroll
     for (int l = 0; l < 4; ++l) {
         const int ww = wc1[l] - wc0[l];

@@ -1225,8 +1225,8 @@ def test_gemm_kres_cat_s2_vs_reference(B, Hin, Win, half):
                                                ([(5, 83), (3, 42), (2, 21), (1, 11)], 3.0), ([(1, 7), (1, 4), (1, 2), (1, 1)], 1.0)])
 def test_msda_encoder_lds_variant3_vs_oracle(level_hw, offscale, half):
     """Variant 3 of the 16-bit query phase (dtlr_msda_encoder_set_variant(3): coordinate clamp + one unsigned compare per axis, v_rcp_f32
-    softmax normalisation, paired weight conversions broadcast through op_sel; 654 VALU instructions per lane-iteration against 747,
-    tools/isa_mix.py) against the oracle at the tolerance of the default form, for both projection-row dtypes, including samples
+    softmax normalisation, paired weight conversions broadcast through op_sel, division-free staging, MODE.FP16_OVFL saturation; 654 VALU
+    instructions per lane-iteration against 747, tools/isa_mix.py) against the oracle at the tolerance of the default form, for both projection-row dtypes, including samples
     outside the map and outside the staged windows; and close to the default form."""
     from dtlr_amd import ops
     from oracle import dtlr_oracle as O
@@ -1252,6 +1252,10 @@ def test_msda_encoder_lds_variant3_vs_oracle(level_hw, offscale, half):
             assert torch.isfinite(got).all()
             assert (got - want).abs().max() <= tol, (owx.dtype, (got - want).abs().max().item(), tol.item())
             assert (got - dflt).abs().max() <= tol
+        if half == torch.bfloat16:      # beyond fp16's range: the hardware saturation (MODE.FP16_OVFL) must keep every output finite
+            big = (vv.float() * 1e6).to(half)
+            ops.msda_encoder_set_variant(3, half)
+            assert torch.isfinite(ops.msda_encoder(big.cuda(), level_hw, ow.to(half).cuda(), ref.cuda()).float()).all()
     finally:
         ops.msda_encoder_set_variant(old, half)
 
