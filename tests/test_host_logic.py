@@ -532,3 +532,29 @@ def test_backbone_chain_wiring_with_cpu_stand_ins_for_the_kernels(monkeypatch, b
             for bi in range(1, blocks[0]):
                 assert f"l1.{bi}.c1" not in cl                                 # every inner conv1 came out of the previous tail
         assert ("cat_s2" in cl) == cat and ("l2.0.ds" in cl) == (not cat)
+
+
+def test_msda_variant3_staging_walk_restated():
+    """The division-free staging walk of msda_enc_lds_kernel<.., VAR = 2> (csrc/msda_enc.hip: a lane advances (row, chunk-in-row) by the
+    constant step (NT / rowlen, NT % rowlen) with one wrap, four chunks per trip, dead lanes re-reading chunk (0, 0)), restated in Python
+    and compared with the default loop's c -> (row, column, part) divisions: every chunk exactly once, at the same place."""
+    import random
+    rnd = random.Random(1)
+    for _ in range(150):
+        H, ww, NT, CP = rnd.choice([1, 2, 3, 5, 8, 16, 33]), rnd.randint(1, 150), rnd.choice([256, 512]), 4
+        rowlen, nchunk = ww * CP, H * ww * CP
+        dq, dr = NT // rowlen, NT % rowlen
+        seen = {}
+        for tid in range(NT):
+            row, x, c0 = tid // rowlen, tid % rowlen, tid
+            while c0 < nchunk:
+                for u in range(4):
+                    if c0 + NT * u < nchunk:
+                        assert c0 + NT * u not in seen
+                        seen[c0 + NT * u] = (row, x // CP, x % CP)
+                    x, row = x + dr, row + dq
+                    if x >= rowlen:
+                        x, row = x - rowlen, row + 1
+                c0 += 4 * NT
+        assert len(seen) == nchunk
+        assert all(v == ((c // CP) // ww, (c // CP) % ww, c % CP) for c, v in seen.items()), (H, ww, NT)
