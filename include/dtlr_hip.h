@@ -100,9 +100,10 @@ int dtlr_msda_encoder_plan_ok(const int *level_hw /* host, 8 ints */, int dtype,
  * dtlr_msda_encoder_forward; dtype = the value dtype (it sets the window plan), ow_dtype = the projection row's dtype. */
 int dtlr_msda_encoder_far_samples(const void *ow, const float *ref, const int *level_hw, int N, int M, int halo,
                                   int dtype, int ow_dtype, unsigned long long *counts, void *stream);
-/* Measurement knob: bf16 query-phase form of dtlr_msda_encoder_forward for subsequent launches (0 = fp32 accumulators /
- * v_fma_mix_f32, 1 = per-level packed-fp16 accumulation with 256-thread workgroups, 2 = the same with 512 threads: the default;
- * env DTLR_MSDA_ENC_V sets the initial value).  Returns the previous value; v outside 0..2 only queries. */
+/* Measurement knob: 16-bit query-phase form of dtlr_msda_encoder_forward for subsequent launches (0 = fp32 accumulators /
+ * v_fma_mix_f32, 1 = per-level packed-fp16 accumulation with 256-thread workgroups, 2 = the same with 512 threads: the default,
+ * 3 = the instruction-lean form with division-free staging and hardware fp16 saturation).  Returns the previous value; v outside
+ * 0..3 only queries.  (The library reads no environment variable: an experiment build alone takes DTLR_MSDA_ENC_V as the initial value.) */
 int dtlr_msda_encoder_set_variant(int v);
 
 /* ---------------------------------------------------------------------------------------------
