@@ -71,6 +71,9 @@ def main():
     loops.sort(key=lambda x: x[0] - x[1])
     for a, b, t in loops[:8]:
         print(f"  loop {t}: lines {a}..{b}  {mix(a, b)[0]}")
+    if not loops:
+        loops = [(0, len(body) - 1, "the whole kernel (no loop)")]
+        print(f"  {mix(0, len(body) - 1)[0]}")
     if loops:
         a, b, t = loops[0]
         print(f"opcode histogram of {t} (both sides of every branch inside it are counted):")
