@@ -659,6 +659,12 @@ __global__ __launch_bounds__(NT, NT / 128) void msda_enc_lds_kernel(
             const int c0q = lq == 3 ? qc0[3] : lq == 2 ? qc0[2] : lq == 1 ? qc0[1] : qc0[0];
             const int Wq = lq == 3 ? lv.W[3] : lq == 2 ? lv.W[2] : lq == 1 ? lv.W[1] : lv.W[0];
             const int stq = lq == 3 ? lv.start[3] : lq == 2 ? lv.start[2] : lq == 1 ? lv.start[1] : lv.start[0];
+            if constexpr (VAR == 2) {
+                // r / nc without the ~60-instruction integer division: (r + 0.5) / nc is at least 0.5 / nc away from an integer, far
+                // more than the fp32 error of the product for r < 2^15 and nc <= 2^8 (restated and swept in tests/test_host_logic.py)
+                const int qi = (int)(((float)r + 0.5f) * __builtin_amdgcn_rcpf((float)nc));
+                tok[q] = stq + qi * Wq + c0q + (r - qi * nc);
+            } else
             tok[q] = stq + (r / nc) * Wq + c0q + r % nc;
         }
     }

@@ -558,3 +558,15 @@ def test_msda_variant3_staging_walk_restated():
                 c0 += 4 * NT
         assert len(seen) == nchunk
         assert all(v == ((c // CP) // ww, (c // CP) % ww, c % CP) for c, v in seen.items()), (H, ww, NT)
+
+
+def test_msda_variant3_token_table_division_restated():
+    """Variant 3 maps a tile-local query number to (row, column) with floor((r + 0.5) * rcp(nc)) in fp32 instead of an integer division
+    (csrc/msda_enc.hip, VAR = 2): exact for every r < 2^15 and nc <= 256 even with the reciprocal off by one ulp either way
+    (v_rcp_f32 is accurate to 1 ulp); the kernel's ranges are r < H_l * nc <= ~4500 and nc <= 65."""
+    r = np.arange(0, 1 << 15, dtype=np.int64)
+    rf = r.astype(np.float32) + np.float32(0.5)
+    for nc in range(1, 257):
+        inv = np.float32(1.0) / np.float32(nc)
+        for cand in (inv, np.nextafter(inv, np.float32(np.inf)), np.nextafter(inv, np.float32(-np.inf))):
+            assert np.array_equal((rf * cand).astype(np.int32), r // nc), nc
