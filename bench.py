@@ -187,10 +187,19 @@ def msda_offset_sensitivity(eng, B, dtype, level_hw, sigmas=(0.0, 8.0, 32.0), it
     return rows
 
 
+def _sci(v: float) -> float:
+    """4 significant digits, whatever the magnitude (round(3e-5, 4) used to print the fp32 engine's error as 0.0)"""
+    return float(f"{v:.3e}")
+
+
 def cer_vs_oracle(cfg, sd, x, mask, out, rows):
-    """Lines `rows` of the benched batch against the CPU oracle on the same canvas / masks, following the engine's own selection."""
+    """Lines `rows` of the benched batch against the CPU oracle on the same canvas / masks, following the engine's own selection.
+    EVERY query is accounted for (oracle/compare.py::tie_aware_compare): `cer_all_queries` = edit distance of the decoded strings over
+    all 900 queries per line; a label may differ only where the oracle's decision margin is below twice the measured logit error, two
+    characters may trade places only if their oracle cx differ by less than twice the measured cx error; `unexplained` counts the
+    differences covered by neither and must be 0."""
     from oracle import dtlr_oracle as O          # checker only
-    from tests.util import compare_decoded
+    from oracle.compare import compare_decoded, tie_aware_compare
     idx = out["_debug"]["topk_idx"][rows].cpu()
     torch.set_num_threads(min(16, os.cpu_count() or 8))
     ref = O.dino_forward(sd, cfg, x[rows].float().cpu(), mask=mask[rows].cpu(), forced_topk=idx)
@@ -199,14 +208,40 @@ def cer_vs_oracle(cfg, sd, x, mask, out, rows):
     Eb = (got_b - ref["pred_boxes"]).abs().max().item()
     Ecx = (got_b[..., 0] - ref["pred_boxes"][..., 0]).abs().max().item()
     st = compare_decoded(ref["pred_logits"], ref["pred_boxes"], got_l, got_b, None, E, Ecx)       # reading order depends on cx only
+    ta = tie_aware_compare(ref["pred_logits"], ref["pred_boxes"], got_l, got_b, None, E, Ecx)
     a = O.decode_blank(ref)
     b = O.decode_blank({"pred_logits": got_l, "pred_boxes": got_b})
     dist = sum(O.levenshtein(x_, y_) for x_, y_ in zip(a, b))
     n = sum(len(x_) for x_ in a)
-    return {"lines": list(rows), "logit_err_max": round(E, 4), "box_err_max": round(Eb, 5), "cx_err_max": round(Ecx, 5), "cer_all_queries": round(dist / max(n, 1), 5),
-            "chars_oracle": n, "edit_distance": dist, "cer_safe_queries": 0.0 if (st["strings_equal"] and st["label_mismatch_on_safe"] == 0) else 1.0,
+    assert dist == ta["edit_distance"] and n == ta["chars_ref"], (dist, n, ta)      # two restatements of the decoder must agree
+    return {"lines": list(rows), "logit_err_max": _sci(E), "box_err_max": _sci(Eb), "cx_err_max": _sci(Ecx),
+            "logit_err_mean": _sci((got_l - ref["pred_logits"]).abs().mean().item()),
+            "cer_all_queries": round(dist / max(n, 1), 5), "chars_oracle": n, "edit_distance": dist,
+            "label_flips": ta["label_flips"], "label_flips_unexplained": ta["label_flips_unexplained"],
+            "order_swaps": ta["order_swaps"], "order_swaps_unexplained": ta["order_swaps_unexplained"], "unexplained": ta["unexplained"],
+            "min_char_gap_px": None if ta["min_gap_px_2048"] is None else round(ta["min_gap_px_2048"] * x.shape[-1] / 2048.0, 3),
+            "cer_safe_queries": 0.0 if (st["strings_equal"] and st["label_mismatch_on_safe"] == 0) else 1.0,
             "safe_query_frac": round(st["safe_frac"], 4), "safe_chars": st["safe_chars"],
-            "note": "safe = oracle decision margin > 2 x measured logit error and cx separation > 2 x measured cx error (tests/util.py)"}
+            "note": "all 900 queries per line; flips / swaps are explained when the oracle margin < 2 x logit_err_max resp. the oracle cx gap < 2 x "
+                    "cx_err_max (oracle/compare.py); safe_* = the round-3 subset gate"}
+
+
+def self_launch(args) -> int:
+    """`python bench.py --gpus N` with N > 1 and no launcher in the environment: start the N ranks ourselves, exactly as the documented
+    command does (python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py ...);
+    rank 0 prints the one JSON line on the inherited stdout, a failing rank's exit code is ours."""
+    import socket
+    import subprocess
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    log(f"--gpus {args.gpus} without a launcher: " + " ".join(cmd))
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")           # dmabuf IPC: RCCL across processes needs it on this driver
+    env.setdefault("OMP_NUM_THREADS", "8")
+    return subprocess.call(cmd, env=env)
 
 
 def main():
@@ -226,8 +261,9 @@ def main():
                     "msda_enc=3 (instruction-lean query phase) -- dtlr_mha_set_variant / dtlr_msda_encoder_set_variant; recorded in config.engine_opts")
     ap.add_argument("--height", type=int, default=128)
     ap.add_argument("--width", type=int, default=0, help="0 = 2048 (latin) / 2560 canvas with mixed widths (chinese)")
-    ap.add_argument("--dtype", default="bf16", choices=["bf16", "f16", "f32"],
-                    help="the timed engine: bf16 (BASELINE configs[1]), f16 (the fp16 build of the same kernels: same rate, 8x finer rounding), f32 (parity engine)")
+    ap.add_argument("--dtype", default="bf16", choices=["bf16", "f16", "f32s", "f32"],
+                    help="the timed engine: bf16 (BASELINE configs[1]), f16 (the fp16 build of the same kernels: same rate, 8x finer rounding), "
+                         "f32s (fp32 activations, split fp16 products: parity-grade), f32 (exact-fp32 MFMA parity engine)")
     ap.add_argument("--no-other-dtypes", action="store_true", help="skip the short lines/s + parity legs of the two engines that are not --dtype")
     ap.add_argument("--parity-lines", type=int, default=8, help="lines of the benched batch decoded by the CPU oracle (cer_vs_oracle)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -235,7 +271,10 @@ def main():
     ap.add_argument("--backend", default=None, help="torch.distributed backend (default nccl = RCCL); gloo for the single-GPU DP test")
     ap.add_argument("--single-device", action="store_true", help="all ranks use cuda:0 (tests: two ranks on one GPU need gloo)")
     ap.add_argument("--min-seconds", type=float, default=MIN_TIMED_SECONDS)
+    ap.add_argument("--no-bs1", action="store_true", help="skip the single-line latency leg (latency_ms_bs1)")
     args = ap.parse_args()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        raise SystemExit(self_launch(args))
     import faulthandler
     faulthandler.dump_traceback_later(900, exit=False, file=sys.stderr)      # diagnose hangs on the box
 
@@ -256,7 +295,7 @@ def main():
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     placement = ddist.pin_to_local_cpus(local, world) if (world > 1 and not args.single_device) else None
-    DT = {"bf16": torch.bfloat16, "f16": torch.float16, "f32": torch.float32}
+    DT = {"bf16": torch.bfloat16, "f16": torch.float16, "f32": torch.float32, "f32s": torch.float32}
     dtype = DT[args.dtype]
 
     chinese = args.config == "chinese"
@@ -266,7 +305,7 @@ def main():
         import dataclasses
         cfg = dataclasses.replace(cfg, backbone=args.backbone)
     sd = weights.synthetic_state_dict(cfg, seed=0)
-    eng = DTLREngine(cfg, sd, dev, dtype)
+    eng = DTLREngine(cfg, sd, dev, dtype, split=args.dtype == "f32s")
     for kv in args.engine_opt:
         k, _, v = kv.partition("=")
         if not hasattr(eng, k):
@@ -406,11 +445,12 @@ def main():
     enc = [(a.elapsed_time(b), n, lq, s) for (a, b, n, lq, s) in events if lq == s]
     dec = [(a.elapsed_time(b), n, lq, s) for (a, b, n, lq, s) in events if lq != s]
     velem = 2 if dtype in (torch.bfloat16, torch.float16) else 4
-    traffic_db = {}
+    traffic_db, traffic_file = {}, None
     for fn in sorted(os.listdir(os.path.join(ROOT, "profiles"))) if os.path.isdir(os.path.join(ROOT, "profiles")) else []:
         if fn.endswith("_traffic.json"):
             try:
                 traffic_db.update(json.load(open(os.path.join(ROOT, "profiles", fn))))
+                traffic_file = fn
             except Exception:
                 pass
     # PMC traffic figures were measured on the Latin bf16 B = 32 step (profiles/*_traffic.json): attach them to that configuration only
@@ -448,11 +488,13 @@ def main():
             s_[0] += dt; s_[1] += flops; s_[2] += 1; s_[3] += nbytes
     names = {"gemm_bf16": "gemm_ws_kernel<bf16> / gemm_k256_kernel / gemm_kres_kernel / conv3x3_patch_kernel (every Linear / 1x1 conv / 3x3 conv, fused epilogues)",
              "gemm_f32": "gemm_ws_kernel<f32> (fp32 heads and selection scores, exact-fp32 MFMA 16x16x4)",
+             "gemm_f32s": "gemm_ws_kernel<f32s> (fp32 operands as fp16 hi + lo halves, three 16x16x32 fp16 MFMAs per product; flops counted once)",
              "ffn_fused_bf16": "ffn3_bf16_kernel / ffn2_bf16_kernel / ffn_fused_bf16_kernel (linear1+ReLU+linear2+residual+LayerNorm, intermediate on chip)",
              "proj_ln_bf16": "proj_ln_bf16_kernel (attention output projection + residual + LayerNorm)"}
 
     def both_roofs(kind, ms, flops, nbytes):
-        peak = MFMA_PEAK_F32_TFLOPS if kind == "gemm_f32" else MFMA_PEAK_BF16_TFLOPS
+        # f32s: algorithmic flops (each product once) against a third of the dense 16-bit peak -- the kernel issues three MFMAs per product
+        peak = MFMA_PEAK_F32_TFLOPS if kind == "gemm_f32" else (MFMA_PEAK_BF16_TFLOPS / 3.0 if kind == "gemm_f32s" else MFMA_PEAK_BF16_TFLOPS)
         ach = flops / (ms * 1e-3) / 1e12
         gbps = nbytes / (ms * 1e-3) / 1e9                        # compulsory operand + result bytes (each tensor once)
         return peak, ach, gbps, ach / peak, gbps / HBM_PEAK_GBS
@@ -503,10 +545,12 @@ def main():
                         "world_size": tdist.get_world_size() if (tdist.is_available() and tdist.is_initialized()) else 1,
                         "dp_verified": dp_verified, "host_placement": placement},
         "roofline": dominant,
+        # `traffic` figures are PMC measurements looked up from profiles/ (not taken in this run): the file and the commit they were measured at
+        "traffic_source": {"file": traffic_file, "measured_at_commit": traffic_db.get("_commit"), "attached": bool(traffic_ok)},
         "roofline_by_kernel": by_kernel,
         "gemm_by_shape": gemm_by_shape[:24],
     }
-    if world == 1 and args.dtype != "f32" and not cfg.is_swin:
+    if world == 1 and args.dtype in ("bf16", "f16") and not cfg.is_swin:
         try:                                                    # the MSDA figure above is the synthetic weights' best case: show the other cases beside it
             lhw = [tuple(int(v) for v in hw) for hw in eng._shape_cache[next(iter(eng._shape_cache))]["level_hw"]] if eng._shape_cache else None
             if lhw is None:
@@ -515,6 +559,25 @@ def main():
             log(f"msda_encoder_by_offset_scale: {line['msda_encoder_by_offset_scale']}")
         except Exception as e:
             line["msda_encoder_by_offset_scale"] = {"error": repr(e)}
+    if world == 1 and not args.no_bs1:
+        # the reference's evaluation loop feeds ONE line at a time (/root/reference/evaluation.py:494-499): forward + decode latency of a single
+        # line of the batch, and of 4 (the decoder's ~60 launches do not shrink with the batch)
+        lat = {}
+        for nb in (1, 4):
+            if nb > B:
+                continue
+            xs, ms_ = x[:nb].contiguous(), mask[:nb].contiguous()
+            for _ in range(3):
+                local_step(xs, ms_)
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for _ in range(20):
+                local_step(xs, ms_)
+            torch.cuda.synchronize()
+            lat[nb] = (time.perf_counter() - t0) / 20 * 1e3
+        line["latency_ms_bs1"] = round(lat[1], 3)
+        line["latency_ms_by_batch"] = {str(k): round(v, 3) for k, v in lat.items()}
+        log(f"single-line latency: {lat}")
     rows = sorted({int(round(i * (B - 1) / max(args.parity_lines - 1, 1))) for i in range(min(args.parity_lines, B))})
     if not args.no_parity:
         try:
@@ -532,11 +595,11 @@ def main():
     if world == 1 and not args.no_other_dtypes:
         del eng
         torch.cuda.empty_cache()
-        for name in ("bf16", "f16", "f32"):
+        for name in ("bf16", "f16", "f32s", "f32"):
             if name == args.dtype:
                 continue
             try:
-                e2 = DTLREngine(cfg, sd, dev, DT[name])
+                e2 = DTLREngine(cfg, sd, dev, DT[name], split=name == "f32s")
 
                 def step2(debug=False):
                     o = e2.forward(x, mask, has_padding=padded, return_debug=debug)
@@ -544,7 +607,7 @@ def main():
                 for _ in range(2):
                     step2()
                 torch.cuda.synchronize()
-                k2 = args.steps if name != "f32" else max(3, args.steps // 5)
+                k2 = args.steps if name in ("bf16", "f16") else max(3, args.steps // (2 if name == "f32s" else 5))
                 t0 = time.perf_counter()
                 for _ in range(k2):
                     step2()

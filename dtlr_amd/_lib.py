@@ -13,7 +13,7 @@ LIB_PATH = os.environ.get("DTLR_HIP_LIB") or os.path.join(HERE, "libdtlr_hip.so"
 # symbols, accepts DTLR_F16 wherever libdtlr_hip.so accepts DTLR_BF16
 LIB_PATH_F16 = os.environ.get("DTLR_HIP_LIB_F16") or os.path.join(HERE, "libdtlr_hip_f16.so")
 
-DTLR_F32, DTLR_F64, DTLR_BF16, DTLR_F16 = 0, 1, 2, 3
+DTLR_F32, DTLR_F64, DTLR_BF16, DTLR_F16, DTLR_F32S = 0, 1, 2, 3, 4
 
 _lib = None
 _lib_f16 = None
@@ -68,6 +68,7 @@ _SIGNATURES = {
     "dtlr_mha_set_variant": (c_int, [c_int]),
     "dtlr_gemm_nt": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
                              c_int, c_int, c_int, c_int, c_int, c_int, c_void_p]),
+    "dtlr_split_pack_weights": (c_int, [c_void_p, c_void_p, ctypes.c_long, c_int, c_void_p]),
     "dtlr_k256_pack_weights": (c_int, [c_void_p, c_void_p, c_int]),
     "dtlr_gemm_k256": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_int, c_int, c_int, c_void_p]),
     "dtlr_proj_ln_k256_pack_weights": (c_int, [c_void_p, c_void_p]),

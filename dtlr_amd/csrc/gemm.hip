@@ -122,6 +122,60 @@ template <> struct GT<float> {
     }
 };
 
+// ---- split-fp16 operands ("f32s", round 4): fp32-grade products at the 16-bit matrix rate / 3 ----------------------------------
+// The parity engine's GEMMs ran on v_mfma_f32_16x16x4_f32 (exact fp32, 1/16 of the 16-bit rate: 567 lines/s against 3556).  Here an
+// fp32 operand x is carried as TWO fp16 numbers, hi = fp16(x) and lo = fp16(x - hi) (x - hi is exact in fp32; |lo| <= 2^-11 |hi|, so
+// hi + lo holds 22 significand bits; gfx950's f16 MFMA keeps fp16 subnormals, so the pair is good down to |x| ~ 2^-14), and
+//     a . w  ~=  a_hi w_hi + a_lo w_hi + a_hi w_lo            (the dropped a_lo w_lo term is 2^-22 relative)
+// is three v_mfma_f32_16x16x32_f16 with fp32 accumulation: 48 matrix cycles per 32 k against 256 for the exact-fp32 MFMAs.
+//   * ACTIVATIONS stay fp32 in HBM (the residual streams, LayerNorm / GroupNorm inputs and the reference-point chain are never
+//     rounded); the LOADER waves split them while staging: a lane's 16-byte load is 4 consecutive k of one row -> 8 bytes of hi and
+//     8 bytes of lo.  The LDS row keeps its 128 bytes: 16-byte chunk c < 4 = hi of k 8c..8c+7, chunk 4 + c = lo of the same k
+//     (chunks XOR-swizzled by row & 7 like every other tile of this file), so an MFMA lane's two ds_read_b128 per row -- chunk g and
+//     chunk 4 + g, the addresses the 16-bit kernel reads for its two k-halves -- are exactly its hi and lo B-fragments.
+//   * WEIGHTS are split ONCE (dtlr_split_pack_weights) into the same slab image, an array with the size and shape of the fp32
+//     weight: the loader copies it to LDS unchanged.
+// Error of a K-term product: ~2^-21 relative per term (representation 2^-22 each side + the dropped term) under fp32 accumulation
+// -- the fp32 engine's own accumulation-order noise; measured in tests/test_gpu_kernels.py against fp64.  Range: |x| < 65504
+// (fp16 hi); every activation of this network is a post-normalisation value, a ReLU of one or a frozen-BN'd convolution output.
+struct f32s_t { float v; };
+template <typename T> constexpr bool kSplit = std::is_same<T, f32s_t>::value;
+typedef __attribute__((ext_vector_type(8))) _Float16 f16x8_t;
+typedef __attribute__((ext_vector_type(2))) _Float16 f16x2_t;
+template <> struct GT<f32s_t> {
+    static constexpr int BK = 32;
+    static __device__ __forceinline__ uint4 add(uint4 a, uint4 b) { return GT<float>::add(a, b); }
+    static __device__ __forceinline__ void mma(const uint4&, const uint4&, f32x4_t&) {}      // (the split kernels multiply whole slabs: mma_slab)
+    // 4 consecutive fp32 k -> 4 fp16 hi (8 bytes) + 4 fp16 lo (8 bytes); v_cvt_pk_f16_f32 rounds to nearest even
+    static __device__ __forceinline__ void split4(const uint4& v, uint2& hi, uint2& lo) {
+        const float x0 = __uint_as_float(v.x), x1 = __uint_as_float(v.y), x2 = __uint_as_float(v.z), x3 = __uint_as_float(v.w);
+        const f16x2_t h01 = __builtin_convertvector(f32x2_hw_t{x0, x1}, f16x2_t), h23 = __builtin_convertvector(f32x2_hw_t{x2, x3}, f16x2_t);
+        const f16x2_t l01 = __builtin_convertvector(f32x2_hw_t{x0 - (float)h01[0], x1 - (float)h01[1]}, f16x2_t);
+        const f16x2_t l23 = __builtin_convertvector(f32x2_hw_t{x2 - (float)h23[0], x3 - (float)h23[1]}, f16x2_t);
+        hi = make_uint2(__builtin_bit_cast(uint32_t, h01), __builtin_bit_cast(uint32_t, h23));
+        lo = make_uint2(__builtin_bit_cast(uint32_t, l01), __builtin_bit_cast(uint32_t, l23));
+    }
+    static __device__ __forceinline__ void mma_h(const uint4& w, const uint4& x, f32x4_t& acc) {
+        acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8_t, w), __builtin_bit_cast(f16x8_t, x), acc, 0, 0, 0);
+    }
+    // one 32-k slab of a 64 x 64 wave tile: wf[0] / xf[0] = hi fragments, wf[1] / xf[1] = lo fragments.  The correction terms go
+    // first and every accumulator is touched once per term, so consecutive MFMAs never depend on each other.
+    static __device__ __forceinline__ void mma_slab(const uint4 (&wf)[2][4], const uint4 (&xf)[2][4], f32x4_t (&acc)[4][4]) {
+#pragma unroll
+        for (int ci = 0; ci < 4; ++ci)
+#pragma unroll
+            for (int ti = 0; ti < 4; ++ti) mma_h(wf[1][ci], xf[0][ti], acc[ci][ti]);      // w_lo . a_hi
+#pragma unroll
+        for (int ci = 0; ci < 4; ++ci)
+#pragma unroll
+            for (int ti = 0; ti < 4; ++ti) mma_h(wf[0][ci], xf[1][ti], acc[ci][ti]);      // w_hi . a_lo
+#pragma unroll
+        for (int ci = 0; ci < 4; ++ci)
+#pragma unroll
+            for (int ti = 0; ti < 4; ++ti) mma_h(wf[0][ci], xf[0][ti], acc[ci][ti]);      // w_hi . a_hi
+    }
+};
+
 template <typename OutT> struct Out;
 template <> struct Out<float> {
     using raw4 = float4;
@@ -567,6 +621,9 @@ __global__ __launch_bounds__(512, HAS_A2 ? 2 : 4) void gemm_ws_kernel(
         const int tid = threadIdx.x - 256;
         const int srow = tid >> 3, kc = tid & 7;
         const int lds0 = srow * LDS_ROW + ((kc ^ (srow & 7)) * 16);
+        // split operands: this lane's 4 k (4 kc ..) land in half kc & 1 of chunk kc >> 1 (hi) and of chunk 4 + (kc >> 1) (lo)
+        const int xh_ = (((kc >> 1) ^ (srow & 7)) * 16) + (kc & 1) * 8, xl_ = (((4 + (kc >> 1)) ^ (srow & 7)) * 16) + (kc & 1) * 8;
+        (void)xh_; (void)xl_;
         long a_off[4], w_off[4], a2_off[4];
         int hi0[4], wi0[4];
         const int slabs_per_tap = CONV ? (cp.Cin * (int)sizeof(T)) / SLAB : 1;
@@ -625,10 +682,18 @@ __global__ __launch_bounds__(512, HAS_A2 ? 2 : 4) void gemm_ws_kernel(
         }
 #define WS_LSTORE1(S, I)                                                                           \
         *reinterpret_cast<uint4*>(wt_ + I * 32 * LDS_ROW) = rw##S##I;                              \
-        *reinterpret_cast<uint4*>(wt_ + TILE_BYTES + I * 32 * LDS_ROW) = HAS_A2 ? GT<T>::add(ra##S##I, rb##S##I) : ra##S##I;
+        if constexpr (kSplit<T>) {      /* fp32 activations -> fp16 hi | lo halves of the row (see GT<f32s_t>) */ \
+            uint2 hi_, lo_;                                                                        \
+            GT<T>::split4(HAS_A2 ? GT<T>::add(ra##S##I, rb##S##I) : ra##S##I, hi_, lo_);           \
+            *reinterpret_cast<uint2*>(xs_ + I * 32 * LDS_ROW + xh_) = hi_;                         \
+            *reinterpret_cast<uint2*>(xs_ + I * 32 * LDS_ROW + xl_) = lo_;                         \
+        } else                                                                                     \
+            *reinterpret_cast<uint4*>(wt_ + TILE_BYTES + I * 32 * LDS_ROW) = HAS_A2 ? GT<T>::add(ra##S##I, rb##S##I) : ra##S##I;
 #define WS_LSTORE(S, STAGE)                                                                        \
         {                                                                                          \
             unsigned char* wt_ = smem + (STAGE) * 2 * TILE_BYTES + lds0;                           \
+            unsigned char* xs_ = smem + (STAGE) * 2 * TILE_BYTES + TILE_BYTES + srow * LDS_ROW;    \
+            (void)xs_;                                                                             \
             WS_LSTORE1(S, 0) WS_LSTORE1(S, 1) WS_LSTORE1(S, 2) WS_LSTORE1(S, 3)                    \
         }
 #define WS_ADVANCE_AND_LOAD(S)                                                                     \
@@ -709,6 +774,8 @@ __global__ __launch_bounds__(512, HAS_A2 ? 2 : 4) void gemm_ws_kernel(
                 xf[kq][i] = *reinterpret_cast<const uint4*>(xt + i * 16 * LDS_ROW + sw);
             }
         }
+        if constexpr (kSplit<T>) GT<T>::mma_slab(wf, xf, acc);
+        else {
 #pragma unroll
         for (int kq = 0; kq < 2; ++kq)
 #pragma unroll
@@ -718,6 +785,7 @@ __global__ __launch_bounds__(512, HAS_A2 ? 2 : 4) void gemm_ws_kernel(
                     if (!ABLATE(DBG_NO_MMA)) GT<T>::mma(wf[kq][ci], xf[kq][ti], acc[ci][ti]);
                     else asm volatile("" :: "v"(wf[kq][ci].x), "v"(xf[kq][ti].x));
                 }
+        }
         TL_EV(11)
         __syncthreads();
         TL_EV(10)
@@ -1106,8 +1174,10 @@ static int launch_conv(const void* X, const void* W, const float* bias, const vo
     const long nwg = (long)nM * nN;
     if (nwg > 0x7fffffffL) return DTLR_ESHAPE;
     const size_t lds = 4 * TILE_BYTES;
-    static DevOnce attr;
-    if (attr.first()) { (void)hipFuncSetAttribute((const void*)gemm_nt_kernel<T, OutT, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); }
+    if constexpr (!kSplit<T>) {
+        static DevOnce attr;
+        if (attr.first()) { (void)hipFuncSetAttribute((const void*)gemm_nt_kernel<T, OutT, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); }
+    }
     if (use_ws()) {
         bool done = false;
         const int rc = try_splitk<T, OutT, true>(X, W, bias, residual, nullptr, C, M, N, K, flags, cp, st, done);
@@ -1124,12 +1194,15 @@ static int launch_conv(const void* X, const void* W, const float* bias, const vo
 #undef CONV_ARGS
         return check_launch();
     }
+    if constexpr (kSplit<T>) return DTLR_ESHAPE;                 // split operands: the wave-specialised kernel only
+    else {
     const int per = plan_chain(nwg);
     const unsigned grid = (unsigned)(nN * ((nM + per - 1) / per));
     hipLaunchKernelGGL((gemm_nt_kernel<T, OutT, false, true>), dim3(grid), dim3(256), lds, st,
                        (const T*)X, (const T*)nullptr, (const T*)W, bias, (const OutT*)residual, (const uint8_t*)nullptr, (OutT*)C,
                        M, N, K, flags, nN, nM, per, cp);
     return check_launch();
+    }
 }
 
 template <typename T, typename OutT>
@@ -1174,6 +1247,8 @@ static int launch_gemm(const void* A, const void* A2, const void* W, const float
 #undef GEMM_ARGS
         return check_launch();
     }
+    if constexpr (kSplit<T>) return DTLR_ESHAPE;
+    else {
     const int per = plan_chain(nwg);
     const unsigned grid = (unsigned)(nN * ((nM + per - 1) / per));
     if (A2) {
@@ -1188,6 +1263,22 @@ static int launch_gemm(const void* A, const void* A2, const void* W, const float
                            (const T*)A, (const T*)nullptr, (const T*)W, bias, (const OutT*)residual, row_mask, (OutT*)C, M, N, K, flags, nN, nM, per, cp);
     }
     return check_launch();
+    }
+}
+
+// fp32 weight [rows, K] -> the split slab image (same bytes): per 32-k slab of a row, chunk c < 4 = fp16 hi of k 8c..8c+7, chunk 4 + c = lo
+__global__ __launch_bounds__(256) void split_pack_kernel(const float* __restrict__ w, unsigned char* __restrict__ out, long n4, int K)
+{
+    const long i = (long)blockIdx.x * 256 + threadIdx.x;          // one thread per 4 consecutive k
+    if (i >= n4) return;
+    const int k4 = K >> 2;
+    const long row = i / k4;
+    const int q = (int)(i % k4), slab = q >> 3, kc = q & 7;
+    uint2 hi, lo;
+    GT<f32s_t>::split4(*reinterpret_cast<const uint4*>(w + i * 4), hi, lo);
+    unsigned char* dst = out + (row * K + slab * 32) * 4 + (kc >> 1) * 16 + (kc & 1) * 8;
+    *reinterpret_cast<uint2*>(dst) = hi;
+    *reinterpret_cast<uint2*>(dst + 64) = lo;
 }
 
 }  // namespace dtlr
@@ -1218,7 +1309,22 @@ extern "C" int dtlr_gemm_nt(const void* A, const void* A2, const void* W, const 
         if (out_dtype == DTLR_F32) return launch_gemm<float, float>(A, A2, W, bias, residual, row_mask, C, M, N, K, flags, st);
         return DTLR_EDTYPE;
     }
+    if (in_dtype == DTLR_F32S) {                                 // fp32 activations, W = dtlr_split_pack_weights image, fp32 result
+        if (K % 32) return DTLR_ESHAPE;
+        if (out_dtype == DTLR_F32) return launch_gemm<f32s_t, float>(A, A2, W, bias, residual, row_mask, C, M, N, K, flags, st);
+        return DTLR_EDTYPE;
+    }
     return DTLR_EDTYPE;
+}
+
+extern "C" int dtlr_split_pack_weights(const float* w, void* out, long rows, int K, void* stream)
+{
+    clear_stale_error();
+    if (!w || !out || rows <= 0 || K <= 0) return DTLR_EINVAL;
+    if (K % 32) return DTLR_ESHAPE;
+    const long n4 = rows * (K / 4);
+    hipLaunchKernelGGL(split_pack_kernel, dim3((unsigned)((n4 + 255) / 256)), dim3(256), 0, (hipStream_t)stream, w, (unsigned char*)out, n4, K);
+    return check_launch();
 }
 
 // dtlr_gemm_nt with a row-BROADCAST A2: A2 has a2_rows rows and row m of A is paired with row m % a2_rows (the encoder's
@@ -1239,6 +1345,10 @@ extern "C" int dtlr_gemm_nt_a2bcast(const void* A, const void* A2, int a2_rows, 
         if (K % 32) return DTLR_ESHAPE;
         return launch_gemm<float, float>(A, A2, W, bias, nullptr, nullptr, C, M, N, K, flags, (hipStream_t)stream, a2_rows);
     }
+    if (dtype == DTLR_F32S) {
+        if (K % 32) return DTLR_ESHAPE;
+        return launch_gemm<f32s_t, float>(A, A2, W, bias, nullptr, nullptr, C, M, N, K, flags, (hipStream_t)stream, a2_rows);
+    }
     return DTLR_EDTYPE;
 }
 
@@ -1255,7 +1365,7 @@ extern "C" int dtlr_gemm_nt_rowmax_lda(const void* A, int lda, const void* W, co
     clear_stale_error();
     if (!A || !W || !rowmax) return DTLR_EINVAL;
     if (M <= 0 || N <= 0 || K <= 0 || lda < K) return DTLR_EINVAL;
-    if ((lda * (in_dtype == DTLR_F32 ? 4 : 2)) & 15) return DTLR_ESHAPE;          // rows must stay 16-byte aligned
+    if ((lda * (in_dtype == DTLR_F32 || in_dtype == DTLR_F32S ? 4 : 2)) & 15) return DTLR_ESHAPE;          // rows must stay 16-byte aligned
     hipStream_t st = (hipStream_t)stream;
     if (hipMemsetD32Async((hipDeviceptr_t)rowmax, (int)0xff800000u, (size_t)M, st) != hipSuccess) { g_last_hip_error = (int)hipGetLastError(); return DTLR_ELAUNCH; }
     const int flags = (bias ? EPI_BIAS : 0) | EPI_ROWMAX;
@@ -1266,6 +1376,10 @@ extern "C" int dtlr_gemm_nt_rowmax_lda(const void* A, int lda, const void* W, co
     if (in_dtype == DTLR_F32) {
         if (K % 32) return DTLR_ESHAPE;
         return launch_gemm<float, float>(A, nullptr, W, bias, nullptr, nullptr, rowmax, M, N, K, flags, st, 0, lda == K ? 0 : lda);
+    }
+    if (in_dtype == DTLR_F32S) {
+        if (K % 32) return DTLR_ESHAPE;
+        return launch_gemm<f32s_t, float>(A, nullptr, W, bias, nullptr, nullptr, rowmax, M, N, K, flags, st, 0, lda == K ? 0 : lda);
     }
     return DTLR_EDTYPE;
 }
@@ -1295,7 +1409,7 @@ extern "C" int dtlr_conv2d_nhwc(const void* X, const void* W, const float* bias,
     clear_stale_error();
     if (!X || !W || !Y) return DTLR_EINVAL;
     if (B <= 0 || H <= 0 || Wd <= 0 || Cin <= 0 || Cout <= 0 || KH <= 0 || KW <= 0 || stride <= 0 || pad < 0) return DTLR_EINVAL;
-    const int elem = dtype == DTLR_H16 ? 2 : dtype == DTLR_F32 ? 4 : 0;
+    const int elem = dtype == DTLR_H16 ? 2 : (dtype == DTLR_F32 || dtype == DTLR_F32S) ? 4 : 0;
     if (!elem) return DTLR_EDTYPE;
     if ((Cin * elem) % SLAB) return DTLR_ESHAPE;                 // a K slab must stay inside one tap
     ConvP cp;
@@ -1314,5 +1428,6 @@ extern "C" int dtlr_conv2d_nhwc(const void* X, const void* W, const float* bias,
         && dtlr_conv3x3_patch_supported(Cin, Cout) == 1)
         return dtlr_conv3x3_patch_bf16(X, W, bias, Y, B, H, Wd, Cin, Cout, relu ? 1 : 0, stream);
     if (dtype == DTLR_H16) return launch_conv<uint16_t, uint16_t>(X, W, bias, residual, Y, (int)M, Cout, K, flags, cp, st);
+    if (dtype == DTLR_F32S) return launch_conv<f32s_t, float>(X, W, bias, residual, Y, (int)M, Cout, K, flags, cp, st);
     return launch_conv<float, float>(X, W, bias, residual, Y, (int)M, Cout, K, flags, cp, st);
 }

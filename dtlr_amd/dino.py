@@ -242,11 +242,15 @@ class _Transformer(nn.Module):
 class DINO(nn.Module):
     """Cross-attention detector used as a text-line recogniser (models/dino/dino.py:49-415)."""
 
-    def __init__(self, cfg: DTLRConfig, compute_dtype: torch.dtype = torch.float32):
+    def __init__(self, cfg: DTLRConfig, compute_dtype=torch.float32):
+        """compute_dtype: torch.float32 (exact-fp32 MFMA: the slow parity engine), torch.bfloat16 / torch.float16 (the 16-bit
+        engines) or the string "f32s" (fp32 activations, every product as three fp16 MFMAs on hi + lo halves: fp32-grade results
+        at about a third of the 16-bit engines' rate -- DTLREngine(split=True))."""
         super().__init__()
         cfg.validate()
         self.cfg = cfg
-        self.compute_dtype = compute_dtype
+        self.compute_split = compute_dtype == "f32s"
+        self.compute_dtype = torch.float32 if self.compute_split else compute_dtype
         d = cfg.hidden_dim
         self.num_queries, self.num_classes, self.hidden_dim = cfg.num_queries, cfg.num_classes, d
         self.num_feature_levels, self.nheads = cfg.num_feature_levels, cfg.nheads
@@ -291,7 +295,7 @@ class DINO(nn.Module):
             dev = next(self.parameters()).device
             if dev.type != "cuda":
                 raise RuntimeError("dtlr_amd.DINO has no CPU path: call model.to('cuda') / model.cuda() first")
-            self._engine = DTLREngine(self.cfg, self.state_dict(), dev, self.compute_dtype)
+            self._engine = DTLREngine(self.cfg, self.state_dict(), dev, self.compute_dtype, split=self.compute_split)
         return self._engine
 
     @torch.no_grad()

@@ -113,6 +113,13 @@ def pin_to_local_cpus(local: int, world: int, max_threads: int = 4):
     sharing cores; torch's intra-op pool is capped (the step has no host-side tensor math).  Returns a description for the bench line."""
     info = {"numa_node": None, "cpus": None}
     try:
+        # `world` counts the ranks of the whole job; CPUs are shared among the ranks of THIS node only (a 16-rank job on two nodes
+        # must not give each rank 1/16 of a node, nor ask for the NUMA node of a GPU the node does not have)
+        n_local = int(os.environ.get("LOCAL_WORLD_SIZE", 0)) or world
+        if torch.cuda.is_available():
+            n_local = min(n_local, max(torch.cuda.device_count(), 1))
+        world = max(1, min(world, n_local))
+        local = local % world
         allowed = sorted(os.sched_getaffinity(0))
         node = gpu_numa_node(local)
         cpus, slot, n_slots = allowed, local, world

@@ -37,9 +37,16 @@ def _fold_bn(sd, conv_key: str, bn_prefix: str):
 
 class DTLREngine:
     def __init__(self, cfg: DTLRConfig, state_dict: Dict[str, torch.Tensor], device="cuda:0",
-                 dtype: torch.dtype = torch.float32):
+                 dtype: torch.dtype = torch.float32, split: bool = False):
+        """`split=True` (with dtype float32): the parity-grade engine at the 16-bit matrix rate / 3 -- activations, residual streams,
+        normalisation inputs and the box chain stay fp32 exactly as in the fp32 engine, but every GEMM / convolution weight is packed
+        as a split fp16 hi + lo image (ops.split_pack) and multiplied by the DTLR_F32S kernels (three fp16 MFMAs per product, fp32
+        accumulation: ~2^-21 relative instead of the 16-bit engines' 2^-9 / 2^-12 per rounding point)."""
         cfg.validate()
         self.cfg, self.device, self.dtype = cfg, torch.device(device), dtype
+        self.split = bool(split)
+        if self.split and dtype != torch.float32:
+            raise ValueError("DTLREngine(split=True) is a float32 engine")
         if self.device.type != "cuda":
             raise RuntimeError("DTLREngine runs on the GPU only (no CPU path)")
         ops.require_cuda(torch.empty(0, device=self.device))
@@ -73,18 +80,23 @@ class DTLREngine:
     def _put(self, name, t, dtype=None):
         self.w[name] = t.to(device=self.device, dtype=dtype or self.dtype).contiguous()
 
+    def _gw(self, t):
+        """a GEMM / convolution weight in the form the engine's kernels multiply: the engine dtype, or its split image."""
+        t = t.to(device=self.device, dtype=self.dtype).contiguous()
+        return ops.split_pack(t) if self.split else t
+
     def _put_conv(self, name, w, b):
         elem = 2 if self.dtype in ops.H16 else 4
         if w.shape[2] == 1 and w.shape[3] == 1:      # 1x1 conv == linear over NHWC pixels: [Cout, Cin]
-            self.w[name + ".w"] = w.flatten(1).to(device=self.device, dtype=self.dtype).contiguous()
+            self.w[name + ".w"] = self._gw(w.flatten(1))
         elif (w.shape[1] * elem) % 128 == 0:         # implicit-GEMM HIP kernel: [Cout, KH, KW, Cin]
-            self.w[name + ".w"] = w.permute(0, 2, 3, 1).to(device=self.device, dtype=self.dtype).contiguous()
+            self.w[name + ".w"] = self._gw(w.permute(0, 2, 3, 1))
         else:
             raise ValueError(f"_put_conv({name}): Cin = {w.shape[1]} does not fit the implicit-GEMM kernel (the stem has its own)")
         self.w[name + ".b"] = b.to(device=self.device, dtype=torch.float32).contiguous()
 
     def _put_linear(self, name, w, b):
-        self._put(name + ".w", w)
+        self.w[name + ".w"] = self._gw(w)
         self._put(name + ".b", b, torch.float32)          # biases enter the GEMM epilogue in fp32
 
     def _pack_swin(self, sd):
@@ -120,7 +132,7 @@ class DTLREngine:
                 self._put(q + "ln.b", sd[p + "norm.bias"], f32)
                 wt = sd[p + "reduction.weight"]
                 kp = self._swin_kpad(wt.shape[1])
-                self._put(q + "w", wt if kp == wt.shape[1] else torch.nn.functional.pad(wt, (0, kp - wt.shape[1])))
+                self.w[q + "w"] = self._gw(wt if kp == wt.shape[1] else torch.nn.functional.pad(wt, (0, kp - wt.shape[1])))
             if i in cfg.return_interm_indices:
                 self._put(f"swin.norm{i}.w", sd[f"{b}norm{i}.weight"], f32)
                 self._put(f"swin.norm{i}.b", sd[f"{b}norm{i}.bias"], f32)
@@ -244,6 +256,9 @@ class DTLREngine:
             self._put(f"enc_bbox{i}.b", sd[f"{t}enc_out_bbox_embed.layers.{i}.bias"], f32)
             self._put(f"bbox{i}.w", sd[f"bbox_embed.0.layers.{i}.weight"], f32)
             self._put(f"bbox{i}.b", sd[f"bbox_embed.0.layers.{i}.bias"], f32)
+            if i < 2 and self.split:                   # the hidden layers are GEMMs; the 256 -> 4 layer is read by box_head_refine as fp32
+                self.w[f"enc_bbox{i}.w"] = ops.split_pack(self.w[f"enc_bbox{i}.w"])
+                self.w[f"bbox{i}.w"] = ops.split_pack(self.w[f"bbox{i}.w"])
             if i < 2 and self.dtype in ops.H16:
                 # bf16 engine: the two hidden layers of the box MLPs run on the bf16 MFMA path (their input, the decoder
                 # state, is bf16 already); accumulation, the 256->4 output layer and all box arithmetic stay fp32.
@@ -257,6 +272,9 @@ class DTLREngine:
         self._put("enc_class.b", sd[t + "enc_out_class_embed.bias"], f32)
         self._put("class.w", sd["class_embed.0.weight"], f32)
         self._put("class.b", sd["class_embed.0.bias"], f32)
+        if self.split:
+            self.w["enc_class.w"] = ops.split_pack(self.w["enc_class.w"])
+            self.w["class.w"] = ops.split_pack(self.w["class.w"])
         self.num_classes = int(sd["class_embed.0.weight"].shape[0])
 
     # ------------------------------------------------------------------------------ stages
@@ -473,7 +491,7 @@ class DTLREngine:
     def _calibrate_msda(self, x_shape, level_hw):
         """One encoder pass on a seeded noise batch (2 lines of this canvas shape, unpadded) -> the per-layer kernel choice."""
         gen = torch.Generator().manual_seed(20260927)
-        xc = torch.randn((min(2, int(x_shape[0])),) + tuple(x_shape[1:]), generator=gen).to(self.device)
+        xc = torch.randn((2,) + tuple(x_shape[1:]), generator=gen).to(self.device)       # always 2 lines: the choice must not depend on the caller's batch size
         mc = torch.zeros((xc.shape[0],) + tuple(x_shape[2:]), dtype=torch.bool, device=self.device)
         self._msda_calibrating = {}
         try:
@@ -483,6 +501,14 @@ class DTLREngine:
             self._msda_state.update(self._msda_calibrating)
         finally:
             self._msda_calibrating = None
+            # a shape the probe never reaches (window plan does not fit, L / P / head size other than 4 / 4 / 32) must not be
+            # re-calibrated on every forward: record the (only possible) choice for it
+            key0 = ("enc0.attn", tuple((int(h), int(w)) for h, w in level_hw))
+            self._msda_state.setdefault(key0, {"mode": "gather", "halo": None})
+            if len(self._msda_state) > 64 * max(1, self.cfg.enc_layers):      # evaluation over many canvas shapes: bounded state
+                for k in list(self._msda_state)[: len(self._msda_state) // 2]:
+                    if k != key0:
+                        del self._msda_state[k]
 
     def _msda_module(self, name, query, query_pos, ref, value_src, g, n_points, value=None, ow_res=None):
         """MSDeformAttn.forward (ops/modules/ms_deform_attn.py:78-126) without the output

@@ -256,7 +256,8 @@ def build_parser() -> argparse.ArgumentParser:
     ap.add_argument("--out", default="stats_dect")
     ap.add_argument("--batch", type=int, default=32)
     ap.add_argument("--batching", default="exact", choices=["exact", "padded"])
-    ap.add_argument("--dtype", default="bf16", choices=["bf16", "f16", "f32"])
+    ap.add_argument("--dtype", default="bf16", choices=["bf16", "f16", "f32s", "f32"],
+                    help="bf16 / f16: the 16-bit engines; f32s: fp32 activations, split fp16 products (parity-grade, ~1/3 of the 16-bit rate); f32: exact-fp32 MFMA")
     ap.add_argument("--limit", type=int, default=0, help="evaluate only the first N lines")
     ap.add_argument("--size", type=int, default=EVAL_SIZE, help="eval resize: short side (config/coco_transformer.py:1)")
     ap.add_argument("--max_size", type=int, default=EVAL_MAX_SIZE, help="eval resize: long-side cap (config/coco_transformer.py:2)")
@@ -281,7 +282,7 @@ def main(argv: Optional[Sequence[str]] = None) -> Dict:
     rows = load_labels(args.labels, args.mode)
     if args.limit:
         rows = rows[: args.limit]
-    model = DINO(cfg, compute_dtype={"bf16": torch.bfloat16, "f16": torch.float16, "f32": torch.float32}[args.dtype])
+    model = DINO(cfg, compute_dtype={"bf16": torch.bfloat16, "f16": torch.float16, "f32": torch.float32, "f32s": "f32s"}[args.dtype])
     model = E.load_model(model, args.weights, device=dev, new_class_embedding=args.new_class_embedding, charset_size=len(charset),
                          new_label_enc=args.new_label_enc, fix_enc_out_class=args.fix_enc_out_class)
     # TH / NM grids exactly as evaluation.py:38-49

@@ -29,6 +29,41 @@ _DT = {torch.float32: _lib.DTLR_F32, torch.bfloat16: _lib.DTLR_BF16, torch.float
 H16 = (torch.bfloat16, torch.float16)
 
 
+class SplitWeight(torch.Tensor):
+    """An fp32-shaped tensor whose BYTES are the split slab image of an fp32 weight (`split_pack` / dtlr_split_pack_weights: per 32-k
+    slab of a row, fp16 hi halves then fp16 lo halves).  `linear`, `linear_rowmax` and `conv2d_nhwc` recognise it and run the DTLR_F32S
+    kernels (fp32 activations, three fp16 MFMAs per product: fp32-grade results at 16/3 x the rate of the exact-fp32 MFMA).  Views and
+    row slices of an image are images of the same rows (the default __torch_function__ keeps the subclass); its VALUES mean nothing to torch."""
+
+
+def split_pack(w):
+    """fp32 weight [N, K] (nn.Linear) or [Cout, KH, KW, Cin] (NHWC convolution), K (resp. KH*KW*Cin) a multiple of 32, on the GPU ->
+    SplitWeight of the same shape (dtlr_split_pack_weights)."""
+    require_cuda(w, "w")
+    w = w.detach().float().contiguous()
+    rows = int(w.shape[0])
+    K = w.numel() // rows
+    if K % 32:
+        raise _lib.DTLRError(f"ops.split_pack: K = {K} is not a multiple of 32")
+    out = torch.empty_like(w)
+    code = _lib.lib().dtlr_split_pack_weights(w.data_ptr(), out.data_ptr(), rows, K, _lib.current_stream())
+    _lib.check(code, "dtlr_split_pack_weights")
+    return out.as_subclass(SplitWeight)
+
+
+def _in_dt(x, w):
+    """dtype code of a GEMM's operands: DTLR_F32S when the weight is a split image (the activations are then fp32)."""
+    if isinstance(w, SplitWeight):
+        if x.dtype != torch.float32:
+            raise _lib.DTLRError("a SplitWeight multiplies fp32 activations")
+        return _lib.DTLR_F32S
+    return _DT[x.dtype]
+
+
+def _gkind(x, w):
+    return "gemm_bf16" if x.dtype in H16 else ("gemm_f32s" if isinstance(w, SplitWeight) else "gemm_f32")
+
+
 def _L(*ts):
     """the library that serves these tensors / dtypes: the fp16 build if any of them is fp16, else the bf16 build."""
     for t in ts:
@@ -101,10 +136,10 @@ def linear(x, w, b=None, relu=False, residual=None, a2=None, row_mask=None, out_
         M, R2 = x.numel() // K, a2.numel() // K
         y = torch.empty(x.shape[:-1] + (N,), dtype=out_dtype, device=x.device)
         es = x.element_size()
-        with _Timed("gemm_bf16" if x.dtype in H16 else "gemm_f32", 2.0 * M * N * K,
+        with _Timed(_gkind(x, w), 2.0 * M * N * K,
                     float(M) * K * es + float(R2) * K * es + float(N) * K * es + float(M) * N * es, f"linear M{M} N{N} K{K}+a2bcast{R2}"):
             code = _L(x).dtlr_gemm_nt_a2bcast(x.data_ptr(), a2.data_ptr(), R2, w.data_ptr(), 0 if b is None else b.data_ptr(), y.data_ptr(),
-                                                   M, N, K, _DT[x.dtype], _lib.current_stream())
+                                                   M, N, K, _in_dt(x, w), _lib.current_stream())
         _lib.check(code, "dtlr_gemm_nt_a2bcast")
         return y
     if x.dtype in H16 + (torch.float32,) and w.dtype == x.dtype and K % slab == 0 \
@@ -122,11 +157,11 @@ def linear(x, w, b=None, relu=False, residual=None, a2=None, row_mask=None, out_
         es, eo = x.element_size(), (2 if out_dtype in H16 else 4)
         nbytes = float(M) * K * es * (2 if a2 is not None else 1) + float(N) * K * es + float(M) * N * eo * (2 if residual is not None else 1)
         tag = f"linear M{M} N{N} K{K}" + ("+a2" if a2 is not None else "") + ("+res" if residual is not None else "") + ("" if out_dtype == x.dtype else "->f32")
-        with _Timed("gemm_bf16" if x.dtype in H16 else "gemm_f32", 2.0 * M * N * K, nbytes, tag):
+        with _Timed(_gkind(x, w), 2.0 * M * N * K, nbytes, tag):
             code = _L(x).dtlr_gemm_nt(x.data_ptr(), 0 if a2 is None else a2.data_ptr(), w.data_ptr(),
                                            0 if b is None else b.data_ptr(), 0 if residual is None else residual.data_ptr(),
                                            0 if row_mask is None else row_mask.data_ptr(), y.data_ptr(),
-                                           M, N, K, int(relu), _DT[x.dtype], _DT[out_dtype], _lib.current_stream())
+                                           M, N, K, int(relu), _in_dt(x, w), _DT[out_dtype], _lib.current_stream())
         _lib.check(code, "dtlr_gemm_nt")
         return y
     raise _lib.DTLRError(f"ops.linear: no HIP kernel for x {tuple(x.shape)} {x.dtype} @ w {tuple(w.shape)} {w.dtype} -> {out_dtype} "
@@ -320,10 +355,10 @@ def linear_rowmax(x, w, b=None):
     M = x.numel() // K
     out = torch.empty(x.shape[:-1], dtype=torch.float32, device=x.device)
     es = x.element_size()
-    with _Timed("gemm_bf16" if x.dtype in H16 else "gemm_f32", 2.0 * M * N * K, float(M) * K * es + float(N) * K * es + 4.0 * M,
+    with _Timed(_gkind(x, w), 2.0 * M * N * K, float(M) * K * es + float(N) * K * es + 4.0 * M,
                 f"rowmax M{M} N{N} K{K}"):
         code = _L(x).dtlr_gemm_nt_rowmax_lda(x.data_ptr(), lda, w.data_ptr(), 0 if b is None else b.data_ptr(), out.data_ptr(),
-                                             M, N, K, _DT[x.dtype], _lib.current_stream())
+                                             M, N, K, _in_dt(x, w), _lib.current_stream())
     _lib.check(code, "dtlr_gemm_nt_rowmax_lda")
     return out
 
@@ -533,11 +568,11 @@ def conv2d_nhwc(x, w, bias, stride: int, padding: int, relu=False, residual=None
         es = x.element_size()
         nbytes = (float(x.numel()) / (stride * stride if KH == 1 else 1) + float(w.numel()) + float(B) * Ho * Wo * Cout * (2 if residual is not None else 1)) * es
         tag = f"conv{KH}x{KW}s{stride} M{B * Ho * Wo} N{Cout} K{KH * KW * Cin}" + ("+res" if residual is not None else "")
-        with _Timed("gemm_bf16" if x.dtype in H16 else "gemm_f32", 2.0 * B * Ho * Wo * Cout * KH * KW * Cin, nbytes, tag):
+        with _Timed(_gkind(x, w), 2.0 * B * Ho * Wo * Cout * KH * KW * Cin, nbytes, tag):
             code = _L(x).dtlr_conv2d_nhwc(x.data_ptr(), w.data_ptr(), 0 if bias is None else bias.data_ptr(),
                                                0 if residual is None else residual.data_ptr(), y.data_ptr(),
                                                B, H, W, Cin, Cout, KH, KW, stride, padding, 2 if relu else 0,
-                                               _DT[x.dtype], _lib.current_stream())
+                                               _in_dt(x, w), _lib.current_stream())
         _lib.check(code, "dtlr_conv2d_nhwc")
         return y
     raise _lib.DTLRError(f"ops.conv2d_nhwc: no HIP kernel for x {tuple(x.shape)} {x.dtype}, w {tuple(w.shape)} (weights must be "
@@ -1082,6 +1117,6 @@ def _device_scoped(fn):
 for _name in ("msda_encoder_far_fraction", "gemm_kres", "gemm_kres_chain", "gemm_kres_cat_s2", "gemm_kres_bcast384", "ffn32", "proj_ln_k256", "swin_patch_embed", "swin_window_attn", "swin_patch_merge", "geometry", "linear", "gemm_k256", "linear_rowmax", "two_stage_gather", "layernorm", "proj_ln", "proj_ln_split", "ffn_fused", "conv2d_nhwc", "stem_conv7x7", "stem_conv7x7_f32",
               "maxpool_nhwc", "groupnorm_tokens", "msda", "msda_fused", "msda_encoder", "mha", "decoder_query_prep", "box_mlp_refine",
               "box_head_refine", "box_refine", "topk_rows", "decode_blank", "preprocess_lines", "ctc_loss_interleaved", "nms_batched",
-              "topk_flat"):
+              "topk_flat", "stem_conv7x7_pool", "dec_query_stage", "blank_emissions", "split_pack"):
     globals()[_name] = _device_scoped(globals()[_name])
 del _name

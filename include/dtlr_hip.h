@@ -29,6 +29,10 @@ extern "C" {
 #define DTLR_F64 1
 #define DTLR_BF16 2
 #define DTLR_F16 3    /* IEEE fp16: accepted by libdtlr_hip_f16.so (the same sources built with -DDTLR_HALF_IS_F16) wherever libdtlr_hip.so accepts DTLR_BF16 */
+#define DTLR_F32S 4   /* "split fp32": fp32 activations / results in memory, products as three fp16 MFMAs on hi + lo halves (fp32-grade, ~2^-21
+                         relative; 16/3 x the rate of the exact-fp32 MFMA).  Accepted as the input dtype of dtlr_gemm_nt / _a2bcast / _rowmax(_lda)
+                         and dtlr_conv2d_nhwc; the weight argument is then the image written by dtlr_split_pack_weights (same size as the
+                         fp32 weight).  |activation| must stay below 65504. */
 
 const char *dtlr_strerror(int code);
 int dtlr_last_hip_error(void);          /* last hipError_t seen by this library (thread-local) */
@@ -238,8 +242,13 @@ int dtlr_mha_set_variant(int v);
  *   epilogue order: + bias -> ReLU (if relu == 1) -> zero rows where row_mask[m] != 0 (may be NULL,
  *   [M] bytes; value.masked_fill of ms_deform_attn.py:95-96) -> + residual (may be NULL, [M,N] out_dtype)
  *   -> ReLU (if relu == 2: the bottleneck tail relu(conv3 + identity)) -> store.
- *   in_dtype BF16 (K % 64 == 0; fp32 accumulate; out BF16 or F32) or F32 (K % 32 == 0; exact fp32 MFMA).
+ *   in_dtype BF16 (K % 64 == 0; fp32 accumulate; out BF16 or F32), F32 (K % 32 == 0; exact fp32 MFMA) or F32S (K % 32 == 0; A / A2 /
+ *   residual / C fp32, W the dtlr_split_pack_weights image: three fp16 MFMAs per product, fp32-grade).
  */
+/* W [rows, K] fp32 (nn.Linear layout; a [Cout, KH, KW, Cin] convolution weight is rows = Cout, K = KH*KW*Cin) -> `out`, rows*K*4 bytes:
+ * per 32-k slab of a row, 16-byte chunk c < 4 holds fp16(w) of k 8c..8c+7 and chunk 4 + c holds fp16(w - fp16(w)) of the same k -- the
+ * slab image the DTLR_F32S kernels copy to LDS.  Row slices of the image are images of the row slices.  K % 32 == 0.  (round 4) */
+int dtlr_split_pack_weights(const float *w, void *out, long rows, int K, void *stream);
 int dtlr_gemm_nt(const void *A, const void *A2, const void *W, const float *bias,
                  const void *residual, const unsigned char *row_mask, void *C,
                  int M, int N, int K, int relu, int in_dtype, int out_dtype, void *stream);

@@ -1291,3 +1291,92 @@ def test_mha_two_pass_variant_vs_fp32_reference(B, L, spread, half):
     assert torch.isfinite(got).all()
     assert (got - want).abs().max() <= tol, (got - want).abs().max()
     assert (got - dflt).abs().max() <= tol
+
+
+# ---- split-fp16 ("f32s") operands: fp32 activations, three fp16 MFMAs per product (round 4) -------------------------------------
+def _split_image_reference(w):
+    """what dtlr_split_pack_weights must write: per 32-k slab of a row, 4 chunks of 8 fp16 hi then 4 chunks of 8 fp16 lo."""
+    rows, K = w.shape[0], w.numel() // w.shape[0]
+    wf = w.reshape(rows, K).float()
+    hi = wf.half()
+    lo = (wf - hi.float()).half()
+    img = torch.cat([hi.view(rows, K // 32, 32), lo.view(rows, K // 32, 32)], -1)            # [rows, slabs, 64 halves]
+    return img.contiguous().view(torch.int16)
+
+
+def test_split_pack_image_and_subnormal_halves():
+    """the packed image is byte-for-byte the hi | lo slab layout, including weights so small that lo is an fp16 subnormal"""
+    from dtlr_amd import ops
+    for shape, scale in (((7, 64), 1.0), ((256, 256), 0.05), ((5, 3, 3, 32), 1e-3), ((3, 2048), 30.0)):
+        w = _rand(shape, 11, scale)
+        got = ops.split_pack(w.cuda())
+        assert isinstance(got, ops.SplitWeight) and got.shape == w.shape and got.dtype == torch.float32
+        want = _split_image_reference(w)
+        assert torch.equal(got.cpu().as_subclass(torch.Tensor).contiguous().view(torch.int16).view(want.shape), want), (shape, scale)
+        assert isinstance(got[1:3], ops.SplitWeight)                       # row slices stay images
+
+
+@pytest.mark.parametrize("M,N,K", GEMM_SHAPES)
+def test_gemm_split_vs_fp64(M, N, K):
+    """DTLR_F32S GEMM vs an fp64 reference on the SAME fp32 operands, every epilogue / prologue combination of the fp32 kernel.
+    The bound is the fp32 engine's own (2e-5 of the output scale: fp32 accumulation order), far below a plain fp16 product
+    (5e-4); a second pass with operands of magnitude 1e-3 .. 1e-2 puts every lo half in the fp16 SUBNORMAL range -- the
+    product stays fp32-grade only if the matrix cores keep subnormal inputs (they do on gfx950)."""
+    from dtlr_amd import ops
+    for sx, sw in ((1.0, 1.0), (1e-2, 3e-2)):
+        x, a2 = _rand((M, K), 1, sx), _rand((M, K), 2, sx)
+        w, b = _rand((N, K), 3, sw) / np.sqrt(K), _rand((N,), 4, sx * sw)
+        res = _rand((M, N), 5, sx * sw)
+        mask = torch.from_numpy(np.random.Generator(np.random.PCG64(6)).random(M) < 0.3)
+        wp = ops.split_pack(w.cuda())
+        worst = 0.0
+        for relu, use_b, use_res, use_a2, use_mask in ((0, False, False, False, False), (1, True, False, False, False),
+                                                       (0, True, True, True, True), (2, True, True, False, False)):
+            want = _gemm_ref(x, w, b if use_b else None, relu, res if use_res else None, a2 if use_a2 else None, mask if use_mask else None)
+            got = ops.linear(x.cuda(), wp, b.cuda() if use_b else None, relu, res.cuda() if use_res else None,
+                             a2.cuda() if use_a2 else None, mask.cuda() if use_mask else None).cpu()
+            assert got.shape == want.shape and got.dtype == torch.float32
+            scale = max(want.abs().max().item(), 1e-30)
+            worst = max(worst, (got - want).abs().max().item() / scale)
+            assert (got - want).abs().max() < 2e-5 * scale, (sx, relu, use_b, use_res, use_a2, use_mask, (got - want).abs().max().item() / scale)
+        print(f"[split gemm M{M} N{N} K{K} scale {sx:g}] worst error / output scale {worst:.2e}")
+
+
+def test_gemm_split_rowmax_a2bcast_and_large_values():
+    from dtlr_amd import ops
+    # row-max epilogue (the two-stage selection scores)
+    x, w, b = _rand((777, 256), 1), _rand((166, 256), 2) / 16.0, _rand((166,), 3)
+    want = (x.double() @ w.double().t() + b.double()).max(-1)[0].float()
+    got = ops.linear_rowmax(x.cuda(), ops.split_pack(w.cuda()), b.cuda()).cpu()
+    assert (got - want).abs().max() < 2e-5 * want.abs().max()
+    # row-broadcast A2 (position embedding of an unpadded batch)
+    x, pos = _rand((3, 640, 256), 4), _rand((640, 256), 5)
+    w, b = _rand((384, 256), 6) / 16.0, _rand((384,), 7)
+    want = ((x + pos).double() @ w.double().t() + b.double()).float()
+    got = ops.linear(x.cuda(), ops.split_pack(w.cuda()), b.cuda(), a2=pos.cuda()).cpu()
+    assert (got - want).abs().max() < 2e-5 * want.abs().max()
+    # activations up to a few thousand (ResNet maps before a normalisation): hi stays finite, the product exact to fp32 grade
+    x, w = _rand((300, 512), 8, 900.0), _rand((128, 512), 9) / 22.0
+    want = (x.double() @ w.double().t()).float()
+    got = ops.linear(x.cuda(), ops.split_pack(w.cuda())).cpu()
+    assert torch.isfinite(got).all() and (got - want).abs().max() < 2e-5 * want.abs().max()
+
+
+@pytest.mark.parametrize("B,H,W,Cin,Cout,k,stride,pad", [(2, 16, 40, 64, 64, 3, 1, 1), (3, 9, 33, 128, 128, 3, 2, 1),
+                                                         (1, 4, 64, 2048, 256, 3, 2, 1), (2, 5, 7, 32, 48, 3, 1, 1),
+                                                         (2, 6, 10, 64, 96, 1, 1, 0), (2, 9, 21, 256, 512, 1, 2, 0)])
+def test_conv2d_nhwc_split_vs_fp64(B, H, W, Cin, Cout, k, stride, pad):
+    """DTLR_F32S implicit-GEMM convolution (padding taps, stride 2, split-K at small grids) vs torch's fp64 conv2d."""
+    from dtlr_amd import ops
+    x = _rand((B, H, W, Cin), 1)
+    w = _rand((Cout, Cin, k, k), 2) / np.sqrt(Cin * k * k)
+    b = _rand((Cout,), 3)
+    ref = F.conv2d(x.permute(0, 3, 1, 2).double(), w.double(), b.double(), stride=stride, padding=pad).permute(0, 2, 3, 1)
+    res = _rand(tuple(ref.shape), 4)
+    wp = ops.split_pack(w.permute(0, 2, 3, 1).contiguous().cuda())
+    for relu, use_res in ((False, False), (True, False), (True, True)):
+        want = ref + res.double() if use_res else ref
+        want = want.clamp(min=0) if relu else want
+        got = ops.conv2d_nhwc(x.cuda(), wp, b.cuda(), stride, pad, relu, res.cuda() if use_res else None).cpu()
+        assert got.shape == want.shape
+        assert (got - want.float()).abs().max() < 3e-5 * max(1.0, want.abs().max().item()), (relu, use_res)

@@ -32,13 +32,18 @@ def _cpu(out):
     return {"pred_logits": out["pred_logits"].float().cpu(), "pred_boxes": out["pred_boxes"].float().cpu()}
 
 
-def test_tiny_model_vs_oracle_and_golden(golden_dir):
+# the two parity-grade engines: exact-fp32 MFMA, and fp32 activations with split fp16 products (DTLREngine(split=True), round 4)
+PARITY_ENGINES = [torch.float32, "f32s"]
+
+
+@pytest.mark.parametrize("engine", PARITY_ENGINES, ids=["f32", "f32s"])
+def test_tiny_model_vs_oracle_and_golden(golden_dir, engine):
     from oracle import dtlr_oracle as O
     g = np.load(os.path.join(golden_dir, "g2_tiny_model.npz"))
     cfg = DTLRConfig.tiny()
     sd = weights.synthetic_state_dict(cfg, 0)
     imgs = synth.stroke_lines(1, 32, 256, seed=5) + synth.noise_lines(1, 32, 192, seed=6)
-    m = _model(cfg, sd)
+    m = _model(cfg, sd, engine)
     m.return_aux = True
     out = m([i.cuda() for i in imgs], return_debug=True)
     d = out["_debug"]
@@ -66,11 +71,12 @@ def _reference_order_labels(g):
     return lab, order
 
 
+@pytest.mark.parametrize("engine", PARITY_ENGINES, ids=["f32", "f32s"])
 @pytest.mark.parametrize("tag", ["latin", "chinese"])
-def test_full_model_vs_golden_and_oracle(golden_dir, tag):
-    """BASELINE configs: Latin 128x2048 and Chinese (C=7356) 128x2560, mixed-width pair (padding).  fp32 engine vs the REAL
-    reference's stored outputs: scores, memory, logits, boxes, and the DECODED goldens (blank decoder decisions in reading order,
-    PostProcess top-k, the NMS decoder's PostProcess call)."""
+def test_full_model_vs_golden_and_oracle(golden_dir, tag, engine):
+    """BASELINE configs: Latin 128x2048 and Chinese (C=7356) 128x2560, mixed-width pair (padding).  The parity-grade engines (exact
+    fp32, and split fp16 products on fp32 activations) vs the REAL reference's stored outputs: scores, memory, logits, boxes, and the
+    DECODED goldens (blank decoder decisions in reading order, PostProcess top-k, the NMS decoder's PostProcess call)."""
     from dtlr_amd import evaluation as E
     from dtlr_amd.dino import PostProcess
     from oracle import dtlr_oracle as O
@@ -82,12 +88,15 @@ def test_full_model_vs_golden_and_oracle(golden_dir, tag):
     h, widths = int(g["height"]), [int(w) for w in g["widths"]]
     imgs = synth.stroke_lines(1, h, widths[0], seed=21) + synth.noise_lines(1, h, widths[1], seed=22)
     dimgs = [i.cuda() for i in imgs]
-    m = _model(cfg, sd)
+    m = _model(cfg, sd, engine)
     # (2) selection pinned to the reference's own -> compare with the reference's outputs
     ref_topk = torch.from_numpy(g["topk_idx"].astype(np.int64))
     out = m(dimgs, forced_topk=ref_topk.cuda(), return_debug=True)
     d = out["_debug"]
     score_err = (d["topk_scores"].cpu() - torch.from_numpy(g["topk_scores"])).abs().max().item()
+    lerr = (torch.gather(out["pred_logits"].cpu(), 2, torch.from_numpy(g["top8_idx"].astype(np.int64))) - torch.from_numpy(g["top8_val"])).abs().max().item()
+    berr = (out["pred_boxes"].cpu() - torch.from_numpy(g["pred_boxes"])).abs().max().item()
+    print(f"[{engine} vs reference golden, {tag}] score err {score_err:.2e}, logit err {lerr:.2e}, box err {berr:.2e}")
     assert score_err < 5e-4, score_err
     assert (d["memory"][:, ::67].cpu() - torch.from_numpy(g["memory_rows"])).abs().max() < 5e-4
     idx = torch.from_numpy(g["top8_idx"].astype(np.int64))
@@ -240,13 +249,14 @@ def test_decoders_and_cer_identical_to_oracle():
         assert E.character_error_rate(p, t) == O.character_error_rate_engine(p, t)
 
 
-def test_full_size_batch_properties():
+@pytest.mark.parametrize("engine", PARITY_ENGINES, ids=["f32", "f32s"])
+def test_full_size_batch_properties(engine):
     """BASELINE bs=32 at 128x2048 (fp32): per-line independence -- a line's result does not depend on
     its batch neighbours (no cross-sample op anywhere in DINO.forward) -- and padding equivalence:
     a narrower line padded into the 2048 canvas gives the same logits as when run alone."""
     cfg = DTLRConfig.latin()
     sd = weights.synthetic_state_dict(cfg, 0)
-    m = _model(cfg, sd)
+    m = _model(cfg, sd, engine)
     imgs = [i.cuda() for i in synth.noise_lines(32, 128, 2048, seed=4)]
     full = m(imgs, return_debug=True)
     idx = full["_debug"]["topk_idx"]
@@ -446,6 +456,28 @@ def test_data_parallel_two_ranks_on_one_gpu_equals_single_process():
     assert line["n_gpus"] == 2 and line["config"]["global_batch"] == 6
     d = line["distributed"]
     assert (d["backend"], d["world_size"], d["dp_verified"]) == ("gloo", 2, True), d
+
+
+def test_bench_gpus_n_starts_its_own_ranks():
+    """The driver's command form, `python bench.py --gpus N` WITHOUT a launcher in the environment (round 3: it exited with "launch with
+    torch.distributed.run"): bench.py re-executes itself through torch.distributed.run, rank 0 prints the one JSON line, dp_verified holds."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT", "LOCAL_WORLD_SIZE")}
+    cmd = [sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1", "--batch", "3",
+           "--backend", "gloo", "--single-device", "--no-cpu-baseline", "--no-parity", "--min-seconds", "0"]
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=600, cwd=root, env=env)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, lines
+    line = json.loads(lines[0])
+    d = line["distributed"]
+    assert line["n_gpus"] == 2 and (d["backend"], d["world_size"], d["dp_verified"]) == ("gloo", 2, True), d
+    # a failing rank's exit code propagates
+    bad = subprocess.run(cmd + ["--engine-opt", "no_such_attribute=1"], capture_output=True, text=True, timeout=600, cwd=root, env=env)
+    assert bad.returncode != 0
 
 
 def test_ngram_emissions_and_rescoring_on_device(golden_dir):

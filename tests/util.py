@@ -86,67 +86,8 @@ def ctc_case(seed, B, nq, C, bias, lmax):
     return {"pred_logits": torch.from_numpy(logits), "pred_boxes": torch.from_numpy(boxes)}, labels
 
 
-# ---- margin-aware comparison of decoded outputs -------------------------------------------------------------------------------
-def query_decisions(logits, boxes, eps):
-    """Per-query view of the blank/argmax decoder (evaluation.py:116-158 / dino.py:466-502), BEFORE the reading-order sort:
-    label [B,nq] (class index, -1 = blank) and a decision margin [B,nq] in LOGIT units: how far the per-query logits may move
-    (max-abs, all classes at once) before the decision can change -- min(top1 - top2 logit gap, |logit(top prob) - logit(blank prob)|),
-    the second term halved because a uniform shift moves the blank channel (1 - sum p) against the class channel."""
-    logits = logits.float()
-    C = logits.shape[-1]
-    p = torch.sigmoid(logits)
-    s = p.sum(-1)
-    e = eps if eps is not None else 0.03 / C
-    small = s < 1 - e
-    ptop, arg = p.max(-1)
-    blank = torch.where(small, 1 - s, torch.full_like(s, e))
-    top = torch.where(small, ptop, (1 - e) * ptop / s)
-    label = torch.where(blank >= top, torch.full_like(arg, -1), arg)
-    t2 = logits.topk(2, -1)[0]
-    lg = lambda x: torch.log(x.clamp(1e-12, 1 - 1e-7) / (1 - x.clamp(1e-12, 1 - 1e-7)))
-    m_blank = (lg(top) - lg(blank)).abs() * 0.5
-    margin = torch.where(label >= 0, torch.minimum(t2[..., 0] - t2[..., 1], m_blank), m_blank)
-    return label, margin
-
-
-def safe_reading(labels, margins, cx, logit_bound, cx_bound):
-    """Reading-order strings restricted to SAFE queries: decision margin > 2 * logit_bound, and (for the order) no other non-blank
-    query closer than 2 * cx_bound in cx.  Returns (list of index tensors = safe non-blank queries in cx order, safe mask [B,nq])."""
-    out, safe_all = [], labels.new_zeros(labels.shape, dtype=torch.bool)
-    for b in range(labels.shape[0]):
-        safe = margins[b] > 2 * logit_bound
-        safe_all[b] = safe
-        cand = torch.nonzero((labels[b] >= 0) | ~safe).flatten()          # every query that may print a character
-        order = cand[torch.argsort(cx[b, cand], stable=True)]
-        c = cx[b, order]
-        close = torch.zeros_like(c, dtype=torch.bool)
-        if len(c) > 1:
-            gap = (c[1:] - c[:-1]) < 2 * cx_bound
-            close[1:] |= gap
-            close[:-1] |= gap
-        keep = ~close & safe[order] & (labels[b, order] >= 0)
-        out.append(order[keep])
-    return out, safe_all
-
-
-def compare_decoded(ref_logits, ref_boxes, got_logits, got_boxes, eps, logit_bound, cx_bound):
-    """Margin-aware equality of two decodes of the same queries: on every query whose reference margin exceeds 2 * logit_bound the
-    labels must be identical, and the reading-order strings restricted to the safe, cx-separated non-blank queries must be identical
-    (CER == 0 on them).  Returns statistics for the caller to assert on / print."""
-    rl, rm = query_decisions(ref_logits, ref_boxes, eps)
-    gl, _ = query_decisions(got_logits, got_boxes, eps)
-    keep, safe = safe_reading(rl, rm, ref_boxes[..., 0].float(), logit_bound, cx_bound)
-    mism = int(((rl != gl) & safe).sum())
-    strings_equal = True
-    n_chars = 0
-    for b, idx in enumerate(keep):
-        ref_s = rl[b, idx].tolist()
-        gi = idx[torch.argsort(got_boxes[b, idx, 0].float(), stable=True)]
-        got_s = gl[b, gi].tolist()
-        n_chars += len(ref_s)
-        strings_equal &= (ref_s == got_s)
-    return dict(safe_frac=float(safe.float().mean()), label_mismatch_on_safe=mism, strings_equal=strings_equal, safe_chars=n_chars,
-                chars_ref=int((rl >= 0).sum()), chars_got=int((gl >= 0).sum()), raw_label_agree=float((rl == gl).float().mean()))
+# ---- margin-aware comparison of decoded outputs: moved to oracle/compare.py (checker code shared with bench.py's parity leg) -------
+from oracle.compare import compare_decoded, query_decisions, safe_reading, tie_aware_compare  # noqa: E402,F401
 
 
 # ---- n-gram re-scoring fixtures (shared by tests/golden/make_golden_ngram.py and the tests) -------------------------------------

@@ -147,6 +147,7 @@ def reduce_(fetch_dir, write_dir, order_path, out_path):
         out[f"{kind}_bytes_per_launch_mean"] = round(b / n)
         out[f"{kind}_algorithmic_bytes_per_launch_mean"] = round(alg / n)
         out[f"{kind}_launches"] = n
+    out["_commit"] = os.environ.get("DTLR_COMMIT") or "unknown (set DTLR_COMMIT=$(git rev-parse --short HEAD) when launching through gpurun: .git does not travel)"
     with open(out_path, "w") as fp:
         json.dump(out, fp, indent=1)
     print(json.dumps({k: v for k, v in out.items() if not k.startswith("gemm")}, indent=1))

@@ -17,6 +17,7 @@ def main():
     ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--top", type=int, default=60)
     ap.add_argument("--batch", type=int, default=32)
+    ap.add_argument("--dtype", default="bf16", choices=["bf16", "f16", "f32s", "f32"])
     args = ap.parse_args()
     from dtlr_amd import ops, synth, weights
     from dtlr_amd.config import DTLRConfig
@@ -24,7 +25,8 @@ def main():
     from dtlr_amd.evaluation import decode_blank_records
     dev = torch.device("cuda:0")
     cfg = DTLRConfig.latin()
-    eng = DTLREngine(cfg, weights.synthetic_state_dict(cfg, seed=0), dev, torch.bfloat16)
+    eng = DTLREngine(cfg, weights.synthetic_state_dict(cfg, seed=0), dev,
+                     {"bf16": torch.bfloat16, "f16": torch.float16}.get(args.dtype, torch.float32), split=args.dtype == "f32s")
     x = torch.stack(synth.noise_lines(args.batch, 128, 2048, seed=1000)).to(dev)
     mask = torch.zeros((args.batch, 128, 2048), dtype=torch.bool, device=dev)
     spans = []

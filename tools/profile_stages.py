@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Stage split of one bench step (HIP events around the engine's stage methods, averaged).
-    python tools/profile_stages.py [--steps 5] [--dtype bf16] [--batch 32]
+    python tools/profile_stages.py [--steps 5] [--dtype bf16|f16|f32s|f32] [--batch 32]
 Prints one JSON line: ms per stage.  Same workload as bench.py (Latin, 128x2048, synthetic)."""
 import argparse
 import json
@@ -24,9 +24,9 @@ def main():
     from dtlr_amd.engine import DTLREngine
     from dtlr_amd.evaluation import decode_blank_records
     dev = torch.device("cuda:0")
-    dtype = torch.bfloat16 if args.dtype == "bf16" else torch.float32
+    dtype = {"bf16": torch.bfloat16, "f16": torch.float16, "f32": torch.float32, "f32s": torch.float32}[args.dtype]
     cfg = DTLRConfig.latin()
-    eng = DTLREngine(cfg, weights.synthetic_state_dict(cfg, seed=0), dev, dtype)
+    eng = DTLREngine(cfg, weights.synthetic_state_dict(cfg, seed=0), dev, dtype, split=args.dtype == "f32s")
     x = torch.stack(synth.noise_lines(args.batch, 128, 2048, seed=1000)).to(dev)
     mask = torch.zeros((args.batch, 128, 2048), dtype=torch.bool, device=dev)
     spans = {}

@@ -15,7 +15,6 @@ run() {
 run
 run --lib-variant msda_enc=3
 run --lib-variant mha=1
-run --lib-variant msda_enc=3 --lib-variant mha=1
 run
 # parity of the combination on 8 lines of the bench batch (cer_vs_oracle of the bf16 line)
 timeout 200 python bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-other-dtypes --lib-variant msda_enc=3 --lib-variant mha=1 2>/dev/null \
