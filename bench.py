@@ -257,8 +257,6 @@ def main():
     ap.add_argument("--backbone", default=None, help="override the config's backbone (e.g. swin_T_224_1k, swin_B_224_22k: models/dino/backbone.py:172-205)")
     ap.add_argument("--engine-opt", action="append", default=[], metavar="NAME=VALUE",
                     help="set a DTLREngine attribute for an A/B run (e.g. sort_queries=0, use_kres=0); recorded in config.engine_opts")
-    ap.add_argument("--lib-variant", action="append", default=[], metavar="KERNEL=N", help="A/B runs of a library knob: mha=1 (two-pass softmax), "
-                    "msda_enc=3 (instruction-lean query phase) -- dtlr_mha_set_variant / dtlr_msda_encoder_set_variant; recorded in config.engine_opts")
     ap.add_argument("--height", type=int, default=128)
     ap.add_argument("--width", type=int, default=0, help="0 = 2048 (latin) / 2560 canvas with mixed widths (chinese)")
     ap.add_argument("--dtype", default="bf16", choices=["bf16", "f16", "f32s", "f32"],
@@ -311,13 +309,6 @@ def main():
         if not hasattr(eng, k):
             raise SystemExit(f"--engine-opt: DTLREngine has no attribute {k!r}")
         setattr(eng, k, type(getattr(eng, k))(int(v)) if isinstance(getattr(eng, k), (bool, int)) else float(v))
-    for kv in args.lib_variant:
-        k, _, v = kv.partition("=")
-        knob = {"mha": ops.mha_set_variant, "msda_enc": ops.msda_encoder_set_variant}.get(k)
-        if knob is None:
-            raise SystemExit(f"--lib-variant: no knob {k!r} (mha, msda_enc)")
-        knob(int(v), dtype)
-        args.engine_opt.append(f"lib:{kv}")
     log(f"engine packed ({args.dtype}, {args.config}), rank {rank}/{world}")
     B = args.batch
     n_total = B * world

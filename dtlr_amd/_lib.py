@@ -36,7 +36,6 @@ _SIGNATURES = {
                                                 c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p, c_void_p]),
     "dtlr_msda_encoder_forward": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int,
                                           c_int, c_int, c_void_p, c_void_p]),
-    "dtlr_msda_encoder_set_variant": (c_int, [c_int]),
     "dtlr_msda_encoder_plan_ok": (c_int, [c_void_p, c_int, c_int]),
     "dtlr_msda_encoder_far_samples": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p, c_void_p]),
     "dtlr_swin_patch_embed": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_float, c_int, c_void_p]),
@@ -65,7 +64,6 @@ _SIGNATURES = {
     "dtlr_proj_ln_split_bf16": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_float, c_void_p, c_int, c_int, c_void_p]),
     "dtlr_mha_forward": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p]),
     "dtlr_mha_workspace_bytes": (ctypes.c_long, [c_int, c_int, c_int, c_int]),
-    "dtlr_mha_set_variant": (c_int, [c_int]),
     "dtlr_gemm_nt": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
                              c_int, c_int, c_int, c_int, c_int, c_int, c_void_p]),
     "dtlr_split_pack_weights": (c_int, [c_void_p, c_void_p, ctypes.c_long, c_int, c_void_p]),

@@ -255,7 +255,7 @@ __global__ __launch_bounds__(1024) void mha_fwd_bf16_lds_kernel(const uint16_t* 
     }
 }
 
-// ---- the same kernel with a TWO-PASS softmax (dtlr_mha_set_variant(1); NOT the default, not timed yet) ------------------------------
+// ---- the same kernel with a TWO-PASS softmax (round 4: the DEFAULT 16-bit form; same-box A/B 9.24 -> 9.14 ms per step) ----------------
 // The LDS-staged kernel is bound by the softmax's VALU work (tools/isa_mix.py: 125 VALU instructions against 8 MFMAs per 32-key block,
 // the matrix pipe idles ~80%), and a good third of that work exists only because the row maximum is not known in advance: the per-block
 // cross-lane max reduction, exp2 of the correction, the rescaling of the 16 accumulator registers and of the running sum.  Pass 1
@@ -520,6 +520,163 @@ __global__ __launch_bounds__(256) void mha_fwd_f32_kernel(const float* __restric
     }
 }
 
+// ---- split-fp32 variant (round 4; dtype DTLR_F32S): fp32 q / k / v / out, every product as three fp16 MFMAs on hi + lo halves ------
+// The exact-fp32 kernel above (v_mfma_f32_16x16x4_f32, operands re-read from global memory by every wave) took 393 us per call at
+// B = 32 -- 2.4 of the split engine's 35 ms.  Here a workgroup owns a (batch, head) like the LDS-staged 16-bit kernel, with K and V^T
+// staged as FOUR fragment images (K_hi, K_lo, V^T_hi, V^T_lo; hi = fp16(x), lo = fp16(x - hi), split while staging: the fp32 values are
+// read once per chunk from L2).  Four images of 900 keys are 232 KB, more than the LDS: the keys are walked in CHUNKS of `kc` 32-key
+// blocks (kc x 8 KB <= 152 KB), each staged between two barriers; the online softmax carries (m, l, O) across chunks in registers.
+//     S^T = K_hi Q_lo + K_lo Q_hi + K_hi Q_hi                     (Q split once per query block)
+//     O^T += V^T_hi P_lo + V^T_lo P_hi + V^T_hi P_hi              (P = exp2(s c - m) in fp32, split in registers: the accumulator
+//                                                                  layout of S^T is still the B-operand layout of the second product)
+// Row sums are taken of the fp32 probabilities (hi + lo reproduces them to 2^-22).  Waves take query blocks w, w + 16, ...; a group of
+// 16 query blocks re-stages the chunks (2 groups at L = 900: 464 KB of L2 reads per (batch, head)).
+typedef __attribute__((ext_vector_type(8))) _Float16 f16x8;
+typedef __attribute__((ext_vector_type(2))) _Float16 f16x2v;
+__device__ __forceinline__ void split8(const float (&x)[8], uint4& hi, uint4& lo) {
+    uint32_t h[4], l[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const f16x2v hh = __builtin_convertvector(f32x2_hw_t{x[2 * i], x[2 * i + 1]}, f16x2v);
+        const f16x2v ll = __builtin_convertvector(f32x2_hw_t{x[2 * i] - (float)hh[0], x[2 * i + 1] - (float)hh[1]}, f16x2v);
+        h[i] = __builtin_bit_cast(uint32_t, hh);
+        l[i] = __builtin_bit_cast(uint32_t, ll);
+    }
+    hi = make_uint4(h[0], h[1], h[2], h[3]);
+    lo = make_uint4(l[0], l[1], l[2], l[3]);
+}
+__device__ __forceinline__ f32x4 mfma_f16(const uint4& a, const uint4& b, f32x4 c) {
+    return __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, a), __builtin_bit_cast(f16x8, b), c, 0, 0, 0);
+}
+
+__global__ __launch_bounds__(1024) void mha_fwd_f32s_kernel(const float* __restrict__ qk, const float* __restrict__ v,
+                                                            float* __restrict__ out, int L, int Lpad, int H, int kc, float scale_log2e)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_att[];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int g = lane >> 4, n = lane & 15;
+    const int h = blockIdx.x, b = blockIdx.y;
+    const int C = H * 32;
+    const float* qkb = qk + (long)b * L * (2 * C);
+    const float* vb = v + (long)b * L * C;
+    const int nkb = Lpad / 32;                               // key blocks of 32
+    unsigned char* k_hi = smem_att;                          // each image: kc * 2 KB (2 fragments of 1 KB per key block)
+    unsigned char* k_lo = smem_att + (long)kc * 2048;
+    unsigned char* v_hi = smem_att + (long)kc * 4096;
+    unsigned char* v_lo = smem_att + (long)kc * 6144;
+    const int nqb = (L + 31) / 32;                           // query blocks of 32
+    for (int grp = 0; grp * 16 < nqb; ++grp) {
+        const int qb = grp * 16 + wave;
+        const bool active = qb < nqb;
+        const int q0 = qb * 32;
+        uint4 qh[2], ql[2];
+#pragma unroll
+        for (int qt = 0; qt < 2; ++qt) {
+            const int q = min(q0 + qt * 16 + n, L - 1);
+            const float4* pq = reinterpret_cast<const float4*>(qkb + (long)q * (2 * C) + h * 32 + 8 * g);
+            const float4 a = pq[0], c = pq[1];
+            const float x[8] = {a.x, a.y, a.z, a.w, c.x, c.y, c.z, c.w};
+            split8(x, qh[qt], ql[qt]);
+        }
+        f32x4 o[2][2];
+#pragma unroll
+        for (int qt = 0; qt < 2; ++qt)
+#pragma unroll
+            for (int dt = 0; dt < 2; ++dt) o[qt][dt] = f32x4{0.f, 0.f, 0.f, 0.f};
+        float m[2] = {-INFINITY, -INFINITY}, lsum[2] = {0.f, 0.f};
+
+        for (int c0 = 0; c0 < nkb; c0 += kc) {
+            const int cn = min(kc, nkb - c0);                // key blocks of this chunk
+            __syncthreads();                                 // the previous chunk (or group) has been consumed by every wave
+            for (int f = wave; f < 2 * cn; f += 16) {
+                // K fragment f = key tile (16 keys): lane (g, n) <- K[16 (2 c0 + f) + n][8 g .. 8 g + 7]
+                const int key = min((2 * c0 + f) * 16 + n, L - 1);
+                const float4* pk = reinterpret_cast<const float4*>(qkb + (long)key * (2 * C) + C + h * 32 + 8 * g);
+                const float4 a = pk[0], c = pk[1];
+                const float kx[8] = {a.x, a.y, a.z, a.w, c.x, c.y, c.z, c.w};
+                uint4 hi, lo;
+                split8(kx, hi, lo);
+                *reinterpret_cast<uint4*>(k_hi + f * 1024 + lane * 16) = hi;
+                *reinterpret_cast<uint4*>(k_lo + f * 1024 + lane * 16) = lo;
+                // V^T fragment (j, dt): lane (g, n) <- V[32 j + 4 g + r][16 dt + n] (r = 0..3) | V[32 j + 16 + 4 g + r][16 dt + n]; keys >= L -> 0
+                const int j = c0 + (f >> 1), dt = f & 1;
+                const float* vc = vb + h * 32 + dt * 16 + n;
+                float vx[8];
+#pragma unroll
+                for (int r = 0; r < 8; ++r) {
+                    const int kk = j * 32 + (r >> 2) * 16 + 4 * g + (r & 3);
+                    vx[r] = kk < L ? vc[(long)kk * C] : 0.f;
+                }
+                split8(vx, hi, lo);
+                *reinterpret_cast<uint4*>(v_hi + f * 1024 + lane * 16) = hi;
+                *reinterpret_cast<uint4*>(v_lo + f * 1024 + lane * 16) = lo;
+            }
+            __syncthreads();
+            if (!active) continue;
+#define MHA_S_KEY_BLOCK(JL, MASKED)                                                                \
+            {                                                                                      \
+                const int kb = (c0 + (JL)) * 32;                                                   \
+                uint4 kh[2], kl[2], vh[2], vl[2];                                                  \
+                _Pragma("unroll") for (int t = 0; t < 2; ++t) {                                    \
+                    kh[t] = *reinterpret_cast<const uint4*>(k_hi + (2 * (JL) + t) * 1024 + lane * 16); \
+                    kl[t] = *reinterpret_cast<const uint4*>(k_lo + (2 * (JL) + t) * 1024 + lane * 16); \
+                    vh[t] = *reinterpret_cast<const uint4*>(v_hi + (2 * (JL) + t) * 1024 + lane * 16); \
+                    vl[t] = *reinterpret_cast<const uint4*>(v_lo + (2 * (JL) + t) * 1024 + lane * 16); \
+                }                                                                                  \
+                _Pragma("unroll") for (int qt = 0; qt < 2; ++qt) {                                 \
+                    f32x4 sc[2];                                                                   \
+                    _Pragma("unroll") for (int kt = 0; kt < 2; ++kt) sc[kt] = mfma_f16(kh[kt], ql[qt], f32x4{0.f, 0.f, 0.f, 0.f}); \
+                    _Pragma("unroll") for (int kt = 0; kt < 2; ++kt) sc[kt] = mfma_f16(kl[kt], qh[qt], sc[kt]); \
+                    _Pragma("unroll") for (int kt = 0; kt < 2; ++kt) sc[kt] = mfma_f16(kh[kt], qh[qt], sc[kt]); \
+                    if (MASKED) {                                                                  \
+                        _Pragma("unroll") for (int kt = 0; kt < 2; ++kt)                           \
+                            _Pragma("unroll") for (int r = 0; r < 4; ++r)                          \
+                                if (kb + kt * 16 + 4 * g + r >= L) sc[kt][r] = -INFINITY;          \
+                    }                                                                              \
+                    float mx = fmaxf(fmaxf(fmaxf(sc[0][0], sc[0][1]), fmaxf(sc[0][2], sc[0][3])),  \
+                                     fmaxf(fmaxf(sc[1][0], sc[1][1]), fmaxf(sc[1][2], sc[1][3]))); \
+                    mx = g4_max(mx) * scale_log2e;                                                 \
+                    const float m_new = fmaxf(m[qt], mx);   /* finite: every key block has >= 1 valid key */ \
+                    const float alpha = __builtin_amdgcn_exp2f(m[qt] - m_new);                     \
+                    m[qt] = m_new;                                                                 \
+                    float ps = 0.f, pv[8];                                                         \
+                    _Pragma("unroll") for (int kt = 0; kt < 2; ++kt)                               \
+                        _Pragma("unroll") for (int r = 0; r < 4; ++r) {                            \
+                            pv[4 * kt + r] = __builtin_amdgcn_exp2f(__builtin_fmaf(sc[kt][r], scale_log2e, -m_new)); \
+                            ps += pv[4 * kt + r];                                                  \
+                        }                                                                          \
+                    lsum[qt] = lsum[qt] * alpha + ps;                                              \
+                    uint4 ph, pl;                                                                  \
+                    split8(pv, ph, pl);                                                            \
+                    _Pragma("unroll") for (int dt = 0; dt < 2; ++dt) o[qt][dt] *= alpha;           \
+                    _Pragma("unroll") for (int dt = 0; dt < 2; ++dt) o[qt][dt] = mfma_f16(vh[dt], pl, o[qt][dt]); \
+                    _Pragma("unroll") for (int dt = 0; dt < 2; ++dt) o[qt][dt] = mfma_f16(vl[dt], ph, o[qt][dt]); \
+                    _Pragma("unroll") for (int dt = 0; dt < 2; ++dt) o[qt][dt] = mfma_f16(vh[dt], ph, o[qt][dt]); \
+                }                                                                                  \
+            }
+            const bool last_chunk = c0 + cn == nkb;
+            for (int jl = 0; jl + (last_chunk ? 1 : 0) < cn; ++jl) MHA_S_KEY_BLOCK(jl, false)
+            if (last_chunk) MHA_S_KEY_BLOCK(cn - 1, true)
+#undef MHA_S_KEY_BLOCK
+        }
+        if (active) {
+#pragma unroll
+            for (int qt = 0; qt < 2; ++qt) {
+                const float l = g4_sum(lsum[qt]);
+                const float inv = 1.0f / l;
+                const int q = q0 + qt * 16 + n;
+                if (q < L) {
+#pragma unroll
+                    for (int dt = 0; dt < 2; ++dt) {
+                        const f32x4 r = o[qt][dt] * inv;
+                        *reinterpret_cast<float4*>(out + ((long)b * L + q) * C + h * 32 + dt * 16 + 4 * g) = make_float4(r[0], r[1], r[2], r[3]);
+                    }
+                }
+            }
+        }
+    }
+}
+
 __global__ __launch_bounds__(256) void v_transpose_f32_kernel(const float* __restrict__ v, float* __restrict__ vt, int L, int Lpad, int H)
 {
     extern __shared__ __attribute__((aligned(16))) float tilef[];      // [C][33]
@@ -540,15 +697,6 @@ __global__ __launch_bounds__(256) void v_transpose_f32_kernel(const float* __res
 
 using namespace dtlr;
 
-// tuning / measurement knob: 0 = online softmax (default), 1 = the two-pass form of the LDS-staged 16-bit kernel; returns the previous value
-static int g_mha_variant = 0;
-extern "C" int dtlr_mha_set_variant(int v)
-{
-    const int old = g_mha_variant;
-    if (v == 0 || v == 1) g_mha_variant = v;
-    return old;
-}
-
 extern "C" int dtlr_mha_forward(const void* qk, const void* v, void* vt_workspace, void* out,
                                 int B, int L, int H, int head_dim, int dtype, void* stream)
 {
@@ -556,10 +704,21 @@ extern "C" int dtlr_mha_forward(const void* qk, const void* v, void* vt_workspac
     if (!qk || !v || !vt_workspace || !out) return DTLR_EINVAL;
     if (B <= 0 || L <= 0 || H <= 0) return DTLR_EINVAL;
     if (head_dim != 32) return DTLR_ESHAPE;
-    if (dtype != DTLR_H16 && dtype != DTLR_F32) return DTLR_EDTYPE;
+    if (dtype != DTLR_H16 && dtype != DTLR_F32 && dtype != DTLR_F32S) return DTLR_EDTYPE;
     hipStream_t st = (hipStream_t)stream;
     const int Lpad = (L + 31) / 32 * 32;
     const int C = H * 32;
+    if (dtype == DTLR_F32S) {
+        // key blocks per staged chunk: the fewest chunks whose four images (8 KB per key block) fit 152 KB, evenly sized
+        const int nkb = Lpad / 32, cap = 19;
+        const int nchunks = (nkb + cap - 1) / cap, kc = (nkb + nchunks - 1) / nchunks;
+        const size_t lds = (size_t)kc * 8192;
+        static DevOnce attr_s;
+        if (attr_s.first()) { (void)hipFuncSetAttribute((const void*)mha_fwd_f32s_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 152 * 1024); (void)hipGetLastError(); }
+        hipLaunchKernelGGL(mha_fwd_f32s_kernel, dim3(H, B), dim3(1024), lds, st, (const float*)qk, (const float*)v, (float*)out, L, Lpad, H, kc,
+                           1.4426950408889634f / sqrtf((float)head_dim));
+        return check_launch();
+    }
     if (dtype == DTLR_F32) {
         hipLaunchKernelGGL(v_transpose_f32_kernel, dim3(Lpad / 32, B), dim3(256), (size_t)C * 33 * sizeof(float), st,
                            (const float*)v, (float*)vt_workspace, L, Lpad, H);
@@ -573,7 +732,10 @@ extern "C" int dtlr_mha_forward(const void* qk, const void* v, void* vt_workspac
     const float scale_log2e = 1.4426950408889634f / sqrtf((float)head_dim);
     const size_t lds = (size_t)(Lpad / 32) * 4096;               // K image + V^T image
     if (lds <= 152 * 1024) {                                     // transposes V while staging: no separate pass, no workspace
-        if (g_mha_variant == 1) {
+        // the two-pass softmax form is the default since round 4 (same-box A/B of the step: 9.24 -> 9.14 ms; its tests ran green on hardware);
+        // the online-softmax form stays reachable in experiment builds only (DTLR_MHA_V=0)
+        static const bool two_pass = exp_env_int("DTLR_MHA_V", 1) != 0;
+        if (two_pass) {
             static DevOnce attr2;
             if (attr2.first()) { (void)hipFuncSetAttribute((const void*)mha_fwd_bf16_lds2_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 152 * 1024); (void)hipGetLastError(); }
             hipLaunchKernelGGL(mha_fwd_bf16_lds2_kernel, dim3(H, B), dim3(1024), lds, st,

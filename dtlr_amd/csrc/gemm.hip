@@ -1088,7 +1088,8 @@ static int try_splitk(const void* A, const void* W, const float* bias, const voi
         hipLaunchKernelGGL((gemm_ws_kernel<T, OutT, A2, CONV, CF>), dim3(GRID), dim3(512), lds, st, __VA_ARGS__); \
     }
 // the flag sets that get a specialised epilogue (bf16 -> bf16 only; everything else runs the generic one)
-template <typename T, typename OutT> constexpr bool kSpecialise = (sizeof(T) == 2 && sizeof(OutT) == 2);
+// (round 4: also the split-fp32 kernels -- their fp32-out tiles ran the generic epilogue, ~50 VALU + 6 branches per 4-channel group)
+template <typename T, typename OutT> constexpr bool kSpecialise = (sizeof(T) == 2 && sizeof(OutT) == 2) || (kSplit<T> && sizeof(OutT) == 4);
 
 static inline bool use_tall() {
     static const int v = exp_env_int("DTLR_GEMM_TALL", 1);    // experiment builds: =0 128x128 tiles only (A/B timing)

@@ -464,7 +464,7 @@ __device__ __forceinline__ void enc_queries_bf16_h(
 }
 
 // ---- bf16 query phase, third form: the second form with fewer VALU instructions per lane -------------------------------------
-// NOT the default: selected only through dtlr_msda_encoder_set_variant(3) (tools/msda_sweep.py, tests) until it has been timed.  The
+// The DEFAULT since round 4 (timed then: same-box A/B of the bench step 9.24 -> 9.12 ms; tests green on hardware).  The
 // kernel is VALU-issue-bound (SQ counters: ~96% of its duration), so the instruction count of this loop is its cost model
 // (tools/isa_mix.py).  Changes against the second form, none of which touches the data layout:
 //   * geometry as in msda_fused_quad_bf16_kernel: the coordinate is clamped to [-1, size] (one v_med3), a corner's validity is ONE
@@ -621,8 +621,163 @@ __device__ __forceinline__ void enc_queries_bf16_h3(
     }
 }
 
+// ---- fp32 query phase (round 4): one lane per (query, head, LEVEL), fp32 windows, packed-fp32 accumulation ----------------------
+// The first fp32 form (8 lanes per (query, head), each lane 4 channels of ALL 16 points) repeated the 16-point geometry and the
+// 16-logit softmax in every lane: ~7000 VALU lane-instructions per (query, head), 1.17 ms per encoder call at B = 32 -- the largest
+// kernel of the split-fp32 engine (7.0 of 35 ms per step).  This is the level-per-lane decomposition of the 16-bit forms on fp32
+// windows: a lane does the geometry of ITS level's 4 points, reads whole 128-byte pixel rows (8 x ds_read_b128, pieces in the
+// lane-rotated order (jj + 2 level) & 7 so the quad's reads spread over the banks), accumulates the 32 channels of its level with
+// v_pk_fma_f32 (two channels per instruction, nothing to unpack), and the quad is combined by the same DPP reduce-scatter (lane i ends
+// up with channels 8i..8i+7 = pieces 2i, 2i+1).  Geometry as in msda_fused_quad / the third 16-bit form: coordinate clamped to
+// [-1, size], ONE unsigned compare per axis and corner, no long-lived lane masks.  Differences from the reference's evaluation order:
+// the attention weight is folded into the bilinear weights and the levels are summed pairwise in the quad -- fp32 rounding-order
+// noise (~1e-7 relative), below the GEMMs' own.  ~460 VALU per lane-iteration; LDS-read-bound (2 KB per lane-iteration).
+typedef float encf2_t __attribute__((ext_vector_type(2)));
+template <typename OT, int NT>
+__device__ __forceinline__ void enc_queries_f32_lvl(
+    const unsigned char* smem, const int* tok, const float* __restrict__ vimg, const OT* __restrict__ ow, const float* __restrict__ ref,
+    float* __restrict__ out, const EncLevels lv, const int (&wc0)[4], const int (&wc1)[4], int nq, int S, int M, int m, int b)
+{
+    const int tid = threadIdx.x, p = tid & 3;
+    const int MD = M * 32;
+    const int Hl = p == 0 ? lv.H[0] : p == 1 ? lv.H[1] : p == 2 ? lv.H[2] : lv.H[3];
+    const int Wl = p == 0 ? lv.W[0] : p == 1 ? lv.W[1] : p == 2 ? lv.W[2] : lv.W[3];
+    const int startl = p == 0 ? lv.start[0] : p == 1 ? lv.start[1] : p == 2 ? lv.start[2] : lv.start[3];
+    const int loffl = p == 0 ? lv.loff[0] : p == 1 ? lv.loff[1] : p == 2 ? lv.loff[2] : lv.loff[3];
+    const int wstride = p == 0 ? lv.wmax[0] : p == 1 ? lv.wmax[1] : p == 2 ? lv.wmax[2] : lv.wmax[3];
+    const int wc0l = p == 0 ? wc0[0] : p == 1 ? wc0[1] : p == 2 ? wc0[2] : wc0[3];
+    const int wc1l = p == 0 ? wc1[0] : p == 1 ? wc1[1] : p == 2 ? wc1[2] : wc1[3];
+    const float fH = (float)Hl, fW = (float)Wl;
+    const float invH = 1.0f / fH, invW = 1.0f / fW;          // exact for power-of-two maps; else the product differs from the quotient by <= 1 ulp
+    const unsigned char* win = smem + (long)loffl * 128;
+    const float* gsrc = vimg + (long)startl * MD;
+    int rot[8];
+#pragma unroll
+    for (int jj = 0; jj < 8; ++jj) rot[jj] = ((jj + 2 * p) & 7) * 16;
+
+    auto token_of = [&](int it) -> long { return (long)b * S + tok[it >> 2]; };
+    const int total = nq * 4;
+    if (tid >= total) return;
+    long bq = token_of(tid);
+    RowRaw<OT> cur, nxt;
+    float2 rf, rf_n;
+    cur.load(ow + bq * (long)(M * 48), M, m, p);
+    rf = *reinterpret_cast<const float2*>(ref + bq * 8 + 2 * p);
+
+    for (int it = tid; it < total; it += NT) {
+        const int itn = it + NT < total ? it + NT : it;          // next iteration's row one iteration ahead
+        const long bqn = token_of(itn);
+        nxt.load(ow + bqn * (long)(M * 48), M, m, p);
+        rf_n = *reinterpret_cast<const float2*>(ref + bqn * 8 + 2 * p);
+
+        float off[8], lg[4];
+        cur.get(off, lg);
+        float mx = fmaxf(fmaxf(lg[0], lg[1]), fmaxf(lg[2], lg[3]));
+        mx = fmaxf(mx, quad_dpp<0xB1>(mx));
+        mx = fmaxf(mx, quad_dpp<0x4E>(mx));
+        float sum = 0.f;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) { lg[i] = __expf(lg[i] - mx); sum += lg[i]; }
+        sum += quad_dpp<0xB1>(sum);
+        sum += quad_dpp<0x4E>(sum);
+        const float inv = 1.0f / sum;
+
+        encf2_t acc[8][2];
+#pragma unroll
+        for (int jj = 0; jj < 8; ++jj) { acc[jj][0] = encf2_t{0.f, 0.f}; acc[jj][1] = encf2_t{0.f, 0.f}; }
+#define DTLR_ACC_F32(D, K)                                                                         \
+        {                                                                                          \
+            const encf2_t k2_ = {(K), (K)};                                                        \
+            _Pragma("unroll") for (int jj = 0; jj < 8; ++jj) {                                     \
+                acc[jj][0] = __builtin_elementwise_fma(k2_, encf2_t{__uint_as_float(D[jj].x), __uint_as_float(D[jj].y)}, acc[jj][0]); \
+                acc[jj][1] = __builtin_elementwise_fma(k2_, encf2_t{__uint_as_float(D[jj].z), __uint_as_float(D[jj].w)}, acc[jj][1]); \
+            }                                                                                      \
+        }
+#pragma unroll
+        for (int pt = 0; pt < 4; ++pt) {
+            const float lx = rf.x + off[2 * pt] * invW;
+            const float ly = rf.y + off[2 * pt + 1] * invH;
+            // v_med3_f32: a NaN operand yields min3 of the others = -1 (zero weights), like fminf(fmaxf(x, -1), size)
+            const float h_im = __builtin_amdgcn_fmed3f(ly * fH - 0.5f, -1.f, fH), w_im = __builtin_amdgcn_fmed3f(lx * fW - 0.5f, -1.f, fW);
+            const float hf = floorf(h_im), wf = floorf(w_im);
+            const int h_low = (int)hf, w_low = (int)wf;
+            const float lh = h_im - hf, lw = w_im - wf;
+            const float a = lg[pt] * inv;
+            const float wy0 = (unsigned)h_low < (unsigned)Hl ? 1.f - lh : 0.f, wy1 = (unsigned)(h_low + 1) < (unsigned)Hl ? lh : 0.f;
+            const float wx0 = (unsigned)w_low < (unsigned)Wl ? (1.f - lw) * a : 0.f, wx1 = (unsigned)(w_low + 1) < (unsigned)Wl ? lw * a : 0.f;
+            const float k1 = wy0 * wx0, k2 = wy0 * wx1, k3 = wy1 * wx0, k4 = wy1 * wx1;
+            const int h0 = clamp0_i32(h_low, Hl - 1), h1 = clamp0_i32(h_low + 1, Hl - 1);
+            const int w0 = clamp0_i32(w_low, Wl - 1), w1c = clamp0_i32(w_low + 1, Wl - 1);
+            if ((w0 >= wc0l) && (w1c < wc1l)) {
+                const unsigned char* r0 = win + (h0 * wstride) * 128;
+                const unsigned char* r1 = win + (h1 * wstride) * 128;
+                const int a0 = (w0 - wc0l) * 128, a1 = (w1c - wc0l) * 128;
+                {
+                    uint4 d1[8], d2[8];
+#pragma unroll
+                    for (int jj = 0; jj < 8; ++jj) {
+                        d1[jj] = *reinterpret_cast<const uint4*>(r0 + a0 + rot[jj]);
+                        d2[jj] = *reinterpret_cast<const uint4*>(r0 + a1 + rot[jj]);
+                    }
+                    DTLR_ACC_F32(d1, k1) DTLR_ACC_F32(d2, k2)
+                }
+                __builtin_amdgcn_sched_barrier(0);
+                {
+                    uint4 d3[8], d4[8];
+#pragma unroll
+                    for (int jj = 0; jj < 8; ++jj) {
+                        d3[jj] = *reinterpret_cast<const uint4*>(r1 + a0 + rot[jj]);
+                        d4[jj] = *reinterpret_cast<const uint4*>(r1 + a1 + rot[jj]);
+                    }
+                    DTLR_ACC_F32(d3, k3) DTLR_ACC_F32(d4, k4)
+                }
+            } else if (k1 != 0.f || k2 != 0.f || k3 != 0.f || k4 != 0.f) {      // inside the map, outside the staged window: global path
+                const float* g00 = gsrc + (long)(h0 * Wl + w0) * MD;
+                const float* g01 = gsrc + (long)(h0 * Wl + w1c) * MD;
+                const float* g10 = gsrc + (long)(h1 * Wl + w0) * MD;
+                const float* g11 = gsrc + (long)(h1 * Wl + w1c) * MD;
+                {
+                    uint4 d1[8], d2[8];
+#pragma unroll
+                    for (int jj = 0; jj < 8; ++jj) {
+                        d1[jj] = *reinterpret_cast<const uint4*>(g00 + (rot[jj] >> 2));
+                        d2[jj] = *reinterpret_cast<const uint4*>(g01 + (rot[jj] >> 2));
+                    }
+                    DTLR_ACC_F32(d1, k1) DTLR_ACC_F32(d2, k2)
+                }
+                {
+                    uint4 d3[8], d4[8];
+#pragma unroll
+                    for (int jj = 0; jj < 8; ++jj) {
+                        d3[jj] = *reinterpret_cast<const uint4*>(g10 + (rot[jj] >> 2));
+                        d4[jj] = *reinterpret_cast<const uint4*>(g11 + (rot[jj] >> 2));
+                    }
+                    DTLR_ACC_F32(d3, k3) DTLR_ACC_F32(d4, k4)
+                }
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        }
+#undef DTLR_ACC_F32
+        // quad reduce-scatter: lane p's acc[jj] is piece (jj + 2p) & 7 of its level; lane i collects pieces 2i (acc[0], acc[2] of lane
+        // i-1, acc[4] of lane i-2, acc[6] of lane i-3) and 2i+1 (the odd ones)
+        float res[8];
+#pragma unroll
+        for (int e = 0; e < 2; ++e)
+#pragma unroll
+            for (int h = 0; h < 2; ++h)
+#pragma unroll
+                for (int c = 0; c < 2; ++c)
+                    res[4 * e + 2 * h + c] = (acc[e][h][c] + quad_dpp<0x39>(acc[6 + e][h][c])) + (quad_dpp<0x4E>(acc[4 + e][h][c]) + quad_dpp<0x93>(acc[2 + e][h][c]));
+        float* dst = out + bq * MD + m * 32 + p * 8;
+        *reinterpret_cast<float4*>(dst) = make_float4(res[0], res[1], res[2], res[3]);
+        *reinterpret_cast<float4*>(dst + 4) = make_float4(res[4], res[5], res[6], res[7]);
+        cur = nxt; rf = rf_n; bq = bqn;
+    }
+}
+
+// VAR: 16-bit values: 0 first form, 1 packed-fp16 form, 2 third form; fp32 values: 0 first form (8 lanes per (query, head)), 3 level-per-lane form
 template <typename T, typename OT, int VAR = 0, int NT = 256>
-__global__ __launch_bounds__(NT, NT / 128) void msda_enc_lds_kernel(
+__global__ __launch_bounds__(NT, VAR == 3 ? 2 : NT / 128) void msda_enc_lds_kernel(
     const T* __restrict__ value, const OT* __restrict__ ow, const float* __restrict__ ref, T* __restrict__ out,
     EncLevels lv, int S, int M, int TW0, int R, int tok_off)
 {
@@ -659,7 +814,7 @@ __global__ __launch_bounds__(NT, NT / 128) void msda_enc_lds_kernel(
             const int c0q = lq == 3 ? qc0[3] : lq == 2 ? qc0[2] : lq == 1 ? qc0[1] : qc0[0];
             const int Wq = lq == 3 ? lv.W[3] : lq == 2 ? lv.W[2] : lq == 1 ? lv.W[1] : lv.W[0];
             const int stq = lq == 3 ? lv.start[3] : lq == 2 ? lv.start[2] : lq == 1 ? lv.start[1] : lv.start[0];
-            if constexpr (VAR == 2) {
+            if constexpr (VAR == 2 || VAR == 3) {
                 // r / nc without the ~60-instruction integer division: (r + 0.5) / nc is at least 0.5 / nc away from an integer, far
                 // more than the fp32 error of the product for r < 2^15 and nc <= 2^8 (restated and swept in tests/test_host_logic.py)
                 const int qi = (int)(((float)r + 0.5f) * __builtin_amdgcn_rcpf((float)nc));
@@ -735,7 +890,12 @@ __global__ __launch_bounds__(NT, NT / 128) void msda_enc_lds_kernel(
         else enc_queries_bf16_h3<OT, NT>(smem, reinterpret_cast<const int*>(smem + tok_off), vimg, ow, ref, out, lv, wc0, wc1, nq, S, M, m, b);
         return;
     }
-    static_assert(sizeof(T) == 2 || NT == 256, "the fp32 query phase strides by 256");
+    if constexpr (VAR == 3) {
+        static_assert(sizeof(T) == 4, "VAR 3 is the fp32 level-per-lane form");
+        enc_queries_f32_lvl<OT, NT>(smem, reinterpret_cast<const int*>(smem + tok_off), vimg, ow, ref, out, lv, wc0, wc1, nq, S, M, m, b);
+        return;
+    }
+    static_assert(sizeof(T) == 2 || VAR == 3 || NT == 256, "the first fp32 query phase strides by 256");
     // ---- queries: CP lanes per query (16 bytes = VEC channels each) ---------------------------------
     for (int it = tid; it < nq * CP; it += 256) {
         const int part = it % CP, q = it / CP;
@@ -963,25 +1123,17 @@ static int launch_enc(const void* value, const void* ow, const float* ref, void*
                        (const T*)value, (const OT*)ow, ref, (T*)out, pl.lv, pl.S, M, pl.TW0, pl.R, pl.tok_off);
     return check_launch();
 }
-// bf16 query-phase variant: env DTLR_MSDA_ENC_V = 0 first form (fp32 accumulators, v_fma_mix), 1 packed-fp16 form with 256 threads,
-// 2 the same with 512 threads per workgroup (default), 3 the third form (fewer VALU instructions, 512 threads; not yet timed); read once per process.
-static int g_enc_variant = -1;
+// 16-bit query-phase form: 3 = the third form, 512 threads (the default since round 4: same-box A/B of the step 9.24 -> 9.12 ms, tests green on
+// hardware); experiment builds only (env DTLR_MSDA_ENC_V, read once per process): 0 first form (fp32 accumulators, v_fma_mix), 1 packed-fp16 form
+// with 256 threads, 2 the same with 512 threads (the round-2/3 default).  The product libraries have no run-time knob.
 static int enc_variant() {
-    if (g_enc_variant < 0) { const int v = exp_env_int("DTLR_MSDA_ENC_V", 2); g_enc_variant = (v >= 0 && v <= 3) ? v : 2; }
-    return g_enc_variant;
+    static const int v = exp_env_int("DTLR_MSDA_ENC_V", 3);
+    return (v >= 0 && v <= 3) ? v : 3;
 }
 
 }  // namespace dtlr
 
 using namespace dtlr;
-
-// tuning / measurement knob (tools/msda_sweep.py): select the bf16 query-phase form for subsequent launches; returns the previous value
-extern "C" int dtlr_msda_encoder_set_variant(int v)
-{
-    const int old = enc_variant();
-    if (v >= 0 && v <= 3) g_enc_variant = v;
-    return old;
-}
 
 // 1 when the LDS window plan of dtlr_msda_encoder_forward fits these level shapes (full-height column windows + halo of all four
 // levels within 160 KB), 0 when it does not (tall canvases: the caller then uses the gather kernel, dtlr_msda_fused_forward,
@@ -1026,18 +1178,22 @@ extern "C" int dtlr_msda_encoder_forward(const void* value, const void* ow, cons
     const int elem = dtype == DTLR_F32 ? 4 : 2;
     if (!make_plan(level_hw, elem, halo, pl)) return DTLR_ESHAPE;
     hipStream_t st = (hipStream_t)stream;
-    if (dtype == DTLR_F32 && ow_dtype == DTLR_F32) return launch_enc<float, float>(value, ow, ref, out, pl, N, M, st);
+    if (dtype == DTLR_F32 && ow_dtype == DTLR_F32) {
+        static const bool first_form = exp_env_int("DTLR_MSDA_ENC_F32_V", 3) == 0;      // experiment builds: =0 the first fp32 form (A/B timing)
+        if (first_form) return launch_enc<float, float>(value, ow, ref, out, pl, N, M, st);
+        return launch_enc<float, float, 3, 512>(value, ow, ref, out, pl, N, M, st);
+    }
     if (dtype == DTLR_H16 && ow_dtype == DTLR_F32) {
         if (enc_variant() == 0) return launch_enc<uint16_t, float>(value, ow, ref, out, pl, N, M, st);
         if (enc_variant() == 1) return launch_enc<uint16_t, float, 1, 256>(value, ow, ref, out, pl, N, M, st);
-        if (enc_variant() == 3) return launch_enc<uint16_t, float, 2, 512>(value, ow, ref, out, pl, N, M, st);
-        return launch_enc<uint16_t, float, 1, 512>(value, ow, ref, out, pl, N, M, st);
+        if (enc_variant() == 2) return launch_enc<uint16_t, float, 1, 512>(value, ow, ref, out, pl, N, M, st);
+        return launch_enc<uint16_t, float, 2, 512>(value, ow, ref, out, pl, N, M, st);
     }
     if (dtype == DTLR_H16 && ow_dtype == DTLR_H16) {
         if (enc_variant() == 0) return launch_enc<uint16_t, uint16_t>(value, ow, ref, out, pl, N, M, st);
         if (enc_variant() == 1) return launch_enc<uint16_t, uint16_t, 1, 256>(value, ow, ref, out, pl, N, M, st);
-        if (enc_variant() == 3) return launch_enc<uint16_t, uint16_t, 2, 512>(value, ow, ref, out, pl, N, M, st);
-        return launch_enc<uint16_t, uint16_t, 1, 512>(value, ow, ref, out, pl, N, M, st);
+        if (enc_variant() == 2) return launch_enc<uint16_t, uint16_t, 1, 512>(value, ow, ref, out, pl, N, M, st);
+        return launch_enc<uint16_t, uint16_t, 2, 512>(value, ow, ref, out, pl, N, M, st);
     }
     return DTLR_EDTYPE;
 }

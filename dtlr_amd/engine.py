@@ -689,7 +689,7 @@ class DTLREngine:
                 # self attention (q = k = tgt + query_pos, v = tgt)
                 qk = self._lin(q + "sa.qk", tgt, a2=qpos)
                 v = self._lin(q + "sa.v", tgt)
-            a = ops.mha(qk, v, cfg.nheads)
+            a = ops.mha(qk, v, cfg.nheads, split=self.split)
             tgt = self._proj_ln(q + "sa.out", q + "norm2", a, tgt)
             # deformable cross attention
             a = self._msda_module(q + "attn", tgt, qpos, ref_in, memory, g, cfg.dec_n_points, value=vall[..., n * C:(n + 1) * C])

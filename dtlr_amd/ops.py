@@ -816,20 +816,6 @@ def msda_encoder_fits(level_hw, dtype, halo: Optional[int] = None) -> bool:
     return rc == 1
 
 
-def mha_set_variant(v: int, dtype=None) -> int:
-    """Select the softmax form of the LDS-staged 16-bit attention kernel for subsequent launches of the library that serves `dtype`
-    (dtlr_mha_set_variant: 0 online softmax -- the default --, 1 two-pass, not timed yet); a measurement / test knob, never called by
-    the engine.  Returns the previous value."""
-    return int(_lib.lib(dtype).dtlr_mha_set_variant(int(v)))
-
-
-def msda_encoder_set_variant(v: int, dtype=None) -> int:
-    """Select the 16-bit query-phase form of the LDS-window encoder kernel for subsequent launches of the library that serves `dtype`
-    (dtlr_msda_encoder_set_variant: 0 fp32 accumulators, 1 / 2 packed-fp16 accumulation with 256 / 512 threads -- 2 is the default --,
-    3 the instruction-lean form that has not been timed yet); a measurement / test knob, never called by the engine.  Returns the previous value."""
-    return int(_lib.lib(dtype).dtlr_msda_encoder_set_variant(int(v)))
-
-
 def msda_encoder(value, level_hw, ow, ref, halo: Optional[int] = None):
     """Encoder MSDA (Lq == S, queries are the level pixels) with LDS-staged value windows.
     value [N,S,M,32] fp32/bf16; level_hw: HOST list of (H_l, W_l); ow [N,S,M*48]; ref [N,S,4,2] fp32."""
@@ -868,9 +854,10 @@ def msda_encoder_far_fraction(value_dtype, level_hw, ow, ref, n_heads: int = 8, 
     return far / max(inside, 1)
 
 
-def mha(qk, v, n_heads: int):
+def mha(qk, v, n_heads: int, split: bool = False):
     """Self-attention core.  qk [B, L, 2C] (projected q | k), v [B, L, C] -> [B, L, C].  Fused flash-style HIP
-    kernel on the matrix cores, scores never leave the chip: bf16 (mfma 16x16x32) or exact fp32 (mfma 16x16x4)."""
+    kernel on the matrix cores, scores never leave the chip: bf16 / fp16 (mfma 16x16x32), exact fp32 (mfma 16x16x4), or -- fp32 tensors
+    with split=True -- fp32 operands as fp16 hi + lo halves, three fp16 MFMAs per product (DTLR_F32S: the split-fp32 engine)."""
     B, L, C2 = qk.shape
     C = C2 // 2
     hd = C // n_heads
@@ -880,8 +867,10 @@ def mha(qk, v, n_heads: int):
     L_ = _L(qk)
     ws = torch.empty(L_.dtlr_mha_workspace_bytes(B, L, n_heads, hd), dtype=torch.uint8, device=qk.device)
     out = torch.empty((B, L, C), dtype=qk.dtype, device=qk.device)
+    if split and qk.dtype != torch.float32:
+        raise RuntimeError("dtlr_amd.ops.mha: split=True takes fp32 tensors")
     code = L_.dtlr_mha_forward(qk.data_ptr(), v.data_ptr(), ws.data_ptr(), out.data_ptr(), B, L, n_heads, hd,
-                               _DT[qk.dtype], _lib.current_stream())
+                               _lib.DTLR_F32S if split else _DT[qk.dtype], _lib.current_stream())
     _lib.check(code, "dtlr_mha_forward")
     return out
 

@@ -104,11 +104,6 @@ int dtlr_msda_encoder_plan_ok(const int *level_hw /* host, 8 ints */, int dtype,
  * dtlr_msda_encoder_forward; dtype = the value dtype (it sets the window plan), ow_dtype = the projection row's dtype. */
 int dtlr_msda_encoder_far_samples(const void *ow, const float *ref, const int *level_hw, int N, int M, int halo,
                                   int dtype, int ow_dtype, unsigned long long *counts, void *stream);
-/* Measurement knob: 16-bit query-phase form of dtlr_msda_encoder_forward for subsequent launches (0 = fp32 accumulators /
- * v_fma_mix_f32, 1 = per-level packed-fp16 accumulation with 256-thread workgroups, 2 = the same with 512 threads: the default,
- * 3 = the instruction-lean form with division-free staging and hardware fp16 saturation).  Returns the previous value; v outside
- * 0..3 only queries.  (The library reads no environment variable: an experiment build alone takes DTLR_MSDA_ENC_V as the initial value.) */
-int dtlr_msda_encoder_set_variant(int v);
 
 /* ---------------------------------------------------------------------------------------------
  * y = LayerNorm(x [+ residual]) * gamma + beta over rows of C channels (C multiple of 256).
@@ -220,15 +215,13 @@ int dtlr_proj_ln_split_bf16(const void *A, const void *W_packed, const float *bi
  *   qk  [B, L, 2*H*head_dim]  projected q (first half of the row) and k (second half);  dtype
  *   v   [B, L, H*head_dim]    projected v;  dtype
  *   vt_workspace              >= dtlr_mha_workspace_bytes(B, L, H, head_dim) bytes of scratch
- *   out [B, L, H*head_dim]    dtype.   head_dim must be 32; dtype BF16 (fp32 accumulate/softmax) or F32
- *                             (exact-fp32 MFMA).
+ *   out [B, L, H*head_dim]    dtype.   head_dim must be 32; dtype BF16 (fp32 accumulate/softmax), F32
+ *                             (exact-fp32 MFMA) or F32S (fp32 tensors, every product as three fp16 MFMAs on hi + lo halves: fp32-grade;
+ *                             the workspace is not used).
  */
 int dtlr_mha_forward(const void *qk, const void *v, void *vt_workspace, void *out,
                      int B, int L, int H, int head_dim, int dtype, void *stream);
 long dtlr_mha_workspace_bytes(int B, int L, int H, int head_dim);
-/* tuning / measurement knob (like dtlr_msda_encoder_set_variant): 0 = online softmax (default), 1 = the two-pass form of the
- * LDS-staged 16-bit kernel (row maxima first, then exp2 with the final maximum; row sums from the matrix pipe).  Returns the previous value. */
-int dtlr_mha_set_variant(int v);
 
 /* ---------------------------------------------------------------------------------------------
  * C[M,N] = epilogue( (A [+ A2])[M,K] . W[N,K]^T )   -- every nn.Linear and 1x1 convolution on the path.

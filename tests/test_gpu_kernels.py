@@ -1218,16 +1218,13 @@ def test_gemm_kres_cat_s2_vs_reference(B, Hin, Win, half):
     assert (y.float() - y_sep.float()).abs().max().item() <= scale * ulp(half, 7)
 
 
-@pytest.mark.skipif(os.environ.get("DTLR_TEST_UNTIMED_VARIANTS") != "1",
-                    reason="variant 3 of the encoder MSDA query phase was written after the round's GPU budget was spent: it is not the default "
-                           "and has not run on hardware yet; set DTLR_TEST_UNTIMED_VARIANTS=1 to test it")
 @pytest.mark.parametrize("level_hw,offscale", [([(16, 256), (8, 128), (4, 64), (2, 32)], 2.0), ([(16, 256), (8, 128), (4, 64), (2, 32)], 40.0),
                                                ([(5, 83), (3, 42), (2, 21), (1, 11)], 3.0), ([(1, 7), (1, 4), (1, 2), (1, 1)], 1.0)])
-def test_msda_encoder_lds_variant3_vs_oracle(level_hw, offscale, half):
-    """Variant 3 of the 16-bit query phase (dtlr_msda_encoder_set_variant(3): coordinate clamp + one unsigned compare per axis, v_rcp_f32
-    softmax normalisation, paired weight conversions broadcast through op_sel, division-free staging, MODE.FP16_OVFL saturation; 654 VALU
-    instructions per lane-iteration against 747, tools/isa_mix.py) against the oracle at the tolerance of the default form, for both projection-row dtypes, including samples
-    outside the map and outside the staged windows; and close to the default form."""
+def test_msda_encoder_lds_default_form_both_row_dtypes(level_hw, offscale, half):
+    """The default 16-bit query phase since round 4 (the "third form": coordinate clamp + one unsigned compare per axis, v_rcp_f32 softmax
+    normalisation, paired weight conversions broadcast through op_sel, division-free staging, MODE.FP16_OVFL saturation; 654 VALU
+    instructions per lane-iteration against 747, tools/isa_mix.py; same-box A/B of the step 9.24 -> 9.12 ms) against the oracle, for
+    both projection-row dtypes, including samples outside the map and outside the staged windows; values beyond fp16's range stay finite."""
     from dtlr_amd import ops
     from oracle import dtlr_oracle as O
     N, M, D, L, P = 2, 8, 32, 4, 4
@@ -1238,36 +1235,24 @@ def test_msda_encoder_lds_variant3_vs_oracle(level_hw, offscale, half):
     vr = torch.tensor([[[1.0, 1.0]] * 4, [[0.75, 1.0]] * 4])
     ref = O.encoder_reference_points(s, vr).contiguous()
     vv = v.to(half)
-    old = ops.msda_encoder_set_variant(3, half)
-    try:
-        for owx in (ow, ow.to(half)):
-            off = owx.float()[..., : M * L * P * 2].view(N, S, M, L, P, 2)
-            aw = torch.softmax(owx.float()[..., M * L * P * 2:].view(N, S, M, L * P), -1).view(N, S, M, L, P)
-            want = O.ms_deform_attn_core(vv.float(), s, O.msda_sampling_locations(ref, off, s, P), aw)
-            ops.msda_encoder_set_variant(3, half)
-            got = ops.msda_encoder(vv.cuda(), level_hw, owx.cuda(), ref.cuda()).float().cpu()
-            ops.msda_encoder_set_variant(2, half)
-            dflt = ops.msda_encoder(vv.cuda(), level_hw, owx.cuda(), ref.cuda()).float().cpu()
-            tol = want.abs().max() * (ulp(half, 8) + 2.0 ** -9 if half == torch.bfloat16 else 2.0 ** -8) + 16 * 2.0 ** -24
-            assert torch.isfinite(got).all()
-            assert (got - want).abs().max() <= tol, (owx.dtype, (got - want).abs().max().item(), tol.item())
-            assert (got - dflt).abs().max() <= tol
-        if half == torch.bfloat16:      # beyond fp16's range: the hardware saturation (MODE.FP16_OVFL) must keep every output finite
-            big = (vv.float() * 1e6).to(half)
-            ops.msda_encoder_set_variant(3, half)
-            assert torch.isfinite(ops.msda_encoder(big.cuda(), level_hw, ow.to(half).cuda(), ref.cuda()).float()).all()
-    finally:
-        ops.msda_encoder_set_variant(old, half)
+    for owx in (ow, ow.to(half)):
+        off = owx.float()[..., : M * L * P * 2].view(N, S, M, L, P, 2)
+        aw = torch.softmax(owx.float()[..., M * L * P * 2:].view(N, S, M, L * P), -1).view(N, S, M, L, P)
+        want = O.ms_deform_attn_core(vv.float(), s, O.msda_sampling_locations(ref, off, s, P), aw)
+        got = ops.msda_encoder(vv.cuda(), level_hw, owx.cuda(), ref.cuda()).float().cpu()
+        tol = want.abs().max() * (ulp(half, 8) + 2.0 ** -9 if half == torch.bfloat16 else 2.0 ** -8) + 16 * 2.0 ** -24
+        assert torch.isfinite(got).all()
+        assert (got - want).abs().max() <= tol, (owx.dtype, (got - want).abs().max().item(), tol.item())
+    if half == torch.bfloat16:      # beyond fp16's range: the hardware saturation (MODE.FP16_OVFL) must keep every output finite
+        big = (vv.float() * 1e6).to(half)
+        assert torch.isfinite(ops.msda_encoder(big.cuda(), level_hw, ow.to(half).cuda(), ref.cuda()).float()).all()
 
 
-@pytest.mark.skipif(os.environ.get("DTLR_TEST_UNTIMED_VARIANTS") != "1",
-                    reason="the two-pass softmax form of the attention kernel was written after the round's GPU budget was spent: it is not the "
-                           "default and has not run on hardware yet; set DTLR_TEST_UNTIMED_VARIANTS=1 to test it")
 @pytest.mark.parametrize("B,L,spread", [(2, 900, 1.5), (1, 37, 1.5), (3, 200, 4.0), (1, 1184, 1.5), (2, 33, 8.0)])
-def test_mha_two_pass_variant_vs_fp32_reference(B, L, spread, half):
-    """dtlr_mha_set_variant(1) (row maxima in a first pass over the staged keys, exp2 with the final maximum in the second, row sums as
-    a third output tile of the P V product) against plain fp32 softmax(QK^T / sqrt(d)) V at the tolerance of the default kernel, incl. a
-    ragged last key block, a single query block, the largest L the LDS form takes, and a dominant late key; and close to the default."""
+def test_mha_two_pass_default_vs_fp32_reference(B, L, spread, half):
+    """The default 16-bit attention kernel since round 4 (row maxima in a first pass over the staged keys, exp2 with the final maximum in
+    the second, row sums as a third output tile of the P V product) against plain fp32 softmax(QK^T / sqrt(d)) V, incl. a ragged last key
+    block, a single query block, the largest L the LDS form takes, and a dominant late key."""
     import math
     from dtlr_amd import ops
     H, hd = 8, 32
@@ -1280,17 +1265,33 @@ def test_mha_two_pass_variant_vs_fp32_reference(B, L, spread, half):
     k = qk[..., C:].float().view(B, L, H, hd).transpose(1, 2)
     vv = v.float().view(B, L, H, hd).transpose(1, 2)
     want = (torch.softmax(q @ k.transpose(-1, -2) / math.sqrt(hd), -1) @ vv).transpose(1, 2).reshape(B, L, C)
-    old = ops.mha_set_variant(1, half)
-    try:
-        got = ops.mha(qk.cuda(), v.cuda(), H).float().cpu()
-        ops.mha_set_variant(0, half)
-        dflt = ops.mha(qk.cuda(), v.cuda(), H).float().cpu()
-    finally:
-        ops.mha_set_variant(old, half)
+    got = ops.mha(qk.cuda(), v.cuda(), H).float().cpu()
     tol = ulp(half, 6) * v.float().abs().max() + 1e-3
     assert torch.isfinite(got).all()
     assert (got - want).abs().max() <= tol, (got - want).abs().max()
-    assert (got - dflt).abs().max() <= tol
+
+
+@pytest.mark.parametrize("B,L,spread", [(2, 900, 1.5), (1, 37, 1.5), (3, 200, 4.0), (1, 1184, 1.5), (2, 33, 8.0), (1, 1500, 1.5), (2, 608, 1.0)])
+def test_mha_split_f32_vs_fp64_reference(B, L, spread):
+    """DTLR_F32S attention (fp32 q / k / v as fp16 hi + lo halves, three MFMAs per product, keys staged in chunks) against an fp64
+    softmax(QK^T / sqrt(d)) V: fp32-grade (the exact-fp32 kernel's own bound), for one and several chunks (L = 608: exactly one chunk
+    of 19 key blocks; 900: two; 1500: three, three query-block groups), ragged last key block, a dominant late key."""
+    import math
+    from dtlr_amd import ops
+    H, hd = 8, 32
+    C = H * hd
+    qk = _rand((B, L, 2 * C), 11) * spread
+    qk[:, (3 * L) // 4, C:] *= 5.0
+    v = _rand((B, L, C), 12)
+    q = qk[..., :C].double().view(B, L, H, hd).transpose(1, 2)
+    k = qk[..., C:].double().view(B, L, H, hd).transpose(1, 2)
+    vv = v.double().view(B, L, H, hd).transpose(1, 2)
+    want = (torch.softmax(q @ k.transpose(-1, -2) / math.sqrt(hd), -1) @ vv).transpose(1, 2).reshape(B, L, C).float()
+    got = ops.mha(qk.cuda(), v.cuda(), H, split=True).cpu()
+    exact = ops.mha(qk.cuda(), v.cuda(), H).cpu()
+    err, err_exact = (got - want).abs().max().item(), (exact - want).abs().max().item()
+    print(f"[split mha B{B} L{L}] max err {err:.2e} (exact-fp32 kernel {err_exact:.2e})")
+    assert torch.isfinite(got).all() and err < 2e-5 * max(1.0, want.abs().max().item())
 
 
 # ---- split-fp16 ("f32s") operands: fp32 activations, three fp16 MFMAs per product (round 4) -------------------------------------
