@@ -72,6 +72,7 @@ _SIGNATURES = {
     "dtlr_proj_ln_k256_pack_weights": (c_int, [c_void_p, c_void_p]),
     "dtlr_proj_ln_k256": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_float, c_void_p, c_int, c_void_p]),
     "dtlr_gemm_nt_a2bcast": (c_int, [c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p]),
+    "dtlr_gemm_nt_resbcast": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_int, c_int, c_int, c_int, c_void_p]),
     "dtlr_gemm_nt_rowmax": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p]),
     "dtlr_gemm_nt_rowmax_lda": (c_int, [c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p]),
     "dtlr_two_stage_gather": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p]),

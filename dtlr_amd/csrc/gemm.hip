@@ -211,9 +211,12 @@ template <> struct Out<uint16_t> {
 template <typename OutT, int CF = -1>
 __device__ __forceinline__ void epilogue_tile(f32x4_t (&acc)[4][4], OutT* __restrict__ C, const float* __restrict__ bias,
                                               const OutT* __restrict__ residual, const uint8_t* __restrict__ row_mask,
-                                              int M, int N, int flags_rt, int tok0, int ch0 TL_PARAMS)
+                                              int M, int N, int flags_rt, int tok0, int ch0 TL_PARAMS, int res_rows = 0)
 {
     const int flags = CF >= 0 ? CF : flags_rt;
+    // row-broadcast residual (res_rows > 0): the encoder's [offsets | logits] projection of an unpadded batch, (src + pos) W^T + b =
+    // src W^T + (pos W^T + b) with the second term ONE [S, N] matrix for every image (L2-resident)
+#define RES_ROW(TOK) (res_rows > 0 ? (long)((TOK) % res_rows) : (long)(TOK))
     if constexpr (sizeof(OutT) == 4 && CF < 0) {
         if (flags & EPI_ROWMAX) {
             // Row-max epilogue (two-stage selection: torch.topk needs only max_c of the class head, deformable_transformer.py:345):
@@ -271,7 +274,7 @@ __device__ __forceinline__ void epilogue_tile(f32x4_t (&acc)[4][4], OutT* __rest
                 for (int tb = 0; tb < TB; ++tb)
 #pragma unroll
                     for (int ci = 0; ci < 4; ++ci)
-                        rr[tb][ci] = *reinterpret_cast<const typename Out<OutT>::raw4*>(residual + (long)(tok0 + (t0 + tb) * 16) * N + ch0 + ci * 16);
+                        rr[tb][ci] = *reinterpret_cast<const typename Out<OutT>::raw4*>(residual + RES_ROW(tok0 + (t0 + tb) * 16) * N + ch0 + ci * 16);
             }
             TL_EV(21)                                              // this batch's residual loads issued
 #pragma unroll
@@ -352,7 +355,7 @@ __device__ __forceinline__ void epilogue_tile(f32x4_t (&acc)[4][4], OutT* __rest
             if (masked) { v[0] = v[1] = v[2] = v[3] = 0.f; }
             OutT* cptr = C + (long)tok * N + ch;
             if (full) {
-                if (flags & EPI_RESIDUAL) { float rr[4]; Out<OutT>::ld4(residual + (long)tok * N + ch, rr); v[0] += rr[0]; v[1] += rr[1]; v[2] += rr[2]; v[3] += rr[3]; }
+                if (flags & EPI_RESIDUAL) { float rr[4]; Out<OutT>::ld4(residual + RES_ROW(tok) * N + ch, rr); v[0] += rr[0]; v[1] += rr[1]; v[2] += rr[2]; v[3] += rr[3]; }
                 if (flags & EPI_RELU_POST) {
 #pragma unroll
                     for (int r = 0; r < 4; ++r) v[r] = fmaxf(v[r], 0.f);
@@ -363,7 +366,7 @@ __device__ __forceinline__ void epilogue_tile(f32x4_t (&acc)[4][4], OutT* __rest
                 for (int r = 0; r < 4; ++r)
                     if (ch + r < N) {
                         float x = v[r];
-                        if (flags & EPI_RESIDUAL) x += Out<OutT>::ld(residual + (long)tok * N + ch + r);
+                        if (flags & EPI_RESIDUAL) x += Out<OutT>::ld(residual + RES_ROW(tok) * N + ch + r);
                         if (flags & EPI_RELU_POST) x = fmaxf(x, 0.f);
                         Out<OutT>::st(cptr + r, x);
                     }
@@ -372,13 +375,16 @@ __device__ __forceinline__ void epilogue_tile(f32x4_t (&acc)[4][4], OutT* __rest
     }
 }
 
+#undef RES_ROW
+
 // Implicit-GEMM convolution (CONV = true): the "A" operand is gathered on the fly from an NHWC image,
 // M = B*Ho*Wo output pixels, K = KH*KW*Cin ordered (kh, kw, ci) so that a 128-byte K slab lies inside
 // one filter tap (Cin*sizeof(T) % 128 == 0) and is one contiguous, 16-byte-aligned run of channels;
 // taps that fall into the zero padding contribute zeros.  Weights are packed [Cout][KH][KW][Cin].
 struct ConvP { int H, W, Cin, Ho, Wo, KH, KW, stride, pad;
                int a2_rows;         // plain GEMM with an A2 prologue: A2 has a2_rows rows, row m of A pairs with row m % a2_rows (0 = M rows)
-               int lda; };          // plain GEMM: elements between consecutive rows of A (0 = K: contiguous); K columns of a wider matrix otherwise
+               int lda;             // plain GEMM: elements between consecutive rows of A (0 = K: contiguous); K columns of a wider matrix otherwise
+               int res_rows; };     // residual epilogue: the residual has res_rows rows, row m of C takes row m % res_rows (0 = M rows)
 __device__ __attribute__((aligned(16))) unsigned int g_zero_line[4] = {0u, 0u, 0u, 0u};   // what a padding tap reads
 
 // Tile chains.  A workgroup owns `tiles_per_block` consecutive TOKEN tiles (tm) of ONE channel tile (tn) and
@@ -571,7 +577,7 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(
 #define EPILOGUE()                                                                                 \
     {                                                                                              \
         const int m0 = tile * BM, n0 = tn * BN;                                                    \
-        epilogue_tile<OutT>(acc, C, bias, residual, row_mask, M, N, flags, m0 + wm * 64 + n, n0 + wn * 64 + 4 * g TL_ARGS_NONE); \
+        epilogue_tile<OutT>(acc, C, bias, residual, row_mask, M, N, flags, m0 + wm * 64 + n, n0 + wn * 64 + 4 * g TL_ARGS_NONE, cp.res_rows); \
     }
 
     int s = 0;
@@ -792,7 +798,7 @@ __global__ __launch_bounds__(512, HAS_A2 ? 2 : 4) void gemm_ws_kernel(
         if (++kt == nk) {
             const int m0 = tile * BM, n0 = tn * BN;
             if (!ABLATE(DBG_NO_EPI))
-                epilogue_tile<OutT, CF>(acc, C, bias, residual, row_mask, M, N, flags, m0 + wm * 64 + n, n0 + wn * 64 + 4 * g TL_ARGS);
+                epilogue_tile<OutT, CF>(acc, C, bias, residual, row_mask, M, N, flags, m0 + wm * 64 + n, n0 + wn * 64 + 4 * g TL_ARGS, cp.res_rows);
             kt = 0; ++tile;
             TL_EV(12)
         }
@@ -893,8 +899,20 @@ __global__ __launch_bounds__(TallCfg<TBN>::NT, TBN == 64 ? 4 : 1) void gemm_ws_t
             unsigned char* wt = smem + stage * TALL_STAGE + lds0;
 #pragma unroll
             for (int i = 0; i < WL; ++i) *reinterpret_cast<uint4*>(wt + i * 32 * LDS_ROW) = rw[S][i];
+            if constexpr (kSplit<T>) {      // fp32 activations -> fp16 hi | lo halves of the row (see GT<f32s_t>)
+                unsigned char* xs = smem + stage * TALL_STAGE + (TBN + srow) * LDS_ROW;
+                const int xh = (((kc >> 1) ^ (srow & 7)) * 16) + (kc & 1) * 8, xl = (((4 + (kc >> 1)) ^ (srow & 7)) * 16) + (kc & 1) * 8;
+#pragma unroll
+                for (int i = 0; i < 8; ++i) {
+                    uint2 hi, lo;
+                    GT<T>::split4(ra[S][i], hi, lo);
+                    *reinterpret_cast<uint2*>(xs + i * 32 * LDS_ROW + xh) = hi;
+                    *reinterpret_cast<uint2*>(xs + i * 32 * LDS_ROW + xl) = lo;
+                }
+            } else {
 #pragma unroll
             for (int i = 0; i < 8; ++i) *reinterpret_cast<uint4*>(wt + TBN * LDS_ROW + i * 32 * LDS_ROW) = ra[S][i];
+            }
         };
         int lkt = 0, ltile = t_begin;
         auto advance_and_load = [&](auto S_) {
@@ -955,12 +973,15 @@ __global__ __launch_bounds__(TallCfg<TBN>::NT, TBN == 64 ? 4 : 1) void gemm_ws_t
                 xf[kq][i] = *reinterpret_cast<const uint4*>(xt + i * 16 * LDS_ROW + sw);
             }
         }
+        if constexpr (kSplit<T>) GT<T>::mma_slab(wf, xf, acc);
+        else {
 #pragma unroll
         for (int kq = 0; kq < 2; ++kq)
 #pragma unroll
             for (int ci = 0; ci < 4; ++ci)
 #pragma unroll
                 for (int ti = 0; ti < 4; ++ti) GT<T>::mma(wf[kq][ci], xf[kq][ti], acc[ci][ti]);
+        }
         __syncthreads();
         if (++kt == nk) {
             epilogue_tile<OutT, CF>(acc, C, bias, residual, (const uint8_t*)nullptr, M, N, flags, tile * TALL_BM + (wave & 3) * 64 + n,
@@ -1107,13 +1128,20 @@ static int try_tall(const void* X, const void* W, const float* bias, const void*
                     int M, int N, int K, int flags, const ConvP& cp, hipStream_t st, bool& done)
 {
     done = false;
-    if constexpr (!(sizeof(T) == 2 && sizeof(OutT) == 2)) return DTLR_OK;
+    if constexpr (!kSpecialise<T, OutT>) return DTLR_OK;       // 16-bit in / out, or split-fp32 operands with fp32 results
     else {
         if (!use_tall() || (N & 3) || (flags & ~(EPI_BIAS | EPI_RELU | EPI_RELU_POST | EPI_RESIDUAL | EPI_GELU))) return DTLR_OK;
         const int nM = (M + TALL_BM - 1) / TALL_BM;
         static const int rr = exp_env_int("DTLR_TALL_XCD", 1) == 0 ? 1 : 0;   // experiment builds: =0 round-robin placement (A/B timing)
         if (N <= 64) {
             if (M < 64 * TALL_BM) return DTLR_OK;
+            if constexpr (kSplit<T>) {
+                // split operands: only the instantiations that fit 128 VGPRs without spilling (tools/resource_usage.py) -- the gathering (CONV)
+                // loader plus the hi / lo conversion does not, and a spilled staging register of the hand-counted asm loads would be
+                // copied before its data lands; those shapes stay on the 128 x 128 kernel
+                if (CONV || !(flags == (EPI_BIAS | EPI_RELU_POST) || flags == EPI_BIAS)) return DTLR_OK;
+            }
+            if constexpr (!(kSplit<T> && CONV)) {
             const long target = 2 * 256 * 2;
             int per = (int)((nM + target - 1) / target);
             if (per < 1) per = 1;
@@ -1128,16 +1156,19 @@ static int try_tall(const void* X, const void* W, const float* bias, const void*
             }
             if (flags == (EPI_BIAS | EPI_RELU_POST)) TALL_LAUNCH((EPI_BIAS | EPI_RELU_POST))
             else if (flags == EPI_BIAS) TALL_LAUNCH(EPI_BIAS)
-            else TALL_LAUNCH(-1)
+            else if constexpr (!kSplit<T>) TALL_LAUNCH(-1)
 #undef TALL_LAUNCH
             done = true;
             return check_launch();
+            }
         }
         // 256 x 128 tiles: enough tiles to occupy the chip (one workgroup per CU), K deep enough that operand delivery is the limit
         const int nN = N / 128;
         // measured (profile_ops, same box): the plain K >= 512 projections over >= 32768 rows gain 8-16%; the implicit-GEMM convolutions
         // and the 28800-row decoder projections lose 10-20% (one workgroup per CU: no second workgroup to overlap an epilogue with)
-        if (!use_tall128() || CONV || (N & 127) || K < 512 || M < 32768 || (long)nM * nN < 192) return DTLR_OK;
+        // split-fp32 operands: two fp32 operand tiles move twice the bytes per k, so the K = 256 projections over all tokens (FFN linear1:
+        // 7.7 TB/s of L2 -> LDS delivery at 128 x 128 tiles) are delivery-bound as well
+        if (!use_tall128() || CONV || (N & 127) || K < (kSplit<T> ? 256 : 512) || M < 32768 || (long)nM * nN < 192) return DTLR_OK;
         {
             const long target = 256;
             int per = (int)(((long)nM * nN + target - 1) / target);
@@ -1154,6 +1185,7 @@ static int try_tall(const void* X, const void* W, const float* bias, const void*
             if (flags == (EPI_BIAS | EPI_RELU_POST)) TALL_LAUNCH((EPI_BIAS | EPI_RELU_POST))
             else if (flags == (EPI_BIAS | EPI_RELU_POST | EPI_RESIDUAL)) TALL_LAUNCH((EPI_BIAS | EPI_RELU_POST | EPI_RESIDUAL))
             else if (flags == EPI_BIAS) TALL_LAUNCH(EPI_BIAS)
+            else if (flags == (EPI_BIAS | EPI_RELU)) TALL_LAUNCH((EPI_BIAS | EPI_RELU))
             else TALL_LAUNCH(-1)
 #undef TALL_LAUNCH
             done = true;
@@ -1208,12 +1240,14 @@ static int launch_conv(const void* X, const void* W, const float* bias, const vo
 
 template <typename T, typename OutT>
 static int launch_gemm(const void* A, const void* A2, const void* W, const float* bias, const void* residual,
-                       const uint8_t* row_mask, void* C, int M, int N, int K, int flags, hipStream_t st, int a2_rows = 0, int lda = 0)
+                       const uint8_t* row_mask, void* C, int M, int N, int K, int flags, hipStream_t st, int a2_rows = 0, int lda = 0,
+                       int res_rows = 0)
 {
     ConvP cp{};
     cp.a2_rows = a2_rows;
     cp.lda = lda;
-    if (!A2 && !row_mask) {
+    cp.res_rows = res_rows;
+    if (!A2 && !row_mask && !res_rows) {
         bool done = false;
         const int rc = try_tall<T, OutT, false>(A, W, bias, residual, C, M, N, K, flags, cp, st, done);
         if (rc != DTLR_OK || done) return rc;
@@ -1223,7 +1257,7 @@ static int launch_gemm(const void* A, const void* A2, const void* W, const float
     if (nwg > 0x7fffffffL) return DTLR_ESHAPE;
     const size_t lds = 4 * TILE_BYTES;
     if (use_ws()) {
-        if (!A2 && !(flags & EPI_ROWMAX)) {
+        if (!A2 && !(flags & EPI_ROWMAX) && !res_rows) {
             bool done = false;
             const int rc = try_splitk<T, OutT, false>(A, W, bias, residual, row_mask, C, M, N, K, flags, cp, st, done);
             if (rc != DTLR_OK || done) return rc;
@@ -1242,6 +1276,9 @@ static int launch_gemm(const void* A, const void* A2, const void* W, const float
                 if (flags == (EPI_BIAS | EPI_RELU)) { WS_LAUNCH(false, false, (EPI_BIAS | EPI_RELU), gridw, GEMM_ARGS(nullptr)) return check_launch(); }
                 if (flags == (EPI_BIAS | EPI_RELU_POST)) { WS_LAUNCH(false, false, (EPI_BIAS | EPI_RELU_POST), gridw, GEMM_ARGS(nullptr)) return check_launch(); }
                 if (flags == (EPI_BIAS | EPI_RELU_POST | EPI_RESIDUAL)) { WS_LAUNCH(false, false, (EPI_BIAS | EPI_RELU_POST | EPI_RESIDUAL), gridw, GEMM_ARGS(nullptr)) return check_launch(); }
+                if constexpr (kSplit<T>) {
+                    if (flags == EPI_RESIDUAL) { WS_LAUNCH(false, false, EPI_RESIDUAL, gridw, GEMM_ARGS(nullptr)) return check_launch(); }
+                }
             }
             WS_LAUNCH(false, false, -1, gridw, GEMM_ARGS(nullptr))
         }
@@ -1350,6 +1387,25 @@ extern "C" int dtlr_gemm_nt_a2bcast(const void* A, const void* A2, int a2_rows, 
         if (K % 32) return DTLR_ESHAPE;
         return launch_gemm<f32s_t, float>(A, A2, W, bias, nullptr, nullptr, C, M, N, K, flags, (hipStream_t)stream, a2_rows);
     }
+    return DTLR_EDTYPE;
+}
+
+// C = A . W^T [+ bias] + residual[m % res_rows]: dtlr_gemm_nt with a row-BROADCAST residual (res_rows rows, M % res_rows == 0).
+extern "C" int dtlr_gemm_nt_resbcast(const void* A, const void* W, const float* bias, const void* residual, int res_rows, void* C,
+                                     int M, int N, int K, int dtype, void* stream)
+{
+    clear_stale_error();
+    if (!A || !W || !residual || !C) return DTLR_EINVAL;
+    if (M <= 0 || N <= 0 || K <= 0 || res_rows <= 0 || M % res_rows) return DTLR_EINVAL;
+    const int flags = (bias ? EPI_BIAS : 0) | EPI_RESIDUAL;
+    hipStream_t st = (hipStream_t)stream;
+    if (dtype == DTLR_H16) {
+        if (K % 64) return DTLR_ESHAPE;
+        return launch_gemm<uint16_t, uint16_t>(A, nullptr, W, bias, residual, nullptr, C, M, N, K, flags, st, 0, 0, res_rows);
+    }
+    if (K % 32) return DTLR_ESHAPE;
+    if (dtype == DTLR_F32) return launch_gemm<float, float>(A, nullptr, W, bias, residual, nullptr, C, M, N, K, flags, st, 0, 0, res_rows);
+    if (dtype == DTLR_F32S) return launch_gemm<f32s_t, float>(A, nullptr, W, bias, residual, nullptr, C, M, N, K, flags, st, 0, 0, res_rows);
     return DTLR_EDTYPE;
 }
 

@@ -648,7 +648,6 @@ __device__ __forceinline__ void enc_queries_f32_lvl(
     const int wc0l = p == 0 ? wc0[0] : p == 1 ? wc0[1] : p == 2 ? wc0[2] : wc0[3];
     const int wc1l = p == 0 ? wc1[0] : p == 1 ? wc1[1] : p == 2 ? wc1[2] : wc1[3];
     const float fH = (float)Hl, fW = (float)Wl;
-    const float invH = 1.0f / fH, invW = 1.0f / fW;          // exact for power-of-two maps; else the product differs from the quotient by <= 1 ulp
     const unsigned char* win = smem + (long)loffl * 128;
     const float* gsrc = vimg + (long)startl * MD;
     int rot[8];
@@ -695,8 +694,10 @@ __device__ __forceinline__ void enc_queries_f32_lvl(
         }
 #pragma unroll
         for (int pt = 0; pt < 4; ++pt) {
-            const float lx = rf.x + off[2 * pt] * invW;
-            const float ly = rf.y + off[2 * pt + 1] * invH;
+            // the reference's own order, two roundings (ms_deform_attn.py:102-105: ref + off / (W, H)): the product with 1 / W, or an FMA the
+            // compiler contracts it into, moves a sampling point by ~1e-5 px at far offsets -- 8e-6 in the output, above the oracle tolerance
+            const float lx = __fadd_rn(rf.x, __fdiv_rn(off[2 * pt], fW));
+            const float ly = __fadd_rn(rf.y, __fdiv_rn(off[2 * pt + 1], fH));
             // v_med3_f32: a NaN operand yields min3 of the others = -1 (zero weights), like fminf(fmaxf(x, -1), size)
             const float h_im = __builtin_amdgcn_fmed3f(ly * fH - 0.5f, -1.f, fH), w_im = __builtin_amdgcn_fmed3f(lx * fW - 0.5f, -1.f, fW);
             const float hf = floorf(h_im), wf = floorf(w_im);

@@ -168,6 +168,27 @@ def linear(x, w, b=None, relu=False, residual=None, a2=None, row_mask=None, out_
                          f"(K must be a multiple of {slab} elements; fp32 operands give fp32 results); there is no library fallback")
 
 
+def linear_resbcast(x, w, resid, b=None):
+    """x @ w.T [+ b] + resid[row % R]: `linear` with a row-BROADCAST residual (dtlr_gemm_nt_resbcast).  x [..., K] (M rows in all), w [N, K]
+    (same dtype, or a SplitWeight for fp32 x), resid [R, N] in the output dtype with M % R == 0.  The encoder's [offsets | logits] projection of
+    an unpadded batch: (src + pos) W^T + b = src W^T + (pos W^T + b), the second term one [S, N] matrix for every image."""
+    require_cuda(x, "x")
+    K, N = x.shape[-1], w.shape[0]
+    M, R = x.numel() // K, resid.numel() // N
+    slab = 64 if x.dtype in H16 else 32
+    if x.dtype not in H16 + (torch.float32,) or w.dtype != x.dtype or resid.dtype != x.dtype or K % slab or M % R or resid.shape[-1] != N:
+        raise _lib.DTLRError(f"ops.linear_resbcast: no HIP kernel for x {tuple(x.shape)} {x.dtype}, w {tuple(w.shape)}, resid {tuple(resid.shape)} {resid.dtype}")
+    x = x if x.is_contiguous() else x.contiguous()
+    resid = resid if resid.is_contiguous() else resid.contiguous()
+    y = torch.empty(x.shape[:-1] + (N,), dtype=x.dtype, device=x.device)
+    es = x.element_size()
+    with _Timed(_gkind(x, w), 2.0 * M * N * K, float(M) * K * es + float(N) * K * es + float(M) * N * es + float(R) * N * es, f"linear M{M} N{N} K{K}+resb{R}"):
+        code = _L(x).dtlr_gemm_nt_resbcast(x.data_ptr(), w.data_ptr(), 0 if b is None else b.data_ptr(), resid.data_ptr(), R, y.data_ptr(),
+                                           M, N, K, _in_dt(x, w), _lib.current_stream())
+    _lib.check(code, "dtlr_gemm_nt_resbcast")
+    return y
+
+
 def k256_pack(w):
     """[N, 256] weight (N = 256 or 384; any float dtype / device) -> the fragment-order bf16 image dtlr_gemm_k256 keeps in
     registers: block ((wave * NRT + rt) * 8 + ks) = 64 lanes x 8 elements, lane (m, g) <- W[(wave*NRT + rt)*16 + m][32 ks + 8 g ..]
@@ -1106,6 +1127,6 @@ def _device_scoped(fn):
 for _name in ("msda_encoder_far_fraction", "gemm_kres", "gemm_kres_chain", "gemm_kres_cat_s2", "gemm_kres_bcast384", "ffn32", "proj_ln_k256", "swin_patch_embed", "swin_window_attn", "swin_patch_merge", "geometry", "linear", "gemm_k256", "linear_rowmax", "two_stage_gather", "layernorm", "proj_ln", "proj_ln_split", "ffn_fused", "conv2d_nhwc", "stem_conv7x7", "stem_conv7x7_f32",
               "maxpool_nhwc", "groupnorm_tokens", "msda", "msda_fused", "msda_encoder", "mha", "decoder_query_prep", "box_mlp_refine",
               "box_head_refine", "box_refine", "topk_rows", "decode_blank", "preprocess_lines", "ctc_loss_interleaved", "nms_batched",
-              "topk_flat", "stem_conv7x7_pool", "dec_query_stage", "blank_emissions", "split_pack"):
+              "topk_flat", "stem_conv7x7_pool", "dec_query_stage", "blank_emissions", "split_pack", "linear_resbcast"):
     globals()[_name] = _device_scoped(globals()[_name])
 del _name

@@ -242,6 +242,12 @@ long dtlr_mha_workspace_bytes(int B, int L, int H, int head_dim);
  * per 32-k slab of a row, 16-byte chunk c < 4 holds fp16(w) of k 8c..8c+7 and chunk 4 + c holds fp16(w - fp16(w)) of the same k -- the
  * slab image the DTLR_F32S kernels copy to LDS.  Row slices of the image are images of the row slices.  K % 32 == 0.  (round 4) */
 int dtlr_split_pack_weights(const float *w, void *out, long rows, int K, void *stream);
+/* C = A . W^T [+ bias] + residual[m % res_rows]  (dtype BF16 / F16 / F32 / F32S as dtlr_gemm_nt; residual and C in the output dtype, i.e. the
+ * 16-bit format for 16-bit operands, fp32 otherwise): the encoder's [offsets | logits] projection of an unpadded batch,
+ * (src + pos) W^T + b = src W^T + (pos W^T + b), where the second term is ONE [S, N] matrix for every image
+ * (ops/modules/ms_deform_attn.py:97-98 with query = src + pos, deformable_transformer.py:812).  M % res_rows == 0.  (round 4) */
+int dtlr_gemm_nt_resbcast(const void *A, const void *W, const float *bias, const void *residual, int res_rows, void *C,
+                          int M, int N, int K, int dtype, void *stream);
 int dtlr_gemm_nt(const void *A, const void *A2, const void *W, const float *bias,
                  const void *residual, const unsigned char *row_mask, void *C,
                  int M, int N, int K, int relu, int in_dtype, int out_dtype, void *stream);

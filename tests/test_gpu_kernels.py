@@ -1339,7 +1339,10 @@ def test_gemm_split_vs_fp64(M, N, K):
             assert got.shape == want.shape and got.dtype == torch.float32
             scale = max(want.abs().max().item(), 1e-30)
             worst = max(worst, (got - want).abs().max().item() / scale)
-            assert (got - want).abs().max() < 2e-5 * scale, (sx, relu, use_b, use_res, use_a2, use_mask, (got - want).abs().max().item() / scale)
+            # small operands: a lo half in fp16's subnormal range keeps an ABSOLUTE quantum of 2^-24, so a weight of ~1e-3 carries ~19
+            # significand bits instead of 22 (measured 1e-5 of the output scale; a flushed lo would give 2.4e-4)
+            bound = 2e-5 if sx == 1.0 else 5e-5
+            assert (got - want).abs().max() < bound * scale, (sx, relu, use_b, use_res, use_a2, use_mask, (got - want).abs().max().item() / scale)
         print(f"[split gemm M{M} N{N} K{K} scale {sx:g}] worst error / output scale {worst:.2e}")
 
 
@@ -1381,3 +1384,25 @@ def test_conv2d_nhwc_split_vs_fp64(B, H, W, Cin, Cout, k, stride, pad):
         got = ops.conv2d_nhwc(x.cuda(), wp, b.cuda(), stride, pad, relu, res.cuda() if use_res else None).cpu()
         assert got.shape == want.shape
         assert (got - want.float()).abs().max() < 3e-5 * max(1.0, want.abs().max().item()), (relu, use_res)
+
+
+@pytest.mark.parametrize("kind", ["f32", "f32s", "h16"])
+@pytest.mark.parametrize("B,S,N", [(3, 640, 384), (32, 5440, 384), (2, 77, 166), (1, 128, 256)])
+def test_linear_row_broadcast_residual(kind, B, S, N, half):
+    """dtlr_gemm_nt_resbcast: x W^T + resid[row % S] against fp64, for the exact-fp32, split-fp32 and 16-bit kernels (ragged M / N tiles,
+    one image, the bench shape); and the identity it serves: (src + pos) W^T + b == src W^T + (pos W^T + b)."""
+    from dtlr_amd import ops
+    K = 256
+    x, pos = _rand((B, S, K), 1), _rand((S, K), 2)
+    w, b = _rand((N, K), 3) / 16.0, _rand((N,), 4)
+    dt = half if kind == "h16" else torch.float32
+    xd, posd, wd = x.to(dt).cuda(), pos.to(dt).cuda(), w.to(dt).cuda()
+    wk = ops.split_pack(wd) if kind == "f32s" else wd
+    res = ops.linear(posd, wk, b.cuda())                                       # [S, N]: pos W^T + b
+    got = ops.linear_resbcast(xd, wk, res).float().cpu()
+    want = ((xd.double().cpu() @ wd.double().cpu().t()) + res.double().cpu()[None]).float()
+    tol = (2e-5 if kind != "h16" else ulp(half, 8)) * max(1.0, want.abs().max().item()) + (0 if kind != "h16" else 1e-4)
+    assert got.shape == (B, S, N) and (got - want).abs().max() < tol, (got - want).abs().max().item()
+    if kind != "h16":
+        full = ((x + pos).double() @ w.double().t() + b.double()).float()
+        assert (got - full).abs().max() < 3e-5 * max(1.0, full.abs().max().item())
