@@ -167,36 +167,41 @@ __device__ __forceinline__ void sample_level4(const T* __restrict__ base, int H,
     for (int p0 = 0; p0 < 4; p0 += G) {
         typename R::raw_t d[G][4];
         float wgt[G][4];
-        bool ok[G][4];
 #pragma unroll
         for (int q = 0; q < G; ++q) {
             const int p = p0 + q;
-            const float h_im = ly[p] * (float)H - 0.5f;
-            const float w_im = lx[p] * (float)W - 0.5f;
-            const bool inside = h_im > -1.f && w_im > -1.f && h_im < (float)H && w_im < (float)W;
+            // Round 4: the validity of a corner no longer travels as a lane mask next to its data.  The first form kept `ok[q][c]`
+            // (inside && h_low >= 0 && ...: chains of s_and_b64 on 64-bit SGPR masks) alive across the 16 gathers and selected the DATA
+            // with them afterwards -- the pattern that lost lanes 48..63 of such masks under multi-process contention in the 16-bit decoder
+            // kernel (tools/mask_lint.py counted 22..30 masks read after an s_waitcnt vmcnt in these kernels).  As in
+            // msda_fused_quad_bf16_kernel the coordinate is clamped to [-1, size] first (identical inside the map; outside it every factor
+            // below becomes zero, which is the reference's `inside` test) and each separable factor depends on ONE unsigned compare that is
+            // consumed by the next instruction; an invalid corner has a zero WEIGHT on a clamped (valid, finite) address.  Products of the
+            // valid corners are bit-identical to the first form (same expression order: hh * hw, ...).
+            const float h_im = __builtin_amdgcn_fmed3f(ly[p] * (float)H - 0.5f, -1.f, (float)H);      // NaN -> -1: zero weights
+            const float w_im = __builtin_amdgcn_fmed3f(lx[p] * (float)W - 0.5f, -1.f, (float)W);
             const float hf = floorf(h_im), wf = floorf(w_im);
             const float lh = h_im - hf, lw = w_im - wf, hh = 1.f - lh, hw = 1.f - lw;
-            const int h_low = (int)fminf(fmaxf(hf, -1.f), (float)H), w_low = (int)fminf(fmaxf(wf, -1.f), (float)W);
+            const int h_low = (int)hf, w_low = (int)wf;
             const int h_high = h_low + 1, w_high = w_low + 1;
-            const bool top = inside && h_low >= 0, bot = inside && h_high <= H - 1;
-            const bool left = w_low >= 0, right = w_high <= W - 1;
-            // clamp BOTH ways: for a far-outside sample h_low can be H (then h_high = H+1): data unused, address must stay in the map
-    const int h0 = min(max(h_low, 0), H - 1), h1 = max(min(h_high, H - 1), 0), w0 = min(max(w_low, 0), W - 1), w1 = max(min(w_high, W - 1), 0);
+            const float wy0 = (unsigned)h_low < (unsigned)H ? hh : 0.f, wy1 = (unsigned)h_high < (unsigned)H ? lh : 0.f;
+            const float wx0 = (unsigned)w_low < (unsigned)W ? hw : 0.f, wx1 = (unsigned)w_high < (unsigned)W ? lw : 0.f;
+            // clamp BOTH ways: h_low ranges over [-1, H], h_high over [0, H + 1]: data unused there, the address must stay in the map
+            const int h0 = min(max(h_low, 0), H - 1), h1 = max(min(h_high, H - 1), 0), w0 = min(max(w_low, 0), W - 1), w1 = max(min(w_high, W - 1), 0);
             const int r0 = h0 * row_stride, r1 = h1 * row_stride, c0 = w0 * MD, c1 = w1 * MD;
             d[q][0] = R::ld(base + (r0 + c0));
             d[q][1] = R::ld(base + (r0 + c1));
             d[q][2] = R::ld(base + (r1 + c0));
             d[q][3] = R::ld(base + (r1 + c1));
-            ok[q][0] = top && left; ok[q][1] = top && right; ok[q][2] = bot && left; ok[q][3] = bot && right;
-            wgt[q][0] = hh * hw; wgt[q][1] = hh * lw; wgt[q][2] = lh * hw; wgt[q][3] = lh * lw;
+            wgt[q][0] = wy0 * wx0; wgt[q][1] = wy0 * wx1; wgt[q][2] = wy1 * wx0; wgt[q][3] = wy1 * wx1;
         }
 #pragma unroll
         for (int q = 0; q < G; ++q) {
             float v1[VEC], v2[VEC], v3[VEC], v4[VEC];
-            R::unpack(d[q][0], ok[q][0], v1);
-            R::unpack(d[q][1], ok[q][1], v2);
-            R::unpack(d[q][2], ok[q][2], v3);
-            R::unpack(d[q][3], ok[q][3], v4);
+            R::unpack(d[q][0], true, v1);
+            R::unpack(d[q][1], true, v2);
+            R::unpack(d[q][2], true, v3);
+            R::unpack(d[q][3], true, v4);
 #pragma unroll
             for (int i = 0; i < VEC; ++i)
                 col[i] += (wgt[q][0] * v1[i] + wgt[q][1] * v2[i] + wgt[q][2] * v3[i] + wgt[q][3] * v4[i]) * aw[p0 + q];

@@ -642,24 +642,26 @@ def test_rccl_collectives_on_a_one_rank_group():
     assert r.returncode == 0 and "RCCL_OK" in r.stdout, (r.stdout[-500:], r.stderr[-3000:])
 
 
-@pytest.mark.parametrize("half", ["bf16", "f16"])
-def test_two_processes_on_one_gpu_are_bit_reproducible(half):
+@pytest.mark.parametrize("kind,conf,n", [("bf16", "latin", 50), ("f16", "latin", 50), ("f32s", "latin", 16), ("f32", "latin", 8),
+                                         ("bf16-gather", "latin", 30), ("bf16", "chinese", 20), ("bf16", "swin", 20)])
+def test_two_processes_on_one_gpu_are_bit_reproducible(kind, conf, n):
     """Round 2's open issue: with two processes driving ONE GPU, ~10% of forwards differed from the same process's own earlier result
     (lanes 48..63 of scattered waves of the decoder's deformable-sampling kernel dropped corner terms).  Two
-    UNLOCKED workers, 50 forwards each of the same batch, no synchronisation inside a forward: every forward of both processes must be
-    bit-identical."""
+    UNLOCKED workers, n forwards each of the same batch, no synchronisation inside a forward: every forward of both processes must be
+    bit-identical.  Round 4 extends the round-3 pair (bf16 / f16 Latin) to every engine and kernel family that could hold a long-lived
+    lane mask: the exact-fp32 and split-fp32 engines, the encoder forced onto the gather kernel, the 7356-class head, the Swin backbone."""
     import json
     import subprocess
     import sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    cmd = [sys.executable, os.path.join(root, "tests", "contention_worker.py"), "50", half]
+    cmd = [sys.executable, os.path.join(root, "tests", "contention_worker.py"), str(n), kind, conf]
     procs = [subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, cwd=root) for _ in range(2)]
     outs = []
     for p in procs:
         o, e = p.communicate(timeout=600)
         assert p.returncode == 0, e[-3000:]
         outs.append(json.loads([l for l in o.splitlines() if l.startswith("{")][-1]))
-    assert all(o["forwards"] == 50 and o["distinct"] == 1 for o in outs), outs
+    assert all(o["forwards"] == n and o["distinct"] == 1 for o in outs), outs
     assert outs[0]["digest"] == outs[1]["digest"], outs
 
 
