@@ -1128,7 +1128,10 @@ static int try_tall(const void* X, const void* W, const float* bias, const void*
                     int M, int N, int K, int flags, const ConvP& cp, hipStream_t st, bool& done)
 {
     done = false;
-    if constexpr (!kSpecialise<T, OutT>) return DTLR_OK;       // 16-bit in / out, or split-fp32 operands with fp32 results
+    // 16-bit in / out only.  Split-fp32 operands were measured on both tall tiles in round 4 (the kernel bodies take them: the loader's
+    // hi / lo conversion and mma_slab are in place): FFN linear1 720 -> 697 us, linear2 569 -> 590 us, value_proj of all decoder layers
+    // (N = 1536, K = 256) 551 -> 985 us, the 256 -> 64 reductions 176 -> 173 us -- no gain, one large loss: they stay on 128 x 128 tiles.
+    if constexpr (!(sizeof(T) == 2 && sizeof(OutT) == 2)) return DTLR_OK;
     else {
         if (!use_tall() || (N & 3) || (flags & ~(EPI_BIAS | EPI_RELU | EPI_RELU_POST | EPI_RESIDUAL | EPI_GELU))) return DTLR_OK;
         const int nM = (M + TALL_BM - 1) / TALL_BM;
@@ -1166,9 +1169,7 @@ static int try_tall(const void* X, const void* W, const float* bias, const void*
         const int nN = N / 128;
         // measured (profile_ops, same box): the plain K >= 512 projections over >= 32768 rows gain 8-16%; the implicit-GEMM convolutions
         // and the 28800-row decoder projections lose 10-20% (one workgroup per CU: no second workgroup to overlap an epilogue with)
-        // split-fp32 operands: two fp32 operand tiles move twice the bytes per k, so the K = 256 projections over all tokens (FFN linear1:
-        // 7.7 TB/s of L2 -> LDS delivery at 128 x 128 tiles) are delivery-bound as well
-        if (!use_tall128() || CONV || (N & 127) || K < (kSplit<T> ? 256 : 512) || M < 32768 || (long)nM * nN < 192) return DTLR_OK;
+        if (!use_tall128() || CONV || (N & 127) || K < 512 || M < 32768 || (long)nM * nN < 192) return DTLR_OK;
         {
             const long target = 256;
             int per = (int)(((long)nM * nN + target - 1) / target);
