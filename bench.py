@@ -481,11 +481,12 @@ def main():
              "gemm_f32": "gemm_ws_kernel<f32> (fp32 heads and selection scores, exact-fp32 MFMA 16x16x4)",
              "gemm_f32s": "gemm_ws_kernel<f32s> (fp32 operands as fp16 hi + lo halves, three 16x16x32 fp16 MFMAs per product; flops counted once)",
              "ffn_fused_bf16": "ffn3_bf16_kernel / ffn2_bf16_kernel / ffn_fused_bf16_kernel (linear1+ReLU+linear2+residual+LayerNorm, intermediate on chip)",
+             "ffn_fused_f32s": "ffn_split_kernel (linear1+ReLU+linear2+residual+LayerNorm on split fp16 hi + lo operands, intermediate on chip; flops counted once)",
              "proj_ln_bf16": "proj_ln_bf16_kernel (attention output projection + residual + LayerNorm)"}
 
     def both_roofs(kind, ms, flops, nbytes):
         # f32s: algorithmic flops (each product once) against a third of the dense 16-bit peak -- the kernel issues three MFMAs per product
-        peak = MFMA_PEAK_F32_TFLOPS if kind == "gemm_f32" else (MFMA_PEAK_BF16_TFLOPS / 3.0 if kind == "gemm_f32s" else MFMA_PEAK_BF16_TFLOPS)
+        peak = MFMA_PEAK_F32_TFLOPS if kind == "gemm_f32" else (MFMA_PEAK_BF16_TFLOPS / 3.0 if kind.endswith("f32s") else MFMA_PEAK_BF16_TFLOPS)
         ach = flops / (ms * 1e-3) / 1e12
         gbps = nbytes / (ms * 1e-3) / 1e9                        # compulsory operand + result bytes (each tensor once)
         return peak, ach, gbps, ach / peak, gbps / HBM_PEAK_GBS

@@ -59,6 +59,8 @@ _SIGNATURES = {
     "dtlr_ffn32_pad_chunks": (c_int, []),
     "dtlr_ffn32_bf16": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_float, c_void_p,
                                 ctypes.c_long, c_int, c_void_p]),
+    "dtlr_ffn_split": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_float, c_void_p, ctypes.c_long, c_int, c_void_p]),
+    "dtlr_ffn_split_pad_chunks": (c_int, []),
     "dtlr_proj_pack_weights": (c_int, [c_void_p, c_void_p]),
     "dtlr_proj_ln_bf16": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_float, c_void_p, c_int, c_int, c_void_p]),
     "dtlr_proj_ln_split_bf16": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_float, c_void_p, c_int, c_int, c_void_p]),

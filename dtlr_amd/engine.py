@@ -51,6 +51,7 @@ class DTLREngine:
             raise RuntimeError("DTLREngine runs on the GPU only (no CPU path)")
         ops.require_cuda(torch.empty(0, device=self.device))
         self.w: Dict[str, torch.Tensor] = {}
+        self._ffn_f32: Dict[str, torch.Tensor] = {}
         self._pack(state_dict)
         self._shape_cache: Dict[tuple, dict] = {}
         self._level_cache: Dict[tuple, tuple] = {}
@@ -97,6 +98,8 @@ class DTLREngine:
         self.w[name + ".b"] = b.to(device=self.device, dtype=torch.float32).contiguous()
 
     def _put_linear(self, name, w, b):
+        if self.split and name.endswith((".ff1", ".ff2")):      # the fused split FFN packs its own image from the fp32 weights
+            self._ffn_f32[name] = w.to(device=self.device, dtype=torch.float32).contiguous()
         self.w[name + ".w"] = self._gw(w)
         self._put(name + ".b", b, torch.float32)          # biases enter the GEMM epilogue in fp32
 
@@ -353,6 +356,11 @@ class DTLREngine:
                               out=y[M - rem:])
                 return y.view(x.shape)
             return ops.ffn32(x, w1p, w[q + "ff1.b"], w2p, w[q + "ff2.b"], w[q + norm + ".w"], w[q + norm + ".b"])
+        if self.split and self.use_fused_ffn and x.shape[-1] == 256 and w[q + "ff1.b"].numel() % 32 == 0 and 32 <= w[q + "ff1.b"].numel() <= 2048:
+            # split-fp32 engine: linear1 + ReLU + linear2 + residual + LayerNorm in one kernel on split operands (ffn_split.hip)
+            if q + "ff.sp" not in w:
+                w[q + "ff.sp"] = ops.ffn_split_pack(self._ffn_f32.pop(q + "ff1"), self._ffn_f32.pop(q + "ff2"))
+            return ops.ffn_split(x, w[q + "ff.sp"], w[q + "ff1.b"], w[q + "ff2.b"], w[q + norm + ".w"], w[q + norm + ".b"])
         if self.use_fused_ffn and ops.ffn_fused_supported(x, w[q + "ff1.w"]):
             if q + "ff2.wp" not in w:                           # chunk-major copy of linear2.weight, packed once
                 w[q + "ff2.wp"] = ops.ffn_pack_w2(w[q + "ff2.w"])

@@ -573,6 +573,50 @@ def ffn_fused(x, w1, b1, w2p, b2, ln_w, ln_b, eps: float = 1e-5, out=None):
     return y
 
 
+def ffn_split_pack(w1, w2):
+    """linear1.weight [d_ff, 256], linear2.weight [256, d_ff] (fp32, any device) -> the chunk-major split image dtlr_ffn_split streams (uint8,
+    same device): per 32-unit chunk one 64 KB block [W1_hi | W1_lo | W2_hi | W2_lo], each 16 fragments of 1 KB in the fragment order of
+    ffn32_pack (W1: lane l <- W1[32 c + (l & 31)][16 s + 8 (l >> 5) + e]; W2: fragment 8 s + ct, lane l <- W2[32 ct + (l & 31)][32 c +
+    8 (2 s + (e >> 2)) + 4 (l >> 5) + (e & 3)]); hi = fp16(w), lo = fp16(w - hi).  An odd chunk count is padded to even and
+    dtlr_ffn_split_pad_chunks() zero chunks follow (streamed by the kernel's look-ahead, multiplied into nothing)."""
+    d_ff = w1.shape[0]
+    assert tuple(w1.shape) == (d_ff, 256) and tuple(w2.shape) == (256, d_ff) and d_ff % 32 == 0 and 32 <= d_ff <= 2048
+    nc = d_ff // 32
+    total = ((nc + 1) & ~1) + int(_lib.lib().dtlr_ffn_split_pad_chunks())
+    w1f, w2f = w1.detach().float(), w2.detach().float()
+    parts = []
+    for wf, kind in ((w1f, 1), (w2f, 2)):
+        hi = wf.half()
+        for t in (hi, (wf - hi.float()).half()):
+            if kind == 1:
+                parts.append(t.view(nc, 32, 16, 2, 8).permute(0, 2, 3, 1, 4).reshape(nc, 8192))
+            else:
+                parts.append(t.view(8, 32, nc, 2, 2, 2, 4).permute(2, 3, 0, 5, 1, 4, 6).reshape(nc, 8192))
+    img = torch.cat(parts, 1)                                     # [nc, 4 x 8192 halves] = 64 KB per chunk
+    out = torch.zeros((total, 4 * 8192), dtype=torch.float16, device=w1.device)
+    out[:nc] = img
+    return out.view(torch.uint8).reshape(-1)
+
+
+def ffn_split(x, wp, b1, b2, ln_w, ln_b, eps: float = 1e-5, out=None):
+    """LayerNorm(x + relu(x W1^T + b1) W2^T + b2) for fp32 rows in ONE kernel, every product as three fp16 MFMAs on hi + lo halves
+    (dtlr_ffn_split: the split-fp32 engine's FFN block; the [M, d_ff] intermediate never reaches HBM).  x [..., 256] fp32;
+    wp = ffn_split_pack(W1, W2); b1 [d_ff], b2 / LN params [256] fp32."""
+    require_cuda(x, "x")
+    d_ff = b1.numel()
+    assert x.dtype == torch.float32 and x.shape[-1] == 256 and wp.dtype == torch.uint8 and d_ff % 32 == 0
+    assert wp.numel() == ((((d_ff // 32) + 1) & ~1) + int(_lib.lib().dtlr_ffn_split_pad_chunks())) * 65536, "wp is not ffn_split_pack(W1, W2) of this d_ff"
+    x = x if x.is_contiguous() else x.contiguous()
+    y = torch.empty_like(x) if out is None else out
+    assert y.is_contiguous() and y.shape == x.shape and y.dtype == x.dtype
+    M = x.numel() // 256
+    with _Timed("ffn_fused_f32s", 4.0 * M * 256 * d_ff, 2.0 * M * 256 * 4 + 2.0 * 256 * d_ff * 4):
+        code = _lib.lib().dtlr_ffn_split(x.data_ptr(), wp.data_ptr(), b1.data_ptr(), b2.data_ptr(), ln_w.data_ptr(), ln_b.data_ptr(),
+                                         eps, y.data_ptr(), M, d_ff, _lib.current_stream())
+    _lib.check(code, "dtlr_ffn_split")
+    return y
+
+
 def conv2d_nhwc(x, w, bias, stride: int, padding: int, relu=False, residual=None):
     """NHWC convolution + folded-BN bias [+ residual] [+ ReLU].  x [B,H,W,Cin] contiguous.
     w: [Cout,KH,KW,Cin] contiguous ("OHWI") -> the implicit-GEMM HIP kernel (dtlr_conv2d_nhwc), which
@@ -1127,6 +1171,6 @@ def _device_scoped(fn):
 for _name in ("msda_encoder_far_fraction", "gemm_kres", "gemm_kres_chain", "gemm_kres_cat_s2", "gemm_kres_bcast384", "ffn32", "proj_ln_k256", "swin_patch_embed", "swin_window_attn", "swin_patch_merge", "geometry", "linear", "gemm_k256", "linear_rowmax", "two_stage_gather", "layernorm", "proj_ln", "proj_ln_split", "ffn_fused", "conv2d_nhwc", "stem_conv7x7", "stem_conv7x7_f32",
               "maxpool_nhwc", "groupnorm_tokens", "msda", "msda_fused", "msda_encoder", "mha", "decoder_query_prep", "box_mlp_refine",
               "box_head_refine", "box_refine", "topk_rows", "decode_blank", "preprocess_lines", "ctc_loss_interleaved", "nms_batched",
-              "topk_flat", "stem_conv7x7_pool", "dec_query_stage", "blank_emissions", "split_pack", "linear_resbcast"):
+              "topk_flat", "stem_conv7x7_pool", "dec_query_stage", "blank_emissions", "split_pack", "linear_resbcast", "ffn_split"):
     globals()[_name] = _device_scoped(globals()[_name])
 del _name

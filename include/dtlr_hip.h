@@ -116,6 +116,19 @@ int dtlr_layernorm(const void *x, const void *residual, const float *gamma, cons
                    void *y, long rows, int C, float eps, int dtype, void *stream);
 
 /* ---------------------------------------------------------------------------------------------
+ * The same block for the SPLIT-fp32 engine (round 4): X, Y [M, 256] fp32, every product as three fp16 MFMAs on hi + lo halves
+ * (fp32-grade), fp32 residual and LayerNorm, the [M, d_ff] intermediate on chip.
+ * Replaces: forward_ffn + norm2 / norm3 (models/dino/deformable_transformer.py:804-823, 876-880).
+ *   Wp: even(d_ff / 32) + dtlr_ffn_split_pad_chunks() blocks of 64 KB, block c = [W1_hi | W1_lo | W2_hi | W2_lo] of hidden units 32 c .. 32 c + 31,
+ *       each part 16 fragments of 1 KB in the fragment order of dtlr_ffn32_pack_weights; hi = fp16(w), lo = fp16(w - hi); zero blocks
+ *       behind the last real chunk (dtlr_amd.ops.ffn_split_pack builds it).  b1 [d_ff], b2 / gamma / beta [256] fp32.
+ *   d_ff a multiple of 32, 32 <= d_ff <= 2048 (DTLR_ESHAPE otherwise).
+ */
+int dtlr_ffn_split(const void *X, const void *Wp, const float *b1, const float *b2, const float *gamma, const float *beta,
+                   float eps, void *Y, long M, int d_ff, void *stream);
+int dtlr_ffn_split_pad_chunks(void);
+
+/* ---------------------------------------------------------------------------------------------
  * Fused position-wise feed-forward block + residual + LayerNorm, bf16 (fp32 accumulate / statistics):
  *     Y = LayerNorm( X + relu(X W1^T + b1) W2^T + b2 )
  * Replaces: DeformableTransformerEncoderLayer.forward_ffn + norm2

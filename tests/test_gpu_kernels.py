@@ -1406,3 +1406,31 @@ def test_linear_row_broadcast_residual(kind, B, S, N, half):
     if kind != "h16":
         full = ((x + pos).double() @ w.double().t() + b.double()).float()
         assert (got - full).abs().max() < 3e-5 * max(1.0, full.abs().max().item())
+
+
+@pytest.mark.parametrize("M,d_ff", [(128, 2048), (300, 2048), (1000, 512), (4097, 2048), (37, 64), (513, 96), (300, 160), (1, 1024), (174080, 2048), (28800, 2048)])
+def test_ffn_split_vs_fp64(M, d_ff):
+    """dtlr_ffn_split (fused FFN block of the split-fp32 engine) against an fp64 evaluation of LayerNorm(x + relu(x W1^T + b1) W2^T + b2)
+    on the same fp32 operands: fp32-grade (two split GEMMs + an fp32 LayerNorm), for ragged M, a single row, odd chunk counts
+    (d_ff = 96 / 160: one zero chunk is run), the encoder and decoder shapes of the bench; and equal to the unfused split path
+    (two DTLR_F32S GEMMs + dtlr_layernorm) to fp32 rounding."""
+    from dtlr_amd import ops
+    big = M > 20000
+    x = _rand((M, 256), 1, 1.5) + 0.3
+    w1, b1 = _rand((d_ff, 256), 2) / 16.0, _rand((d_ff,), 3) * 0.5
+    w2, b2 = _rand((256, d_ff), 4) / np.sqrt(d_ff), _rand((256,), 5) * 0.3
+    g, be = _rand((256,), 6) * 0.2 + 1.0, _rand((256,), 7) * 0.1
+    wp = ops.ffn_split_pack(w1.cuda(), w2.cuda())
+    xd = x.cuda()
+    got = ops.ffn_split(xd, wp, b1.cuda(), b2.cuda(), g.cuda(), be.cuda()).cpu()
+    assert got.shape == x.shape and torch.isfinite(got).all()
+    rows = torch.arange(0, M, max(1, M // 4000)) if big else torch.arange(M)          # the fp64 reference on a sample of the rows
+    xs = x[rows].double()
+    h = torch.relu(xs @ w1.double().t() + b1.double())
+    want = F.layer_norm(xs + h @ w2.double().t() + b2.double(), (256,), g.double(), be.double(), 1e-5).float()
+    err = (got[rows] - want).abs().max().item()
+    print(f"[ffn_split M{M} d_ff{d_ff}] max err {err:.2e}")
+    assert err < 3e-5 * max(1.0, want.abs().max().item()), err
+    hid = ops.linear(xd, ops.split_pack(w1.cuda()), b1.cuda(), relu=True)
+    unf = ops.layernorm(ops.linear(hid, ops.split_pack(w2.cuda()), b2.cuda()), g.cuda(), be.cuda(), 1e-5, xd).cpu()
+    assert (got - unf).abs().max() < 3e-5 * max(1.0, want.abs().max().item())
