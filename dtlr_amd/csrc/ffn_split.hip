@@ -31,6 +31,17 @@ typedef __attribute__((ext_vector_type(8))) _Float16 fs_f16x8_t;
 typedef __attribute__((ext_vector_type(2))) _Float16 fs_f16x2_t;
 typedef __attribute__((ext_vector_type(16))) float fs_f32x16_t;
 
+// experiment hooks (tools/experiments/ffn_split_bench.py builds this file alone with -DFS_STANDALONE and these): fragment look-ahead in groups,
+// and timing ablations whose results are garbage (1: no weight DMA in the chunk loop, 2: no wait / barrier per chunk, 4: no fragment reads)
+#ifndef FS_LA
+#define FS_LA 2
+#endif
+#ifndef FS_DBG
+#define FS_DBG 0
+#endif
+#ifdef FS_STANDALONE
+thread_local int g_last_hip_error = 0;
+#endif
 constexpr int FS_CHUNK = 65536;                              // W1_hi | W1_lo | W2_hi | W2_lo of one 32-unit chunk: 4 x 16 fragments of 1 KB
 constexpr int FS_IMG = 32768;                                // the W1 (or W2) half of a chunk image: hi fragments, then lo fragments
 constexpr int FS_W2_OFF = 2 * FS_IMG;                        // LDS: W1 ring (2 stages), then W2 ring (2 stages)
@@ -134,15 +145,16 @@ __global__ __launch_bounds__(256, 1) void ffn_split_kernel(
     asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
     {   // ---- prologue: phase A of chunk 0 (W1 ring stage 0) ------------------------------------------------------------------------
-        uint4 fh[3], fl[3];
-        fh[0] = FS_F1(0, 0, 0); fl[0] = FS_F1(0, 0, 1);
-        fh[1] = FS_F1(0, 1, 0); fl[1] = FS_F1(0, 1, 1);
+        constexpr int NB = FS_LA + 1;
+        uint4 fh[NB], fl[NB];
+#pragma unroll
+        for (int g = 0; g < FS_LA; ++g) { fh[g] = FS_F1(0, g, 0); fl[g] = FS_F1(0, g, 1); }
 #pragma unroll
         for (int g = 0; g < 16; ++g) {
-            if (g + 2 < 16) { fh[(g + 2) % 3] = FS_F1(0, g + 2, 0); fl[(g + 2) % 3] = FS_F1(0, g + 2, 1); }
-            he0 = fs_mma(fh[g % 3], xl[g], g == 0 ? zero16 : he0);
-            he0 = fs_mma(fl[g % 3], xh[g], he0);
-            he0 = fs_mma(fh[g % 3], xh[g], he0);
+            if (g + FS_LA < 16) { fh[(g + FS_LA) % NB] = FS_F1(0, g + FS_LA, 0); fl[(g + FS_LA) % NB] = FS_F1(0, g + FS_LA, 1); }
+            he0 = fs_mma(fh[g % NB], xl[g], g == 0 ? zero16 : he0);
+            he0 = fs_mma(fl[g % NB], xh[g], he0);
+            he0 = fs_mma(fh[g % NB], xh[g], he0);
             __builtin_amdgcn_sched_barrier(0);
         }
     }
@@ -153,18 +165,22 @@ __global__ __launch_bounds__(256, 1) void ffn_split_kernel(
         const int st1_ = ((C) + 1) & 1, st2_ = (C) & 1;        /* stages of W1(C + 1) and W2(C); the DMA targets are the OTHER stages */ \
         const float* b1c_ = reinterpret_cast<const float*>(fs_smem + FS_B1_OFF) + (C) * 32 + 4 * hh; \
         float4 bq_[4];                                                                             \
-        uint4 fh[3], fl[3];                                                                        \
-        fh[0] = FS_F1(st1_, 0, 0); fl[0] = FS_F1(st1_, 0, 1);                                      \
-        fh[1] = FS_F1(st1_, 1, 0); fl[1] = FS_F1(st1_, 1, 1);                                      \
+        constexpr int NB = FS_LA + 1;                                                              \
+        uint4 fh[NB], fl[NB];                                                                      \
+        _Pragma("unroll") for (int g = 0; g < FS_LA; ++g) {                                        \
+            if (!(FS_DBG & 4)) { fh[g] = FS_F1(st1_, g, 0); fl[g] = FS_F1(st1_, g, 1); }           \
+            else { fh[g] = xh[g]; fl[g] = xl[g]; }                                                 \
+        }                                                                                          \
         _Pragma("unroll") for (int q = 0; q < 4; ++q) bq_[q] = *reinterpret_cast<const float4*>(b1c_ + 8 * q); \
         _Pragma("unroll") for (int g = 0; g < 32; ++g) {                                           \
-            if (g + 2 < 16) { fh[(g + 2) % 3] = FS_F1(st1_, g + 2, 0); fl[(g + 2) % 3] = FS_F1(st1_, g + 2, 1); } \
-            else if (g + 2 < 32) { fh[(g + 2) % 3] = FS_F2(st2_, g + 2 - 16, 0); fl[(g + 2) % 3] = FS_F2(st2_, g + 2 - 16, 1); } \
+            if (FS_DBG & 4) { if (g + FS_LA < 32) { fh[(g + FS_LA) % NB] = xh[g & 15]; fl[(g + FS_LA) % NB] = xl[g & 15]; } } \
+            else if (g + FS_LA < 16) { fh[(g + FS_LA) % NB] = FS_F1(st1_, g + FS_LA, 0); fl[(g + FS_LA) % NB] = FS_F1(st1_, g + FS_LA, 1); } \
+            else if (g + FS_LA < 32) { fh[(g + FS_LA) % NB] = FS_F2(st2_, g + FS_LA - 16, 0); fl[(g + FS_LA) % NB] = FS_F2(st2_, g + FS_LA - 16, 1); } \
             if (g < 16) {                                                                          \
-                HN = fs_mma(fh[g % 3], xl[g], g == 0 ? zero16 : HN);                               \
-                HN = fs_mma(fl[g % 3], xh[g], HN);                                                 \
-                HN = fs_mma(fh[g % 3], xh[g], HN);                                                 \
-                if (g < 8) FS_PIECE(0, (C) + 2, st2_, g) else FS_PIECE(1, (C) + 1, st1_, g - 8)     \
+                HN = fs_mma(fh[g % NB], xl[g], g == 0 ? zero16 : HN);                              \
+                HN = fs_mma(fl[g % NB], xh[g], HN);                                                \
+                HN = fs_mma(fh[g % NB], xh[g], HN);                                                \
+                if (!(FS_DBG & 1)) { if (g < 8) FS_PIECE(0, (C) + 2, st2_, g) else FS_PIECE(1, (C) + 1, st1_, g - 8) } \
                 if (g >= 2 && g < 10 && (g & 1) == 0) {        /* H epilogue slice q: registers 4 q .. 4 q + 3 of HC */ \
                     const int q = (g - 2) >> 1;                                                    \
                     const float v0 = fmaxf(HC[4 * q] + bq_[q].x, 0.f), v1 = fmaxf(HC[4 * q + 1] + bq_[q].y, 0.f); \
@@ -178,14 +194,16 @@ __global__ __launch_bounds__(256, 1) void ffn_split_kernel(
                 }                                                                                  \
             } else {                                                                               \
                 const int ct = (g - 16) & 7, s = (g - 16) >> 3;                                    \
-                yacc[ct] = fs_mma(fh[g % 3], hsl[s], yacc[ct]);                                    \
-                yacc[ct] = fs_mma(fl[g % 3], hsh[s], yacc[ct]);                                    \
-                yacc[ct] = fs_mma(fh[g % 3], hsh[s], yacc[ct]);                                    \
+                yacc[ct] = fs_mma(fh[g % NB], hsl[s], yacc[ct]);                                   \
+                yacc[ct] = fs_mma(fl[g % NB], hsh[s], yacc[ct]);                                   \
+                yacc[ct] = fs_mma(fh[g % NB], hsh[s], yacc[ct]);                                   \
             }                                                                                      \
             __builtin_amdgcn_sched_barrier(0);                                                     \
         }                                                                                          \
-        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");                                \
-        __builtin_amdgcn_s_barrier();                                                              \
+        if (!(FS_DBG & 2)) {                                                                       \
+            asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");                            \
+            __builtin_amdgcn_s_barrier();                                                          \
+        }                                                                                          \
     }
     for (int c = 0; c < nc2; c += 2) {
         FS_ITER(c, he0, he1)

@@ -820,8 +820,10 @@ __global__ __launch_bounds__(512, HAS_A2 ? 2 : 4) void gemm_ws_kernel(
 constexpr int TALL_BM = 256;
 template <int TBN> struct TallCfg { static constexpr int STAGE = (TBN + TALL_BM) * LDS_ROW, NMW = 4 * (TBN / 64), NT = 64 * (NMW + 4); };
 
+// (split operands + the gathering loader need more than 128 VGPRs: two waves per SIMD there -- a spilled staging register of the hand-counted
+// asm loads would be copied before its data lands)
 template <typename T, typename OutT, bool CONV, int CF = -1, int TBN = 64>
-__global__ __launch_bounds__(TallCfg<TBN>::NT, TBN == 64 ? 4 : 1) void gemm_ws_tall_kernel(
+__global__ __launch_bounds__(TallCfg<TBN>::NT, TBN == 64 ? ((kSplit<T> && CONV) ? 2 : 4) : 1) void gemm_ws_tall_kernel(
     const T* __restrict__ A, const T* __restrict__ W, const float* __restrict__ bias, const OutT* __restrict__ residual,
     OutT* __restrict__ C, int M, int N, int K, int flags, int ntilesM, int tiles_per_block, ConvP cp, int round_robin)
 {
@@ -1131,7 +1133,7 @@ static int try_tall(const void* X, const void* W, const float* bias, const void*
     // 16-bit in / out only.  Split-fp32 operands were measured on both tall tiles in round 4 (the kernel bodies take them: the loader's
     // hi / lo conversion and mma_slab are in place): FFN linear1 720 -> 697 us, linear2 569 -> 590 us, value_proj of all decoder layers
     // (N = 1536, K = 256) 551 -> 985 us, the 256 -> 64 reductions 176 -> 173 us -- no gain, one large loss: they stay on 128 x 128 tiles.
-    if constexpr (!(sizeof(T) == 2 && sizeof(OutT) == 2)) return DTLR_OK;
+    if constexpr (!(sizeof(T) == 2 && sizeof(OutT) == 2) && !(kSplit<T> && CONV && sizeof(OutT) == 4)) return DTLR_OK;
     else {
         if (!use_tall() || (N & 3) || (flags & ~(EPI_BIAS | EPI_RELU | EPI_RELU_POST | EPI_RESIDUAL | EPI_GELU))) return DTLR_OK;
         const int nM = (M + TALL_BM - 1) / TALL_BM;
@@ -1139,12 +1141,11 @@ static int try_tall(const void* X, const void* W, const float* bias, const void*
         if (N <= 64) {
             if (M < 64 * TALL_BM) return DTLR_OK;
             if constexpr (kSplit<T>) {
-                // split operands: only the instantiations that fit 128 VGPRs without spilling (tools/resource_usage.py) -- the gathering (CONV)
-                // loader plus the hi / lo conversion does not, and a spilled staging register of the hand-counted asm loads would be
-                // copied before its data lands; those shapes stay on the 128 x 128 kernel
-                if (CONV || !(flags == (EPI_BIAS | EPI_RELU_POST) || flags == EPI_BIAS)) return DTLR_OK;
+                // split operands: the 64-channel 3x3 convolutions of layer1 only (at 128 x 128 tiles half of their MFMA work multiplies
+                // duplicated weight rows: 232 us per launch at B = 32), specialised epilogues only
+                if (!CONV || !(flags == (EPI_BIAS | EPI_RELU_POST) || flags == EPI_BIAS)) return DTLR_OK;
             }
-            if constexpr (!(kSplit<T> && CONV)) {
+            {
             const long target = 2 * 256 * 2;
             int per = (int)((nM + target - 1) / target);
             if (per < 1) per = 1;
@@ -1165,6 +1166,8 @@ static int try_tall(const void* X, const void* W, const float* bias, const void*
             return check_launch();
             }
         }
+        if constexpr (kSplit<T>) return DTLR_OK;
+        else {
         // 256 x 128 tiles: enough tiles to occupy the chip (one workgroup per CU), K deep enough that operand delivery is the limit
         const int nN = N / 128;
         // measured (profile_ops, same box): the plain K >= 512 projections over >= 32768 rows gain 8-16%; the implicit-GEMM convolutions
@@ -1191,6 +1194,7 @@ static int try_tall(const void* X, const void* W, const float* bias, const void*
 #undef TALL_LAUNCH
             done = true;
             return check_launch();
+        }
         }
     }
 }
