@@ -783,7 +783,7 @@ class DTLREngine:
         """forward + blank decode of ONE canvas shape captured in a HIP graph (torch.cuda.CUDAGraph): returns `replay(x, mask) ->
         (labels [B, nq] int32, lengths [B] int32, out dict)` whose tensors are the graph's static outputs (valid until the next replay).
         At 32 lines per step the forward is GPU-bound and a graph buys nothing (round 1: 11.50 against 11.44 ms); at the reference's
-        evaluation batch of ONE line (/root/reference/evaluation.py:494-499) the ~200 launches of a step are launch-bound -- 2.8 ms eager
+        evaluation batch of ONE line (the reference's evaluation.py:494-499) the ~200 launches of a step are launch-bound -- 2.8 ms eager
         -- and the replay removes the host from the loop.  Shape-specific: the engine's per-shape state (geometry cache, MSDA kernel
         choice) is settled by the warm-up forwards before the capture; a different canvas shape needs its own capture."""
         from .evaluation import decode_blank_records
