@@ -77,6 +77,7 @@ class DTLREngine:
         self.use_l1_chain_out = True      #         ... including the last tail -> layer2.0.conv1
         self.use_l2_cat = True            # 16-bit: layer2.0's strided shortcut convolution as extra K columns of its tail GEMM
         self.use_ow_resbcast = True       # fp32 / split: the encoder's [offsets | logits] projection as src W^T + (pos W^T + b), unpadded batches
+        self._range_check_pending = (dtype == torch.float16) or self.split      # engines whose operands are fp16: see forward()
 
     # ------------------------------------------------------------------------------ packing
     def _put(self, name, t, dtype=None):
@@ -825,6 +826,15 @@ class DTLREngine:
         cfg = self.cfg
         B = x.shape[0]
         feats, last, level_hw = self.features(x)
+        if self._range_check_pending:
+            # fp16 storage / split fp16 operands saturate at 65504 (the conversions do not clamp: a larger backbone activation becomes inf and
+            # poisons a whole GroupNorm group).  No trained checkpoint ships with the reference, so the range assumption is CHECKED on the
+            # first forward of an engine instead of trusted: one host read, once.
+            self._range_check_pending = False
+            peak = max(float(f.float().abs().max()) for f in list(feats) + [last])
+            if not (peak < 6.0e4):
+                raise RuntimeError(f"DTLREngine({'f32s' if self.split else 'float16'}): backbone activations reach {peak:.3g}, beyond fp16's range "
+                                   "(65504) -- run this checkpoint on the bfloat16 or the exact float32 engine")
         g = self.geometry_for(x, mask, level_hw, has_padding)
         src = self.tokens(feats, last, level_hw)
         if self.msda_auto and self.use_lds_msda and ("enc0.attn", tuple((int(h), int(w)) for h, w in level_hw)) not in self._msda_state:

@@ -9,8 +9,8 @@ mkdir -p $D
 export TMPDIR=/tmp
 for C in FETCH_SIZE WRITE_SIZE; do
   ( cd /tmp && timeout 400 rocprofv3 --kernel-trace --pmc $C -d $D/$C -o pmc -- python $R/tools/pmc_traffic.py workload $D/order.json 2>&1 | tail -2 )
-  python tools/rocprof_summary.py $D/$C gpurun_out/r03_pmc_${C}_step_$TAG --keep > /dev/null 2>&1
+  python tools/rocprof_summary.py $D/$C gpurun_out/r04_pmc_${C}_step_$TAG --keep > /dev/null 2>&1
 done
-python tools/pmc_traffic.py reduce $D/FETCH_SIZE $D/WRITE_SIZE $D/order.json gpurun_out/r03_step_${TAG}_traffic.json
-cp $D/order.json gpurun_out/r03_pmc_order_$TAG.json
+python tools/pmc_traffic.py reduce $D/FETCH_SIZE $D/WRITE_SIZE $D/order.json gpurun_out/r04_step_${TAG}_traffic.json
+cp $D/order.json gpurun_out/r04_pmc_order_$TAG.json
 rm -rf $D
