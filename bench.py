@@ -570,22 +570,6 @@ def main():
         line["latency_ms_bs1"] = round(lat[1], 3)
         line["latency_ms_by_batch"] = {str(k): round(v, 3) for k, v in lat.items()}
         log(f"single-line latency: {lat}")
-        try:                                                    # the same single line as a HIP-graph replay (DTLREngine.graphed_step): no host launches
-            rp = eng.graphed_step(x[:1].contiguous(), mask[:1].contiguous(), has_padding=padded)
-            lab_g, ln_g, _ = rp()
-            lab_e, ln_e = local_step(x[:1].contiguous(), mask[:1].contiguous())
-            torch.cuda.synchronize()
-            same = bool(torch.equal(lab_g, lab_e) and torch.equal(ln_g, ln_e))
-            t0 = time.perf_counter()
-            for _ in range(50):
-                rp()
-            torch.cuda.synchronize()
-            line["latency_ms_bs1_graph"] = round((time.perf_counter() - t0) / 50 * 1e3, 3)
-            line["latency_bs1_graph_equals_eager"] = same
-            log(f"single-line latency, HIP-graph replay: {line['latency_ms_bs1_graph']} ms (records equal eager: {same})")
-            del rp
-        except Exception as e:
-            line["latency_ms_bs1_graph"] = {"error": repr(e)[:300]}
     rows = sorted({int(round(i * (B - 1) / max(args.parity_lines - 1, 1))) for i in range(min(args.parity_lines, B))})
     if not args.no_parity:
         try:

@@ -778,44 +778,6 @@ class DTLREngine:
         out["dn_meta"] = None
         return out
 
-    # ------------------------------------------------------------------------------ HIP-graph replay of a fixed shape
-    @torch.no_grad()
-    def graphed_step(self, x: torch.Tensor, mask: torch.Tensor, has_padding: bool = True, decode_eps: Optional[float] = None):
-        """forward + blank decode of ONE canvas shape captured in a HIP graph (torch.cuda.CUDAGraph): returns `replay(x, mask) ->
-        (labels [B, nq] int32, lengths [B] int32, out dict)` whose tensors are the graph's static outputs (valid until the next replay).
-        At 32 lines per step the forward is GPU-bound and a graph buys nothing (round 1: 11.50 against 11.44 ms); at the reference's
-        evaluation batch of ONE line (the reference's evaluation.py:494-499) the ~200 launches of a step are launch-bound -- 2.8 ms eager
-        -- and the replay removes the host from the loop.  Shape-specific: the engine's per-shape state (geometry cache, MSDA kernel
-        choice) is settled by the warm-up forwards before the capture; a different canvas shape needs its own capture."""
-        from .evaluation import decode_blank_records
-        sx, sm = x.clone(), mask.clone()
-
-        def step():
-            out = self.forward(sx, sm, has_padding=has_padding)
-            lab, ln = decode_blank_records(out, decode_eps)
-            return lab, ln, out
-        side = torch.cuda.Stream(device=self.device)
-        side.wait_stream(torch.cuda.current_stream(self.device))
-        with torch.cuda.stream(side):
-            for _ in range(3):                                  # calibration, caches and lazily packed weights happen here, outside the capture
-                step()
-        torch.cuda.current_stream(self.device).wait_stream(side)
-        graph = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(graph):
-            res = step()
-
-        def replay(x_new: Optional[torch.Tensor] = None, mask_new: Optional[torch.Tensor] = None):
-            if x_new is not None:
-                if x_new.shape != sx.shape:
-                    raise ValueError(f"graphed_step: captured for {tuple(sx.shape)}, got {tuple(x_new.shape)}")
-                sx.copy_(x_new)
-            if mask_new is not None:
-                sm.copy_(mask_new)
-            graph.replay()
-            return res
-        replay.graph = graph
-        return replay
-
     # ------------------------------------------------------------------------------ forward
     @torch.no_grad()
     def forward(self, x: torch.Tensor, mask: torch.Tensor, forced_topk: Optional[torch.Tensor] = None,
