@@ -1133,7 +1133,7 @@ static int try_tall(const void* X, const void* W, const float* bias, const void*
     // 16-bit in / out only.  Split-fp32 operands were measured on both tall tiles in round 4 (the kernel bodies take them: the loader's
     // hi / lo conversion and mma_slab are in place): FFN linear1 720 -> 697 us, linear2 569 -> 590 us, value_proj of all decoder layers
     // (N = 1536, K = 256) 551 -> 985 us, the 256 -> 64 reductions 176 -> 173 us -- no gain, one large loss: they stay on 128 x 128 tiles.
-    if constexpr (!(sizeof(T) == 2 && sizeof(OutT) == 2) && !(kSplit<T> && CONV && sizeof(OutT) == 4)) return DTLR_OK;
+    if constexpr (!(sizeof(T) == 2 && sizeof(OutT) == 2)) return DTLR_OK;       // (... incl. the 64-channel 3x3 convolutions on the 256 x 64 tile: 232 -> 228 us)
     else {
         if (!use_tall() || (N & 3) || (flags & ~(EPI_BIAS | EPI_RELU | EPI_RELU_POST | EPI_RESIDUAL | EPI_GELU))) return DTLR_OK;
         const int nM = (M + TALL_BM - 1) / TALL_BM;
