@@ -132,6 +132,134 @@ __global__ __launch_bounds__(512, 2) void stem_conv7x7_kernel(const float* __res
 }
 
 
+// ---- the same convolution for the SPLIT-fp32 engine (round 4): fp32 image, fp32 output, every product as three fp16 MFMAs on hi + lo halves ----
+// The exact-fp32 stem (stem_conv7x7_f32_kernel: a direct convolution on the VALU) takes 0.88 ms of the split engine's 23.7 ms step.  This is
+// stem_conv7x7_kernel's formulation with both operands split: the staged input rows exist twice in LDS (an fp16 hi plane and an fp16 lo plane
+// of x - hi: same shifted layout, so tile t's B-fragment is the same compile-time dword window of two aligned 16-byte reads in either plane),
+// and the 24 weight fragments exist twice (hi, lo) -- 48 KB, kept in LDS instead of registers (48 fragments would be 192 VGPRs):
+//     acc += W_hi . x_lo + W_lo . x_hi + W_hi . x_hi          per (k-step, channel tile, pixel tile): 3 MFMAs, 288 per (row, 64-column strip) unit.
+// LDS: 2 x 49,920 (planes) + 2 x 24,576 (weights) = 148,992 bytes: one workgroup per CU.  Output fp32 NHWC (the folded-BN shift, ReLU and
+// max-pool follow in maxpool3x3s2, as for the exact engine).
+typedef __attribute__((ext_vector_type(8))) _Float16 stem_f16x8_t;
+typedef __attribute__((ext_vector_type(2))) _Float16 stem_f16x2_t;
+constexpr int STEMS_PLANE = 3 * STEM_IN_ROWS * STEM_PITCH * 2;      // 49,920 B
+constexpr int STEMS_WOFF = 2 * STEMS_PLANE;
+constexpr int STEMS_LDS = STEMS_WOFF + 2 * 24576;
+__device__ __forceinline__ stem_f32x4_t stems_mma(const uint4& a, uint32_t b0, uint32_t b1, uint32_t b2, uint32_t b3, stem_f32x4_t c) {
+    const uint4 b = make_uint4(b0, b1, b2, b3);
+    return __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(stem_f16x8_t, a), __builtin_bit_cast(stem_f16x8_t, b), c, 0, 0, 0);
+}
+
+// x [B,3,H,W] fp32 ; wfrag_hi / wfrag_lo [4][6][64][8] fp16 (dtlr_stem_pack_weights of the fp16 build applied to fp16(w) and to w - fp16(w)) ; y [B,Ho,Wo,64] fp32
+__global__ __launch_bounds__(512, 1) void stem_conv7x7_f32s_kernel(const float* __restrict__ x, const uint16_t* __restrict__ wfrag_hi,
+                                                                   const uint16_t* __restrict__ wfrag_lo, float* __restrict__ y,
+                                                                   int H, int W, int Ho, int Wo)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_stem[];
+    uint16_t* img_hi = reinterpret_cast<uint16_t*>(smem_stem);
+    uint16_t* img_lo = reinterpret_cast<uint16_t*>(smem_stem + STEMS_PLANE);
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int n = lane & 15, g = lane >> 4;
+    const int ow_b0 = blockIdx.x * STEM_COLS, oh0 = blockIdx.y * STEM_ROWS, b = blockIdx.z;
+    const int ir0 = 2 * oh0 - 3, ic0 = 2 * ow_b0 - 3;
+
+    // ---- stage 3 x 13 input rows x 520 columns as fp16 hi / lo pairs (zero outside the image); all loads before the first conversion ----
+    const float* xb = x + (long)b * 3 * H * W;
+    constexpr int NP = 3 * STEM_IN_ROWS * (STEM_IN_COLS / 2);
+    constexpr int NIT = (NP + 511) / 512;
+    float v0[NIT], v1[NIT];
+#pragma unroll
+    for (int it = 0; it < NIT; ++it) {
+        const int p = min((int)threadIdx.x + 512 * it, NP - 1);
+        const int row = p / (STEM_IN_COLS / 2), cc = (p % (STEM_IN_COLS / 2)) * 2;
+        const int ci = row / STEM_IN_ROWS, ir = ir0 + row % STEM_IN_ROWS, ic = ic0 + cc;
+        const float* src = xb + ((long)ci * H + min(max(ir, 0), H - 1)) * W;
+        const float a0 = src[min(max(ic, 0), W - 1)], a1 = src[min(max(ic + 1, 0), W - 1)];
+        const bool rok = ir >= 0 && ir < H;
+        v0[it] = (rok && ic >= 0 && ic < W) ? a0 : 0.f;
+        v1[it] = (rok && ic + 1 >= 0 && ic + 1 < W) ? a1 : 0.f;
+    }
+#pragma unroll
+    for (int it = 0; it < NIT; ++it) {
+        const int p = (int)threadIdx.x + 512 * it;
+        if (p < NP) {
+            const int row = p / (STEM_IN_COLS / 2), cc = (p % (STEM_IN_COLS / 2)) * 2;
+            const stem_f16x2_t hi = __builtin_convertvector(f32x2_hw_t{v0[it], v1[it]}, stem_f16x2_t);
+            const stem_f16x2_t lo = __builtin_convertvector(f32x2_hw_t{v0[it] - (float)hi[0], v1[it] - (float)hi[1]}, stem_f16x2_t);
+            *reinterpret_cast<uint32_t*>(img_hi + row * STEM_PITCH + cc) = __builtin_bit_cast(uint32_t, hi);
+            *reinterpret_cast<uint32_t*>(img_lo + row * STEM_PITCH + cc) = __builtin_bit_cast(uint32_t, lo);
+        }
+    }
+    // ---- weights: 2 x 24 fragments of 1 KB -> LDS (1536 x 16 bytes per image, 3 per thread) ----
+    {
+        uint4* wl = reinterpret_cast<uint4*>(smem_stem + STEMS_WOFF);
+        const uint4* gh = reinterpret_cast<const uint4*>(wfrag_hi);
+        const uint4* gl = reinterpret_cast<const uint4*>(wfrag_lo);
+#pragma unroll
+        for (int it = 0; it < 3; ++it) {
+            const int i = (int)threadIdx.x + 512 * it;
+            wl[i] = gh[i];
+            wl[1536 + i] = gl[i];
+        }
+    }
+    __syncthreads();
+
+    int rowoff[6];
+#pragma unroll
+    for (int ks = 0; ks < 6; ++ks) {
+        const int pair = min(4 * ks + g, 20);
+        rowoff[ks] = ((pair / 7) * STEM_IN_ROWS + pair % 7) * STEM_PITCH;
+    }
+    const unsigned char* wfl = smem_stem + STEMS_WOFF + lane * 16;
+    for (int u = wave; u < STEM_ROWS * (STEM_COLS / 64); u += 8) {
+        const int ro = u >> 2, s = u & 3;
+        const int oh = oh0 + ro;
+        if (oh >= Ho) continue;                                 // wave-uniform
+        stem_f32x4_t acc[4][4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int t = 0; t < 4; ++t) acc[i][t] = stem_f32x4_t{0.f, 0.f, 0.f, 0.f};
+        const int boff = 2 * ro * STEM_PITCH + (16 * s + n) * 8;
+#pragma unroll
+        for (int ks = 0; ks < 6; ++ks) {
+            const uint4 h0 = *reinterpret_cast<const uint4*>(img_hi + boff + rowoff[ks]);
+            const uint4 h1 = *reinterpret_cast<const uint4*>(img_hi + boff + rowoff[ks] + 8);
+            const uint4 l0 = *reinterpret_cast<const uint4*>(img_lo + boff + rowoff[ks]);
+            const uint4 l1 = *reinterpret_cast<const uint4*>(img_lo + boff + rowoff[ks] + 8);
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const uint4 wh = *reinterpret_cast<const uint4*>(wfl + (i * 6 + ks) * 1024);
+                const uint4 wl = *reinterpret_cast<const uint4*>(wfl + 24576 + (i * 6 + ks) * 1024);
+                acc[i][0] = stems_mma(wh, l0.x, l0.y, l0.z, l0.w, acc[i][0]);
+                acc[i][1] = stems_mma(wh, l0.y, l0.z, l0.w, l1.x, acc[i][1]);
+                acc[i][2] = stems_mma(wh, l0.z, l0.w, l1.x, l1.y, acc[i][2]);
+                acc[i][3] = stems_mma(wh, l0.w, l1.x, l1.y, l1.z, acc[i][3]);
+                acc[i][0] = stems_mma(wl, h0.x, h0.y, h0.z, h0.w, acc[i][0]);
+                acc[i][1] = stems_mma(wl, h0.y, h0.z, h0.w, h1.x, acc[i][1]);
+                acc[i][2] = stems_mma(wl, h0.z, h0.w, h1.x, h1.y, acc[i][2]);
+                acc[i][3] = stems_mma(wl, h0.w, h1.x, h1.y, h1.z, acc[i][3]);
+                acc[i][0] = stems_mma(wh, h0.x, h0.y, h0.z, h0.w, acc[i][0]);
+                acc[i][1] = stems_mma(wh, h0.y, h0.z, h0.w, h1.x, acc[i][1]);
+                acc[i][2] = stems_mma(wh, h0.z, h0.w, h1.x, h1.y, acc[i][2]);
+                acc[i][3] = stems_mma(wh, h0.w, h1.x, h1.y, h1.z, acc[i][3]);
+            }
+        }
+        // ---- store: lane (n, g) holds channels 16 i + 4 g + r of pixel 64 s + 4 n + t: 16 bytes per (i, t) ----
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+            const int ow = ow_b0 + 64 * s + 4 * n + t;
+            if (ow < Wo) {
+                float* dst = y + (((long)b * Ho + oh) * Wo + ow) * 64 + 4 * g;
+#pragma unroll
+                for (int i = 0; i < 4; ++i)
+                    *reinterpret_cast<float4*>(dst + 16 * i) = make_float4(acc[i][t][0], acc[i][t][1], acc[i][t][2], acc[i][t][3]);
+            }
+        }
+    }
+}
+
+
 // ---- stem convolution + folded-BN shift + ReLU + 3x3 / stride-2 max-pool in ONE kernel (round 3) ------------------------------------------
 // torchvision resnet50: conv1 -> bn1 -> relu -> maxpool (models/dino/backbone.py:97-106).  As two kernels the 64-channel full-resolution
 // map (268 MB for 32 lines of 128 x 2048) is written by the convolution and read back by the pooling pass; here it never leaves the CU:
@@ -371,6 +499,21 @@ extern "C" int dtlr_stem_conv7x7_f32(const float* x, const float* wk, float* y, 
     const dim3 grid((Wo + SF_COLS - 1) / SF_COLS, (Ho + SF_ROWS - 1) / SF_ROWS, B);
     if (grid.y > 65535u || grid.z > 65535u) return DTLR_ESHAPE;
     hipLaunchKernelGGL(stem_conv7x7_f32_kernel, grid, dim3(256), SF_LDS, (hipStream_t)stream, x, wk, y, H, W, Ho, Wo);
+    return check_launch();
+}
+
+extern "C" int dtlr_stem_conv7x7_f32s(const float* x, const void* wfrag_hi, const void* wfrag_lo, float* y, int B, int H, int W, void* stream)
+{
+    clear_stale_error();
+    if (!x || !wfrag_hi || !wfrag_lo || !y) return DTLR_EINVAL;
+    if (B <= 0 || H <= 0 || W <= 0) return DTLR_EINVAL;
+    const int Ho = (H + 6 - 7) / 2 + 1, Wo = (W + 6 - 7) / 2 + 1;
+    static DevOnce attr;
+    if (attr.first()) { (void)hipFuncSetAttribute((const void*)stem_conv7x7_f32s_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, STEMS_LDS); (void)hipGetLastError(); }
+    const dim3 grid((Wo + STEM_COLS - 1) / STEM_COLS, (Ho + STEM_ROWS - 1) / STEM_ROWS, B);
+    if (grid.y > 65535u || grid.z > 65535u) return DTLR_ESHAPE;
+    hipLaunchKernelGGL(stem_conv7x7_f32s_kernel, grid, dim3(512), STEMS_LDS, (hipStream_t)stream,
+                       x, (const uint16_t*)wfrag_hi, (const uint16_t*)wfrag_lo, y, H, W, Ho, Wo);
     return check_launch();
 }
 

@@ -193,6 +193,9 @@ class DTLREngine:
         self.w["conv1.b"] = b1.to(device=self.device, dtype=torch.float32).contiguous()
         if self.dtype in ops.H16:               # bf16 engine: MFMA stem kernel, weights as a fragment image in registers
             self.w["conv1.frag"] = ops.stem_pack_weights(w1, self.dtype).to(self.device)
+        elif self.split:                               # split engine: the MFMA stem on fp16 hi + lo fragment images
+            fh, fl = ops.stem_pack_weights_split(w1)
+            self.w["conv1.fh"], self.w["conv1.fl"] = fh.to(self.device), fl.to(self.device)
         else:                                          # fp32 engine: exact-fp32 direct-convolution stem kernel, k-major weights
             self.w["conv1.wk"] = ops.stem_pack_weights_f32(w1).to(self.device)
         for li, nblocks in enumerate(cfg.backbone_blocks, start=1):
@@ -379,6 +382,8 @@ class DTLREngine:
         else:
             if "conv1.frag" in self.w:
                 x = ops.stem_conv7x7(x_nchw, self.w["conv1.frag"], self.dtype)
+            elif "conv1.fh" in self.w:
+                x = ops.stem_conv7x7_f32s(x_nchw, self.w["conv1.fh"], self.w["conv1.fl"])
             else:
                 x = ops.stem_conv7x7_f32(x_nchw, self.w["conv1.wk"])
             x = ops.maxpool_nhwc(x, bias=self.w["conv1.b"], relu=True)

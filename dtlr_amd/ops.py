@@ -678,6 +678,28 @@ def stem_conv7x7_f32(x_nchw, wk):
     return y
 
 
+def stem_pack_weights_split(w_oihw):
+    """conv1.weight (FrozenBN scale folded) [64,3,7,7] fp32 -> (hi, lo): two fragment images of dtlr_stem_conv7x7_f32s (fp16, as uint16 CPU
+    tensors): the fp16 build's packer applied to fp16(w) and to w - fp16(w)."""
+    wf = w_oihw.detach().float().cpu()
+    hi = wf.half().float()
+    return stem_pack_weights(hi, torch.float16), stem_pack_weights(wf - hi, torch.float16)
+
+
+def stem_conv7x7_f32s(x_nchw, wfrag_hi, wfrag_lo):
+    """ResNet stem 7x7/s2/p3 convolution 3 -> 64 for the split-fp32 engine (dtlr_stem_conv7x7_f32s: the MFMA formulation of stem_conv7x7
+    with the image and the weights as fp16 hi + lo halves, three MFMAs per product): x [B,3,H,W] fp32 NCHW -> [B,Ho,Wo,64] fp32 NHWC, no bias."""
+    require_cuda(x_nchw, "images")
+    assert x_nchw.dtype == torch.float32 and x_nchw.dim() == 4 and x_nchw.shape[1] == 3
+    assert wfrag_hi.numel() == 4 * 6 * 64 * 8 and wfrag_lo.numel() == wfrag_hi.numel() and wfrag_hi.is_cuda and wfrag_lo.is_cuda
+    x = x_nchw if x_nchw.is_contiguous() else x_nchw.contiguous()
+    B, _, H, W = x.shape
+    y = torch.empty((B, (H - 1) // 2 + 1, (W - 1) // 2 + 1, 64), dtype=torch.float32, device=x.device)
+    code = _lib.lib().dtlr_stem_conv7x7_f32s(x.data_ptr(), wfrag_hi.data_ptr(), wfrag_lo.data_ptr(), y.data_ptr(), B, H, W, _lib.current_stream())
+    _lib.check(code, "dtlr_stem_conv7x7_f32s")
+    return y
+
+
 def stem_conv7x7(x_nchw, wfrag, out_dtype=torch.bfloat16):
     """ResNet stem 7x7/s2/p3 convolution 3 -> 64 on the bf16 MFMA (HIP kernel): x [B,3,H,W] fp32 NCHW -> [B,Ho,Wo,64] bf16
     NHWC, no bias (the max-pool pass applies the folded-BN shift + ReLU)."""
@@ -1171,6 +1193,6 @@ def _device_scoped(fn):
 for _name in ("msda_encoder_far_fraction", "gemm_kres", "gemm_kres_chain", "gemm_kres_cat_s2", "gemm_kres_bcast384", "ffn32", "proj_ln_k256", "swin_patch_embed", "swin_window_attn", "swin_patch_merge", "geometry", "linear", "gemm_k256", "linear_rowmax", "two_stage_gather", "layernorm", "proj_ln", "proj_ln_split", "ffn_fused", "conv2d_nhwc", "stem_conv7x7", "stem_conv7x7_f32",
               "maxpool_nhwc", "groupnorm_tokens", "msda", "msda_fused", "msda_encoder", "mha", "decoder_query_prep", "box_mlp_refine",
               "box_head_refine", "box_refine", "topk_rows", "decode_blank", "preprocess_lines", "ctc_loss_interleaved", "nms_batched",
-              "topk_flat", "stem_conv7x7_pool", "dec_query_stage", "blank_emissions", "split_pack", "linear_resbcast", "ffn_split"):
+              "topk_flat", "stem_conv7x7_pool", "dec_query_stage", "blank_emissions", "split_pack", "linear_resbcast", "ffn_split", "stem_conv7x7_f32s"):
     globals()[_name] = _device_scoped(globals()[_name])
 del _name

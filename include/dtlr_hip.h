@@ -457,6 +457,10 @@ int dtlr_stem_conv7x7_pool(const float *x, const void *wfrag, const float *bias,
 /* The same convolution in exact fp32 (the parity engine; direct convolution on the vector ALUs, patch + weights in LDS).
  *   wk: device [147][64] fp32, k-major image of conv1.weight * bn_scale (k = (ci*7 + kh)*7 + kw) ; y [B,Ho,Wo,64] fp32 NHWC. */
 int dtlr_stem_conv7x7_f32(const float *x, const float *wk, float *y, int B, int H, int W, void *stream);
+/* The same convolution for the split-fp32 engine (round 4): fp32 image and output, the image and the weights as fp16 hi + lo halves, three fp16
+ * MFMAs per product (stem_conv7x7's MFMA formulation; 4x faster than the direct fp32 kernel above).  wfrag_hi / wfrag_lo: the fragment
+ * images dtlr_stem_pack_weights of the fp16 build (libdtlr_hip_f16.so) writes for fp16(w) and for w - fp16(w). */
+int dtlr_stem_conv7x7_f32s(const float *x, const void *wfrag_hi, const void *wfrag_lo, float *y, int B, int H, int W, void *stream);
 
 /* 3x3 / stride 2 / pad 1 max pooling on NHWC, optionally preceded by a per-channel bias and ReLU:
  *     y = maxpool(relu(x + bias))      (bias NULL: no bias; relu 0: no ReLU)

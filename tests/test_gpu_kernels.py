@@ -1434,3 +1434,20 @@ def test_ffn_split_vs_fp64(M, d_ff):
     hid = ops.linear(xd, ops.split_pack(w1.cuda()), b1.cuda(), relu=True)
     unf = ops.layernorm(ops.linear(hid, ops.split_pack(w2.cuda()), b2.cuda()), g.cuda(), be.cuda(), 1e-5, xd).cpu()
     assert (got - unf).abs().max() < 3e-5 * max(1.0, want.abs().max().item())
+
+
+@pytest.mark.parametrize("B,H,W", [(2, 128, 2048), (1, 37, 531), (3, 8, 16), (1, 128, 2560), (2, 83, 1328)])
+def test_stem_conv7x7_split_vs_fp64(B, H, W):
+    """The split-fp32 stem (image and weights as fp16 hi + lo halves, three MFMAs per product) against an fp64 conv2d on the same fp32
+    operands: fp32-grade, for odd sizes, maps narrower than a strip, the eval canvas; and within fp32 rounding of the exact direct kernel."""
+    from dtlr_amd import ops
+    x = _rand((B, 3, H, W), 11)
+    w = _rand((64, 3, 7, 7), 12, 0.1)
+    want = F.conv2d(x.double(), w.double(), None, stride=2, padding=3).permute(0, 2, 3, 1).float()
+    fh, fl = ops.stem_pack_weights_split(w)
+    got = ops.stem_conv7x7_f32s(x.cuda(), fh.cuda(), fl.cuda()).cpu()
+    exact = ops.stem_conv7x7_f32(x.cuda(), ops.stem_pack_weights_f32(w).cuda()).cpu()
+    assert got.shape == want.shape
+    err, err_exact = (got - want).abs().max().item(), (exact - want).abs().max().item()
+    print(f"[split stem {B}x{H}x{W}] max err {err:.2e} (exact-fp32 kernel {err_exact:.2e})")
+    assert err < 2e-5 * max(1.0, want.abs().max().item())
