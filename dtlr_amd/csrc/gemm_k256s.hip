@@ -1,0 +1,255 @@
+// Weight-resident streaming projection for the SPLIT-fp32 engine, K = 256, N = 256 (round 4; dtype DTLR_F32S):
+//
+//     MODE 0:  C[M, 256] = A[M, 256] . W^T + bias,  rows with row_mask != 0 written as zeros      (encoder value_proj: ms_deform_attn.py:94-96)
+//     MODE 1:  C[M, 256] = LayerNorm( R + A . W^T + bias )                                         (output_proj + residual + norm1:
+//                                                                                                   deformable_transformer.py:810-815)
+// every product as three fp16 MFMAs on hi + lo halves (gemm.hip, GT<f32s_t>), fp32 accumulation, fp32 residual and statistics.
+//
+// Why: through the tiled split GEMM these 13 projections per step are HBM streams held at 3.2 TB/s (111 us each at B = 32: eight K slabs, then
+// an epilogue during which the loader waves stall), and MODE 1's LayerNorm is a second pass over the same rows (83 us).  This is gemm_k256.hip's
+// structure for fp32 rows:
+//   * the WEIGHT is resident: wave w of 8 keeps its 32 output channels x 256 k as MFMA A-fragments, hi AND lo (32 fragments = 128 VGPRs), loaded
+//     once per workgroup from the packed image (dtlr_k256s_pack_weights: fragment order, so a wave-load is one contiguous KB);
+//   * TOKENS stream: tiles of 64 tokens x 1 KB are DMA'd global -> LDS (global_load_lds_dwordx4, one row per instruction) into a two-stage
+//     ring; the 16-byte chunks of a row are permuted on the SOURCE side (chunk c of row r lands in slot c ^ (r & 15)) so that the 16 tokens of
+//     a B-fragment read hit 16 distinct bank groups; a lane's B-fragment (8 k of one token) is two ds_read_b128 of raw fp32, split into hi / lo
+//     in registers (20 VALU per fragment, in the shadow of the 6 MFMAs it feeds);
+//   * one barrier per tile; persistent, one workgroup per CU; the accumulators ARE the output slice (C^T layout: a lane holds 4 consecutive
+//     channels of one token): 16-byte fp32 stores;
+//   * MODE 1: the residual is read in the accumulator layout (16 bytes per lane and tile), the row statistics are exchanged between the eight
+//     waves through LDS (two passes: mean, then centred squares -- the fp32 LayerNorm kernels' own arithmetic), one extra barrier pair per tile.
+// HBM-bound by construction: 128 KB (MODE 0) / 192 KB (MODE 1) of traffic per 64-token tile against 192 MFMAs and ~700 VALU per wave.
+#include "dtlr_common.h"
+
+namespace dtlr {
+
+typedef __attribute__((ext_vector_type(8))) _Float16 ks_f16x8_t;
+typedef __attribute__((ext_vector_type(2))) _Float16 ks_f16x2_t;
+typedef __attribute__((ext_vector_type(4))) float ks_f32x4_t;
+
+constexpr int KS_TOK = 64;                        // tokens per tile
+constexpr int KS_STAGE = KS_TOK * 1024;           // 64 KB: 64 fp32 rows of 256
+constexpr int KS_STAT_OFF = 2 * KS_STAGE;         // statistics exchange: [64 tokens][8 waves] floats
+constexpr int KS_LDS = KS_STAT_OFF + KS_TOK * 8 * 4;
+
+__device__ __forceinline__ void ks_glds16(const void* gsrc, unsigned lds_dst) {
+    unsigned keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep) : "v"(gsrc), "s"(lds_dst) : "memory");
+}
+__device__ __forceinline__ ks_f32x4_t ks_mma(const uint4& a, const uint4& b, ks_f32x4_t c) {
+    return __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(ks_f16x8_t, a), __builtin_bit_cast(ks_f16x8_t, b), c, 0, 0, 0);
+}
+__device__ __forceinline__ void ks_split2(float x0, float x1, uint32_t& hi, uint32_t& lo) {
+    const ks_f16x2_t a = __builtin_convertvector(f32x2_hw_t{x0, x1}, ks_f16x2_t);
+    const ks_f16x2_t b = __builtin_convertvector(f32x2_hw_t{x0 - (float)a[0], x1 - (float)a[1]}, ks_f16x2_t);
+    hi = __builtin_bit_cast(uint32_t, a);
+    lo = __builtin_bit_cast(uint32_t, b);
+}
+
+// Wp: [2 parts (hi, lo)][8 waves][2 row tiles][8 k-steps][64 lanes][8 halves]: lane (m = l & 15, g = l >> 4) <- W[32 wave + 16 rt + m][32 ks + 8 g + e]
+template <int MODE>
+__global__ __launch_bounds__(512, 1) void gemm_k256s_kernel(
+    const float* __restrict__ A, const uint16_t* __restrict__ Wp, const float* __restrict__ bias, const float* __restrict__ R,
+    const uint8_t* __restrict__ row_mask, const float* __restrict__ gamma, const float* __restrict__ beta, float eps,
+    float* __restrict__ C, int M, int tiles_per_wg)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char ks_smem[];
+    const unsigned lds_base = (unsigned)(size_t)(__attribute__((address_space(3))) unsigned char*)ks_smem;
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const int n = lane & 15, g = lane >> 4;
+    const int ntiles = (M + KS_TOK - 1) / KS_TOK;
+    const int t_begin = (int)blockIdx.x * tiles_per_wg;
+    const int t_end = min(t_begin + tiles_per_wg, ntiles);
+    if (t_begin >= t_end) return;
+
+    // ---- DMA of token tile t into a ring stage: 64 rows of 1 KB, this wave issues rows 8 wave .. 8 wave + 7; lane L fetches source chunk
+    //      L ^ (row & 15), which lands in slot L of the row's LDS image
+    auto issue = [&](int t, int stage) {
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const int row = 8 * wave + u;
+            const long tok = min((long)t * KS_TOK + row, (long)M - 1);
+            ks_glds16(A + tok * 256 + ((lane ^ (row & 15)) * 4), lds_base + (unsigned)(stage * KS_STAGE + row * 1024));
+        }
+    };
+    issue(t_begin, 0);
+
+    // ---- the resident operand: this wave's 32 channels x 256 k, hi and lo fragments
+    uint4 wh[2][8], wl[2][8];
+#pragma unroll
+    for (int rt = 0; rt < 2; ++rt)
+#pragma unroll
+        for (int ks = 0; ks < 8; ++ks) {
+            const long f = ((long)(wave * 2 + rt) * 8 + ks) * 64 + lane;
+            wh[rt][ks] = *reinterpret_cast<const uint4*>(Wp + f * 8);
+            wl[rt][ks] = *reinterpret_cast<const uint4*>(Wp + (8L * 2 * 8 * 64 + f) * 8);
+        }
+    float4 bv[2], gv[2], ev[2];
+#pragma unroll
+    for (int rt = 0; rt < 2; ++rt) {
+        const int ch = wave * 32 + rt * 16 + 4 * g;
+        bv[rt] = bias ? *reinterpret_cast<const float4*>(bias + ch) : make_float4(0.f, 0.f, 0.f, 0.f);
+        gv[rt] = MODE == 1 ? *reinterpret_cast<const float4*>(gamma + ch) : make_float4(1.f, 1.f, 1.f, 1.f);
+        ev[rt] = MODE == 1 ? *reinterpret_cast<const float4*>(beta + ch) : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+    float* stat = reinterpret_cast<float*>(ks_smem + KS_STAT_OFF);
+
+    for (int t = t_begin; t < t_end; ++t) {
+        const int st = (t - t_begin) & 1;
+        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");      // tile t has landed (mine); the previous tile's stores are out
+        __builtin_amdgcn_s_barrier();                                    // ... everyone's; every wave has left the other stage
+        if (t + 1 < t_end) issue(t + 1, st ^ 1);
+        const unsigned char* tile = ks_smem + st * KS_STAGE;
+        ks_f32x4_t acc[2][4];
+#pragma unroll
+        for (int rt = 0; rt < 2; ++rt)
+#pragma unroll
+            for (int tt = 0; tt < 4; ++tt) acc[rt][tt] = ks_f32x4_t{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int tt = 0; tt < 4; ++tt) {
+            const int row = 16 * tt + n;                                 // row & 15 == n
+            const unsigned char* rp = tile + row * 1024;
+#pragma unroll
+            for (int ks = 0; ks < 8; ++ks) {
+                const float4 a = *reinterpret_cast<const float4*>(rp + (((8 * ks + 2 * g) ^ n) * 16));
+                const float4 c = *reinterpret_cast<const float4*>(rp + (((8 * ks + 2 * g + 1) ^ n) * 16));
+                uint4 xh, xl;
+                ks_split2(a.x, a.y, xh.x, xl.x); ks_split2(a.z, a.w, xh.y, xl.y);
+                ks_split2(c.x, c.y, xh.z, xl.z); ks_split2(c.z, c.w, xh.w, xl.w);
+#pragma unroll
+                for (int rt = 0; rt < 2; ++rt) {
+                    acc[rt][tt] = ks_mma(wh[rt][ks], xl, acc[rt][tt]);
+                    acc[rt][tt] = ks_mma(wl[rt][ks], xh, acc[rt][tt]);
+                    acc[rt][tt] = ks_mma(wh[rt][ks], xh, acc[rt][tt]);
+                }
+            }
+        }
+        // ---- epilogue: lane (g, n), (rt, tt): channels 32 wave + 16 rt + 4 g .. + 3 of token 64 t + 16 tt + n ----
+        if constexpr (MODE == 0) {
+#pragma unroll
+            for (int tt = 0; tt < 4; ++tt) {
+                const long tok = (long)t * KS_TOK + 16 * tt + n;
+                if (tok < M) {
+                    const bool masked = row_mask && row_mask[tok];
+#pragma unroll
+                    for (int rt = 0; rt < 2; ++rt) {
+                        float4 v = make_float4(acc[rt][tt][0] + bv[rt].x, acc[rt][tt][1] + bv[rt].y, acc[rt][tt][2] + bv[rt].z, acc[rt][tt][3] + bv[rt].w);
+                        if (masked) v = make_float4(0.f, 0.f, 0.f, 0.f);
+                        *reinterpret_cast<float4*>(C + tok * 256 + wave * 32 + rt * 16 + 4 * g) = v;
+                    }
+                }
+            }
+        } else {
+            float v[4][2][4];
+            float ps[4];
+#pragma unroll
+            for (int tt = 0; tt < 4; ++tt) {
+                const long tok = min((long)t * KS_TOK + 16 * tt + n, (long)M - 1);
+                ps[tt] = 0.f;
+#pragma unroll
+                for (int rt = 0; rt < 2; ++rt) {
+                    const float4 r = *reinterpret_cast<const float4*>(R + tok * 256 + wave * 32 + rt * 16 + 4 * g);
+                    v[tt][rt][0] = acc[rt][tt][0] + bv[rt].x + r.x; v[tt][rt][1] = acc[rt][tt][1] + bv[rt].y + r.y;
+                    v[tt][rt][2] = acc[rt][tt][2] + bv[rt].z + r.z; v[tt][rt][3] = acc[rt][tt][3] + bv[rt].w + r.w;
+                    ps[tt] += (v[tt][rt][0] + v[tt][rt][1]) + (v[tt][rt][2] + v[tt][rt][3]);
+                }
+                ps[tt] += __shfl_xor(ps[tt], 16, 64);
+                ps[tt] += __shfl_xor(ps[tt], 32, 64);                    // this wave's 32 channels of token (tt, n)
+                if (g == 0) stat[(16 * tt + n) * 8 + wave] = ps[tt];
+            }
+            __builtin_amdgcn_s_waitcnt(0xc07f);                          // lgkmcnt(0)
+            __builtin_amdgcn_s_barrier();
+            float mean[4], pq[4];
+#pragma unroll
+            for (int tt = 0; tt < 4; ++tt) {
+                const float4 s0 = *reinterpret_cast<const float4*>(stat + (16 * tt + n) * 8), s1 = *reinterpret_cast<const float4*>(stat + (16 * tt + n) * 8 + 4);
+                mean[tt] = (((s0.x + s0.y) + (s0.z + s0.w)) + ((s1.x + s1.y) + (s1.z + s1.w))) * (1.0f / 256.0f);
+                pq[tt] = 0.f;
+#pragma unroll
+                for (int rt = 0; rt < 2; ++rt)
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) { const float d = v[tt][rt][e] - mean[tt]; pq[tt] += d * d; }
+                pq[tt] += __shfl_xor(pq[tt], 16, 64);
+                pq[tt] += __shfl_xor(pq[tt], 32, 64);
+            }
+            __builtin_amdgcn_s_waitcnt(0xc07f);
+            __builtin_amdgcn_s_barrier();                                // every wave has read the sums: the table may be overwritten
+#pragma unroll
+            for (int tt = 0; tt < 4; ++tt)
+                if (g == 0) stat[(16 * tt + n) * 8 + wave] = pq[tt];
+            __builtin_amdgcn_s_waitcnt(0xc07f);
+            __builtin_amdgcn_s_barrier();
+#pragma unroll
+            for (int tt = 0; tt < 4; ++tt) {
+                const float4 s0 = *reinterpret_cast<const float4*>(stat + (16 * tt + n) * 8), s1 = *reinterpret_cast<const float4*>(stat + (16 * tt + n) * 8 + 4);
+                const float var = (((s0.x + s0.y) + (s0.z + s0.w)) + ((s1.x + s1.y) + (s1.z + s1.w))) * (1.0f / 256.0f);
+                const float rstd = rsqrtf(var + eps);
+                const long tok = (long)t * KS_TOK + 16 * tt + n;
+                if (tok < M) {
+#pragma unroll
+                    for (int rt = 0; rt < 2; ++rt)
+                        *reinterpret_cast<float4*>(C + tok * 256 + wave * 32 + rt * 16 + 4 * g) =
+                            make_float4((v[tt][rt][0] - mean[tt]) * rstd * gv[rt].x + ev[rt].x, (v[tt][rt][1] - mean[tt]) * rstd * gv[rt].y + ev[rt].y,
+                                        (v[tt][rt][2] - mean[tt]) * rstd * gv[rt].z + ev[rt].z, (v[tt][rt][3] - mean[tt]) * rstd * gv[rt].w + ev[rt].w);
+                }
+            }
+        }
+    }
+}
+
+// fp32 weight [256, 256] -> the resident-operand image: [hi | lo][wave 8][rt 2][ks 8][lane 64][8 halves]
+__global__ __launch_bounds__(256) void k256s_pack_kernel(const float* __restrict__ w, uint16_t* __restrict__ out)
+{
+    const int i = (int)blockIdx.x * 256 + threadIdx.x;           // one thread per (fragment, lane): 8 x 2 x 8 x 64 = 8192
+    if (i >= 8192) return;
+    const int lane = i & 63, ks = (i >> 6) & 7, rt = (i >> 9) & 1, wave = i >> 10;
+    const int m = lane & 15, g = lane >> 4;
+    const float* src = w + (long)(32 * wave + 16 * rt + m) * 256 + 32 * ks + 8 * g;
+    uint32_t h[4], l[4];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) ks_split2(src[2 * e], src[2 * e + 1], h[e], l[e]);
+    *reinterpret_cast<uint4*>(out + (long)i * 8) = make_uint4(h[0], h[1], h[2], h[3]);
+    *reinterpret_cast<uint4*>(out + (8192L + i) * 8) = make_uint4(l[0], l[1], l[2], l[3]);
+}
+
+}  // namespace dtlr
+
+using namespace dtlr;
+
+extern "C" int dtlr_k256s_pack_weights(const float* w, void* out, void* stream)
+{
+    clear_stale_error();
+    if (!w || !out) return DTLR_EINVAL;
+    hipLaunchKernelGGL(k256s_pack_kernel, dim3(32), dim3(256), 0, (hipStream_t)stream, w, (uint16_t*)out);
+    return check_launch();
+}
+
+// A, C (and R) [M, 256] fp32; Wp = dtlr_k256s_pack_weights(W [256, 256]) (256 KB); bias [256] fp32 or NULL.
+//   R == NULL: C = A W^T + bias, rows with row_mask[m] != 0 (may be NULL) written as zeros.
+//   R != NULL: C = LayerNorm(R + A W^T + bias) with gamma / beta [256] fp32 (row_mask ignored).
+extern "C" int dtlr_gemm_k256s(const float* A, const void* Wp, const float* bias, const float* R, const unsigned char* row_mask,
+                               const float* gamma, const float* beta, float eps, float* C, long M, void* stream)
+{
+    clear_stale_error();
+    if (!A || !Wp || !C) return DTLR_EINVAL;
+    if (M <= 0 || M > 0x7fffffffL) return DTLR_EINVAL;
+    if (R && (!gamma || !beta)) return DTLR_EINVAL;
+    const int ntiles = (int)((M + KS_TOK - 1) / KS_TOK);
+    int nwg = 256;                                               // one workgroup per CU (132 KB of LDS)
+    if (nwg > ntiles) nwg = ntiles;
+    const int per = (ntiles + nwg - 1) / nwg;
+    nwg = (ntiles + per - 1) / per;
+    hipStream_t st = (hipStream_t)stream;
+    if (R) {
+        static DevOnce once;
+        if (once.first()) { (void)hipFuncSetAttribute((const void*)gemm_k256s_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, KS_LDS); (void)hipGetLastError(); }
+        hipLaunchKernelGGL(gemm_k256s_kernel<1>, dim3(nwg), dim3(512), KS_LDS, st, A, (const uint16_t*)Wp, bias, R, (const uint8_t*)nullptr, gamma, beta, eps, C, (int)M, per);
+    } else {
+        static DevOnce once;
+        if (once.first()) { (void)hipFuncSetAttribute((const void*)gemm_k256s_kernel<0>, hipFuncAttributeMaxDynamicSharedMemorySize, KS_LDS); (void)hipGetLastError(); }
+        hipLaunchKernelGGL(gemm_k256s_kernel<0>, dim3(nwg), dim3(512), KS_LDS, st, A, (const uint16_t*)Wp, bias, (const float*)nullptr, row_mask, (const float*)nullptr, (const float*)nullptr, eps, C, (int)M, per);
+    }
+    return check_launch();
+}

@@ -52,6 +52,7 @@ class DTLREngine:
         ops.require_cuda(torch.empty(0, device=self.device))
         self.w: Dict[str, torch.Tensor] = {}
         self._ffn_f32: Dict[str, torch.Tensor] = {}
+        self._k256s_ok = set()                      # split engine: the [256, 256] encoder projections that run through dtlr_gemm_k256s
         self._pack(state_dict)
         self._shape_cache: Dict[tuple, dict] = {}
         self._level_cache: Dict[tuple, tuple] = {}
@@ -59,6 +60,7 @@ class DTLREngine:
         self.use_fused_ffn = True      # bf16: linear1+ReLU+linear2+residual+LayerNorm in one kernel (False: two GEMMs + LN)
         self.use_k256 = True   # bf16: weight-resident streaming kernel for the K = 256 projections over all tokens
         self.use_pln_k256 = True
+        self.use_k256s = True  # split: the same for the [256, 256] encoder projections (value_proj; output_proj + residual + norm1)
         self.use_ffn32 = True
         self.pln_k256_min_rows = 16384
         self.use_kres = True
@@ -99,8 +101,11 @@ class DTLREngine:
         self.w[name + ".b"] = b.to(device=self.device, dtype=torch.float32).contiguous()
 
     def _put_linear(self, name, w, b):
-        if self.split and name.endswith((".ff1", ".ff2")):      # the fused split FFN packs its own image from the fp32 weights
+        if self.split and (name.endswith((".ff1", ".ff2")) or (name.startswith("enc") and name.endswith((".attn.value", ".attn.out")))):
+            # the fused split FFN and the weight-resident K = 256 projections pack their own images from the fp32 weights
             self._ffn_f32[name] = w.to(device=self.device, dtype=torch.float32).contiguous()
+            if not name.endswith((".ff1", ".ff2")) and tuple(w.shape) == (256, 256):
+                self._k256s_ok.add(name)
         self.w[name + ".w"] = self._gw(w)
         self._put(name + ".b", b, torch.float32)          # biases enter the GEMM epilogue in fp32
 
@@ -314,6 +319,8 @@ class DTLREngine:
     def _proj_ln(self, proj, norm, a, residual):
         """output projection of an attention block + residual + post-norm (deformable_transformer.py:810-815, 847-870)."""
         w = self.w
+        if self.split and self.use_k256s and proj in self._k256s_ok and a.shape[-1] == 256 and a.numel() // 256 >= self.pln_k256_min_rows:
+            return ops.gemm_k256s(a, self._k256sw(proj), w[proj + ".b"], residual=residual, ln_w=w[norm + ".w"], ln_b=w[norm + ".b"])
         if self.use_pln_k256 and a.dtype in ops.H16 and a.shape[-1] == 256 and a.numel() // 256 >= self.pln_k256_min_rows:
             if proj + ".wk" not in w:                          # large M (the encoder): weight-resident streaming form
                 w[proj + ".wk"] = ops.proj_ln_k256_pack(w[proj + ".w"])
@@ -464,6 +471,13 @@ class DTLREngine:
         g.update(shapes=shapes, lsi=lsi, has_padding=has_padding, level_hw=level_hw, lds_msda_fits=fits)
         return g
 
+    def _k256sw(self, name):
+        """split engine: the resident-operand image of a [256, 256] projection for dtlr_gemm_k256s, packed once from the fp32 weight."""
+        key = name + ".k256s"
+        if key not in self.w:
+            self.w[key] = ops.k256s_pack(self._ffn_f32.pop(name))
+        return self.w[key]
+
     def _k256w(self, name):
         """fragment-order image of a [N, 256] projection weight for the weight-resident kernel, packed once."""
         key = name + ".k256"
@@ -534,8 +548,12 @@ class DTLREngine:
         S = value_src.shape[1]
         M, L, P = cfg.nheads, cfg.num_feature_levels, n_points
         k256 = self.use_k256 and query.dtype in ops.H16 and C == 256 and Lq == S
+        k256s = self.split and self.use_k256s and C == 256 and Lq == S and (name + ".value") in self._k256s_ok
         if value is None:
-            if k256:
+            if k256s:
+                value = ops.gemm_k256s(value_src, self._k256sw(name + ".value"), self.w[name + ".value.b"],
+                                       row_mask=g["mask_flat"] if g["has_padding"] else None)
+            elif k256:
                 value = ops.gemm_k256(value_src, self._k256w(name + ".value"), 256, self.w[name + ".value.b"],
                                       row_mask=g["mask_flat"] if g["has_padding"] else None)
             else:

@@ -617,6 +617,41 @@ def ffn_split(x, wp, b1, b2, ln_w, ln_b, eps: float = 1e-5, out=None):
     return y
 
 
+def k256s_pack(w):
+    """fp32 [256, 256] weight on the GPU -> the resident-operand image of dtlr_gemm_k256s (int16 [2 x 65536]: hi then lo fp16 halves in MFMA
+    fragment order; dtlr_k256s_pack_weights)."""
+    require_cuda(w, "w")
+    assert tuple(w.shape) == (256, 256)
+    w = w.detach().float().contiguous()
+    out = torch.empty(2 * 65536, dtype=torch.int16, device=w.device)
+    _lib.check(_lib.lib().dtlr_k256s_pack_weights(w.data_ptr(), out.data_ptr(), _lib.current_stream()), "dtlr_k256s_pack_weights")
+    return out
+
+
+def gemm_k256s(x, wp, b, residual=None, row_mask=None, ln_w=None, ln_b=None, eps: float = 1e-5):
+    """The split-fp32 engine's weight-resident streaming K = N = 256 projection (dtlr_gemm_k256s).  x [..., 256] fp32, wp = k256s_pack(W).
+    residual None: x W^T + b with the rows flagged in row_mask (bool [M], optional) written as zeros (value_proj + masked_fill);
+    residual [..., 256] fp32: LayerNorm(residual + x W^T + b) (output_proj + residual + norm1)."""
+    require_cuda(x, "x")
+    assert x.dtype == torch.float32 and x.shape[-1] == 256 and wp.dtype == torch.int16 and wp.numel() == 2 * 65536
+    x = x if x.is_contiguous() else x.contiguous()
+    M = x.numel() // 256
+    y = torch.empty_like(x)
+    if residual is not None:
+        assert residual.dtype == torch.float32 and residual.shape == x.shape and ln_w is not None and ln_b is not None
+        residual = residual if residual.is_contiguous() else residual.contiguous()
+    if row_mask is not None:
+        assert residual is None and row_mask.numel() == M and row_mask.dtype in (torch.bool, torch.uint8)
+        row_mask = row_mask if row_mask.is_contiguous() else row_mask.contiguous()
+    nbytes = float(M) * 256 * 4 * (3 if residual is not None else 2) + 2.0 * 65536 * 2
+    with _Timed("gemm_f32s", 2.0 * M * 256 * 256, nbytes, f"k256s M{M}" + ("+res+ln" if residual is not None else "")):
+        code = _lib.lib().dtlr_gemm_k256s(x.data_ptr(), wp.data_ptr(), 0 if b is None else b.data_ptr(), 0 if residual is None else residual.data_ptr(),
+                                          0 if row_mask is None else row_mask.data_ptr(), 0 if ln_w is None else ln_w.data_ptr(),
+                                          0 if ln_b is None else ln_b.data_ptr(), eps, y.data_ptr(), M, _lib.current_stream())
+    _lib.check(code, "dtlr_gemm_k256s")
+    return y
+
+
 def conv2d_nhwc(x, w, bias, stride: int, padding: int, relu=False, residual=None):
     """NHWC convolution + folded-BN bias [+ residual] [+ ReLU].  x [B,H,W,Cin] contiguous.
     w: [Cout,KH,KW,Cin] contiguous ("OHWI") -> the implicit-GEMM HIP kernel (dtlr_conv2d_nhwc), which
@@ -1193,6 +1228,6 @@ def _device_scoped(fn):
 for _name in ("msda_encoder_far_fraction", "gemm_kres", "gemm_kres_chain", "gemm_kres_cat_s2", "gemm_kres_bcast384", "ffn32", "proj_ln_k256", "swin_patch_embed", "swin_window_attn", "swin_patch_merge", "geometry", "linear", "gemm_k256", "linear_rowmax", "two_stage_gather", "layernorm", "proj_ln", "proj_ln_split", "ffn_fused", "conv2d_nhwc", "stem_conv7x7", "stem_conv7x7_f32",
               "maxpool_nhwc", "groupnorm_tokens", "msda", "msda_fused", "msda_encoder", "mha", "decoder_query_prep", "box_mlp_refine",
               "box_head_refine", "box_refine", "topk_rows", "decode_blank", "preprocess_lines", "ctc_loss_interleaved", "nms_batched",
-              "topk_flat", "stem_conv7x7_pool", "dec_query_stage", "blank_emissions", "split_pack", "linear_resbcast", "ffn_split", "stem_conv7x7_f32s"):
+              "topk_flat", "stem_conv7x7_pool", "dec_query_stage", "blank_emissions", "split_pack", "linear_resbcast", "ffn_split", "stem_conv7x7_f32s", "k256s_pack", "gemm_k256s"):
     globals()[_name] = _device_scoped(globals()[_name])
 del _name

@@ -129,6 +129,19 @@ int dtlr_ffn_split(const void *X, const void *Wp, const float *b1, const float *
 int dtlr_ffn_split_pad_chunks(void);
 
 /* ---------------------------------------------------------------------------------------------
+ * SPLIT-fp32 engine, K = N = 256: the weight-resident streaming projection (round 4).  A, C (and R) [M, 256] fp32.
+ *   R == NULL: C = A W^T + bias, rows with row_mask[m] != 0 (may be NULL) written as zeros.
+ *              Replaces: value = self.value_proj(input_flatten); value.masked_fill(padding_mask, 0) (ops/modules/ms_deform_attn.py:94-96).
+ *   R != NULL: C = LayerNorm(R + A W^T + bias), gamma / beta [256] fp32 (row_mask ignored).
+ *              Replaces: output_proj (ms_deform_attn.py:124) + src = norm1(src + dropout1(src2)) (deformable_transformer.py:810-815).
+ *   Wp = dtlr_k256s_pack_weights(W [256, 256] fp32): 256 KB, fp16 hi then lo halves in MFMA fragment order
+ *        ([8 waves][2 row tiles][8 k-steps][64 lanes][8]: lane (m, g) <- W[32 wave + 16 rt + m][32 ks + 8 g + e]).
+ */
+int dtlr_k256s_pack_weights(const float *w, void *out, void *stream);
+int dtlr_gemm_k256s(const float *A, const void *Wp, const float *bias, const float *R, const unsigned char *row_mask,
+                    const float *gamma, const float *beta, float eps, float *C, long M, void *stream);
+
+/* ---------------------------------------------------------------------------------------------
  * Fused position-wise feed-forward block + residual + LayerNorm, bf16 (fp32 accumulate / statistics):
  *     Y = LayerNorm( X + relu(X W1^T + b1) W2^T + b2 )
  * Replaces: DeformableTransformerEncoderLayer.forward_ffn + norm2

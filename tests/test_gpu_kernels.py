@@ -1451,3 +1451,34 @@ def test_stem_conv7x7_split_vs_fp64(B, H, W):
     err, err_exact = (got - want).abs().max().item(), (exact - want).abs().max().item()
     print(f"[split stem {B}x{H}x{W}] max err {err:.2e} (exact-fp32 kernel {err_exact:.2e})")
     assert err < 2e-5 * max(1.0, want.abs().max().item())
+
+
+@pytest.mark.parametrize("M", [64, 1, 37, 300, 4097, 16384 + 5, 174080])
+@pytest.mark.parametrize("mode", ["value", "proj_ln"])
+def test_gemm_k256s_vs_fp64(M, mode):
+    """dtlr_gemm_k256s (weight-resident streaming projection of the split-fp32 engine) against fp64 on the same fp32 operands, both modes
+    (bias + masked rows; bias + residual + LayerNorm), for a single row, ragged tails, more tiles than workgroups, the bench's token count;
+    and within fp32 rounding of the tiled split GEMM (+ dtlr_layernorm)."""
+    from dtlr_amd import ops
+    x = _rand((M, 256), 21, 1.5) + 0.2
+    w, b = _rand((256, 256), 22) / 16.0, _rand((256,), 23) * 0.5
+    wp = ops.k256s_pack(w.cuda())
+    rows = torch.arange(0, M, max(1, M // 4000))
+    if mode == "value":
+        mask = (torch.arange(M) % 7 == 3) if M > 1 else torch.zeros(1, dtype=torch.bool)
+        got = ops.gemm_k256s(x.cuda(), wp, b.cuda(), row_mask=mask.cuda()).cpu()
+        want = (x[rows].double() @ w.double().t() + b.double()).masked_fill(mask[rows][:, None], 0.0).float()
+        tiled = ops.linear(x.cuda(), ops.split_pack(w.cuda()), b.cuda(), row_mask=mask.cuda()).cpu()
+        nomask = ops.gemm_k256s(x.cuda(), wp, None).cpu()
+        assert (nomask[rows] - (x[rows].double() @ w.double().t()).float()).abs().max() < 2e-5 * max(1.0, want.abs().max().item())
+    else:
+        r = _rand((M, 256), 24, 2.0)
+        g, be = _rand((256,), 25) * 0.2 + 1.0, _rand((256,), 26) * 0.1
+        got = ops.gemm_k256s(x.cuda(), wp, b.cuda(), residual=r.cuda(), ln_w=g.cuda(), ln_b=be.cuda()).cpu()
+        want = F.layer_norm(r[rows].double() + x[rows].double() @ w.double().t() + b.double(), (256,), g.double(), be.double(), 1e-5).float()
+        tiled = ops.layernorm(ops.linear(x.cuda(), ops.split_pack(w.cuda()), b.cuda()), g.cuda(), be.cuda(), 1e-5, r.cuda()).cpu()
+    assert got.shape == x.shape and torch.isfinite(got).all()
+    err = (got[rows] - want).abs().max().item()
+    print(f"[k256s {mode} M{M}] max err {err:.2e}")
+    assert err < 2e-5 * max(1.0, want.abs().max().item()), err
+    assert (got - tiled).abs().max() < 2e-5 * max(1.0, want.abs().max().item())
