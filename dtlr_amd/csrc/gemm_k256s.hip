@@ -10,11 +10,14 @@
 // structure for fp32 rows:
 //   * the WEIGHT is resident: wave w of 8 keeps its 32 output channels x 256 k as MFMA A-fragments, hi AND lo (32 fragments = 128 VGPRs), loaded
 //     once per workgroup from the packed image (dtlr_k256s_pack_weights: fragment order, so a wave-load is one contiguous KB);
-//   * TOKENS stream: tiles of 64 tokens x 1 KB are DMA'd global -> LDS (global_load_lds_dwordx4, one row per instruction) into a two-stage
-//     ring; the 16-byte chunks of a row are permuted on the SOURCE side (chunk c of row r lands in slot c ^ (r & 15)) so that the 16 tokens of
-//     a B-fragment read hit 16 distinct bank groups; a lane's B-fragment (8 k of one token) is two ds_read_b128 of raw fp32, split into hi / lo
-//     in registers (20 VALU per fragment, in the shadow of the 6 MFMAs it feeds);
-//   * one barrier per tile; persistent, one workgroup per CU; the accumulators ARE the output slice (C^T layout: a lane holds 4 consecutive
+//   * TOKENS stream: tiles of 64 tokens x 1 KB are DMA'd global -> LDS (global_load_lds_dwordx4, one row per instruction) into a raw
+//     buffer; the eight waves then split the tile ONCE between them (8 rows each: one ds_read_b128 of 4 fp32, 10 VALU, two ds_write_b64) into
+//     a fragment-ready fp16 image -- per token 512 B of hi halves then 512 B of lo halves, the 16-byte chunks of each part XOR-swizzled by
+//     (token & 15) so that the 16 tokens of a B-fragment read hit 16 distinct bank groups -- and every wave reads its B-fragments (hi, lo:
+//     two ds_read_b128) from that image.  (The first form split in registers from the raw tile: every wave converted ALL 64 tokens, 1024 VALU
+//     per wave and tile, and the kernel ran no faster than the tiled GEMM.)  The next tile's DMA is issued as soon as the raw buffer has
+//     been converted and flies under this tile's MFMAs and stores;
+//   * two barriers per tile; persistent, one workgroup per CU; the accumulators ARE the output slice (C^T layout: a lane holds 4 consecutive
 //     channels of one token): 16-byte fp32 stores;
 //   * MODE 1: the residual is read in the accumulator layout (16 bytes per lane and tile), the row statistics are exchanged between the eight
 //     waves through LDS (two passes: mean, then centred squares -- the fp32 LayerNorm kernels' own arithmetic), one extra barrier pair per tile.
@@ -28,9 +31,11 @@ typedef __attribute__((ext_vector_type(2))) _Float16 ks_f16x2_t;
 typedef __attribute__((ext_vector_type(4))) float ks_f32x4_t;
 
 constexpr int KS_TOK = 64;                        // tokens per tile
-constexpr int KS_STAGE = KS_TOK * 1024;           // 64 KB: 64 fp32 rows of 256
+constexpr int KS_STAGE = KS_TOK * 1024;           // 64 KB: 64 fp32 rows of 256 (raw), and the same size for their hi | lo fp16 image
+constexpr int KS_IMG_OFF = KS_STAGE;
 constexpr int KS_STAT_OFF = 2 * KS_STAGE;         // statistics exchange: [64 tokens][8 waves] floats
-constexpr int KS_LDS = KS_STAT_OFF + KS_TOK * 8 * 4;
+constexpr int KS_PAR_OFF = KS_STAT_OFF + KS_TOK * 8 * 4;   // bias | gamma | beta, [3][256] floats (read in the epilogue: no VGPRs across the MFMAs)
+constexpr int KS_LDS = KS_PAR_OFF + 3 * 256 * 4;
 
 __device__ __forceinline__ void ks_glds16(const void* gsrc, unsigned lds_dst) {
     unsigned keep;
@@ -64,17 +69,16 @@ __global__ __launch_bounds__(512, 1) void gemm_k256s_kernel(
     const int t_end = min(t_begin + tiles_per_wg, ntiles);
     if (t_begin >= t_end) return;
 
-    // ---- DMA of token tile t into a ring stage: 64 rows of 1 KB, this wave issues rows 8 wave .. 8 wave + 7; lane L fetches source chunk
-    //      L ^ (row & 15), which lands in slot L of the row's LDS image
-    auto issue = [&](int t, int stage) {
+    // ---- DMA of token tile t into the raw buffer: 64 rows of 1 KB, this wave issues (and later converts) rows 8 wave .. 8 wave + 7
+    auto issue = [&](int t) {
 #pragma unroll
         for (int u = 0; u < 8; ++u) {
             const int row = 8 * wave + u;
             const long tok = min((long)t * KS_TOK + row, (long)M - 1);
-            ks_glds16(A + tok * 256 + ((lane ^ (row & 15)) * 4), lds_base + (unsigned)(stage * KS_STAGE + row * 1024));
+            ks_glds16(A + tok * 256 + lane * 4, lds_base + (unsigned)(row * 1024));
         }
     };
-    issue(t_begin, 0);
+    issue(t_begin);
 
     // ---- the resident operand: this wave's 32 channels x 256 k, hi and lo fragments
     uint4 wh[2][8], wl[2][8];
@@ -86,22 +90,66 @@ __global__ __launch_bounds__(512, 1) void gemm_k256s_kernel(
             wh[rt][ks] = *reinterpret_cast<const uint4*>(Wp + f * 8);
             wl[rt][ks] = *reinterpret_cast<const uint4*>(Wp + (8L * 2 * 8 * 64 + f) * 8);
         }
-    float4 bv[2], gv[2], ev[2];
+    float* par = reinterpret_cast<float*>(ks_smem + KS_PAR_OFF);
+    if (threadIdx.x < 256) {
+        par[threadIdx.x] = bias ? bias[threadIdx.x] : 0.f;
+        if constexpr (MODE == 1) { par[256 + threadIdx.x] = gamma[threadIdx.x]; par[512 + threadIdx.x] = beta[threadIdx.x]; }
+    }
+    // Pin the resident operands BEFORE the loop: left alone, the compiler waits for these loads lazily at their first use inside the loop
+    // body -- a vmcnt(0) executed every iteration right after the next tile's DMA was issued (the first build: no overlap at all).
+    // An empty asm that "modifies" each register forces the waits here.
 #pragma unroll
     for (int rt = 0; rt < 2; ++rt) {
-        const int ch = wave * 32 + rt * 16 + 4 * g;
-        bv[rt] = bias ? *reinterpret_cast<const float4*>(bias + ch) : make_float4(0.f, 0.f, 0.f, 0.f);
-        gv[rt] = MODE == 1 ? *reinterpret_cast<const float4*>(gamma + ch) : make_float4(1.f, 1.f, 1.f, 1.f);
-        ev[rt] = MODE == 1 ? *reinterpret_cast<const float4*>(beta + ch) : make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+        for (int ks = 0; ks < 8; ++ks) {
+            asm volatile("" : "+v"(wh[rt][ks].x), "+v"(wh[rt][ks].y), "+v"(wh[rt][ks].z), "+v"(wh[rt][ks].w));
+            asm volatile("" : "+v"(wl[rt][ks].x), "+v"(wl[rt][ks].y), "+v"(wl[rt][ks].z), "+v"(wl[rt][ks].w));
+        }
     }
     float* stat = reinterpret_cast<float*>(ks_smem + KS_STAT_OFF);
 
+    int mk[4] = {0, 0, 0, 0};
     for (int t = t_begin; t < t_end; ++t) {
-        const int st = (t - t_begin) & 1;
-        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");      // tile t has landed (mine); the previous tile's stores are out
-        __builtin_amdgcn_s_barrier();                                    // ... everyone's; every wave has left the other stage
-        if (t + 1 < t_end) issue(t + 1, st ^ 1);
-        const unsigned char* tile = ks_smem + st * KS_STAGE;
+        // my rows of tile t have landed.  The counter is in order and the only requests younger than that DMA group are the previous tile's
+        // 8 stores per lane, which stay in flight: vmcnt(8), not a write acknowledgement per tile (first tile: nothing younger, vmcnt(0)).
+        // (A tail tile issues fewer stores, but it is the last of its workgroup: nothing waits after it.)
+        if (t == t_begin) asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+        else              asm volatile("s_waitcnt vmcnt(8) lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();                                    // every wave has finished reading the previous image
+        // ---- split my 8 rows: lane L holds k = 4 L .. 4 L + 3 -> 8 bytes of hi at chunk (L >> 1) ^ (row & 15), half L & 1; lo 512 B further
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const int row = 8 * wave + u;
+            const float4 a = *reinterpret_cast<const float4*>(ks_smem + row * 1024 + lane * 16);
+            uint2 h, l;
+            ks_split2(a.x, a.y, h.x, l.x); ks_split2(a.z, a.w, h.y, l.y);
+            unsigned char* dst = ks_smem + KS_IMG_OFF + row * 1024 + (((lane >> 1) ^ (row & 15)) * 16) + (lane & 1) * 8;
+            *reinterpret_cast<uint2*>(dst) = h;
+            *reinterpret_cast<uint2*>(dst + 512) = l;
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        if constexpr (MODE == 0) {
+            if (row_mask) {                                              // padded batch: this tile's flags, pinned BEFORE the DMA issue (a
+#pragma unroll                                                           // wait after it would drain the DMA; this one drains the stores)
+                for (int tt = 0; tt < 4; ++tt) {
+                    mk[tt] = row_mask[min((long)t * KS_TOK + 16 * tt + n, (long)M - 1)];
+                }
+#pragma unroll
+                for (int tt = 0; tt < 4; ++tt) asm volatile("" : "+v"(mk[tt]));
+            }
+        }
+        __builtin_amdgcn_s_barrier();                                    // the image is complete; the raw buffer is free
+        if (t + 1 < t_end) issue(t + 1);
+        float4 rr[4][2];
+        if constexpr (MODE == 1) {                                       // this tile's residual rows, in the accumulator layout: requested here,
+#pragma unroll                                                           // consumed in the epilogue (the MFMA phase hides them)
+            for (int tt = 0; tt < 4; ++tt) {
+                const long tok = min((long)t * KS_TOK + 16 * tt + n, (long)M - 1);
+#pragma unroll
+                for (int rt = 0; rt < 2; ++rt) rr[tt][rt] = *reinterpret_cast<const float4*>(R + tok * 256 + wave * 32 + rt * 16 + 4 * g);
+            }
+        }
+        const unsigned char* tile = ks_smem + KS_IMG_OFF;
         ks_f32x4_t acc[2][4];
 #pragma unroll
         for (int rt = 0; rt < 2; ++rt)
@@ -113,11 +161,8 @@ __global__ __launch_bounds__(512, 1) void gemm_k256s_kernel(
             const unsigned char* rp = tile + row * 1024;
 #pragma unroll
             for (int ks = 0; ks < 8; ++ks) {
-                const float4 a = *reinterpret_cast<const float4*>(rp + (((8 * ks + 2 * g) ^ n) * 16));
-                const float4 c = *reinterpret_cast<const float4*>(rp + (((8 * ks + 2 * g + 1) ^ n) * 16));
-                uint4 xh, xl;
-                ks_split2(a.x, a.y, xh.x, xl.x); ks_split2(a.z, a.w, xh.y, xl.y);
-                ks_split2(c.x, c.y, xh.z, xl.z); ks_split2(c.z, c.w, xh.w, xl.w);
+                const uint4 xh = *reinterpret_cast<const uint4*>(rp + (((4 * ks + g) ^ n) * 16));
+                const uint4 xl = *reinterpret_cast<const uint4*>(rp + 512 + (((4 * ks + g) ^ n) * 16));
 #pragma unroll
                 for (int rt = 0; rt < 2; ++rt) {
                     acc[rt][tt] = ks_mma(wh[rt][ks], xl, acc[rt][tt]);
@@ -127,12 +172,15 @@ __global__ __launch_bounds__(512, 1) void gemm_k256s_kernel(
             }
         }
         // ---- epilogue: lane (g, n), (rt, tt): channels 32 wave + 16 rt + 4 g .. + 3 of token 64 t + 16 tt + n ----
+        float4 bv[2];
+#pragma unroll
+        for (int rt = 0; rt < 2; ++rt) bv[rt] = *reinterpret_cast<const float4*>(par + wave * 32 + rt * 16 + 4 * g);
         if constexpr (MODE == 0) {
 #pragma unroll
             for (int tt = 0; tt < 4; ++tt) {
                 const long tok = (long)t * KS_TOK + 16 * tt + n;
                 if (tok < M) {
-                    const bool masked = row_mask && row_mask[tok];
+                    const bool masked = mk[tt] != 0;
 #pragma unroll
                     for (int rt = 0; rt < 2; ++rt) {
                         float4 v = make_float4(acc[rt][tt][0] + bv[rt].x, acc[rt][tt][1] + bv[rt].y, acc[rt][tt][2] + bv[rt].z, acc[rt][tt][3] + bv[rt].w);
@@ -146,11 +194,10 @@ __global__ __launch_bounds__(512, 1) void gemm_k256s_kernel(
             float ps[4];
 #pragma unroll
             for (int tt = 0; tt < 4; ++tt) {
-                const long tok = min((long)t * KS_TOK + 16 * tt + n, (long)M - 1);
                 ps[tt] = 0.f;
 #pragma unroll
                 for (int rt = 0; rt < 2; ++rt) {
-                    const float4 r = *reinterpret_cast<const float4*>(R + tok * 256 + wave * 32 + rt * 16 + 4 * g);
+                    const float4 r = rr[tt][rt];
                     v[tt][rt][0] = acc[rt][tt][0] + bv[rt].x + r.x; v[tt][rt][1] = acc[rt][tt][1] + bv[rt].y + r.y;
                     v[tt][rt][2] = acc[rt][tt][2] + bv[rt].z + r.z; v[tt][rt][3] = acc[rt][tt][3] + bv[rt].w + r.w;
                     ps[tt] += (v[tt][rt][0] + v[tt][rt][1]) + (v[tt][rt][2] + v[tt][rt][3]);
@@ -189,10 +236,13 @@ __global__ __launch_bounds__(512, 1) void gemm_k256s_kernel(
                 const long tok = (long)t * KS_TOK + 16 * tt + n;
                 if (tok < M) {
 #pragma unroll
-                    for (int rt = 0; rt < 2; ++rt)
+                    for (int rt = 0; rt < 2; ++rt) {
+                        const float4 gvr = *reinterpret_cast<const float4*>(par + 256 + wave * 32 + rt * 16 + 4 * g);
+                        const float4 evr = *reinterpret_cast<const float4*>(par + 512 + wave * 32 + rt * 16 + 4 * g);
                         *reinterpret_cast<float4*>(C + tok * 256 + wave * 32 + rt * 16 + 4 * g) =
-                            make_float4((v[tt][rt][0] - mean[tt]) * rstd * gv[rt].x + ev[rt].x, (v[tt][rt][1] - mean[tt]) * rstd * gv[rt].y + ev[rt].y,
-                                        (v[tt][rt][2] - mean[tt]) * rstd * gv[rt].z + ev[rt].z, (v[tt][rt][3] - mean[tt]) * rstd * gv[rt].w + ev[rt].w);
+                            make_float4((v[tt][rt][0] - mean[tt]) * rstd * gvr.x + evr.x, (v[tt][rt][1] - mean[tt]) * rstd * gvr.y + evr.y,
+                                        (v[tt][rt][2] - mean[tt]) * rstd * gvr.z + evr.z, (v[tt][rt][3] - mean[tt]) * rstd * gvr.w + evr.w);
+                    }
                 }
             }
         }

@@ -31,7 +31,7 @@ def main():
     mask = torch.zeros((args.batch, 128, 2048), dtype=torch.bool, device=dev)
     spans = []
     names = ["linear", "layernorm", "conv2d_nhwc", "maxpool_nhwc", "groupnorm_tokens", "msda", "msda_fused", "msda_encoder", "mha",
-             "ffn_fused", "ffn32", "proj_ln", "proj_ln_k256", "proj_ln_split", "gemm_k256", "gemm_kres", "gemm_kres_chain", "dec_query_stage", "stem_conv7x7_pool", "linear_rowmax", "geometry", "two_stage_gather", "stem_conv7x7", "stem_conv7x7_f32", "linear_resbcast", "box_mlp_refine", "blank_emissions", "box_head_refine", "decoder_query_prep", "box_refine", "topk_rows", "decode_blank"]
+             "ffn_fused", "ffn32", "proj_ln", "proj_ln_k256", "proj_ln_split", "gemm_k256", "gemm_kres", "gemm_kres_chain", "dec_query_stage", "stem_conv7x7_pool", "linear_rowmax", "geometry", "two_stage_gather", "stem_conv7x7", "stem_conv7x7_f32", "linear_resbcast", "box_mlp_refine", "blank_emissions", "box_head_refine", "decoder_query_prep", "box_refine", "topk_rows", "decode_blank", "ffn_split", "gemm_k256s", "stem_conv7x7_f32s"]
 
     def wrap(name):
         fn = getattr(ops, name)
@@ -43,8 +43,12 @@ def main():
             e1.record()
             shp = tuple(tuple(t.shape) for t in a[:2] if torch.is_tensor(t))
             dt = str(a[0].dtype).replace("torch.", "") if torch.is_tensor(a[0]) else ""
+            if name == "gemm_k256s" and k.get("residual") is not None:
+                name_ = name + "+res+ln"
+            else:
+                name_ = name
             extra = "+a2" if k.get("a2") is not None or (name == "linear" and len(a) > 5 and a[5] is not None) else ""
-            spans.append((name + extra, dt, shp, e0, e1))
+            spans.append((name_ + extra, dt, shp, e0, e1))
             return r
         setattr(ops, name, timed)
 
