@@ -101,7 +101,7 @@ class DTLREngine:
         self.w[name + ".b"] = b.to(device=self.device, dtype=torch.float32).contiguous()
 
     def _put_linear(self, name, w, b):
-        if self.split and (name.endswith((".ff1", ".ff2")) or (name.startswith("enc") and name.endswith((".attn.value", ".attn.out")))):
+        if self.split and (name.endswith((".ff1", ".ff2", ".attn.out", ".sa.out")) or (name.startswith("enc") and name.endswith(".attn.value"))):
             # the fused split FFN and the weight-resident K = 256 projections pack their own images from the fp32 weights
             self._ffn_f32[name] = w.to(device=self.device, dtype=torch.float32).contiguous()
             if not name.endswith((".ff1", ".ff2")) and tuple(w.shape) == (256, 256):

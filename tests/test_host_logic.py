@@ -570,3 +570,61 @@ def test_msda_variant3_token_table_division_restated():
         inv = np.float32(1.0) / np.float32(nc)
         for cand in (inv, np.nextafter(inv, np.float32(np.inf)), np.nextafter(inv, np.float32(-np.inf))):
             assert np.array_equal((rf * cand).astype(np.int32), r // nc), nc
+
+
+def test_split_operand_contract_and_split_packers():
+    """The split-fp32 engine's arithmetic contract and its host-side packers, restated in numpy (no GPU).
+    (1) x = hi + lo with hi = fp16(x), lo = fp16(x - hi): the three-term product a_hi w_hi + a_lo w_hi + a_hi w_lo (exact in fp32
+    accumulators for one term) differs from a w by at most 2^-21 |a w| + 2^-24 (|a| + |w|): the dropped lo lo term plus the fp16
+    SUBNORMAL floor of the lo halves (a lo half below 2^-14 is carried with absolute spacing 2^-24) -- fp32-grade for the O(1)
+    activations and O(1/16) weights of the model, and the reason operands far below 1e-3 are not.
+    (2) ops.ffn_split_pack: per 32-unit chunk [W1_hi | W1_lo | W2_hi | W2_lo], each part 16 fragments of 64 lanes x 8 halves in the
+    order the header documents; zero chunks pad to an even count + the kernel's look-ahead.
+    (3) ops.stem_pack_weights_split: the 16-bit stem packer applied to fp16(w) and to w - fp16(w)."""
+    import numpy as np
+    from dtlr_amd import _lib, ops
+    rng = np.random.Generator(np.random.PCG64(11))
+    # (1)
+    for sa, sw in ((1.0, 1.0 / 16), (30.0, 0.5), (1e-2, 1e-2)):
+        a = (rng.standard_normal(200000) * sa).astype(np.float32)
+        w = (rng.standard_normal(200000) * sw).astype(np.float32)
+        ah, wh = a.astype(np.float16), w.astype(np.float16)
+        al, wl = (a - ah.astype(np.float32)).astype(np.float16), (w - wh.astype(np.float32)).astype(np.float16)
+        d = lambda t: t.astype(np.float64)                                               # noqa: E731
+        got = d(ah) * d(wh) + d(al) * d(wh) + d(ah) * d(wl)
+        err = np.abs(got - d(a) * d(w))
+        bound = 2.0 ** -21 * np.abs(d(a) * d(w)) + 2.0 ** -24 * (np.abs(d(a)) + np.abs(d(w)))
+        assert (err <= bound).all(), (sa, sw, float((err / bound).max()))
+        assert np.abs(d(a) - d(ah) - d(al)).max() <= max(2.0 ** -22 * np.abs(a).max(), 2.0 ** -25)      # the representation itself
+    # (2)
+    pad = int(_lib.lib().dtlr_ffn_split_pad_chunks())
+    for d_ff in (64, 96, 2048):
+        w1 = torch.from_numpy(rng.standard_normal((d_ff, 256)).astype(np.float32) / 16)
+        w2 = torch.from_numpy(rng.standard_normal((256, d_ff)).astype(np.float32) / np.sqrt(d_ff).astype(np.float32))
+        img = ops.ffn_split_pack(w1, w2)
+        nc = d_ff // 32
+        total = ((nc + 1) & ~1) + pad
+        assert img.dtype == torch.uint8 and img.numel() == total * 65536
+        h = img.view(torch.float16).reshape(total, 4, 16, 64, 8).float().numpy()         # [chunk][part][fragment][lane][e]
+        assert not h[nc:].any()                                                           # padding chunks are zeros
+        lane = np.arange(64)
+        for c in (0, nc - 1):
+            for part, (wf, kind) in enumerate(((w1, 1), (w1, 1), (w2, 2), (w2, 2))):
+                wn = wf.numpy()
+                hi = wn.astype(np.float16).astype(np.float32)
+                src = hi if part % 2 == 0 else (wn - hi).astype(np.float16).astype(np.float32)
+                for f in (0, 7, 15):
+                    for e in range(8):
+                        if kind == 1:        # W1: fragment s: lane l <- W1[32 c + (l & 31)][16 s + 8 (l >> 5) + e]
+                            want = src[32 * c + (lane & 31), 16 * f + 8 * (lane >> 5) + e]
+                        else:                # W2: fragment 8 s + ct: lane l <- W2[32 ct + (l & 31)][32 c + 8 (2 s + (e >> 2)) + 4 (l >> 5) + (e & 3)]
+                            s_, ct = f >> 3, f & 7
+                            want = src[32 * ct + (lane & 31), 32 * c + 8 * (2 * s_ + (e >> 2)) + 4 * (lane >> 5) + (e & 3)]
+                        assert np.array_equal(h[c, part, f, :, e], want), (d_ff, c, part, f, e)
+    # (3)
+    w = torch.from_numpy(rng.standard_normal((64, 3, 7, 7)).astype(np.float32) * 0.1)
+    fh, fl = ops.stem_pack_weights_split(w)
+    hi = w.half().float()
+    assert torch.equal(fh, ops.stem_pack_weights(hi, torch.float16)) and torch.equal(fl, ops.stem_pack_weights(w - hi, torch.float16))
+    back = fh.view(torch.float16).float() + fl.view(torch.float16).float()              # same fragment order in both: the sum is the packed w
+    assert (back - ops.stem_pack_weights(w, torch.float16).view(torch.float16).float()).abs().max() <= 2.0 ** -11 * 0.5
