@@ -3,6 +3,9 @@
 //     MODE 0:  C[M, 256] = A[M, 256] . W^T + bias,  rows with row_mask != 0 written as zeros      (encoder value_proj: ms_deform_attn.py:94-96)
 //     MODE 1:  C[M, 256] = LayerNorm( R + A . W^T + bias )                                         (output_proj + residual + norm1:
 //                                                                                                   deformable_transformer.py:810-815)
+//     MODE 2:  C[M, 256] = LayerNorm( bias + (row_mask ? 0 : A . W^T) )                            (two-stage front end: enc_output(memory with the
+//                                                                                                   invalid rows zeroed) + enc_output_norm,
+//                                                                                                   deformable_transformer.py:320-330, utils.py:58-62)
 // every product as three fp16 MFMAs on hi + lo halves (gemm.hip, GT<f32s_t>), fp32 accumulation, fp32 residual and statistics.
 //
 // Why: through the tiled split GEMM these 13 projections per step are HBM streams held at 3.2 TB/s (111 us each at B = 32: eight K slabs, then
@@ -53,7 +56,9 @@ __device__ __forceinline__ void ks_split2(float x0, float x1, uint32_t& hi, uint
 }
 
 // Wp: [2 parts (hi, lo)][8 waves][2 row tiles][8 k-steps][64 lanes][8 halves]: lane (m = l & 15, g = l >> 4) <- W[32 wave + 16 rt + m][32 ks + 8 g + e]
-template <int MODE>
+// MASK (compile time): row_mask is read.  (As a run-time `if (row_mask)` around the flag loads and around their pin, hipcc's wait insertion
+// assumed a path with the loads issued and the pin skipped, and put vmcnt(3..0) in front of the stores: every tile drained its successor's DMA.)
+template <int MODE, bool MASK>
 __global__ __launch_bounds__(512, 1) void gemm_k256s_kernel(
     const float* __restrict__ A, const uint16_t* __restrict__ Wp, const float* __restrict__ bias, const float* __restrict__ R,
     const uint8_t* __restrict__ row_mask, const float* __restrict__ gamma, const float* __restrict__ beta, float eps,
@@ -93,7 +98,7 @@ __global__ __launch_bounds__(512, 1) void gemm_k256s_kernel(
     float* par = reinterpret_cast<float*>(ks_smem + KS_PAR_OFF);
     if (threadIdx.x < 256) {
         par[threadIdx.x] = bias ? bias[threadIdx.x] : 0.f;
-        if constexpr (MODE == 1) { par[256 + threadIdx.x] = gamma[threadIdx.x]; par[512 + threadIdx.x] = beta[threadIdx.x]; }
+        if constexpr (MODE != 0) { par[256 + threadIdx.x] = gamma[threadIdx.x]; par[512 + threadIdx.x] = beta[threadIdx.x]; }
     }
     // Pin the resident operands BEFORE the loop: left alone, the compiler waits for these loads lazily at their first use inside the loop
     // body -- a vmcnt(0) executed every iteration right after the next tile's DMA was issued (the first build: no overlap at all).
@@ -115,31 +120,35 @@ __global__ __launch_bounds__(512, 1) void gemm_k256s_kernel(
         // (A tail tile issues fewer stores, but it is the last of its workgroup: nothing waits after it.)
         if (t == t_begin) asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
         else              asm volatile("s_waitcnt vmcnt(8) lgkmcnt(0)" ::: "memory");
+        if constexpr (MASK) {                                            // padded batch: this tile's flags, pinned BEFORE the DMA issue (a
+#pragma unroll                                                           // wait after it would drain the DMA; this one drains the stores)
+            for (int tt = 0; tt < 4; ++tt) mk[tt] = row_mask[min((long)t * KS_TOK + 16 * tt + n, (long)M - 1)];
+        }
+        // ---- my 8 raw rows into registers: lane L holds k = 4 L .. 4 L + 3 of each; the raw rows are then free, and the NEXT tile's DMA is
+        //      issued at once (it flies under this tile's split, MFMAs and stores; the first form issued it after the second barrier)
+        float4 raw[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) raw[u] = *reinterpret_cast<const float4*>(ks_smem + (8 * wave + u) * 1024 + lane * 16);
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        if constexpr (MASK) {
+#pragma unroll
+            for (int tt = 0; tt < 4; ++tt) asm volatile("" : "+v"(mk[tt]));
+        }
+        if (t + 1 < t_end) issue(t + 1);
+        uint2 sh[8], sl[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) { ks_split2(raw[u].x, raw[u].y, sh[u].x, sl[u].x); ks_split2(raw[u].z, raw[u].w, sh[u].y, sl[u].y); }
         __builtin_amdgcn_s_barrier();                                    // every wave has finished reading the previous image
-        // ---- split my 8 rows: lane L holds k = 4 L .. 4 L + 3 -> 8 bytes of hi at chunk (L >> 1) ^ (row & 15), half L & 1; lo 512 B further
+        // ---- 8 bytes of hi at chunk (L >> 1) ^ (row & 15), half L & 1; lo 512 B further
 #pragma unroll
         for (int u = 0; u < 8; ++u) {
             const int row = 8 * wave + u;
-            const float4 a = *reinterpret_cast<const float4*>(ks_smem + row * 1024 + lane * 16);
-            uint2 h, l;
-            ks_split2(a.x, a.y, h.x, l.x); ks_split2(a.z, a.w, h.y, l.y);
             unsigned char* dst = ks_smem + KS_IMG_OFF + row * 1024 + (((lane >> 1) ^ (row & 15)) * 16) + (lane & 1) * 8;
-            *reinterpret_cast<uint2*>(dst) = h;
-            *reinterpret_cast<uint2*>(dst + 512) = l;
+            *reinterpret_cast<uint2*>(dst) = sh[u];
+            *reinterpret_cast<uint2*>(dst + 512) = sl[u];
         }
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        if constexpr (MODE == 0) {
-            if (row_mask) {                                              // padded batch: this tile's flags, pinned BEFORE the DMA issue (a
-#pragma unroll                                                           // wait after it would drain the DMA; this one drains the stores)
-                for (int tt = 0; tt < 4; ++tt) {
-                    mk[tt] = row_mask[min((long)t * KS_TOK + 16 * tt + n, (long)M - 1)];
-                }
-#pragma unroll
-                for (int tt = 0; tt < 4; ++tt) asm volatile("" : "+v"(mk[tt]));
-            }
-        }
-        __builtin_amdgcn_s_barrier();                                    // the image is complete; the raw buffer is free
-        if (t + 1 < t_end) issue(t + 1);
+        __builtin_amdgcn_s_barrier();                                    // the image is complete
         float4 rr[4][2];
         if constexpr (MODE == 1) {                                       // this tile's residual rows, in the accumulator layout: requested here,
 #pragma unroll                                                           // consumed in the epilogue (the MFMA phase hides them)
@@ -180,7 +189,7 @@ __global__ __launch_bounds__(512, 1) void gemm_k256s_kernel(
             for (int tt = 0; tt < 4; ++tt) {
                 const long tok = (long)t * KS_TOK + 16 * tt + n;
                 if (tok < M) {
-                    const bool masked = mk[tt] != 0;
+                    const bool masked = MASK && mk[tt] != 0;
 #pragma unroll
                     for (int rt = 0; rt < 2; ++rt) {
                         float4 v = make_float4(acc[rt][tt][0] + bv[rt].x, acc[rt][tt][1] + bv[rt].y, acc[rt][tt][2] + bv[rt].z, acc[rt][tt][3] + bv[rt].w);
@@ -197,7 +206,9 @@ __global__ __launch_bounds__(512, 1) void gemm_k256s_kernel(
                 ps[tt] = 0.f;
 #pragma unroll
                 for (int rt = 0; rt < 2; ++rt) {
-                    const float4 r = rr[tt][rt];
+                    float4 r = make_float4(0.f, 0.f, 0.f, 0.f);
+                    if constexpr (MODE == 1) r = rr[tt][rt];
+                    if constexpr (MODE == 2 && MASK) { if (mk[tt] != 0) acc[rt][tt] = ks_f32x4_t{0.f, 0.f, 0.f, 0.f}; }
                     v[tt][rt][0] = acc[rt][tt][0] + bv[rt].x + r.x; v[tt][rt][1] = acc[rt][tt][1] + bv[rt].y + r.y;
                     v[tt][rt][2] = acc[rt][tt][2] + bv[rt].z + r.z; v[tt][rt][3] = acc[rt][tt][3] + bv[rt].w + r.w;
                     ps[tt] += (v[tt][rt][0] + v[tt][rt][1]) + (v[tt][rt][2] + v[tt][rt][3]);
@@ -277,29 +288,33 @@ extern "C" int dtlr_k256s_pack_weights(const float* w, void* out, void* stream)
 }
 
 // A, C (and R) [M, 256] fp32; Wp = dtlr_k256s_pack_weights(W [256, 256]) (256 KB); bias [256] fp32 or NULL.
-//   R == NULL: C = A W^T + bias, rows with row_mask[m] != 0 (may be NULL) written as zeros.
-//   R != NULL: C = LayerNorm(R + A W^T + bias) with gamma / beta [256] fp32 (row_mask ignored).
+//   R == NULL, gamma == NULL: C = A W^T + bias, rows with row_mask[m] != 0 (may be NULL) written as zeros.
+//   R != NULL:                C = LayerNorm(R + A W^T + bias) with gamma / beta [256] fp32 (row_mask ignored).
+//   R == NULL, gamma != NULL: C = LayerNorm(bias + A W^T), the product of rows with row_mask[m] != 0 (may be NULL) taken as zero.
 extern "C" int dtlr_gemm_k256s(const float* A, const void* Wp, const float* bias, const float* R, const unsigned char* row_mask,
                                const float* gamma, const float* beta, float eps, float* C, long M, void* stream)
 {
     clear_stale_error();
     if (!A || !Wp || !C) return DTLR_EINVAL;
     if (M <= 0 || M > 0x7fffffffL) return DTLR_EINVAL;
-    if (R && (!gamma || !beta)) return DTLR_EINVAL;
+    if ((R || gamma || beta) && (!gamma || !beta)) return DTLR_EINVAL;
     const int ntiles = (int)((M + KS_TOK - 1) / KS_TOK);
-    int nwg = 256;                                               // one workgroup per CU (132 KB of LDS)
+    int nwg = 256;                                               // one workgroup per CU (133 KB of LDS)
     if (nwg > ntiles) nwg = ntiles;
     const int per = (ntiles + nwg - 1) / nwg;
     nwg = (ntiles + per - 1) / per;
     hipStream_t st = (hipStream_t)stream;
-    if (R) {
-        static DevOnce once;
-        if (once.first()) { (void)hipFuncSetAttribute((const void*)gemm_k256s_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, KS_LDS); (void)hipGetLastError(); }
-        hipLaunchKernelGGL(gemm_k256s_kernel<1>, dim3(nwg), dim3(512), KS_LDS, st, A, (const uint16_t*)Wp, bias, R, (const uint8_t*)nullptr, gamma, beta, eps, C, (int)M, per);
-    } else {
-        static DevOnce once;
-        if (once.first()) { (void)hipFuncSetAttribute((const void*)gemm_k256s_kernel<0>, hipFuncAttributeMaxDynamicSharedMemorySize, KS_LDS); (void)hipGetLastError(); }
-        hipLaunchKernelGGL(gemm_k256s_kernel<0>, dim3(nwg), dim3(512), KS_LDS, st, A, (const uint16_t*)Wp, bias, (const float*)nullptr, row_mask, (const float*)nullptr, (const float*)nullptr, eps, C, (int)M, per);
+#define KS_LAUNCH(MODE, HASM, RES, MASK)                                                                                                       \
+    {                                                                                                                                       \
+        static DevOnce once;                                                                                                                \
+        if (once.first()) { (void)hipFuncSetAttribute((const void*)gemm_k256s_kernel<MODE, HASM>, hipFuncAttributeMaxDynamicSharedMemorySize, KS_LDS); (void)hipGetLastError(); } \
+        hipLaunchKernelGGL((gemm_k256s_kernel<MODE, HASM>), dim3(nwg), dim3(512), KS_LDS, st, A, (const uint16_t*)Wp, bias, RES, MASK, gamma, beta, eps, C, (int)M, per); \
     }
+    if (R) KS_LAUNCH(1, false, R, (const uint8_t*)nullptr)
+    else if (gamma && row_mask) KS_LAUNCH(2, true, (const float*)nullptr, row_mask)
+    else if (gamma) KS_LAUNCH(2, false, (const float*)nullptr, row_mask)
+    else if (row_mask) KS_LAUNCH(0, true, (const float*)nullptr, row_mask)
+    else KS_LAUNCH(0, false, (const float*)nullptr, row_mask)
+#undef KS_LAUNCH
     return check_launch();
 }

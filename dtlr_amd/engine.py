@@ -101,7 +101,8 @@ class DTLREngine:
         self.w[name + ".b"] = b.to(device=self.device, dtype=torch.float32).contiguous()
 
     def _put_linear(self, name, w, b):
-        if self.split and (name.endswith((".ff1", ".ff2", ".attn.out", ".sa.out")) or (name.startswith("enc") and name.endswith(".attn.value"))):
+        if self.split and (name.endswith((".ff1", ".ff2", ".attn.out", ".sa.out")) or (name.startswith("enc") and name.endswith(".attn.value"))
+                           or name == "enc_output"):
             # the fused split FFN and the weight-resident K = 256 projections pack their own images from the fp32 weights
             self._ffn_f32[name] = w.to(device=self.device, dtype=torch.float32).contiguous()
             if not name.endswith((".ff1", ".ff2")) and tuple(w.shape) == (256, 256):
@@ -632,9 +633,16 @@ class DTLREngine:
             # the 2 x 0.059 bound of the 900-th.  Dropped; the lever for that head is the large-N GEMM itself.)
             scores = ops.linear_rowmax(om, w["enc_class.w3"], w["enc_class.b3"])
         else:
-            om = memory * g["keep"].unsqueeze(-1).to(memory.dtype)
-            # selection scores are computed in fp32: the projection writes fp32 straight from its accumulators
-            om = self._ln("enc_output_norm", self._lin("enc_output", om, out_dtype=torch.float32))
+            if self.split and self.use_k256s and "enc_output" in self._k256s_ok and memory.shape[-1] == 256:
+                # split engine: masking, projection and LayerNorm in one streaming pass (dtlr_gemm_k256s, LN form with a row mask)
+                if "drop_rows" not in g:
+                    g["drop_rows"] = (~g["keep"].bool()).contiguous()
+                om = ops.gemm_k256s(memory, self._k256sw("enc_output"), w["enc_output.b"], row_mask=g["drop_rows"],
+                                    ln_w=w["enc_output_norm.w"], ln_b=w["enc_output_norm.b"])
+            else:
+                om = memory * g["keep"].unsqueeze(-1).to(memory.dtype)
+                # selection scores are computed in fp32: the projection writes fp32 straight from its accumulators
+                om = self._ln("enc_output_norm", self._lin("enc_output", om, out_dtype=torch.float32))
             scores = ops.linear_rowmax(om, w["enc_class.w"], w["enc_class.b"])
         idx = ops.topk_rows(scores, cfg.num_queries) if forced_topk is None else forced_topk
         sel_raw, sel_x, prop_sel, init_box = ops.two_stage_gather(om, g["proposals"], idx)      # one launch for all the gathers

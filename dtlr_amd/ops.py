@@ -630,21 +630,24 @@ def k256s_pack(w):
 
 def gemm_k256s(x, wp, b, residual=None, row_mask=None, ln_w=None, ln_b=None, eps: float = 1e-5):
     """The split-fp32 engine's weight-resident streaming K = N = 256 projection (dtlr_gemm_k256s).  x [..., 256] fp32, wp = k256s_pack(W).
-    residual None: x W^T + b with the rows flagged in row_mask (bool [M], optional) written as zeros (value_proj + masked_fill);
-    residual [..., 256] fp32: LayerNorm(residual + x W^T + b) (output_proj + residual + norm1)."""
+    no LN params:  x W^T + b with the rows flagged in row_mask (bool [M], optional) written as zeros (value_proj + masked_fill);
+    residual:      LayerNorm(residual + x W^T + b) (output_proj + residual + norm1);
+    LN params, no residual: LayerNorm(b + x W^T) with the PRODUCT of the flagged rows taken as zero (enc_output on the masked memory + norm)."""
     require_cuda(x, "x")
     assert x.dtype == torch.float32 and x.shape[-1] == 256 and wp.dtype == torch.int16 and wp.numel() == 2 * 65536
     x = x if x.is_contiguous() else x.contiguous()
     M = x.numel() // 256
     y = torch.empty_like(x)
+    assert (ln_w is None) == (ln_b is None)
     if residual is not None:
-        assert residual.dtype == torch.float32 and residual.shape == x.shape and ln_w is not None and ln_b is not None
+        assert residual.dtype == torch.float32 and residual.shape == x.shape and ln_w is not None and row_mask is None
         residual = residual if residual.is_contiguous() else residual.contiguous()
     if row_mask is not None:
-        assert residual is None and row_mask.numel() == M and row_mask.dtype in (torch.bool, torch.uint8)
+        assert row_mask.numel() == M and row_mask.dtype in (torch.bool, torch.uint8)
         row_mask = row_mask if row_mask.is_contiguous() else row_mask.contiguous()
     nbytes = float(M) * 256 * 4 * (3 if residual is not None else 2) + 2.0 * 65536 * 2
-    with _Timed("gemm_f32s", 2.0 * M * 256 * 256, nbytes, f"k256s M{M}" + ("+res+ln" if residual is not None else "")):
+    tag = f"k256s M{M}" + ("+res+ln" if residual is not None else "+ln" if ln_w is not None else "")
+    with _Timed("gemm_f32s", 2.0 * M * 256 * 256, nbytes, tag):
         code = _lib.lib().dtlr_gemm_k256s(x.data_ptr(), wp.data_ptr(), 0 if b is None else b.data_ptr(), 0 if residual is None else residual.data_ptr(),
                                           0 if row_mask is None else row_mask.data_ptr(), 0 if ln_w is None else ln_w.data_ptr(),
                                           0 if ln_b is None else ln_b.data_ptr(), eps, y.data_ptr(), M, _lib.current_stream())

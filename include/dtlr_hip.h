@@ -130,10 +130,13 @@ int dtlr_ffn_split_pad_chunks(void);
 
 /* ---------------------------------------------------------------------------------------------
  * SPLIT-fp32 engine, K = N = 256: the weight-resident streaming projection (round 4).  A, C (and R) [M, 256] fp32.
- *   R == NULL: C = A W^T + bias, rows with row_mask[m] != 0 (may be NULL) written as zeros.
+ *   R == NULL, gamma == NULL: C = A W^T + bias, rows with row_mask[m] != 0 (may be NULL) written as zeros.
  *              Replaces: value = self.value_proj(input_flatten); value.masked_fill(padding_mask, 0) (ops/modules/ms_deform_attn.py:94-96).
  *   R != NULL: C = LayerNorm(R + A W^T + bias), gamma / beta [256] fp32 (row_mask ignored).
  *              Replaces: output_proj (ms_deform_attn.py:124) + src = norm1(src + dropout1(src2)) (deformable_transformer.py:810-815).
+ *   R == NULL, gamma != NULL: C = LayerNorm(bias + A W^T), the product of rows with row_mask[m] != 0 (may be NULL) taken as zero.
+ *              Replaces: output_memory.masked_fill(..) -> enc_output -> enc_output_norm of the two-stage front end
+ *              (deformable_transformer.py:320-330; models/dino/utils.py:58-62).
  *   Wp = dtlr_k256s_pack_weights(W [256, 256] fp32): 256 KB, fp16 hi then lo halves in MFMA fragment order
  *        ([8 waves][2 row tiles][8 k-steps][64 lanes][8]: lane (m, g) <- W[32 wave + 16 rt + m][32 ks + 8 g + e]).
  */

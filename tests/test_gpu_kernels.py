@@ -1454,7 +1454,7 @@ def test_stem_conv7x7_split_vs_fp64(B, H, W):
 
 
 @pytest.mark.parametrize("M", [64, 1, 37, 300, 4097, 16384 + 5, 174080])
-@pytest.mark.parametrize("mode", ["value", "proj_ln"])
+@pytest.mark.parametrize("mode", ["value", "proj_ln", "masked_ln"])
 def test_gemm_k256s_vs_fp64(M, mode):
     """dtlr_gemm_k256s (weight-resident streaming projection of the split-fp32 engine) against fp64 on the same fp32 operands, both modes
     (bias + masked rows; bias + residual + LayerNorm), for a single row, ragged tails, more tiles than workgroups, the bench's token count;
@@ -1471,6 +1471,16 @@ def test_gemm_k256s_vs_fp64(M, mode):
         tiled = ops.linear(x.cuda(), ops.split_pack(w.cuda()), b.cuda(), row_mask=mask.cuda()).cpu()
         nomask = ops.gemm_k256s(x.cuda(), wp, None).cpu()
         assert (nomask[rows] - (x[rows].double() @ w.double().t()).float()).abs().max() < 2e-5 * max(1.0, want.abs().max().item())
+    elif mode == "masked_ln":                              # LayerNorm(b + (flagged ? 0 : x W^T)): the two-stage front end
+        mask = (torch.arange(M) % 5 == 2) if M > 1 else torch.ones(1, dtype=torch.bool)
+        g, be = _rand((256,), 25) * 0.2 + 1.0, _rand((256,), 26) * 0.1
+        got = ops.gemm_k256s(x.cuda(), wp, b.cuda(), row_mask=mask.cuda(), ln_w=g.cuda(), ln_b=be.cuda()).cpu()
+        xm = x.masked_fill(mask[:, None], 0.0)
+        want = F.layer_norm(xm[rows].double() @ w.double().t() + b.double(), (256,), g.double(), be.double(), 1e-5).float()
+        tiled = ops.layernorm(ops.linear(xm.cuda(), ops.split_pack(w.cuda()), b.cuda()), g.cuda(), be.cuda(), 1e-5).cpu()
+        nomask = ops.gemm_k256s(x.cuda(), wp, b.cuda(), ln_w=g.cuda(), ln_b=be.cuda()).cpu()
+        wantn = F.layer_norm(x[rows].double() @ w.double().t() + b.double(), (256,), g.double(), be.double(), 1e-5).float()
+        assert (nomask[rows] - wantn).abs().max() < 2e-5 * max(1.0, wantn.abs().max().item())
     else:
         r = _rand((M, 256), 24, 2.0)
         g, be = _rand((256,), 25) * 0.2 + 1.0, _rand((256,), 26) * 0.1

@@ -35,8 +35,11 @@ def main():
     t1 = timeit(lambda: ops.linear(x, ws, b))
     t2 = timeit(lambda: ops.gemm_k256s(x, wp, b, residual=r, ln_w=gm, ln_b=be))
     t3 = timeit(lambda: ops.layernorm(ops.linear(x, ws, b), gm, be, 1e-5, r))
+    mk = (torch.arange(M, device="cuda") % 5 == 2)
+    t4 = timeit(lambda: ops.gemm_k256s(x, wp, b, row_mask=mk, ln_w=gm, ln_b=be))
+    t5 = timeit(lambda: ops.gemm_k256s(x, wp, b, row_mask=mk))
     gb = M * 256 * 4 / 1e3
-    print(f"M {M}: k256s plain {t0:.1f} us ({2 * gb / t0:.0f} GB/s)  tiled {t1:.1f} us | k256s +res+LN {t2:.1f} us ({3 * gb / t2:.0f} GB/s)  tiled + LN {t3:.1f} us")
+    print(f"M {M}: k256s plain {t0:.1f} us ({2 * gb / t0:.0f} GB/s)  tiled {t1:.1f} us | k256s +res+LN {t2:.1f} us ({3 * gb / t2:.0f} GB/s)  tiled + LN {t3:.1f} us | masked+LN {t4:.1f} us, masked plain {t5:.1f} us")
 
 
 if __name__ == "__main__":
