@@ -650,9 +650,14 @@ __device__ __forceinline__ void enc_queries_f32_lvl(
     const float fH = (float)Hl, fW = (float)Wl;
     const unsigned char* win = smem + (long)loffl * 128;
     const float* gsrc = vimg + (long)startl * MD;
+    // Piece order of this lane: (jj + 2 level + query slot) & 7.  With 2 level alone the 16 lanes of one ds_read_b128 group used FOUR of
+    // the eight 16-byte columns (SQ counters: 61 % of the LDS-active cycles were bank conflicts, LDS active 66 % of the CU time); the
+    // query term spreads them over all eight -- two lanes per column instead of four.  The quad shares the slot, so the reduce-scatter
+    // below is unchanged and only the two 16-byte output pieces of a lane rotate with it.
+    const int qs = (tid >> 2) & 7;
     int rot[8];
 #pragma unroll
-    for (int jj = 0; jj < 8; ++jj) rot[jj] = ((jj + 2 * p) & 7) * 16;
+    for (int jj = 0; jj < 8; ++jj) rot[jj] = ((jj + 2 * p + qs) & 7) * 16;
 
     auto token_of = [&](int it) -> long { return (long)b * S + tok[it >> 2]; };
     const int total = nq * 4;
@@ -759,8 +764,8 @@ __device__ __forceinline__ void enc_queries_f32_lvl(
             __builtin_amdgcn_sched_barrier(0);
         }
 #undef DTLR_ACC_F32
-        // quad reduce-scatter: lane p's acc[jj] is piece (jj + 2p) & 7 of its level; lane i collects pieces 2i (acc[0], acc[2] of lane
-        // i-1, acc[4] of lane i-2, acc[6] of lane i-3) and 2i+1 (the odd ones)
+        // quad reduce-scatter: lane p's acc[jj] is piece (jj + 2p + slot) & 7 of its level; lane i collects pieces 2i + slot (acc[0], acc[2]
+        // of lane i-1, acc[4] of lane i-2, acc[6] of lane i-3) and 2i + 1 + slot (the odd ones)
         float res[8];
 #pragma unroll
         for (int e = 0; e < 2; ++e)
@@ -769,9 +774,9 @@ __device__ __forceinline__ void enc_queries_f32_lvl(
 #pragma unroll
                 for (int c = 0; c < 2; ++c)
                     res[4 * e + 2 * h + c] = (acc[e][h][c] + quad_dpp<0x39>(acc[6 + e][h][c])) + (quad_dpp<0x4E>(acc[4 + e][h][c]) + quad_dpp<0x93>(acc[2 + e][h][c]));
-        float* dst = out + bq * MD + m * 32 + p * 8;
-        *reinterpret_cast<float4*>(dst) = make_float4(res[0], res[1], res[2], res[3]);
-        *reinterpret_cast<float4*>(dst + 4) = make_float4(res[4], res[5], res[6], res[7]);
+        float* dst = out + bq * MD + m * 32;                        // res[0..3] = piece (2 i + slot) & 7, res[4..7] = the next one
+        *reinterpret_cast<float4*>(dst + ((2 * p + qs) & 7) * 4) = make_float4(res[0], res[1], res[2], res[3]);
+        *reinterpret_cast<float4*>(dst + ((2 * p + 1 + qs) & 7) * 4) = make_float4(res[4], res[5], res[6], res[7]);
         cur = nxt; rf = rf_n; bq = bqn;
     }
 }
