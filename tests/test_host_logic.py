@@ -628,3 +628,29 @@ def test_split_operand_contract_and_split_packers():
     assert torch.equal(fh, ops.stem_pack_weights(hi, torch.float16)) and torch.equal(fl, ops.stem_pack_weights(w - hi, torch.float16))
     back = fh.view(torch.float16).float() + fl.view(torch.float16).float()              # same fragment order in both: the sum is the packed w
     assert (back - ops.stem_pack_weights(w, torch.float16).view(torch.float16).float()).abs().max() <= 2.0 ** -11 * 0.5
+
+
+def test_bench_self_launch_builds_the_documented_command(monkeypatch):
+    """`python bench.py --gpus N` without a launcher re-executes itself through torch.distributed.run on 127.0.0.1 with one rank per
+    GPU, forwards its own arguments untouched and returns the launcher's exit code (no GPU: the subprocess call is intercepted)."""
+    import importlib
+    import subprocess
+    import types
+    sys.path.insert(0, ROOT)
+    bench = importlib.import_module("bench")
+    seen = {}
+
+    def fake_call(cmd, env=None):
+        seen["cmd"], seen["env"] = cmd, env
+        return 7
+    monkeypatch.setattr(subprocess, "call", fake_call)
+    monkeypatch.setattr(sys, "argv", ["bench.py", "--gpus", "4", "--steps", "5", "--warmup", "1"])
+    monkeypatch.delenv("HSA_ENABLE_IPC_MODE_LEGACY", raising=False)
+    rc = bench.self_launch(types.SimpleNamespace(gpus=4))
+    cmd = seen["cmd"]
+    assert rc == 7
+    assert cmd[:3] == [sys.executable, "-m", "torch.distributed.run"] and "--nnodes=1" in cmd and "--nproc-per-node=4" in cmd
+    assert cmd[cmd.index("--master-addr") + 1] == "127.0.0.1" and 1024 < int(cmd[cmd.index("--master-port") + 1]) < 65536
+    i = cmd.index(os.path.join(ROOT, "bench.py"))
+    assert cmd[i + 1:] == ["--gpus", "4", "--steps", "5", "--warmup", "1"]
+    assert seen["env"]["HSA_ENABLE_IPC_MODE_LEGACY"] == "0"

@@ -203,3 +203,52 @@ def test_g7_swin_backbone_and_full_model(golden_dir):
     assert (out["_debug"]["memory"][:, ::7] - _t(g["b_memory"])).abs().max() < 2e-4
     assert (out["pred_logits"] - _t(g["b_pred_logits"])).abs().max() < 1e-3
     assert (out["pred_boxes"] - _t(g["b_pred_boxes"])).abs().max() < 1e-5
+
+
+def test_tie_aware_compare_counts_what_it_says():
+    """oracle/compare.py::tie_aware_compare on constructed decodes: identical inputs give zeros; a label flip is explained exactly when the
+    reference margin is below twice the stated logit error; two printing queries that trade places are explained exactly when their
+    reference cx differ by less than twice the stated cx error; the edit distance is over the strings of ALL queries."""
+    from oracle.compare import query_decisions, tie_aware_compare
+    C, nq = 12, 6
+
+    def make(labels, strength, cx):
+        """one class logit per query (the others at -12): label l prints when its logit is > 0 (p > 1 - p = the blank channel), the
+        decision margin is ~ |logit|; label -1 = every logit at -12 (blank with a large margin)"""
+        lg = torch.full((1, nq, C), -12.0)
+        bx = torch.zeros((1, nq, 4))
+        for i, (l, m, x) in enumerate(zip(labels, strength, cx)):
+            if l >= 0:
+                lg[0, i, l] = m
+            bx[0, i] = torch.tensor([x, 0.5, 0.01, 0.5])
+        return lg, bx
+
+    labels = [3, 4, -1, 5, -1, 6]
+    st = [2.0, 0.001, 0.0, 2.0, 0.0, 2.0]
+    cx = [0.10, 0.30, 0.50, 0.3001, 0.70, 0.90]
+    rl, rb = make(labels, st, cx)
+    lab, mar = query_decisions(rl, rb, 0.03)
+    assert lab[0].tolist() == labels and 5e-4 < float(mar[0, 1]) < 2e-3 and float(mar[0, 0]) > 1.0
+    same = tie_aware_compare(rl, rb, rl.clone(), rb.clone(), 0.03, 1e-3, 1e-4)
+    assert same["edit_distance"] == 0 and same["label_flips"] == 0 and same["order_swaps"] == 0 and same["unexplained"] == 0
+    assert same["chars_ref"] == 4 and abs(same["min_gap_px_2048"] - 0.0001 * 2048) < 1e-2
+    # (1) query 1 (margin ~0.001) drops to blank: explained at logit_err 1e-3 (2e-3 > margin), unexplained at 1e-4
+    st1 = list(st)
+    st1[1] = -0.001
+    gl, gb = make(labels, st1, cx)
+    r = tie_aware_compare(rl, rb, gl, gb, 0.03, 1e-3, 1e-4)
+    assert r["label_flips"] == 1 and r["label_flips_unexplained"] == 0 and r["edit_distance"] == 1 and r["unexplained"] == 0
+    r = tie_aware_compare(rl, rb, gl, gb, 0.03, 1e-4, 1e-4)
+    assert r["label_flips_unexplained"] == 1 and r["unexplained"] == 1
+    # (2) queries 1 and 3 (cx 0.3000 / 0.3001) trade places: explained at cx_err 1e-4 (gap 1e-4 < 2e-4), unexplained at 2e-5
+    cx2 = list(cx)
+    cx2[1], cx2[3] = 0.30012, 0.30008
+    gl, gb = make(labels, st, cx2)
+    r = tie_aware_compare(rl, rb, gl, gb, 0.03, 1e-3, 1e-4)
+    assert r["order_swaps"] == 1 and r["order_swaps_unexplained"] == 0 and r["label_flips"] == 0 and r["edit_distance"] == 2
+    r = tie_aware_compare(rl, rb, gl, gb, 0.03, 1e-3, 2e-5)
+    assert r["order_swaps_unexplained"] == 1 and r["unexplained"] == 1
+    # (3) a flip of a confident query is never explained
+    gl, gb = make([7, 4, -1, 5, -1, 6], st, cx)
+    r = tie_aware_compare(rl, rb, gl, gb, 0.03, 1e-2, 1e-4)
+    assert r["label_flips"] == 1 and r["label_flips_unexplained"] == 1
