@@ -19,14 +19,20 @@ timing       : W warm-up steps, then blocks of exactly K steps, each bracketed b
 data-parallel: the global batch is ONE seeded list of n_gpus x 32 lines; rank r owns the contiguous shard shard_bounds(r)
                (dtlr_amd/dist.py).  After the timed region rank 0 recomputes every shard itself and compares the all-gathered
                records bit for bit (`dp_verified`): N-rank output == single-process output on the same lines, in order.
-parity       : `cer_vs_oracle`: --parity-lines (8) lines of the benched batch are decoded by the CPU oracle (following the engine's
-               own query selection): max logit / box / cx error and the CER of the engine's strings against the oracle's over ALL
-               queries.  `by_dtype`: the same batch through the other two engines (bf16 = libdtlr_hip.so, f16 = libdtlr_hip_f16.so,
-               f32 = the exact-fp32 parity engine): a short timed block (lines/s) and the same parity leg each.
-roofline     : per kernel class, measured live with HIP events on the launch stream: MSDA inside the timed blocks, the MFMA
-               classes (GEMM / fused FFN / projection+norm) in a replay of the same steps right after them (an event pair per
-               launch inside the timed region would cost ~2.5 ms of stream time per step).  GEMM launches are also listed
-               per shape (`gemm_by_shape`), each with its MFMA fraction AND the HBM fraction of its compulsory bytes.
+parity       : `parity_vs_oracle` (oracle/parity.py): the CPU oracle runs --parity-lines (16) lines of the benched batch ONCE, with its
+               own two-stage selection; every engine is compared against that run twice: `free_running` = the engine's decoded strings
+               (its own selection) against the oracle's, as they come out -- `strings_identical_free_running: k/n`, no tolerance, no
+               accounting -- and `teacher_forced` = the oracle's decoder re-run on the engine's selection: max logit / box / cx error
+               against a FIXED per-engine budget (fp32-grade engines: north_star's 1e-3) and the strings on the same selection.
+               `by_dtype`: the same batch through the other engines (bf16 = libdtlr_hip.so, f16 = libdtlr_hip_f16.so, f32s = split
+               fp32, f32 = exact fp32): a short timed block (lines/s) and the same two legs each.
+roofline     : per KERNEL, measured live with HIP events on the launch stream: MSDA inside the timed blocks, the MFMA kernels (fused FFN,
+               GEMM, projection+norm) in a replay of the same steps right after them (an event pair per launch inside the timed region
+               would cost ~2.5 ms of stream time per step).  `roofline` = the single kernel with the largest share of the step
+               (`symbol` = its name in profiles/*_kernel_stats.csv, so achieved = algorithmic flops per launch / average launch time
+               can be recomputed from that file); `roofline_by_kernel` rows carry `symbol` when they are one kernel and
+               `class: true` when they aggregate several (the tiled GEMM's instantiations: listed per shape in `gemm_by_shape`,
+               each with its MFMA fraction AND the HBM fraction of its compulsory bytes).
                `traffic` = PMC-measured HBM bytes per launch (profiles/*_traffic.json: rocprofv3 --pmc FETCH_SIZE /
                WRITE_SIZE passes, gfx950 correction per MI355X_MICROARCH.md) when a measurement for that kernel is committed.
 cpu_baseline : SURVEY.md 8(d): the CPU oracle (oracle/dtlr_oracle.py, a port pinned to the reference through tests/golden;
@@ -192,38 +198,12 @@ def _sci(v: float) -> float:
     return float(f"{v:.3e}")
 
 
-def cer_vs_oracle(cfg, sd, x, mask, out, rows):
-    """Lines `rows` of the benched batch against the CPU oracle on the same canvas / masks, following the engine's own selection.
-    EVERY query is accounted for (oracle/compare.py::tie_aware_compare): `cer_all_queries` = edit distance of the decoded strings over
-    all 900 queries per line; a label may differ only where the oracle's decision margin is below twice the measured logit error, two
-    characters may trade places only if their oracle cx differ by less than twice the measured cx error; `unexplained` counts the
-    differences covered by neither and must be 0."""
-    from oracle import dtlr_oracle as O          # checker only
-    from oracle.compare import compare_decoded, tie_aware_compare
-    idx = out["_debug"]["topk_idx"][rows].cpu()
-    torch.set_num_threads(min(16, os.cpu_count() or 8))
-    ref = O.dino_forward(sd, cfg, x[rows].float().cpu(), mask=mask[rows].cpu(), forced_topk=idx)
-    got_l, got_b = out["pred_logits"][rows].float().cpu(), out["pred_boxes"][rows].float().cpu()
-    E = (got_l - ref["pred_logits"]).abs().max().item()
-    Eb = (got_b - ref["pred_boxes"]).abs().max().item()
-    Ecx = (got_b[..., 0] - ref["pred_boxes"][..., 0]).abs().max().item()
-    st = compare_decoded(ref["pred_logits"], ref["pred_boxes"], got_l, got_b, None, E, Ecx)       # reading order depends on cx only
-    ta = tie_aware_compare(ref["pred_logits"], ref["pred_boxes"], got_l, got_b, None, E, Ecx)
-    a = O.decode_blank(ref)
-    b = O.decode_blank({"pred_logits": got_l, "pred_boxes": got_b})
-    dist = sum(O.levenshtein(x_, y_) for x_, y_ in zip(a, b))
-    n = sum(len(x_) for x_ in a)
-    assert dist == ta["edit_distance"] and n == ta["chars_ref"], (dist, n, ta)      # two restatements of the decoder must agree
-    return {"lines": list(rows), "logit_err_max": _sci(E), "box_err_max": _sci(Eb), "cx_err_max": _sci(Ecx),
-            "logit_err_mean": _sci((got_l - ref["pred_logits"]).abs().mean().item()),
-            "cer_all_queries": round(dist / max(n, 1), 5), "chars_oracle": n, "edit_distance": dist,
-            "label_flips": ta["label_flips"], "label_flips_unexplained": ta["label_flips_unexplained"],
-            "order_swaps": ta["order_swaps"], "order_swaps_unexplained": ta["order_swaps_unexplained"], "unexplained": ta["unexplained"],
-            "min_char_gap_px": None if ta["min_gap_px_2048"] is None else round(ta["min_gap_px_2048"] * x.shape[-1] / 2048.0, 3),
-            "cer_safe_queries": 0.0 if (st["strings_equal"] and st["label_mismatch_on_safe"] == 0) else 1.0,
-            "safe_query_frac": round(st["safe_frac"], 4), "safe_chars": st["safe_chars"],
-            "note": "all 900 queries per line; flips / swaps are explained when the oracle margin < 2 x logit_err_max resp. the oracle cx gap < 2 x "
-                    "cx_err_max (oracle/compare.py); safe_* = the round-3 subset gate"}
+def parity_vs_oracle(ob, engine_name, out, rows, chinese=False):
+    """One engine's FREE-RUNNING outputs for lines `rows` of the benched batch against the oracle's run of the same lines
+    (oracle/parity.py::OracleBatch.compare): `free_running` (strings as they come out) and `teacher_forced` (arithmetic error on the
+    engine's own selection against the engine's fixed budget)."""
+    d = out["_debug"]
+    return ob.compare(engine_name, out["pred_logits"][rows], out["pred_boxes"][rows], d["topk_idx"][rows], d["topk_scores"][rows], chinese=chinese)
 
 
 def self_launch(args) -> int:
@@ -263,9 +243,13 @@ def main():
                     help="the timed engine: bf16 (BASELINE configs[1]), f16 (the fp16 build of the same kernels: same rate, 8x finer rounding), "
                          "f32s (fp32 activations, split fp16 products: parity-grade), f32 (exact-fp32 MFMA parity engine)")
     ap.add_argument("--no-other-dtypes", action="store_true", help="skip the short lines/s + parity legs of the two engines that are not --dtype")
-    ap.add_argument("--parity-lines", type=int, default=8, help="lines of the benched batch decoded by the CPU oracle (cer_vs_oracle)")
+    ap.add_argument("--parity-lines", type=int, default=16, help="lines of the benched batch the CPU oracle runs (parity_vs_oracle)")
+    ap.add_argument("--weights", default=None, help="a reference checkpoint (checkpoint.pth: {'model': state_dict}) instead of the name-seeded synthetic weights "
+                                                    "(BASELINE configs[2]); class count and backbone are taken from the tensors")
+    ap.add_argument("--images", default=None, help="a folder of line images (png / jpg): the first --batch x N of them (sorted by name) through the "
+                                                   "reference's eval transform replace the synthetic lines")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--no-parity", action="store_true", help="skip the cer_vs_oracle leg (two oracle forwards on the host)")
+    ap.add_argument("--no-parity", action="store_true", help="skip the parity_vs_oracle legs (an oracle forward of --parity-lines lines on the host)")
     ap.add_argument("--backend", default=None, help="torch.distributed backend (default nccl = RCCL); gloo for the single-GPU DP test")
     ap.add_argument("--single-device", action="store_true", help="all ranks use cuda:0 (tests: two ranks on one GPU need gloo)")
     ap.add_argument("--min-seconds", type=float, default=MIN_TIMED_SECONDS)
@@ -302,7 +286,14 @@ def main():
     if args.backbone:
         import dataclasses
         cfg = dataclasses.replace(cfg, backbone=args.backbone)
-    sd = weights.synthetic_state_dict(cfg, seed=0)
+    if args.weights:
+        # BASELINE configs[2]: a user-supplied checkpoint (none ships with the reference: README.md:63-71).  The class count comes from the tensors
+        import dataclasses
+        sd = weights.load_checkpoint_state_dict(args.weights)
+        cfg = dataclasses.replace(cfg, num_classes=weights.num_classes_of(sd))
+        log(f"--weights {args.weights}: {len(sd)} tensors, {cfg.num_classes} classes")
+    else:
+        sd = weights.synthetic_state_dict(cfg, seed=0)
     eng = DTLREngine(cfg, sd, dev, dtype, split=args.dtype == "f32s")
     for kv in args.engine_opt:
         k, _, v = kv.partition("=")
@@ -338,7 +329,29 @@ def main():
         return x.to(dev), m.to(dev)
 
     preproc_ms = None
-    if evalshape:
+    user_images = None
+    if args.images:
+        # BASELINE configs[2]: real line crops through the reference's eval transform (datasets/transforms.py:78-142) on the device, padded to
+        # one canvas with masks (util/misc.py:375-397); rank r takes files [lo, hi) of the sorted folder
+        from dtlr_amd.eval_harness import read_rgb
+        from dtlr_amd.transforms import preprocess_lines
+        names = sorted(f for f in os.listdir(args.images) if f.lower().endswith((".png", ".jpg", ".jpeg", ".bmp", ".tif", ".tiff")))
+        if len(names) < n_total:
+            raise SystemExit(f"--images {args.images}: {len(names)} images, {n_total} needed (--batch x --gpus)")
+        user_images = [os.path.join(args.images, f) for f in names[:n_total]]
+        nt = preprocess_lines([read_rgb(f) for f in user_images[lo:hi]], device=dev)
+        x, mask = nt.tensors, nt.mask
+        canvas_w = int(x.shape[3])
+
+        def to_batch(lines):                                  # noqa: F811
+            t = preprocess_lines(lines, device=dev)
+            if t.tensors.shape[2:] != x.shape[2:]:            # the dp self-check compares records only: any canvas is a valid padding of the same lines
+                log(f"shard canvas {tuple(t.tensors.shape[2:])} != rank 0's {tuple(x.shape[2:])}")
+            return t.tensors, t.mask
+
+        def make_lines(a, b):                                 # noqa: F811
+            return [read_rgb(f) for f in user_images[a:b]]
+    elif evalshape:
         # the reference's eval pipeline on the device: uint8 lines -> resize (Pillow's fixed-point bilinear, bit-exact) -> /255 -> normalise
         # -> pad + mask, ONE launch (dtlr_preprocess_lines); the timed step then runs on the resulting 83x1328 canvas
         from dtlr_amd.transforms import preprocess_lines
@@ -362,6 +375,13 @@ def main():
         imgs = make_lines(lo, hi)
         x, mask = to_batch(imgs)
     padded = chinese or mixed or bool(mask.any().item())
+    observed = None
+    if args.weights or args.images:
+        # what the synthetic generator only assumes: the backbone's activation peak (fp16 / split engines need < 65504)
+        # and how far the encoder's offset heads look (the LDS-window sampler's far fraction at a halo of 8 columns, per layer after calibration)
+        f_, l_, _hw = eng.features(x)
+        observed = {"backbone_activation_peak": float(max(t.float().abs().max() for t in list(f_) + [l_])), "canvas": [int(x.shape[2]), int(x.shape[3])]}
+        del f_, l_
 
     # --single-device: all ranks drive cuda:0 (the 2-ranks-on-one-GPU test; gloo, because RCCL refuses duplicate devices).  Their kernels
     # interleave freely on the device -- round 2 serialised the ranks through a file lock here because ~10% of forwards then differed;
@@ -453,7 +473,9 @@ def main():
         alg = msda_algorithmic_bytes_per_line(s, lq, velem) * n
         achieved = alg / (ms * 1e-3) / 1e9
         traffic = traffic_db.get(f"{args.dtype}_enc_bytes_per_launch") if traffic_ok else None
-        roof = {"bound": "hbm", "kernel": f"msda_enc_lds_kernel (deformable sampling, encoder call, Lq=S={s}/line)", "achieved": round(achieved, 1),
+        roof = {"bound": "hbm", "kernel": f"msda_enc_lds_kernel (deformable sampling, encoder call, Lq=S={s}/line)",
+                "symbol": "msda_enc_lds_kernel<unsigned short, unsigned short, 2, 512>" if velem == 2 else "msda_enc_lds_kernel<float, float, 3, 512>",
+                "achieved": round(achieved, 1),
                 "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
                 "algorithmic_bytes_per_launch": alg, "mean_launch_ms": round(ms, 4), "launches_timed": len(enc)}
         if dec:
@@ -471,8 +493,11 @@ def main():
     for ev in mfma_events:
         a, b, kind, flops, nbytes = ev[:5]
         tag = ev[5] if len(ev) > 5 else None
+        sym = ev[6] if len(ev) > 6 else None
         dt = a.elapsed_time(b)
-        c = classes.setdefault(kind, [0.0, 0.0, 0, 0.0])
+        # a launch that is ONE kernel is accounted under that kernel's symbol (and its token count: the encoder and decoder calls of a
+        # kernel are different launches in the rocprof summary's average, so they stay together here too); the rest per class
+        c = classes.setdefault((kind, sym), [0.0, 0.0, 0, 0.0])
         c[0] += dt; c[1] += flops; c[2] += 1; c[3] += nbytes
         if tag and kind.startswith("gemm"):
             s_ = shapes.setdefault((kind, tag), [0.0, 0.0, 0, 0.0])
@@ -491,15 +516,17 @@ def main():
         gbps = nbytes / (ms * 1e-3) / 1e9                        # compulsory operand + result bytes (each tensor once)
         return peak, ach, gbps, ach / peak, gbps / HBM_PEAK_GBS
 
-    for kind, (ms, flops, cnt, nbytes) in classes.items():
+    for (kind, sym), (ms, flops, cnt, nbytes) in classes.items():
         peak, ach, gbps, mf, hf = both_roofs(kind, ms, flops, nbytes)
         # SURVEY 8(d) labels every GEMM "MFMA-bound"; at K = 256 (128 flop/byte < 312) the binding roof is HBM.  Both fractions are
         # reported; `bound`/`achieved`/`peak`/`frac` name the larger (binding) one, `mfma_frac` is the 8(d) label's number.
+        label = (sym + ": " if sym else "") + names.get(kind, kind)
         if hf > mf:
-            head = {"bound": "hbm", "kernel": names.get(kind, kind), "achieved": round(gbps, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(hf, 4)}
+            head = {"bound": "hbm", "kernel": label, "achieved": round(gbps, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(hf, 4)}
         else:
-            head = {"bound": "mfma", "kernel": names.get(kind, kind), "achieved": round(ach, 1), "peak": peak, "unit": "TFLOP/s", "frac": round(mf, 4)}
-        by_kernel.append({**head, "traffic": traffic_db.get(f"{kind}_bytes_per_launch_mean") if traffic_ok else None, "mfma_tflops": round(ach, 1), "mfma_frac": round(mf, 4),
+            head = {"bound": "mfma", "kernel": label, "achieved": round(ach, 1), "peak": peak, "unit": "TFLOP/s", "frac": round(mf, 4)}
+        head["symbol" if sym else "class"] = sym if sym else True
+        by_kernel.append({**head, "traffic": traffic_db.get(f"{sym or kind}_bytes_per_launch_mean") if traffic_ok else None, "mfma_tflops": round(ach, 1), "mfma_frac": round(mf, 4),
                           "hbm_gbps_algorithmic": round(gbps, 1), "hbm_frac": round(hf, 4),
                           "algorithmic_flops_per_launch": round(flops / cnt), "algorithmic_bytes_per_launch": round(nbytes / cnt),
                           "mean_launch_ms": round(ms / cnt, 4), "launches_timed": cnt, "ms_per_step": round(ms / replay_steps, 3),
@@ -512,7 +539,8 @@ def main():
                               "ms_per_step": round(ms / replay_steps, 3), "mfma_tflops": round(ach, 1), "mfma_frac": round(mf, 4),
                               "hbm_gbps_algorithmic": round(gbps, 1), "hbm_frac": round(hf, 4), "traffic": traffic_db.get(f"gemm:{tag}") if traffic_ok else None})
     gemm_by_shape.sort(key=lambda r: -r["ms_per_step"])
-    dominant = by_kernel[0] if by_kernel else None
+    # `roofline` = the single KERNEL with the largest share of the step (class rows aggregate many instantiations: never the headline)
+    dominant = next((r for r in by_kernel if r.get("symbol")), by_kernel[0] if by_kernel else None)
     line = {
         "metric": ("text-lines/sec (Chinese 7356-class head, mixed-length 128x2560, bs=32)" if chinese else
                    "text-lines/sec (Latin, mixed widths padded to 128x2048, bs=32)" if mixed else
@@ -535,6 +563,9 @@ def main():
                    "library_backed_ops": sorted(ops.LIBRARY_BACKED)},
         "distributed": {"backend": tdist.get_backend() if (tdist.is_available() and tdist.is_initialized()) else None,
                         "world_size": tdist.get_world_size() if (tdist.is_available() and tdist.is_initialized()) else 1,
+                        # ranks in the RCCL communicator as torch.distributed reports them (backend "nccl" IS RCCL on ROCm): a first multi-GPU run describes itself
+                        "rccl_ranks": (tdist.get_world_size() if (tdist.is_available() and tdist.is_initialized() and tdist.get_backend() == "nccl") else 0),
+                        "devices_visible": torch.cuda.device_count(),
                         "dp_verified": dp_verified, "host_placement": placement},
         "roofline": dominant,
         # `traffic` figures are PMC measurements looked up from profiles/ (not taken in this run): the file and the commit they were measured at
@@ -571,19 +602,29 @@ def main():
         line["latency_ms_by_batch"] = {str(k): round(v, 3) for k, v in lat.items()}
         log(f"single-line latency: {lat}")
     rows = sorted({int(round(i * (B - 1) / max(args.parity_lines - 1, 1))) for i in range(min(args.parity_lines, B))})
+    ob = None
+    if observed is not None:
+        observed["msda_encoder_choice_by_layer"] = {k[0]: {kk: (round(vv, 5) if isinstance(vv, float) else vv) for kk, vv in v.items()}
+                                                    for k, v in eng._msda_state.items()}      # mode / halo / far fraction the calibration saw
+        line["observed_on_user_assets"] = observed
     if not args.no_parity:
         try:
+            from oracle.parity import OracleBatch          # the checker: never the product path
+            t0 = time.perf_counter()
+            ob = OracleBatch(cfg, sd, x[rows], mask[rows])
+            log(f"oracle free run of {len(rows)} lines: {time.perf_counter() - t0:.1f}s")
             (_, out) = local_step(debug=True)
             torch.cuda.synchronize()
             t0 = time.perf_counter()
-            line["cer_vs_oracle"] = cer_vs_oracle(cfg, sd, x, mask, out, rows)
-            log(f"cer_vs_oracle ({time.perf_counter() - t0:.1f}s): {line['cer_vs_oracle']}")
+            line["parity_vs_oracle"] = parity_vs_oracle(ob, args.dtype, out, rows, chinese)
+            line["parity_vs_oracle"]["rows"] = rows
+            log(f"parity_vs_oracle ({time.perf_counter() - t0:.1f}s): {line['parity_vs_oracle']}")
             del out
         except Exception as e:                                   # the parity leg must never cost the throughput line
-            line["cer_vs_oracle"] = {"error": repr(e)}
+            line["parity_vs_oracle"] = {"error": repr(e)}
     # ---- the other two engines on the SAME batch: a short timed block each + the same parity leg.  `value` above is --dtype's. ----
     by_dtype = {args.dtype: {"lines_per_s": line["value"], "ms_per_step": line["ms_per_step"], "steps_timed": total_steps,
-                             "cer_vs_oracle": line.get("cer_vs_oracle")}}
+                             "parity_vs_oracle": line.get("parity_vs_oracle")}}
     if world == 1 and not args.no_other_dtypes:
         del eng
         torch.cuda.empty_cache()
@@ -606,10 +647,10 @@ def main():
                 torch.cuda.synchronize()
                 dt2 = time.perf_counter() - t0
                 ent = {"lines_per_s": round(B * k2 / dt2, 2), "ms_per_step": round(dt2 / k2 * 1e3, 3), "steps_timed": k2}
-                if not args.no_parity:
+                if ob is not None:
                     _, o = step2(debug=True)
                     torch.cuda.synchronize()
-                    ent["cer_vs_oracle"] = cer_vs_oracle(cfg, sd, x, mask, o, rows)
+                    ent["parity_vs_oracle"] = parity_vs_oracle(ob, name, o, rows, chinese)
                     del o
                 by_dtype[name] = ent
                 log(f"engine {name}: {ent}")

@@ -1474,7 +1474,7 @@ extern "C" int dtlr_conv2d_nhwc(const void* X, const void* W, const float* bias,
     const int elem = dtype == DTLR_H16 ? 2 : (dtype == DTLR_F32 || dtype == DTLR_F32S) ? 4 : 0;
     if (!elem) return DTLR_EDTYPE;
     if ((Cin * elem) % SLAB) return DTLR_ESHAPE;                 // a K slab must stay inside one tap
-    ConvP cp;
+    ConvP cp{};                                                  // a2_rows = lda = res_rows = 0: the epilogue indexes the residual by row m itself
     cp.H = H; cp.W = Wd; cp.Cin = Cin; cp.KH = KH; cp.KW = KW; cp.stride = stride; cp.pad = pad;
     cp.Ho = (H + 2 * pad - KH) / stride + 1;
     cp.Wo = (Wd + 2 * pad - KW) / stride + 1;

@@ -92,10 +92,12 @@ MFMA_EVENTS_MIN_FLOPS = 2.0e9     # only launches this large are timed: an event
 
 class _Timed:
     """with _Timed(kind, flops): <launch>  -- records a HIP event pair around the launch when MFMA_EVENTS is a list."""
-    __slots__ = ("kind", "flops", "nbytes", "tag", "a", "st")
+    __slots__ = ("kind", "flops", "nbytes", "tag", "symbol", "a", "st")
 
-    def __init__(self, kind, flops, nbytes=0.0, tag=None):
-        self.kind, self.flops, self.nbytes, self.tag = kind, flops, nbytes, tag
+    def __init__(self, kind, flops, nbytes=0.0, tag=None, symbol=None):
+        # symbol = the ONE kernel this launch runs (as rocprofv3 names it), when the call is a single kernel: bench.py keys
+        # roofline_by_kernel by it so that each row can be recomputed from profiles/*_kernel_stats.csv
+        self.kind, self.flops, self.nbytes, self.tag, self.symbol = kind, flops, nbytes, tag, symbol
 
     def __enter__(self):
         self.a = None
@@ -109,7 +111,7 @@ class _Timed:
         if self.a is not None:
             b = torch.cuda.Event(enable_timing=True)
             b.record(self.st)
-            MFMA_EVENTS.append((self.a, b, self.kind, self.flops, self.nbytes, self.tag))
+            MFMA_EVENTS.append((self.a, b, self.kind, self.flops, self.nbytes, self.tag, self.symbol))
         return False
 
 
@@ -547,7 +549,7 @@ def ffn32(x, w1p, b1, w2p, b2, ln_w, ln_b, eps: float = 1e-5, out=None):
     y = torch.empty_like(x) if out is None else out
     assert y.is_contiguous() and y.shape == x.shape and y.dtype == x.dtype
     M = x.numel() // 256
-    with _Timed("ffn_fused_bf16", 4.0 * M * 256 * d_ff, 2.0 * M * 256 * 2 + 2.0 * 256 * d_ff * 2):
+    with _Timed("ffn_fused_bf16", 4.0 * M * 256 * d_ff, 2.0 * M * 256 * 2 + 2.0 * 256 * d_ff * 2, symbol="ffn3_bf16_kernel<0>"):
         code = _L(x).dtlr_ffn32_bf16(x.data_ptr(), w1p.data_ptr(), b1.data_ptr(), w2p.data_ptr(), b2.data_ptr(),
                                           ln_w.data_ptr(), ln_b.data_ptr(), eps, y.data_ptr(), M, d_ff, _lib.current_stream())
     _lib.check(code, "dtlr_ffn32_bf16")
@@ -565,7 +567,9 @@ def ffn_fused(x, w1, b1, w2p, b2, ln_w, ln_b, eps: float = 1e-5, out=None):
     y = torch.empty_like(x) if out is None else out
     assert y.is_contiguous() and y.shape == x.shape and y.dtype == x.dtype
     M = x.numel() // x.shape[-1]
-    with _Timed("ffn_fused_bf16", 4.0 * M * x.shape[-1] * w1.shape[0], 2.0 * M * 256 * 2 + 2.0 * w1.numel() * 2):
+    # dtlr_ffn_fused_bf16's dispatch (ffn.hip): one ffn2_bf16_kernel<3> launch for 32768 < M <= 49152, the first structure at or below
+    sym = "ffn2_bf16_kernel<3>" if 32768 < M <= 49152 else ("ffn_fused_bf16_kernel<0, false>" if M <= 32768 else None)
+    with _Timed("ffn_fused_bf16", 4.0 * M * x.shape[-1] * w1.shape[0], 2.0 * M * 256 * 2 + 2.0 * w1.numel() * 2, symbol=sym):
         code = _L(x).dtlr_ffn_fused_bf16(x.data_ptr(), w1.data_ptr(), b1.data_ptr(), w2p.data_ptr(), b2.data_ptr(),
                                               ln_w.data_ptr(), ln_b.data_ptr(), eps, y.data_ptr(), M, x.shape[-1], w1.shape[0],
                                               _lib.current_stream())
@@ -610,7 +614,7 @@ def ffn_split(x, wp, b1, b2, ln_w, ln_b, eps: float = 1e-5, out=None):
     y = torch.empty_like(x) if out is None else out
     assert y.is_contiguous() and y.shape == x.shape and y.dtype == x.dtype
     M = x.numel() // 256
-    with _Timed("ffn_fused_f32s", 4.0 * M * 256 * d_ff, 2.0 * M * 256 * 4 + 2.0 * 256 * d_ff * 4):
+    with _Timed("ffn_fused_f32s", 4.0 * M * 256 * d_ff, 2.0 * M * 256 * 4 + 2.0 * 256 * d_ff * 4, symbol="ffn_split_kernel"):
         code = _lib.lib().dtlr_ffn_split(x.data_ptr(), wp.data_ptr(), b1.data_ptr(), b2.data_ptr(), ln_w.data_ptr(), ln_b.data_ptr(),
                                          eps, y.data_ptr(), M, d_ff, _lib.current_stream())
     _lib.check(code, "dtlr_ffn_split")

@@ -485,30 +485,38 @@ def decoder_layer(sd, p, tgt, query_pos, ref_input, memory, spatial_shapes, padd
     return layer_norm(sd, p + ".norm3", tgt + ff)
 
 
-def transformer_forward(sd, cfg, srcs, masks, poss, forced_topk: Optional[Tensor] = None) -> Dict[str, Tensor]:
+def transformer_forward(sd, cfg, srcs, masks, poss, forced_topk: Optional[Tensor] = None,
+                        resume: Optional[Dict[str, Tensor]] = None) -> Dict[str, Tensor]:
     """DeformableTransformer.forward (deformable_transformer.py:257-429), inference branch
     (refpoint_embed=None, tgt=None, attn_mask=None).  `forced_topk` [B,nq] overrides the two-stage
     selection indices: used by parity tests to separate rounding-induced rank swaps of near-tied
-    scores (a discrete effect present between ANY two fp32 implementations) from arithmetic error."""
+    scores (a discrete effect present between ANY two fp32 implementations) from arithmetic error.
+    `resume` = the dict an earlier call on the SAME inputs returned: the encoder output is taken from it
+    (memory, masks, shapes are functions of the inputs only) and only the selection + decoder are
+    recomputed -- what makes a teacher-forced re-run of many lines affordable for the checkers."""
     t = "transformer."
-    src_f, mask_f, pos_f, shapes = [], [], [], []
-    for lvl, (src, mask, pos) in enumerate(zip(srcs, masks, poss)):
-        bs, c, h, w = src.shape
-        shapes.append((h, w))
-        src_f.append(src.flatten(2).transpose(1, 2))
-        mask_f.append(mask.flatten(1))
-        pos_f.append(pos.flatten(2).transpose(1, 2) + sd[t + "level_embed"][lvl].view(1, 1, -1))
-    src_flatten = torch.cat(src_f, 1)
-    mask_flatten = torch.cat(mask_f, 1)
-    lvl_pos = torch.cat(pos_f, 1)
-    spatial_shapes = torch.as_tensor(shapes, dtype=torch.long)
-    valid_ratios = torch.stack([get_valid_ratio(m) for m in masks], 1)
+    if resume is not None:
+        memory, mask_flatten = resume["memory"], resume["mask_flatten"]
+        spatial_shapes, valid_ratios = resume["spatial_shapes"], resume["valid_ratios"]
+    else:
+        src_f, mask_f, pos_f, shapes = [], [], [], []
+        for lvl, (src, mask, pos) in enumerate(zip(srcs, masks, poss)):
+            bs, c, h, w = src.shape
+            shapes.append((h, w))
+            src_f.append(src.flatten(2).transpose(1, 2))
+            mask_f.append(mask.flatten(1))
+            pos_f.append(pos.flatten(2).transpose(1, 2) + sd[t + "level_embed"][lvl].view(1, 1, -1))
+        src_flatten = torch.cat(src_f, 1)
+        mask_flatten = torch.cat(mask_f, 1)
+        lvl_pos = torch.cat(pos_f, 1)
+        spatial_shapes = torch.as_tensor(shapes, dtype=torch.long)
+        valid_ratios = torch.stack([get_valid_ratio(m) for m in masks], 1)
 
-    # ---- encoder (494-580) ----
-    ref = encoder_reference_points(spatial_shapes, valid_ratios)
-    memory = src_flatten
-    for n in range(cfg.enc_layers):
-        memory = encoder_layer(sd, f"{t}encoder.layers.{n}", memory, lvl_pos, ref, spatial_shapes, mask_flatten, cfg)
+        # ---- encoder (494-580) ----
+        ref = encoder_reference_points(spatial_shapes, valid_ratios)
+        memory = src_flatten
+        for n in range(cfg.enc_layers):
+            memory = encoder_layer(sd, f"{t}encoder.layers.{n}", memory, lvl_pos, ref, spatial_shapes, mask_flatten, cfg)
 
     # ---- two-stage query selection (320-363) ----
     output_memory, output_proposals = gen_encoder_output_proposals(memory, mask_flatten, spatial_shapes)
@@ -543,7 +551,7 @@ def transformer_forward(sd, cfg, srcs, masks, poss, forced_topk: Optional[Tensor
         intermediate.append(layer_norm(sd, t + "decoder.norm", output))
     return dict(hs=intermediate, references=ref_points, hs_enc=tgt_undetach, ref_enc=refpoint_undetach.sigmoid(),
                 init_box_proposal=init_box_proposal, topk_idx=topk_idx, topk_scores=topk_scores,
-                memory=memory, spatial_shapes=spatial_shapes, valid_ratios=valid_ratios)
+                memory=memory, spatial_shapes=spatial_shapes, valid_ratios=valid_ratios, mask_flatten=mask_flatten)
 
 
 # ======================================================================================
@@ -557,9 +565,14 @@ def input_proj_level(sd, l: int, x: Tensor, stride: int = 1, padding: int = 0) -
 
 @torch.no_grad()
 def dino_forward(sd: Dict[str, Tensor], cfg, samples, mask: Optional[Tensor] = None,
-                 forced_topk: Optional[Tensor] = None, return_debug: bool = False) -> Dict[str, Tensor]:
+                 forced_topk: Optional[Tensor] = None, return_debug: bool = False,
+                 resume: Optional[Dict[str, Tensor]] = None) -> Dict[str, Tensor]:
     """DINO.forward (models/dino/dino.py:270-415), eval, targets=None.
-    `samples`: [B,3,H,W] tensor (+ optional explicit mask) or list of [3,h,w] tensors."""
+    `samples`: [B,3,H,W] tensor (+ optional explicit mask) or list of [3,h,w] tensors.
+    `resume` = the `_debug` dict of an earlier call on the same samples (optionally row-sliced with
+    `resume_rows`): backbone and encoder are not recomputed, only selection + decoder + heads."""
+    if resume is not None:
+        return _dino_heads(sd, cfg, transformer_forward(sd, cfg, None, None, None, forced_topk, resume=resume), return_debug, {})
     if mask is None:
         x, mask = nested_tensor_from_tensor_list(samples)
     else:
@@ -582,6 +595,18 @@ def dino_forward(sd: Dict[str, Tensor], cfg, samples, mask: Optional[Tensor] = N
     poss.append(position_embedding_sine_hw(m, cfg.hidden_dim // 2, cfg.pe_temperatureH, cfg.pe_temperatureW))
 
     tr = transformer_forward(sd, cfg, srcs, masks, poss, forced_topk)
+    return _dino_heads(sd, cfg, tr, return_debug, dict(srcs=srcs, masks=masks, poss=poss, feats=feats))
+
+
+def resume_rows(debug: Dict[str, Tensor], rows) -> Dict[str, Tensor]:
+    """the `resume` argument of dino_forward for a subset of the lines of an earlier call"""
+    rows = torch.as_tensor(list(rows), dtype=torch.long)
+    return dict(memory=debug["memory"][rows], mask_flatten=debug["mask_flatten"][rows],
+                spatial_shapes=debug["spatial_shapes"], valid_ratios=debug["valid_ratios"][rows])
+
+
+def _dino_heads(sd, cfg, tr, return_debug, extra) -> Dict[str, Tensor]:
+    """dino.py:339-415: class / box heads of every decoder layer, the interm outputs."""
     hs, reference = tr["hs"], tr["references"]
     coords, classes = [], []
     for n in range(cfg.dec_layers):                                    # dino.py:339-354
@@ -595,7 +620,7 @@ def dino_forward(sd: Dict[str, Tensor], cfg, samples, mask: Optional[Tensor] = N
     out["interm_outputs_for_matching_pre"] = {"pred_logits": interm_class, "pred_boxes": tr["init_box_proposal"]}
     out["dn_meta"] = None
     if return_debug:
-        out["_debug"] = dict(tr, srcs=srcs, masks=masks, poss=poss, feats=feats)
+        out["_debug"] = dict(tr, **extra)
     return out
 
 

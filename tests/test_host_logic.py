@@ -207,6 +207,40 @@ def test_dp_all_gather_world_size_2_gloo(tmp_path):
     assert (tmp_path / "rank0.ok").exists() and (tmp_path / "rank1.ok").exists()
 
 
+_WORKER8 = r"""
+import os, sys, torch
+sys.path.insert(0, {root!r})
+from dtlr_amd import dist as D
+rank, local, world = D.init_from_env("gloo")
+assert world == 8
+n_total, nq = 250, 900                      # BASELINE configs[3]'s shape of the exchange (bs 256 over 8 ranks), RAGGED: 250 = 2 x 32 + 6 x 31
+g = torch.Generator().manual_seed(1)
+labels_all = torch.randint(-1, 166, (n_total, nq), generator=g, dtype=torch.int32)
+lens_all = torch.randint(0, nq + 1, (n_total,), generator=g, dtype=torch.int32)
+lo, hi = D.shard_bounds(n_total, rank, world)
+assert hi - lo == (32 if rank < 2 else 31)
+lab, ln = D.all_gather_records(labels_all[lo:hi].clone(), lens_all[lo:hi].clone(), n_total)
+assert lab.shape == (n_total, nq) and torch.equal(lab, labels_all) and torch.equal(ln, lens_all), rank
+assert D.max_over_ranks(float(rank + 1), torch.device("cpu")) == 8.0
+D.barrier()
+open(os.path.join({out!r}, f"rank{{rank}}.ok"), "w").write("ok")
+D.finalize()
+"""
+
+
+def test_dp_all_gather_world_size_8_ragged_gloo(tmp_path):
+    """The 8-rank job's only exchange on CPU: 250 lines (ragged: two ranks hold 32, six hold 31) x 900-query records through
+    all_gather_records == the global order on every rank; max_over_ranks over 8 ranks."""
+    script = tmp_path / "w8.py"
+    script.write_text(_WORKER8.format(root=ROOT, out=str(tmp_path)))
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT="29631", OMP_NUM_THREADS="1")
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "8",
+                        "--master-addr", "127.0.0.1", "--master-port", "29631", str(script)],
+                       capture_output=True, text=True, timeout=600, env=env)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
+    assert all((tmp_path / f"rank{k}.ok").exists() for k in range(8))
+
+
 def test_synthetic_inputs_deterministic():
     a, b = synth.stroke_lines(2, 32, [64, 48], seed=3), synth.stroke_lines(2, 32, [64, 48], seed=3)
     assert all(torch.equal(x, y) for x, y in zip(a, b))

@@ -252,3 +252,34 @@ def test_tie_aware_compare_counts_what_it_says():
     gl, gb = make([7, 4, -1, 5, -1, 6], st, cx)
     r = tie_aware_compare(rl, rb, gl, gb, 0.03, 1e-2, 1e-4)
     assert r["label_flips"] == 1 and r["label_flips_unexplained"] == 1
+
+
+def test_oracle_resume_and_parity_legs():
+    """oracle/parity.py on a constructed 'engine' (the oracle's own outputs, perturbed): dino_forward(resume=...) reproduces the full
+    forward bit for bit (also row-sliced, also teacher-forced); an unperturbed engine is identical on both legs; a logit error beyond
+    the fp32 budget fails the gate; a forced rank swap shows up in the free-running leg (rank_slots_changed) while the teacher-forced
+    leg, which follows the engine's selection, stays exact."""
+    from oracle import dtlr_oracle as O
+    from oracle.parity import OracleBatch
+    cfg = DTLRConfig.tiny()
+    sd = synthetic_state_dict(cfg, 0)
+    imgs = stroke_lines(3, 32, 256, seed=9)
+    x, m = torch.stack(imgs), torch.zeros(3, 32, 256, dtype=torch.bool)
+    ob = OracleBatch(cfg, sd, x, m, threads=4)
+    f, d = ob.free, ob.debug
+    again = O.dino_forward(sd, cfg, None, resume=d)
+    assert torch.equal(again["pred_logits"], f["pred_logits"]) and torch.equal(again["pred_boxes"], f["pred_boxes"])
+    sub = O.dino_forward(sd, cfg, None, forced_topk=d["topk_idx"][[0, 2]], resume=O.resume_rows(d, [0, 2]))
+    assert torch.equal(sub["pred_logits"], f["pred_logits"][[0, 2]])
+    same = ob.compare("f32s", f["pred_logits"], f["pred_boxes"], d["topk_idx"], d["topk_scores"])
+    assert same["parity_gate"] and same["free_running"]["strings_identical_free_running"] == "3/3"
+    assert same["teacher_forced"]["logit_err_max"] == 0.0 and same["free_running"]["rank_slots_changed"] == 0
+    off = ob.compare("f32s", f["pred_logits"] + 2e-3, f["pred_boxes"], d["topk_idx"], d["topk_scores"])
+    assert not off["teacher_forced"]["within_budget"] and not off["parity_gate"]
+    assert ob.compare("bf16", f["pred_logits"] + 2e-3, f["pred_boxes"], d["topk_idx"], d["topk_scores"])["parity_gate"]      # inside the bf16 budget
+    idx = d["topk_idx"].clone()
+    idx[:, [0, 1]] = idx[:, [1, 0]]                                # ranks 0 and 1 trade places: the two queries trade tgt_embed rows
+    sw = O.dino_forward(sd, cfg, None, forced_topk=idx, resume=d)
+    r = ob.compare("f32", sw["pred_logits"], sw["pred_boxes"], idx, d["topk_scores"])
+    assert r["free_running"]["rank_slots_changed"] == 6 and r["free_running"]["lines_with_identical_selection"] == 0
+    assert r["teacher_forced"]["logit_err_max"] == 0.0 and r["teacher_forced"]["strings_identical_same_selection"] == "3/3"

@@ -3,7 +3,7 @@
 # stats, secondary configurations.  Outputs land in gpurun_out/ (copy what should be judged into profiles/).
 # usage: [BENCH_EXTRA="--no-cpu-baseline"] [ROUND=r04] bash tools/final_check.sh <tag> [prof-only|no-tests]
 TAG=${1:-vX}
-R4=${ROUND:-r04}
+R4=${ROUND:-r05}
 cd ${GRAFT_REPO_ROOT:-.}
 mkdir -p gpurun_out
 if [ "$2" != "prof-only" ]; then
@@ -23,8 +23,8 @@ if [ "$2" != "prof-only" ]; then
 import json
 try:
     d=json.loads(open('gpurun_out/${R4}_bench_${nm}_$TAG.json').read().strip().splitlines()[-1])
-    c=d.get('cer_vs_oracle') or {}
-    print('$nm', d['value'], d['ms_per_step'], {k:c.get(k) for k in ('logit_err_max','cx_err_max','cer_all_queries','unexplained')})
+    c=d.get('parity_vs_oracle') or {}
+    print('$nm', d['value'], d['ms_per_step'], c.get('teacher_forced'), (c.get('free_running') or {}).get('strings_identical_free_running'))
 except Exception as e: print('$nm', 'failed', e)
 P
   done
