@@ -140,6 +140,16 @@ template <> struct GT<float> {
 // (fp16 hi); every activation of this network is a post-normalisation value, a ReLU of one or a frozen-BN'd convolution output.
 struct f32s_t { float v; };
 template <typename T> constexpr bool kSplit = std::is_same<T, f32s_t>::value;
+// XOR swizzle of the 16-byte chunks of LDS row r.  16-bit / fp32 operands: r & 7 (every ds_read_b128 service group lands on 16 distinct
+// slots; their loaders write whole 128-byte rows).  Split operands: the activation loader writes a row's hi and lo halves as 8-byte stores
+// (ds_write_b64: 16 CONTIGUOUS lanes per service group = rows r, r + 1, banks taken modulo 128 bytes), and with r & 7 both rows put their
+// four hi chunks on the same 64 bytes -- a 2-way conflict on every store, the constant ~20% conflict share of the split GEMM's LDS cycles
+// (profiles/r04_sq_f32s_v1.txt).  Toggling chunk bit 2 with the row's parity sends the odd row's hi chunks to the other 64 bytes: stores
+// conflict-free, reads still 16 distinct slots per group (tools/lds_bank_model.py enumerates both).
+template <typename T> __device__ __forceinline__ int lds_swz(int r) {
+    if constexpr (kSplit<T>) return (r & 7) ^ ((r & 1) << 2);
+    else return r & 7;
+}
 typedef __attribute__((ext_vector_type(8))) _Float16 f16x8_t;
 typedef __attribute__((ext_vector_type(2))) _Float16 f16x2_t;
 template <> struct GT<f32s_t> {
@@ -626,9 +636,9 @@ __global__ __launch_bounds__(512, HAS_A2 ? 2 : 4) void gemm_ws_kernel(
         // ================================ loader role ================================
         const int tid = threadIdx.x - 256;
         const int srow = tid >> 3, kc = tid & 7;
-        const int lds0 = srow * LDS_ROW + ((kc ^ (srow & 7)) * 16);
+        const int lds0 = srow * LDS_ROW + ((kc ^ lds_swz<T>(srow)) * 16);
         // split operands: this lane's 4 k (4 kc ..) land in half kc & 1 of chunk kc >> 1 (hi) and of chunk 4 + (kc >> 1) (lo)
-        const int xh_ = (((kc >> 1) ^ (srow & 7)) * 16) + (kc & 1) * 8, xl_ = (((4 + (kc >> 1)) ^ (srow & 7)) * 16) + (kc & 1) * 8;
+        const int xh_ = (((kc >> 1) ^ lds_swz<T>(srow)) * 16) + (kc & 1) * 8, xl_ = (((4 + (kc >> 1)) ^ lds_swz<T>(srow)) * 16) + (kc & 1) * 8;
         (void)xh_; (void)xl_;
         long a_off[4], w_off[4], a2_off[4];
         int hi0[4], wi0[4];
@@ -773,7 +783,7 @@ __global__ __launch_bounds__(512, HAS_A2 ? 2 : 4) void gemm_ws_kernel(
         uint4 wf[2][4], xf[2][4];
 #pragma unroll
         for (int kq = 0; kq < 2; ++kq) {
-            const int sw = (((kq * 4 + g) ^ (n & 7)) * 16);
+            const int sw = (((kq * 4 + g) ^ lds_swz<T>(n)) * 16);        // rows i * 16 + n: same low three bits as n
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
                 wf[kq][i] = *reinterpret_cast<const uint4*>(wt + i * 16 * LDS_ROW + sw);
@@ -848,7 +858,7 @@ __global__ __launch_bounds__(TallCfg<TBN>::NT, TBN == 64 ? ((kSplit<T> && CONV) 
         // ================================ loader role ================================
         const int tid = threadIdx.x - NMW * 64;
         const int srow = tid >> 3, kc = tid & 7;
-        const int lds0 = srow * LDS_ROW + ((kc ^ (srow & 7)) * 16);
+        const int lds0 = srow * LDS_ROW + ((kc ^ lds_swz<T>(srow)) * 16);
         const int slabs_per_tap = CONV ? (cp.Cin * (int)sizeof(T)) / SLAB : 1;
         const char* Ab = reinterpret_cast<const char*>(A);
         const char* Wb = reinterpret_cast<const char*>(W);
@@ -903,7 +913,7 @@ __global__ __launch_bounds__(TallCfg<TBN>::NT, TBN == 64 ? ((kSplit<T> && CONV) 
             for (int i = 0; i < WL; ++i) *reinterpret_cast<uint4*>(wt + i * 32 * LDS_ROW) = rw[S][i];
             if constexpr (kSplit<T>) {      // fp32 activations -> fp16 hi | lo halves of the row (see GT<f32s_t>)
                 unsigned char* xs = smem + stage * TALL_STAGE + (TBN + srow) * LDS_ROW;
-                const int xh = (((kc >> 1) ^ (srow & 7)) * 16) + (kc & 1) * 8, xl = (((4 + (kc >> 1)) ^ (srow & 7)) * 16) + (kc & 1) * 8;
+                const int xh = (((kc >> 1) ^ lds_swz<T>(srow)) * 16) + (kc & 1) * 8, xl = (((4 + (kc >> 1)) ^ lds_swz<T>(srow)) * 16) + (kc & 1) * 8;
 #pragma unroll
                 for (int i = 0; i < 8; ++i) {
                     uint2 hi, lo;
@@ -968,7 +978,7 @@ __global__ __launch_bounds__(TallCfg<TBN>::NT, TBN == 64 ? ((kSplit<T> && CONV) 
         uint4 wf[2][4], xf[2][4];
 #pragma unroll
         for (int kq = 0; kq < 2; ++kq) {
-            const int sw = (((kq * 4 + g) ^ (n & 7)) * 16);
+            const int sw = (((kq * 4 + g) ^ lds_swz<T>(n)) * 16);
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
                 wf[kq][i] = *reinterpret_cast<const uint4*>(wt + i * 16 * LDS_ROW + sw);
