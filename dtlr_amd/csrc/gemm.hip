@@ -26,6 +26,7 @@
 //                 + residual, ReLU-after-residual (ResNet bottleneck tail), output fp32 or bf16.
 #include "dtlr_common.h"
 #include <cstdlib>
+#include <mutex>
 #include <type_traits>
 
 namespace dtlr {
@@ -124,8 +125,11 @@ template <> struct GT<float> {
 
 // ---- split-fp16 operands ("f32s", round 4): fp32-grade products at the 16-bit matrix rate / 3 ----------------------------------
 // The parity engine's GEMMs ran on v_mfma_f32_16x16x4_f32 (exact fp32, 1/16 of the 16-bit rate: 567 lines/s against 3556).  Here an
-// fp32 operand x is carried as TWO fp16 numbers, hi = fp16(x) and lo = fp16(x - hi) (x - hi is exact in fp32; |lo| <= 2^-11 |hi|, so
-// hi + lo holds 22 significand bits; gfx950's f16 MFMA keeps fp16 subnormals, so the pair is good down to |x| ~ 2^-14), and
+// fp32 operand x is carried as TWO fp16 numbers, hi = fp16(x) and lo = fp16(x - hi) (x - hi is exact in fp32; |lo| <= 2^-11 |hi|).
+// Precision of the pair: 22 significand bits while lo is a NORMAL fp16 number, i.e. for |x| >= 2^-3; below that lo is an fp16 subnormal
+// (gfx950's f16 MFMA keeps subnormal inputs -- measured) with the ABSOLUTE spacing 2^-24, so the pair carries x to 2^-25 absolute:
+// 2^-21 relative at |x| = 1/16 (the synthetic weights), ~2^-18 at |x| = 1e-2 (a trained checkpoint's typical weight), nothing below
+// 2^-25.  Activations are O(1) post-normalisation values (full 22 bits); the weights are where the floor shows.  And
 //     a . w  ~=  a_hi w_hi + a_lo w_hi + a_hi w_lo            (the dropped a_lo w_lo term is 2^-22 relative)
 // is three v_mfma_f32_16x16x32_f16 with fp32 accumulation: 48 matrix cycles per 32 k against 256 for the exact-fp32 MFMAs.
 //   * ACTIVATIONS stay fp32 in HBM (the residual streams, LayerNorm / GroupNorm inputs and the reference-point chain are never
@@ -135,8 +139,10 @@ template <> struct GT<float> {
 //     chunk 4 + g, the addresses the 16-bit kernel reads for its two k-halves -- are exactly its hi and lo B-fragments.
 //   * WEIGHTS are split ONCE (dtlr_split_pack_weights) into the same slab image, an array with the size and shape of the fp32
 //     weight: the loader copies it to LDS unchanged.
-// Error of a K-term product: ~2^-21 relative per term (representation 2^-22 each side + the dropped term) under fp32 accumulation
-// -- the fp32 engine's own accumulation-order noise; measured in tests/test_gpu_kernels.py against fp64.  Range: |x| < 65504
+// Error of one term: <= 2^-21 |a w| + 2^-24 (|a| + |w|) (representation + dropped term + the subnormal floor of the lo halves;
+// restated and swept in tests/test_host_logic.py) under fp32 accumulation; measured against fp64 in tests/test_gpu_kernels.py.
+// (Pre-scaling lo by 2^11 would lift the floor but needs a second accumulator set for the correction products: 64 more VGPRs in the
+// MFMA waves of a kernel that sits at its 128-register bound.)  Range: |x| < 65504
 // (fp16 hi); every activation of this network is a post-normalisation value, a ReLU of one or a frozen-BN'd convolution output.
 struct f32s_t { float v; };
 template <typename T> constexpr bool kSplit = std::is_same<T, f32s_t>::value;
@@ -1029,20 +1035,46 @@ static inline int plan_chain(long ntiles) {
 // tiles of K = 18432: 0.23 ms on 32 of 256 CUs).  KSPLIT copies of the tile grid each multiply a K range into an fp32
 // partial tile (slice s of a workspace); a second small kernel sums the slices and applies the epilogue.  Deterministic
 // (no atomics): the slices are added in index order.
-// one workspace per device (a process may drive several GPUs; the pointer of one is not addressable from another)
-static float* g_splitk_ws[64] = {};
-static size_t g_splitk_bytes[64] = {};
-static float* splitk_workspace(size_t bytes) {
+// One workspace per (device, STREAM) (round 5; it was per device): the partial tiles of a launch live in it until that launch's reduce
+// kernel has run, so two forwards a caller overlaps on two streams of one device must not share it -- with one buffer per device the
+// second forward's partial tiles would overwrite the first's between its two kernels (a silent wrong result; the engine itself uses
+// one stream and never hit it).  A slot is found by linear search (a handful of streams per process); buffers only grow.  hipFree waits
+// for the device, so no launch still reads a replaced buffer.  Under stream capture no allocation is possible: a stream without a slot
+// borrows the largest buffer of its device (a captured graph is one linear chain; overlapping its replays with other work on that
+// buffer's stream is the caller's to order), and with none the caller falls back to the plain (unsplit) launch.
+struct SplitKSlot { int dev; hipStream_t st; float* p; size_t bytes; };
+static SplitKSlot g_splitk_slots[64] = {};
+static int g_splitk_n = 0;
+static std::mutex g_splitk_mu;
+static float* splitk_workspace(size_t bytes, hipStream_t st) {
     int d = 0;
     (void)hipGetDevice(&d);
-    d &= 63;
-    if (bytes > g_splitk_bytes[d]) {
-        if (g_splitk_ws[d]) (void)hipFree(g_splitk_ws[d]);          // hipFree waits for the device: no launch still reads the old buffer
-        g_splitk_ws[d] = nullptr; g_splitk_bytes[d] = 0;
-        if (hipMalloc((void**)&g_splitk_ws[d], bytes) != hipSuccess) { (void)hipGetLastError(); return nullptr; }
-        g_splitk_bytes[d] = bytes;
+    std::lock_guard<std::mutex> lk(g_splitk_mu);
+    SplitKSlot* slot = nullptr;
+    SplitKSlot* biggest = nullptr;
+    for (int i = 0; i < g_splitk_n; ++i) {
+        SplitKSlot& s = g_splitk_slots[i];
+        if (s.dev != d) continue;
+        if (s.st == st) slot = &s;
+        if (!biggest || s.bytes > biggest->bytes) biggest = &s;
     }
-    return g_splitk_ws[d];
+    if (slot && slot->bytes >= bytes) return slot->p;
+    hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
+    if (hipStreamIsCapturing(st, &cap) != hipSuccess) { (void)hipGetLastError(); cap = hipStreamCaptureStatusNone; }
+    if (cap != hipStreamCaptureStatusNone)                       // capturing: borrow, never allocate
+        return (biggest && biggest->bytes >= bytes) ? biggest->p : nullptr;
+    if (!slot) {
+        if (g_splitk_n < 64) slot = &g_splitk_slots[g_splitk_n++];
+        else { slot = &g_splitk_slots[0]; for (int i = 1; i < 64; ++i) if (g_splitk_slots[i].bytes < slot->bytes) slot = &g_splitk_slots[i]; }   // table full: recycle the smallest
+        if (slot->p && slot->dev != d) { int cur = d; (void)hipSetDevice(slot->dev); (void)hipFree(slot->p); (void)hipSetDevice(cur); slot->p = nullptr; }
+        slot->dev = d; slot->st = st;
+        if (!slot->p) slot->bytes = 0;
+    }
+    if (slot->p) (void)hipFree(slot->p);
+    slot->p = nullptr; slot->bytes = 0;
+    if (hipMalloc((void**)&slot->p, bytes) != hipSuccess) { (void)hipGetLastError(); slot->p = nullptr; return nullptr; }
+    slot->bytes = bytes;
+    return slot->p;
 }
 static inline int plan_split(long nwg, int nk) {
     if (nwg >= 96 || nk < 16) return 1;
@@ -1095,7 +1127,7 @@ static int try_splitk(const void* A, const void* W, const float* bias, const voi
     const int nk = K / GT<T>::BK;
     const int S = plan_split((long)nM * nN, nk);
     if (S <= 1 || (N & 3)) return DTLR_OK;
-    float* ws = splitk_workspace((size_t)S * M * N * sizeof(float));
+    float* ws = splitk_workspace((size_t)S * M * N * sizeof(float), st);
     if (!ws) return DTLR_OK;                                     // no workspace: fall back to the plain path
     const size_t lds = 4 * TILE_BYTES;
     static DevOnce attr;

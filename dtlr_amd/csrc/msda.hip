@@ -178,6 +178,10 @@ __device__ __forceinline__ void sample_level4(const T* __restrict__ base, int H,
             // below becomes zero, which is the reference's `inside` test) and each separable factor depends on ONE unsigned compare that is
             // consumed by the next instruction; an invalid corner has a zero WEIGHT on a clamped (valid, finite) address.  Products of the
             // valid corners are bit-identical to the first form (same expression order: hh * hw, ...).
+            // CONTRACT that follows (include/dtlr_hip.h, dtlr_msda_forward): `value` must be FINITE.  A corner outside the map multiplies the
+            // clamped BORDER pixel by a zero weight, where the reference does not read at all (cuh:49-70): an inf / NaN stored in a border
+            // pixel therefore reaches outputs the reference would keep finite (0 * inf = NaN).  Every producer of `value` in this engine
+            // is a projection of a normalised stream; the fp16 engine saturates instead of overflowing (FP16_OVFL / the staging clamps).
             const float h_im = __builtin_amdgcn_fmed3f(ly[p] * (float)H - 0.5f, -1.f, (float)H);      // NaN -> -1: zero weights
             const float w_im = __builtin_amdgcn_fmed3f(lx[p] * (float)W - 0.5f, -1.f, (float)W);
             const float hf = floorf(h_im), wf = floorf(w_im);

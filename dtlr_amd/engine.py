@@ -41,7 +41,10 @@ class DTLREngine:
         """`split=True` (with dtype float32): the parity-grade engine at the 16-bit matrix rate / 3 -- activations, residual streams,
         normalisation inputs and the box chain stay fp32 exactly as in the fp32 engine, but every GEMM / convolution weight is packed
         as a split fp16 hi + lo image (ops.split_pack) and multiplied by the DTLR_F32S kernels (three fp16 MFMAs per product, fp32
-        accumulation: ~2^-21 relative instead of the 16-bit engines' 2^-9 / 2^-12 per rounding point)."""
+        accumulation: operands carried to 22 bits for |x| >= 2^-3 and to 2^-25 absolute below that -- ~2^-21 relative at the synthetic weights'
+        scale, ~2^-18 at a trained checkpoint's ~1e-2 -- instead of the 16-bit engines' 2^-9 / 2^-12 per rounding point).
+        Range guard: the fp16 hi halves saturate at 65504; the engine checks the backbone's output maps on its FIRST forward only
+        (one host read), so a later batch with larger activations is the caller's to watch (`check_activation_range()` re-arms it)."""
         cfg.validate()
         self.cfg, self.device, self.dtype = cfg, torch.device(device), dtype
         self.split = bool(split)
@@ -80,6 +83,10 @@ class DTLREngine:
         self.use_l2_cat = True            # 16-bit: layer2.0's strided shortcut convolution as extra K columns of its tail GEMM
         self.use_ow_resbcast = True       # fp32 / split: the encoder's [offsets | logits] projection as src W^T + (pos W^T + b), unpadded batches
         self._range_check_pending = (dtype == torch.float16) or self.split      # engines whose operands are fp16: see forward()
+
+    def check_activation_range(self) -> None:
+        """re-arm the fp16-range check of the f16 / f32s engines for the next forward (it runs on the first forward only: a host sync)"""
+        self._range_check_pending = (self.dtype == torch.float16) or self.split
 
     # ------------------------------------------------------------------------------ packing
     def _put(self, name, t, dtype=None):

@@ -29,8 +29,9 @@ extern "C" {
 #define DTLR_F64 1
 #define DTLR_BF16 2
 #define DTLR_F16 3    /* IEEE fp16: accepted by libdtlr_hip_f16.so (the same sources built with -DDTLR_HALF_IS_F16) wherever libdtlr_hip.so accepts DTLR_BF16 */
-#define DTLR_F32S 4   /* "split fp32": fp32 activations / results in memory, products as three fp16 MFMAs on hi + lo halves (fp32-grade, ~2^-21
-                         relative; 16/3 x the rate of the exact-fp32 MFMA).  Accepted as the input dtype of dtlr_gemm_nt / _a2bcast / _rowmax(_lda)
+#define DTLR_F32S 4   /* "split fp32": fp32 activations / results in memory, products as three fp16 MFMAs on hi + lo halves (per term <= 2^-21 |a w| +
+                         2^-24 (|a| + |w|): 22-bit operands down to |x| = 2^-3, an absolute floor of 2^-25 below -- ~18 bits at |w| = 1e-2;
+                         16/3 x the rate of the exact-fp32 MFMA).  Accepted as the input dtype of dtlr_gemm_nt / _a2bcast / _rowmax(_lda)
                          and dtlr_conv2d_nhwc; the weight argument is then the image written by dtlr_split_pack_weights (same size as the
                          fp32 weight).  |activation| must stay below 65504. */
 
@@ -52,6 +53,9 @@ int dtlr_abi_version(void);
  * out[b,q,m,:] = sum_l sum_p attn * bilinear(value_l[b,:,m,:], (x*W-0.5, y*H-0.5)), zero padding.
  * No im2col_step: the whole batch is one launch (the reference's chunk loop, cu:50-75, is a CUDA
  * grid-size workaround; its divisibility check is kept in the Python binding).
+ * `value` must be finite: the fused forms (Lq x L x P = 4 x 4 front ends) give a corner outside the map a ZERO
+ * WEIGHT on the clamped border pixel where the reference skips the read (cuh:49-70), so an inf / NaN stored in a
+ * border pixel turns outputs the reference keeps finite into NaN.
  */
 int dtlr_msda_forward(const void *value, const int64_t *shapes, const int64_t *level_start_index,
                       const void *loc, const void *attn,

@@ -266,6 +266,33 @@ def test_conv2d_nhwc_implicit_gemm(B, H, W, Cin, Cout, k, stride, pad, half):
         assert (gotb - refb).abs().max() < ulp(half, 8) * max(1.0, refb.abs().max().item()) + 1e-4
 
 
+def test_splitk_convolutions_overlapped_on_two_streams():
+    """Round 5: the split-K workspace is per (device, stream).  Two DIFFERENT split-K convolutions (input_proj[3]'s shape: 3x3 / 2 on a
+    4 x 64 map, K = 18432) issued back to back on two HIP streams, repeatedly, with nothing ordering the streams: each must equal its own
+    single-stream result bit for bit (with one workspace per device the second launch's partial tiles overwrote the first's between
+    its two kernels whenever the streams overlapped)."""
+    from dtlr_amd import ops
+    xs = [_rand((1, 4, 64, 2048), 11 + i).cuda() for i in range(2)]
+    ws = [(_rand((256, 3, 3, 2048), 21 + i) / np.sqrt(9 * 2048)).cuda() for i in range(2)]
+    bs = [_rand((256,), 31 + i).cuda() for i in range(2)]
+    want = [ops.conv2d_nhwc(xs[i], ws[i], bs[i], 2, 1, False, None) for i in range(2)]
+    torch.cuda.synchronize()
+    streams = [torch.cuda.Stream(), torch.cuda.Stream()]
+    for st in streams:                                             # each stream's workspace slot is allocated here, outside the race
+        with torch.cuda.stream(st):
+            ops.conv2d_nhwc(xs[0], ws[0], bs[0], 2, 1, False, None)
+    torch.cuda.synchronize()
+    bad = 0
+    for rep in range(40):
+        outs = []
+        for i, st in enumerate(streams):
+            with torch.cuda.stream(st):
+                outs.append(ops.conv2d_nhwc(xs[i], ws[i], bs[i], 2, 1, False, None))
+        torch.cuda.synchronize()
+        bad += sum(int(not torch.equal(outs[i], want[i])) for i in range(2))
+    assert bad == 0, f"{bad} of 80 overlapped launches differ from their single-stream result"
+
+
 def test_decoder_query_prep_and_box_refine_vs_oracle(half):
     """Fused decoder glue == oracle gen_sineembed_for_position / reference scaling / inverse_sigmoid refinement."""
     from dtlr_amd import ops
