@@ -198,6 +198,28 @@ def _sci(v: float) -> float:
     return float(f"{v:.3e}")
 
 
+V4_PARITY_LINES = 8
+
+
+def free_running_v4(cfg, sd4, ob4, engine_name, dtype, dev, x, mask, rows4, padded):
+    """The free-running leg proper: the engine `engine_name` rebuilt on generator-v4 weights (dtlr_amd/weights.py: identical content queries,
+    characters read from the image -- rank-invariant like a trained recogniser) on lines `rows4` of the benched batch, against the oracle's own
+    run of the same weights and lines (ob4).  Strings as they come out: `strings_identical_free_running` k/n and `cer_free_running`."""
+    from dtlr_amd.engine import DTLREngine
+    from dtlr_amd.evaluation import decode_blank_records      # noqa: F401  (the product decoder runs inside compare() through the oracle's restatement of it on the engine's outputs)
+    e4 = DTLREngine(cfg, sd4, dev, dtype, split=engine_name == "f32s")
+    out = e4.forward(x[rows4].contiguous(), mask[rows4].contiguous(), has_padding=padded, return_debug=True)
+    torch.cuda.synchronize()
+    d = out["_debug"]
+    all_rows = list(range(len(rows4)))
+    r = ob4.compare(engine_name, out["pred_logits"][all_rows], out["pred_boxes"][all_rows], d["topk_idx"][all_rows], d["topk_scores"][all_rows], budgeted=False)
+    r["rows"] = list(rows4)
+    r["weights"] = "generator v4 (rank-invariant content queries, image-driven characters)"
+    del e4, out
+    torch.cuda.empty_cache()
+    return r
+
+
 def parity_vs_oracle(ob, engine_name, out, rows, chinese=False):
     """One engine's FREE-RUNNING outputs for lines `rows` of the benched batch against the oracle's run of the same lines
     (oracle/parity.py::OracleBatch.compare): `free_running` (strings as they come out) and `teacher_forced` (arithmetic error on the
@@ -618,13 +640,28 @@ def main():
             t0 = time.perf_counter()
             line["parity_vs_oracle"] = parity_vs_oracle(ob, args.dtype, out, rows, chinese)
             line["parity_vs_oracle"]["rows"] = rows
+            line["parity_vs_oracle"]["weights"] = f"generator v{weights.GENERATOR_VERSION} (the benched weights; characters planted per selection rank)" if not args.weights else args.weights
             log(f"parity_vs_oracle ({time.perf_counter() - t0:.1f}s): {line['parity_vs_oracle']}")
             del out
         except Exception as e:                                   # the parity leg must never cost the throughput line
             line["parity_vs_oracle"] = {"error": repr(e)}
+    # ---- free-running leg on generator-v4 weights (Latin only: the generator's calibration), every engine against ONE oracle run
+    ob4 = sd4 = None
+    rows4 = sorted({int(round(i * (B - 1) / max(V4_PARITY_LINES - 1, 1))) for i in range(min(V4_PARITY_LINES, B))})
+    if not args.no_parity and args.config == "latin" and not args.backbone and not args.weights and not args.images:
+        try:
+            from oracle.parity import OracleBatch
+            t0 = time.perf_counter()
+            sd4 = weights.synthetic_state_dict(cfg, seed=0, version=4)
+            ob4 = OracleBatch(cfg, sd4, x[rows4], mask[rows4])
+            log(f"oracle free run, generator v4, {len(rows4)} lines: {time.perf_counter() - t0:.1f}s; characters per line {[len(s_) for s_ in ob4.strings]}")
+            line["free_running_v4"] = free_running_v4(cfg, sd4, ob4, args.dtype, dtype, dev, x, mask, rows4, padded)
+            log(f"free_running_v4: {line['free_running_v4']}")
+        except Exception as e:
+            line["free_running_v4"] = {"error": repr(e)}
     # ---- the other two engines on the SAME batch: a short timed block each + the same parity leg.  `value` above is --dtype's. ----
     by_dtype = {args.dtype: {"lines_per_s": line["value"], "ms_per_step": line["ms_per_step"], "steps_timed": total_steps,
-                             "parity_vs_oracle": line.get("parity_vs_oracle")}}
+                             "parity_vs_oracle": line.get("parity_vs_oracle"), "free_running_v4": line.get("free_running_v4")}}
     if world == 1 and not args.no_other_dtypes:
         del eng
         torch.cuda.empty_cache()
@@ -652,6 +689,11 @@ def main():
                     torch.cuda.synchronize()
                     ent["parity_vs_oracle"] = parity_vs_oracle(ob, name, o, rows, chinese)
                     del o
+                if ob4 is not None:
+                    del e2
+                    e2 = None
+                    torch.cuda.empty_cache()
+                    ent["free_running_v4"] = free_running_v4(cfg, sd4, ob4, name, DT[name], dev, x, mask, rows4, padded)
                 by_dtype[name] = ent
                 log(f"engine {name}: {ent}")
                 del e2

@@ -14,6 +14,12 @@ tokens whose two-stage scores differ by less than the score error of an implemen
 That happens between any two fp32 implementations (the reference on CPU vs on CUDA too).  `self_sensitivity` puts a number on it
 for the weights at hand: the ORACLE against ITSELF with its selection scores perturbed by the engine's measured score error.
 
+Weights: the teacher-forced budgets are stated for generator v2 (the goldens' weights), whose characters are planted per selection RANK --
+which makes v2's free-running strings a measure of rank swaps, not of arithmetic (a 16-bit engine: ~90% CER; the oracle against itself at
+1e-5 score noise: half of the strings).  The free-running leg that says something about the engine runs on generator v4
+(dtlr_amd/weights.py: identical content queries, characters read from the image by one-shot detector units -- rank-invariant like a trained
+recogniser): there the strings must simply be equal for an fp32-grade engine.
+
 The a-priori error budgets (north_star: logits within 1e-3 for the fp32-grade engines; the stated bounds of the 16-bit engines) are
 the gate -- fixed numbers, not derived from the measured error."""
 from __future__ import annotations
@@ -71,8 +77,11 @@ class OracleBatch:
                 "lines_with_identical_selection": int((idx == self.debug["topk_idx"]).all(1).sum())}
 
     def compare(self, engine: str, logits: torch.Tensor, boxes: torch.Tensor, topk_idx: torch.Tensor,
-                topk_scores: Optional[torch.Tensor] = None, chinese: bool = False, sensitivity: bool = True) -> Dict[str, object]:
-        """`logits` / `boxes` / `topk_idx` (/ `topk_scores`) = the engine's FREE-RUNNING outputs for the same n lines."""
+                topk_scores: Optional[torch.Tensor] = None, chinese: bool = False, sensitivity: bool = True,
+                budgeted: bool = True) -> Dict[str, object]:
+        """`logits` / `boxes` / `topk_idx` (/ `topk_scores`) = the engine's FREE-RUNNING outputs for the same n lines.  `budgeted` False:
+        no error budget is applied (generator v4's detector units amplify a hidden-state error ~1e3-fold by design -- its purpose is the
+        free-running string comparison; the budgets belong to the v2 weights of the goldens)."""
         got = {"pred_logits": logits.float().cpu(), "pred_boxes": boxes.float().cpu()}
         idx = topk_idx.cpu().long()
         got_strings = O.decode_blank(got, self.eps)
@@ -108,6 +117,10 @@ class OracleBatch:
               "strings_identical_same_selection": f"{tsame}/{self.n}", "cer_same_selection": round(tdist / max(tn, 1), 5),
               "edit_distance": tdist, "chars_oracle": tn, "label_flips": int((rl != gl).sum()),
               "min_oracle_margin_on_flipped": (_sci(rm[rl != gl].min().item()) if bool((rl != gl).any()) else None)}
+        if not budgeted:
+            for k in ("logit_budget", "box_budget", "within_budget"):
+                tf.pop(k)
+            return {"lines": self.n, "free_running": free, "teacher_forced": tf}
         return {"lines": self.n, "free_running": free, "teacher_forced": tf,
                 # the north_star statement for this engine: logits within its budget AND identical strings on the same selection
                 "parity_gate": bool(tf["within_budget"] and tdist == 0) if engine in ("f32", "f32s") else bool(tf["within_budget"])}

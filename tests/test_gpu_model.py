@@ -323,6 +323,49 @@ def test_parity_engines_bench_batch_vs_oracle(engine):
     assert E.decode_blank(sub) == O_decode(sub)
 
 
+_ORACLE_BATCH_V4 = {}
+
+
+def _bench_oracle_batch_v4():
+    """generator-v4 weights (rank-invariant content queries, image-driven characters: dtlr_amd/weights.py) on BENCH_PARITY_ROWS of the bench batch"""
+    from oracle.parity import OracleBatch
+    if "ob" not in _ORACLE_BATCH_V4:
+        cfg = DTLRConfig.latin()
+        sd = weights.synthetic_state_dict(cfg, 0, version=4)
+        imgs = synth.noise_lines(32, 128, 2048, seed=1000)
+        x = torch.stack([imgs[r] for r in BENCH_PARITY_ROWS])
+        _ORACLE_BATCH_V4["ob"] = (OracleBatch(cfg, sd, x, torch.zeros(x.shape[0], 128, 2048, dtype=torch.bool)), cfg, sd, imgs)
+    return _ORACLE_BATCH_V4["ob"]
+
+
+# free-running CER bounds of the 16-bit engines on generator v4 (measured on MI355X in round 5; what differs is mostly the SET of selected
+# tokens at the 900-th score -- the oracle against itself at the same score error shows the same CER)
+V4_FREE_CER_BOUND = {"bf16": 0.30, "f16": 0.10}
+
+
+@pytest.mark.parametrize("engine", ["f32", "f32s", "f16", "bf16"])
+def test_free_running_strings_vs_oracle_on_image_driven_weights(engine):
+    """FREE-RUNNING, no teacher forcing, no tolerance: the engine with its own two-stage selection against the CPU oracle with ITS own, on
+    the bench batch (32 lines, 128x2048) with generator-v4 weights -- characters read from the image, identical content queries, so a rank
+    swap among near-tied tokens permutes queries without changing the decode (the property a trained recogniser has and v2's planted
+    characters lack).  fp32-grade engines: the decoded strings of the compared lines are IDENTICAL to the oracle's.  16-bit engines: CER
+    bounded (their score error moves ~50 of the 900 selected tokens per line across the cut)."""
+    ob, cfg, sd, imgs = _bench_oracle_batch_v4()
+    dt = {"f32": torch.float32, "f32s": "f32s", "f16": torch.float16, "bf16": torch.bfloat16}[engine]
+    m = _model(cfg, sd, dt)
+    out = m(torch.stack(imgs).cuda(), return_debug=True)
+    d = out["_debug"]
+    rows = BENCH_PARITY_ROWS
+    r = ob.compare(engine, out["pred_logits"][rows], out["pred_boxes"][rows], d["topk_idx"][rows], d["topk_scores"][rows], budgeted=False)
+    print(f"[{engine} free-running on v4 weights] {r}")
+    fr = r["free_running"]
+    assert sum(len(s_) for s_ in ob.strings) > 100                 # the lines do carry text
+    if engine in ("f32", "f32s"):
+        assert fr["edit_distance"] == 0 and fr["strings_identical_free_running"] == f"{len(rows)}/{len(rows)}", fr
+    else:
+        assert fr["cer_free_running"] < V4_FREE_CER_BOUND[engine], fr
+
+
 def O_decode(sub):
     from oracle import dtlr_oracle as O
     return O.decode_blank({k: v.float().cpu() for k, v in sub.items()})
