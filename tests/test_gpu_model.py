@@ -340,7 +340,7 @@ def _bench_oracle_batch_v4():
 
 # free-running CER bounds of the 16-bit engines on generator v4 (measured on MI355X in round 5; what differs is mostly the SET of selected
 # tokens at the 900-th score -- the oracle against itself at the same score error shows the same CER)
-V4_FREE_CER_BOUND = {"bf16": 0.30, "f16": 0.10}
+V4_FREE_CER_BOUND = {"bf16": 0.35, "f16": 0.10}      # measured: 0.264 / 0.035 on these four lines (0.269 / 0.062 on the bench's eight)
 
 
 @pytest.mark.parametrize("engine", ["f32", "f32s", "f16", "bf16"])
