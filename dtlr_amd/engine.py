@@ -392,19 +392,31 @@ class DTLREngine:
         (models/dino/backbone.py:97-106,118-120)."""
         # stem: own kernels for both engines, reading the NCHW fp32 image directly (bf16: MFMA; fp32: exact direct convolution);
         # the folded-BN shift, the ReLU and the max-pool run as ONE pass over the full-resolution map
-        if "conv1.frag" in self.w and self.use_stem_pool:      # 16-bit engines: convolution + shift + ReLU + max-pool in one kernel
-            x = ops.stem_conv7x7_pool(x_nchw, self.w["conv1.frag"], self.w["conv1.b"], self.dtype)
+        # (16-bit engines: convolution + shift + ReLU + max-pool in one kernel)
+        # (Round 5 tried the HBM-heavy front -- stem + layer1 + layer2, 268 MB maps at B = 32 -- per group of 4 / 8 / 16 images so that a
+        # producer's map would still be in the 256 MiB Infinity Cache when its consumer reads it: 8.66 -> 9.74 / 9.08 / 8.86 ms per step;
+        # the smaller launches lose more than the cache returns.  tools/experiments/gpu_calls/r05_call3.sh, profiles/r05_bb_group_c3.txt.)
+        x = self._stem(x_nchw)
+        return self._backbone_layers(x, 1, len(self.cfg.backbone_blocks))
+
+    def _stem(self, x_nchw):
+        if "conv1.frag" in self.w and self.use_stem_pool:
+            return ops.stem_conv7x7_pool(x_nchw, self.w["conv1.frag"], self.w["conv1.b"], self.dtype)
+        if "conv1.frag" in self.w:
+            x = ops.stem_conv7x7(x_nchw, self.w["conv1.frag"], self.dtype)
+        elif "conv1.fh" in self.w:
+            x = ops.stem_conv7x7_f32s(x_nchw, self.w["conv1.fh"], self.w["conv1.fl"])
         else:
-            if "conv1.frag" in self.w:
-                x = ops.stem_conv7x7(x_nchw, self.w["conv1.frag"], self.dtype)
-            elif "conv1.fh" in self.w:
-                x = ops.stem_conv7x7_f32s(x_nchw, self.w["conv1.fh"], self.w["conv1.fl"])
-            else:
-                x = ops.stem_conv7x7_f32(x_nchw, self.w["conv1.wk"])
-            x = ops.maxpool_nhwc(x, bias=self.w["conv1.b"], relu=True)
+            x = ops.stem_conv7x7_f32(x_nchw, self.w["conv1.wk"])
+        return ops.maxpool_nhwc(x, bias=self.w["conv1.b"], relu=True)
+
+    def _backbone_layers(self, x, li_from, li_to):
+        """bottleneck layers li_from..li_to (1-based, inclusive) on the NHWC map x; returns the maps of layers >= 2 among them"""
         outs = []
         pre = None                       # the NEXT bottleneck's conv1 output when the previous tail already computed it (layer1 chain)
         for li, nblocks in enumerate(self.cfg.backbone_blocks, start=1):
+            if li < li_from or li > li_to:
+                continue
             if li == 1 and self.use_l1_chain and x.dtype in ops.H16 and x.shape[-1] == 64 and x.numel() // 64 >= 16384 \
                     and self.w["l1.0.c3.w"].shape == (256, 64) and self.w["l1.0.ds.w"].shape == (256, 64):
                 x, pre = self._layer1_chain(x, nblocks)

@@ -18,6 +18,7 @@ def main():
     ap.add_argument("--batch", type=int, default=32)
     ap.add_argument("--dtype", default="bf16")
     ap.add_argument("--convs", action="store_true", help="also time every backbone convolution (name, shape, ms, GB/s, TFLOP/s)")
+    ap.add_argument("--engine-opt", action="append", default=[], metavar="NAME=VALUE", help="set a DTLREngine attribute (as bench.py --engine-opt)")
     args = ap.parse_args()
     from dtlr_amd import synth, weights
     from dtlr_amd.config import DTLRConfig
@@ -27,6 +28,9 @@ def main():
     dtype = {"bf16": torch.bfloat16, "f16": torch.float16, "f32": torch.float32, "f32s": torch.float32}[args.dtype]
     cfg = DTLRConfig.latin()
     eng = DTLREngine(cfg, weights.synthetic_state_dict(cfg, seed=0), dev, dtype, split=args.dtype == "f32s")
+    for kv in args.engine_opt:
+        k, _, v = kv.partition("=")
+        setattr(eng, k, type(getattr(eng, k))(int(v)) if isinstance(getattr(eng, k), (bool, int)) else float(v))
     x = torch.stack(synth.noise_lines(args.batch, 128, 2048, seed=1000)).to(dev)
     mask = torch.zeros((args.batch, 128, 2048), dtype=torch.bool, device=dev)
     spans = {}
