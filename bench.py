@@ -571,7 +571,7 @@ def main():
         "value": round(n_total * args.steps / elapsed, 2), "unit": "lines/s",
         "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": round(elapsed / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak",
-        "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
+        "vs_baseline": None, "dtype": args.dtype, "data": "synthetic" if not args.images else f"user images ({os.path.basename(os.path.normpath(args.images))})",
         "timed_blocks": len(blocks), "block_ms": [round(b * 1e3, 2) for b in blocks],
         "config": {"workload": (f"Latin DTLR (C=166) forward+decode, {B} synthetic lines per GPU, widths seeded from {{{canvas_w - 768}..{canvas_w}}}, zero-padded to {args.height}x{canvas_w} with masks"
                                 if mixed else
@@ -581,6 +581,8 @@ def main():
                                 if not chinese else
                                 f"Chinese DTLR (C=7356) forward+decode, {B} synthetic lines per GPU, widths seeded from {{{canvas_w - 1024}..{canvas_w}}}, zero-padded to {args.height}x{canvas_w} with masks")
                                + f", random-init name-seeded weights (generator v{weights.GENERATOR_VERSION})",
+                   "weights": args.weights or f"synthetic, generator v{weights.GENERATOR_VERSION}", "images": args.images or "synthetic noise lines (seed 1000)",
+                   "canvas": [int(x.shape[2]), int(x.shape[3])], "num_classes": cfg.num_classes,
                    "backbone": cfg.backbone, "engine_opts": args.engine_opt, "global_batch": n_total, "parallelism": f"dp{world}",
                    "library_backed_ops": sorted(ops.LIBRARY_BACKED)},
         "distributed": {"backend": tdist.get_backend() if (tdist.is_available() and tdist.is_initialized()) else None,

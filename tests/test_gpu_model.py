@@ -584,6 +584,41 @@ def test_bench_gpus_n_starts_its_own_ranks():
     assert bad.returncode != 0
 
 
+def test_bench_accepts_a_user_checkpoint_and_an_image_folder(tmp_path):
+    """BASELINE configs[2] the day its assets exist (round 5): `python bench.py --weights checkpoint.pth --images DIR` -- a reference-layout
+    checkpoint ({"model": state_dict}; here the synthetic Latin weights with a 97-class head written to disk) and a folder of line images
+    (PNG, sorted by name) through the reference's eval transform -- produces the one JSON line with the class count taken from the
+    tensors, the observed backbone activation peak / MSDA choice, and the parity legs against the oracle ON THOSE ASSETS (fp32 engine:
+    logits within 1e-3, identical strings on the same selection)."""
+    import dataclasses
+    import json
+    import subprocess
+    import sys
+    from PIL import Image
+    from tests.util import preproc_image
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    cfg = dataclasses.replace(DTLRConfig.latin(), num_classes=97)
+    torch.save({"model": weights.synthetic_state_dict(cfg, 2), "epoch": 7}, tmp_path / "checkpoint.pth")
+    img_dir = tmp_path / "lines"
+    img_dir.mkdir()
+    for k in range(5):                                             # one more than the batch: the first 4 by name are taken
+        Image.fromarray(preproc_image(96 + 8 * (k % 2), 1400 + 100 * k, 50 + k), "RGB").save(img_dir / f"line{k:02d}.png")
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT", "LOCAL_WORLD_SIZE")}
+    cmd = [sys.executable, os.path.join(root, "bench.py"), "--steps", "2", "--warmup", "1", "--batch", "4", "--dtype", "f32", "--weights",
+           str(tmp_path / "checkpoint.pth"), "--images", str(img_dir), "--no-cpu-baseline", "--no-other-dtypes", "--no-bs1", "--parity-lines", "2",
+           "--min-seconds", "0"]
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=900, cwd=root, env=env)
+    assert r.returncode == 0, r.stderr[-3000:]
+    line = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
+    assert line["value"] > 0 and line["dtype"] == "f32" and line["config"]["global_batch"] == 4
+    obs = line["observed_on_user_assets"]
+    assert 0 < obs["backbone_activation_peak"] < 6e4 and len(obs["canvas"]) == 2 and obs["canvas"][1] <= 1333
+    p = line["parity_vs_oracle"]
+    assert "error" not in p, p
+    assert p["parity_gate"] and p["teacher_forced"]["logit_err_max"] < LOGIT_TOL and p["teacher_forced"]["edit_distance"] == 0, p
+    assert "free_running_v4" not in line                            # the v4 leg belongs to the synthetic Latin weights only
+
+
 def test_ngram_emissions_and_rescoring_on_device(golden_dir):
     """SURVEY 8 f.4 on the GPU: the CTC-style emissions of the n-gram path (get_new_pred_logits, ngram/prediction_helpers.py:5-46) are
     produced by dtlr_blank_emissions (per-query sums chip-wide, the decoders' reading-order sort, one wave per row): (1) the vectors
