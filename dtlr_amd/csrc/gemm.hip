@@ -1463,6 +1463,18 @@ extern "C" int dtlr_gemm_nt_rowmax(const void* A, const void* W, const float* bi
     return dtlr_gemm_nt_rowmax_lda(A, K, W, bias, rowmax, M, N, K, in_dtype, stream);
 }
 
+// -inf initialisation of a row-max vector as an ORDINARY kernel (round 5).  It was hipMemsetD32Async: under stream capture that becomes a
+// memset node, and a replay of the captured forward after any eager forward of the fp32 engine filled the vector with ZEROS instead of
+// 0xff800000 (tools/experiments/graph_replay_probe2.py: every stage identical up to `memory`, two-stage scores off by up to 6.0 = the
+// class bias, i.e. atomicMin against 0 instead of -inf; the eager path never differed) -- the runtime's fill pattern is not part of the
+// captured node's own state.  A kernel node carries its value argument by value.
+__global__ __launch_bounds__(256) void fill_u32_kernel(uint32_t* __restrict__ p, uint32_t v, long n)
+{
+    const long i = ((long)blockIdx.x * 256 + threadIdx.x) * 4;
+    if (i + 3 < n && (((size_t)p & 15) == 0)) *reinterpret_cast<uint4*>(p + i) = make_uint4(v, v, v, v);
+    else for (long k = i; k < n && k < i + 4; ++k) p[k] = v;
+}
+
 extern "C" int dtlr_gemm_nt_rowmax_lda(const void* A, int lda, const void* W, const float* bias, float* rowmax,
                                        int M, int N, int K, int in_dtype, void* stream)
 {
@@ -1471,7 +1483,8 @@ extern "C" int dtlr_gemm_nt_rowmax_lda(const void* A, int lda, const void* W, co
     if (M <= 0 || N <= 0 || K <= 0 || lda < K) return DTLR_EINVAL;
     if ((lda * (in_dtype == DTLR_F32 || in_dtype == DTLR_F32S ? 4 : 2)) & 15) return DTLR_ESHAPE;          // rows must stay 16-byte aligned
     hipStream_t st = (hipStream_t)stream;
-    if (hipMemsetD32Async((hipDeviceptr_t)rowmax, (int)0xff800000u, (size_t)M, st) != hipSuccess) { g_last_hip_error = (int)hipGetLastError(); return DTLR_ELAUNCH; }
+    hipLaunchKernelGGL(fill_u32_kernel, dim3((unsigned)(((long)M + 1023) / 1024)), dim3(256), 0, st, reinterpret_cast<uint32_t*>(rowmax), 0xff800000u, (long)M);
+    { const int rc_ = check_launch(); if (rc_ != DTLR_OK) return rc_; }
     const int flags = (bias ? EPI_BIAS : 0) | EPI_ROWMAX;
     if (in_dtype == DTLR_H16) {
         if (K % 64) return DTLR_ESHAPE;
