@@ -87,6 +87,10 @@ inline int exp_env_int(const char* name, int dflt) { const char* e = getenv(name
 constexpr int exp_env_int(const char*, int dflt) { return dflt; }
 #endif
 
+// Scratch buffer of at least `bytes` owned by (current device, stream): defined in gemm.hip (the split-K workspace).  Contents are only
+// meaningful between the launches of ONE operator on that stream; nullptr when no buffer can be had (capture without a warm slot, OOM).
+float* stream_workspace(size_t bytes, hipStream_t st);
+
 // ---- wave reductions (all 64 lanes participate) ----------------------------------------------
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll

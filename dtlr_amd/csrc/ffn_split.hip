@@ -41,6 +41,11 @@ typedef __attribute__((ext_vector_type(16))) float fs_f32x16_t;
 #endif
 #ifdef FS_STANDALONE
 thread_local int g_last_hip_error = 0;
+float* stream_workspace(size_t bytes, hipStream_t) {           // the standalone experiment build has no gemm.hip: one growing buffer
+    static float* p = nullptr; static size_t n = 0;
+    if (bytes > n) { if (p) (void)hipFree(p); p = nullptr; n = 0; if (hipMalloc((void**)&p, bytes) != hipSuccess) return nullptr; n = bytes; }
+    return p;
+}
 #endif
 constexpr int FS_CHUNK = 65536;                              // W1_hi | W1_lo | W2_hi | W2_lo of one 32-unit chunk: 4 x 16 fragments of 1 KB
 constexpr int FS_IMG = 32768;                                // the W1 (or W2) half of a chunk image: hi fragments, then lo fragments
@@ -85,17 +90,32 @@ __device__ __forceinline__ void fs_split2(float x0, float x1, uint32_t& hi, uint
 // matrix cycles) to land; __builtin_amdgcn_sched_barrier(0) between groups keeps hipcc from re-serialising read -> wait -> MFMA (its
 // own schedule of the straightforward loop used ONE fragment register pair).  The packed image carries FS_PAD zero chunks, and an odd
 // chunk count is padded by one more (b1 = 0 there: relu(0) = 0 adds nothing), so the steady state has no conditionals.
+// PART (round 5): the hidden-dimension split of the LAST, partial round.  1360 tiles on 256 CUs are 5.31 rounds of one workgroup per CU:
+// the sixth round ran 80 workgroups for a full tile time (31% of the chip, 148 of the call's 889 us).  With PART the tail tiles are
+// launched NS-fold: workgroup b = tile (tile0 + b / NS), part b % NS multiplies only the hidden chunks [cb[part], cb[part + 1]) (even
+// counts; the image's look-ahead chunks behind a part are the next part's real chunks or the zero padding: streamed, phase-A'd into a
+// discarded accumulator) and stores its RAW Y^T accumulators to part `part` of a workspace; ffn_split_finish_kernel adds the parts,
+// b2 and the residual and normalises.  Summation order of the tail rows differs from the other rows' by that regrouping only.
+struct FsParts { int ns, tile0, cb[5]; };
+template <bool PART>
 __global__ __launch_bounds__(256, 1) void ffn_split_kernel(
     const float* __restrict__ X, const unsigned char* __restrict__ Wp, const float* __restrict__ b1, const float* __restrict__ b2,
-    const float* __restrict__ gamma, const float* __restrict__ beta, float eps, float* __restrict__ Y, int M, int d_ff)
+    const float* __restrict__ gamma, const float* __restrict__ beta, float eps, float* __restrict__ Y, int M, int d_ff, FsParts fp)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char fs_smem[];
     const unsigned lds_base = (unsigned)(size_t)(__attribute__((address_space(3))) unsigned char*)fs_smem;
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     const int j = lane & 31, hh = lane >> 5;
-    const int nchunk = d_ff >> 5, nc2 = (nchunk + 1) & ~1;     // chunks multiplied (an odd count runs one zero chunk)
-    const long tok0 = (long)blockIdx.x * 128 + wave * 32;
+    const int part = PART ? (int)blockIdx.x % fp.ns : 0;
+    const int tile = PART ? fp.tile0 + (int)blockIdx.x / fp.ns : (int)blockIdx.x;
+    const int c_lo = PART ? (part == 0 ? fp.cb[0] : part == 1 ? fp.cb[1] : part == 2 ? fp.cb[2] : fp.cb[3]) : 0;
+    const int c_hi = PART ? (part == 0 ? fp.cb[1] : part == 1 ? fp.cb[2] : part == 2 ? fp.cb[3] : fp.cb[4]) : 0;
+    const int nchunk = d_ff >> 5;
+    const int nc2 = PART ? (c_hi - c_lo) : ((nchunk + 1) & ~1);        // chunks multiplied (an odd count runs one zero chunk)
+    if (PART) { Wp += (long)c_lo * FS_CHUNK; }
+    const int b1_off = c_lo * 32;                                       // first hidden unit of this workgroup's chunk range
+    const long tok0 = (long)tile * 128 + wave * 32;
     const long tok = min(tok0 + j, (long)M - 1);               // rows past M are clamped (computed, never stored)
 
     // ---- weight DMA: wave w moves bytes [8 w KB, 8 (w + 1) KB) of a 32 KB W1 / W2 image, 8 pieces of 1 KB ------------------------------
@@ -126,7 +146,7 @@ __global__ __launch_bounds__(256, 1) void ffn_split_kernel(
     {   // b1 table (zero behind d_ff: the padding chunks) and the epilogue parameters
         float* b1s = reinterpret_cast<float*>(fs_smem + FS_B1_OFF);
         for (int i = (int)threadIdx.x * 4; i < (nc2 + FS_PAD) * 32; i += 256 * 4)
-            *reinterpret_cast<float4*>(b1s + i) = i < d_ff ? *reinterpret_cast<const float4*>(b1 + i) : make_float4(0.f, 0.f, 0.f, 0.f);
+            *reinterpret_cast<float4*>(b1s + i) = b1_off + i < d_ff ? *reinterpret_cast<const float4*>(b1 + b1_off + i) : make_float4(0.f, 0.f, 0.f, 0.f);
         float* prm = reinterpret_cast<float*>(fs_smem + FS_PRM_OFF);
         prm[threadIdx.x] = b2[threadIdx.x];
         prm[256 + threadIdx.x] = gamma[threadIdx.x];
@@ -215,6 +235,20 @@ __global__ __launch_bounds__(256, 1) void ffn_split_kernel(
 #undef FS_IMAGE
 #undef FS_PIECE
 
+    if constexpr (PART) {
+        // raw partial sums of this chunk range: workspace [ns][tail rows][256], same lane -> channel map as the final store below
+        if (tok0 + j < M) {
+            const long trow = (tok0 + j) - (long)fp.tile0 * 128;
+            const long tail_rows = (long)M - (long)fp.tile0 * 128;
+            float* prow = Y + ((long)part * tail_rows + trow) * 256 + 4 * hh;
+#pragma unroll
+            for (int ct = 0; ct < 8; ++ct)
+#pragma unroll
+                for (int q = 0; q < 4; ++q)
+                    *reinterpret_cast<float4*>(prow + 32 * ct + 8 * q) = make_float4(yacc[ct][4 * q], yacc[ct][4 * q + 1], yacc[ct][4 * q + 2], yacc[ct][4 * q + 3]);
+        }
+        return;
+    }
     // ---- epilogue: + b2 + X (fp32 residual), LayerNorm, store.  Lane (j, hh), tile ct, register r: channel 32 ct + 8 (r >> 2) + 4 hh + (r & 3) ----
     const float* prm_ = reinterpret_cast<const float*>(fs_smem + FS_PRM_OFF);
     const float* xrow = X + tok * 256 + 4 * hh;
@@ -252,6 +286,29 @@ __global__ __launch_bounds__(256, 1) void ffn_split_kernel(
     }
 }
 
+// tail rows: Y[row] = LayerNorm(sum of the NS partial rows + b2 + X[row]); one wave per row, lane l owns channels 4 l .. 4 l + 3.
+// Two-pass statistics like the main epilogue.
+__global__ __launch_bounds__(256) void ffn_split_finish_kernel(const float* __restrict__ P, int ns, long tail_rows, const float* __restrict__ X,
+                                                               const float* __restrict__ b2, const float* __restrict__ gamma,
+                                                               const float* __restrict__ beta, float eps, float* __restrict__ Y)
+{
+    const int lane = threadIdx.x & 63;
+    const long row = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= tail_rows) return;
+    float4 v = *reinterpret_cast<const float4*>(P + row * 256 + 4 * lane);
+    for (int p = 1; p < ns; ++p) {
+        const float4 t = *reinterpret_cast<const float4*>(P + ((long)p * tail_rows + row) * 256 + 4 * lane);
+        v.x += t.x; v.y += t.y; v.z += t.z; v.w += t.w;
+    }
+    const float4 bb = *reinterpret_cast<const float4*>(b2 + 4 * lane), xx = *reinterpret_cast<const float4*>(X + row * 256 + 4 * lane);
+    v.x += bb.x + xx.x; v.y += bb.y + xx.y; v.z += bb.z + xx.z; v.w += bb.w + xx.w;
+    const float mean = wave_sum((v.x + v.y) + (v.z + v.w)) * (1.0f / 256.0f);
+    const float dx = v.x - mean, dy = v.y - mean, dz = v.z - mean, dw = v.w - mean;
+    const float rstd = rsqrtf(wave_sum(dx * dx + dy * dy + dz * dz + dw * dw) * (1.0f / 256.0f) + eps);
+    const float4 ga = *reinterpret_cast<const float4*>(gamma + 4 * lane), be = *reinterpret_cast<const float4*>(beta + 4 * lane);
+    *reinterpret_cast<float4*>(Y + row * 256 + 4 * lane) = make_float4(dx * rstd * ga.x + be.x, dy * rstd * ga.y + be.y, dz * rstd * ga.z + be.z, dw * rstd * ga.w + be.w);
+}
+
 }  // namespace dtlr
 
 using namespace dtlr;
@@ -269,8 +326,37 @@ extern "C" int dtlr_ffn_split(const void* X, const void* Wp, const float* b1, co
     if (M <= 0 || M > 0x7fffffffL) return DTLR_EINVAL;
     if (d_ff < 32 || d_ff > FS_MAX_DFF || (d_ff & 31)) return DTLR_ESHAPE;
     static DevOnce once;
-    if (once.first()) { (void)hipFuncSetAttribute((const void*)ffn_split_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, FS_LDS); (void)hipGetLastError(); }
-    hipLaunchKernelGGL(ffn_split_kernel, dim3((unsigned)((M + 127) / 128)), dim3(256), FS_LDS, (hipStream_t)stream,
-                       (const float*)X, (const unsigned char*)Wp, b1, b2, gamma, beta, eps, (float*)Y, (int)M, d_ff);
+    if (once.first()) {
+        (void)hipFuncSetAttribute((const void*)ffn_split_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, FS_LDS);
+        (void)hipFuncSetAttribute((const void*)ffn_split_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, FS_LDS);
+        (void)hipGetLastError();
+    }
+    hipStream_t st = (hipStream_t)stream;
+    const long ntiles = (M + 127) / 128;
+    // whole rounds of one workgroup per CU on the plain kernel; a last round that fills at most half of the chip is split over the hidden
+    // dimension (see ffn_split_kernel<true>): NS = 2..4 parts of an even number of chunks each, as many as fit one round
+    const int NCU = 256;
+    const long full = (ntiles / NCU) * NCU, rem = ntiles - full;
+    const int nc2 = ((d_ff >> 5) + 1) & ~1;
+    int ns = (rem > 0 && full > 0) ? (int)(NCU / rem) : 1;
+    if (ns > 4) ns = 4;
+    if (ns > nc2 / 8) ns = nc2 / 8;                              // at least 8 chunks per part
+    float* ws = nullptr;
+    const long tail_rows = M - full * 128;
+    if (ns >= 2) ws = stream_workspace((size_t)ns * tail_rows * 256 * sizeof(float), st);
+    if (ns < 2 || !ws) {
+        hipLaunchKernelGGL(ffn_split_kernel<false>, dim3((unsigned)ntiles), dim3(256), FS_LDS, st,
+                           (const float*)X, (const unsigned char*)Wp, b1, b2, gamma, beta, eps, (float*)Y, (int)M, d_ff, FsParts{});
+        return check_launch();
+    }
+    FsParts fp{};
+    fp.ns = ns; fp.tile0 = (int)full;
+    for (int p = 0; p <= ns; ++p) fp.cb[p] = (int)(((long)nc2 / 2 * p / ns) * 2);      // even boundaries, cb[0] = 0, cb[ns] = nc2
+    hipLaunchKernelGGL(ffn_split_kernel<false>, dim3((unsigned)full), dim3(256), FS_LDS, st,
+                       (const float*)X, (const unsigned char*)Wp, b1, b2, gamma, beta, eps, (float*)Y, (int)(full * 128), d_ff, FsParts{});
+    hipLaunchKernelGGL(ffn_split_kernel<true>, dim3((unsigned)(rem * ns)), dim3(256), FS_LDS, st,
+                       (const float*)X, (const unsigned char*)Wp, b1, b2, gamma, beta, eps, ws, (int)M, d_ff, fp);
+    hipLaunchKernelGGL(ffn_split_finish_kernel, dim3((unsigned)((tail_rows + 3) / 4)), dim3(256), 0, st,
+                       (const float*)ws, ns, tail_rows, (const float*)X + full * 128 * 256, b2, gamma, beta, eps, (float*)Y + full * 128 * 256);
     return check_launch();
 }

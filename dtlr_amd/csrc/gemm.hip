@@ -1046,7 +1046,9 @@ struct SplitKSlot { int dev; hipStream_t st; float* p; size_t bytes; };
 static SplitKSlot g_splitk_slots[64] = {};
 static int g_splitk_n = 0;
 static std::mutex g_splitk_mu;
-static float* splitk_workspace(size_t bytes, hipStream_t st) {
+float* stream_workspace(size_t bytes, hipStream_t st);         // (also used by ffn_split.hip's hidden-dimension split: declared in dtlr_common.h)
+static float* splitk_workspace(size_t bytes, hipStream_t st) { return stream_workspace(bytes, st); }
+float* stream_workspace(size_t bytes, hipStream_t st) {
     int d = 0;
     (void)hipGetDevice(&d);
     std::lock_guard<std::mutex> lk(g_splitk_mu);

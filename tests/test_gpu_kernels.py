@@ -1435,12 +1435,15 @@ def test_linear_row_broadcast_residual(kind, B, S, N, half):
         assert (got - full).abs().max() < 3e-5 * max(1.0, full.abs().max().item())
 
 
-@pytest.mark.parametrize("M,d_ff", [(128, 2048), (300, 2048), (1000, 512), (4097, 2048), (37, 64), (513, 96), (300, 160), (1, 1024), (174080, 2048), (28800, 2048)])
+@pytest.mark.parametrize("M,d_ff", [(128, 2048), (300, 2048), (1000, 512), (4097, 2048), (37, 64), (513, 96), (300, 160), (1, 1024), (174080, 2048), (28800, 2048),
+                                    (37768, 2048), (33000, 512), (33000, 96), (65700, 2048)])
 def test_ffn_split_vs_fp64(M, d_ff):
     """dtlr_ffn_split (fused FFN block of the split-fp32 engine) against an fp64 evaluation of LayerNorm(x + relu(x W1^T + b1) W2^T + b2)
     on the same fp32 operands: fp32-grade (two split GEMMs + an fp32 LayerNorm), for ragged M, a single row, odd chunk counts
     (d_ff = 96 / 160: one zero chunk is run), the encoder and decoder shapes of the bench; and equal to the unfused split path
-    (two DTLR_F32S GEMMs + dtlr_layernorm) to fp32 rounding."""
+    (two DTLR_F32S GEMMs + dtlr_layernorm) to fp32 rounding.  Round 5: M beyond whole rounds of 256 workgroups runs the tail tiles
+    split over the hidden dimension (174080: 80 tiles x 3 parts; 37768: 40 ragged tiles x 4; 33000 / 512: 2 tiles x 2; 65700: 2 full rounds + 2
+    tiles x 4; 33000 / 96: too few chunks, plain kernel): every row is compared with the unfused path."""
     from dtlr_amd import ops
     big = M > 20000
     x = _rand((M, 256), 1, 1.5) + 0.3
