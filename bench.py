@@ -548,7 +548,8 @@ def main():
         else:
             head = {"bound": "mfma", "kernel": label, "achieved": round(ach, 1), "peak": peak, "unit": "TFLOP/s", "frac": round(mf, 4)}
         head["symbol" if sym else "class"] = sym if sym else True
-        by_kernel.append({**head, "traffic": traffic_db.get(f"{sym or kind}_bytes_per_launch_mean") if traffic_ok else None, "mfma_tflops": round(ach, 1), "mfma_frac": round(mf, 4),
+        by_kernel.append({**head, "traffic": ((traffic_db.get(f"symbol:{sym}") or {}).get("bytes_per_dispatch_mean") if sym else traffic_db.get(f"{kind}_bytes_per_launch_mean")) if traffic_ok else None,
+                          "mfma_tflops": round(ach, 1), "mfma_frac": round(mf, 4),
                           "hbm_gbps_algorithmic": round(gbps, 1), "hbm_frac": round(hf, 4),
                           "algorithmic_flops_per_launch": round(flops / cnt), "algorithmic_bytes_per_launch": round(nbytes / cnt),
                           "mean_launch_ms": round(ms / cnt, 4), "launches_timed": cnt, "ms_per_step": round(ms / replay_steps, 3),

@@ -147,10 +147,24 @@ def reduce_(fetch_dir, write_dir, order_path, out_path):
         out[f"{kind}_bytes_per_launch_mean"] = round(b / n)
         out[f"{kind}_algorithmic_bytes_per_launch_mean"] = round(alg / n)
         out[f"{kind}_launches"] = n
+    # per kernel SYMBOL (round 5: bench.py's `roofline` is one kernel, named as rocprofv3 names it): mean bytes per dispatch of every dtlr kernel
+    # of the recorded step.  Symbols whose dispatches have unlike shapes (the tiled GEMM's instantiations) are means over those shapes.
+    sym_f, sym_w = {}, {}
+    for (rows, acc) in ((fetch, sym_f), (write, sym_w)):
+        for n, v in rows:
+            m = re.search(r"dtlr::([A-Za-z0-9_]+(?:<[^(]*>)?)\(", n)
+            if m:
+                a = acc.setdefault(m.group(1), [0.0, 0])
+                a[0] += v; a[1] += 1
+    for sym in sorted(sym_f):
+        if sym in sym_w and sym_f[sym][1] == sym_w[sym][1]:
+            nd = sym_f[sym][1]
+            out[f"symbol:{sym}"] = {"bytes_per_dispatch_mean": round(1024.0 * (f_factor * sym_f[sym][0] + w_factor * sym_w[sym][0]) / nd),
+                                    "fetch": round(1024.0 * f_factor * sym_f[sym][0] / nd), "write": round(1024.0 * w_factor * sym_w[sym][0] / nd), "dispatches": nd}
     out["_commit"] = os.environ.get("DTLR_COMMIT") or "unknown (set DTLR_COMMIT=$(git rev-parse --short HEAD) when launching through gpurun: .git does not travel)"
     with open(out_path, "w") as fp:
         json.dump(out, fp, indent=1)
-    print(json.dumps({k: v for k, v in out.items() if not k.startswith("gemm")}, indent=1))
+    print(json.dumps({k: v for k, v in out.items() if not k.startswith("gemm") and not k.startswith("symbol:")}, indent=1))
 
 
 if __name__ == "__main__":
