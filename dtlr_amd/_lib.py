@@ -61,6 +61,8 @@ _SIGNATURES = {
                                 ctypes.c_long, c_int, c_void_p]),
     "dtlr_ffn_split": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_float, c_void_p, ctypes.c_long, c_int, c_void_p]),
     "dtlr_ffn_split_pad_chunks": (c_int, []),
+    "dtlr_head_ts": (c_int, [c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_int, c_int, c_int, c_void_p, ctypes.c_long, c_void_p]),
+    "dtlr_head_ts_pad_chunks": (c_int, []),
     "dtlr_k256s_pack_weights": (c_int, [c_void_p, c_void_p, c_void_p]),
     "dtlr_gemm_k256s": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_float, c_void_p, ctypes.c_long, c_void_p]),
     "dtlr_proj_pack_weights": (c_int, [c_void_p, c_void_p]),

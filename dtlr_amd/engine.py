@@ -81,6 +81,7 @@ class DTLREngine:
         self.use_l1_chain = True          # 16-bit: layer1's 1x1 convolutions chained (shortcut conv as extra K columns; tail + next conv1 in one launch)
         self.use_l1_chain_out = True      #         ... including the last tail -> layer2.0.conv1
         self.use_l2_cat = True            # 16-bit: layer2.0's strided shortcut convolution as extra K columns of its tail GEMM
+        self.head_ts_min_classes = 1024   # 16-bit engines: class heads with at least this many classes run on the token-stationary kernel (dtlr_head_ts)
         self.use_ow_resbcast = True       # fp32 / split: the encoder's [offsets | logits] projection as src W^T + (pos W^T + b), unpadded batches
         self._range_check_pending = (dtype == torch.float16) or self.split      # engines whose operands are fp16: see forward()
 
@@ -339,12 +340,25 @@ class DTLREngine:
             return ops.proj_ln(a, w[proj + ".wp"], w[proj + ".b"], residual, w[norm + ".w"], w[norm + ".b"])
         return self._ln(norm, self._lin(proj, a), residual=residual)
 
+    def _head_ts(self, name):
+        """(image, padded bias) of class head `name` for the token-stationary kernel, packed once (ops.head_ts_pack)"""
+        key = name + ".ts"
+        if key not in self.w:
+            self.w[key] = ops.head_ts_pack(self.w[name + ".w"], self.w[name + ".b"], self.dtype)
+        return self.w[key]
+
     def _class_head(self, hs):
         """class_embed on decoder states (models/dino/dino.py:349-352), fp32 logits.  bf16 engine: the states are exact bf16
         values, so [hs | hs] . [W_hi | W_lo]^T on the bf16 matrix cores is the fp32-weight product to ~2^-16 relative -- the
         fp32 MFMA path (a quarter of the rate, plus an fp32 copy of hs) is only used by the fp32 engine."""
         w = self.w
         if self.use_fused_ffn and hs.dtype in ops.H16:
+            C = int(w["class.w"].shape[0])
+            if C >= self.head_ts_min_classes and C % 4 == 0 and hs.shape[-1] == 256:
+                # large charsets (Chinese: 7356 classes): tokens stationary in registers, the weight streamed once per 256 tokens --
+                # the same two terms hs . W_hi + hs . W_lo (dtlr_head_ts; the tiled GEMM ran this head at 0.2 of the MFMA peak)
+                img, bias = self._head_ts("class")
+                return ops.head_ts(hs.contiguous(), img, bias, C, "logits")
             if "class.w2" not in w:
                 wf = w["class.w"].float()
                 hi = wf.to(hs.dtype)
@@ -650,7 +664,14 @@ class DTLREngine:
             # row-max epilogue per 4 k-slabs instead of 12), and the cut "no outsider can reach the exact top 900" could not be PROVEN
             # from the weights at that budget: the max over 7356 classes concentrates the token scores, ~600 tokens per line lie within
             # the 2 x 0.059 bound of the 900-th.  Dropped; the lever for that head is the large-N GEMM itself.)
-            scores = ops.linear_rowmax(om, w["enc_class.w3"], w["enc_class.b3"])
+            C_enc = int(w["enc_class.w"].shape[0])
+            if C_enc >= self.head_ts_min_classes:
+                # round 5: for a large charset the tiled GEMM re-reads its token rows once per 128-channel tile (58 times for 7356 classes:
+                # 4.9 of the Chinese step's 17 ms at 0.2 of the MFMA peak); the token-stationary kernel streams the weight instead
+                img, bias = self._head_ts("enc_class")
+                scores = ops.head_ts(om, img, bias, C_enc, "rowmax", 0, 256)
+            else:
+                scores = ops.linear_rowmax(om, w["enc_class.w3"], w["enc_class.b3"])
         else:
             if self.split and self.use_k256s and "enc_output" in self._k256s_ok and memory.shape[-1] == 256:
                 # split engine: masking, projection and LayerNorm in one streaming pass (dtlr_gemm_k256s, LN form with a row mask)
@@ -820,7 +841,11 @@ class DTLREngine:
                                   for i in range(n)]
         if "hs_enc3" in ts:                                        # bf16 engine: the two-stage head on its split images
             C = int(self.w["enc_class.w"].shape[0])     # the two-stage head's OWN class count (--fix_enc_out_class keeps the old one)
-            interm_class = ops.linear(ts["hs_enc3"], self.w["enc_class.w3"][:C], self.w["enc_class.b3"][:C], out_dtype=torch.float32)
+            if C >= self.head_ts_min_classes and C % 4 == 0:
+                img, bias = self._head_ts("enc_class")
+                interm_class = ops.head_ts(ts["hs_enc3"].contiguous(), img, bias, C, "logits", 0, 256)
+            else:
+                interm_class = ops.linear(ts["hs_enc3"], self.w["enc_class.w3"][:C], self.w["enc_class.b3"][:C], out_dtype=torch.float32)
         else:
             interm_class = ops.linear(ts["hs_enc"], self.w["enc_class.w"], self.w["enc_class.b"])
         out["interm_outputs"] = {"pred_logits": interm_class, "pred_boxes": ts["ref_unsig"].sigmoid()}

@@ -511,6 +511,49 @@ def split_head_weight(w, b, pad_to: int = 64, dtype=torch.bfloat16):
     return out.contiguous(), bias
 
 
+HEAD_TS_NEG = -3.0e38        # bias of a padded class in head_ts_pack (== HT_NEG of csrc/head_ts.hip)
+
+
+def head_ts_pack(w, b, dtype=torch.bfloat16):
+    """fp32 class head [N, 256] (+ bias [N]) on the GPU -> (image, bias_padded) for dtlr_head_ts: per 32-class chunk 32 KB = [W_hi fragments |
+    W_lo fragments], 16 fragments of [64 lanes][8] each (lane l of k-step s <- W[32 c + (l & 31)][16 s + 8 (l >> 5) + e]: ffn_split_pack's
+    W1 order), W_hi = dtype(W), W_lo = dtype(W - W_hi); dtlr_head_ts_pad_chunks() zero chunks behind; bias padded to 32 ceil(N / 32) with -3e38."""
+    N = w.shape[0]
+    assert w.dim() == 2 and w.shape[1] == 256 and dtype in H16
+    nc = -(-N // 32)
+    pad = int(_lib.lib().dtlr_head_ts_pad_chunks())
+    wf = torch.zeros((nc * 32, 256), dtype=torch.float32, device=w.device)
+    wf[:N] = w.float()
+    hi = wf.to(dtype)
+    lo = (wf - hi.float()).to(dtype)
+    frag = lambda t: t.view(nc, 32, 16, 2, 8).permute(0, 2, 3, 1, 4).reshape(nc, 8192)        # noqa: E731
+    img = torch.zeros((nc + pad, 2 * 8192), dtype=dtype, device=w.device)
+    img[:nc, :8192], img[:nc, 8192:] = frag(hi), frag(lo)
+    bias = torch.full((nc * 32,), HEAD_TS_NEG, dtype=torch.float32, device=w.device)
+    bias[:N] = b.float()
+    return img.contiguous().view(-1), bias
+
+
+def head_ts(x, img, bias, N: int, mode: str, a_off: int = 0, b_off=None):
+    """Token-stationary class head (dtlr_head_ts): x [..., ldx] 16-bit rows; the 256-wide operand A = x[..., a_off:a_off+256] and, when b_off is
+    given, B = x[..., b_off:b_off+256] (three products A.Whi + B.Whi + A.Wlo: x = proj_ln_split's [hi | lo | hi] image with a_off 0, b_off 256)
+    or only A (two products: x = the 16-bit decoder state).  mode "rowmax" -> [...] fp32, "logits" -> [..., N] fp32.  (img, bias) = head_ts_pack."""
+    require_cuda(x, "x")
+    assert x.dtype in H16 and img.dtype == x.dtype and x.is_contiguous() and bias.dtype == torch.float32
+    ldx = x.shape[-1]
+    M = x.numel() // ldx
+    nprod = 3 if b_off is not None else 2
+    nc = -(-N // 32)
+    assert bias.numel() == nc * 32 and img.numel() == (nc + int(_lib.lib().dtlr_head_ts_pad_chunks())) * 16384, "(img, bias) is not head_ts_pack of this N"
+    out = torch.empty(x.shape[:-1] + ((N,) if mode == "logits" else ()), dtype=torch.float32, device=x.device)
+    with _Timed(_gkind(x, img), 2.0 * M * N * 256 * nprod, float(M) * 256 * 2 * (nprod - 1) + float(N) * 512 * 2 + 4.0 * M * (N if mode == "logits" else 1),
+                f"head_ts {mode} M{M} N{N} x{nprod}"):
+        code = _L(x).dtlr_head_ts(x.data_ptr(), ldx, a_off, 0 if b_off is None else b_off, img.data_ptr(), bias.data_ptr(), N, nprod,
+                                  1 if mode == "logits" else 0, out.data_ptr(), M, _lib.current_stream())
+    _lib.check(code, "dtlr_head_ts")
+    return out
+
+
 def ffn_fused_supported(x, w1) -> bool:
     """The fused FFN kernel covers the bf16 engine at d_model 256, d_ff <= 2048 (multiple of 32)."""
     return x.dtype in H16 and x.shape[-1] == 256 and w1.shape[0] % 32 == 0 and w1.shape[0] <= 2048

@@ -133,6 +133,26 @@ int dtlr_ffn_split(const void *X, const void *Wp, const float *b1, const float *
 int dtlr_ffn_split_pad_chunks(void);
 
 /* ---------------------------------------------------------------------------------------------
+ * Token-stationary class head for large charsets (round 5; 16-bit engines: DTLR_BF16 in libdtlr_hip.so, DTLR_F16 in libdtlr_hip_f16.so):
+ *   nprod 3:  Y = A Whi^T + B Whi^T + A Wlo^T + bias      nprod 2:  Y = A Whi^T + A Wlo^T + bias
+ *   A = X[:, a_off : a_off + 256], B = X[:, b_off : b_off + 256] of the 16-bit rows X [M, ldx]; Whi = 16-bit(W), Wlo = 16-bit(W - Whi), W [N, 256] fp32.
+ *   mode 0: out [M] fp32 = max over the N classes of Y.
+ *           Replaces: topk_logits = enc_outputs_class_unselected.max(-1)[0] of the two-stage selection
+ *           (models/dino/deformable_transformer.py:341-345) on the [hi | lo | hi] image of output_memory (a_off 0, b_off 256, nprod 3).
+ *   mode 1: out [M, N] fp32 = Y (N % 4 == 0).
+ *           Replaces: class_embed on the decoder states (models/dino/dino.py:349-352; nprod 2 on the 16-bit state) and the interm_outputs
+ *           logits of the selected two-stage rows (dino.py:382-385; nprod 3).
+ *   Wp: ceil(N / 32) + dtlr_head_ts_pad_chunks() blocks of 32 KB, block c = [Whi fragments | Wlo fragments] of classes 32 c .. 32 c + 31,
+ *       16 fragments of 1 KB each: lane l of k-step s <- W[32 c + (l & 31)][16 s + 8 (l >> 5) .. + 7]; zero blocks behind the last chunk
+ *       (dtlr_amd.ops.head_ts_pack builds it).  bias: 32 ceil(N / 32) floats, classes >= N at -3e38.
+ *   ldx, a_off, b_off multiples of 8; N <= 24576.  Same three (two) terms as the tiled GEMM on [hi | lo | hi] . [Whi | Whi | Wlo], summed in
+ *   another order: equal to fp32 rounding.  The tokens are stationary in registers, the weights stream through LDS once per 256 tokens.
+ */
+int dtlr_head_ts(const void *X, int ldx, int a_off, int b_off, const void *Wp, const float *bias, int N, int nprod, int mode,
+                 void *out, long M, void *stream);
+int dtlr_head_ts_pad_chunks(void);
+
+/* ---------------------------------------------------------------------------------------------
  * SPLIT-fp32 engine, K = N = 256: the weight-resident streaming projection (round 4).  A, C (and R) [M, 256] fp32.
  *   R == NULL, gamma == NULL: C = A W^T + bias, rows with row_mask[m] != 0 (may be NULL) written as zeros.
  *              Replaces: value = self.value_proj(input_flatten); value.masked_fill(padding_mask, 0) (ops/modules/ms_deform_attn.py:94-96).

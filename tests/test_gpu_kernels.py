@@ -796,6 +796,49 @@ def test_linear_rowmax_vs_reference(M, N, K, dt, half):
     assert torch.equal(ops.linear_rowmax(wide[:, :K], w.cuda(), b.cuda()), got)
 
 
+@pytest.mark.parametrize("M,N", [(300, 166), (1000, 7356), (257, 2048), (8704, 7356), (31, 36), (512, 4)])
+def test_head_ts_vs_fp64_and_tiled_gemm(M, N, half):
+    """dtlr_head_ts (token-stationary class head, round 5) in all four forms -- row maximum / fp32 logits x three products on a
+    [hi | lo | hi] image / two products on a 16-bit state -- against an fp64 evaluation of the SAME 16-bit operands (exact products, so
+    the only difference is fp32 accumulation order) and against the tiled GEMM path it replaces for large charsets; ragged M (clamped
+    tail rows), N not a multiple of 32 (padded classes never win and are never stored), one chunk, many chunks."""
+    from dtlr_amd import ops
+    xf = _rand((M, 256), 1, 1.2) + 0.1                              # an fp32 row (output_memory after enc_output_norm)
+    w, b = _rand((N, 256), 2) / 16.0, _rand((N,), 3) * 0.5 - 2.0
+    hi = xf.to(half)
+    lo = (xf - hi.float()).to(half)
+    x3 = torch.cat([hi, lo, hi], -1).contiguous().cuda()            # proj_ln_split's image
+    whi = w.to(half)
+    wlo = (w - whi.float()).to(half)
+    img, bias = ops.head_ts_pack(w.cuda(), b.cuda(), half)
+    d = lambda t: t.double()                                        # noqa: E731
+    want3 = d(hi) @ d(whi).t() + d(lo) @ d(whi).t() + d(hi) @ d(wlo).t() + d(b)
+    want2 = d(hi) @ d(whi).t() + d(hi) @ d(wlo).t() + d(b)
+    tol = 2e-5 * max(1.0, want3.abs().max().item())
+    r3 = ops.head_ts(x3, img, bias, N, "rowmax", 0, 256).cpu()
+    assert r3.shape == (M,) and (r3 - want3.max(-1)[0].float()).abs().max() < tol
+    r2 = ops.head_ts(hi.cuda().contiguous(), img, bias, N, "rowmax").cpu()
+    assert (r2 - want2.max(-1)[0].float()).abs().max() < tol
+    # the operand offsets: B taken from the THIRD block of the image (= hi again): A Whi + A Whi + A Wlo
+    r3b = ops.head_ts(x3, img, bias, N, "rowmax", 0, 512).cpu()
+    assert (r3b - (want2 + d(hi) @ d(whi).t()).max(-1)[0].float()).abs().max() < 2 * tol
+    if N % 4 == 0:
+        y3 = ops.head_ts(x3, img, bias, N, "logits", 0, 256).cpu()
+        assert y3.shape == (M, N) and (y3 - want3.float()).abs().max() < tol
+        assert torch.equal(y3.max(-1)[0], r3)                       # the two modes run the same arithmetic
+        y2 = ops.head_ts(hi.cuda().contiguous(), img, bias, N, "logits").cpu()
+        assert (y2 - want2.float()).abs().max() < tol
+    # the tiled GEMM forms the engine used for every charset before round 5
+    w3, b3 = ops.split_head_weight(w.cuda(), b.cuda(), dtype=half)
+    old = ops.linear_rowmax(x3, w3, b3).cpu()
+    assert (old - r3).abs().max() < tol
+    w2 = torch.cat([whi, wlo], 1).contiguous().cuda()
+    old2 = ops.linear(torch.cat([hi, hi], -1).cuda(), w2, b.cuda(), out_dtype=torch.float32).cpu()
+    assert (old2.max(-1)[0] - r2).abs().max() < tol
+    with pytest.raises(Exception):
+        ops.head_ts(x3, img[:-8], bias, N, "rowmax", 0, 256)        # not the image of this N
+
+
 @pytest.mark.parametrize("dt", ["h16", torch.float32])
 def test_two_stage_gather(dt, half):
     from dtlr_amd import ops

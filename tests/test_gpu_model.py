@@ -461,6 +461,32 @@ def test_bf16_chinese_cfg5_batch_properties(half):
     assert st["label_mismatch_on_safe"] == 0, st
 
 
+@pytest.mark.parametrize("half", ["bf16", "f16"])
+def test_chinese_heads_token_stationary_equals_tiled(half):
+    """Round 5: the Chinese model's three 7356-class heads (two-stage scores, interm logits, final logits) on the token-stationary kernel
+    (dtlr_head_ts; DTLREngine.head_ts_min_classes = 1024) against the tiled-GEMM forms they replace (head_ts_min_classes beyond the class
+    count): the same split products in another summation order -- scores / logits equal to fp32 rounding, and with the selection pinned
+    the decoded strings identical."""
+    from dtlr_amd import evaluation as E_
+    from dtlr_amd.engine import DTLREngine
+    cfg = DTLRConfig.chinese()
+    sd = weights.synthetic_state_dict(cfg, 0)
+    x = torch.stack(synth.noise_lines(3, 128, 1536, seed=61)).cuda()
+    mask = torch.zeros((3, 128, 1536), dtype=torch.bool, device="cuda:0")
+    eng = DTLREngine(cfg, sd, "cuda:0", HALF[half])
+    assert eng.head_ts_min_classes <= cfg.num_classes
+    new = eng.forward(x, mask, has_padding=False, return_debug=True)
+    eng.head_ts_min_classes = 10 ** 9
+    old = eng.forward(x, mask, has_padding=False, return_debug=True, forced_topk=new["_debug"]["topk_idx"])
+    free_old = eng.forward(x, mask, has_padding=False, return_debug=True)
+    ds = (new["_debug"]["topk_scores"] - free_old["_debug"]["topk_scores"]).abs().max().item()
+    dl = (new["pred_logits"] - old["pred_logits"]).abs().max().item()
+    di = (new["interm_outputs"]["pred_logits"] - old["interm_outputs"]["pred_logits"]).abs().max().item()
+    print(f"[{half} chinese heads: token-stationary vs tiled] score diff {ds:.2e}, logit diff {dl:.2e}, interm diff {di:.2e}")
+    assert ds < 2e-5 and dl < 5e-5 and di < 5e-5
+    assert E_.decode_blank(new) == E_.decode_blank(old)
+
+
 def test_head_resize_checkpoint_flow_forward(tmp_path):
     """a model built from the stock config (23 classes here) ingests a checkpoint whose heads were
     rebuilt to another charset (11 classes) through evaluation.load_model (evaluation.py:51-88) and then produces the
