@@ -16,7 +16,8 @@
 //   * a workgroup = 8 waves (two per SIMD) owns 256 tokens, a wave 32 of them: X^T of its tokens as B-fragments of the 32x32x16 MFMA in
 //     registers (xa[s], xb[s]: lane (j = token, hh): k = 16 s + 8 hh .. + 7 -- 128 VGPRs), loaded once;
 //   * the classes are walked in chunks of 32: H^T[32 classes, 32 tokens] = Wc X^T as 16 k-steps x nprod MFMAs into ONE accumulator
-//     (16 registers); + bias; mode 0: running maximum in a register, mode 1: four 16-byte fp32 stores per lane;
+//     (16 registers); + bias; mode 0: running maximum in a register, mode 1: the tile leaves through a per-wave LDS transpose as full
+//     128-byte fp32 rows (four 16-byte stores per lane);
 //   * the weight image of a chunk (W_hi fragments | W_lo fragments: 2 x 16 KB, fragment order, packed by ops.head_ts_pack) is DMA'd
 //     global -> LDS (global_load_lds_dwordx4, 4 pieces per wave and chunk) into a two-stage ring, chunk c + 1 while chunk c is multiplied;
 //     one barrier per chunk.  A weight byte serves 256 tokens: 850 workgroups x 7.5 MB = 6.4 GB of L2 -> LDS traffic per launch.
@@ -35,6 +36,7 @@ constexpr int HT_PART = 16384;
 constexpr int HT_PAD = 2;                                    // zero chunks behind the image (streamed by the look-ahead DMA, never multiplied)
 constexpr int HT_LA = 2;                                     // fragment look-ahead in k-steps
 constexpr int HT_TOK = 256;                                  // tokens per workgroup
+constexpr int HT_YP = 36;                                    // row pitch (floats) of the per-wave output scratch of mode 1
 constexpr float HT_NEG = -3.0e38f;                           // bias of a padded class: never the maximum, never stored
 
 template <int OFF> __device__ __forceinline__ void ht_glds16(const void* sbase, unsigned voff, unsigned lds_dst) {
@@ -131,13 +133,25 @@ __global__ __launch_bounds__(512, 1) void head_ts_kernel(
             }
             asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");          // my pieces of chunk c + 1 have landed
         } else {
-            float* yrow = out + tok * (long)N + c * 32 + 4 * hh;
+            // The accumulator layout gives a lane 4 x 16 bytes of one token's 128-byte class row, interleaved with its partner lane's: stored
+            // directly, an instruction wrote 32-byte runs 29 KB apart (1.7 TB/s on the 848 MB logit matrix of the Chinese model).  The
+            // 32 x 32 tile goes through a per-wave LDS scratch (row pitch 36 floats: conflict-free 16-byte writes, 2-way reads) and leaves as
+            // FULL 128-byte rows: lane l stores piece l & 7 of token 8 it + (l >> 3).  Wave-local: the LDS serves a wave's requests in order.
+            float* ys = reinterpret_cast<float*>(ht_smem + 2 * HT_CHUNK + nchunk * 128) + wave * (32 * HT_YP);
 #pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                // the class group 32 c + 8 q + 4 hh .. + 3 is all real or all padding (N % 4 == 0); every wave issues all four stores
-                if (c * 32 + 8 * q + 4 * hh < N)
-                    *reinterpret_cast<float4*>(yrow + 8 * q) = make_float4(acc[4 * q] + bq[q].x, acc[4 * q + 1] + bq[q].y, acc[4 * q + 2] + bq[q].z, acc[4 * q + 3] + bq[q].w);
+            for (int q = 0; q < 4; ++q)
+                *reinterpret_cast<float4*>(ys + j * HT_YP + 8 * q + 4 * hh) =
+                    make_float4(acc[4 * q] + bq[q].x, acc[4 * q + 1] + bq[q].y, acc[4 * q + 2] + bq[q].z, acc[4 * q + 3] + bq[q].w);
+            __builtin_amdgcn_wave_barrier();
+            const int pc = lane & 7, tr = lane >> 3;
+#pragma unroll
+            for (int it = 0; it < 4; ++it) {
+                const float4 v = *reinterpret_cast<const float4*>(ys + (8 * it + tr) * HT_YP + 4 * pc);
+                const long trow = min((long)blockIdx.x * HT_TOK + wave * 32 + 8 * it + tr, (long)M - 1);      // clamped rows rewrite row M - 1 with its own values
+                // the class group 32 c + 4 pc .. + 3 is all real or all padding (N % 4 == 0); piece 0 is always real: every wave issues all four stores
+                if (c * 32 + 4 * pc < N) *reinterpret_cast<float4*>(out + trow * (long)N + c * 32 + 4 * pc) = v;
             }
+            __builtin_amdgcn_wave_barrier();
             // the DMA pieces of chunk c + 1 are OLDER than this chunk's four stores: the in-order counter at <= 4 means they have landed
             asm volatile("s_waitcnt vmcnt(4) lgkmcnt(0)" ::: "memory");
         }
@@ -172,8 +186,8 @@ extern "C" int dtlr_head_ts(const void* X, int ldx, int a_off, int b_off, const 
     if ((ldx & 7) || (a_off & 7) || (b_off & 7) || a_off < 0 || b_off < 0 || a_off + 256 > ldx || (nprod == 3 && b_off + 256 > ldx)) return DTLR_ESHAPE;
     if ((nprod != 2 && nprod != 3) || (mode != 0 && mode != 1) || (mode == 1 && (N & 3))) return DTLR_ESHAPE;
     const int nchunk = (N + 31) / 32;
-    const size_t lds = 2 * (size_t)HT_CHUNK + (size_t)nchunk * 32 * sizeof(float);
-    if (lds > 160 * 1024) return DTLR_ESHAPE;                   // N <= 24576
+    const size_t lds = 2 * (size_t)HT_CHUNK + (size_t)nchunk * 32 * sizeof(float) + (mode == 1 ? 8 * 32 * HT_YP * sizeof(float) : 0);
+    if (lds > 160 * 1024) return DTLR_ESHAPE;                   // N <= 24576 (mode 0) / 15360 (mode 1)
     hipStream_t st = (hipStream_t)stream;
     const dim3 grid((unsigned)((M + HT_TOK - 1) / HT_TOK));
 #define HT_LAUNCH(MODE_, NP_)                                                                      \

@@ -82,6 +82,7 @@ class DTLREngine:
         self.use_l1_chain_out = True      #         ... including the last tail -> layer2.0.conv1
         self.use_l2_cat = True            # 16-bit: layer2.0's strided shortcut convolution as extra K columns of its tail GEMM
         self.head_ts_min_classes = 1024   # 16-bit engines: class heads with at least this many classes run on the token-stationary kernel (dtlr_head_ts)
+        self.head_ts_scores = True        # ... and the two-stage selection scores (row maximum: no logits leave the chip) for EVERY charset: 142 -> 74 us at 166 classes
         self.use_ow_resbcast = True       # fp32 / split: the encoder's [offsets | logits] projection as src W^T + (pos W^T + b), unpadded batches
         self._range_check_pending = (dtype == torch.float16) or self.split      # engines whose operands are fp16: see forward()
 
@@ -665,7 +666,7 @@ class DTLREngine:
             # from the weights at that budget: the max over 7356 classes concentrates the token scores, ~600 tokens per line lie within
             # the 2 x 0.059 bound of the 900-th.  Dropped; the lever for that head is the large-N GEMM itself.)
             C_enc = int(w["enc_class.w"].shape[0])
-            if C_enc >= self.head_ts_min_classes:
+            if self.head_ts_scores or C_enc >= self.head_ts_min_classes:
                 # round 5: for a large charset the tiled GEMM re-reads its token rows once per 128-channel tile (58 times for 7356 classes:
                 # 4.9 of the Chinese step's 17 ms at 0.2 of the MFMA peak); the token-stationary kernel streams the weight instead
                 img, bias = self._head_ts("enc_class")

@@ -145,7 +145,7 @@ int dtlr_ffn_split_pad_chunks(void);
  *   Wp: ceil(N / 32) + dtlr_head_ts_pad_chunks() blocks of 32 KB, block c = [Whi fragments | Wlo fragments] of classes 32 c .. 32 c + 31,
  *       16 fragments of 1 KB each: lane l of k-step s <- W[32 c + (l & 31)][16 s + 8 (l >> 5) .. + 7]; zero blocks behind the last chunk
  *       (dtlr_amd.ops.head_ts_pack builds it).  bias: 32 ceil(N / 32) floats, classes >= N at -3e38.
- *   ldx, a_off, b_off multiples of 8; N <= 24576.  Same three (two) terms as the tiled GEMM on [hi | lo | hi] . [Whi | Whi | Wlo], summed in
+ *   ldx, a_off, b_off multiples of 8; N <= 24576 (mode 0) / 15360 (mode 1).  Same three (two) terms as the tiled GEMM on [hi | lo | hi] . [Whi | Whi | Wlo], summed in
  *   another order: equal to fp32 rounding.  The tokens are stationary in registers, the weights stream through LDS once per 256 tokens.
  */
 int dtlr_head_ts(const void *X, int ldx, int a_off, int b_off, const void *Wp, const float *bias, int N, int nprod, int mode,

@@ -476,7 +476,7 @@ def test_chinese_heads_token_stationary_equals_tiled(half):
     eng = DTLREngine(cfg, sd, "cuda:0", HALF[half])
     assert eng.head_ts_min_classes <= cfg.num_classes
     new = eng.forward(x, mask, has_padding=False, return_debug=True)
-    eng.head_ts_min_classes = 10 ** 9
+    eng.head_ts_min_classes, eng.head_ts_scores = 10 ** 9, False
     old = eng.forward(x, mask, has_padding=False, return_debug=True, forced_topk=new["_debug"]["topk_idx"])
     free_old = eng.forward(x, mask, has_padding=False, return_debug=True)
     ds = (new["_debug"]["topk_scores"] - free_old["_debug"]["topk_scores"]).abs().max().item()
