@@ -35,7 +35,7 @@ constexpr int HT_CHUNK = 32768;                              // W_hi | W_lo of o
 constexpr int HT_PART = 16384;
 constexpr int HT_PAD = 2;                                    // zero chunks behind the image (streamed by the look-ahead DMA, never multiplied)
 constexpr int HT_LA = 2;                                     // fragment look-ahead in k-steps
-constexpr int HT_TOK = 256;                                  // tokens per workgroup
+constexpr int HT_TOK = 256;                                  // tokens per workgroup of the 8-wave form (the 4-wave form: 128)
 constexpr int HT_YP = 36;                                    // row pitch (floats) of the per-wave output scratch of mode 1
 constexpr float HT_NEG = -3.0e38f;                           // bias of a padded class: never the maximum, never stored
 
@@ -48,9 +48,10 @@ __device__ __forceinline__ ht_f32x16_t ht_mma(const uint4& a, const uint4& b, ht
     return DTLR_MFMA_32x32x16_H16(__builtin_bit_cast(ht_h16x8_t, a), __builtin_bit_cast(ht_h16x8_t, b), c, 0, 0, 0);
 }
 
-// MODE 0: out = rowmax [M] fp32.  MODE 1: out = Y [M, N] fp32 (N % 4 == 0).  NPROD 2 | 3.
-template <int MODE, int NPROD>
-__global__ __launch_bounds__(512, 1) void head_ts_kernel(
+// MODE 0: out = rowmax [M] fp32.  MODE 1: out = Y [M, N] fp32 (N % 4 == 0).  NPROD 2 | 3.  NW = 8 waves (256 tokens per workgroup) or 4
+// (128 tokens: for M too small to give every CU an 8-wave workgroup -- the decoder's 28,800 rows are 113 of those on 256 CUs, 225 of these).
+template <int MODE, int NPROD, int NW>
+__global__ __launch_bounds__(64 * NW, 1) void head_ts_kernel(
     const uint16_t* __restrict__ X, int ldx, int a_off, int b_off, const unsigned char* __restrict__ Wp, const float* __restrict__ bias,
     float* __restrict__ out, int M, int N, int nchunk)
 {
@@ -59,18 +60,24 @@ __global__ __launch_bounds__(512, 1) void head_ts_kernel(
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     const int j = lane & 31, hh = lane >> 5;
-    const long tok0 = (long)blockIdx.x * HT_TOK + wave * 32;
+    constexpr int TOKW = 32 * NW;                              // tokens per workgroup
+    const long tok0 = (long)blockIdx.x * TOKW + wave * 32;
     const long tok = min(tok0 + j, (long)M - 1);               // rows past M are clamped: computed like row M - 1 (mode 1 stores the same values twice)
 
-    // ---- weight DMA: wave w moves bytes [4 w KB, 4 (w + 1) KB) of a 32 KB chunk image, 4 pieces of 1 KB ----------------------------
+    // ---- weight DMA: wave w moves bytes [w, w + 1) x (32 / NW) KB of a 32 KB chunk image, in pieces of 1 KB ------------------------
     const unsigned vlane = (unsigned)lane * 16u;
-    const unsigned char* Wb = Wp + wave * 4096;
-    const unsigned mine = lds_base + (unsigned)wave * 4096u;
+    constexpr int WSHARE = HT_CHUNK / NW;                      // 4 KB (8 waves) or 8 KB (4 waves)
+    const unsigned char* Wb = Wp + wave * WSHARE;
+    const unsigned mine = lds_base + (unsigned)wave * (unsigned)WSHARE;
 #define HT_IMAGE(C, ST)                                                                            \
     {                                                                                              \
         const unsigned char* s_ = Wb + (long)(C) * HT_CHUNK;                                       \
         const unsigned d_ = mine + (unsigned)(ST) * HT_CHUNK;                                      \
         ht_glds16<0>(s_, vlane, d_); ht_glds16<1024>(s_, vlane, d_); ht_glds16<2048>(s_, vlane, d_); ht_glds16<3072>(s_, vlane, d_); \
+        if constexpr (NW == 4) {                                                                   \
+            ht_glds16<0>(s_ + 4096, vlane, d_ + 4096u); ht_glds16<1024>(s_ + 4096, vlane, d_ + 4096u);                           \
+            ht_glds16<2048>(s_ + 4096, vlane, d_ + 4096u); ht_glds16<3072>(s_ + 4096, vlane, d_ + 4096u);                        \
+        }                                                                                          \
     }
     HT_IMAGE(0, 0)
 
@@ -87,7 +94,7 @@ __global__ __launch_bounds__(512, 1) void head_ts_kernel(
     }
     // bias table: 32 (nchunk + HT_PAD) floats behind the ring (padded classes carry HT_NEG from the packer; the look-ahead chunks too)
     float* bs = reinterpret_cast<float*>(ht_smem + 2 * HT_CHUNK);
-    for (int i = (int)threadIdx.x * 4; i < nchunk * 32; i += 512 * 4) *reinterpret_cast<float4*>(bs + i) = *reinterpret_cast<const float4*>(bias + i);
+    for (int i = (int)threadIdx.x * 4; i < nchunk * 32; i += 64 * NW * 4) *reinterpret_cast<float4*>(bs + i) = *reinterpret_cast<const float4*>(bias + i);
     // Pin X before the loop: left alone the compiler waits for these loads at their first use inside the loop, i.e. vmcnt(0) behind a DMA issue.
 #pragma unroll
     for (int s = 0; s < 16; ++s) {
@@ -147,7 +154,7 @@ __global__ __launch_bounds__(512, 1) void head_ts_kernel(
 #pragma unroll
             for (int it = 0; it < 4; ++it) {
                 const float4 v = *reinterpret_cast<const float4*>(ys + (8 * it + tr) * HT_YP + 4 * pc);
-                const long trow = min((long)blockIdx.x * HT_TOK + wave * 32 + 8 * it + tr, (long)M - 1);      // clamped rows rewrite row M - 1 with its own values
+                const long trow = min((long)blockIdx.x * TOKW + wave * 32 + 8 * it + tr, (long)M - 1);      // clamped rows rewrite row M - 1 with its own values
                 // the class group 32 c + 4 pc .. + 3 is all real or all padding (N % 4 == 0); piece 0 is always real: every wave issues all four stores
                 if (c * 32 + 4 * pc < N) *reinterpret_cast<float4*>(out + trow * (long)N + c * 32 + 4 * pc) = v;
             }
@@ -189,16 +196,19 @@ extern "C" int dtlr_head_ts(const void* X, int ldx, int a_off, int b_off, const 
     const size_t lds = 2 * (size_t)HT_CHUNK + (size_t)nchunk * 32 * sizeof(float) + (mode == 1 ? 8 * 32 * HT_YP * sizeof(float) : 0);
     if (lds > 160 * 1024) return DTLR_ESHAPE;                   // N <= 24576 (mode 0) / 15360 (mode 1)
     hipStream_t st = (hipStream_t)stream;
-    const dim3 grid((unsigned)((M + HT_TOK - 1) / HT_TOK));
-#define HT_LAUNCH(MODE_, NP_)                                                                      \
+    // 8-wave workgroups of 256 tokens when they give at least ~3/4 of the 256 CUs one each; 4-wave workgroups of 128 tokens below that
+    const bool small = (M + HT_TOK - 1) / HT_TOK < 192;
+#define HT_LAUNCH(MODE_, NP_, NW_)                                                                 \
     {                                                                                              \
         static DevOnce once;                                                                       \
-        if (once.first()) { (void)hipFuncSetAttribute((const void*)head_ts_kernel<MODE_, NP_>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); (void)hipGetLastError(); } \
-        hipLaunchKernelGGL((head_ts_kernel<MODE_, NP_>), grid, dim3(512), lds, st, (const uint16_t*)X, ldx, a_off, b_off,          \
-                           (const unsigned char*)Wp, bias, (float*)out, (int)M, N, nchunk);        \
+        if (once.first()) { (void)hipFuncSetAttribute((const void*)head_ts_kernel<MODE_, NP_, NW_>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); (void)hipGetLastError(); } \
+        hipLaunchKernelGGL((head_ts_kernel<MODE_, NP_, NW_>), dim3((unsigned)((M + 32 * NW_ - 1) / (32 * NW_))), dim3(64 * NW_), lds, st,         \
+                           (const uint16_t*)X, ldx, a_off, b_off, (const unsigned char*)Wp, bias, (float*)out, (int)M, N, nchunk); \
     }
-    if (mode == 0) { if (nprod == 3) HT_LAUNCH(0, 3) else HT_LAUNCH(0, 2) }
-    else { if (nprod == 3) HT_LAUNCH(1, 3) else HT_LAUNCH(1, 2) }
+#define HT_PICK(MODE_, NP_) { if (small) HT_LAUNCH(MODE_, NP_, 4) else HT_LAUNCH(MODE_, NP_, 8) }
+    if (mode == 0) { if (nprod == 3) HT_PICK(0, 3) else HT_PICK(0, 2) }
+    else { if (nprod == 3) HT_PICK(1, 3) else HT_PICK(1, 2) }
+#undef HT_PICK
 #undef HT_LAUNCH
     return check_launch();
 }

@@ -796,12 +796,13 @@ def test_linear_rowmax_vs_reference(M, N, K, dt, half):
     assert torch.equal(ops.linear_rowmax(wide[:, :K], w.cuda(), b.cuda()), got)
 
 
-@pytest.mark.parametrize("M,N", [(300, 166), (1000, 7356), (257, 2048), (8704, 7356), (31, 36), (512, 4)])
+@pytest.mark.parametrize("M,N", [(300, 166), (1000, 7356), (257, 2048), (8704, 7356), (31, 36), (512, 4), (50000, 166), (49300, 36)])
 def test_head_ts_vs_fp64_and_tiled_gemm(M, N, half):
     """dtlr_head_ts (token-stationary class head, round 5) in all four forms -- row maximum / fp32 logits x three products on a
     [hi | lo | hi] image / two products on a 16-bit state -- against an fp64 evaluation of the SAME 16-bit operands (exact products, so
     the only difference is fp32 accumulation order) and against the tiled GEMM path it replaces for large charsets; ragged M (clamped
-    tail rows), N not a multiple of 32 (padded classes never win and are never stored), one chunk, many chunks."""
+    tail rows), N not a multiple of 32 (padded classes never win and are never stored), one chunk, many chunks; M < 49152 runs the
+    4-wave form (128 tokens per workgroup), M >= 49152 the 8-wave form (256)."""
     from dtlr_amd import ops
     xf = _rand((M, 256), 1, 1.2) + 0.1                              # an fp32 row (output_memory after enc_output_norm)
     w, b = _rand((N, 256), 2) / 16.0, _rand((N,), 3) * 0.5 - 2.0
