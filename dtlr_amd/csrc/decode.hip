@@ -225,7 +225,12 @@ __global__ __launch_bounds__(256) void query_label_kernel(const float* __restric
     float blank, top;
     if (sum < 1.f - eps) { blank = 1.f - sum; top = best; }
     else { blank = eps; top = (1.f - eps) * best / sum; }
-    if (live && l16 == 0) raw[q] = (blank >= top) ? -1 : arg;       // argmax over [blank | classes]: blank wins ties
+    // A NaN / inf logit leaves `sum` or `best` non-finite or NaN.  Such a query gets the label -2 and its LINE the length -1
+    // (decode_blank_kernel): the fp16 / split engines turn an activation beyond 65504 into inf and from there into NaN everywhere
+    // (DTLREngine checks the range on its first forward only) -- the caller sees it in the record, without a host synchronisation on the
+    // step, instead of reading garbage labels.  (sum - sum is 0 for every finite sum, NaN for inf / NaN.)
+    const bool bad = !(sum - sum == 0.f);
+    if (live && l16 == 0) raw[q] = bad ? -2 : ((blank >= top) ? -1 : arg);       // argmax over [blank | classes]: blank wins ties
 }
 
 // Step 2, one workgroup per line: sort the queries by box cx, read their labels in that order, drop the blanks.
@@ -239,11 +244,15 @@ __global__ __launch_bounds__(1024) void decode_blank_kernel(const float* __restr
     int* lab = reinterpret_cast<int*>(keys + npow2);
     int* rawl = lab + npow2;
     __shared__ int wave_tot[16];
+    __shared__ int s_bad;
     const int b = blockIdx.x;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nwave = blockDim.x >> 6;
+    if (threadIdx.x == 0) s_bad = 0;
+    __syncthreads();
     for (int i = threadIdx.x; i < npow2; i += blockDim.x) {
         keys[i] = i < nq ? (((unsigned long long)f32_sortable(boxes[((long)b * nq + i) * 4])) << 32) | (unsigned)i : ~0ull;
         rawl[i] = i < nq ? labels[(long)b * nq + i] : -1;
+        if (rawl[i] == -2) s_bad = 1;                                          // a query with non-finite logits (query_label_kernel): benign race, same value
     }
     bitonic_sort_u64(keys, npow2);                                             // ascending cx, ties: lower index first
     for (int p = threadIdx.x; p < nq; p += blockDim.x) lab[p] = rawl[(int)(keys[p] & 0xffffffffull)];
@@ -267,7 +276,7 @@ __global__ __launch_bounds__(1024) void decode_blank_kernel(const float* __restr
         __syncthreads();
     }
     for (int i = running + threadIdx.x; i < nq; i += blockDim.x) labels[(long)b * nq + i] = -1;
-    if (threadIdx.x == 0) lengths[b] = running;
+    if (threadIdx.x == 0) lengths[b] = s_bad ? -1 : running;                     // -1: this line's logits were not finite
 }
 
 // ---- CTC-style emissions of the n-gram re-scoring path (ngram/prediction_helpers.py:5-46, get_new_pred_logits; with scale = 1 the

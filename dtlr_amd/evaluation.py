@@ -105,7 +105,14 @@ def evaluate_ctc_step(outputs, target_labels: Sequence[Sequence[int]]) -> Dict[s
 
 
 def records_to_lists(labels: torch.Tensor, lengths: torch.Tensor) -> List[List[int]]:
+    """decode records -> label lists.  A length of -1 marks a line whose logits were not finite (dtlr_decode_blank flags it on the device):
+    on the float16 / split engines that is an activation beyond fp16's range (65504) -- raise instead of returning garbage."""
     lab, ln = labels.cpu().tolist(), lengths.cpu().tolist()
+    bad = [i for i, n in enumerate(ln) if n < 0]
+    if bad:
+        from ._lib import DTLRError
+        raise DTLRError(f"non-finite logits in line(s) {bad[:8]}{'...' if len(bad) > 8 else ''}: on the float16 / f32s engines an activation left fp16's "
+                        "range (65504) -- run this checkpoint on the bfloat16 or the exact float32 engine")
     return [row[:n] for row, n in zip(lab, ln)]
 
 

@@ -534,7 +534,8 @@ int dtlr_two_stage_gather(const void *om, const float *proposals, const long *id
  *           s = sum_c p; blank = 1 - s if s < 1 - eps else eps (then p <- (1-eps) p / s); argmax over
  *           [blank | p]; drop blanks; no repeat collapse.
  *   logits [B,nq,C] fp32, boxes [B,nq,4] fp32 (cx first) -> labels [B,nq] int32 left-packed, -1 padded;
- *   lengths [B] int32.   eps = 0.03/C (evaluation.py:141) or 0.003 (dino.py:491).
+ *   lengths [B] int32; -1 for a line with a query whose logits are not finite (NaN / a non-finite sigmoid sum: on the fp16 / split engines an
+ *   activation beyond 65504) -- flagged on the device, no host synchronisation.   eps = 0.03/C (evaluation.py:141) or 0.003 (dino.py:491).
  */
 int dtlr_decode_blank(const float *logits, const float *boxes, int *labels, int *lengths,
                       int B, int nq, int C, float eps, void *stream);

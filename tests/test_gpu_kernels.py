@@ -796,6 +796,27 @@ def test_linear_rowmax_vs_reference(M, N, K, dt, half):
     assert torch.equal(ops.linear_rowmax(wide[:, :K], w.cuda(), b.cuda()), got)
 
 
+def test_decode_blank_flags_non_finite_lines():
+    """Round 5 (advisor, round 4): the fp16 / split engines turn an activation beyond 65504 into inf and then NaN; their range check runs on
+    the first forward only.  The blank decoder now flags a line whose logits are not finite ON THE DEVICE (length -1, no host sync), the
+    other lines of the batch decode as before, and the host-side consumer raises instead of returning garbage labels."""
+    from dtlr_amd import _lib, evaluation as E, ops
+    g = torch.Generator().manual_seed(5)
+    logits = (torch.randn((4, 900, 166), generator=g) * 2 - 4).cuda()
+    boxes = torch.rand((4, 900, 4), generator=g).cuda()
+    lab0, len0 = ops.decode_blank(logits, boxes, 0.03 / 166)
+    assert (len0 >= 0).all()
+    bad = logits.clone()
+    bad[1, 17, 3] = float("nan")
+    bad[3, 899, 165] = float("inf") - float("inf")
+    lab1, len1 = ops.decode_blank(bad, boxes, 0.03 / 166)
+    assert len1.tolist()[1] == -1 and len1.tolist()[3] == -1
+    assert len1[0] == len0[0] and len1[2] == len0[2] and torch.equal(lab1[0], lab0[0]) and torch.equal(lab1[2], lab0[2])
+    with pytest.raises(_lib.DTLRError):
+        E.records_to_lists(lab1, len1)
+    assert E.records_to_lists(lab0, len0)[0] == lab0[0, : int(len0[0])].tolist()
+
+
 @pytest.mark.parametrize("M,N", [(300, 166), (1000, 7356), (257, 2048), (8704, 7356), (31, 36), (512, 4), (50000, 166), (49300, 36)])
 def test_head_ts_vs_fp64_and_tiled_gemm(M, N, half):
     """dtlr_head_ts (token-stationary class head, round 5) in all four forms -- row maximum / fp32 logits x three products on a
