@@ -44,7 +44,9 @@ class DTLREngine:
         accumulation: operands carried to 22 bits for |x| >= 2^-3 and to 2^-25 absolute below that -- ~2^-21 relative at the synthetic weights'
         scale, ~2^-18 at a trained checkpoint's ~1e-2 -- instead of the 16-bit engines' 2^-9 / 2^-12 per rounding point).
         Range guard: the fp16 hi halves saturate at 65504; the engine checks the backbone's output maps on its FIRST forward only
-        (one host read), so a later batch with larger activations is the caller's to watch (`check_activation_range()` re-arms it)."""
+        (one host read; `check_activation_range()` re-arms it).  A later batch that overflows does not pass silently either: inf becomes NaN
+        in the next normalisation, and the blank decoder flags every line with non-finite logits on the device (length -1 in the
+        record, evaluation.records_to_lists raises) -- without a host synchronisation on the step."""
         cfg.validate()
         self.cfg, self.device, self.dtype = cfg, torch.device(device), dtype
         self.split = bool(split)
