@@ -85,11 +85,17 @@ __device__ __forceinline__ void unpack8(const uint4& t, float (&v)[8]) {
 // the epilogue applies ReLU to the second layer, multiplies by the 4 x 256 output layer (fp32, `gamma` = its weight, `beta` = its
 // bias) and finishes with mode 0: sigmoid(delta + inverse_sigmoid(ref)) or mode 1: delta + ref -- `eps` carries the mode, Y is
 // the fp32 [M, 4] result and `ref4` the fp32 [M, 4] reference boxes.  (3 launches of M = 28800 per evaluation -> 1.)
-template <int DBG, bool HEAD = false>
+// PART = true (round 5, small M): the block runs NS-fold over the hidden dimension.  At M = 900 (ONE line: the reference's evaluation batch,
+// evaluation.py:494-499) the block is 8 workgroups walking 64 chunks one after the other -- 60 us on 8 of 256 CUs, whatever the batch.
+// Workgroup b = (tile b / NS, part b % NS) multiplies only the chunks [cb[part], cb[part + 1]) (the weight / bias pointers are advanced,
+// the pipeline below runs unchanged on the shorter range) and stores its RAW fp32 accumulators to part `part` of a workspace
+// (`Y` then points at it: [NS][M][256] floats); ffn_fused_finish_kernel adds the parts, b2 and the residual and normalises.
+struct FfnParts { int ns, cb[9]; };
+template <int DBG, bool HEAD = false, bool PART = false>
 __global__ __launch_bounds__(512, 2) void ffn_fused_bf16_kernel(
     const uint16_t* __restrict__ X, const uint16_t* __restrict__ W1, const float* __restrict__ b1,
     const uint16_t* __restrict__ W2, const float* __restrict__ b2, const float* __restrict__ gamma,
-    const float* __restrict__ beta, float eps, uint16_t* __restrict__ Y, int M, int d_ff, const float* __restrict__ ref4)
+    const float* __restrict__ beta, float eps, uint16_t* __restrict__ Y, int M, int d_ff, const float* __restrict__ ref4, FfnParts fpp)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const unsigned lds_base = (unsigned)(size_t)(__attribute__((address_space(3))) unsigned char*)smem;
@@ -97,8 +103,19 @@ __global__ __launch_bounds__(512, 2) void ffn_fused_bf16_kernel(
     const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     const int tg = wave >> 1, half = wave & 1;
     const int n = lane & 15, g = lane >> 4;
+    const int part = PART ? (int)blockIdx.x % fpp.ns : 0;
+    const int tile = PART ? (int)blockIdx.x / fpp.ns : (int)blockIdx.x;
+    if constexpr (PART) {
+        int c_lo = 0, c_hi = 0;
+#pragma unroll
+        for (int p_ = 0; p_ < 8; ++p_) if (p_ == part) { c_lo = fpp.cb[p_]; c_hi = fpp.cb[p_ + 1]; }
+        W1 += (long)c_lo * 32 * 256;                            // rows 32 c_lo .. of [d_ff, 256]
+        W2 += (long)c_lo * 256 * 32;                            // chunk-major [d_ff / 32][256][32]
+        b1 += c_lo * 32;
+        d_ff = (c_hi - c_lo) * 32;
+    }
     const int nchunk = d_ff >> 5;
-    const long tok0 = (long)blockIdx.x * 128 + tg * 32;
+    const long tok0 = (long)tile * 128 + tg * 32;
 
     // ---- X^T fragments of this wave's 32 tokens: lane (n, g) holds X[tok][32 ks + 8 g .. +7] ----------------
     uint4 xf[8][2];
@@ -313,6 +330,23 @@ __global__ __launch_bounds__(512, 2) void ffn_fused_bf16_kernel(
         }
         return;
     }
+    if constexpr (PART) {
+        // raw partial sums: workspace [NS][M][256] fp32; lane (n, g), kq: channels 128 half + 32 kq + 8 g + e (e < 4: yacc[2 kq], e >= 4: yacc[2 kq + 1])
+        float* P = reinterpret_cast<float*>(Y) + (long)part * M * 256;
+#pragma unroll
+        for (int tt = 0; tt < 2; ++tt) {
+            const long tok = tok0 + tt * 16 + n;
+            if (tok < M) {
+#pragma unroll
+                for (int kq = 0; kq < 4; ++kq) {
+                    float* dst = P + tok * 256 + 128 * half + 32 * kq + 8 * g;
+                    *reinterpret_cast<float4*>(dst) = make_float4(yacc[2 * kq][tt][0], yacc[2 * kq][tt][1], yacc[2 * kq][tt][2], yacc[2 * kq][tt][3]);
+                    *reinterpret_cast<float4*>(dst + 4) = make_float4(yacc[2 * kq + 1][tt][0], yacc[2 * kq + 1][tt][1], yacc[2 * kq + 1][tt][2], yacc[2 * kq + 1][tt][3]);
+                }
+            }
+        }
+        return;
+    }
     // ---- epilogue: + b2 + residual, LayerNorm over 256 channels, store -----------------------------------------
     // lane (n, g), ks' = 0..3: channels ch = 128 half + 32 ks' + 8 g + e, e = 0..7: e < 4 from yacc[2 ks'][tt][e],
     // e >= 4 from yacc[2 ks' + 1][tt][e - 4]; the residual is X fragment ks = 4 half + ks'.
@@ -381,6 +415,31 @@ __global__ __launch_bounds__(512, 2) void ffn_fused_bf16_kernel(
     }
 }
 
+
+// rows of the hidden-split form: Y[row] = LayerNorm(sum of the NS partial rows + b2 + X[row]) in the 16-bit format; one wave per row, lane l
+// owns channels 4 l .. 4 l + 3; two-pass statistics (the fused epilogue's arithmetic on another reduction tree).
+__global__ __launch_bounds__(256) void ffn_fused_finish_kernel(const float* __restrict__ P, int ns, long M, const uint16_t* __restrict__ X,
+                                                               const float* __restrict__ b2, const float* __restrict__ gamma,
+                                                               const float* __restrict__ beta, float eps, uint16_t* __restrict__ Y)
+{
+    const int lane = threadIdx.x & 63;
+    const long row = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= M) return;
+    float4 v = *reinterpret_cast<const float4*>(P + row * 256 + 4 * lane);
+    for (int p = 1; p < ns; ++p) {
+        const float4 t = *reinterpret_cast<const float4*>(P + ((long)p * M + row) * 256 + 4 * lane);
+        v.x += t.x; v.y += t.y; v.z += t.z; v.w += t.w;
+    }
+    const float4 bb = *reinterpret_cast<const float4*>(b2 + 4 * lane);
+    const uint2 xw = *reinterpret_cast<const uint2*>(X + row * 256 + 4 * lane);
+    v.x += bb.x + h16_lo(xw.x); v.y += bb.y + h16_hi(xw.x); v.z += bb.z + h16_lo(xw.y); v.w += bb.w + h16_hi(xw.y);
+    const float mean = wave_sum((v.x + v.y) + (v.z + v.w)) * (1.0f / 256.0f);
+    const float dx = v.x - mean, dy = v.y - mean, dz = v.z - mean, dw = v.w - mean;
+    const float rstd = rsqrtf(wave_sum(dx * dx + dy * dy + dz * dz + dw * dw) * (1.0f / 256.0f) + eps);
+    const float4 ga = *reinterpret_cast<const float4*>(gamma + 4 * lane), be = *reinterpret_cast<const float4*>(beta + 4 * lane);
+    *reinterpret_cast<uint2*>(Y + row * 256 + 4 * lane) =
+        make_uint2(pack_bf16x2(dx * rstd * ga.x + be.x, dy * rstd * ga.y + be.y), pack_bf16x2(dz * rstd * ga.z + be.z, dw * rstd * ga.w + be.w));
+}
 
 // ---------------------------------------------------------------------------------------------------------------
 // Fused FFN, second structure (large M: the encoder call): ONE wave per SIMD, 64 tokens per wave, 256 per workgroup.
@@ -853,12 +912,34 @@ extern "C" int dtlr_ffn_fused_bf16(const void* X, const void* W1, const float* b
         return check_launch();
     }
     const unsigned grid = (unsigned)((M + 127) / 128);
+    // Hidden split (round 5): when the 128-token tiles fill less than half of the chip -- one to a few lines: the latency case -- run
+    // every tile NS-fold over the hidden dimension (>= 8 chunks per part) into the stream's workspace and finish with one small kernel.
+    if (dbg == 0 && grid <= 96 && d_ff >= 512) {
+        const int nchunk = d_ff >> 5;
+        int ns = (int)(256 / grid);
+        if (ns > 8) ns = 8;
+        if (ns > nchunk / 8) ns = nchunk / 8;
+        float* ws = ns >= 2 ? stream_workspace((size_t)ns * M * 256 * sizeof(float), (hipStream_t)stream) : nullptr;
+        if (ws) {
+            FfnParts fp{};
+            fp.ns = ns;
+            for (int p = 0; p <= ns; ++p) fp.cb[p] = (int)((long)nchunk * p / ns);
+            static DevOnce attrp;
+            if (attrp.first()) { (void)hipFuncSetAttribute((const void*)ffn_fused_bf16_kernel<0, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, FFN_LDS); (void)hipGetLastError(); }
+            hipLaunchKernelGGL((ffn_fused_bf16_kernel<0, false, true>), dim3(grid * (unsigned)ns), dim3(512), FFN_LDS, (hipStream_t)stream,
+                               (const uint16_t*)X, (const uint16_t*)W1, b1, (const uint16_t*)W2, b2, gamma, beta, eps, reinterpret_cast<uint16_t*>(ws), M, d_ff,
+                               (const float*)nullptr, fp);
+            hipLaunchKernelGGL(ffn_fused_finish_kernel, dim3((unsigned)((M + 3) / 4)), dim3(256), 0, (hipStream_t)stream,
+                               (const float*)ws, ns, (long)M, (const uint16_t*)X, b2, gamma, beta, eps, (uint16_t*)Y);
+            return check_launch();
+        }
+    }
 #define FFN_LAUNCH(D)                                                                              \
     {                                                                                              \
         static DevOnce attr;                                                                  \
         if (attr.first()) { (void)hipFuncSetAttribute((const void*)ffn_fused_bf16_kernel<D>, hipFuncAttributeMaxDynamicSharedMemorySize, FFN_LDS); (void)hipGetLastError(); } \
         hipLaunchKernelGGL(ffn_fused_bf16_kernel<D>, dim3(grid), dim3(512), FFN_LDS, (hipStream_t)stream, \
-                           (const uint16_t*)X, (const uint16_t*)W1, b1, (const uint16_t*)W2, b2, gamma, beta, eps, (uint16_t*)Y, M, d_ff, (const float*)nullptr); \
+                           (const uint16_t*)X, (const uint16_t*)W1, b1, (const uint16_t*)W2, b2, gamma, beta, eps, (uint16_t*)Y, M, d_ff, (const float*)nullptr, FfnParts{}); \
     }
     switch (dbg) {
     case 1: FFN_LAUNCH(1) break;
@@ -893,7 +974,7 @@ extern "C" int dtlr_box_mlp_refine_bf16(const void* X, const void* W1, const flo
     static DevOnce attr;
     if (attr.first()) { (void)hipFuncSetAttribute((const void*)ffn_fused_bf16_kernel<0, true>, hipFuncAttributeMaxDynamicSharedMemorySize, FFN_LDS); (void)hipGetLastError(); }
     hipLaunchKernelGGL((ffn_fused_bf16_kernel<0, true>), dim3((unsigned)((M + 127) / 128)), dim3(512), FFN_LDS, (hipStream_t)stream,
-                       (const uint16_t*)X, (const uint16_t*)W1, b1, (const uint16_t*)W2p, b2, W3, b3, (float)mode, (uint16_t*)out, M, 256, ref);
+                       (const uint16_t*)X, (const uint16_t*)W1, b1, (const uint16_t*)W2p, b2, W3, b3, (float)mode, (uint16_t*)out, M, 256, ref, FfnParts{});
     return check_launch();
 }
 

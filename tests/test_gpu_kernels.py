@@ -425,14 +425,16 @@ def test_mha_f32_vs_fp64_reference(B, L):
 
 
 @pytest.mark.parametrize("M,dff", [(128, 2048), (300, 2048), (1000, 512), (4097, 2048), (37, 64), (4097, 512),
-                                   (50152, 128), (89152, 128), (40000, 128), (33000, 2048), (49153, 512)])
+                                   (50152, 128), (89152, 128), (40000, 128), (33000, 2048), (49153, 512), (900, 2048), (5440, 2048), (12289, 2048)])
 def test_ffn_fused_bf16_vs_reference(M, dff, half):
     """Fused FFN + residual + LayerNorm (dtlr_ffn_fused_bf16) vs an fp64 restatement of
     norm(x + linear2(relu(linear1(x)))) (deformable_transformer.py:804-823) on the same bf16-rounded
     inputs, with the intermediate rounded to bf16 as the kernel (and the unfused path) does; and vs the
     unfused HIP path (two GEMMs + LayerNorm).  Ragged M exercises the token-tile tail.  Both kernel structures are covered:
     the first structure up to M = 32768 and for d_ff = 64; above that the second one (whole rounds of 192-token workgroups + a
-    128- or 192-token remainder launch).  (The product library reads no environment variables: the dispatch is a function of the
+    128- or 192-token remainder launch).  Round 5: up to 96 tiles (M <= 12288) with d_ff >= 512 the first structure runs split over the hidden
+    dimension (2 .. 8 parts of >= 8 chunks + a finish kernel: the single-line latency case -- M = 900 and 5440 are one line's decoder /
+    encoder call); M = 12289 is the first size back on the unsplit kernel.  (The product library reads no environment variables: the dispatch is a function of the
     shape only.)"""
     from dtlr_amd import ops
     x = _rand((M, 256), 1).to(half)
