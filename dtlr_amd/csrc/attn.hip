@@ -301,7 +301,10 @@ __global__ __launch_bounds__(1024) void mha_fwd_bf16_lds2_kernel(const uint16_t*
     // numerator multiplies -- from the idle matrix pipe instead of 16 v_add_f32 per key block
     const uint32_t one2 = n == 0 ? ((uint32_t)H16_ONE | ((uint32_t)H16_ONE << 16)) : 0u;
     const bf16x8 ones_f = __builtin_bit_cast(bf16x8, make_uint4(one2, one2, one2, one2));
-    for (int qb = wave; qb < nqb; qb += 16) {
+    // query blocks: wave w of workgroup z takes blocks w + 16 z, + 16 gridDim.z, ...  (gridDim.z = 1: the whole head in one workgroup; 2 for
+    // small batches (round 5): at ONE line the 8 (head) workgroups each walked two query blocks per wave after staging K / V^T -- 58 us on 8
+    // CUs; two workgroups per head stage the images twice and finish in one block per wave)
+    for (int qb = wave + 16 * (int)blockIdx.z; qb < nqb; qb += 16 * (int)gridDim.z) {
         const int q0 = qb * 32;
         bf16x8 qf[2];
 #pragma unroll
@@ -738,7 +741,8 @@ extern "C" int dtlr_mha_forward(const void* qk, const void* v, void* vt_workspac
         if (two_pass) {
             static DevOnce attr2;
             if (attr2.first()) { (void)hipFuncSetAttribute((const void*)mha_fwd_bf16_lds2_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 152 * 1024); (void)hipGetLastError(); }
-            hipLaunchKernelGGL(mha_fwd_bf16_lds2_kernel, dim3(H, B), dim3(1024), lds, st,
+            const int nz = (B * H <= 64 && (L + 31) / 32 > 16) ? 2 : 1;        // few (batch, head) pairs: split the query blocks over two workgroups
+            hipLaunchKernelGGL(mha_fwd_bf16_lds2_kernel, dim3(H, B, nz), dim3(1024), lds, st,
                                (const uint16_t*)qk, (const uint16_t*)v, (uint16_t*)out, L, Lpad, H, scale_log2e);
             return check_launch();
         }
