@@ -37,13 +37,18 @@ namespace dtlr {
 typedef __attribute__((ext_vector_type(8))) h16_hw_t dq_h16x8_t;
 typedef __attribute__((ext_vector_type(4))) float dq_f32x4_t;
 
-constexpr int DQ_ROWS = 128;                      // queries per workgroup
+constexpr int DQ_ROWS = 128;                      // queries per workgroup (NTT = 8 query tiles of 16); the small-batch form: 32 (NTT = 2)
 constexpr int DQ_PITCH_Q = 128 * 2 + 16;          // sine quarter tile: 128 channels per row
 constexpr int DQ_PITCH = 256 * 2 + 16;            // 256-channel tiles (H, A, tgt)
-constexpr int DQ_R0 = 2 * DQ_ROWS * DQ_PITCH_Q;   // 69632 B: two sine quarters | the A tile (67584 B)
-constexpr int DQ_R1 = DQ_ROWS * DQ_PITCH;         // 67584 B: H | tgt
+constexpr int DQ_R0 = 2 * DQ_ROWS * DQ_PITCH_Q;   // 69632 B: two sine quarters | the A tile (67584 B)   (sizes of the 128-query form; the
+constexpr int DQ_R1 = DQ_ROWS * DQ_PITCH;         // 67584 B: H | tgt                                     32-query form uses a quarter of each)
 constexpr int DQ_RCP = DQ_R0 + DQ_R1;             // 128 floats: 1 / dim_t
 constexpr int DQ_LDS = DQ_RCP + 128 * 4;
+template <int NTT> struct DqCfg {
+    static constexpr int ROWS = 16 * NTT, R0 = 2 * ROWS * DQ_PITCH_Q, R1 = ROWS * DQ_PITCH, RCP = R0 + R1, LDS = RCP + 128 * 4;
+    static constexpr int TPT = 512 / ROWS;        // threads per query in the sine / reference-box stage: 4 or 16
+    static constexpr int PPT = 64 / TPT;          // (sin, cos) pairs per thread and quarter: 16 or 4
+};
 
 __device__ __forceinline__ dq_f32x4_t dq_mma(const uint4& a, const uint4& b, dq_f32x4_t c) {
     return DTLR_MFMA_16x16x32_H16(__builtin_bit_cast(dq_h16x8_t, a), __builtin_bit_cast(dq_h16x8_t, b), c, 0, 0, 0);
@@ -66,14 +71,14 @@ __device__ __forceinline__ void dq_fetch(uint4 (&a)[KT / 32][2], const uint16_t*
 
 // acc[t][tt] += W-fragments . X[16 tt + n][0 .. KT)^T for the wave's NT row tiles and the 8 query tiles; xt: LDS tile (rows = queries),
 // `pitch` bytes per row.  One activation fragment (ds_read_b128) feeds the NT MFMAs of its k-step.
-template <int KT, int NT>
-__device__ __forceinline__ void dq_gemm(dq_f32x4_t (&acc)[NT][8], const uint4 (&a)[KT / 32][NT], const unsigned char* xt, int pitch, int lane)
+template <int KT, int NT, int NTT>
+__device__ __forceinline__ void dq_gemm(dq_f32x4_t (&acc)[NT][NTT], const uint4 (&a)[KT / 32][NT], const unsigned char* xt, int pitch, int lane)
 {
     const unsigned char* xp = xt + (lane & 15) * pitch + 16 * (lane >> 4);
 #pragma unroll
     for (int ks = 0; ks < KT / 32; ++ks) {
 #pragma unroll
-        for (int tt = 0; tt < 8; ++tt) {
+        for (int tt = 0; tt < NTT; ++tt) {
             const uint4 b = *reinterpret_cast<const uint4*>(xp + (16 * tt) * pitch + 64 * ks);
 #pragma unroll
             for (int t = 0; t < NT; ++t) acc[t][tt] = dq_mma(a[ks][t], b, acc[t][tt]);
@@ -94,21 +99,23 @@ __device__ __forceinline__ void dq_store_pair(uint16_t* __restrict__ row /* &out
     if (live) *reinterpret_cast<uint4*>(row + (g & 1) * 16 + 8 * (g >> 1)) = make_uint4(s0[0], s1[0], s0[1], s1[1]);
 }
 
-template <int NT>
-__device__ __forceinline__ void dq_zero(dq_f32x4_t (&acc)[NT][8]) {
+template <int NT, int NTT>
+__device__ __forceinline__ void dq_zero(dq_f32x4_t (&acc)[NT][NTT]) {
 #pragma unroll
     for (int t = 0; t < NT; ++t)
 #pragma unroll
-        for (int tt = 0; tt < 8; ++tt) acc[t][tt] = dq_f32x4_t{0.f, 0.f, 0.f, 0.f};
+        for (int tt = 0; tt < NTT; ++tt) acc[t][tt] = dq_f32x4_t{0.f, 0.f, 0.f, 0.f};
 }
 
-// one sine quarter: coordinate value c[token] (already x 2 pi), 128 channels = 64 (sin, cos) pairs; thread -> (token = tid >> 2, 16 pairs)
+// one sine quarter: coordinate value c[token] (already x 2 pi), 128 channels = 64 (sin, cos) pairs; thread -> (token = tid / TPT, PPT pairs)
+template <int NTT>
 __device__ __forceinline__ void dq_sine_quarter(unsigned char* dst, float c, const float* rcp, int tid)
 {
-    const int tok = tid >> 2, p0 = (tid & 3) * 16;
+    constexpr int TPT = DqCfg<NTT>::TPT, PPT = DqCfg<NTT>::PPT;
+    const int tok = tid / TPT, p0 = (tid % TPT) * PPT;
     unsigned char* row = dst + tok * DQ_PITCH_Q + p0 * 4;
 #pragma unroll
-    for (int j = 0; j < 16; j += 4) {
+    for (int j = 0; j < PPT; j += 4) {
         uint32_t w[4];
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
@@ -119,6 +126,7 @@ __device__ __forceinline__ void dq_sine_quarter(unsigned char* dst, float c, con
     }
 }
 
+template <int NTT>
 __global__ __launch_bounds__(512) void dec_query_stage_kernel(
     const float* __restrict__ ref, const float* __restrict__ vr, const float* __restrict__ dim_t, const uint16_t* __restrict__ tgt,
     const uint16_t* __restrict__ W0, const float* __restrict__ b0, const uint16_t* __restrict__ W1, const float* __restrict__ b1,
@@ -127,27 +135,29 @@ __global__ __launch_bounds__(512) void dec_query_stage_kernel(
     long Q, int nq, int L)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    using Cfg = DqCfg<NTT>;
+    constexpr int ROWS = Cfg::ROWS, TPT = Cfg::TPT;
     unsigned char* r0 = smem;
-    unsigned char* r1 = smem + DQ_R0;
-    float* rcp = reinterpret_cast<float*>(smem + DQ_RCP);
+    unsigned char* r1 = smem + Cfg::R0;
+    float* rcp = reinterpret_cast<float*>(smem + Cfg::RCP);
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int n = lane & 15, g = lane >> 4;
-    const long q0 = (long)blockIdx.x * DQ_ROWS;
+    const long q0 = (long)blockIdx.x * ROWS;
 
     // ---- reference boxes of this workgroup's queries: ref_in for every level, the four sine arguments of level 0 ----------------
     if (tid < 128) rcp[tid] = __frcp_rn(dim_t[tid]);
-    const long qs = min(q0 + (tid >> 2), Q - 1);                  // thread -> (query tid >> 2, level / pair group tid & 3)
+    const long qs = min(q0 + (tid / TPT), Q - 1);                 // thread -> (query tid / TPT, level / pair group tid % TPT)
     const int bs = (int)(qs / nq);
     const float4 rr = *reinterpret_cast<const float4*>(ref + qs * 4);
     {
-        const int lv = tid & 3;
-        if (lv < L && q0 + (tid >> 2) < Q) {
+        const int lv = tid % TPT;
+        if (lv < L && q0 + (tid / TPT) < Q) {
             const float vx = vr[(bs * L + lv) * 2], vy = vr[(bs * L + lv) * 2 + 1];
             *reinterpret_cast<float4*>(ref_in + (qs * L + lv) * 4) = make_float4(rr.x * vx, rr.y * vy, rr.z * vx, rr.w * vy);
         }
-        for (int lv2 = 4 + (tid & 3); lv2 < L; lv2 += 4) {        // more than four levels (not the reference's configuration)
-            if (q0 + (tid >> 2) < Q) {
+        for (int lv2 = TPT + (tid % TPT); lv2 < L; lv2 += TPT) {  // more levels than threads per query (not the reference's configuration)
+            if (q0 + (tid / TPT) < Q) {
                 const float vx = vr[(bs * L + lv2) * 2], vy = vr[(bs * L + lv2) * 2 + 1];
                 *reinterpret_cast<float4*>(ref_in + (qs * L + lv2) * 4) = make_float4(rr.x * vx, rr.y * vy, rr.z * vx, rr.w * vy);
             }
@@ -163,20 +173,20 @@ __global__ __launch_bounds__(512) void dec_query_stage_kernel(
     uint4 wq[2][4][2];                                            // two quarters of W0 fragments in flight
     uint4 w1f[8][2];
     dq_fetch<128>(wq[0], W0, wave, 16, 0, lane);
-    dq_sine_quarter(r0, cq[0], rcp, tid);
+    dq_sine_quarter<NTT>(r0, cq[0], rcp, tid);
     __syncthreads();
     {
-        dq_f32x4_t acc[2][8];
-        dq_zero<2>(acc);
+        dq_f32x4_t acc[2][NTT];
+        dq_zero<2, NTT>(acc);
 #pragma unroll
         for (int qd = 0; qd < 4; ++qd) {
             if (qd + 1 < 4) {
                 dq_fetch<128>(wq[(qd + 1) & 1], W0, wave, 16, 4 * (qd + 1), lane);
-                dq_sine_quarter(r0 + ((qd + 1) & 1) * (DQ_ROWS * DQ_PITCH_Q), cq[qd + 1], rcp, tid);
+                dq_sine_quarter<NTT>(r0 + ((qd + 1) & 1) * (ROWS * DQ_PITCH_Q), cq[qd + 1], rcp, tid);
             } else {
                 dq_fetch<256>(w1f, W1, wave, 8, 0, lane);      // the next stage's weights
             }
-            dq_gemm<128, 2>(acc, wq[qd & 1], r0 + (qd & 1) * (DQ_ROWS * DQ_PITCH_Q), DQ_PITCH_Q, lane);
+            dq_gemm<128, 2, NTT>(acc, wq[qd & 1], r0 + (qd & 1) * (ROWS * DQ_PITCH_Q), DQ_PITCH_Q, lane);
             __syncthreads();
         }
 #pragma unroll
@@ -184,7 +194,7 @@ __global__ __launch_bounds__(512) void dec_query_stage_kernel(
             const int ch = wave * 32 + 16 * t + 4 * g;
             const float4 bb = *reinterpret_cast<const float4*>(b0 + ch);
 #pragma unroll
-            for (int tt = 0; tt < 8; ++tt) {
+            for (int tt = 0; tt < NTT; ++tt) {
                 const dq_f32x4_t c = acc[t][tt];
                 *reinterpret_cast<uint2*>(r1 + (16 * tt + n) * DQ_PITCH + ch * 2) =
                     make_uint2(pack_bf16x2(fmaxf(c[0] + bb.x, 0.f), fmaxf(c[1] + bb.y, 0.f)), pack_bf16x2(fmaxf(c[2] + bb.z, 0.f), fmaxf(c[3] + bb.w, 0.f)));
@@ -196,25 +206,25 @@ __global__ __launch_bounds__(512) void dec_query_stage_kernel(
     // ---- qpos = H W1^T + b1 ; A = tgt + qpos -> region 0, tgt -> region 1, qpos -> global --------------------------------------
     uint4 wf[8][2];                                               // the [q|k] projection's first half (row tiles 0, 1 of the wave's four)
     {
-        dq_f32x4_t acc[2][8];
-        dq_zero<2>(acc);
+        dq_f32x4_t acc[2][NTT];
+        dq_zero<2, NTT>(acc);
         dq_fetch<256>(wf, Wqk, 2 * wave, 8, 0, lane);
         // this lane's tgt values (the residual input of A = tgt + qpos and the v projection's operand): requested BEFORE the GEMM so that
         // their HBM latency hides behind it (loaded inside the epilogue loop they cost a dependent round trip per tile: 16 x ~2 us)
-        uint2 tq[2][8];
+        uint2 tq[2][NTT];
 #pragma unroll
         for (int t = 0; t < 2; ++t)
 #pragma unroll
-            for (int tt = 0; tt < 8; ++tt)
+            for (int tt = 0; tt < NTT; ++tt)
                 tq[t][tt] = *reinterpret_cast<const uint2*>(tgt + min(q0 + 16 * tt + n, Q - 1) * 256 + wave * 32 + 16 * t + 4 * g);
-        dq_gemm<256, 2>(acc, w1f, r1, DQ_PITCH, lane);
+        dq_gemm<256, 2, NTT>(acc, w1f, r1, DQ_PITCH, lane);
         __syncthreads();                                          // every wave has finished reading H: region 1 may take the tgt tile
 #pragma unroll
         for (int t = 0; t < 2; ++t) {
             const int ch = wave * 32 + 16 * t + 4 * g;
             const float4 bb = *reinterpret_cast<const float4*>(b1 + ch);
 #pragma unroll
-            for (int tt = 0; tt < 8; ++tt) {
+            for (int tt = 0; tt < NTT; ++tt) {
                 const long q = q0 + 16 * tt + n;
                 const bool live = q < Q;
                 const uint2 tw = tq[t][tt];
@@ -234,12 +244,12 @@ __global__ __launch_bounds__(512) void dec_query_stage_kernel(
     //      stage's weights are always in flight behind the current one -------------------------------------------------------------
 #define DQ_OUT_STAGE(WF, XT, OUT, LDO, CH0, BIAS)                                                  \
     {                                                                                              \
-        dq_f32x4_t acc[2][8];                                                                      \
-        dq_zero<2>(acc);                                                                           \
-        dq_gemm<256, 2>(acc, WF, XT, DQ_PITCH, lane);                                              \
+        dq_f32x4_t acc[2][NTT];                                                                    \
+        dq_zero<2, NTT>(acc);                                                                      \
+        dq_gemm<256, 2, NTT>(acc, WF, XT, DQ_PITCH, lane);                                         \
         const float4 bb0 = *reinterpret_cast<const float4*>((BIAS) + (CH0) + 4 * g);               \
         const float4 bb1 = *reinterpret_cast<const float4*>((BIAS) + (CH0) + 16 + 4 * g);          \
-        _Pragma("unroll") for (int tt = 0; tt < 8; ++tt) {                                         \
+        _Pragma("unroll") for (int tt = 0; tt < NTT; ++tt) {                                       \
             const long q = q0 + 16 * tt + n;                                                       \
             dq_store_pair((OUT) + min(q, Q - 1) * (LDO) + (CH0), acc[0][tt], acc[1][tt], bb0, bb1, g, q < Q); \
         }                                                                                          \
@@ -287,9 +297,19 @@ extern "C" int dtlr_dec_query_stage(const float* ref, const float* valid_ratios,
     const long Q = (long)B * nq;
     const long grid = (Q + DQ_ROWS - 1) / DQ_ROWS;
     if (grid > 0x7fffffffL) return DTLR_ESHAPE;
+    if (grid <= 64) {
+        // small batches (round 5; one line = 900 queries = 8 workgroups of 128): workgroups of 32 queries -- the four dependent GEMM stages,
+        // the sine quarters and the 64 KB of output per workgroup shrink four-fold, the per-workgroup weight fetch from L2 does not grow
+        static DevOnce attrs;
+        if (attrs.first()) { (void)hipFuncSetAttribute((const void*)dec_query_stage_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize, DqCfg<2>::LDS); (void)hipGetLastError(); }
+        hipLaunchKernelGGL(dec_query_stage_kernel<2>, dim3((unsigned)((Q + 31) / 32)), dim3(512), DqCfg<2>::LDS, (hipStream_t)stream,
+                           ref, valid_ratios, dim_t, (const uint16_t*)tgt, (const uint16_t*)W0, b0, (const uint16_t*)W1, b1,
+                           (const uint16_t*)Wqk, bqk, (const uint16_t*)Wv, bv, ref_in, (uint16_t*)qpos, (uint16_t*)qk, (uint16_t*)v, Q, nq, L);
+        return check_launch();
+    }
     static DevOnce attr;
-    if (attr.first()) { (void)hipFuncSetAttribute((const void*)dec_query_stage_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, DQ_LDS); (void)hipGetLastError(); }
-    hipLaunchKernelGGL(dec_query_stage_kernel, dim3((unsigned)grid), dim3(512), DQ_LDS, (hipStream_t)stream,
+    if (attr.first()) { (void)hipFuncSetAttribute((const void*)dec_query_stage_kernel<8>, hipFuncAttributeMaxDynamicSharedMemorySize, DQ_LDS); (void)hipGetLastError(); }
+    hipLaunchKernelGGL(dec_query_stage_kernel<8>, dim3((unsigned)grid), dim3(512), DQ_LDS, (hipStream_t)stream,
                        ref, valid_ratios, dim_t, (const uint16_t*)tgt, (const uint16_t*)W0, b0, (const uint16_t*)W1, b1,
                        (const uint16_t*)Wqk, bqk, (const uint16_t*)Wv, bv, ref_in, (uint16_t*)qpos, (uint16_t*)qk, (uint16_t*)v, Q, nq, L);
     return check_launch();
