@@ -24,8 +24,11 @@ parity       : `parity_vs_oracle` (oracle/parity.py): the CPU oracle runs --pari
                (its own selection) against the oracle's, as they come out -- `strings_identical_free_running: k/n`, no tolerance, no
                accounting -- and `teacher_forced` = the oracle's decoder re-run on the engine's selection: max logit / box / cx error
                against a FIXED per-engine budget (fp32-grade engines: north_star's 1e-3) and the strings on the same selection.
+               `free_running_v4`: the free-running leg on generator-v4 weights (dtlr_amd/weights.py: identical content queries, characters
+               read from the image -- rank-invariant like a trained recogniser; the benched v2 weights plant a character per selection
+               RANK, so on them the leg measures rank swaps): the engine rebuilt on v4 weights, 8 lines, strings as they come out.
                `by_dtype`: the same batch through the other engines (bf16 = libdtlr_hip.so, f16 = libdtlr_hip_f16.so, f32s = split
-               fp32, f32 = exact fp32): a short timed block (lines/s) and the same two legs each.
+               fp32, f32 = exact fp32): a short timed block (lines/s) and the same legs each.
 roofline     : per KERNEL, measured live with HIP events on the launch stream: MSDA inside the timed blocks, the MFMA kernels (fused FFN,
                GEMM, projection+norm) in a replay of the same steps right after them (an event pair per launch inside the timed region
                would cost ~2.5 ms of stream time per step).  `roofline` = the single kernel with the largest share of the step
