@@ -3,41 +3,60 @@
 instruction is served in fixed lane groups (ds_read_b128: four non-contiguous groups of 16, banks = dword address mod 64; ds_write_b64:
 four contiguous groups of 16, mod 32; ds_write_b128: eight groups of 8, mod 32), one LDS-array cycle per group when all lanes of the group
 hit distinct banks, N cycles for an N-way conflict.  Prints the cycles per instruction of the split (fp32 -> fp16 hi | lo) loader's stores,
-the MFMA waves' fragment reads and the weight tile's stores under the old row swizzle (r & 7) and the round-5 one (lds_swz<f32s_t>)."""
-R128 = [list(range(0,4))+list(range(12,16))+list(range(20,28)), list(range(4,12))+list(range(16,20))+list(range(28,32)),
-        list(range(32,36))+list(range(44,48))+list(range(52,60)), list(range(36,44))+list(range(48,52))+list(range(60,64))]
-def cyc(groups, addr, nbytes, nbanks):
-    tot=0
+the MFMA waves' fragment reads and the weight tile's stores under the old row swizzle (r & 7) and the round-5 one (lds_swz<f32s_t>).
+Importable: tests/test_host_logic.py asserts the round-5 swizzle conflict-free in this model (the SQ counters agree: profiles/r05_sq_f32s_v1.txt)."""
+
+R128 = [list(range(0, 4)) + list(range(12, 16)) + list(range(20, 28)), list(range(4, 12)) + list(range(16, 20)) + list(range(28, 32)),
+        list(range(32, 36)) + list(range(44, 48)) + list(range(52, 60)), list(range(36, 44)) + list(range(48, 52)) + list(range(60, 64))]
+
+
+def cycles(groups, addr, nbytes, nbanks):
+    """LDS-array cycles of one wave instruction: per lane group the largest number of distinct dwords on one bank"""
+    tot = 0
     for grp in groups:
-        bank={}
+        bank = {}
         for l in grp:
-            a=addr(l)
-            for d in range(nbytes//4):
-                b=((a//4)+d)%nbanks
-                bank.setdefault(b,set()).add((a//4)+d)
-        tot+=max(len(v) for v in bank.values())
+            a = addr(l)
+            for d in range(nbytes // 4):
+                bank.setdefault(((a // 4) + d) % nbanks, set()).add((a // 4) + d)
+        tot += max(len(v) for v in bank.values())
     return tot
-def f_old(r): return r&7
-def f_new(r): return (r&7)^((r&1)<<2)
-for name,f in (("old",f_old),("new",f_new)):
-    # loader write b64: tid 0..255: srow=tid>>3, kc=tid&7 ; wave = 64 lanes; groups 4x16 contiguous
-    w=[]
+
+
+def swz_old(r):
+    return r & 7
+
+
+def swz_new(r):                                   # lds_swz<f32s_t> of gemm.hip
+    return (r & 7) ^ ((r & 1) << 2)
+
+
+def split_gemm_cycles(f):
+    """(store cycles of the 8 split-store instructions of a loader wave set, read cycles of the two fragment reads, weight-tile store cycles)
+    under row swizzle f; ideal: 4 per ds_write_b64, 4 per ds_read_b128, 8 per ds_write_b128"""
+    w = []
     for wave in range(4):
-        for half in (0,1):   # hi / lo
+        for half in (0, 1):                       # hi / lo
             def addr(l, wave=wave, half=half):
-                tid=wave*64+l; srow=tid>>3; kc=tid&7
-                return srow*128 + (((half*4+(kc>>1))^f(srow))*16)+(kc&1)*8
-            w.append(cyc([list(range(16*j,16*j+16)) for j in range(4)], addr, 8, 32))
-    # reader b128: lane (g=l>>4, n=l&15): row i*16+n, chunk (kq*4+g)^f(n)
-    r=[]
-    for kq in (0,1):
-        def addr(l,kq=kq):
-            g=l>>4;n=l&15
-            return n*128+(((kq*4+g)^f(n))*16)
-        r.append(cyc(R128, addr, 16, 64))
-    # W tile write b128: 8x8 contiguous groups, bank mod 32
+                tid = wave * 64 + l
+                srow, kc = tid >> 3, tid & 7
+                return srow * 128 + (((half * 4 + (kc >> 1)) ^ f(srow)) * 16) + (kc & 1) * 8
+            w.append(cycles([list(range(16 * j, 16 * j + 16)) for j in range(4)], addr, 8, 32))
+    r = []
+    for kq in (0, 1):
+        def addr(l, kq=kq):
+            g, n = l >> 4, l & 15
+            return n * 128 + (((kq * 4 + g) ^ f(n)) * 16)
+        r.append(cycles(R128, addr, 16, 64))
+
     def addrw(l):
-        srow=l>>3;kc=l&7
-        return srow*128+((kc^f(srow))*16)
-    ww=cyc([list(range(8*j,8*j+8)) for j in range(8)], addrw, 16, 32)
-    print(name,"write_b64 cycles/instr (ideal 4):",w,"read_b128 (ideal 4):",r,"W write_b128 (ideal 8):",ww)
+        srow, kc = l >> 3, l & 7
+        return srow * 128 + ((kc ^ f(srow)) * 16)
+    ww = cycles([list(range(8 * j, 8 * j + 8)) for j in range(8)], addrw, 16, 32)
+    return w, r, ww
+
+
+if __name__ == "__main__":
+    for name, f in (("old", swz_old), ("new", swz_new)):
+        w, r, ww = split_gemm_cycles(f)
+        print(name, "write_b64 cycles/instr (ideal 4):", w, "read_b128 (ideal 4):", r, "W write_b128 (ideal 8):", ww)
