@@ -705,3 +705,30 @@ def test_split_gemm_lds_swizzle_is_conflict_free_in_the_bank_model():
     assert w0 == [8] * 8 and r0 == [4, 4] and ww0 == 8
     src = open(os.path.join(ROOT, "dtlr_amd", "csrc", "gemm.hip")).read()
     assert "return (r & 7) ^ ((r & 1) << 2);" in src            # the kernel's function is the model's swz_new
+
+
+def test_head_ts_pack_layout_and_padding():
+    """ops.head_ts_pack (the weight hand-over of dtlr_head_ts, include/dtlr_hip.h) on the CPU: per 32-class chunk [W_hi fragments | W_lo fragments],
+    lane l of k-step s <- W[32 c + (l & 31)][16 s + 8 (l >> 5) + e]; W_hi + W_lo reproduces W to the 16-bit pair's precision; classes beyond N
+    are zero rows with bias -3e38; dtlr_head_ts_pad_chunks() zero chunks follow (the look-ahead DMA reads them)."""
+    from dtlr_amd import _lib, ops
+    g = torch.Generator().manual_seed(7)
+    N = 70                                                      # 3 chunks, the last one 6 real classes
+    w = torch.randn((N, 256), generator=g) / 16
+    b = torch.randn((N,), generator=g)
+    for dt in (torch.bfloat16, torch.float16):
+        img, bias = ops.head_ts_pack(w, b, dt)
+        pad = int(_lib.lib().dtlr_head_ts_pad_chunks())
+        nc = 3
+        assert img.dtype == dt and img.numel() == (nc + pad) * 16384 and bias.shape == (96,)
+        assert torch.equal(bias[:N], b) and (bias[N:] == ops.HEAD_TS_NEG).all()
+        im = img.view(nc + pad, 2, 16, 64, 8).float()
+        assert (im[nc:] == 0).all()
+        hi = w.to(dt)
+        lo = (w - hi.float()).to(dt)
+        for c, s_, l, e in ((0, 0, 0, 0), (1, 5, 37, 3), (2, 15, 63, 7), (2, 9, 5, 1), (2, 3, 6, 2)):
+            row, col = 32 * c + (l & 31), 16 * s_ + 8 * (l >> 5) + e
+            want_hi = float(hi[row, col]) if row < N else 0.0
+            want_lo = float(lo[row, col]) if row < N else 0.0
+            assert float(im[c, 0, s_, l, e]) == want_hi and float(im[c, 1, s_, l, e]) == want_lo
+        assert (hi.float() + lo.float() - w).abs().max() < (2.0 ** -16 if dt == torch.bfloat16 else 2.0 ** -21) * w.abs().max() + 2.0 ** -24
