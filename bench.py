@@ -10,7 +10,9 @@ A "step" = one pass of the hot path over one batch of 32 synthetic lines per GPU
 (backbone -> encoder -> two-stage -> decoder -> heads) + the blank decoder producing per-line label records (+ ONE RCCL
 all-gather of those records when N > 1).  Workload = BASELINE.json configs[1]: Latin model (C=166), bf16, bs=32, 128x2048,
 random-init name-seeded weights with trained-like head margins (generator v2; no checkpoint ships with the reference).
-Rank 0 prints ONE JSON line.
+Rank 0 prints ONE JSON line on stdout, kept below 6 KB (compact_line: the contract's keys, `roofline` of the dominant kernel, `roofline_msda`,
+`cpu_baseline`, `distributed`, six numbers per engine in `by_dtype`); the FULL result -- everything described below -- is written to
+gpurun_out/bench_detail.json (or ./bench_detail.json) and to stderr.
 
 timing       : W warm-up steps, then blocks of exactly K steps, each bracketed by barrier + torch.cuda.synchronize() on both
                sides and reduced with MAX over ranks.  The block is repeated until >= 2 s have been timed (a 20-step block is
@@ -139,6 +141,8 @@ def cpu_baseline(n_lines: int = 16, height: int = 128, width: int = 2048, timed:
     best = max(legs, key=lambda k: legs[k]["lines_per_s"])
     return {"value": legs[best]["lines_per_s"], "unit": "lines/s", "cores": best, "kind": "port",
             "physical_cores": nphys, "by_threads": {str(k): v for k, v in legs.items()},
+            "sample_short": f"configs[0]: {n_lines} synthetic {height}x{width} fp32 lines, oracle forward + blank decode; `value` = the faster of the 8-thread and "
+                            f"all-{nphys}-core legs (a leg with timed_runs 0 is a single run: its warm-up exceeded the time cap)",
             "sample": f"BASELINE configs[0]: {n_lines} synthetic {height}x{width} fp32 lines, oracle forward + blank decode (MSDA = the reference's "
                       f"grid_sample core), 1 warm-up + up to {timed} timed runs per leg (median; {cap_s:.0f} s cap per leg), legs at 8 threads and at "
                       f"all {nphys} physical cores; `value` is the faster leg"}
@@ -199,6 +203,104 @@ def msda_offset_sensitivity(eng, B, dtype, level_hw, sigmas=(0.0, 8.0, 32.0), it
 def _sci(v: float) -> float:
     """4 significant digits, whatever the magnitude (round(3e-5, 4) used to print the fp32 engine's error as 0.0)"""
     return float(f"{v:.3e}")
+
+
+STDOUT_LINE_LIMIT = 6000        # bytes: the driver parses ONE stdout line; round 5's 22 KB line came back `parsed: null`
+
+
+def _tf(p):
+    return (p or {}).get("teacher_forced") or {}
+
+
+def _fr(p):
+    return (p or {}).get("free_running") or {}
+
+
+def _compact_roof(r):
+    """the dominant kernel's roofline object: SURVEY 8(d)'s fields + what lets a reader recompute `achieved` from profiles/*_kernel_stats.csv"""
+    if not r:
+        return None
+    keep = ("bound", "symbol", "achieved", "peak", "unit", "frac", "traffic", "algorithmic_flops_per_launch", "algorithmic_bytes_per_launch",
+            "mean_launch_ms", "launches_timed", "ms_per_step")
+    out = {k: r[k] for k in keep if r.get(k) is not None}
+    out.setdefault("traffic", None)
+    if "symbol" not in out:
+        out["kernel"] = str(r.get("kernel", ""))[:96]
+    return out
+
+
+def _compact_engine(ent):
+    """six numbers per engine: rate, step time, teacher-forced logit error + strings on the benched weights, free-running strings + CER on v4"""
+    if not isinstance(ent, dict) or "error" in ent:
+        return {"error": str((ent or {}).get("error"))[:120]}
+    pv, v4 = ent.get("parity_vs_oracle"), ent.get("free_running_v4")
+    out = {"lines_per_s": ent.get("lines_per_s"), "ms_per_step": ent.get("ms_per_step")}
+    if isinstance(pv, dict) and "error" not in pv:
+        out.update(logit_err_max=_tf(pv).get("logit_err_max"), logit_budget=_tf(pv).get("logit_budget"),
+                   strings_teacher_forced=_tf(pv).get("strings_identical_same_selection"), parity_gate=pv.get("parity_gate"))
+    if isinstance(v4, dict) and "error" not in v4:
+        out.update(strings_free_running_v4=_fr(v4).get("strings_identical_free_running"), cer_free_running_v4=_fr(v4).get("cer_free_running"))
+    return out
+
+
+def compact_line(full: dict) -> dict:
+    """The ONE stdout line (< STDOUT_LINE_LIMIT bytes) from the full result: the contract's keys, the dominant kernel's `roofline`, the
+    deformable-sampling kernel's HBM figure beside it (`roofline_msda`), `cpu_baseline`, `distributed` and six numbers per engine.  Everything
+    else (roofline_by_kernel, gemm_by_shape, the full parity objects, block times) goes to bench_detail.json and stderr."""
+    keys = ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype", "data")
+    line = {k: full.get(k) for k in keys}
+    cfg = full.get("config") or {}
+    line["config"] = {k: cfg.get(k) for k in ("workload", "global_batch", "parallelism", "canvas", "num_classes", "backbone") if k in cfg}
+    if cfg.get("engine_opts"):
+        line["config"]["engine_opts"] = cfg["engine_opts"]
+    line["timed_blocks"] = full.get("timed_blocks")
+    d = full.get("distributed") or {}
+    line["distributed"] = {k: d.get(k) for k in ("backend", "world_size", "rccl_ranks", "devices_visible", "dp_verified")}
+    line["roofline"] = _compact_roof(full.get("roofline"))
+    msda = next((r for r in full.get("roofline_by_kernel") or [] if str(r.get("symbol", "")).startswith("msda_enc")), None)
+    if msda is not None and msda is not full.get("roofline"):
+        line["roofline_msda"] = _compact_roof(msda)
+    ts = full.get("traffic_source") or {}
+    line["traffic_source"] = ts.get("file") if ts.get("attached") else None
+    cb = full.get("cpu_baseline")
+    if cb:
+        c = {k: cb.get(k) for k in ("value", "unit", "cores", "kind", "physical_cores")}
+        c["sample"] = cb.get("sample_short") or str(cb.get("sample", ""))[:200]
+        legs = {}
+        for th, leg in (cb.get("by_threads") or {}).items():
+            runs = leg.get("timed_runs", 0)
+            legs[th] = {"lines_per_s": leg.get("lines_per_s"), "runs": (f"median of {runs} timed" if runs else "single run (the warm-up; time cap)")}
+        c["by_threads"] = legs
+        line["cpu_baseline"] = c
+        line["speedup_vs_cpu"] = full.get("speedup_vs_cpu")
+    if "latency_ms_bs1" in full:
+        line["latency_ms_bs1"] = full["latency_ms_bs1"]
+    if full.get("by_dtype"):
+        line["by_dtype"] = {k: _compact_engine(v) for k, v in full["by_dtype"].items()}
+    if "observed_on_user_assets" in full:
+        line["observed_on_user_assets"] = {k: v for k, v in full["observed_on_user_assets"].items() if k != "msda_encoder_choice_by_layer"}
+    line["detail"] = full.get("detail_file")
+    # belt and braces: whatever a future field adds, the stdout line stays parseable -- drop optional objects, largest first
+    for k in ("observed_on_user_assets", "roofline_msda", "by_dtype", "timed_blocks", "traffic_source"):
+        if len(json.dumps(line)) < STDOUT_LINE_LIMIT:
+            break
+        line.pop(k, None)
+    return line
+
+
+def write_detail(full: dict) -> str:
+    """the full result beside the line: gpurun_out/bench_detail.json when that directory exists (it is merged back from the GPU box),
+    else ./bench_detail.json; returns the path relative to the repo root (or "" when nothing could be written)"""
+    for d in (os.path.join(ROOT, "gpurun_out"), ROOT):
+        if os.path.isdir(d) and os.access(d, os.W_OK):
+            path = os.path.join(d, "bench_detail.json")
+            try:
+                with open(path, "w") as f:
+                    json.dump(full, f, indent=1)
+                return os.path.relpath(path, ROOT)
+            except OSError:
+                continue
+    return ""
 
 
 V4_PARITY_LINES = 8
@@ -710,7 +812,9 @@ def main():
     if world == 1 and not args.no_cpu_baseline and args.config == "latin" and not args.backbone:
         line["cpu_baseline"] = cpu_baseline()
         line["speedup_vs_cpu"] = round(line["value"] / line["cpu_baseline"]["value"], 1)
-    print(json.dumps(line), flush=True)
+    line["detail_file"] = write_detail(line)
+    log("full result (also in " + (line["detail_file"] or "<not written>") + "): " + json.dumps(line))
+    print(json.dumps(compact_line(line)), flush=True)          # ONE line, < 6 KB (STDOUT_LINE_LIMIT)
     ddist.finalize()
 
 

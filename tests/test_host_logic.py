@@ -690,6 +690,46 @@ def test_bench_self_launch_builds_the_documented_command(monkeypatch):
     assert seen["env"]["HSA_ENABLE_IPC_MODE_LEGACY"] == "0"
 
 
+def test_bench_stdout_line_stays_below_6kb_whatever_the_detail_holds():
+    """Round 5's bench line was 22 KB on stdout and the driver recorded `parsed: null`.  bench.compact_line keeps the ONE stdout line
+    below 6 KB: built here from the largest full result on record (profiles/r05_bench_v4.json, 22 KB) and from an inflated fake
+    (every list and parity object ten times as long), with every key of the bench contract, `roofline` (bound / achieved / peak / unit /
+    frac / traffic) and `cpu_baseline` (value / unit / cores / kind / sample) present."""
+    import copy
+    import importlib
+    import json
+    sys.path.insert(0, ROOT)
+    bench = importlib.import_module("bench")
+    full = json.load(open(os.path.join(ROOT, "profiles", "r05_bench_v4.json")))
+    assert len(json.dumps(full)) > 20000
+    fat = copy.deepcopy(full)
+    fat["roofline_by_kernel"] = fat["roofline_by_kernel"] * 10
+    fat["gemm_by_shape"] = fat["gemm_by_shape"] * 10
+    fat["block_ms"] = fat["block_ms"] * 50
+    for e in fat["by_dtype"].values():
+        e["parity_vs_oracle"]["rows"] = list(range(4000))
+    fat["config"]["workload"] = fat["config"]["workload"] + " x" * 40
+    for src in (full, fat):
+        line = bench.compact_line(src)
+        text = json.dumps(line)
+        assert len(text) < bench.STDOUT_LINE_LIMIT <= 6000, len(text)
+        assert "\n" not in text
+        for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype", "data", "config"):
+            assert k in line, k
+        assert line["value"] == src["value"] and line["config"]["workload"].startswith("Latin DTLR")
+        assert {"bound", "achieved", "peak", "unit", "frac", "traffic", "symbol"} <= set(line["roofline"])
+        assert line["roofline"]["symbol"] == "ffn3_bf16_kernel<0>" and line["roofline_msda"]["bound"] == "hbm"
+        assert {"value", "unit", "cores", "kind", "sample"} <= set(line["cpu_baseline"])
+        assert line["cpu_baseline"]["by_threads"]["128"]["runs"].startswith("single run")       # never quoted as a median of nothing
+        assert set(line["by_dtype"]) == {"bf16", "f16", "f32s", "f32"}
+        assert line["by_dtype"]["f32s"]["strings_teacher_forced"] == "16/16" and line["by_dtype"]["f32s"]["strings_free_running_v4"] == "8/8"
+    # an engine leg that raised is carried as a short error string, not dropped
+    broken = copy.deepcopy(full)
+    broken["by_dtype"]["f32"] = {"error": "RuntimeError(" + "x" * 5000 + ")"}
+    assert len(json.dumps(bench.compact_line(broken))) < bench.STDOUT_LINE_LIMIT
+    assert "error" in bench.compact_line(broken)["by_dtype"]["f32"]
+
+
 def test_split_gemm_lds_swizzle_is_conflict_free_in_the_bank_model():
     """tools/lds_bank_model.py (the guide's LDS service groups and bank moduli): under the round-5 row swizzle of the split GEMM
     (gemm.hip lds_swz<f32s_t>: chunk bit 2 toggled with the row parity) the loader's 8-byte hi | lo stores, the MFMA waves' 16-byte fragment
