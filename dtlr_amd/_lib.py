@@ -28,6 +28,8 @@ _SIGNATURES = {
     "dtlr_strerror": (c_char_p, [c_int]),
     "dtlr_last_hip_error": (c_int, []),
     "dtlr_abi_version": (c_int, []),
+    "dtlr_workspace_reserve": (c_int, [ctypes.c_long, c_void_p]),
+    "dtlr_workspace_retired_bytes": (ctypes.c_long, []),
     "dtlr_msda_forward": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
                                   c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p, c_void_p]),
     "dtlr_msda_fused_forward": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int,

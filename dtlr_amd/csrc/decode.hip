@@ -198,7 +198,7 @@ __global__ __launch_bounds__(256) void query_label_kernel(const float* __restric
     const long q = (long)blockIdx.x * 16 + (threadIdx.x >> 4);
     const bool live = q < nrows;
     const float* lr = logits + (live ? q : 0) * C;
-    float sum = 0.f, best = -1.f;
+    float sum = 0.f, best = -1.f, nonfin = 0.f;
     int arg = 0x7fffffff;
     for (int c0 = 0; c0 < C; c0 += 64) {                            // four classes per lane in flight
         float x[4];
@@ -209,12 +209,14 @@ __global__ __launch_bounds__(256) void query_label_kernel(const float* __restric
             const int c = c0 + 16 * u + l16;
             const float pq = 1.f / (1.f + expf(-x[u]));             // sigmoid(-inf) = 0 for the padding
             sum += pq;
+            if (live && c < C) nonfin += x[u] - x[u];               // 0 for a finite logit, NaN for +-inf / NaN (sigmoid(+-inf) is finite: `sum` alone misses it)
             if (c < C && pq > best) { best = pq; arg = c; }         // ascending c: the first maximum of the lane
         }
     }
 #define QL_STEP(CTRL)                                                                          \
     {                                                                                          \
         sum += dpp_f<CTRL>(sum);                                                               \
+        nonfin += dpp_f<CTRL>(nonfin);                                                         \
         const float ob = dpp_f<CTRL>(best);                                                    \
         const int oa = dpp_i<CTRL>(arg);                                                       \
         if (ob > best || (ob == best && oa < arg)) { best = ob; arg = oa; }                    \
@@ -225,11 +227,12 @@ __global__ __launch_bounds__(256) void query_label_kernel(const float* __restric
     float blank, top;
     if (sum < 1.f - eps) { blank = 1.f - sum; top = best; }
     else { blank = eps; top = (1.f - eps) * best / sum; }
-    // A NaN / inf logit leaves `sum` or `best` non-finite or NaN.  Such a query gets the label -2 and its LINE the length -1
-    // (decode_blank_kernel): the fp16 / split engines turn an activation beyond 65504 into inf and from there into NaN everywhere
-    // (DTLREngine checks the range on its first forward only) -- the caller sees it in the record, without a host synchronisation on the
-    // step, instead of reading garbage labels.  (sum - sum is 0 for every finite sum, NaN for inf / NaN.)
-    const bool bad = !(sum - sum == 0.f);
+    // A query with ANY non-finite logit (NaN, +inf or -inf) gets the label -2 and its LINE the length -1 (decode_blank_kernel): the
+    // fp16 / split engines turn an activation beyond 65504 into inf and from there into NaN everywhere (DTLREngine checks the range on
+    // its first forward only) -- the caller sees it in the record, without a host synchronisation on the step, instead of reading
+    // garbage labels.  `nonfin` sums x - x over the query's logits (0 for finite x, NaN otherwise; round 5 tested `sum` only, which a
+    // +-inf logit leaves finite: sigmoid(+inf) = 1, sigmoid(-inf) = 0).
+    const bool bad = !(nonfin == 0.f) || !(sum - sum == 0.f);
     if (live && l16 == 0) raw[q] = bad ? -2 : ((blank >= top) ? -1 : arg);       // argmax over [blank | classes]: blank wins ties
 }
 

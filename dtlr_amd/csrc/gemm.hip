@@ -1038,16 +1038,28 @@ static inline int plan_chain(long ntiles) {
 // One workspace per (device, STREAM) (round 5; it was per device): the partial tiles of a launch live in it until that launch's reduce
 // kernel has run, so two forwards a caller overlaps on two streams of one device must not share it -- with one buffer per device the
 // second forward's partial tiles would overwrite the first's between its two kernels (a silent wrong result; the engine itself uses
-// one stream and never hit it).  A slot is found by linear search (a handful of streams per process); buffers only grow.  hipFree waits
-// for the device, so no launch still reads a replaced buffer.  Under stream capture no allocation is possible: a stream without a slot
-// borrows the largest buffer of its device (a captured graph is one linear chain; overlapping its replays with other work on that
-// buffer's stream is the caller's to order), and with none the caller falls back to the plain (unsplit) launch.
+// one stream and never hit it).  A slot is found by linear search (a handful of streams per process).
+// LIFETIME (round 6): a pointer handed out here may be baked into a captured HIP graph, so a buffer is NEVER freed or moved once it
+// has been returned: a larger request on the same slot allocates a NEW buffer and RETIRES the old one (it stays allocated for the
+// life of the process; sizes grow in powers of two from 1 MiB, so all retired buffers of a slot together are smaller than its live one).
+// Round 5 hipFree()d on growth: "capture a 1-line graph, run one larger eager batch, replay" replayed into freed memory.
+// Under stream capture no allocation is possible: a stream without a (large enough) slot borrows the largest buffer of its device
+// (a captured graph is one linear chain; overlapping its replays with other work on that buffer's stream is the caller's to order),
+// and with none the callers fall back to their unsplit launch -- which sums in another order, so callers that capture should call
+// dtlr_workspace_reserve() on the capture stream first (DTLREngine does, before its first forward): then eager and captured launches
+// of one shape take the same kernels.
 struct SplitKSlot { int dev; hipStream_t st; float* p; size_t bytes; };
 static SplitKSlot g_splitk_slots[64] = {};
 static int g_splitk_n = 0;
 static std::mutex g_splitk_mu;
+static size_t g_retired_bytes = 0;                             // kept alive on purpose (see LIFETIME): only counted
 float* stream_workspace(size_t bytes, hipStream_t st);         // (also used by ffn_split.hip's hidden-dimension split: declared in dtlr_common.h)
 static float* splitk_workspace(size_t bytes, hipStream_t st) { return stream_workspace(bytes, st); }
+static inline size_t ws_round_up(size_t bytes) {
+    size_t r = (size_t)1 << 20;
+    while (r < bytes) r <<= 1;
+    return r;
+}
 float* stream_workspace(size_t bytes, hipStream_t st) {
     int d = 0;
     (void)hipGetDevice(&d);
@@ -1068,14 +1080,15 @@ float* stream_workspace(size_t bytes, hipStream_t st) {
     if (!slot) {
         if (g_splitk_n < 64) slot = &g_splitk_slots[g_splitk_n++];
         else { slot = &g_splitk_slots[0]; for (int i = 1; i < 64; ++i) if (g_splitk_slots[i].bytes < slot->bytes) slot = &g_splitk_slots[i]; }   // table full: recycle the smallest
-        if (slot->p && slot->dev != d) { int cur = d; (void)hipSetDevice(slot->dev); (void)hipFree(slot->p); (void)hipSetDevice(cur); slot->p = nullptr; }
-        slot->dev = d; slot->st = st;
-        if (!slot->p) slot->bytes = 0;
+        if (slot->p) g_retired_bytes += slot->bytes;             // the recycled slot's buffer may be captured somewhere: retired, not freed
+        slot->dev = d; slot->st = st; slot->p = nullptr; slot->bytes = 0;
     }
-    if (slot->p) (void)hipFree(slot->p);
-    slot->p = nullptr; slot->bytes = 0;
-    if (hipMalloc((void**)&slot->p, bytes) != hipSuccess) { (void)hipGetLastError(); slot->p = nullptr; return nullptr; }
-    slot->bytes = bytes;
+    float* fresh = nullptr;
+    const size_t want = ws_round_up(bytes);
+    if (hipMalloc((void**)&fresh, want) != hipSuccess) { (void)hipGetLastError(); return nullptr; }     // the old buffer (if any) stays the slot's
+    if (slot->p) g_retired_bytes += slot->bytes;                 // retired: never freed (LIFETIME)
+    slot->p = fresh;
+    slot->bytes = want;
     return slot->p;
 }
 static inline int plan_split(long nwg, int nk) {
@@ -1371,6 +1384,25 @@ __global__ __launch_bounds__(256) void split_pack_kernel(const float* __restrict
 }  // namespace dtlr
 
 using namespace dtlr;
+
+// Pre-size the calling stream's scratch workspace (split-K partial tiles, hidden-split FFN parts) OUTSIDE stream capture, so that
+// captured and eager launches of one shape take the same kernels and no allocation is attempted while capturing.  Returns DTLR_OK,
+// DTLR_EINVAL (bytes <= 0, or the stream is capturing) or DTLR_ELAUNCH (out of memory).
+extern "C" int dtlr_workspace_reserve(long bytes, void* stream)
+{
+    clear_stale_error();
+    if (bytes <= 0) return DTLR_EINVAL;
+    hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
+    if (hipStreamIsCapturing((hipStream_t)stream, &cap) != hipSuccess) { (void)hipGetLastError(); cap = hipStreamCaptureStatusNone; }
+    if (cap != hipStreamCaptureStatusNone) return DTLR_EINVAL;
+    return stream_workspace((size_t)bytes, (hipStream_t)stream) ? DTLR_OK : DTLR_ELAUNCH;
+}
+// bytes of workspace buffers that were replaced by larger ones and are kept allocated because a captured graph may still hold them
+extern "C" long dtlr_workspace_retired_bytes(void)
+{
+    std::lock_guard<std::mutex> lk(g_splitk_mu);
+    return (long)g_retired_bytes;
+}
 
 extern "C" int dtlr_gemm_nt(const void* A, const void* A2, const void* W, const float* bias,
                             const void* residual, const unsigned char* row_mask, void* C,

@@ -87,6 +87,7 @@ class DTLREngine:
         self.head_ts_scores = True        # ... and the two-stage selection scores (row maximum: no logits leave the chip) for EVERY charset: 142 -> 74 us at 166 classes
         self.use_ow_resbcast = True       # fp32 / split: the encoder's [offsets | logits] projection as src W^T + (pos W^T + b), unpadded batches
         self._range_check_pending = (dtype == torch.float16) or self.split      # engines whose operands are fp16: see forward()
+        self._ws_streams = set()           # streams whose library workspace this engine has pre-sized (ops.workspace_reserve)
 
     def check_activation_range(self) -> None:
         """re-arm the fp16-range check of the f16 / f32s engines for the next forward (it runs on the first forward only: a host sync)"""
@@ -357,7 +358,7 @@ class DTLREngine:
         w = self.w
         if self.use_fused_ffn and hs.dtype in ops.H16:
             C = int(w["class.w"].shape[0])
-            if C >= self.head_ts_min_classes and C % 4 == 0 and hs.shape[-1] == 256:
+            if C >= self.head_ts_min_classes and ops.head_ts_supported(C, "logits") and hs.shape[-1] == 256:
                 # large charsets (Chinese: 7356 classes): tokens stationary in registers, the weight streamed once per 256 tokens --
                 # the same two terms hs . W_hi + hs . W_lo (dtlr_head_ts; the tiled GEMM ran this head at 0.2 of the MFMA peak)
                 img, bias = self._head_ts("class")
@@ -668,7 +669,7 @@ class DTLREngine:
             # from the weights at that budget: the max over 7356 classes concentrates the token scores, ~600 tokens per line lie within
             # the 2 x 0.059 bound of the 900-th.  Dropped; the lever for that head is the large-N GEMM itself.)
             C_enc = int(w["enc_class.w"].shape[0])
-            if self.head_ts_scores or C_enc >= self.head_ts_min_classes:
+            if (self.head_ts_scores or C_enc >= self.head_ts_min_classes) and ops.head_ts_supported(C_enc, "rowmax"):
                 # round 5: for a large charset the tiled GEMM re-reads its token rows once per 128-channel tile (58 times for 7356 classes:
                 # 4.9 of the Chinese step's 17 ms at 0.2 of the MFMA peak); the token-stationary kernel streams the weight instead
                 img, bias = self._head_ts("enc_class")
@@ -844,7 +845,7 @@ class DTLREngine:
                                   for i in range(n)]
         if "hs_enc3" in ts:                                        # bf16 engine: the two-stage head on its split images
             C = int(self.w["enc_class.w"].shape[0])     # the two-stage head's OWN class count (--fix_enc_out_class keeps the old one)
-            if C >= self.head_ts_min_classes and C % 4 == 0:
+            if C >= self.head_ts_min_classes and ops.head_ts_supported(C, "logits"):
                 img, bias = self._head_ts("enc_class")
                 interm_class = ops.head_ts(ts["hs_enc3"].contiguous(), img, bias, C, "logits", 0, 256)
             else:
@@ -865,6 +866,12 @@ class DTLREngine:
         ops.require_cuda(x, "images")
         cfg = self.cfg
         B = x.shape[0]
+        st = torch.cuda.current_stream(self.device).cuda_stream
+        if st not in self._ws_streams and not torch.cuda.is_current_stream_capturing():
+            # the library's split-K / hidden-split scratch of THIS stream, sized once before anything can be captured on it: a captured
+            # forward then allocates nothing and dispatches exactly as an eager one (dtlr_hip.h, dtlr_workspace_reserve)
+            ops.workspace_reserve(self.dtype)
+            self._ws_streams.add(st)
         feats, last, level_hw = self.features(x)
         if self._range_check_pending:
             # fp16 storage / split fp16 operands saturate at 65504 (the conversions do not clamp: a larger backbone activation becomes inf and

@@ -83,6 +83,18 @@ def require_cuda(t: torch.Tensor, what: str = "input") -> None:
     _lib.lib()      # raises if libdtlr_hip.so is missing
 
 
+def workspace_reserve(dtype, nbytes: int = 128 << 20) -> None:
+    """Pre-size the current stream's scratch workspace of the library serving `dtype` (split-K partial tiles, hidden-split FFN parts:
+    include/dtlr_hip.h, dtlr_workspace_reserve) -- outside stream capture, so that a later captured forward allocates nothing and takes the
+    same kernels as an eager one.  128 MiB covers every shape of a 32-line batch (the largest user: 8 parts x 12288 rows x 1 KB)."""
+    _lib.check(_L(dtype).dtlr_workspace_reserve(int(nbytes), _lib.current_stream()), "dtlr_workspace_reserve")
+
+
+def workspace_retired_bytes(dtype=None) -> int:
+    """bytes of replaced workspace buffers the library keeps allocated (a captured graph may still hold their addresses)"""
+    return int(_L(dtype if dtype is not None else torch.float32).dtlr_workspace_retired_bytes())
+
+
 # --------------------------------------------------------------------------------------------
 # bench.py sets this to a list to time every MFMA-class launch (GEMM / implicit-GEMM conv / fused FFN) with HIP events on
 # the launch stream: entries are (start_event, end_event, kind, flops).
@@ -534,6 +546,12 @@ def head_ts_pack(w, b, dtype=torch.bfloat16):
     return img.contiguous().view(-1), bias
 
 
+def head_ts_supported(N: int, mode: str) -> bool:
+    """dtlr_head_ts keeps the padded bias (and, for "logits", a per-wave transpose tile) in LDS: charsets up to 24576 classes for "rowmax",
+    15360 for "logits" (head_ts.hip); "logits" also needs N % 4 == 0.  Larger heads run on the tiled GEMM (ops.linear / linear_rowmax)."""
+    return N <= (15360 if mode == "logits" else 24576) and (mode != "logits" or N % 4 == 0)
+
+
 def head_ts(x, img, bias, N: int, mode: str, a_off: int = 0, b_off=None):
     """Token-stationary class head (dtlr_head_ts): x [..., ldx] 16-bit rows; the 256-wide operand A = x[..., a_off:a_off+256] and, when b_off is
     given, B = x[..., b_off:b_off+256] (three products A.Whi + B.Whi + A.Wlo: x = proj_ln_split's [hi | lo | hi] image with a_off 0, b_off 256)
@@ -611,7 +629,11 @@ def ffn_fused(x, w1, b1, w2p, b2, ln_w, ln_b, eps: float = 1e-5, out=None):
     assert y.is_contiguous() and y.shape == x.shape and y.dtype == x.dtype
     M = x.numel() // x.shape[-1]
     # dtlr_ffn_fused_bf16's dispatch (ffn.hip): one ffn2_bf16_kernel<3> launch for 32768 < M <= 49152, the first structure at or below
-    sym = "ffn2_bf16_kernel<3>" if 32768 < M <= 49152 else ("ffn_fused_bf16_kernel<0, false>" if M <= 32768 else None)
+    # ... and, when its 128-token tiles fill at most 96 workgroups (M <= 12288) at d_ff >= 512, the hidden-split pair
+    # ffn_fused_bf16_kernel<0, false, true> + ffn_fused_finish_kernel: TWO kernels, accounted as a class (symbol None) so that a
+    # roofline_by_kernel row always joins to exactly one rocprof symbol
+    hidden_split = (M + 127) // 128 <= 96 and w1.shape[0] >= 512 and min(8, 256 // ((M + 127) // 128), (w1.shape[0] // 32) // 8) >= 2
+    sym = "ffn2_bf16_kernel<3>" if 32768 < M <= 49152 else ("ffn_fused_bf16_kernel<0, false, false>" if (M <= 32768 and not hidden_split) else None)
     with _Timed("ffn_fused_bf16", 4.0 * M * x.shape[-1] * w1.shape[0], 2.0 * M * 256 * 2 + 2.0 * w1.numel() * 2, symbol=sym):
         code = _L(x).dtlr_ffn_fused_bf16(x.data_ptr(), w1.data_ptr(), b1.data_ptr(), w2p.data_ptr(), b2.data_ptr(),
                                               ln_w.data_ptr(), ln_b.data_ptr(), eps, y.data_ptr(), M, x.shape[-1], w1.shape[0],
@@ -657,7 +679,13 @@ def ffn_split(x, wp, b1, b2, ln_w, ln_b, eps: float = 1e-5, out=None):
     y = torch.empty_like(x) if out is None else out
     assert y.is_contiguous() and y.shape == x.shape and y.dtype == x.dtype
     M = x.numel() // 256
-    with _Timed("ffn_fused_f32s", 4.0 * M * 256 * d_ff, 2.0 * M * 256 * 4 + 2.0 * 256 * d_ff * 4, symbol="ffn_split_kernel"):
+    # dtlr_ffn_split's dispatch (ffn_split.hip): whole rounds of 256 tiles on ffn_split_kernel<false>; a last round filling at most half
+    # of the chip runs as ffn_split_kernel<true> + ffn_split_finish_kernel -- then the launch is THREE kernels: class accounting
+    ntiles = (M + 127) // 128
+    full, rem = (ntiles // 256) * 256, ntiles % 256
+    nc2 = ((d_ff // 32) + 1) & ~1
+    ns = min(4, 256 // rem, nc2 // 8) if (rem > 0 and full > 0) else 1
+    with _Timed("ffn_fused_f32s", 4.0 * M * 256 * d_ff, 2.0 * M * 256 * 4 + 2.0 * 256 * d_ff * 4, symbol="ffn_split_kernel<false>" if ns < 2 else None):
         code = _lib.lib().dtlr_ffn_split(x.data_ptr(), wp.data_ptr(), b1.data_ptr(), b2.data_ptr(), ln_w.data_ptr(), ln_b.data_ptr(),
                                          eps, y.data_ptr(), M, d_ff, _lib.current_stream())
     _lib.check(code, "dtlr_ffn_split")

@@ -39,6 +39,19 @@ const char *dtlr_strerror(int code);
 int dtlr_last_hip_error(void);          /* last hipError_t seen by this library (thread-local) */
 int dtlr_abi_version(void);
 
+/* The library's only internal scratch memory: one workspace per (device, stream), used by the split-K convolutions / GEMMs
+ * (dtlr_conv2d_nhwc, dtlr_gemm_nt at grids that cannot fill the chip) and by the hidden-dimension split of dtlr_ffn_fused_bf16 /
+ * dtlr_ffn_split at small M.  Contract:
+ *   - a buffer that has been handed to a launch is never freed or moved (its address may live in a captured HIP graph); a larger
+ *     request allocates a new buffer and keeps the old one (dtlr_workspace_retired_bytes(): how much is kept that way);
+ *   - under stream capture nothing is allocated: a launch borrows the device's largest existing buffer, and falls back to its
+ *     unsplit kernel (another summation order, same tolerance) when none is large enough.  A caller that captures should therefore
+ *     call dtlr_workspace_reserve(bytes, stream) once before capturing (128 MiB covers every shape of a 32-line batch);
+ *   - two streams never share a buffer outside capture.
+ * No reference counterpart (torch's caching allocator plays this role for the reference's temporaries). */
+int dtlr_workspace_reserve(long bytes, void *stream);
+long dtlr_workspace_retired_bytes(void);
+
 /* ---------------------------------------------------------------------------------------------
  * Multi-scale deformable attention forward.
  * Replaces: MultiScaleDeformableAttention.ms_deform_attn_forward
@@ -534,7 +547,7 @@ int dtlr_two_stage_gather(const void *om, const float *proposals, const long *id
  *           s = sum_c p; blank = 1 - s if s < 1 - eps else eps (then p <- (1-eps) p / s); argmax over
  *           [blank | p]; drop blanks; no repeat collapse.
  *   logits [B,nq,C] fp32, boxes [B,nq,4] fp32 (cx first) -> labels [B,nq] int32 left-packed, -1 padded;
- *   lengths [B] int32; -1 for a line with a query whose logits are not finite (NaN / a non-finite sigmoid sum: on the fp16 / split engines an
+ *   lengths [B] int32; -1 for a line with a query that has ANY non-finite logit (NaN, +inf or -inf: on the fp16 / split engines an
  *   activation beyond 65504) -- flagged on the device, no host synchronisation.   eps = 0.03/C (evaluation.py:141) or 0.003 (dino.py:491).
  */
 int dtlr_decode_blank(const float *logits, const float *boxes, int *labels, int *lengths,

@@ -293,6 +293,48 @@ def test_splitk_convolutions_overlapped_on_two_streams():
     assert bad == 0, f"{bad} of 80 overlapped launches differ from their single-stream result"
 
 
+def test_workspace_growth_never_invalidates_a_captured_graph():
+    """Round 6: a workspace pointer baked into a captured HIP graph must stay valid when a later, larger request grows
+    that stream's workspace.  On a fresh stream: a small split-K convolution runs eagerly (allocates the slot), the same launch is captured,
+    then a 10x larger split-K convolution runs eagerly on the same stream (round 5 hipFree()d the small buffer here), then other
+    allocations churn the heap, and the graph is replayed: its output must equal the eager result bit for bit, and the library must
+    report the replaced buffer as retired (kept), not freed.  dtlr_workspace_reserve refuses to run under capture."""
+    from dtlr_amd import _lib, ops
+    x = _rand((1, 4, 64, 2048), 41).cuda()
+    w = (_rand((256, 3, 3, 2048), 42) / np.sqrt(9 * 2048)).cuda()
+    b = _rand((256,), 43).cuda()
+    xbig = _rand((12, 4, 64, 2048), 44).cuda()
+    want = ops.conv2d_nhwc(x, w, b, 2, 1, False, None).clone()
+    retired0 = ops.workspace_retired_bytes()
+    st = torch.cuda.Stream()
+    st.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(st):
+        for _ in range(2):
+            ops.conv2d_nhwc(x, w, b, 2, 1, False, None)            # eager: this stream's slot comes to exist at the small size
+    torch.cuda.synchronize()
+    graph = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(graph, stream=st):
+        out = ops.conv2d_nhwc(x, w, b, 2, 1, False, None)
+        rc = _lib.lib().dtlr_workspace_reserve(1 << 30, _lib.current_stream())
+    assert rc == -1                                                # DTLR_EINVAL: nothing is allocated while capturing
+    graph.replay()
+    torch.cuda.synchronize()
+    assert torch.equal(out, want)
+    with torch.cuda.stream(st):
+        big = ops.conv2d_nhwc(xbig, w, b, 2, 1, False, None)       # 12x the partial tiles: the slot grows
+        ops.workspace_reserve(torch.float32, 64 << 20)              # ... and again
+    torch.cuda.synchronize()
+    assert ops.workspace_retired_bytes() > retired0, "the replaced buffer must be retired (kept allocated), not freed"
+    junk = [torch.full((1 << 20,), float("nan"), device="cuda") for _ in range(64)]      # would land in a freed buffer's pages
+    torch.cuda.synchronize()
+    out.zero_()
+    graph.replay()
+    torch.cuda.synchronize()
+    assert torch.equal(out, want), "replay after the workspace grew differs from the eager result"
+    assert bool(big.isfinite().all())
+    del junk
+
+
 def test_decoder_query_prep_and_box_refine_vs_oracle(half):
     """Fused decoder glue == oracle gen_sineembed_for_position / reference scaling / inverse_sigmoid refinement."""
     from dtlr_amd import ops
@@ -817,6 +859,14 @@ def test_decode_blank_flags_non_finite_lines():
     with pytest.raises(_lib.DTLRError):
         E.records_to_lists(lab1, len1)
     assert E.records_to_lists(lab0, len0)[0] == lab0[0, : int(len0[0])].tolist()
+    # round 6: +inf / -inf logits leave the sigmoid sum FINITE (sigmoid(+inf) = 1, sigmoid(-inf) = 0) -- they are flagged too,
+    # whichever class lane and 64-class chunk they sit in
+    for val, (bb, qq, cc) in ((float("inf"), (0, 0, 0)), (float("-inf"), (2, 451, 70)), (float("inf"), (2, 899, 165)), (float("-inf"), (1, 3, 64))):
+        inf = logits.clone()
+        inf[bb, qq, cc] = val
+        lab2, len2 = ops.decode_blank(inf, boxes, 0.03 / 166)
+        got = len2.tolist()
+        assert got[bb] == -1 and all(got[i] == len0.tolist()[i] for i in range(4) if i != bb), (val, bb, qq, cc, got)
 
 
 @pytest.mark.parametrize("M,N", [(300, 166), (1000, 7356), (257, 2048), (8704, 7356), (31, 36), (512, 4), (50000, 166), (49300, 36)])
