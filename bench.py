@@ -288,9 +288,16 @@ def compact_line(full: dict) -> dict:
     return line
 
 
-def write_detail(full: dict) -> str:
-    """the full result beside the line: gpurun_out/bench_detail.json when that directory exists (it is merged back from the GPU box),
-    else ./bench_detail.json; returns the path relative to the repo root (or "" when nothing could be written)"""
+def write_detail(full: dict, path: str = "") -> str:
+    """the full result beside the line: `path` (--detail) if given, else gpurun_out/bench_detail.json when that directory exists (it is merged
+    back from the GPU box), else ./bench_detail.json; returns the path relative to the repo root (or "" when nothing could be written)"""
+    if path:
+        try:
+            with open(path, "w") as f:
+                json.dump(full, f, indent=1)
+            return os.path.relpath(path, ROOT)
+        except OSError:
+            pass
     for d in (os.path.join(ROOT, "gpurun_out"), ROOT):
         if os.path.isdir(d) and os.access(d, os.W_OK):
             path = os.path.join(d, "bench_detail.json")
@@ -381,6 +388,8 @@ def main():
     ap.add_argument("--single-device", action="store_true", help="all ranks use cuda:0 (tests: two ranks on one GPU need gloo)")
     ap.add_argument("--min-seconds", type=float, default=MIN_TIMED_SECONDS)
     ap.add_argument("--no-bs1", action="store_true", help="skip the single-line latency leg (latency_ms_bs1)")
+    ap.add_argument("--detail", default="", help="where the FULL result (roofline_by_kernel, gemm_by_shape, parity objects ...) is written as JSON; "
+                                                 "default gpurun_out/bench_detail.json, else ./bench_detail.json.  stdout carries the compact line only")
     args = ap.parse_args()
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         raise SystemExit(self_launch(args))
@@ -812,7 +821,7 @@ def main():
     if world == 1 and not args.no_cpu_baseline and args.config == "latin" and not args.backbone:
         line["cpu_baseline"] = cpu_baseline()
         line["speedup_vs_cpu"] = round(line["value"] / line["cpu_baseline"]["value"], 1)
-    line["detail_file"] = write_detail(line)
+    line["detail_file"] = write_detail(line, args.detail)
     log("full result (also in " + (line["detail_file"] or "<not written>") + "): " + json.dumps(line))
     print(json.dumps(compact_line(line)), flush=True)          # ONE line, < 6 KB (STDOUT_LINE_LIMIT)
     ddist.finalize()

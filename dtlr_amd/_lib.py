@@ -23,6 +23,12 @@ class DTLRError(RuntimeError):
     pass
 
 
+class K256sSlice(ctypes.Structure):
+    """include/dtlr_hip.h: dtlr_k256s_slice"""
+    _fields_ = [("Wp", c_void_p), ("bias", c_void_p), ("R", c_void_p), ("C", c_void_p),
+                ("ldc", c_int), ("ldr", c_int), ("n_valid", c_int), ("relu", c_int)]
+
+
 # name -> (restype, argtypes): every symbol include/dtlr_hip.h declares
 _SIGNATURES = {
     "dtlr_strerror": (c_char_p, [c_int]),
@@ -50,6 +56,8 @@ _SIGNATURES = {
                                     c_int, c_int, c_int, c_void_p]),
     "dtlr_conv3x3_patch_supported": (c_int, [c_int, c_int]),
     "dtlr_conv3x3_patch_bf16": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p]),
+    "dtlr_conv3x3_patch_f32s_supported": (c_int, [c_int, c_int]),
+    "dtlr_conv3x3_patch_f32s": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p]),
     "dtlr_gemm_kres_pack_weights": (c_int, [c_void_p, c_void_p, c_int, c_int]),
     "dtlr_gemm_kres_pack_weights_bcast384": (c_int, [c_void_p, c_void_p]),
     "dtlr_gemm_kres_bcast384": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_int, c_void_p]),
@@ -67,6 +75,7 @@ _SIGNATURES = {
     "dtlr_head_ts_pad_chunks": (c_int, []),
     "dtlr_k256s_pack_weights": (c_int, [c_void_p, c_void_p, c_void_p]),
     "dtlr_gemm_k256s": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_float, c_void_p, ctypes.c_long, c_void_p]),
+    "dtlr_gemm_k256s_multi": (c_int, [c_void_p, ctypes.c_long, c_void_p, c_int, c_void_p, c_int, c_void_p]),
     "dtlr_proj_pack_weights": (c_int, [c_void_p, c_void_p]),
     "dtlr_proj_ln_bf16": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_float, c_void_p, c_int, c_int, c_void_p]),
     "dtlr_proj_ln_split_bf16": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_float, c_void_p, c_int, c_int, c_void_p]),

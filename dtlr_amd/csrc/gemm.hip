@@ -1550,6 +1550,9 @@ extern "C" int dtlr_debug_gemm_trace(unsigned long long* out, int clear_only)
 #endif
 
 extern "C" int dtlr_conv3x3_patch_supported(int Cin, int Cout);
+extern "C" int dtlr_conv3x3_patch_f32s_supported(int Cin, int Cout);
+extern "C" int dtlr_conv3x3_patch_f32s(const float* X, const void* Wt, const float* bias, float* Y, int B, int H, int W, int Cin, int Cout,
+                                       int relu, void* stream);
 extern "C" int dtlr_conv3x3_patch_bf16(const void* X, const void* Wt, const float* bias, void* Y, int B, int H, int W, int Cin, int Cout,
                                        int relu, void* stream);
 
@@ -1578,6 +1581,10 @@ extern "C" int dtlr_conv2d_nhwc(const void* X, const void* W, const float* bias,
     if (use_patch && dtype == DTLR_H16 && KH == 3 && KW == 3 && stride == 1 && pad == 1 && !residual && M >= 16384
         && dtlr_conv3x3_patch_supported(Cin, Cout) == 1)
         return dtlr_conv3x3_patch_bf16(X, W, bias, Y, B, H, Wd, Cin, Cout, relu ? 1 : 0, stream);
+    // ... and its split-fp32 form (round 6): the fp32 patch is split into fp16 hi + lo planes once per workgroup instead of once per tap
+    if (use_patch && dtype == DTLR_F32S && KH == 3 && KW == 3 && stride == 1 && pad == 1 && !residual && M >= 16384
+        && dtlr_conv3x3_patch_f32s_supported(Cin, Cout) == 1)
+        return dtlr_conv3x3_patch_f32s((const float*)X, W, bias, (float*)Y, B, H, Wd, Cin, Cout, relu ? 1 : 0, stream);
     if (dtype == DTLR_H16) return launch_conv<uint16_t, uint16_t>(X, W, bias, residual, Y, (int)M, Cout, K, flags, cp, st);
     if (dtype == DTLR_F32S) return launch_conv<f32s_t, float>(X, W, bias, residual, Y, (int)M, Cout, K, flags, cp, st);
     return launch_conv<float, float>(X, W, bias, residual, Y, (int)M, Cout, K, flags, cp, st);

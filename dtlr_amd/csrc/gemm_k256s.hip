@@ -260,6 +260,262 @@ __global__ __launch_bounds__(512, 1) void gemm_k256s_kernel(
     }
 }
 
+// ---- the same projection with several OUTPUT SLICES per launch (round 6) -------------------------------------------------------------------
+//     slice y (blockIdx.y):  C_y[M, n_valid_y] = act( A[M, 256] . W_y^T + bias_y + R_y ),   rows with row_mask != 0 written as zeros
+// Every slice multiplies the SAME token tiles by its own resident [256, 256] weight image (rows >= n_valid zero: the waves that own them
+// only help with the DMA and the split) and writes its own column range / buffer (row stride ldc).  Use: the split-fp32 engine's decoder,
+// value_proj(memory) of all six cross-attention layers (ms_deform_attn.py:94-96) as six slices of one [M, 1536] buffer (474-534 us against
+// 565 through the tiled GEMM).  res_rows > 0: R_y is ONE [res_rows, ldr] matrix shared by the M / res_rows images (row m pairs with row
+// m % res_rows) and tiles are walked position-major; res_rows == 0: R_y (if any) is [M, ldr].
+// What was measured while building it (tools/experiments/k256s_multi_bench.py, B = 32, M = 174080; boxes differ by +-10 %):
+//   * the slices of one launch do NOT share their token tiles through the XCD's L2 (n plain slices cost n x one slice: 112 / 196 / 266 / 484 us
+//     for 1 / 2 / 3 / 6): with 128 KB of stores per tile step and CU a 64 KB tile is evicted before its peer slices read it.  The encoder form
+//     (value_proj | offsets | logits of `src` as three slices with the position term as a row-broadcast residual, ms_deform_attn.py:94-98)
+//     therefore takes 302-314 us against 89 + 192 for the two launches it would replace: built, tested, OFF in the engine;
+//   * the launch time follows 0.10 us per MB read + 0.53 us per MB written (a second 178 MB stream to read costs +18 us, halving the
+//     written bytes -46 us) although plain elementwise kernels on the same box read AND write at 6 TB/s: the kernel is bound by its own
+//     tile loop, not by HBM.  Ablation of this kernel (run-time switches, same call): 94.6 us complete; without the MFMAs 83.0; without
+//     the global stores 77.7; without either 36.4; additionally without the in-loop DMA 29.9; the bare loop (barriers, raw reads) 24.0 --
+//     i.e. DMA + split ~12 us, MFMAs ~42 us (192 MFMAs of 17 cycles per SIMD and 32-token tile), stores ~46 us, skeleton ~24 us, of
+//     which only the MFMA and store phases overlap.  Neither the tile -> workgroup order (XCD bands / plain bands / strided: 111.7 / 114.3 /
+//     112.9 us), nor this software-pipelined loop (two DMA tiles in flight, split of tile t + 1 under the MFMAs of tile t: 111.9 us), nor
+//     whole-row 1 KB stores through an LDS transpose (119.5 us) moved it beyond box noise.
+struct KsSlice { const uint16_t* Wp; const float* bias; const float* R; float* C; const uint8_t* row_mask; int ldc, ldr, n_valid, relu; };
+constexpr int KS_MAX_SLICES = 8;
+struct KsMulti { KsSlice s[KS_MAX_SLICES]; };
+
+// Software-pipelined tile loop (round 6).  gemm_k256s_kernel above walks 64-token tiles through raw buffer -> split -> barrier -> image ->
+// barrier -> MFMAs -> stores with every wave in the same phase at the same time: 10.5 us per tile and CU whatever the traffic (a launch
+// with a second [M, 256] stream to read took 130 us against 112: the kernel was never bandwidth-bound, its phases just do not overlap).
+// Here a tile is 32 tokens, the raw buffer AND the image are double-buffered (4 x 32 KB), and an iteration is
+//     read my 4 raw rows of tile t + 1 -> registers | request tile t's residual rows | DMA tile t + 3 into the raw slot just read |
+//     split tile t + 1 into image slot (t + 1) & 1 | MFMAs on image slot t & 1 | epilogue + stores of tile t | ONE barrier
+// so a wave's split of the next tile overlaps the other waves' MFMAs of this one, two tiles of DMA are always in flight, and the three
+// MFMAs of a product go to the four accumulators in turn (a dependent MFMA is three others away).
+constexpr int KP_TOK = 32;
+constexpr int KP_STAGE = KP_TOK * 1024;            // 32 KB: 32 fp32 rows of 256 (raw) / their hi | lo fp16 image
+constexpr int KP_IMG_OFF = 2 * KP_STAGE;
+constexpr int KP_PAR_OFF = 4 * KP_STAGE;
+constexpr int KP_LDS = KP_PAR_OFF + 256 * 4;
+
+template <int N> __device__ __forceinline__ void kp_wait() {
+    asm volatile("s_waitcnt vmcnt(%0)" :: "n"(N) : "memory");
+}
+
+template <bool MASK>
+__global__ __launch_bounds__(512, 1) void gemm_k256s_multi_kernel(const float* __restrict__ A, KsMulti P, int M, int tiles_per_wg, int res_rows, int n_img)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char ks_smem[];
+    const unsigned lds_base = (unsigned)(size_t)(__attribute__((address_space(3))) unsigned char*)ks_smem;
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const int n = lane & 15, g = lane >> 4;
+    const KsSlice& S = P.s[blockIdx.y];
+    const uint16_t* __restrict__ Wp = S.Wp;
+    const float* __restrict__ R = S.R;
+    float* __restrict__ C = S.C;
+    const uint8_t* __restrict__ row_mask = S.row_mask;
+    const int ldc = S.ldc, ldr = S.ldr, relu = S.relu;
+    const bool active = 32 * wave < S.n_valid;                       // wave-uniform: this wave's 32 channels exist
+    const bool has_r = active && R != nullptr;
+    const int ntiles = (M + KP_TOK - 1) / KP_TOK;
+    const int t_begin = (int)blockIdx.x * tiles_per_wg;
+    const int t_end = min(t_begin + tiles_per_wg, ntiles);
+    if (t_begin >= t_end) return;
+    // res_rows > 0: position-major walk -- tile t = position tile t / n_img of image t % n_img (res_rows % 32 == 0)
+    auto row0 = [&](int t) -> long {
+        if (n_img > 0) { const int pt = t / n_img; return (long)(t - pt * n_img) * res_rows + (long)pt * KP_TOK; }
+        return (long)t * KP_TOK;
+    };
+    // DMA of tile t into raw slot t & 1: 32 rows of 1 KB, this wave issues (and later splits) rows 4 wave .. 4 wave + 3
+    auto issue = [&](int t) {
+        const long r0 = row0(t);
+        const unsigned dst = lds_base + (unsigned)((t & 1) * KP_STAGE);
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int row = 4 * wave + u;
+            const long tok = min(r0 + row, (long)M - 1);
+            ks_glds16(A + tok * 256 + lane * 4, dst + (unsigned)(row * 1024));
+        }
+    };
+    // split my 4 raw rows (registers) into image slot `slot`: 8 bytes of hi at chunk (L >> 1) ^ (row & 15), half L & 1; lo 512 B further
+    auto split_store = [&](const float4 (&raw)[4], int slot) {
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            uint2 sh, sl;
+            ks_split2(raw[u].x, raw[u].y, sh.x, sl.x);
+            ks_split2(raw[u].z, raw[u].w, sh.y, sl.y);
+            const int row = 4 * wave + u;
+            unsigned char* dst = ks_smem + KP_IMG_OFF + slot * KP_STAGE + row * 1024 + (((lane >> 1) ^ (row & 15)) * 16) + (lane & 1) * 8;
+            *reinterpret_cast<uint2*>(dst) = sh;
+            *reinterpret_cast<uint2*>(dst + 512) = sl;
+        }
+    };
+    auto read_raw = [&](float4 (&raw)[4], int slot) {
+#pragma unroll
+        for (int u = 0; u < 4; ++u) raw[u] = *reinterpret_cast<const float4*>(ks_smem + slot * KP_STAGE + (4 * wave + u) * 1024 + lane * 16);
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    };
+
+    issue(t_begin);
+    if (t_begin + 1 < t_end) issue(t_begin + 1);
+
+    uint4 wh[2][8], wl[2][8];
+#pragma unroll
+    for (int rt = 0; rt < 2; ++rt)
+#pragma unroll
+        for (int ks = 0; ks < 8; ++ks) {
+            const long f = ((long)(wave * 2 + rt) * 8 + ks) * 64 + lane;
+            wh[rt][ks] = active ? *reinterpret_cast<const uint4*>(Wp + f * 8) : make_uint4(0u, 0u, 0u, 0u);
+            wl[rt][ks] = active ? *reinterpret_cast<const uint4*>(Wp + (8L * 2 * 8 * 64 + f) * 8) : make_uint4(0u, 0u, 0u, 0u);
+        }
+    float* par = reinterpret_cast<float*>(ks_smem + KP_PAR_OFF);
+    if (threadIdx.x < 256) par[threadIdx.x] = (S.bias && (int)threadIdx.x < S.n_valid) ? S.bias[threadIdx.x] : 0.f;
+    kp_wait<0>();                                                    // both prologue tiles and the resident operand have landed
+#pragma unroll
+    for (int rt = 0; rt < 2; ++rt) {
+#pragma unroll
+        for (int ks = 0; ks < 8; ++ks) {
+            asm volatile("" : "+v"(wh[rt][ks].x), "+v"(wh[rt][ks].y), "+v"(wh[rt][ks].z), "+v"(wh[rt][ks].w));
+            asm volatile("" : "+v"(wl[rt][ks].x), "+v"(wl[rt][ks].y), "+v"(wl[rt][ks].z), "+v"(wl[rt][ks].w));
+        }
+    }
+    {   // tile t_begin: raw slot 0 -> image slot of its parity; its raw slot then takes tile t_begin + 2
+        float4 raw[4];
+        read_raw(raw, t_begin & 1);
+        if (t_begin + 2 < t_end) issue(t_begin + 2);
+        split_store(raw, t_begin & 1);
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    }
+    __builtin_amdgcn_s_barrier();
+
+    int mk[2] = {0, 0};
+    for (int t = t_begin; t < t_end; ++t) {
+        const long r0 = row0(t);
+        const bool nxt = t + 1 < t_end;                              // a next tile exists: split it in this iteration
+        const bool dma3 = t + 3 < t_end;                             // ... and tile t + 3 is requested into the raw slot it frees
+        if constexpr (MASK) {                                        // this tile's flags (compiler-counted loads: pinned before anything I count)
+#pragma unroll
+            for (int tt = 0; tt < 2; ++tt) mk[tt] = row_mask[min(r0 + 16 * tt + n, (long)M - 1)];
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#pragma unroll
+            for (int tt = 0; tt < 2; ++tt) asm volatile("" : "+v"(mk[tt]));
+        }
+        float4 raw[4];
+        if (nxt) {
+            // my rows of tile t + 1 have landed.  In-order counter; requests younger than that DMA group (issued in iteration t - 2, or in the
+            // prologue): stores(t - 2) [4], residual(t - 1) [4], DMA(t + 2) [4], stores(t - 1) [4] -- those that exist.  The first two
+            // iterations follow the prologue's vmcnt(0) (the DMA they need was covered by it or by iteration 0's own wait below).
+            if constexpr (!MASK) {
+                const bool d2 = t + 2 < t_end;
+                if (t - t_begin < 2) { if (t == t_begin) {} else kp_wait<0>(); }
+                else if (has_r) { if (d2) kp_wait<16>(); else kp_wait<12>(); }
+                else            { if (d2) kp_wait<12>(); else kp_wait<8>(); }
+            }
+            read_raw(raw, (t + 1) & 1);
+        }
+        uint4 rr[2][2];
+        if (has_r) {
+            const long rbase = n_img > 0 ? (long)(t / n_img) * KP_TOK : r0;
+#pragma unroll
+            for (int tt = 0; tt < 2; ++tt) {
+                const long rrow = n_img > 0 ? rbase + 16 * tt + n : min(rbase + 16 * tt + n, (long)M - 1);
+#pragma unroll
+                for (int rt = 0; rt < 2; ++rt)
+                    asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(rr[tt][rt]) : "v"(R + rrow * ldr + wave * 32 + rt * 16 + 4 * g) : "memory");
+            }
+        }
+        if (dma3) issue(t + 3);
+        if (nxt) split_store(raw, (t + 1) & 1);
+
+        ks_f32x4_t acc[2][2];                                        // the accumulators, then (bias / residual / ReLU / mask applied in place) the output values
+        if (active) {
+            const unsigned char* tile = ks_smem + KP_IMG_OFF + (t & 1) * KP_STAGE;
+#pragma unroll
+            for (int rt = 0; rt < 2; ++rt)
+#pragma unroll
+                for (int tt = 0; tt < 2; ++tt) acc[rt][tt] = ks_f32x4_t{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int ks = 0; ks < 8; ++ks) {
+                uint4 xh[2], xl[2];
+#pragma unroll
+                for (int tt = 0; tt < 2; ++tt) {
+                    const unsigned char* rp = tile + (16 * tt + n) * 1024 + (((4 * ks + g) ^ n) * 16);
+                    xh[tt] = *reinterpret_cast<const uint4*>(rp);
+                    xl[tt] = *reinterpret_cast<const uint4*>(rp + 512);
+                }
+#pragma unroll
+                for (int rt = 0; rt < 2; ++rt)
+#pragma unroll
+                    for (int tt = 0; tt < 2; ++tt) acc[rt][tt] = ks_mma(wh[rt][ks], xl[tt], acc[rt][tt]);
+#pragma unroll
+                for (int rt = 0; rt < 2; ++rt)
+#pragma unroll
+                    for (int tt = 0; tt < 2; ++tt) acc[rt][tt] = ks_mma(wl[rt][ks], xh[tt], acc[rt][tt]);
+#pragma unroll
+                for (int rt = 0; rt < 2; ++rt)
+#pragma unroll
+                    for (int tt = 0; tt < 2; ++tt) acc[rt][tt] = ks_mma(wh[rt][ks], xh[tt], acc[rt][tt]);
+            }
+            float4 bv[2];
+#pragma unroll
+            for (int rt = 0; rt < 2; ++rt) bv[rt] = *reinterpret_cast<const float4*>(par + wave * 32 + rt * 16 + 4 * g);
+            if (has_r) {
+                // the residual rows have landed: the only requests younger than them are tile t + 3's 4 DMA rows (if issued)
+                if (dma3) kp_wait<4>(); else kp_wait<0>();
+#pragma unroll
+                for (int tt = 0; tt < 2; ++tt)
+#pragma unroll
+                    for (int rt = 0; rt < 2; ++rt) asm volatile("" : "+v"(rr[tt][rt].x), "+v"(rr[tt][rt].y), "+v"(rr[tt][rt].z), "+v"(rr[tt][rt].w));
+            }
+#pragma unroll
+            for (int tt = 0; tt < 2; ++tt) {
+                const bool masked = MASK && mk[tt] != 0;
+#pragma unroll
+                for (int rt = 0; rt < 2; ++rt) {
+                    ks_f32x4_t v = acc[rt][tt] + ks_f32x4_t{bv[rt].x, bv[rt].y, bv[rt].z, bv[rt].w};
+                    if (has_r) v += ks_f32x4_t{__uint_as_float(rr[tt][rt].x), __uint_as_float(rr[tt][rt].y), __uint_as_float(rr[tt][rt].z), __uint_as_float(rr[tt][rt].w)};
+                    if (relu) v = ks_f32x4_t{fmaxf(v[0], 0.f), fmaxf(v[1], 0.f), fmaxf(v[2], 0.f), fmaxf(v[3], 0.f)};
+                    if (masked) v = ks_f32x4_t{0.f, 0.f, 0.f, 0.f};
+                    acc[rt][tt] = v;
+                }
+            }
+        }
+        // ---- the output tile leaves through LDS so that every store instruction writes ONE whole row (1 KB contiguous) ------------------
+        // As 16-byte stores straight from the accumulator layout an instruction wrote 64 bytes of each of 16 rows, and the launch time
+        // followed 0.10 us per MB read + 0.53 us per MB WRITTEN (tools/experiments/k256s_multi_bench.py: 112 us plain, 130 us with a second
+        // 178 MB stream to read, 66 us for a 128-channel slice): the scattered 64-byte writes, not the reads, set the time.
+        __builtin_amdgcn_s_barrier();                                // every wave has finished its MFMA reads of image(t): the slot is the staging tile now
+        unsigned char* stg = ks_smem + KP_IMG_OFF + (t & 1) * KP_STAGE;
+        if (active) {
+#pragma unroll
+            for (int tt = 0; tt < 2; ++tt)
+#pragma unroll
+                for (int rt = 0; rt < 2; ++rt)             // row 16 tt + n, 16-byte chunk (8 wave + 4 rt + g) ^ n: conflict-free for the 16 rows of a group
+                    *reinterpret_cast<ks_f32x4_t*>(stg + (16 * tt + n) * 1024 + (((8 * wave + 4 * rt + g) ^ n) * 16)) = acc[rt][tt];
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        {
+            // 4 store instructions per wave and iteration, every wave (the hand-counted waits rely on it; only the ragged last tile of the whole
+            // problem issues fewer, in its workgroup's last iteration)
+            const int rw = 4 * wave;
+            const ks_f32x4_t o0 = *reinterpret_cast<const ks_f32x4_t*>(stg + (rw + 0) * 1024 + ((lane ^ ((rw + 0) & 15)) * 16));
+            const ks_f32x4_t o1 = *reinterpret_cast<const ks_f32x4_t*>(stg + (rw + 1) * 1024 + ((lane ^ ((rw + 1) & 15)) * 16));
+            const ks_f32x4_t o2 = *reinterpret_cast<const ks_f32x4_t*>(stg + (rw + 2) * 1024 + ((lane ^ ((rw + 2) & 15)) * 16));
+            const ks_f32x4_t o3 = *reinterpret_cast<const ks_f32x4_t*>(stg + (rw + 3) * 1024 + ((lane ^ ((rw + 3) & 15)) * 16));
+            const bool colok = 4 * lane < S.n_valid;
+            float* crow = C + (r0 + rw) * ldc + 4 * lane;
+            if (colok && r0 + rw + 0 < M) *reinterpret_cast<ks_f32x4_t*>(crow) = o0;
+            if (colok && r0 + rw + 1 < M) *reinterpret_cast<ks_f32x4_t*>(crow + ldc) = o1;
+            if (colok && r0 + rw + 2 < M) *reinterpret_cast<ks_f32x4_t*>(crow + 2L * ldc) = o2;
+            if (colok && r0 + rw + 3 < M) *reinterpret_cast<ks_f32x4_t*>(crow + 3L * ldc) = o3;
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();                                // image(t + 1) complete; image(t) and raw(t + 1) no longer read
+    }
+}
+
 // fp32 weight [256, 256] -> the resident-operand image: [hi | lo][wave 8][rt 2][ks 8][lane 64][8 halves]
 __global__ __launch_bounds__(256) void k256s_pack_kernel(const float* __restrict__ w, uint16_t* __restrict__ out)
 {
@@ -284,6 +540,43 @@ extern "C" int dtlr_k256s_pack_weights(const float* w, void* out, void* stream)
     clear_stale_error();
     if (!w || !out) return DTLR_EINVAL;
     hipLaunchKernelGGL(k256s_pack_kernel, dim3(32), dim3(256), 0, (hipStream_t)stream, w, (uint16_t*)out);
+    return check_launch();
+}
+
+// One pass over A [M, 256] fp32 for `nslices` (1..8) output slices (the kernel's notes; dtlr_hip.h documents the structure).
+extern "C" int dtlr_gemm_k256s_multi(const float* A, long M, const dtlr_k256s_slice* slices, int nslices, const unsigned char* row_mask, int res_rows, void* stream)
+{
+    clear_stale_error();
+    if (!A || !slices) return DTLR_EINVAL;
+    if (M <= 0 || M > 0x7fffffffL || nslices < 1 || nslices > KS_MAX_SLICES || res_rows < 0) return DTLR_EINVAL;
+    if (res_rows > 0 && ((res_rows % KP_TOK) || (M % res_rows))) return DTLR_ESHAPE;
+    const dtlr_k256s_slice* sl = slices;
+    KsMulti P{};
+    for (int i = 0; i < nslices; ++i) {
+        if (!sl[i].Wp || !sl[i].C) return DTLR_EINVAL;
+        if (sl[i].n_valid < 32 || sl[i].n_valid > 256 || (sl[i].n_valid & 31) || sl[i].ldc < sl[i].n_valid || (sl[i].ldc & 3)) return DTLR_ESHAPE;
+        if (sl[i].R && (sl[i].ldr < sl[i].n_valid || (sl[i].ldr & 3))) return DTLR_ESHAPE;
+        if (((size_t)sl[i].C & 15) || ((size_t)sl[i].R & 15)) return DTLR_ESHAPE;
+        P.s[i] = KsSlice{(const uint16_t*)sl[i].Wp, sl[i].bias, sl[i].R, sl[i].C, row_mask, sl[i].ldc, sl[i].ldr, sl[i].n_valid, sl[i].relu};
+    }
+    for (int i = nslices; i < KS_MAX_SLICES; ++i) P.s[i] = P.s[0];
+    const int ntiles = (int)((M + KP_TOK - 1) / KP_TOK);
+    // one workgroup per CU (129 KB of LDS): gridDim.x * nslices <= 256; workgroup b of a slice owns tiles [b per, (b + 1) per)
+    int gx = 256 / nslices;
+    if (gx > ntiles) gx = ntiles;
+    const int per = (ntiles + gx - 1) / gx;
+    gx = (ntiles + per - 1) / per;
+    const int n_img = res_rows > 0 ? (int)(M / res_rows) : 0;
+    hipStream_t st = (hipStream_t)stream;
+    if (row_mask) {
+        static DevOnce once;
+        if (once.first()) { (void)hipFuncSetAttribute((const void*)gemm_k256s_multi_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, KP_LDS); (void)hipGetLastError(); }
+        hipLaunchKernelGGL((gemm_k256s_multi_kernel<true>), dim3(gx, nslices), dim3(512), KP_LDS, st, A, P, (int)M, per, res_rows, n_img);
+    } else {
+        static DevOnce once;
+        if (once.first()) { (void)hipFuncSetAttribute((const void*)gemm_k256s_multi_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, KP_LDS); (void)hipGetLastError(); }
+        hipLaunchKernelGGL((gemm_k256s_multi_kernel<false>), dim3(gx, nslices), dim3(512), KP_LDS, st, A, P, (int)M, per, res_rows, n_img);
+    }
     return check_launch();
 }
 

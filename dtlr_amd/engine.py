@@ -86,8 +86,26 @@ class DTLREngine:
         self.head_ts_min_classes = 1024   # 16-bit engines: class heads with at least this many classes run on the token-stationary kernel (dtlr_head_ts)
         self.head_ts_scores = True        # ... and the two-stage selection scores (row maximum: no logits leave the chip) for EVERY charset: 142 -> 74 us at 166 classes
         self.use_ow_resbcast = True       # fp32 / split: the encoder's [offsets | logits] projection as src W^T + (pos W^T + b), unpadded batches
+        # split: value_proj(memory) of the six decoder layers as six slices of one launch (dtlr_gemm_k256s_multi): 474-534 us against 565
+        # through the tiled GEMM.  The encoder form -- value_proj + [offsets | logits] of `src` as three slices of one launch -- is built and
+        # tested but OFF: measured 302-314 us against 89 + 192 for the two launches it replaces (tools/experiments/k256s_multi_bench.py): the
+        # slices' token tiles do NOT meet in the XCD's L2, so every slice streams `src` again (gemm_k256s.hip's notes).
+        self.use_k256s_multi = True
+        self.use_k256s_multi_enc = False
         self._range_check_pending = (dtype == torch.float16) or self.split      # engines whose operands are fp16: see forward()
         self._ws_streams = set()           # streams whose library workspace this engine has pre-sized (ops.workspace_reserve)
+        # Round 6: independent launches on side HIP streams (fork / join with stream waits; buffers that cross streams are allocated on
+        # the caller's stream BEFORE the fork and outlive the join, so the caching allocator never hands a block to another stream early):
+        #   * input_proj + GroupNorm of level 0 (on C3) runs under layer3, of level 1 (on C4) under layer4 -- layer3 / layer4 launch
+        #     128-512 workgroups on 256 CUs (8,192-32,768 pixels per map at B = 32) and leave the HBM idle;
+        #   * value_proj(memory) of the six decoder layers runs under the two-stage selection (top-k: 32 workgroups; gathers; box MLP).
+        #   * the shortcut (`downsample`) convolution of a ResNet layer's first bottleneck runs under its conv1 -> conv2;
+        # Same kernels, same arguments, same per-kernel arithmetic: results are bit-identical to the one-stream schedule.
+        self.overlap_streams = True
+        self._side_streams = [torch.cuda.Stream(device=self.device) for _ in range(3)]      # created (and their library workspace pre-sized) HERE:
+        for st in self._side_streams:                                                       # nothing is created or allocated under a later capture
+            with torch.cuda.stream(st):
+                ops.workspace_reserve(self.dtype, 16 << 20)
 
     def check_activation_range(self) -> None:
         """re-arm the fp16-range check of the f16 / f32s engines for the next forward (it runs on the first forward only: a host sync)"""
@@ -113,8 +131,8 @@ class DTLREngine:
         self.w[name + ".b"] = b.to(device=self.device, dtype=torch.float32).contiguous()
 
     def _put_linear(self, name, w, b):
-        if self.split and (name.endswith((".ff1", ".ff2", ".attn.out", ".sa.out")) or (name.startswith("enc") and name.endswith(".attn.value"))
-                           or name == "enc_output"):
+        if self.split and (name.endswith((".ff1", ".ff2", ".attn.out", ".sa.out")) or (name.startswith("enc") and name.endswith((".attn.value", ".attn.ow")))
+                           or name in ("enc_output", "dec.value_all")):
             # the fused split FFN and the weight-resident K = 256 projections pack their own images from the fp32 weights
             self._ffn_f32[name] = w.to(device=self.device, dtype=torch.float32).contiguous()
             if not name.endswith((".ff1", ".ff2")) and tuple(w.shape) == (256, 256):
@@ -443,10 +461,24 @@ class DTLREngine:
                 q = f"l{li}.{bi}."
                 stride = 2 if (bi == 0 and li > 1) else 1
                 cat = li == 2 and bi == 0 and self.use_l2_cat and x.dtype in ops.H16 and x.shape[-1] == 256 and self.w[q + "c3.w"].shape == (512, 128)
-                idt = None if cat else (self._conv(q + "ds", x, stride, 0) if bi == 0 else x)
+                join = None
+                if cat:
+                    idt = None
+                elif bi != 0:
+                    idt = x
+                elif getattr(self, "overlap_streams", False) and x.is_cuda:
+                    # the shortcut convolution of a layer's first bottleneck is independent of conv1 -> conv2: on a side stream under them
+                    cur, join = self._side(2)
+                    join.wait_stream(cur)
+                    with torch.cuda.stream(join):
+                        idt = self._conv(q + "ds", x, stride, 0)
+                else:
+                    idt = self._conv(q + "ds", x, stride, 0)
                 o = pre if pre is not None else self._conv(q + "c1", x, 1, 0, relu=True)
                 pre = None
                 o = self._conv(q + "c2", o, stride, 1, relu=True)
+                if join is not None:
+                    cur.wait_stream(join)
                 if cat:       # the strided shortcut convolution as K columns 128..383 of the tail GEMM: no shortcut map, no gather launch
                     if q + "cat.wk" not in self.w:
                         self.w[q + "cat.wk"] = ops.kres_pack(torch.cat([self.w[q + "c3.w"], self.w[q + "ds.w"]], 1).contiguous())
@@ -514,6 +546,23 @@ class DTLREngine:
         key = name + ".k256s"
         if key not in self.w:
             self.w[key] = ops.k256s_pack(self._ffn_f32.pop(name))
+        return self.w[key]
+
+    def _k256s_slices(self, name):
+        """split engine: the weight [N, 256] of projection `name` (N a multiple of 128) as ceil(N / 256) resident-operand images of
+        dtlr_gemm_k256s_multi, the last one zero-padded to 256 rows; packed once from the fp32 weight.  Returns [(image, first row, rows)]."""
+        key = name + ".k256sm"
+        if key not in self.w:
+            wf = self._ffn_f32.pop(name)
+            N = wf.shape[0]
+            imgs = []
+            for r0 in range(0, N, 256):
+                n = min(256, N - r0)
+                blk = wf[r0:r0 + n]
+                if n < 256:
+                    blk = torch.cat([blk, blk.new_zeros((256 - n, 256))], 0)
+                imgs.append((ops.k256s_pack(blk.contiguous()), r0, n))
+            self.w[key] = imgs
         return self.w[key]
 
     def _k256w(self, name):
@@ -587,6 +636,20 @@ class DTLREngine:
         M, L, P = cfg.nheads, cfg.num_feature_levels, n_points
         k256 = self.use_k256 and query.dtype in ops.H16 and C == 256 and Lq == S
         k256s = self.split and self.use_k256s and C == 256 and Lq == S and (name + ".value") in self._k256s_ok
+        ow = None
+        if (k256s and self.use_k256s_multi_enc and value is None and ow_res is not None and not g["has_padding"] and value_src is query
+                and query.is_contiguous() and ((name + ".ow") in self._ffn_f32 or (name + ".ow.k256sm") in self.w)
+                and tuple(self.w[name + ".ow.w"].shape) == (384, 256) and ow_res.shape[-2] == S and S % 32 == 0):
+            # split engine, unpadded batch: value_proj(src) and [offsets | logits](src + pos) = src W^T + (pos W^T + b) in ONE pass over src
+            # (three slices: 256 | 256 | 128 channels; the position term is the row-broadcast residual of the last two)
+            vimg = self._k256sw(name + ".value")
+            oimgs = self._k256s_slices(name + ".ow")
+            value = torch.empty((B, S, 256), dtype=torch.float32, device=query.device)
+            ow = torch.empty((B, S, 384), dtype=torch.float32, device=query.device)
+            sl = [dict(wp=vimg, out=value, bias=self.w[name + ".value.b"])]
+            for img, r0, nr in oimgs:
+                sl.append(dict(wp=img, out=ow[..., r0:r0 + nr], residual=ow_res[..., r0:r0 + nr]))
+            ops.gemm_k256s_multi(query, sl, res_rows=S)
         if value is None:
             if k256s:
                 value = ops.gemm_k256s(value_src, self._k256sw(name + ".value"), self.w[name + ".value.b"],
@@ -598,7 +661,9 @@ class DTLREngine:
                 value = self._lin(name + ".value", value_src, row_mask=g["mask_flat"] if g["has_padding"] else None)
         # the [offsets|logits] row stays in the activation dtype: in the bf16 engine its 2^-8 relative rounding
         # moves a sampling point by < 0.02 px, far below the bf16 noise of the sampled values themselves
-        if k256 and ow_res is not None:
+        if ow is not None:
+            pass
+        elif k256 and ow_res is not None:
             # unpadded batch: (src + pos) W^T + b = src W^T + (pos W^T + b), and the second term is ONE [S, 384] matrix for every
             # image (L2-resident): the projection streams src alone and adds the row-broadcast term in its epilogue
             rows = ow_res.numel() // 384
@@ -734,9 +799,44 @@ class DTLREngine:
         """sigmoid(bbox_embed(x) + inverse_sigmoid(ref)) (deformable_transformer.py:734-756; dino.py:339-354)."""
         return self._box_mlp("bbox", x, ref, mode=0)
 
-    def decoder(self, memory, ts, g, want_aux=False, dbg=None):
+    def _side(self, i: int):
+        """(current stream, side stream i).  One set of side streams per engine: two forwards of one engine issued from two caller streams
+        at once share them -- that only adds ordering between the two, never a race (every use is bracketed by stream waits)."""
+        return torch.cuda.current_stream(self.device), self._side_streams[i]
+
+    def _value_all_alloc(self, memory):
+        Nall = self.w["dec.value_all.w"].shape[0]
+        return torch.empty(memory.shape[:-1] + (Nall,), dtype=memory.dtype, device=memory.device)
+
+    def _value_all_into(self, memory, g, vall) -> bool:
+        """value_proj(memory) of ALL decoder layers into the caller's [B, S, layers x 256] buffer (same input, N = layers x 256: memory is
+        read once instead of once per layer; layer n samples its column slice through the strided MSDA entry point).  False: no
+        out-of-place form for this engine / shape (the caller runs ops.linear)."""
+        C = self.cfg.hidden_dim
+        rmask = g["mask_flat"] if g["has_padding"] else None
+        Nall = self.w["dec.value_all.w"].shape[0]
+        if self.use_k256 and memory.dtype in ops.H16 and C == 256 and Nall % 384 == 0:
+            # weight-resident streaming kernel, 384 output channels per launch, written as column slices of one [B, S, N] buffer
+            for j in range(Nall // 384):
+                key = f"dec.value_all.k256.{j}"
+                if key not in self.w:
+                    self.w[key] = ops.k256_pack(self.w["dec.value_all.w"][384 * j:384 * (j + 1)])
+                ops.gemm_k256(memory, self.w[key], 384, self.w["dec.value_all.b"][384 * j:384 * (j + 1)], row_mask=rmask,
+                              out=vall[..., 384 * j:384 * (j + 1)])
+            return True
+        if (self.split and self.use_k256s_multi and C == 256 and Nall % 256 == 0 and Nall // 256 <= 8 and memory.is_contiguous()
+                and ("dec.value_all" in self._ffn_f32 or "dec.value_all.k256sm" in self.w)):
+            # split engine: the six value projections as six slices of ONE pass over memory (dtlr_gemm_k256s_multi)
+            bias = self.w["dec.value_all.b"]
+            ops.gemm_k256s_multi(memory, [dict(wp=img, out=vall[..., r0:r0 + nr], bias=bias[r0:r0 + nr]) for img, r0, nr in self._k256s_slices("dec.value_all")],
+                                 row_mask=rmask)
+            return True
+        return False
+
+    def decoder(self, memory, ts, g, want_aux=False, dbg=None, vall=None):
         """TransformerDecoder.forward + DeformableTransformerDecoderLayer
-        (deformable_transformer.py:652-766, 882-997), batch-first."""
+        (deformable_transformer.py:652-766, 882-997), batch-first.  vall: value_proj(memory) of all layers when the caller already
+        computed it (forward() does, on a side stream under the two-stage selection)."""
         cfg = self.cfg
         B = memory.shape[0]
         ref = ts["ref_unsig"].sigmoid()
@@ -747,22 +847,11 @@ class DTLREngine:
         tgt = self.w["tgt_embed"][None].expand(B, -1, -1).contiguous()
         refs = [ref]
         hs = []
-        # value_proj(memory) of all decoder layers in ONE GEMM (same input, N = layers x 256): memory is read once instead
-        # of once per layer; layer n samples its column slice through the strided MSDA entry point
         C = cfg.hidden_dim
-        rmask = g["mask_flat"] if g["has_padding"] else None
-        Nall = self.w["dec.value_all.w"].shape[0]
-        if self.use_k256 and memory.dtype in ops.H16 and C == 256 and Nall % 384 == 0:
-            # weight-resident streaming kernel, 384 output channels per launch, written as column slices of one [B, S, N] buffer
-            vall = torch.empty(memory.shape[:-1] + (Nall,), dtype=memory.dtype, device=memory.device)
-            for j in range(Nall // 384):
-                key = f"dec.value_all.k256.{j}"
-                if key not in self.w:
-                    self.w[key] = ops.k256_pack(self.w["dec.value_all.w"][384 * j:384 * (j + 1)])
-                ops.gemm_k256(memory, self.w[key], 384, self.w["dec.value_all.b"][384 * j:384 * (j + 1)], row_mask=rmask,
-                              out=vall[..., 384 * j:384 * (j + 1)])
-        else:
-            vall = ops.linear(memory, self.w["dec.value_all.w"], self.w["dec.value_all.b"], row_mask=rmask)
+        if vall is None:
+            vall = self._value_all_alloc(memory)
+            if not self._value_all_into(memory, g, vall):
+                vall = ops.linear(memory, self.w["dec.value_all.w"], self.w["dec.value_all.b"], row_mask=g["mask_flat"] if g["has_padding"] else None)
         for n in range(cfg.dec_layers):
             q = f"dec{n}."
             w = self.w
@@ -803,6 +892,45 @@ class DTLREngine:
         last = self._conv(f"ip{len(feats)}", feats[-1], 2, 1)
         level_hw.append((last.shape[1], last.shape[2]))
         return feats, last, level_hw
+
+    def _features_tokens_overlapped(self, x):
+        """features() + tokens() of the ResNet path with input_proj + GroupNorm of level 0 / 1 on side streams under layer3 / layer4
+        (dino.py:290-311 consumes C3 / C4 / C5 only after the whole backbone; nothing orders level 0's projection after layer3).  The token
+        matrix is allocated before the forks, on the caller's stream; the side streams write disjoint row ranges of it."""
+        x1 = self._stem(x.float())
+        c3 = self._backbone_layers(x1, 1, 2)[-1]
+        B, h, w_ = c3.shape[0], c3.shape[1], c3.shape[2]
+        nlev = self.cfg.num_feature_levels
+        level_hw = [(h, w_)]
+        for _ in range(nlev - 1):                                   # 3x3 / stride 2 / pad 1 stages: layer3, layer4, input_proj[3]
+            h, w_ = (h - 1) // 2 + 1, (w_ - 1) // 2 + 1
+            level_hw.append((h, w_))
+        if nlev != 4 or len(self.cfg.backbone_blocks) != 4:
+            raise RuntimeError("overlap_streams: the overlapped schedule is written for the 4-level ResNet configuration")
+        T = [a * b for a, b in level_hw]
+        src = torch.empty((B, sum(T), self.cfg.hidden_dim), dtype=self.dtype, device=c3.device)
+
+        def proj_norm(l, f, off):
+            t = self._lin(f"ip{l}", f.flatten(1, 2)) if l < nlev - 1 else f.flatten(1, 2)
+            ops.groupnorm_tokens(t, 32, self.w[f"ip{l}.gn.w"], self.w[f"ip{l}.gn.b"], out=src[:, off:off + T[l]])
+
+        cur, s0 = self._side(0)
+        s0.wait_stream(cur)
+        with torch.cuda.stream(s0):
+            proj_norm(0, c3, 0)
+        c4 = self._backbone_layers(c3, 3, 3)[-1]
+        _, s1 = self._side(1)
+        s1.wait_stream(cur)
+        with torch.cuda.stream(s1):
+            proj_norm(1, c4, T[0])
+        c5 = self._backbone_layers(c4, 4, 4)[-1]
+        last = self._conv(f"ip{nlev - 1}", c5, 2, 1)
+        assert [(f.shape[1], f.shape[2]) for f in (c3, c4, c5, last)] == level_hw
+        proj_norm(2, c5, T[0] + T[1])
+        proj_norm(3, last, T[0] + T[1] + T[2])
+        cur.wait_stream(s0)
+        cur.wait_stream(s1)
+        return [c3, c4, c5], last, level_hw, src
 
     def geometry_for(self, x, mask, level_hw, has_padding=True):
         # geometry depends only on the canvas shape and the padding masks: for an unpadded batch it is
@@ -872,7 +1000,12 @@ class DTLREngine:
             # forward then allocates nothing and dispatches exactly as an eager one (dtlr_hip.h, dtlr_workspace_reserve)
             ops.workspace_reserve(self.dtype)
             self._ws_streams.add(st)
-        feats, last, level_hw = self.features(x)
+        overlap = self.overlap_streams and not cfg.is_swin
+        src = None
+        if overlap:
+            feats, last, level_hw, src = self._features_tokens_overlapped(x)
+        else:
+            feats, last, level_hw = self.features(x)
         if self._range_check_pending:
             # fp16 storage / split fp16 operands saturate at 65504 (the conversions do not clamp: a larger backbone activation becomes inf and
             # poisons a whole GroupNorm group).  No trained checkpoint ships with the reference, so the range assumption is CHECKED on the
@@ -883,12 +1016,25 @@ class DTLREngine:
                 raise RuntimeError(f"DTLREngine({'f32s' if self.split else 'float16'}): backbone activations reach {peak:.3g}, beyond fp16's range "
                                    "(65504) -- run this checkpoint on the bfloat16 or the exact float32 engine")
         g = self.geometry_for(x, mask, level_hw, has_padding)
-        src = self.tokens(feats, last, level_hw)
+        if src is None:
+            src = self.tokens(feats, last, level_hw)
         if self.msda_auto and self.use_lds_msda and ("enc0.attn", tuple((int(h), int(w)) for h, w in level_hw)) not in self._msda_state:
             self._calibrate_msda(x.shape, level_hw)            # once per canvas shape
         memory = self.encoder(src, g)
+        vall = None
+        if overlap and memory.is_contiguous():
+            # value_proj(memory) of the six decoder layers on a side stream, under the two-stage selection (buffer allocated HERE, on this stream)
+            vall = self._value_all_alloc(memory)
+            cur, side = self._side(0)
+            side.wait_stream(cur)
+            with torch.cuda.stream(side):
+                done = self._value_all_into(memory, g, vall)
+            if not done:
+                vall = None
         ts = self.two_stage(memory, g, forced_topk)
-        hs, refs = self.decoder(memory, ts, g, want_aux)
+        if vall is not None:
+            cur.wait_stream(side)
+        hs, refs = self.decoder(memory, ts, g, want_aux, vall=vall)
         out = self.heads(hs, refs, ts, want_aux)
         if return_debug:
             out["_debug"] = dict(memory=memory, topk_idx=ts["topk_idx"], topk_scores=ts["topk_scores"], src=src,

@@ -730,6 +730,45 @@ def gemm_k256s(x, wp, b, residual=None, row_mask=None, ln_w=None, ln_b=None, eps
     return y
 
 
+def gemm_k256s_multi(x, slices, row_mask=None, res_rows: int = 0):
+    """ONE pass over x [..., 256] fp32 for several projections of it (dtlr_gemm_k256s_multi; split-fp32 engine).  slices: list of dicts
+    {wp: k256s_pack image of the slice's weight zero-padded to [256, 256], out: fp32 view [..., n] (last dim contiguous, any row stride),
+     bias: [n] fp32 or None, residual: fp32 [rows, n] view or None, relu: bool}; n a multiple of 32, <= 256.  res_rows > 0: every residual is
+    ONE [res_rows, n] matrix shared by the M / res_rows images (row m pairs with row m % res_rows).  row_mask (bool [M]): those rows are
+    written as zeros in every slice."""
+    require_cuda(x, "x")
+    assert x.dtype == torch.float32 and x.shape[-1] == 256 and x.is_contiguous() and 1 <= len(slices) <= 8
+    M = x.numel() // 256
+    arr = (_lib.K256sSlice * len(slices))()
+    nbytes, ncols = float(M) * 256 * 4, 0
+    for i, sl in enumerate(slices):
+        out, wp, res = sl["out"], sl["wp"], sl.get("residual")
+        n = out.shape[-1]
+        assert out.dtype == torch.float32 and out.is_cuda and out.stride(-1) == 1 and out.numel() // n == M and n % 32 == 0 and n <= 256
+        o2 = out.reshape(M, n) if out.is_contiguous() else out
+        ldc = o2.stride(-2)
+        assert wp.dtype == torch.int16 and wp.numel() == 2 * 65536
+        arr[i].Wp, arr[i].C, arr[i].ldc, arr[i].n_valid, arr[i].relu = wp.data_ptr(), out.data_ptr(), int(ldc), int(n), int(bool(sl.get("relu")))
+        b = sl.get("bias")
+        arr[i].bias = 0 if b is None else b.data_ptr()
+        if b is not None:
+            assert b.dtype == torch.float32 and b.numel() >= n and b.is_contiguous()
+        if res is not None:
+            assert res.dtype == torch.float32 and res.stride(-1) == 1 and res.shape[-1] == n and res.numel() // n == (res_rows if res_rows else M)
+            arr[i].R, arr[i].ldr = res.data_ptr(), int(res.stride(-2))
+            nbytes += 4.0 * n * (res_rows if res_rows else M)
+        else:
+            arr[i].R, arr[i].ldr = 0, 0
+        nbytes += 4.0 * M * n + 2.0 * 65536 * 2
+        ncols += n
+    if row_mask is not None:
+        assert row_mask.numel() == M and row_mask.dtype in (torch.bool, torch.uint8) and row_mask.is_contiguous()
+    with _Timed("gemm_f32s", 2.0 * M * 256 * ncols, nbytes, f"k256s_multi M{M} N{ncols}x{len(slices)}"):
+        code = _lib.lib().dtlr_gemm_k256s_multi(x.data_ptr(), M, ctypes.addressof(arr), len(slices), 0 if row_mask is None else row_mask.data_ptr(),
+                                                int(res_rows), _lib.current_stream())
+    _lib.check(code, "dtlr_gemm_k256s_multi")
+
+
 def conv2d_nhwc(x, w, bias, stride: int, padding: int, relu=False, residual=None):
     """NHWC convolution + folded-BN bias [+ residual] [+ ReLU].  x [B,H,W,Cin] contiguous.
     w: [Cout,KH,KW,Cin] contiguous ("OHWI") -> the implicit-GEMM HIP kernel (dtlr_conv2d_nhwc), which

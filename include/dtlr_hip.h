@@ -181,6 +181,29 @@ int dtlr_k256s_pack_weights(const float *w, void *out, void *stream);
 int dtlr_gemm_k256s(const float *A, const void *Wp, const float *bias, const float *R, const unsigned char *row_mask,
                     const float *gamma, const float *beta, float eps, float *C, long M, void *stream);
 
+/* The same kernel structure with SEVERAL output slices per launch (round 6): ONE pass over A [M, 256] fp32 for `nslices` (1..8)
+ * projections of it,
+ *     C_y[m, 0:n_valid_y] = act( A[m, :] W_y^T + bias_y + R_y[m or m % res_rows, 0:n_valid_y] ),   rows with row_mask[m] != 0 written as zeros.
+ * Replaces (split-fp32 engine):
+ *   - decoder: value_proj(memory) of all six cross-attention layers (ms_deform_attn.py:94-96) as six slices of one [M, 1536] buffer;
+ *   - (built and tested, not used by the engine: measured slower than its parts -- the slices' token tiles do not meet in L2)
+ *     encoder layer, unpadded batch: value = value_proj(src) AND [sampling_offsets | attention_weights](src + pos)
+ *     (ops/modules/ms_deform_attn.py:94-98) as three slices (256 | 256 | 128 channels), the position term pos W^T + b as the
+ *     row-broadcast residual (res_rows = tokens per image).
+ * slices: HOST array of dtlr_k256s_slice.  Wp = dtlr_k256s_pack_weights of the slice's weight zero-padded to [256, 256]; bias [n_valid] fp32 or
+ * NULL; R fp32 or NULL, row stride ldr: [M, ldr] when res_rows == 0, ONE [res_rows, ldr] matrix shared by the M / res_rows images otherwise
+ * (res_rows % 32 == 0, M % res_rows == 0; launch-wide); C = the slice's first output column, row stride ldc; n_valid a multiple of 32, <= 256;
+ * relu != 0: ReLU after the residual; row_mask [M] or NULL applies to every slice.  C and R 16-byte aligned, ldc / ldr multiples of 4. */
+typedef struct dtlr_k256s_slice {
+    const void *Wp;
+    const float *bias;
+    const float *R;
+    float *C;
+    int ldc, ldr, n_valid, relu;
+} dtlr_k256s_slice;
+int dtlr_gemm_k256s_multi(const float *A, long M, const dtlr_k256s_slice *slices, int nslices, const unsigned char *row_mask,
+                          int res_rows, void *stream);
+
 /* ---------------------------------------------------------------------------------------------
  * Fused position-wise feed-forward block + residual + LayerNorm, bf16 (fp32 accumulate / statistics):
  *     Y = LayerNorm( X + relu(X W1^T + b1) W2^T + b2 )
@@ -371,6 +394,13 @@ int dtlr_conv2d_nhwc(const void *X, const void *W, const float *bias, const void
  * routes here by itself.  X [B,H,W,Cin], Wt [Cout,3,3,Cin], Y [B,H,W,Cout] bf16; bias [Cout] fp32 or NULL; relu != 0: ReLU after the bias. */
 int dtlr_conv3x3_patch_supported(int Cin, int Cout);
 int dtlr_conv3x3_patch_bf16(const void *X, const void *Wt, const float *bias, void *Y, int B, int H, int W, int Cin, int Cout,
+                            int relu, void *stream);
+/* The same case for the split-fp32 engine (DTLR_F32S; round 6): X, Y fp32 NHWC, Wt = dtlr_split_pack_weights of [Cout,3,3,Cin] (rows = Cout,
+ * K = 9 Cin).  The fp32 patch is split into fp16 hi + lo LDS planes ONCE per workgroup (the implicit-GEMM form re-gathers and re-splits it
+ * for each of the nine taps); three fp16 MFMAs per product, fp32 accumulation.  Cin = 64 (Cout a multiple of 64) or Cin = 128 (Cout a
+ * multiple of 128) (dtlr_conv3x3_patch_f32s_supported); dtlr_conv2d_nhwc routes here by itself.  Same reference lines as above. */
+int dtlr_conv3x3_patch_f32s_supported(int Cin, int Cout);
+int dtlr_conv3x3_patch_f32s(const float *X, const void *Wt, const float *bias, float *Y, int B, int H, int W, int Cin, int Cout,
                             int relu, void *stream);
 
 /* ---------------------------------------------------------------------------------------------

@@ -293,6 +293,69 @@ def test_splitk_convolutions_overlapped_on_two_streams():
     assert bad == 0, f"{bad} of 80 overlapped launches differ from their single-stream result"
 
 
+@pytest.mark.parametrize("case", ["encoder3", "decoder6_masked", "one_ragged_relu_res"])
+def test_gemm_k256s_multi_vs_fp64_and_single_slice_kernel(case):
+    """dtlr_gemm_k256s_multi (round 6: ONE pass over A for several projections of it) against fp64 on the same fp32 operands and against
+    dtlr_gemm_k256s slice by slice (same MFMA order per output: bit-identical where both exist):
+      encoder3            -- value_proj | offsets (256) | logits (128, zero-padded image) with the position term as a row-broadcast residual
+                             [res_rows, 384] (position-major tile walk), bias only on the first slice, outputs as column views of two buffers;
+      decoder6_masked     -- six slices of one [M, 1536] buffer, row mask on all of them, ragged M;
+      one_ragged_relu_res -- one slice, full residual [M, 256], ReLU, M not a multiple of 64."""
+    from dtlr_amd import ops
+    dd = lambda t: t.double()                                       # noqa: E731
+    if case == "encoder3":
+        S, B = 320, 5
+        M = S * B
+        x = (_rand((B, S, 256), 61, 1.5) + 0.2).cuda()
+        wv, bv = _rand((256, 256), 62) / 16.0, _rand((256,), 63) * 0.5
+        wo = _rand((384, 256), 64) / 16.0
+        res = _rand((S, 384), 65, 2.0).cuda()
+        value = torch.empty((B, S, 256), device="cuda")
+        ow = torch.full((B, S, 384), float("nan"), device="cuda")
+        wpad = torch.cat([wo[256:], torch.zeros((128, 256))], 0)
+        sl = [dict(wp=ops.k256s_pack(wv.cuda()), out=value, bias=bv.cuda()),
+              dict(wp=ops.k256s_pack(wo[:256].contiguous().cuda()), out=ow[..., :256], residual=res[:, :256]),
+              dict(wp=ops.k256s_pack(wpad.cuda()), out=ow[..., 256:], residual=res[:, 256:])]
+        ops.gemm_k256s_multi(x, sl, res_rows=S)
+        torch.cuda.synchronize()
+        xc = x.cpu()
+        want_v = (dd(xc) @ dd(wv).t() + dd(bv)).float()
+        want_o = (dd(xc) @ dd(wo).t() + dd(res.cpu())[None]).float()
+        assert torch.isfinite(ow).all()
+        assert (value.cpu() - want_v).abs().max() < 2e-5 * max(1.0, want_v.abs().max().item())
+        assert (ow.cpu() - want_o).abs().max() < 2e-5 * max(1.0, want_o.abs().max().item())
+        assert torch.equal(value, ops.gemm_k256s(x, sl[0]["wp"], bv.cuda()))          # same products in the same order
+    elif case == "decoder6_masked":
+        M = 2 * 333
+        x = (_rand((2, 333, 256), 71, 1.5) - 0.1).cuda()
+        w, b = _rand((1536, 256), 72) / 16.0, _rand((1536,), 73) * 0.5
+        mask = (torch.arange(M) % 6 == 1).cuda()
+        out = torch.full((2, 333, 1536), float("nan"), device="cuda")
+        bc = b.cuda()
+        imgs = [ops.k256s_pack(w[256 * j:256 * (j + 1)].contiguous().cuda()) for j in range(6)]
+        ops.gemm_k256s_multi(x, [dict(wp=imgs[j], out=out[..., 256 * j:256 * (j + 1)], bias=bc[256 * j:256 * (j + 1)]) for j in range(6)], row_mask=mask)
+        torch.cuda.synchronize()
+        want = (dd(x.cpu()) @ dd(w).t() + dd(b)).masked_fill(mask.cpu().view(2, 333, 1), 0.0).float()
+        assert torch.isfinite(out).all()
+        assert (out.cpu() - want).abs().max() < 2e-5 * max(1.0, want.abs().max().item())
+        for j in (0, 5):
+            assert torch.equal(out[..., 256 * j:256 * (j + 1)], ops.gemm_k256s(x, imgs[j], bc[256 * j:256 * (j + 1)].contiguous(), row_mask=mask))
+        nomask = torch.empty_like(out)
+        ops.gemm_k256s_multi(x, [dict(wp=imgs[j], out=nomask[..., 256 * j:256 * (j + 1)], bias=bc[256 * j:256 * (j + 1)]) for j in range(6)])
+        keep = ~mask.view(2, 333)
+        assert torch.equal(nomask[keep], out[keep]) and bool((out[~keep] == 0).all())
+    else:
+        M = 64 * 300 + 29                                            # more tiles than workgroups, ragged tail
+        x = (_rand((M, 256), 81, 1.5)).cuda()
+        w, b, r = _rand((256, 256), 82) / 16.0, _rand((256,), 83) * 0.5, _rand((M, 256), 84, 2.0)
+        out = torch.empty((M, 256), device="cuda")
+        ops.gemm_k256s_multi(x, [dict(wp=ops.k256s_pack(w.cuda()), out=out, bias=b.cuda(), residual=r.cuda(), relu=True)])
+        torch.cuda.synchronize()
+        want = (dd(x.cpu()) @ dd(w).t() + dd(b) + dd(r)).clamp(min=0).float()
+        assert (out.cpu() - want).abs().max() < 2e-5 * max(1.0, want.abs().max().item())
+        assert bool((out >= 0).all())
+
+
 def test_workspace_growth_never_invalidates_a_captured_graph():
     """Round 6: a workspace pointer baked into a captured HIP graph must stay valid when a later, larger request grows
     that stream's workspace.  On a fresh stream: a small split-K convolution runs eagerly (allocates the slot), the same launch is captured,
@@ -1258,6 +1321,42 @@ def test_conv3x3_patch_kernel_vs_reference(B, H, W, Cin, Cout, half):
         assert (got - want).abs().max() < ulp(half, 8) * max(1.0, want.abs().max().item()) + 1e-4, relu
     got = ops.conv2d_nhwc(x.cuda(), w_ohwi, None, 1, 1, False, None).float().cpu()
     assert (got - (ref - b.double()).float()).abs().max() < ulp(half, 8) * max(1.0, ref.abs().max().item()) + 1e-4
+
+
+@pytest.mark.parametrize("B,H,W,Cin,Cout", [(4, 37, 131, 64, 64), (2, 64, 200, 128, 128), (3, 40, 150, 64, 128), (1, 128, 130, 128, 256),
+                                            (2, 32, 512, 64, 64)])
+def test_conv3x3_patch_f32s_kernel_vs_fp64_and_tiled_split_gemm(B, H, W, Cin, Cout):
+    """Round 6: the split-fp32 form of the LDS-resident-patch 3x3 convolution (dtlr_conv3x3_patch_f32s, reached through conv2d_nhwc with a
+    SplitWeight) against fp64 on the same fp32 operands -- image borders (zero padding), tiles cut by the right / bottom edge, bias, ReLU,
+    both channel-block counts -- at the split engine's tolerance, and against the implicit-GEMM split kernel it replaces (a crop below
+    the routing threshold runs that one)."""
+    import torch.nn.functional as F
+    from dtlr_amd import _lib, ops
+    assert _lib.lib().dtlr_conv3x3_patch_f32s_supported(Cin, Cout) == 1 and B * H * W >= 16384
+    x = _rand((B, H, W, Cin), 1, 1.5) + 0.1
+    w = _rand((Cout, Cin, 3, 3), 2) / (3.0 * Cin ** 0.5)
+    b = _rand((Cout,), 3)
+    ref = F.conv2d(x.permute(0, 3, 1, 2).double(), w.double(), b.double(), stride=1, padding=1).permute(0, 2, 3, 1)
+    wsp = ops.split_pack(w.permute(0, 2, 3, 1).contiguous().cuda())
+    tol = 3e-5 * max(1.0, ref.abs().max().item())
+    for relu in (True, False):
+        want = (ref.clamp(min=0) if relu else ref).float()
+        got = ops.conv2d_nhwc(x.cuda(), wsp, b.cuda(), 1, 1, relu, None).cpu()
+        assert torch.isfinite(got).all()
+        err = (got - want).abs().max().item()
+        print(f"[conv3x3 f32s patch {B}x{H}x{W} {Cin}->{Cout} relu={relu}] max err {err:.2e} (tol {tol:.2e})")
+        assert err < tol, (relu, err)
+    got = ops.conv2d_nhwc(x.cuda(), wsp, None, 1, 1, False, None).cpu()
+    assert (got - (ref - b.double()).float()).abs().max() < tol
+    # the implicit-GEMM split kernel on a crop below the patch kernel's routing threshold (M < 16384): the same numbers to fp32 rounding
+    hc = max(1, min(H, 16000 // (B * W)))
+    xc = x[:, :hc].contiguous()
+    small = ops.conv2d_nhwc(xc.cuda(), wsp, b.cuda(), 1, 1, True, None).cpu()
+    refc = F.conv2d(xc.permute(0, 3, 1, 2).double(), w.double(), b.double(), stride=1, padding=1).permute(0, 2, 3, 1).clamp(min=0).float()
+    assert (small - refc).abs().max() < tol
+    big = ops.conv2d_nhwc(x.cuda(), wsp, b.cuda(), 1, 1, True, None).cpu()
+    if hc >= 3:                                                     # rows 0 .. hc - 2 of the crop see the same 3x3 neighbourhoods as in the full image
+        assert (big[:, :hc - 1] - small[:, :hc - 1]).abs().max() < tol
 
 
 @pytest.mark.parametrize("B,nq", [(32, 900), (3, 900), (2, 100), (1, 37)])

@@ -704,13 +704,18 @@ def test_bench_accepts_a_user_checkpoint_and_an_image_folder(tmp_path):
     env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT", "LOCAL_WORLD_SIZE")}
     cmd = [sys.executable, os.path.join(root, "bench.py"), "--steps", "2", "--warmup", "1", "--batch", "4", "--dtype", "f32", "--weights",
            str(tmp_path / "checkpoint.pth"), "--images", str(img_dir), "--no-cpu-baseline", "--no-other-dtypes", "--no-bs1", "--parity-lines", "2",
-           "--min-seconds", "0"]
+           "--min-seconds", "0", "--detail", str(tmp_path / "detail.json")]
     r = subprocess.run(cmd, capture_output=True, text=True, timeout=900, cwd=root, env=env)
     assert r.returncode == 0, r.stderr[-3000:]
-    line = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
-    assert line["value"] > 0 and line["dtype"] == "f32" and line["config"]["global_batch"] == 4
+    stdout_lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(stdout_lines) == 1 and len(stdout_lines[0]) < 6000          # round 6: ONE compact line on stdout, the full result in --detail
+    short = json.loads(stdout_lines[0])
+    assert short["value"] > 0 and short["dtype"] == "f32" and short["by_dtype"]["f32"]["strings_teacher_forced"] == "2/2"
+    line = json.load(open(tmp_path / "detail.json"))
+    assert line["value"] == short["value"] and line["dtype"] == "f32" and line["config"]["global_batch"] == 4
     obs = line["observed_on_user_assets"]
     assert 0 < obs["backbone_activation_peak"] < 6e4 and len(obs["canvas"]) == 2 and 1333 <= obs["canvas"][1] <= 1344      # long side capped at 1333, canvas padded
+    assert short["observed_on_user_assets"]["canvas"] == obs["canvas"]
     p = line["parity_vs_oracle"]
     assert "error" not in p, p
     assert p["parity_gate"] and p["teacher_forced"]["logit_err_max"] < LOGIT_TOL and p["teacher_forced"]["edit_distance"] == 0, p
@@ -822,6 +827,78 @@ def test_layer1_chain_backbone_equals_the_separate_convolutions(half):
     eng.use_l1_chain, eng.use_l1_chain_out = True, False
     for g, h in zip(got, eng.backbone(x)):
         assert torch.equal(g, h.float())
+
+
+@pytest.mark.parametrize("engine", ["bf16", "f32s", "f32"])
+def test_side_stream_schedule_is_bit_identical_to_the_one_stream_schedule(engine):
+    """Round 6: DTLREngine.overlap_streams runs input_proj + GroupNorm of levels 0 / 1 under layer3 / layer4 and the decoder's six value
+    projections under the two-stage selection, on side HIP streams (fork / join with stream waits, buffers allocated before the fork).
+    Same kernels, same arguments: every output is bit-identical to the one-stream schedule -- tiny model with mixed widths (padded),
+    full-size lines, repeated forwards (a missing join would show up as a difference in some repetition), and a caller-side stream."""
+    from dtlr_amd.engine import DTLREngine
+    dt = HALF[engine] if engine in HALF else torch.float32
+    for cfg, H, W, n in ((DTLRConfig.tiny(), 32, 256, 3), (DTLRConfig.latin(), 128, 2048, 2)):
+        sd = weights.synthetic_state_dict(cfg, 0)
+        eng = DTLREngine(cfg, sd, "cuda:0", dt, split=engine == "f32s")
+        assert eng.overlap_streams
+        x = torch.stack(synth.stroke_lines(n - 1, H, W, seed=61) + synth.noise_lines(1, H, W, seed=62)).cuda()
+        mask = torch.zeros((n, H, W), dtype=torch.bool, device="cuda:0")
+        for padded in (False, True):
+            if padded:
+                mask[0, :, W - W // 4:] = True
+                x[0, :, :, W - W // 4:] = 0
+            eng.overlap_streams = False
+            want = eng.forward(x, mask, has_padding=padded, return_debug=True)
+            torch.cuda.synchronize()
+            eng.overlap_streams = True
+            for rep in range(6 if cfg.enc_layers == 2 else 2):
+                got = eng.forward(x, mask, has_padding=padded, return_debug=True)
+                for k in ("pred_logits", "pred_boxes"):
+                    assert torch.equal(got[k], want[k]), (engine, padded, rep, k)
+                for k in ("src", "memory", "topk_idx"):
+                    assert torch.equal(got["_debug"][k], want["_debug"][k]), (engine, padded, rep, k)
+            caller = torch.cuda.Stream()
+            caller.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(caller):
+                got = eng.forward(x, mask, has_padding=padded)
+            caller.synchronize()
+            assert torch.equal(got["pred_logits"], want["pred_logits"])
+        del eng
+        torch.cuda.empty_cache()
+
+
+def test_split_engine_multi_slice_projections_equal_the_separate_launches():
+    """Round 6: the split engine's two uses of dtlr_gemm_k256s_multi inside the model, on two bench-sized lines (the encoder form needs
+    S % 64 == 0: 5440 at 128x2048).  (i) decoder value_proj(memory) as six slices of one launch (default ON) against the tiled split GEMM:
+    the same products in another summation order -- logits within 2e-5; (ii) the encoder form (value_proj + [offsets | logits] of src as
+    three slices, default OFF: measured slower than its parts) against the default path: encoder memory and logits within 2e-5."""
+    from dtlr_amd.engine import DTLREngine
+    cfg = DTLRConfig.latin()
+    sd = weights.synthetic_state_dict(cfg, 0)
+    x = torch.stack(synth.stroke_lines(1, 128, 2048, seed=51) + synth.noise_lines(1, 128, 2048, seed=52)).cuda()
+    mask = torch.zeros((2, 128, 2048), dtype=torch.bool, device="cuda:0")
+    eng = DTLREngine(cfg, sd, "cuda:0", torch.float32, split=True)
+    assert eng.use_k256s_multi and not eng.use_k256s_multi_enc
+    base = eng.forward(x, mask, has_padding=False, return_debug=True)
+    idx = base["_debug"]["topk_idx"]
+    eng.use_k256s_multi = False
+    tiled = eng.forward(x, mask, has_padding=False, forced_topk=idx, return_debug=True)
+    eng.use_k256s_multi, eng.use_k256s_multi_enc = True, True
+    enc3 = eng.forward(x, mask, has_padding=False, forced_topk=idx, return_debug=True)
+    assert "enc0.attn.ow.k256sm" in eng.w, "the encoder form did not run"
+    for name, other in (("decoder slices vs tiled GEMM", tiled), ("encoder slices vs separate launches", enc3)):
+        dm = (other["_debug"]["memory"] - base["_debug"]["memory"]).abs().max().item()
+        dl = (other["pred_logits"] - base["pred_logits"]).abs().max().item()
+        db = (other["pred_boxes"] - base["pred_boxes"]).abs().max().item()
+        print(f"[k256s_multi in the model] {name}: memory {dm:.2e}, logits {dl:.2e}, boxes {db:.2e}")
+        assert dm < 2e-5 and dl < 2e-5 and db < 2e-6, (name, dm, dl, db)
+    # padded batch: the six decoder slices carry the row mask
+    mask[1, :, 1500:] = True
+    x[1, :, :, 1500:] = 0
+    p_on = eng.forward(x, mask, has_padding=True, return_debug=True)
+    eng.use_k256s_multi = False
+    p_off = eng.forward(x, mask, has_padding=True, forced_topk=p_on["_debug"]["topk_idx"])
+    assert (p_on["pred_logits"] - p_off["pred_logits"]).abs().max().item() < 2e-5
 
 
 @pytest.mark.parametrize("half", ["bf16", "f16"])
