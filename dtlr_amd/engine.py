@@ -96,12 +96,14 @@ class DTLREngine:
         self._ws_streams = set()           # streams whose library workspace this engine has pre-sized (ops.workspace_reserve)
         # Round 6: independent launches on side HIP streams (fork / join with stream waits; buffers that cross streams are allocated on
         # the caller's stream BEFORE the fork and outlive the join, so the caching allocator never hands a block to another stream early):
-        #   * input_proj + GroupNorm of level 0 (on C3) runs under layer3, of level 1 (on C4) under layer4 -- layer3 / layer4 launch
-        #     128-512 workgroups on 256 CUs (8,192-32,768 pixels per map at B = 32) and leave the HBM idle;
-        #   * value_proj(memory) of the six decoder layers runs under the two-stage selection (top-k: 32 workgroups; gathers; box MLP).
-        #   * the shortcut (`downsample`) convolution of a ResNet layer's first bottleneck runs under its conv1 -> conv2;
-        # Same kernels, same arguments, same per-kernel arithmetic: results are bit-identical to the one-stream schedule.
-        self.overlap_streams = True
+        #   * input_proj + GroupNorm of level 0 (on C3) under layer3, of level 1 (on C4) under layer4;
+        #   * value_proj(memory) of the six decoder layers under the two-stage selection (top-k: 32 workgroups; gathers; box MLP);
+        #   * the shortcut (`downsample`) convolution of a ResNet layer's first bottleneck under its conv1 -> conv2.
+        # Same kernels, same arguments, same per-kernel arithmetic: bit-identical to the one-stream schedule (GPU test, also under HIP-graph
+        # capture).  MEASURED AND OFF: same-box A/B at B = 32 (profiles/r06_streams_ab_c4.txt): bf16 8.78 -> 8.84 ms, f32s 21.50 -> 21.68 ms
+        # per step -- every kernel of the path already fills the chip (>= 256 workgroups, one or two per CU by LDS), so a side stream's
+        # workgroups only queue behind the main stream's, and the five fork / join pairs cost more than the small grids (top-k, gathers) free.
+        self.overlap_streams = False
         self._side_streams = [torch.cuda.Stream(device=self.device) for _ in range(3)]      # created (and their library workspace pre-sized) HERE:
         for st in self._side_streams:                                                       # nothing is created or allocated under a later capture
             with torch.cuda.stream(st):
