@@ -3,7 +3,7 @@
 # stats, secondary configurations.  Outputs land in gpurun_out/ (copy what should be judged into profiles/).
 # usage: [BENCH_EXTRA="--no-cpu-baseline"] [ROUND=r04] bash tools/final_check.sh <tag> [prof-only|no-tests]
 TAG=${1:-vX}
-R4=${ROUND:-r05}
+R4=${ROUND:-r06}
 cd ${GRAFT_REPO_ROOT:-.}
 mkdir -p gpurun_out
 if [ "$2" != "prof-only" ]; then

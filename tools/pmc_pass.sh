@@ -2,7 +2,7 @@
 # PMC traffic passes on the GPU box (run through gpurun): FETCH_SIZE and WRITE_SIZE in separate rocprofv3 runs (--kernel-trace only),
 # reduced to per-shape / per-class bytes per launch by tools/pmc_traffic.py.   usage: bash tools/pmc_pass.sh <tag>
 TAG=${1:-vX}
-RN=${ROUND:-r05}
+RN=${ROUND:-r06}
 cd ${GRAFT_REPO_ROOT:-.}
 R=$PWD
 D=$R/gpurun_out/pmc_$TAG

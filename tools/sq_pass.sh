@@ -2,7 +2,7 @@
 # SQ counter pass on the GPU box (run through gpurun): matrix-pipe busy cycles, LDS activity and bank conflicts, VALU activity per kernel of a
 # bench step, bf16 and f32s engines; rocprofv3 --kernel-trace --pmc only (one pass per engine).   usage: bash tools/sq_pass.sh <tag>
 TAG=${1:-vX}
-RN=${ROUND:-r05}
+RN=${ROUND:-r06}
 cd ${GRAFT_REPO_ROOT:-.}
 R=$PWD
 export TMPDIR=/tmp
