@@ -69,6 +69,8 @@ _SIGNATURES = {
     "dtlr_ffn32_pad_chunks": (c_int, []),
     "dtlr_ffn32_bf16": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_float, c_void_p,
                                 ctypes.c_long, c_int, c_void_p]),
+    "dtlr_ffn4_bf16": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_float, c_void_p,
+                               ctypes.c_long, c_int, c_void_p]),
     "dtlr_ffn_split": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_float, c_void_p, ctypes.c_long, c_int, c_void_p]),
     "dtlr_ffn_split_pad_chunks": (c_int, []),
     "dtlr_head_ts": (c_int, [c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_int, c_int, c_int, c_void_p, ctypes.c_long, c_void_p]),

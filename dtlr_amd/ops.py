@@ -617,6 +617,25 @@ def ffn32(x, w1p, b1, w2p, b2, ln_w, ln_b, eps: float = 1e-5, out=None):
     return y
 
 
+def ffn4(x, w1p, b1, w2p, b2, ln_w, ln_b, eps: float = 1e-5, out=None):
+    """LayerNorm(x + relu(x W1^T + b1) W2^T + b2) for any number of rows as ONE persistent launch (dtlr_ffn4_bf16, round 6: two 128-row tiles
+    per workgroup half a period apart over a cyclic weight stream; epilogues and loads under the other tile's MFMAs); (w1p, w2p) =
+    ffn32_pack(W1, W2).  Same result as ffn32 / ffn_fused up to the fp32 summation order over the hidden chunks."""
+    require_cuda(x, "x")
+    d_ff = b1.numel()
+    assert x.dtype in H16 and x.shape[-1] == 256 and w1p.dtype in H16 and w2p.dtype in H16
+    assert w1p.numel() == (d_ff // 32 + FFN32_PAD) * 8192 and w2p.numel() == w1p.numel()
+    x = x if x.is_contiguous() else x.contiguous()
+    y = torch.empty_like(x) if out is None else out
+    assert y.is_contiguous() and y.shape == x.shape and y.dtype == x.dtype
+    M = x.numel() // 256
+    with _Timed("ffn_fused_bf16", 4.0 * M * 256 * d_ff, 2.0 * M * 256 * 2 + 2.0 * 256 * d_ff * 2, symbol="ffn4_bf16_kernel"):
+        code = _L(x).dtlr_ffn4_bf16(x.data_ptr(), w1p.data_ptr(), b1.data_ptr(), w2p.data_ptr(), b2.data_ptr(),
+                                    ln_w.data_ptr(), ln_b.data_ptr(), eps, y.data_ptr(), M, d_ff, _lib.current_stream())
+    _lib.check(code, "dtlr_ffn4_bf16")
+    return y
+
+
 def ffn_fused(x, w1, b1, w2p, b2, ln_w, ln_b, eps: float = 1e-5, out=None):
     """LayerNorm(x + relu(x W1^T + b1) W2^T + b2) in ONE kernel (dtlr_ffn_fused_bf16): the [M, d_ff]
     intermediate never reaches HBM.  x [..., 256] bf16; W1 [d_ff,256] bf16; w2p = ffn_pack_w2(W2) ([d_ff/32,256,32] bf16);
@@ -1342,7 +1361,7 @@ def _device_scoped(fn):
     return wrapper
 
 
-for _name in ("msda_encoder_far_fraction", "gemm_kres", "gemm_kres_chain", "gemm_kres_cat_s2", "gemm_kres_bcast384", "ffn32", "proj_ln_k256", "swin_patch_embed", "swin_window_attn", "swin_patch_merge", "geometry", "linear", "gemm_k256", "linear_rowmax", "two_stage_gather", "layernorm", "proj_ln", "proj_ln_split", "ffn_fused", "conv2d_nhwc", "stem_conv7x7", "stem_conv7x7_f32",
+for _name in ("msda_encoder_far_fraction", "gemm_kres", "gemm_kres_chain", "gemm_kres_cat_s2", "gemm_kres_bcast384", "ffn32", "ffn4", "proj_ln_k256", "swin_patch_embed", "swin_window_attn", "swin_patch_merge", "geometry", "linear", "gemm_k256", "linear_rowmax", "two_stage_gather", "layernorm", "proj_ln", "proj_ln_split", "ffn_fused", "conv2d_nhwc", "stem_conv7x7", "stem_conv7x7_f32",
               "maxpool_nhwc", "groupnorm_tokens", "msda", "msda_fused", "msda_encoder", "mha", "decoder_query_prep", "box_mlp_refine",
               "box_head_refine", "box_refine", "topk_rows", "decode_blank", "preprocess_lines", "ctc_loss_interleaved", "nms_batched",
               "topk_flat", "stem_conv7x7_pool", "dec_query_stage", "blank_emissions", "split_pack", "linear_resbcast", "ffn_split", "stem_conv7x7_f32s", "k256s_pack", "gemm_k256s"):

@@ -272,6 +272,13 @@ int dtlr_ffn32_pack_weights(const void *w1, const void *w2, void *w1p, void *w2p
 int dtlr_ffn32_pad_chunks(void);
 int dtlr_ffn32_bf16(const void *X, const void *W1p, const float *b1, const void *W2p, const float *b2,
                     const float *gamma, const float *beta, float eps, void *Y, long M, int d_ff, void *stream);
+/*   dtlr_ffn4_bf16 (round 6): the same block, same packed images, as ONE persistent launch for any M >= 1 (ffn4.hip): every workgroup streams
+ *     the weights cyclically and carries two 128-row tiles half a tile period apart, so that a tile's epilogue (LayerNorm, stores) and the
+ *     load of its successor run under the other tile's MFMAs; no tail kernel.  Same result as dtlr_ffn32_bf16 up to the fp32 summation order
+ *     over the hidden chunks (a tile starts at the chunk the stream happens to be at).
+ */
+int dtlr_ffn4_bf16(const void *X, const void *W1p, const float *b1, const void *W2p, const float *b2,
+                   const float *gamma, const float *beta, float eps, void *Y, long M, int d_ff, void *stream);
 
 /* ---------------------------------------------------------------------------------------------
  * Output projection + residual + LayerNorm of an attention block, bf16 (fp32 accumulate / statistics):

@@ -1187,6 +1187,34 @@ def test_ffn32_vs_reference_and_first_structures(M, d_ff, half):
     assert np.array_equal(o2, w2p.cpu().view(torch.int16).numpy().view(np.uint16))
 
 
+@pytest.mark.parametrize("M,d_ff", [(1, 2048), (100, 2048), (128, 2048), (129, 2048), (256, 128), (257, 64), (1000, 2048), (5440, 2048), (28800, 2048),
+                                    (65536 + 77, 2048), (174080, 2048), (700, 96), (40000, 160), (66000, 1024)])
+def test_ffn4_vs_reference_and_ffn32(M, d_ff, half):
+    """The persistent fused FFN (dtlr_ffn4_bf16, round 6: two staggered 128-row tiles per workgroup over a cyclic weight stream) against an
+    fp32 reference that rounds the hidden activations to the 16-bit format like the kernel does, and against the 32x32x16 kernel it replaces
+    (same arithmetic up to the fp32 summation order over the hidden chunks); row counts that leave the last tile ragged, a last PAIR with one
+    tile, fewer tiles than compute units, more than two pairs per workgroup; the call is repeated to show it reproduces itself."""
+    from dtlr_amd import ops
+    x = _rand((M, 256), 1).to(half)
+    w1 = (_rand((d_ff, 256), 2) / 16.0).to(half)
+    w2 = (_rand((256, d_ff), 3) / 45.0).to(half)
+    b1, b2 = _rand((d_ff,), 4) * 0.1, _rand((256,), 5) * 0.1
+    gw, gb = _rand((256,), 6) * 0.2 + 1.0, _rand((256,), 7) * 0.1
+    h = torch.relu(x.float() @ w1.float().t() + b1).to(half).float()
+    want = F.layer_norm(x.float() + h @ w2.float().t() + b2, (256,), gw, gb, 1e-5)
+    w1p, w2p = ops.ffn32_pack(w1.cuda(), w2.cuda())
+    xc = x.cuda()
+    guard = torch.full((M + 64, 256), 7.0, dtype=half, device="cuda")          # rows past M must stay untouched
+    got = ops.ffn4(xc, w1p, b1.cuda(), w2p, b2.cuda(), gw.cuda(), gb.cuda(), out=guard[:M])
+    assert (got.float().cpu() - want).abs().max() < 0.05
+    assert bool((guard[M:] == 7.0).all())
+    again = ops.ffn4(xc, w1p, b1.cuda(), w2p, b2.cuda(), gw.cuda(), gb.cuda())
+    assert torch.equal(got, again)
+    old = ops.ffn32(xc, w1p, b1.cuda(), w2p, b2.cuda(), gw.cuda(), gb.cuda())
+    assert (got.float() - old.float()).abs().max() <= 0.0315                # at most one bf16 ulp at |y| < 8
+    assert (got == old).float().mean() > (0.995 if half == torch.bfloat16 else 0.98)
+
+
 @pytest.mark.parametrize("M,N,K,res", [(524288, 256, 64, True), (131072, 512, 128, True), (32768, 1024, 256, True), (16384 + 37, 256, 64, False),
                                          (20000, 2048, 256, True), (16500, 256, 128, True), (17000, 512, 64, True),
                                          (524288, 64, 256, False), (131072 + 5, 128, 256, False), (20000, 64, 64, False), (16400, 192, 128, False)])

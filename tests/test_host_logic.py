@@ -772,3 +772,20 @@ def test_head_ts_pack_layout_and_padding():
             want_lo = float(lo[row, col]) if row < N else 0.0
             assert float(im[c, 0, s_, l, e]) == want_hi and float(im[c, 1, s_, l, e]) == want_lo
         assert (hi.float() + lo.float() - w).abs().max() < (2.0 ** -16 if dt == torch.bfloat16 else 2.0 ** -21) * w.abs().max() + 2.0 ** -24
+
+
+def test_ffn4_inline_asm_mfmas_have_no_valu_written_sources():
+    """dtlr_amd/csrc/ffn4.hip issues its MFMAs as inline asm (tied accumulator operands), so hipcc inserts no wait states for them; the
+    generated code must not contain a VALU write of an MFMA source register within three wait states of that MFMA (the first build had one:
+    a `v_or_b32` of an identity-fragment register directly in front of the seeding MFMA -- garbage in a slot's first tile).  Both builds."""
+    import importlib.util
+    import shutil
+    if not shutil.which("/opt/rocm/bin/hipcc"):
+        pytest.skip("no hipcc")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    spec = importlib.util.spec_from_file_location("ffn4_lint", os.path.join(root, "tools", "ffn4_lint.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    for defs in ("", "-DDTLR_HALF_IS_F16"):
+        n, bad = mod.lint(defs)
+        assert n >= 300 and not bad, bad[:3]

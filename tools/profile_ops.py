@@ -31,7 +31,7 @@ def main():
     mask = torch.zeros((args.batch, 128, 2048), dtype=torch.bool, device=dev)
     spans = []
     names = ["linear", "layernorm", "conv2d_nhwc", "maxpool_nhwc", "groupnorm_tokens", "msda", "msda_fused", "msda_encoder", "mha",
-             "ffn_fused", "ffn32", "proj_ln", "proj_ln_k256", "proj_ln_split", "gemm_k256", "gemm_kres", "gemm_kres_chain", "dec_query_stage", "stem_conv7x7_pool", "linear_rowmax", "geometry", "two_stage_gather", "stem_conv7x7", "stem_conv7x7_f32", "linear_resbcast", "box_mlp_refine", "blank_emissions", "box_head_refine", "decoder_query_prep", "box_refine", "topk_rows", "decode_blank", "ffn_split", "gemm_k256s", "gemm_k256s_multi", "stem_conv7x7_f32s", "head_ts", "gemm_kres_bcast384", "gemm_kres_cat_s2"]
+             "ffn_fused", "ffn32", "ffn4", "proj_ln", "proj_ln_k256", "proj_ln_split", "gemm_k256", "gemm_kres", "gemm_kres_chain", "dec_query_stage", "stem_conv7x7_pool", "linear_rowmax", "geometry", "two_stage_gather", "stem_conv7x7", "stem_conv7x7_f32", "linear_resbcast", "box_mlp_refine", "blank_emissions", "box_head_refine", "decoder_query_prep", "box_refine", "topk_rows", "decode_blank", "ffn_split", "gemm_k256s", "gemm_k256s_multi", "stem_conv7x7_f32s", "head_ts", "gemm_kres_bcast384", "gemm_kres_cat_s2"]
 
     def wrap(name):
         fn = getattr(ops, name)
