@@ -67,6 +67,7 @@ class DTLREngine:
         self.use_pln_k256 = True
         self.use_k256s = True  # split: the same for the [256, 256] encoder projections (value_proj; output_proj + residual + norm1)
         self.use_ffn32 = True
+        self.ffn32_tail = True          # the encoder FFN's last partial round of 256 workgroups on the 16x16x32 kernel (round 4); False: dtlr_ffn32_bf16 over all rows
         self.pln_k256_min_rows = 16384
         self.use_kres = True
         self.use_kres_narrow = True
@@ -403,7 +404,7 @@ class DTLREngine:
             # kernel (192 or 128 rows each: a shorter round than a third full-length one) goes to that kernel
             M = x.numel() // 256
             rem = M % 65536
-            if 0 < rem <= 49152 and ops.ffn_fused_supported(x, w[q + "ff1.w"]):
+            if self.ffn32_tail and 0 < rem <= 49152 and ops.ffn_fused_supported(x, w[q + "ff1.w"]):
                 if q + "ff2.wp" not in w:
                     w[q + "ff2.wp"] = ops.ffn_pack_w2(w[q + "ff2.w"])
                 x2 = x.reshape(M, 256)
