@@ -621,6 +621,163 @@ __device__ __forceinline__ void enc_queries_bf16_h3(
     }
 }
 
+// ---- bf16 query phase, fourth form (round 6): the third form with the window reads one half-point AHEAD of the FMAs -------------------
+// tools/experiments/valu_rate.hip put numbers on the third form: per lane-iteration ~880 ns of VALU issue per SIMD and ~750 ns of LDS time
+// per CU (64 ds_read_b128 at a 1.65x bank-conflict factor) -- 75 us + 64 us per launch back to back, 139 us measured: the kernel is bound by
+// the SERIALISATION of the two inside a wave (eight read -> wait -> FMA phases per lane-iteration; four waves per SIMD and 127 of 128 VGPRs
+// leave nothing to read ahead into).  Here: 384 threads per workgroup (three waves per SIMD at two workgroups per CU: 168 VGPRs), the
+// geometry of all four points first, then the eight half-points (a pixel row pair of one point: 8 reads, 32 packed FMAs) through TWO register
+// buffers -- the reads of half-point h + 2 are issued right after the FMAs of half-point h freed their buffer and land under the FMAs of h + 1.
+// The loop has no branch: a point whose columns are not all inside the staged window reads a clamped (valid) window address with zero
+// weights and is added afterwards through the global path (same arithmetic; those lanes sum their points in a different order: fp16
+// rounding-order noise, the oracle tolerance is unchanged).
+template <typename OT, int NT>
+__device__ __forceinline__ void enc_queries_bf16_h4(
+    const unsigned char* smem, const int* tok, const uint16_t* __restrict__ vimg, const OT* __restrict__ ow, const float* __restrict__ ref,
+    uint16_t* __restrict__ out, const EncLevels lv, const int (&wc0)[4], const int (&wc1)[4], int nq, int S, int M, int m, int b)
+{
+    const int tid = threadIdx.x, p = tid & 3;
+    const int MD = M * 32;
+    const int Hl = p == 0 ? lv.H[0] : p == 1 ? lv.H[1] : p == 2 ? lv.H[2] : lv.H[3];
+    const int Wl = p == 0 ? lv.W[0] : p == 1 ? lv.W[1] : p == 2 ? lv.W[2] : lv.W[3];
+    const int startl = p == 0 ? lv.start[0] : p == 1 ? lv.start[1] : p == 2 ? lv.start[2] : lv.start[3];
+    const int loffl = p == 0 ? lv.loff[0] : p == 1 ? lv.loff[1] : p == 2 ? lv.loff[2] : lv.loff[3];
+    const int wstride = p == 0 ? lv.wmax[0] : p == 1 ? lv.wmax[1] : p == 2 ? lv.wmax[2] : lv.wmax[3];
+    const int wc0l = p == 0 ? wc0[0] : p == 1 ? wc0[1] : p == 2 ? wc0[2] : wc0[3];
+    const int wc1l = p == 0 ? wc1[0] : p == 1 ? wc1[1] : p == 2 ? wc1[2] : wc1[3];
+    const float fH = (float)Hl, fW = (float)Wl;
+    const float invH = 1.0f / fH, invW = 1.0f / fW;
+    const unsigned char* win = smem + (long)loffl * 64;
+    const uint16_t* gsrc = vimg + (long)startl * MD;
+    int rot[4];
+#pragma unroll
+    for (int jj = 0; jj < 4; ++jj) rot[jj] = ((jj + p) & 3) * 16;
+
+    auto token_of = [&](int it) -> long { return (long)b * S + tok[it >> 2]; };
+    const int total = nq * 4;
+    if (tid >= total) return;
+    long bq = token_of(tid);
+    RowRaw<OT> cur, nxt;
+    float2 rf, rf_n;
+    cur.load(ow + bq * (long)(M * 48), M, m, p);
+    rf = *reinterpret_cast<const float2*>(ref + bq * 8 + 2 * p);
+
+    for (int it = tid; it < total; it += NT) {
+        const int itn = it + NT < total ? it + NT : it;
+        const long bqn = token_of(itn);
+        nxt.load(ow + bqn * (long)(M * 48), M, m, p);
+        rf_n = *reinterpret_cast<const float2*>(ref + bqn * 8 + 2 * p);
+
+        float off[8], lg[4];
+        cur.get(off, lg);
+        float mx = fmaxf(fmaxf(lg[0], lg[1]), fmaxf(lg[2], lg[3]));
+        mx = fmaxf(mx, quad_dpp<0xB1>(mx));
+        mx = fmaxf(mx, quad_dpp<0x4E>(mx));
+        float sum = 0.f;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) { lg[i] = __expf(lg[i] - mx); sum += lg[i]; }
+        sum += quad_dpp<0xB1>(sum);
+        sum += quad_dpp<0x4E>(sum);
+        const float inv = __builtin_amdgcn_rcpf(sum);
+
+        // geometry of the four points: packed corner weights (real ones: the global path uses them), window byte offsets of the four corners
+        // (clamped into the window for a point outside it), and the mask of such points
+        uint32_t k12[4], k34[4];
+        int ad[4][4];                                           // [point][row * 2 + column]
+        int hw[4][4];                                           // h0, h1, w0, w1c of the far points' global path
+        unsigned far = 0u;
+#pragma unroll
+        for (int pt = 0; pt < 4; ++pt) {
+            const float lx = rf.x + off[2 * pt] * invW;
+            const float ly = rf.y + off[2 * pt + 1] * invH;
+            const float h_im = __builtin_amdgcn_fmed3f(ly * fH - 0.5f, -1.f, fH), w_im = __builtin_amdgcn_fmed3f(lx * fW - 0.5f, -1.f, fW);
+            const float hf = floorf(h_im), wf = floorf(w_im);
+            const int h_low = (int)hf, w_low = (int)wf;
+            const float lh = h_im - hf, lw = w_im - wf;
+            const float a = lg[pt] * inv;
+            const float wy0 = (unsigned)h_low < (unsigned)Hl ? 1.f - lh : 0.f, wy1 = (unsigned)(h_low + 1) < (unsigned)Hl ? lh : 0.f;
+            const float wx0 = (unsigned)w_low < (unsigned)Wl ? (1.f - lw) * a : 0.f, wx1 = (unsigned)(w_low + 1) < (unsigned)Wl ? lw * a : 0.f;
+            k12[pt] = h2_pair(wy0 * wx0, wy0 * wx1); k34[pt] = h2_pair(wy1 * wx0, wy1 * wx1);
+            const int h0 = clamp0_i32(h_low, Hl - 1), h1 = clamp0_i32(h_low + 1, Hl - 1);
+            const int w0 = clamp0_i32(w_low, Wl - 1), w1c = clamp0_i32(w_low + 1, Wl - 1);
+            hw[pt][0] = h0; hw[pt][1] = h1; hw[pt][2] = w0; hw[pt][3] = w1c;
+            const bool inw = (w0 >= wc0l) && (w1c < wc1l);
+            if (!inw) far |= 1u << pt;
+            const int c0 = inw ? w0 - wc0l : 0, c1 = inw ? w1c - wc0l : 0;
+            const int r0 = h0 * wstride, r1 = h1 * wstride;
+            ad[pt][0] = (r0 + c0) * 64; ad[pt][1] = (r0 + c1) * 64; ad[pt][2] = (r1 + c0) * 64; ad[pt][3] = (r1 + c1) * 64;
+        }
+
+        uint32_t acc[4][4];
+#pragma unroll
+        for (int jj = 0; jj < 4; ++jj)
+#pragma unroll
+            for (int i = 0; i < 4; ++i) acc[jj][i] = 0u;
+        uint4 bufA[8], bufB[8];
+#define DTLR_H4_LOAD(BUF, HP)                                                                      \
+        _Pragma("unroll") for (int jj = 0; jj < 4; ++jj) {                                         \
+            BUF[jj] = *reinterpret_cast<const uint4*>(win + ad[(HP) >> 1][2 * ((HP) & 1)] + rot[jj]);      \
+            BUF[4 + jj] = *reinterpret_cast<const uint4*>(win + ad[(HP) >> 1][2 * ((HP) & 1) + 1] + rot[jj]); \
+        }
+#define DTLR_H4_FMA(BUF, HP)                                                                       \
+        {                                                                                          \
+            const uint32_t kreal_ = ((HP) & 1) ? k34[(HP) >> 1] : k12[(HP) >> 1];                  \
+            const uint32_t kk_ = (far >> ((HP) >> 1)) & 1u ? 0u : kreal_;                          \
+            _Pragma("unroll") for (int jj = 0; jj < 4; ++jj) {                                     \
+                acc[jj][0] = pk_fma_h2_bl(kk_, BUF[jj].x, acc[jj][0]);                             \
+                acc[jj][1] = pk_fma_h2_bl(kk_, BUF[jj].y, acc[jj][1]);                             \
+                acc[jj][2] = pk_fma_h2_bl(kk_, BUF[jj].z, acc[jj][2]);                             \
+                acc[jj][3] = pk_fma_h2_bl(kk_, BUF[jj].w, acc[jj][3]);                             \
+            }                                                                                      \
+            _Pragma("unroll") for (int jj = 0; jj < 4; ++jj) {                                     \
+                acc[jj][0] = pk_fma_h2_bh(kk_, BUF[4 + jj].x, acc[jj][0]);                         \
+                acc[jj][1] = pk_fma_h2_bh(kk_, BUF[4 + jj].y, acc[jj][1]);                         \
+                acc[jj][2] = pk_fma_h2_bh(kk_, BUF[4 + jj].z, acc[jj][2]);                         \
+                acc[jj][3] = pk_fma_h2_bh(kk_, BUF[4 + jj].w, acc[jj][3]);                         \
+            }                                                                                      \
+        }
+        DTLR_H4_LOAD(bufA, 0)
+        DTLR_H4_LOAD(bufB, 1)
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int hp = 0; hp < 8; ++hp) {
+            if (hp & 1) { DTLR_H4_FMA(bufB, hp) } else { DTLR_H4_FMA(bufA, hp) }
+            if (hp + 2 < 8) { if (hp & 1) { DTLR_H4_LOAD(bufB, hp + 2) } else { DTLR_H4_LOAD(bufA, hp + 2) } }
+            __builtin_amdgcn_sched_barrier(0);
+        }
+#undef DTLR_H4_FMA
+#undef DTLR_H4_LOAD
+        if (far) {                                              // points outside the staged window: global path (MODE.FP16_OVFL is set)
+#pragma unroll
+            for (int pt = 0; pt < 4; ++pt) {
+                if (!((far >> pt) & 1u)) continue;
+                const int h0 = hw[pt][0], h1 = hw[pt][1], w0 = hw[pt][2], w1c = hw[pt][3];
+#pragma unroll
+                for (int jj = 0; jj < 4; ++jj) {
+                    const int pe = rot[jj] >> 1;
+                    const uint4 e1 = stage_convert_ovfl<uint16_t>(*reinterpret_cast<const uint4*>(gsrc + (long)(h0 * Wl + w0) * MD + pe));
+                    const uint4 e2 = stage_convert_ovfl<uint16_t>(*reinterpret_cast<const uint4*>(gsrc + (long)(h0 * Wl + w1c) * MD + pe));
+                    const uint4 e3 = stage_convert_ovfl<uint16_t>(*reinterpret_cast<const uint4*>(gsrc + (long)(h1 * Wl + w0) * MD + pe));
+                    const uint4 e4 = stage_convert_ovfl<uint16_t>(*reinterpret_cast<const uint4*>(gsrc + (long)(h1 * Wl + w1c) * MD + pe));
+                    acc[jj][0] = pk_fma_h2_bh(k34[pt], e4.x, pk_fma_h2_bl(k34[pt], e3.x, pk_fma_h2_bh(k12[pt], e2.x, pk_fma_h2_bl(k12[pt], e1.x, acc[jj][0]))));
+                    acc[jj][1] = pk_fma_h2_bh(k34[pt], e4.y, pk_fma_h2_bl(k34[pt], e3.y, pk_fma_h2_bh(k12[pt], e2.y, pk_fma_h2_bl(k12[pt], e1.y, acc[jj][1]))));
+                    acc[jj][2] = pk_fma_h2_bh(k34[pt], e4.z, pk_fma_h2_bl(k34[pt], e3.z, pk_fma_h2_bh(k12[pt], e2.z, pk_fma_h2_bl(k12[pt], e1.z, acc[jj][2]))));
+                    acc[jj][3] = pk_fma_h2_bh(k34[pt], e4.w, pk_fma_h2_bl(k34[pt], e3.w, pk_fma_h2_bh(k12[pt], e2.w, pk_fma_h2_bl(k12[pt], e1.w, acc[jj][3]))));
+                }
+            }
+        }
+        float res[8];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const uint32_t t3 = quad_dpp_u<0x39>(acc[3][i]), t2 = quad_dpp_u<0x4E>(acc[2][i]), t1 = quad_dpp_u<0x93>(acc[1][i]);
+            res[2 * i] = fma_mix_lo(1.f, t1, fma_mix_lo(1.f, t2, fma_mix_lo(1.f, t3, fma_mix_lo(1.f, acc[0][i], 0.f))));
+            res[2 * i + 1] = fma_mix_hi(1.f, t1, fma_mix_hi(1.f, t2, fma_mix_hi(1.f, t3, fma_mix_hi(1.f, acc[0][i], 0.f))));
+        }
+        *reinterpret_cast<uint4*>(out + bq * MD + m * 32 + p * 8) = ET<uint16_t>::pack(res);
+        cur = nxt; rf = rf_n; bq = bqn;
+    }
+}
+
 // ---- fp32 query phase (round 4): one lane per (query, head, LEVEL), fp32 windows, packed-fp32 accumulation ----------------------
 // The first fp32 form (8 lanes per (query, head), each lane 4 channels of ALL 16 points) repeated the 16-point geometry and the
 // 16-logit softmax in every lane: ~7000 VALU lane-instructions per (query, head), 1.17 ms per encoder call at B = 32 -- the largest
@@ -783,7 +940,7 @@ __device__ __forceinline__ void enc_queries_f32_lvl(
 
 // VAR: 16-bit values: 0 first form, 1 packed-fp16 form, 2 third form; fp32 values: 0 first form (8 lanes per (query, head)), 3 level-per-lane form
 template <typename T, typename OT, int VAR = 0, int NT = 256>
-__global__ __launch_bounds__(NT, VAR == 3 ? 2 : NT / 128) void msda_enc_lds_kernel(
+__global__ __launch_bounds__(NT, VAR == 3 ? 2 : NT == 384 ? 3 : NT / 128) void msda_enc_lds_kernel(
     const T* __restrict__ value, const OT* __restrict__ ow, const float* __restrict__ ref, T* __restrict__ out,
     EncLevels lv, int S, int M, int TW0, int R, int tok_off)
 {
@@ -820,7 +977,7 @@ __global__ __launch_bounds__(NT, VAR == 3 ? 2 : NT / 128) void msda_enc_lds_kern
             const int c0q = lq == 3 ? qc0[3] : lq == 2 ? qc0[2] : lq == 1 ? qc0[1] : qc0[0];
             const int Wq = lq == 3 ? lv.W[3] : lq == 2 ? lv.W[2] : lq == 1 ? lv.W[1] : lv.W[0];
             const int stq = lq == 3 ? lv.start[3] : lq == 2 ? lv.start[2] : lq == 1 ? lv.start[1] : lv.start[0];
-            if constexpr (VAR == 2 || VAR == 3) {
+            if constexpr (VAR == 2 || VAR == 3 || VAR == 4) {
                 // r / nc without the ~60-instruction integer division: (r + 0.5) / nc is at least 0.5 / nc away from an integer, far
                 // more than the fp32 error of the product for r < 2^15 and nc <= 2^8 (restated and swept in tests/test_host_logic.py)
                 const int qi = (int)(((float)r + 0.5f) * __builtin_amdgcn_rcpf((float)nc));
@@ -832,7 +989,7 @@ __global__ __launch_bounds__(NT, VAR == 3 ? 2 : NT / 128) void msda_enc_lds_kern
 
     // ---- stage the four windows of head m: coalesced 16-byte chunks, CP chunks per pixel ------------
     const T* vimg = value + (long)b * S * MD + m * 32;
-    if constexpr (VAR == 2) {
+    if constexpr (VAR == 2 || VAR == 4) {
         // Variant 3 stages with ~45% of the default loop's VALU instructions (270 per four chunks there: two divisions by the runtime window
         // width per chunk, and the fp16 saturation guard as v_max + v_med3 per element): a lane walks its chunks as (row, chunk-in-row)
         // advanced by the constant step (NT / rowlen, NT % rowlen) -- ONE division per level per lane --, and the conversion saturates in
@@ -893,6 +1050,7 @@ __global__ __launch_bounds__(NT, VAR == 3 ? 2 : NT / 128) void msda_enc_lds_kern
     if constexpr (sizeof(T) == 2) {
         if constexpr (VAR == 0) enc_queries_bf16<OT>(smem, vimg, ow, ref, out, lv, qc0, qn, wc0, wc1, qbase, nq, S, M, m, b);
         else if constexpr (VAR == 1) enc_queries_bf16_h<OT, NT>(smem, reinterpret_cast<const int*>(smem + tok_off), vimg, ow, ref, out, lv, qc0, qn, wc0, wc1, qbase, nq, S, M, m, b);
+        else if constexpr (VAR == 4) enc_queries_bf16_h4<OT, NT>(smem, reinterpret_cast<const int*>(smem + tok_off), vimg, ow, ref, out, lv, wc0, wc1, nq, S, M, m, b);
         else enc_queries_bf16_h3<OT, NT>(smem, reinterpret_cast<const int*>(smem + tok_off), vimg, ow, ref, out, lv, wc0, wc1, nq, S, M, m, b);
         return;
     }
@@ -1134,7 +1292,7 @@ static int launch_enc(const void* value, const void* ow, const float* ref, void*
 // with 256 threads, 2 the same with 512 threads (the round-2/3 default).  The product libraries have no run-time knob.
 static int enc_variant() {
     static const int v = exp_env_int("DTLR_MSDA_ENC_V", 3);
-    return (v >= 0 && v <= 3) ? v : 3;
+    return (v >= 0 && v <= 4) ? v : 3;
 }
 
 }  // namespace dtlr
@@ -1193,12 +1351,14 @@ extern "C" int dtlr_msda_encoder_forward(const void* value, const void* ow, cons
         if (enc_variant() == 0) return launch_enc<uint16_t, float>(value, ow, ref, out, pl, N, M, st);
         if (enc_variant() == 1) return launch_enc<uint16_t, float, 1, 256>(value, ow, ref, out, pl, N, M, st);
         if (enc_variant() == 2) return launch_enc<uint16_t, float, 1, 512>(value, ow, ref, out, pl, N, M, st);
+        if (enc_variant() == 4) return launch_enc<uint16_t, float, 4, 384>(value, ow, ref, out, pl, N, M, st);
         return launch_enc<uint16_t, float, 2, 512>(value, ow, ref, out, pl, N, M, st);
     }
     if (dtype == DTLR_H16 && ow_dtype == DTLR_H16) {
         if (enc_variant() == 0) return launch_enc<uint16_t, uint16_t>(value, ow, ref, out, pl, N, M, st);
         if (enc_variant() == 1) return launch_enc<uint16_t, uint16_t, 1, 256>(value, ow, ref, out, pl, N, M, st);
         if (enc_variant() == 2) return launch_enc<uint16_t, uint16_t, 1, 512>(value, ow, ref, out, pl, N, M, st);
+        if (enc_variant() == 4) return launch_enc<uint16_t, uint16_t, 4, 384>(value, ow, ref, out, pl, N, M, st);
         return launch_enc<uint16_t, uint16_t, 2, 512>(value, ow, ref, out, pl, N, M, st);
     }
     return DTLR_EDTYPE;
