@@ -631,6 +631,8 @@ __device__ __forceinline__ void enc_queries_bf16_h3(
 // The loop has no branch: a point whose columns are not all inside the staged window reads a clamped (valid) window address with zero
 // weights and is added afterwards through the global path (same arithmetic; those lanes sum their points in a different order: fp16
 // rounding-order noise, the oracle tolerance is unchanged).
+// MEASURED (profiles/r06_msda_v4_c16.txt, same box, separate processes): 206 us per launch against 142-145 us for the third form, the bench
+// step 9.96 against 9.63 ms -- the fourth wave per SIMD hides more than the read-ahead does.  Experiment builds only (DTLR_MSDA_ENC_V=4).
 template <typename OT, int NT>
 __device__ __forceinline__ void enc_queries_bf16_h4(
     const unsigned char* smem, const int* tok, const uint16_t* __restrict__ vimg, const OT* __restrict__ ow, const float* __restrict__ ref,
@@ -1351,14 +1353,18 @@ extern "C" int dtlr_msda_encoder_forward(const void* value, const void* ow, cons
         if (enc_variant() == 0) return launch_enc<uint16_t, float>(value, ow, ref, out, pl, N, M, st);
         if (enc_variant() == 1) return launch_enc<uint16_t, float, 1, 256>(value, ow, ref, out, pl, N, M, st);
         if (enc_variant() == 2) return launch_enc<uint16_t, float, 1, 512>(value, ow, ref, out, pl, N, M, st);
+#ifdef DTLR_EXPERIMENT
         if (enc_variant() == 4) return launch_enc<uint16_t, float, 4, 384>(value, ow, ref, out, pl, N, M, st);
+#endif
         return launch_enc<uint16_t, float, 2, 512>(value, ow, ref, out, pl, N, M, st);
     }
     if (dtype == DTLR_H16 && ow_dtype == DTLR_H16) {
         if (enc_variant() == 0) return launch_enc<uint16_t, uint16_t>(value, ow, ref, out, pl, N, M, st);
         if (enc_variant() == 1) return launch_enc<uint16_t, uint16_t, 1, 256>(value, ow, ref, out, pl, N, M, st);
         if (enc_variant() == 2) return launch_enc<uint16_t, uint16_t, 1, 512>(value, ow, ref, out, pl, N, M, st);
+#ifdef DTLR_EXPERIMENT
         if (enc_variant() == 4) return launch_enc<uint16_t, uint16_t, 4, 384>(value, ow, ref, out, pl, N, M, st);
+#endif
         return launch_enc<uint16_t, uint16_t, 2, 512>(value, ow, ref, out, pl, N, M, st);
     }
     return DTLR_EDTYPE;
