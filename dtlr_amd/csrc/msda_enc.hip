@@ -632,7 +632,8 @@ __device__ __forceinline__ void enc_queries_bf16_h3(
 // weights and is added afterwards through the global path (same arithmetic; those lanes sum their points in a different order: fp16
 // rounding-order noise, the oracle tolerance is unchanged).
 // MEASURED (profiles/r06_msda_v4_c16.txt, same box, separate processes): 206 us per launch against 142-145 us for the third form, the bench
-// step 9.96 against 9.63 ms -- the fourth wave per SIMD hides more than the read-ahead does.  Experiment builds only (DTLR_MSDA_ENC_V=4).
+// step 9.96 against 9.63 ms -- the fourth wave per SIMD hides more than the read-ahead does.  Experiment builds only (DTLR_MSDA_ENC_V=4); it was
+// timed, its results were NOT compared with the oracle (no test selects it).
 template <typename OT, int NT>
 __device__ __forceinline__ void enc_queries_bf16_h4(
     const unsigned char* smem, const int* tok, const uint16_t* __restrict__ vimg, const OT* __restrict__ ow, const float* __restrict__ ref,
