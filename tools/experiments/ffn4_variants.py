@@ -1,5 +1,10 @@
 #!/usr/bin/env python3
-"""Run standalone builds of ffn4.hip (tools/experiments/ffn4v/libffn4_<name>.so) against dtlr_ffn32_bf16: error of slot-0 / slot-1 rows."""
+"""Run standalone builds of ffn4.hip (tools/experiments/ffn4v/libffn4_<name>.so) against dtlr_ffn32_bf16: error of slot-0 / slot-1 rows, time of
+the encoder call.  The libraries are built ad hoc (not tracked), e.g.
+    echo 'namespace dtlr { thread_local int g_last_hip_error = 0; }' > /tmp/stub.cpp
+    hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -shared -DDTLR_EXPERIMENT [-D...] dtlr_amd/csrc/ffn4.hip /tmp/stub.cpp -o tools/experiments/ffn4v/libffn4_lagrt.so
+(DTLR_EXPERIMENT makes the entry point read DTLR_FFN4_LAG: low byte = slot lag in steps, bit 8 = no LayerNorm / store slices, bit 9 =
+additionally no row loads / seeding -- timing ablations whose results are garbage).  Used by tools/experiments/gpu_calls/r06_call9.sh .. call14.sh."""
 import ctypes, glob, os, sys
 import torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
