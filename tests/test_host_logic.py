@@ -723,6 +723,10 @@ def test_bench_stdout_line_stays_below_6kb_whatever_the_detail_holds():
         assert line["cpu_baseline"]["by_threads"]["128"]["runs"].startswith("single run")       # never quoted as a median of nothing
         assert set(line["by_dtype"]) == {"bf16", "f16", "f32s", "f32"}
         assert line["by_dtype"]["f32s"]["strings_teacher_forced"] == "16/16" and line["by_dtype"]["f32s"]["strings_free_running_v4"] == "8/8"
+        # round 6: the parity-grade rate is named at the top level -- the fastest engine within 1e-3 of the oracle with identical strings on
+        # both legs (f32s here), never the bf16 headline
+        assert line["parity_grade"] == {"dtype": "f32s", "lines_per_s": line["by_dtype"]["f32s"]["lines_per_s"]}
+        assert line["by_dtype"]["bf16"]["lines_per_s"] > line["parity_grade"]["lines_per_s"] > line["by_dtype"]["f32"]["lines_per_s"]
     # an engine leg that raised is carried as a short error string, not dropped
     broken = copy.deepcopy(full)
     broken["by_dtype"]["f32"] = {"error": "RuntimeError(" + "x" * 5000 + ")"}
