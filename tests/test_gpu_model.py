@@ -170,8 +170,9 @@ def test_full_model_vs_golden_and_oracle(golden_dir, tag, engine):
     print(f"[{engine} free-running vs reference golden, {tag}] selection identical on {n_same_sel}/{len(fdec)} lines, strings identical on {n_same_str}/{len(fdec)}")
 
 
-# Stated bounds of the bf16 (bench) engine against the fp32 CPU oracle on the same selection (measured on MI355X, margin-bearing
-# generator v2): max |logit difference| and max |box difference|.
+# Bounds of the bf16 (bench) engine against the fp32 CPU oracle on the same selection (measured on MI355X, margin-bearing
+# generator v2): max |logit difference| and max |box difference|.  REGRESSION ALARMS, not the north_star's 1e-3: only the
+# f32 / f32s engines are held to that (test_parity_engines_bench_batch_vs_oracle).
 BF16_LOGIT_BOUND = {"latin": 0.3, "chinese": 0.4}      # measured: 0.126 (Latin pair), mean 0.017
 BF16_BOX_BOUND = 2e-2                                   # measured: 8.4e-3 max over (cx, cy, w, h), mean 8e-4
 # ... and of the fp16 build of the same kernels (libdtlr_hip_f16.so; round 3): 8x finer rounding everywhere
@@ -339,7 +340,9 @@ def _bench_oracle_batch_v4():
 
 
 # free-running CER bounds of the 16-bit engines on generator v4 (measured on MI355X in round 5; what differs is mostly the SET of selected
-# tokens at the 900-th score -- the oracle against itself at the same score error shows the same CER)
+# tokens at the 900-th score -- the oracle against itself at the same score error shows the same CER).  These are REGRESSION ALARMS set from
+# measurements, not parity statements: the 16-bit engines are throughput engines that do not reproduce the reference's strings (README /
+# DESIGN section 2); the parity statement -- identical strings, no tolerance -- is asserted for f32 and f32s only.
 V4_FREE_CER_BOUND = {"bf16": 0.35, "f16": 0.10}      # measured: 0.264 / 0.035 on these four lines (0.269 / 0.062 on the bench's eight)
 
 
