@@ -284,6 +284,8 @@ def compact_line(full: dict) -> dict:
         line["speedup_vs_cpu"] = full.get("speedup_vs_cpu")
     if "latency_ms_bs1" in full:
         line["latency_ms_bs1"] = full["latency_ms_bs1"]
+    if full.get("latency_ms_bs1_graph") is not None:
+        line["latency_ms_bs1_graph"] = full["latency_ms_bs1_graph"]
     if full.get("by_dtype"):
         line["by_dtype"] = {k: _compact_engine(v) for k, v in full["by_dtype"].items()}
         # the rate of the fastest engine that meets north_star's parity statement (logits within 1e-3 of the fp32 CPU oracle, identical strings
@@ -757,6 +759,34 @@ def main():
         line["latency_ms_bs1"] = round(lat[1], 3)
         line["latency_ms_by_batch"] = {str(k): round(v, 3) for k, v in lat.items()}
         log(f"single-line latency: {lat}")
+        # the same single line as a HIP-graph replay (round 6: one line is ~200 dependent launches; the replay is bit-identical to the eager
+        # forward -- tests/test_gpu_model.py -- and, unlike at 4 or 32 lines, measurably shorter)
+        try:
+            xs, ms_ = x[:1].contiguous(), mask[:1].contiguous()
+            side = torch.cuda.Stream()
+            side.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(side):
+                for _ in range(3):
+                    local_step(xs, ms_)
+            torch.cuda.current_stream().wait_stream(side)
+            eager_rec = [t.clone() for t in local_step(xs, ms_)]
+            graph = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(graph):
+                graph_rec = local_step(xs, ms_)
+            for _ in range(3):
+                graph.replay()
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for _ in range(20):
+                graph.replay()
+            torch.cuda.synchronize()
+            line["latency_ms_bs1_graph"] = round((time.perf_counter() - t0) / 20 * 1e3, 3)
+            line["latency_bs1_graph_equals_eager"] = bool(all(torch.equal(a, b) for a, b in zip(graph_rec, eager_rec)))
+            log(f"single-line latency, HIP-graph replay: {line['latency_ms_bs1_graph']} ms (records == eager: {line['latency_bs1_graph_equals_eager']})")
+            del graph
+        except Exception as e:
+            line["latency_ms_bs1_graph"] = None
+            log(f"single-line HIP-graph leg failed: {e!r}")
     rows = sorted({int(round(i * (B - 1) / max(args.parity_lines - 1, 1))) for i in range(min(args.parity_lines, B))})
     ob = None
     if observed is not None:

@@ -11,7 +11,7 @@ from dtlr_amd.evaluation import decode_blank_records
 dev = torch.device("cuda:0")
 cfg = DTLRConfig.latin()
 eng = DTLREngine(cfg, weights.synthetic_state_dict(cfg, seed=0), dev, torch.bfloat16)
-B = 32
+B = int(sys.argv[1]) if len(sys.argv) > 1 else 32
 x = torch.stack(synth.noise_lines(B, 128, 2048, seed=1000)).to(dev)
 mask = torch.zeros((B, 128, 2048), dtype=torch.bool, device=dev)
 
