@@ -1,5 +1,5 @@
-// Fused position-wise feed-forward block, fourth structure (round 6): PERSISTENT workgroups whose waves each carry TWO token tiles half a
-// tile period apart over ONE cyclic weight stream, so that a tile's prologue and epilogue run under the other tile's MFMAs.
+// Fused position-wise feed-forward block, fourth structure (round 6): PERSISTENT workgroups whose waves each carry TWO token tiles a few
+// steps apart over ONE cyclic weight stream, so that a tile's epilogue and its successor's load never coincide with the other tile's.
 //
 //     Y = LayerNorm( X + relu(X W1^T + b1) W2^T + b2 )            X, Y: [M, 256]   W1: [d_ff, 256]   W2: [256, d_ff]
 // == forward_ffn + norm2 of the encoder layer (models/dino/deformable_transformer.py:804-823).
@@ -12,20 +12,20 @@
 //   * the weights stream CYCLICALLY through the two 4-stage LDS rings (chunk s mod d_ff/32 at stream step s) for the whole life of the
 //     workgroup.  The sum over hidden chunks is order-free, so a tile may START at any chunk;
 //   * a wave's two 32-token column tiles are two independent SLOTS.  Slot 0 of the four waves = one 128-token tile, slot 1 another, started
-//     half a period apart.  In the steady state both slots multiply against every weight fragment the wave reads (ffn3's step, unchanged:
-//     one ds_read_b128 feeds two MFMAs); while one slot is in its four epilogue steps / its seeding step the other one keeps computing;
-//   * a slot's period = 1 seeding step (accumulators = X through the matrix pipe, as in ffn3) + d_ff/32 + 1 chunk steps + 4 epilogue steps
-//     (row sum | centred squares | scale, round, store channel tiles 0..3 | 4..7; three READ-ONLY passes over the accumulators: the slot's X^T
-//     registers already receive the NEXT tile, loaded at the first epilogue step).  A slot's first chunk step multiplies phase B by zero
+//     `lag` steps apart (a kernel argument, 2).  In the steady state both slots multiply against every weight fragment the wave reads (ffn3's
+//     step, unchanged: one ds_read_b128 feeds two MFMAs); in a slot's OWN step the other slot runs a single-slot chunk step first;
+//   * a slot's period = d_ff/32 + 1 chunk steps + 1 own step: row sum | centred squares | rows of the NEXT tile start to load | scale, round,
+//     store (channel tiles 0..3, then 4..7) | wait for the rows | accumulators = X through the matrix pipe, as in ffn3.  Three READ-ONLY passes
+//     over the accumulators (the slot's X^T registers receive the next tile meanwhile).  A slot's first chunk step multiplies phase B by zero
 //     H fragments and its last one runs a redundant phase A: 32 wasted MFMAs per tile (1.5 %) for one step body instead of three;
-//   * tiles are dealt round-robin: workgroup b, slot position k takes tile k G + b (G = min(#CU, tiles / 2)), even k to slot 0, odd k to
-//     slot 1.  One kernel for any M >= 1: no tail kernel.
+//   * tiles are dealt in PAIRS: workgroup b, iteration i takes tiles 2 (b + i G) and 2 (b + i G) + 1 (G = min(#CU, pairs)) for slot 0 and
+//     slot 1 (a missing last tile: clamped rows, no stores).  One kernel for any M >= 1: no tail kernel.
 //
 // vmcnt bookkeeping.  The counter is in order and shared by the weight DMA (8 pieces per wave and step), the X loads and the Y stores.  The
 // pieces of step s - 2 must have landed at the top of step s; what may stay in flight there is everything issued after them:
-// post(s - 2) + tot(s - 1), tot = all vector-memory operations of a step, post = those after its pieces (16 X loads in the first epilogue
-// step, 8 stores in each store step -- counts that must be EXACT: a wave with no row below M issues no stores and counts none).  The values
-// that occur (8, 16, 24) are tracked in three scalars and waited for by a three-way uniform branch.
+// post(s - 2) + tot(s - 1), tot = all vector-memory operations of a step, post = those after its pieces (a slot's own step: 16 X loads and
+// 16 stores -- counts that must be EXACT: a wave with no row below M issues no stores and counts none).  The values that occur (8, 24, 40)
+// are tracked in three scalars and waited for by a three-way uniform branch.
 //
 // STATUS (round 6, measured on MI355X, tools/experiments/ffn4_scaling.py, profiles/r06_ffn4_*.txt): CORRECT (tests/test_gpu_kernels.py::
 // test_ffn4_vs_reference_and_ffn32) and NOT ADOPTED by the engine -- the encoder call (174,080 rows) takes 350-388 us here against 305 us for
@@ -270,8 +270,8 @@ __global__ __launch_bounds__(256, 1) void ffn4_bf16_kernel(
         __builtin_amdgcn_sched_barrier(0);                                                         \
     }
 
-    // ---- the steps of a slot that is not computing (run after the other slot's chunk step) ------------------------------------------------
-    // KIND: 0 seeding, 1..4 epilogue steps, anything else: nothing.  Sets post_ / tot_ additions through `extra`.
+    // ---- the parts of a slot's own step (run after the other slot's chunk step) ------------------------------------------------------------
+    // KIND: 0 seeding, 1 row sum, 2 centred squares, 3 / 4 scale + round + store of channel tiles 0..3 / 4..7; `extra` += stores issued.
 #define F4_SPECIAL(TT, KIND, NTILE, extra)                                                         \
     {                                                                                              \
         if ((KIND) == 0) {                                                                         \
